@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by importing the REAL reference.
+
+Runs only in the build container (needs /root/reference).  Nothing of the reference is
+copied: this script imports it in-process behind sys.modules stand-ins for its missing
+third-party imports (timm, mmcv, mmseg, torchvision, bert -- SURVEY.md 8c / Appendix C),
+drives it with deterministic weights (lavt_hip.detweights, keyed by state-dict name) and
+seeded inputs, and stores ONLY inputs-by-seed + expected outputs as .npz.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "lavt-rs_amd"))
+from lavt_hip.detweights import det_inputs, det_tensor, fill_state_dict_  # noqa: E402
+
+REF = "/root/reference"
+
+
+# ----------------------------------------------------------------------------- shims
+def _install_shims():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class DropPath(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+            self.p = p
+
+        def forward(self, x):
+            if self.p == 0.0 or not self.training:
+                return x
+            keep = 1 - self.p
+            mask = torch.floor(keep + torch.rand((x.shape[0],) + (1,) * (x.dim() - 1)))
+            return x / keep * mask
+
+    def to_2tuple(x):
+        return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+    mod("timm")
+    mod("timm.models")
+    mod("timm.models.layers", DropPath=DropPath, to_2tuple=to_2tuple, trunc_normal_=nn.init.trunc_normal_)
+    import logging
+    mod("mmseg")
+    mod("mmseg.utils", get_root_logger=lambda *a, **k: logging.getLogger("ref"))
+    mod("mmcv")
+    mod("mmcv.fileio", FileClient=object, load=lambda *a, **k: None)
+    mod("mmcv.parallel", is_module_wrapper=lambda m: False)
+    mod("mmcv.utils", mkdir_or_exist=lambda *a, **k: None)
+    mod("mmcv.runner", get_dist_info=lambda: (0, 1))
+    tv = mod("torchvision")
+    tv.__path__ = []
+    mod("torchvision.ops")
+    mod("torchvision.ops.boxes", box_area=None)
+
+    class BertModel(nn.Module):
+        @classmethod
+        def from_pretrained(cls, *a, **k):
+            return cls()
+
+    mod("bert")
+    mod("bert.modeling_bert", BertModel=BertModel)
+
+
+def ref_args(*flags):
+    sys.path.insert(0, REF)
+    argv, sys.argv = sys.argv, ["x"]
+    try:
+        import args as ref_args_mod
+        return ref_args_mod.get_parser().parse_args(list(flags))
+    finally:
+        sys.argv = argv
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB")
+
+
+def randn(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator("cpu").manual_seed(seed))
+
+
+def grad_digest(t, n=24):
+    """Compact pin of a gradient tensor: [l2, sum, first n/2, strided n/2]."""
+    f = t.detach().reshape(-1).double()
+    step = max(f.numel() // (n // 2), 1)
+    samp = torch.cat([f[: n // 2], f[::step][: n // 2]])
+    samp = F.pad(samp, (0, n - samp.numel()))
+    return torch.cat([torch.stack([f.norm(), f.sum()]), samp]).float()
+
+
+# ----------------------------------------------------------------------------- cases
+def main():
+    ap = argparse.ArgumentParser()
+    ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    _install_shims()
+    sys.path.insert(0, REF)
+    args = ref_args()
+    from lib import backbone as rb
+    from lib import mask_predictor as rmp
+    from lib import _utils as ru
+
+    # --- window attention, with/without mask, both window sizes ------------------------------
+    for tag, C, nH, ws, Bw, Hp in (("w7", 96, 3, 7, 8, 14), ("w12", 128, 4, 12, 4, 24)):
+        m = rb.WindowAttention(C, (ws, ws), nH).eval()
+        fill_state_dict_(m)
+        sd = {f"attn.{k}": v for k, v in m.state_dict().items()}
+        x = randn(11, Bw, ws * ws, C)
+        layer = types.SimpleNamespace(window_size=ws, shift_size=ws // 2)
+        mask = _ref_mask(rb, Hp, Hp, ws)
+        with torch.no_grad():
+            y0 = m(x, None)
+            y1 = m(x, mask)
+        save(f"win_attn_{tag}", C=C, nH=nH, ws=ws, Bw=Bw, Hp=Hp, seed=11, y_nomask=y0, y_mask=y1)
+
+    # --- shift masks (bit-packed) --------------------------------------------------------------
+    packs = {}
+    for Hp, ws in ((126, 7), (36, 12), (24, 12), (7, 7), (14, 7)):
+        mk = _ref_mask(rb, Hp, Hp, ws)
+        assert set(mk.unique().tolist()) <= {0.0, -100.0}
+        packs[f"m_{Hp}_{ws}"] = np.packbits((mk != 0).numpy().reshape(-1))
+        packs[f"n_{Hp}_{ws}"] = np.array(mk.shape)
+    save("shift_masks", **packs)
+
+    # --- Swin blocks (pad 15->24 with ws 12; 28 with ws 7), shifted and not --------------------
+    for tag, C, nH, ws, H, B in (("15_w12", 128, 4, 12, 15, 2), ("28_w7", 96, 3, 7, 28, 1), ("10_w7", 64, 2, 7, 10, 2)):
+        for shifted in (0, 1):
+            blk = rb.SwinTransformerBlock(C, nH, ws, shift_size=(ws // 2 if shifted else 0)).eval()
+            fill_state_dict_(blk)
+            blk.H = blk.W = H
+            x = randn(21, B, H * H, C)
+            Hp = -(-H // ws) * ws
+            with torch.no_grad():
+                y = blk(x, _ref_mask(rb, Hp, Hp, ws))
+            save(f"block_{tag}_s{shifted}", C=C, nH=nH, ws=ws, H=H, B=B, seed=21, shifted=shifted, y=y)
+
+    # --- patch merging (even, odd), patch embed (needs padding) ---------------------------------
+    for tag, H, W in (("even", 8, 6), ("odd", 7, 5)):
+        pm = rb.PatchMerging(32).eval()
+        fill_state_dict_(pm)
+        x = randn(31, 2, H * W, 32)
+        with torch.no_grad():
+            y = pm(x, H, W)
+        save(f"patch_merging_{tag}", H=H, W=W, C=32, B=2, seed=31, y=y)
+    pe = rb.PatchEmbed(4, 3, 48, nn.LayerNorm).eval()
+    fill_state_dict_(pe)
+    x = randn(32, 2, 3, 30, 27)
+    with torch.no_grad():
+        y = pe(x)
+    save("patch_embed", C=48, seed=32, shape=np.array(x.shape), y=y)
+
+    # --- PWAM with ragged mask, 1 and 2 heads ------------------------------------------------------
+    for G in (1, 2):
+        pw = rb.PWAM(64, 64, 768, 64, 64, num_heads=G, dropout=0.0).eval()
+        fill_state_dict_(pw)
+        x = randn(41, 2, 90, 64)
+        l = randn(42, 2, 768, 20)
+        lm = torch.zeros(2, 20, 1)
+        lm[0, :9] = 1
+        lm[1, :15] = 1
+        with torch.no_grad():
+            y = pw(x, l, lm)
+            lang = pw.image_lang_att(x, l, lm)
+        save(f"pwam_g{G}", C=64, T=90, G=G, seeds=np.array([41, 42]), valid=np.array([9, 15]), y=y, lang=lang)
+
+    # --- one full stage (blocks + PWAM + gate + merge) ---------------------------------------------
+    st = rb.MMBasicLayer(dim=64, depth=2, num_heads=2, window_size=7, drop_path=0.0, downsample=rb.PatchMerging,
+                         num_heads_fusion=1, fusion_drop=0.0, args=args).eval()
+    fill_state_dict_(st)
+    x = randn(51, 2, 10 * 9, 64)
+    l = randn(52, 2, 768, 20)
+    lm = torch.zeros(2, 20, 1)
+    lm[0, :7] = 1
+    lm[1, :20] = 1
+    with torch.no_grad():
+        r, H, W, xd, Wh, Ww = st(x, 10, 9, l, lm)
+    save("stage_10x9", seeds=np.array([51, 52]), valid=np.array([7, 20]), r=r, x_down=xd, hw=np.array([H, W, Wh, Ww]))
+
+    # --- decoder, eval BN and train-mode BN ------------------------------------------------------
+    dec = rmp.SimpleDecoding(64, args)
+    fill_state_dict_(dec)
+    feats = [randn(60 + i, 2, c, s, s) for i, (c, s) in enumerate(((64, 4), (32, 8), (16, 16), (8, 32)))]
+    with torch.no_grad():
+        y_eval = dec.eval()(*feats)
+        y_train = dec.train()(*feats)
+    save("decoder_c64", seeds=np.arange(60, 64), y_eval=y_eval, y_train=y_train)
+
+    # --- end to end --------------------------------------------------------------------------------
+    def build(embed_dim, depths, heads, ws, dpr=0.3):
+        bb = rb.MultiModalSwinTransformer(embed_dim=embed_dim, depths=depths, num_heads=heads, window_size=ws,
+                                          ape=False, drop_path_rate=dpr, patch_norm=True, out_indices=(0, 1, 2, 3),
+                                          use_checkpoint=False, num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=args)
+        bb.init_weights()
+        model = ru.LAVT(bb, rmp.SimpleDecoding(8 * embed_dim, args))
+        fill_state_dict_(model)
+        return model
+
+    # config 1: Swin-T, 1x224x224, 20 tokens (12 valid)
+    model = build(96, [2, 2, 6, 2], [3, 6, 12, 24], 7).eval()
+    keys = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in model.state_dict().items())
+    with open(os.path.join(HERE, "state_dict_keys_swin_t.txt"), "w") as f:
+        f.write("\n".join(keys) + "\n")
+    x, l, lm, tgt = det_inputs(1, 224, 20, seed=1234)
+    lm = torch.zeros(1, 20, 1)
+    lm[0, :12] = 1
+    with torch.no_grad():
+        feats = model.backbone(x, l, lm)
+        logits = model(x, l, lm)
+    loss = F.cross_entropy(logits, tgt, weight=torch.tensor([0.9, 1.1]))
+    pred = logits.argmax(1)
+    save("e2e_swin_t_224", seed=1234, valid=12,
+         c1=feats[0][:, :, ::4, ::4], c2=feats[1][:, :, ::2, ::2], c3=feats[2], c4=feats[3],
+         feat_sums=np.array([float(f.double().sum()) for f in feats]),
+         feat_abs=np.array([float(f.double().abs().sum()) for f in feats]),
+         logits=logits, mask=np.packbits(pred.numpy().astype(np.uint8).reshape(-1)),
+         I=int((pred & tgt).sum()), U=int((pred | tgt).sum()), loss=float(loss),
+         margin_frac=float(((logits[:, 1] - logits[:, 0]).abs() > 1e-2).float().mean()))
+    print("   swin_t margin>1e-2 fraction:", float(((logits[:, 1] - logits[:, 0]).abs() > 1e-2).float().mean()),
+          "logit std", float(logits.std()), "pos frac", float(pred.float().mean()))
+
+    # Swin-B window 12 at a small image: exercises padded windows (24->24, 12, 6->12, 3->12)
+    model = build(128, [2, 2, 18, 2], [4, 8, 16, 32], 12).eval()
+    keys = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in model.state_dict().items())
+    with open(os.path.join(HERE, "state_dict_keys_swin_b_w12.txt"), "w") as f:
+        f.write("\n".join(keys) + "\n")
+    x, l, lm, tgt = det_inputs(2, 96, 20, seed=77)
+    with torch.no_grad():
+        logits = model(x, l, lm)
+    pred = logits.argmax(1)
+    save("e2e_swin_b_w12_96", seed=77, logits=logits, I=int((pred & tgt).sum()), U=int((pred | tgt).sum()))
+    print("   swin_b margin>1e-2 fraction:", float(((logits[:, 1] - logits[:, 0]).abs() > 1e-2).float().mean()))
+
+    # tiny model: forward + every parameter gradient (train mode: BN batch stats, drop path 0)
+    model = build(32, [2, 2, 2, 2], [1, 2, 4, 8], 7, dpr=0.0).train()
+    x, l, lm, tgt = det_inputs(2, 64, 20, seed=99)
+    x.requires_grad_(True)
+    l.requires_grad_(True)
+    logits = model(x, l, lm)
+    loss = F.cross_entropy(logits, tgt, weight=torch.tensor([0.9, 1.1]))
+    loss.backward()
+    digests = {}
+    nograd = []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            nograd.append(k)
+        else:
+            digests["g|" + k] = grad_digest(p.grad)
+    save("e2e_tiny_train", seed=99, logits=logits, loss=float(loss), dx=grad_digest(x.grad), dl=grad_digest(l.grad),
+         nograd=np.array(nograd), **digests)
+    print("   tiny: params without grad:", nograd)
+
+
+def _ref_mask(rb, Hp, Wp, ws):
+    """Run the reference's own mask construction (lib/backbone.py:634-652) by calling the
+    stage forward with zero blocks and capturing the mask handed to a probe block."""
+    captured = {}
+
+    class Probe(nn.Module):
+        H = W = None
+
+        def forward(self, x, mask):
+            captured["m"] = mask
+            return x
+
+    st = rb.MMBasicLayer.__new__(rb.MMBasicLayer)
+    nn.Module.__init__(st)
+    st.window_size, st.shift_size, st.use_checkpoint = ws, ws // 2, False
+    st.blocks = nn.ModuleList([Probe()])
+    st.lazy_pred, st.version, st.hs, st.downsample = False, "none", False, None
+    st.fusion = lambda x, l, m: x
+    st(torch.zeros(1, Hp * Wp, 1), Hp, Wp, None, None)
+    return captured["m"]
+
+
+if __name__ == "__main__":
+    main()
