@@ -1,0 +1,232 @@
+/*
+ * lavt_hip.h -- C ABI of the MI355X (gfx950) LAVT hot-path library (liblavt_hip.so).
+ *
+ * Every entry point is `extern "C"`, takes raw DEVICE pointers + sizes + a hipStream_t (as void*),
+ * allocates nothing, keeps no global state besides the last-error string, launches asynchronously on
+ * the given stream and returns 0 or a negative LAVT_ERR_* code.  No torch types anywhere.
+ *
+ * The reference (Yxxxb/LAVT-RS) is pure PyTorch and has no native layer; each group of functions
+ * below names the reference code (file:line under the reference root) whose arithmetic it replaces.
+ * The Python host side that binds these with ctypes is lavt-rs_amd/lavt_hip/_capi.py;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Layout conventions: activations are token-major / NHWC ([rows][channels], channels contiguous);
+ * "dtype" selects the storage type of activations and of the compute copies of the weights
+ * (LAVT_F32 = exact-fp32 MFMA path used for parity, LAVT_BF16 = bf16 MFMA with fp32 accumulation).
+ * Biases, LayerNorm/BatchNorm affine parameters, statistics and every parameter GRADIENT are fp32.
+ */
+#ifndef LAVT_HIP_H
+#define LAVT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAVT_F32 0
+#define LAVT_BF16 1
+
+#define LAVT_OK 0
+#define LAVT_ERR_INVALID (-22) /* bad argument (EINVAL) */
+#define LAVT_ERR_LAUNCH (-5)   /* kernel launch failed (EIO) */
+
+#define LAVT_ACT_NONE 0
+#define LAVT_ACT_GELU 1 /* exact erf form */
+#define LAVT_ACT_RELU 2
+#define LAVT_ACT_TANH 3
+
+int lavt_abi_version(void);
+const char* lavt_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gather-GEMM, "NT" family:   C[M,N] = epilogue( alpha * A_op[M,K] x B_op[K,N] )
+ *
+ * Replaces every nn.Linear / 1x1 Conv1d / 3x3 Conv2d forward and data-gradient on the path:
+ *   qkv, proj (lib/backbone.py:121,141), Mlp fc1/fc2 (:24-30), PatchMerging.reduction (:286),
+ *   PWAM vis_project/f_query/f_key/f_value/W/project_mm (:1244-1327), res_gate (:604-611),
+ *   PatchEmbed.proj (:309, after lavt_im2col4), SimpleDecoding conv3x3 (lib/mask_predictor.py:18-38),
+ *   and the window partition / roll / pad / reverse copies (lib/backbone.py:33-62, 204-237), which become
+ *   row gather (a_rowmap) and row scatter (c_rowmap) of the GEMMs on either side of the attention core.
+ *
+ * A_op: rows along M with K contiguous.  Row m is read from source row a_rowmap[m] (or m); -1 reads zeros.
+ *   conv_cin > 0 makes this an implicit-GEMM 3x3 convolution (pad 1) over a (batch, conv_h, conv_w) pixel grid:
+ *   K = 9*conv_kc, k = tap*conv_kc + c, tap = (dy+1)*3+(dx+1); row m = pixel, source row = neighbour pixel
+ *   (mirrored neighbour when conv_flip = 1, i.e. the data gradient).  Channels c >= a_split come from A2
+ *   (fused torch.cat of [top-down, skip], lib/mask_predictor.py:60,70,81).
+ * B_op: b_kmajor = 0: B[N][K] (nn.Linear weight layout);  1: B[K][N] (used for x @ W, i.e. data gradients).
+ *   With conv and b_kmajor = 1, k = tap*conv_kc + c addresses B + c*ldb + tap*b_tap_stride + n.
+ * Epilogue, in order: *alpha, +bias[n], *row_scale[m], (Cpre = value), act, +R[out_row][n], store.
+ *   Output row = c_rowmap[m] (or m); -1 drops the row.  Columns >= c_split go to C2 (fused split of the
+ *   gradient of a concatenation).  c_f32 stores fp32 whatever dtype is.
+ * Requirements: K % (16/sizeof(dtype)) == 0; if b_kmajor, N % (16/sizeof(dtype)) == 0; lda/ldb/ldc multiples of
+ *   the same; all pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lavt_gemm_nt {
+    int32_t dtype, M, N, K, batch;
+    /* A */
+    const void* A;
+    int64_t lda, strideA;
+    const void* A2;
+    int64_t lda2;
+    int32_t a_split;
+    const int32_t* a_rowmap;
+    int32_t conv_h, conv_w, conv_kc, conv_flip;
+    /* B */
+    const void* B;
+    int64_t ldb, strideB;
+    int32_t b_kmajor;
+    int64_t b_tap_stride;
+    /* epilogue */
+    float alpha;
+    const float* bias;
+    int64_t strideBias;
+    const float* row_scale;
+    int64_t strideRowScale;
+    int32_t row_scale_div; /* row m uses row_scale[m / row_scale_div] (<=1 means m): per-sample DropPath factors */
+    int32_t act;
+    void* Cpre;
+    int64_t ldcpre;
+    const void* R;
+    int64_t ldr;
+    void* C;
+    int64_t ldc, strideC;
+    void* C2;
+    int64_t ldc2;
+    int32_t c_split;
+    const int32_t* c_rowmap;
+    int32_t c_f32;
+} lavt_gemm_nt_t;
+
+int lavt_gemm_nt(const lavt_gemm_nt_t* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gather-GEMM, "TN" family (weight gradients):   C[I,J] += alpha * sum_k A[k][i] * B[k][j]      (fp32 C)
+ *
+ * Replaces the weight-gradient half of autograd for every layer listed above (the reference gets it from
+ * torch.autograd; there is no reference source line).  Rows k of A / B are gathered through a_rowmap / b_rowmap
+ * (-1 = zero row); conv_cin > 0: J = 9*conv_kc and column j = tap*conv_kc + c reads B row = neighbour pixel of k
+ * for that tap (channels >= b_split from B2).  c_conv_permute stores column (tap,c) at c*9+tap so that C is
+ * directly the PyTorch [Cout][Cin][3][3] gradient.  The reduction over k is split across workgroups
+ * (split_k, 0 = auto) and accumulated with fp32 atomics: C must hold zeros or a running sum.
+ * colsum (optional, fp32 [I]) additionally receives sum_k A[k][i] (the bias gradient).
+ * Requirements: I, J (and conv_kc) % (16/sizeof(dtype)) == 0; lda/ldb likewise.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lavt_gemm_tn {
+    int32_t dtype, I, J, K, batch;
+    const void* A;
+    int64_t lda, strideA;
+    const int32_t* a_rowmap;
+    const float* a_rowscale; /* optional fp32 factor of A row k: a_rowscale[k / a_rowscale_div] (mask / DropPath of the forward) */
+    int32_t a_rowscale_div;
+    const void* B;
+    int64_t ldb, strideB;
+    const void* B2;
+    int64_t ldb2;
+    int32_t b_split;
+    const int32_t* b_rowmap;
+    int32_t conv_h, conv_w, conv_kc;
+    float alpha;
+    float* C;
+    int64_t ldc, strideC;
+    int32_t c_conv_permute;
+    int32_t split_k;
+    float* colsum;
+    int64_t strideColsum;
+} lavt_gemm_tn_t;
+
+int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Shifted-window attention core (WindowAttention.forward, lib/backbone.py:123-140; mask :634-652).
+ * qkv: [nwin*N][3C] in windowed row order (columns s*C + h*32 + d, s in {q,k,v}), head_dim = C/heads.
+ * out: [nwin*N][C].  bias: dense fp32 [heads][N][N] (from lavt_relpos_expand).  region: optional int8
+ * [nw_img][N] region ids of the shift mask (window w uses row w % nw_img); unequal ids add -100.
+ * lse: fp32 [nwin][heads][N] log-sum-exp of each score row (saved for backward).
+ * Backward: dqkv [nwin*N][3C] (every element written), dbias fp32 [heads][N][N] accumulated with atomics.
+ * ------------------------------------------------------------------------------------------- */
+int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, const int8_t* region, int nw_img, void* out,
+                         float* lse, int nwin, int N, int heads, int head_dim, float scale, void* stream);
+int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, const int8_t* region, int nw_img,
+                         const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int nwin, int N,
+                         int heads, int head_dim, float scale, void* stream);
+
+/* relative_position_bias_table[(2ws-1)^2][heads] -> dense bias[heads][N][N] (lib/backbone.py:89-103,125-127)
+ * and its transpose (dense gradient -> table gradient, deterministic, accumulates into dtable). */
+int lavt_relpos_expand(const float* table, float* dense, int ws, int heads, void* stream);
+int lavt_relpos_reduce(const float* ddense, float* dtable, int ws, int heads, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm over the channel dimension (nn.LayerNorm, eps 1e-5; lib/backbone.py:201,243,285,328,510).
+ * x,y: [rows][C].  mean/rstd: fp32 [rows] saved for backward.  gamma/beta fp32 [C].
+ * gather != NULL: row r of the INPUT is assembled from 4 source rows gather[4r..4r+3] of C/4 channels each
+ * (-1 = zeros): the 2x2 neighbour concat of PatchMerging (lib/backbone.py:278-283) fused into its LayerNorm.
+ * Backward accumulates dgamma/dbeta (fp32 atomics); with gather, dx rows are scattered back (every source
+ * row appears exactly once).
+ * ------------------------------------------------------------------------------------------- */
+int lavt_layernorm_fwd(int dtype, const void* x, const int32_t* gather, const float* gamma, const float* beta, void* y,
+                       float* mean, float* rstd, int rows, int C, float eps, void* stream);
+int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
+                       const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int C,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-channel statistics over rows, and the normalisations built on them:
+ *   InstanceNorm1d over all H*W positions (PWAM f_query / W, lib/backbone.py:1311-1327): groups = batch;
+ *   BatchNorm2d (+ReLU) of the decoder (lib/mask_predictor.py:19-37; SyncBN = all-reduce of sums between the calls).
+ * lavt_colstats: x [groups][rows][C] -> sum, sumsq fp32 [groups][C] (accumulated: pass zeroed buffers).
+ * lavt_norm_apply: y = ((x-mean)*rstd*gamma + beta) (*mul) with optional ReLU; mean/rstd [groups][C]; gamma/beta/mul optional.
+ * lavt_norm_bwd_stats: s1 += sum(g), s2 += sum(g*xhat) with g = dy (*mul) masked by relu (y>0);  [groups][C].
+ * lavt_norm_bwd_apply: dx = gamma*rstd*(g - s1/n - xhat*s2/n); dmul = dy*xhat_affine (optional).
+ * ------------------------------------------------------------------------------------------- */
+int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq, int groups, int rows, int C, void* stream);
+int lavt_stats_finalize(const float* sum, const float* sumsq, float count, float eps, float* mean, float* rstd,
+                        float* running_mean, float* running_var, float momentum, int n, void* stream);
+int lavt_norm_apply(int dtype, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    const void* mul, int relu, void* y, int groups, int rows, int C, void* stream);
+int lavt_norm_bwd_stats(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, const void* mul, int relu, float* s1, float* s2,
+                        int groups, int rows, int C, void* stream);
+int lavt_norm_bwd_apply(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, const void* mul, int relu, const float* s1, const float* s2,
+                        float count, void* dx, void* dmul, int groups, int rows, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Element-wise pieces.
+ * ------------------------------------------------------------------------------------------- */
+/* dx = dy * act'(pre)   (GELU of Mlp / PWAM projections, ReLU of res_gate) */
+int lavt_act_bwd(int dtype, int act, const void* dy, const void* pre, void* dx, int64_t n, void* stream);
+/* language gate, lib/backbone.py:669:  xo = x + tanh(gpre) * r ;  backward gives dgpre, dr (+= into dr_acc semantics: written) */
+int lavt_gate_fwd(int dtype, const void* x, const void* gpre, const void* r, void* xo, int64_t n, void* stream);
+int lavt_gate_bwd(int dtype, const void* dxo, const void* gpre, const void* r, void* dgpre, void* dr, int64_t n, void* stream);
+/* masked softmax over the (padded) word axis of PWAM scores, lib/backbone.py:1358-1361.
+ * s,p: [rows][ld] (only the first n_l columns are real; p's padding columns are written as 0). */
+int lavt_rowsoftmax_fwd(int dtype, const void* s, void* p, int64_t rows, int n_l, int ld, void* stream);
+int lavt_rowsoftmax_bwd(int dtype, const void* p, const void* dp, void* ds, int64_t rows, int n_l, int ld, void* stream);
+/* bilinear resize, align_corners=True, NHWC (F.interpolate in lib/mask_predictor.py:59,69,80) */
+int lavt_bilinear_fwd(int dtype, const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
+int lavt_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
+/* final logits: NHWC [B,Hi,Wi,2] (dtype) -> NCHW fp32 [B,2,Ho,Wo] (lib/_utils.py:21) and its gradient */
+int lavt_logits_up_fwd(int dtype, const void* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, void* stream);
+int lavt_logits_up_bwd(int dtype, const float* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, void* stream);
+/* classifier head conv1_1: 1x1 conv hidden->2 with bias (lib/mask_predictor.py:50,99) */
+int lavt_cls_head_fwd(int dtype, const void* x, const float* w, const float* b, void* y, int64_t rows, int C, void* stream);
+int lavt_cls_head_bwd(int dtype, const void* x, const void* dy, const float* w, void* dx, float* dw, float* db,
+                      int64_t rows, int C, void* stream);
+/* PatchEmbed im2col: NCHW fp32 image -> [B*H4*W4][48] patches (zero padded to x4), lib/backbone.py:318-324;
+ * col2im scatters the patch gradient back to an NCHW fp32 image gradient. */
+int lavt_im2col4(int dtype, const float* img, void* cols, int B, int H, int W, void* stream);
+int lavt_col2im4(int dtype, const void* dcols, float* dimg, int B, int H, int W, void* stream);
+/* layout / dtype plumbing */
+int lavt_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
+int lavt_nchw_to_nhwc(int src_dtype, const void* src, int dst_dtype, void* dst, int B, int C, int HW, void* stream);
+int lavt_nhwc_to_nchw(int src_dtype, const void* src, int dst_dtype, void* dst, int B, int C, int HW, void* stream);
+/* conv weight fp32 [Cout][Cin][3][3] -> dtype [Cout][9][Cin] (compute copy used by lavt_gemm_nt) */
+int lavt_pack_conv3x3(const float* w, int dtype, void* packed, int Cout, int Cin, void* stream);
+/* many small fp32 -> dtype casts in one launch: desc = int64 triples (src_ptr, dst_ptr, n) on the DEVICE */
+int lavt_cast_multi(const int64_t* desc, int count, int dst_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAVT_HIP_H */

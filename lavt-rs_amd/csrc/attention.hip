@@ -1,0 +1,288 @@
+// Shifted-window attention core (scores + relative-position bias + shift mask + softmax + PV) and its
+// backward, one workgroup per (window, head).  Reference: WindowAttention.forward, lib/backbone.py:123-140.
+//
+// This file holds the exact-fp32 VALU formulation used for LAVT_F32 (parity path) and, until the MFMA
+// formulation in attention_mfma.hip takes a shape, for LAVT_BF16 as well (bf16 storage, fp32 math).
+// K and V of the window live in LDS for the whole workgroup; each wave owns query rows i = wave, wave+4, ...
+// and spreads the key index j over its 64 lanes, so the softmax row reductions are wave shuffles.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 32;          // head_dim is 32 in every stage of every Swin variant
+constexpr int KV_LD = HD + 1;   // +1 float: lanes index rows -> conflict-free LDS reads
+
+template <typename T>
+__device__ __forceinline__ void load_kv(const T* qkv, int64_t row0, int C, int h, int N, float* Ks, float* Vs, float* Qs, float scale) {
+    // each thread copies (row, d) pairs; global reads are 32 contiguous elements per row
+    for (int e = threadIdx.x; e < N * HD; e += blockDim.x) {
+        const int j = e / HD, d = e % HD;
+        const T* r = qkv + (row0 + j) * (int64_t)(3 * C) + h * HD + d;
+        if (Qs) Qs[j * KV_LD + d] = to_f<T>(r[0]) * scale;
+        Ks[j * KV_LD + d] = to_f<T>(r[C]);
+        Vs[j * KV_LD + d] = to_f<T>(r[2 * C]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void window_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
+                                                              const int8_t* __restrict__ region, int nw_img, T* __restrict__ out,
+                                                              float* __restrict__ lse, int N, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Ks = reinterpret_cast<float*>(smem_raw);
+    float* Vs = Ks + N * KV_LD;
+    float* Qs = Vs + N * KV_LD;
+    float* Pw = Qs + N * KV_LD;                 // [4][NJ*64]
+    const int w = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int C = heads * HD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)w * N;
+    load_kv<T>(qkv, row0, C, h, N, Ks, Vs, Qs, scale);
+    __syncthreads();
+    const int8_t* reg = region ? region + (int64_t)(w % nw_img) * N : nullptr;
+    const float* bh = bias + (int64_t)h * N * N;
+    float* P = Pw + wave * NJ * 64;
+
+    int rid_j[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) { const int j = lane + 64 * t; rid_j[t] = (reg && j < N) ? reg[j] : 0; }
+
+    for (int i = wave; i < N; i += 4) {
+        const float* q = Qs + i * KV_LD;
+        const int rid_i = reg ? reg[i] : 0;
+        float s[NJ], mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) {
+            const int j = lane + 64 * t;
+            float a = -INFINITY;
+            if (j < N) {
+                a = 0.f;
+                const float* k = Ks + j * KV_LD;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) a = fmaf(q[d], k[d], a);
+                a += bh[(int64_t)i * N + j];
+                if (rid_j[t] != rid_i) a += -100.0f;
+            }
+            s[t] = a;
+            mx = fmaxf(mx, a);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) { s[t] = (lane + 64 * t < N) ? __expf(s[t] - mx) : 0.f; sum += s[t]; }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) P[lane + 64 * t] = s[t] * inv;
+        if (lane == 0) lse[((int64_t)w * heads + h) * N + i] = mx + __logf(sum);
+        __builtin_amdgcn_wave_barrier();
+        // PV: lanes 0..31 take even j, lanes 32..63 odd j, for column d = lane & 31
+        const int d = lane & 31, par = lane >> 5;
+        float o = 0.f;
+        for (int j = par; j < N; j += 2) o = fmaf(P[j], Vs[j * KV_LD + d], o);
+        o += __shfl_xor(o, 32, 64);
+        if (lane < 32) out[(row0 + i) * C + h * HD + d] = from_f<T>(o);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
+                                                              const int8_t* __restrict__ region, int nw_img,
+                                                              const T* __restrict__ out, const T* __restrict__ dout,
+                                                              const float* __restrict__ lse, T* __restrict__ dqkv,
+                                                              float* __restrict__ dbias, int N, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Ks = reinterpret_cast<float*>(smem_raw);
+    float* Vs = Ks + N * KV_LD;
+    float* Qs = Vs + N * KV_LD;                 // scaled q
+    float* dKs = Qs + N * KV_LD;                // cross-wave accumulators
+    float* dVs = dKs + N * KV_LD;
+    float* Sw = dVs + N * KV_LD;                // [4][NJ*64] dS rows
+    float* Dw = Sw + 4 * NJ * 64;               // [4][HD] dO row
+    const int w = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int C = heads * HD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)w * N;
+    load_kv<T>(qkv, row0, C, h, N, Ks, Vs, Qs, scale);
+    for (int e = threadIdx.x; e < N * KV_LD; e += blockDim.x) { dKs[e] = 0.f; dVs[e] = 0.f; }
+    __syncthreads();
+    const int8_t* reg = region ? region + (int64_t)(w % nw_img) * N : nullptr;
+    const float* bh = bias + (int64_t)h * N * N;
+    float* dbh = dbias + (int64_t)h * N * N;
+    float* dS = Sw + wave * NJ * 64;
+    float* dOr = Dw + wave * HD;
+
+    int rid_j[NJ];
+    float dk[NJ][HD], dv[NJ][HD];
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) {
+        const int j = lane + 64 * t;
+        rid_j[t] = (reg && j < N) ? reg[j] : 0;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { dk[t][d] = 0.f; dv[t][d] = 0.f; }
+    }
+
+    for (int i = wave; i < N; i += 4) {
+        const float* q = Qs + i * KV_LD;
+        const int rid_i = reg ? reg[i] : 0;
+        const float l = lse[((int64_t)w * heads + h) * N + i];
+        // dO row and delta = sum_d dO*O
+        float dl = 0.f;
+        if (lane < HD) {
+            const float g = to_f<T>(dout[(row0 + i) * C + h * HD + lane]);
+            dOr[lane] = g;
+            dl = g * to_f<T>(out[(row0 + i) * C + h * HD + lane]);
+        }
+        dl = wave_sum(dl);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) {
+            const int j = lane + 64 * t;
+            float ds = 0.f;
+            if (j < N) {
+                float a = 0.f, dp = 0.f;
+                const float* k = Ks + j * KV_LD;
+                const float* v = Vs + j * KV_LD;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) { a = fmaf(q[d], k[d], a); dp = fmaf(dOr[d], v[d], dp); }
+                a += bh[(int64_t)i * N + j];
+                if (rid_j[t] != rid_i) a += -100.0f;
+                const float pj = __expf(a - l);
+                ds = pj * (dp - dl);
+                atomicAdd(dbh + (int64_t)i * N + j, ds);
+#pragma unroll
+                for (int d = 0; d < HD; ++d) {
+                    dv[t][d] = fmaf(pj, dOr[d], dv[t][d]);
+                    dk[t][d] = fmaf(ds, q[d], dk[t][d]);          // q already carries `scale`
+                }
+            }
+            dS[j] = ds;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // dQ[i][d] = scale * sum_j dS[j] K[j][d]
+        const int d = lane & 31, par = lane >> 5;
+        float o = 0.f;
+        for (int j = par; j < N; j += 2) o = fmaf(dS[j], Ks[j * KV_LD + d], o);
+        o += __shfl_xor(o, 32, 64);
+        if (lane < 32) dqkv[(row0 + i) * (int64_t)(3 * C) + h * HD + d] = from_f<T>(o * scale);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // cross-wave reduction of dK, dV through LDS, then store
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) {
+        const int j = lane + 64 * t;
+        if (j < N) {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                atomicAdd(dKs + j * KV_LD + d, dk[t][d]);
+                atomicAdd(dVs + j * KV_LD + d, dv[t][d]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * HD; e += blockDim.x) {
+        const int j = e / HD, d = e % HD;
+        T* r = dqkv + (row0 + j) * (int64_t)(3 * C) + h * HD + d;
+        r[C] = from_f<T>(dKs[j * KV_LD + d]);
+        r[2 * C] = from_f<T>(dVs[j * KV_LD + d]);
+    }
+}
+
+// relative position bias: table[(2ws-1)^2][heads] <-> dense[heads][N][N]
+__global__ void relpos_expand_kernel(const float* __restrict__ table, float* __restrict__ dense, int ws, int heads) {
+    const int N = ws * ws;
+    const int64_t total = (int64_t)heads * N * N;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = e % N, i = (e / N) % N, h = e / ((int64_t)N * N);
+        const int idx = (i / ws - j / ws + ws - 1) * (2 * ws - 1) + (i % ws - j % ws + ws - 1);
+        dense[e] = table[idx * heads + h];
+    }
+}
+// one thread per (table row, head): sums the dense gradient over every (i,j) pair that maps to it -- deterministic
+__global__ void relpos_reduce_kernel(const float* __restrict__ ddense, float* __restrict__ dtable, int ws, int heads) {
+    const int R = (2 * ws - 1) * (2 * ws - 1), N = ws * ws;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R * heads) return;
+    const int h = e % heads, idx = e / heads;
+    const int dr = idx / (2 * ws - 1) - (ws - 1), dc = idx % (2 * ws - 1) - (ws - 1);   // (ri - rj, ci - cj)
+    float s = 0.f;
+    for (int rj = max(0, -dr); rj < min(ws, ws - dr); ++rj)
+        for (int cj = max(0, -dc); cj < min(ws, ws - dc); ++cj) {
+            const int i = (rj + dr) * ws + (cj + dc), j = rj * ws + cj;
+            s += ddense[((int64_t)h * N + i) * N + j];
+        }
+    dtable[idx * heads + h] += s;
+}
+
+template <typename T>
+int launch_fwd(const void* qkv, const float* bias, const int8_t* region, int nw_img, void* out, float* lse, int nwin, int N,
+               int heads, float scale, hipStream_t st) {
+    const int NJ = (N + 63) / 64;
+    const size_t lds = (size_t)(3 * N * KV_LD + 4 * NJ * 64) * sizeof(float);
+    dim3 grid(nwin * heads);
+#define L(NJ_)                                                                                                              \
+    hipLaunchKernelGGL((window_attn_fwd_kernel<T, NJ_>), grid, dim3(256), lds, st, (const T*)qkv, bias, region, nw_img, \
+                       (T*)out, lse, N, heads, scale)
+    if (NJ == 1) L(1); else if (NJ == 2) L(2); else if (NJ == 3) L(3); else { lavt_set_error("lavt_window_attn_fwd: N=%d > 192 not supported by this kernel", N); return LAVT_ERR_INVALID; }
+#undef L
+    LAVT_CHECK_LAUNCH("lavt_window_attn_fwd");
+    return LAVT_OK;
+}
+template <typename T>
+int launch_bwd(const void* qkv, const float* bias, const int8_t* region, int nw_img, const void* out, const void* dout,
+               const float* lse, void* dqkv, float* dbias, int nwin, int N, int heads, float scale, hipStream_t st) {
+    const int NJ = (N + 63) / 64;
+    const size_t lds = (size_t)(5 * N * KV_LD + 4 * NJ * 64 + 4 * HD) * sizeof(float);
+    dim3 grid(nwin * heads);
+#define L(NJ_)                                                                                                              \
+    hipLaunchKernelGGL((window_attn_bwd_kernel<T, NJ_>), grid, dim3(256), lds, st, (const T*)qkv, bias, region, nw_img, \
+                       (const T*)out, (const T*)dout, lse, (T*)dqkv, dbias, N, heads, scale)
+    if (NJ == 1) L(1); else if (NJ == 2) L(2); else if (NJ == 3) L(3); else { lavt_set_error("lavt_window_attn_bwd: N=%d > 192 not supported by this kernel", N); return LAVT_ERR_INVALID; }
+#undef L
+    LAVT_CHECK_LAUNCH("lavt_window_attn_bwd");
+    return LAVT_OK;
+}
+
+}  // namespace
+
+extern "C" int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, const int8_t* region, int nw_img, void* out,
+                                    float* lse, int nwin, int N, int heads, int head_dim, float scale, void* stream) {
+    LAVT_CHECK_ARG(head_dim == HD, "lavt_window_attn_fwd: head_dim %d != 32", head_dim);
+    LAVT_CHECK_ARG(qkv && bias && out && lse && nwin > 0 && N > 0 && heads > 0, "lavt_window_attn_fwd: bad arguments");
+    LAVT_CHECK_ARG(!region || nw_img > 0, "lavt_window_attn_fwd: region needs nw_img");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == LAVT_F32) return launch_fwd<float>(qkv, bias, region, nw_img, out, lse, nwin, N, heads, scale, st);
+    if (dtype == LAVT_BF16) return launch_fwd<bf16>(qkv, bias, region, nw_img, out, lse, nwin, N, heads, scale, st);
+    lavt_set_error("lavt_window_attn_fwd: bad dtype %d", dtype);
+    return LAVT_ERR_INVALID;
+}
+
+extern "C" int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, const int8_t* region, int nw_img,
+                                    const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int nwin,
+                                    int N, int heads, int head_dim, float scale, void* stream) {
+    LAVT_CHECK_ARG(head_dim == HD, "lavt_window_attn_bwd: head_dim %d != 32", head_dim);
+    LAVT_CHECK_ARG(qkv && bias && out && dout && lse && dqkv && dbias && nwin > 0 && N > 0 && heads > 0, "lavt_window_attn_bwd: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == LAVT_F32) return launch_bwd<float>(qkv, bias, region, nw_img, out, dout, lse, dqkv, dbias, nwin, N, heads, scale, st);
+    if (dtype == LAVT_BF16) return launch_bwd<bf16>(qkv, bias, region, nw_img, out, dout, lse, dqkv, dbias, nwin, N, heads, scale, st);
+    lavt_set_error("lavt_window_attn_bwd: bad dtype %d", dtype);
+    return LAVT_ERR_INVALID;
+}
+
+extern "C" int lavt_relpos_expand(const float* table, float* dense, int ws, int heads, void* stream) {
+    LAVT_CHECK_ARG(table && dense && ws > 0 && heads > 0, "lavt_relpos_expand: bad arguments");
+    const int64_t total = (int64_t)heads * ws * ws * ws * ws;
+    hipLaunchKernelGGL(relpos_expand_kernel, dim3(cdiv(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, dense, ws, heads);
+    LAVT_CHECK_LAUNCH("lavt_relpos_expand");
+    return LAVT_OK;
+}
+extern "C" int lavt_relpos_reduce(const float* ddense, float* dtable, int ws, int heads, void* stream) {
+    LAVT_CHECK_ARG(ddense && dtable && ws > 0 && heads > 0, "lavt_relpos_reduce: bad arguments");
+    const int total = (2 * ws - 1) * (2 * ws - 1) * heads;
+    hipLaunchKernelGGL(relpos_reduce_kernel, dim3(cdiv(total, 128)), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), ddense, dtable, ws, heads);
+    LAVT_CHECK_LAUNCH("lavt_relpos_reduce");
+    return LAVT_OK;
+}

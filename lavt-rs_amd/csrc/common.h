@@ -1,0 +1,92 @@
+// Shared device/host helpers for the LAVT gfx950 kernels.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/lavt_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+
+#define LAVT_WAVE 64
+
+// ---- error plumbing -------------------------------------------------------------------------
+void lavt_set_error(const char* fmt, ...);
+#define LAVT_CHECK_ARG(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            lavt_set_error(__VA_ARGS__);          \
+            return LAVT_ERR_INVALID;              \
+        }                                         \
+    } while (0)
+#define LAVT_CHECK_LAUNCH(name)                                                  \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) {                                                 \
+            lavt_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return LAVT_ERR_LAUNCH;                                              \
+        }                                                                        \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- scalar conversions -----------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
+
+// A 16-byte chunk of T: 4 floats or 8 bf16.
+template <typename T> struct Chunk { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T> __device__ __forceinline__ void chunk_to_f(const uint4& c, float* f) {
+    if constexpr (std::is_same<T, float>::value) {
+        f[0] = __uint_as_float(c.x); f[1] = __uint_as_float(c.y); f[2] = __uint_as_float(c.z); f[3] = __uint_as_float(c.w);
+    } else {
+        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    }
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    bf16 a = (bf16)lo, b = (bf16)hi;
+    return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+}
+template <typename T> __device__ __forceinline__ uint4 f_to_chunk(const float* f) {
+    uint4 c;
+    if constexpr (std::is_same<T, float>::value) {
+        c.x = __float_as_uint(f[0]); c.y = __float_as_uint(f[1]); c.z = __float_as_uint(f[2]); c.w = __float_as_uint(f[3]);
+    } else {
+        c.x = pack_bf16x2(f[0], f[1]); c.y = pack_bf16x2(f[2], f[3]);
+        c.z = pack_bf16x2(f[4], f[5]); c.w = pack_bf16x2(f[6], f[7]);
+    }
+    return c;
+}
+
+// ---- wave / block reductions ----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- activations ------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

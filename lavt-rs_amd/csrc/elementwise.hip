@@ -1,0 +1,457 @@
+// HBM-bound element-wise / data-movement kernels of the LAVT path (16-byte accesses, grid-stride).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+// ---- error string (the only global state of the library) ----------------------------------------
+static thread_local char g_err[512] = "";
+void lavt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* lavt_last_error(void) { return g_err; }
+extern "C" int lavt_abi_version(void) { return 1; }
+
+namespace {
+
+inline int ew_grid(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+#define GRID_STRIDE(i, n) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------------------------------------- activations / gate
+template <typename T> __global__ void act_bwd_kernel(int act, const T* dy, const T* pre, T* dx, int64_t nchunks) {
+    constexpr int EPC = Chunk<T>::N;
+    GRID_STRIDE(i, nchunks) {
+        float g[EPC], x[EPC];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(dy + i * EPC), g);
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(pre + i * EPC), x);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            if (act == LAVT_ACT_GELU) g[e] *= gelu_grad_f(x[e]);
+            else if (act == LAVT_ACT_RELU) g[e] = x[e] > 0.f ? g[e] : 0.f;
+            else if (act == LAVT_ACT_TANH) { const float t = tanhf(x[e]); g[e] *= 1.f - t * t; }
+        }
+        *reinterpret_cast<uint4*>(dx + i * EPC) = f_to_chunk<T>(g);
+    }
+}
+template <typename T> __global__ void gate_fwd_kernel(const T* x, const T* gpre, const T* r, T* xo, int64_t nchunks) {
+    constexpr int EPC = Chunk<T>::N;
+    GRID_STRIDE(i, nchunks) {
+        float a[EPC], g[EPC], b[EPC];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + i * EPC), a);
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(gpre + i * EPC), g);
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(r + i * EPC), b);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) a[e] += tanhf(g[e]) * b[e];
+        *reinterpret_cast<uint4*>(xo + i * EPC) = f_to_chunk<T>(a);
+    }
+}
+template <typename T> __global__ void gate_bwd_kernel(const T* dxo, const T* gpre, const T* r, T* dgpre, T* dr, int64_t nchunks) {
+    constexpr int EPC = Chunk<T>::N;
+    GRID_STRIDE(i, nchunks) {
+        float d[EPC], g[EPC], b[EPC], o1[EPC], o2[EPC];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(dxo + i * EPC), d);
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(gpre + i * EPC), g);
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(r + i * EPC), b);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { const float t = tanhf(g[e]); o1[e] = d[e] * b[e] * (1.f - t * t); o2[e] = d[e] * t; }
+        *reinterpret_cast<uint4*>(dgpre + i * EPC) = f_to_chunk<T>(o1);
+        *reinterpret_cast<uint4*>(dr + i * EPC) = f_to_chunk<T>(o2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- PWAM word softmax
+template <typename T> __global__ void rowsoftmax_fwd_kernel(const T* s, T* p, int64_t rows, int n_l, int ld) {
+    GRID_STRIDE(r, rows) {
+        const T* sr = s + r * ld;
+        T* pr = p + r * ld;
+        float mx = -INFINITY;
+        for (int j = 0; j < n_l; ++j) mx = fmaxf(mx, to_f<T>(sr[j]));
+        float sum = 0.f;
+        for (int j = 0; j < n_l; ++j) sum += __expf(to_f<T>(sr[j]) - mx);
+        const float inv = 1.f / sum;
+        for (int j = 0; j < ld; ++j) pr[j] = from_f<T>(j < n_l ? __expf(to_f<T>(sr[j]) - mx) * inv : 0.f);
+    }
+}
+template <typename T> __global__ void rowsoftmax_bwd_kernel(const T* p, const T* dp, T* ds, int64_t rows, int n_l, int ld) {
+    GRID_STRIDE(r, rows) {
+        const T* pr = p + r * ld;
+        const T* dr = dp + r * ld;
+        float dot = 0.f;
+        for (int j = 0; j < n_l; ++j) dot += to_f<T>(pr[j]) * to_f<T>(dr[j]);
+        for (int j = 0; j < ld; ++j) ds[r * ld + j] = from_f<T>(j < n_l ? to_f<T>(pr[j]) * (to_f<T>(dr[j]) - dot) : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- bilinear (align_corners=True)
+__device__ __forceinline__ void bl_coord(int o, float scale, int n_in, int& i0, int& i1, float& lam) {
+    const float src = scale * (float)o;
+    i0 = (int)src;
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = min(i0 + 1, n_in - 1);
+    lam = src - (float)i0;
+}
+__host__ __device__ inline float bl_scale(int n_in, int n_out) { return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f; }
+
+template <typename T> __global__ void bilinear_fwd_kernel(const T* x, T* y, int B, int Hi, int Wi, int Ho, int Wo, int C, float sh, float sw) {
+    constexpr int EPC = Chunk<T>::N;
+    const int cpr = C / EPC;
+    const int64_t n = (int64_t)B * Ho * Wo * cpr;
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % cpr) * EPC;
+        const int xo = (int)((i / cpr) % Wo), yo = (int)((i / cpr / Wo) % Ho), b = (int)(i / cpr / Wo / Ho);
+        int y0, y1, x0, x1; float ly, lx;
+        bl_coord(yo, sh, Hi, y0, y1, ly);
+        bl_coord(xo, sw, Wi, x0, x1, lx);
+        const T* base = x + (int64_t)b * Hi * Wi * C + c;
+        float f00[EPC], f01[EPC], f10[EPC], f11[EPC], o[EPC];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(base + ((int64_t)y0 * Wi + x0) * C), f00);
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(base + ((int64_t)y0 * Wi + x1) * C), f01);
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(base + ((int64_t)y1 * Wi + x0) * C), f10);
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(base + ((int64_t)y1 * Wi + x1) * C), f11);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+            o[e] = (1.f - ly) * ((1.f - lx) * f00[e] + lx * f01[e]) + ly * ((1.f - lx) * f10[e] + lx * f11[e]);
+        *reinterpret_cast<uint4*>(y + i * EPC) = f_to_chunk<T>(o);
+    }
+}
+// gather form of the transpose: every input pixel sums the output pixels that sampled it (deterministic, no atomics)
+__device__ __forceinline__ void bl_range(int i, float scale, int n_in, int n_out, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = n_out - 1; return; }
+    lo = max(0, (int)floorf((float)(i - 1) / scale) - 1);
+    hi = min(n_out - 1, (int)ceilf((float)(i + 1) / scale) + 1);
+}
+template <typename T> __global__ void bilinear_bwd_kernel(const T* dy, T* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, float sh, float sw) {
+    constexpr int EPC = Chunk<T>::N;
+    const int cpr = C / EPC;
+    const int64_t n = (int64_t)B * Hi * Wi * cpr;
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % cpr) * EPC;
+        const int xi = (int)((i / cpr) % Wi), yi = (int)((i / cpr / Wi) % Hi), b = (int)(i / cpr / Wi / Hi);
+        int ylo, yhi, xlo, xhi;
+        bl_range(yi, sh, Hi, Ho, ylo, yhi);
+        bl_range(xi, sw, Wi, Wo, xlo, xhi);
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        for (int yo = ylo; yo <= yhi; ++yo) {
+            int y0, y1; float ly;
+            bl_coord(yo, sh, Hi, y0, y1, ly);
+            const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int xo = xlo; xo <= xhi; ++xo) {
+                int x0, x1; float lx;
+                bl_coord(xo, sw, Wi, x0, x1, lx);
+                const float wx = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
+                if (wx == 0.f) continue;
+                float g[EPC];
+                chunk_to_f<T>(*reinterpret_cast<const uint4*>(dy + (((int64_t)b * Ho + yo) * Wo + xo) * C + c), g);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] += wy * wx * g[e];
+            }
+        }
+        *reinterpret_cast<uint4*>(dx + i * EPC) = f_to_chunk<T>(acc);
+    }
+}
+// logits: NHWC [B,Hi,Wi,2] (T) -> NCHW fp32 [B,2,Ho,Wo]
+template <typename T> __global__ void logits_up_fwd_kernel(const T* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, float sh, float sw) {
+    const int64_t n = (int64_t)B * Ho * Wo;
+    GRID_STRIDE(i, n) {
+        const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho), b = (int)(i / Wo / Ho);
+        int y0, y1, x0, x1; float ly, lx;
+        bl_coord(yo, sh, Hi, y0, y1, ly);
+        bl_coord(xo, sw, Wi, x0, x1, lx);
+        const T* base = x + (int64_t)b * Hi * Wi * 2;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float f00 = to_f<T>(base[((int64_t)y0 * Wi + x0) * 2 + c]), f01 = to_f<T>(base[((int64_t)y0 * Wi + x1) * 2 + c]);
+            const float f10 = to_f<T>(base[((int64_t)y1 * Wi + x0) * 2 + c]), f11 = to_f<T>(base[((int64_t)y1 * Wi + x1) * 2 + c]);
+            y[(((int64_t)b * 2 + c) * Ho + yo) * Wo + xo] = (1.f - ly) * ((1.f - lx) * f00 + lx * f01) + ly * ((1.f - lx) * f10 + lx * f11);
+        }
+    }
+}
+template <typename T> __global__ void logits_up_bwd_kernel(const float* dy, T* dx, int B, int Hi, int Wi, int Ho, int Wo, float sh, float sw) {
+    const int64_t n = (int64_t)B * Hi * Wi;
+    GRID_STRIDE(i, n) {
+        const int xi = (int)(i % Wi), yi = (int)((i / Wi) % Hi), b = (int)(i / Wi / Hi);
+        int ylo, yhi, xlo, xhi;
+        bl_range(yi, sh, Hi, Ho, ylo, yhi);
+        bl_range(xi, sw, Wi, Wo, xlo, xhi);
+        float a0 = 0.f, a1 = 0.f;
+        for (int yo = ylo; yo <= yhi; ++yo) {
+            int y0, y1; float ly;
+            bl_coord(yo, sh, Hi, y0, y1, ly);
+            const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int xo = xlo; xo <= xhi; ++xo) {
+                int x0, x1; float lx;
+                bl_coord(xo, sw, Wi, x0, x1, lx);
+                const float wx = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
+                if (wx == 0.f) continue;
+                a0 += wy * wx * dy[(((int64_t)b * 2 + 0) * Ho + yo) * Wo + xo];
+                a1 += wy * wx * dy[(((int64_t)b * 2 + 1) * Ho + yo) * Wo + xo];
+            }
+        }
+        dx[i * 2] = from_f<T>(a0);
+        dx[i * 2 + 1] = from_f<T>(a1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- classifier head (hidden -> 2)
+template <typename T> __global__ __launch_bounds__(256) void cls_head_fwd_kernel(const T* x, const float* w, const float* bias, T* y, int64_t rows, int C) {
+    constexpr int EPC = Chunk<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int nchunk = C / EPC;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int ch = lane; ch < nchunk; ch += 64) {
+            float f[EPC];
+            chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + row * C + ch * EPC), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { a0 = fmaf(f[e], w[ch * EPC + e], a0); a1 = fmaf(f[e], w[C + ch * EPC + e], a1); }
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1);
+        if (lane == 0) { y[row * 2] = from_f<T>(a0 + bias[0]); y[row * 2 + 1] = from_f<T>(a1 + bias[1]); }
+    }
+}
+template <typename T> __global__ __launch_bounds__(256) void cls_head_bwd_kernel(const T* x, const T* dy, const float* w, T* dx, float* dw, float* db, int64_t rows, int C) {
+    // thread owns one chunk column for a strip of rows: dx = dy0*w0 + dy1*w1 ; dw[c] += dy[c]*x ; db += dy
+    constexpr int EPC = Chunk<T>::N;
+    const int cpr = C / EPC;
+    const int tc = threadIdx.x % cpr, tr = threadIdx.x / cpr, rstep = blockDim.x / cpr;
+    if (tr >= rstep) return;
+    float w0[EPC], w1[EPC], g0[EPC], g1[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { w0[e] = w[tc * EPC + e]; w1[e] = w[C + tc * EPC + e]; g0[e] = 0.f; g1[e] = 0.f; }
+    float b0 = 0.f, b1 = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * rstep + tr; row < rows; row += (int64_t)gridDim.x * rstep) {
+        const float d0 = to_f<T>(dy[row * 2]), d1 = to_f<T>(dy[row * 2 + 1]);
+        float f[EPC], o[EPC];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + row * C + tc * EPC), f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { o[e] = d0 * w0[e] + d1 * w1[e]; g0[e] += d0 * f[e]; g1[e] += d1 * f[e]; }
+        *reinterpret_cast<uint4*>(dx + row * C + tc * EPC) = f_to_chunk<T>(o);
+        if (tc == 0) { b0 += d0; b1 += d1; }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { atomicAdd(dw + tc * EPC + e, g0[e]); atomicAdd(dw + C + tc * EPC + e, g1[e]); }
+    if (tc == 0) { atomicAdd(db, b0); atomicAdd(db + 1, b1); }
+}
+
+// ---------------------------------------------------------------------------------------------- patch-embed im2col (4x4 / stride 4)
+// cols[(b*H4+py)*W4+px][c*16 + ky*4 + kx] = img[b][c][4py+ky][4px+kx]   (zero beyond H,W); matches Conv2d weight.view(Cout, 48)
+template <typename T> __global__ void im2col4_kernel(const float* img, T* cols, int B, int H, int W, int H4, int W4) {
+    const int64_t n = (int64_t)B * H4 * W4 * 12;      // 12 = 3 channels * 4 kernel rows; each item = 4 contiguous pixels
+    GRID_STRIDE(i, n) {
+        const int ky = (int)(i % 4), c = (int)((i / 4) % 3);
+        const int64_t pix = i / 12;
+        const int px = (int)(pix % W4), py = (int)((pix / W4) % H4), b = (int)(pix / W4 / H4);
+        const int y = 4 * py + ky;
+        T* dst = cols + pix * 48 + c * 16 + ky * 4;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int x = 4 * px + kx;
+            dst[kx] = from_f<T>((y < H && x < W) ? img[(((int64_t)b * 3 + c) * H + y) * W + x] : 0.f);
+        }
+    }
+}
+template <typename T> __global__ void col2im4_kernel(const T* dcols, float* dimg, int B, int H, int W, int H4, int W4) {
+    const int64_t n = (int64_t)B * 3 * H * W;
+    GRID_STRIDE(i, n) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), c = (int)((i / W / H) % 3), b = (int)(i / W / H / 3);
+        const int64_t pix = ((int64_t)b * H4 + y / 4) * W4 + x / 4;
+        dimg[i] = to_f<T>(dcols[pix * 48 + c * 16 + (y % 4) * 4 + (x % 4)]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- casts / layout
+template <typename S, typename D> __global__ void cast_kernel(const S* src, D* dst, int64_t n) {
+    GRID_STRIDE(i, n) dst[i] = from_f<D>(to_f<S>(src[i]));
+}
+// [B][C][HW] <-> [B][HW][C] through a 32x33 LDS tile
+template <typename S, typename D> __global__ void transpose_kernel(const S* src, D* dst, int R, int Cc) {
+    // src: [batch][R][Cc] -> dst: [batch][Cc][R]
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const S* s = src + (int64_t)b * R * Cc;
+    D* d = dst + (int64_t)b * R * Cc;
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + threadIdx.x;
+        if (r < R && c < Cc) tile[k][threadIdx.x] = to_f<S>(s[(int64_t)r * Cc + c]);
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + threadIdx.x;
+        if (r < R && c < Cc) d[(int64_t)c * R + r] = from_f<D>(tile[threadIdx.x][k]);
+    }
+}
+template <typename T> __global__ void pack_conv3x3_kernel(const float* w, T* packed, int Cout, int Cin) {
+    const int64_t n = (int64_t)Cout * 9 * Cin;
+    GRID_STRIDE(i, n) {
+        const int ci = (int)(i % Cin), tap = (int)((i / Cin) % 9), co = (int)(i / Cin / 9);
+        packed[i] = from_f<T>(w[((int64_t)co * Cin + ci) * 9 + tap]);
+    }
+}
+template <typename D> __global__ void cast_multi_kernel(const int64_t* desc, int count) {
+    // blockIdx.y = tensor; grid-stride over its elements
+    const int t = blockIdx.y;
+    if (t >= count) return;
+    const float* src = reinterpret_cast<const float*>(desc[3 * t]);
+    D* dst = reinterpret_cast<D*>(desc[3 * t + 1]);
+    const int64_t n = desc[3 * t + 2];
+    GRID_STRIDE(i, n) dst[i] = from_f<D>(src[i]);
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, NAME, ...)                                   \
+    if (dtype == LAVT_F32) { using T = float; __VA_ARGS__; }           \
+    else if (dtype == LAVT_BF16) { using T = bf16; __VA_ARGS__; }      \
+    else { lavt_set_error(NAME ": bad dtype %d", dtype); return LAVT_ERR_INVALID; }
+#define ST reinterpret_cast<hipStream_t>(stream)
+#define EPC_OF(dtype) ((dtype) == LAVT_F32 ? 4 : 8)
+
+extern "C" int lavt_act_bwd(int dtype, int act, const void* dy, const void* pre, void* dx, int64_t n, void* stream) {
+    LAVT_CHECK_ARG(dy && pre && dx && n > 0 && n % EPC_OF(dtype) == 0, "lavt_act_bwd: bad arguments (n=%ld)", (long)n);
+    const int64_t nc = n / EPC_OF(dtype);
+    DISPATCH_T(dtype, "lavt_act_bwd", hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(ew_grid(nc)), dim3(256), 0, ST, act, (const T*)dy, (const T*)pre, (T*)dx, nc));
+    LAVT_CHECK_LAUNCH("lavt_act_bwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_gate_fwd(int dtype, const void* x, const void* gpre, const void* r, void* xo, int64_t n, void* stream) {
+    LAVT_CHECK_ARG(x && gpre && r && xo && n > 0 && n % EPC_OF(dtype) == 0, "lavt_gate_fwd: bad arguments");
+    const int64_t nc = n / EPC_OF(dtype);
+    DISPATCH_T(dtype, "lavt_gate_fwd", hipLaunchKernelGGL(gate_fwd_kernel<T>, dim3(ew_grid(nc)), dim3(256), 0, ST, (const T*)x, (const T*)gpre, (const T*)r, (T*)xo, nc));
+    LAVT_CHECK_LAUNCH("lavt_gate_fwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_gate_bwd(int dtype, const void* dxo, const void* gpre, const void* r, void* dgpre, void* dr, int64_t n, void* stream) {
+    LAVT_CHECK_ARG(dxo && gpre && r && dgpre && dr && n > 0 && n % EPC_OF(dtype) == 0, "lavt_gate_bwd: bad arguments");
+    const int64_t nc = n / EPC_OF(dtype);
+    DISPATCH_T(dtype, "lavt_gate_bwd", hipLaunchKernelGGL(gate_bwd_kernel<T>, dim3(ew_grid(nc)), dim3(256), 0, ST, (const T*)dxo, (const T*)gpre, (const T*)r, (T*)dgpre, (T*)dr, nc));
+    LAVT_CHECK_LAUNCH("lavt_gate_bwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_rowsoftmax_fwd(int dtype, const void* s, void* p, int64_t rows, int n_l, int ld, void* stream) {
+    LAVT_CHECK_ARG(s && p && rows > 0 && n_l > 0 && n_l <= ld, "lavt_rowsoftmax_fwd: bad arguments");
+    DISPATCH_T(dtype, "lavt_rowsoftmax_fwd", hipLaunchKernelGGL(rowsoftmax_fwd_kernel<T>, dim3(ew_grid(rows)), dim3(256), 0, ST, (const T*)s, (T*)p, rows, n_l, ld));
+    LAVT_CHECK_LAUNCH("lavt_rowsoftmax_fwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_rowsoftmax_bwd(int dtype, const void* p, const void* dp, void* ds, int64_t rows, int n_l, int ld, void* stream) {
+    LAVT_CHECK_ARG(p && dp && ds && rows > 0 && n_l > 0 && n_l <= ld, "lavt_rowsoftmax_bwd: bad arguments");
+    DISPATCH_T(dtype, "lavt_rowsoftmax_bwd", hipLaunchKernelGGL(rowsoftmax_bwd_kernel<T>, dim3(ew_grid(rows)), dim3(256), 0, ST, (const T*)p, (const T*)dp, (T*)ds, rows, n_l, ld));
+    LAVT_CHECK_LAUNCH("lavt_rowsoftmax_bwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_bilinear_fwd(int dtype, const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream) {
+    LAVT_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % EPC_OF(dtype) == 0, "lavt_bilinear_fwd: bad arguments");
+    const int64_t nc = (int64_t)B * Ho * Wo * (C / EPC_OF(dtype));
+    DISPATCH_T(dtype, "lavt_bilinear_fwd", hipLaunchKernelGGL(bilinear_fwd_kernel<T>, dim3(ew_grid(nc)), dim3(256), 0, ST, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
+    LAVT_CHECK_LAUNCH("lavt_bilinear_fwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream) {
+    LAVT_CHECK_ARG(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % EPC_OF(dtype) == 0, "lavt_bilinear_bwd: bad arguments");
+    const int64_t nc = (int64_t)B * Hi * Wi * (C / EPC_OF(dtype));
+    DISPATCH_T(dtype, "lavt_bilinear_bwd", hipLaunchKernelGGL(bilinear_bwd_kernel<T>, dim3(ew_grid(nc)), dim3(256), 0, ST, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
+    LAVT_CHECK_LAUNCH("lavt_bilinear_bwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_logits_up_fwd(int dtype, const void* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, void* stream) {
+    LAVT_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "lavt_logits_up_fwd: bad arguments");
+    const int64_t n = (int64_t)B * Ho * Wo;
+    DISPATCH_T(dtype, "lavt_logits_up_fwd", hipLaunchKernelGGL(logits_up_fwd_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, ST, (const T*)x, y, B, Hi, Wi, Ho, Wo, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
+    LAVT_CHECK_LAUNCH("lavt_logits_up_fwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_logits_up_bwd(int dtype, const float* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, void* stream) {
+    LAVT_CHECK_ARG(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "lavt_logits_up_bwd: bad arguments");
+    const int64_t n = (int64_t)B * Hi * Wi;
+    DISPATCH_T(dtype, "lavt_logits_up_bwd", hipLaunchKernelGGL(logits_up_bwd_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, ST, dy, (T*)dx, B, Hi, Wi, Ho, Wo, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
+    LAVT_CHECK_LAUNCH("lavt_logits_up_bwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_cls_head_fwd(int dtype, const void* x, const float* w, const float* b, void* y, int64_t rows, int C, void* stream) {
+    LAVT_CHECK_ARG(x && w && b && y && rows > 0 && C % EPC_OF(dtype) == 0, "lavt_cls_head_fwd: bad arguments");
+    int blocks = cdiv(rows, 4 * 4);
+    if (blocks > 2048) blocks = 2048;
+    DISPATCH_T(dtype, "lavt_cls_head_fwd", hipLaunchKernelGGL(cls_head_fwd_kernel<T>, dim3(blocks), dim3(256), 0, ST, (const T*)x, w, b, (T*)y, rows, C));
+    LAVT_CHECK_LAUNCH("lavt_cls_head_fwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_cls_head_bwd(int dtype, const void* x, const void* dy, const float* w, void* dx, float* dw, float* db,
+                                 int64_t rows, int C, void* stream) {
+    const int cpr = C / EPC_OF(dtype);
+    LAVT_CHECK_ARG(x && dy && w && dx && dw && db && rows > 0 && C % EPC_OF(dtype) == 0 && cpr <= 256, "lavt_cls_head_bwd: bad arguments");
+    const int rstep = 256 / cpr;
+    int blocks = cdiv(rows, (long)rstep * 16);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    DISPATCH_T(dtype, "lavt_cls_head_bwd", hipLaunchKernelGGL(cls_head_bwd_kernel<T>, dim3(blocks), dim3(256), 0, ST, (const T*)x, (const T*)dy, w, (T*)dx, dw, db, rows, C));
+    LAVT_CHECK_LAUNCH("lavt_cls_head_bwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_im2col4(int dtype, const float* img, void* cols, int B, int H, int W, void* stream) {
+    LAVT_CHECK_ARG(img && cols && B > 0 && H > 0 && W > 0, "lavt_im2col4: bad arguments");
+    const int H4 = (H + 3) / 4, W4 = (W + 3) / 4;
+    const int64_t n = (int64_t)B * H4 * W4 * 12;
+    DISPATCH_T(dtype, "lavt_im2col4", hipLaunchKernelGGL(im2col4_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, ST, img, (T*)cols, B, H, W, H4, W4));
+    LAVT_CHECK_LAUNCH("lavt_im2col4");
+    return LAVT_OK;
+}
+extern "C" int lavt_col2im4(int dtype, const void* dcols, float* dimg, int B, int H, int W, void* stream) {
+    LAVT_CHECK_ARG(dcols && dimg && B > 0 && H > 0 && W > 0, "lavt_col2im4: bad arguments");
+    const int H4 = (H + 3) / 4, W4 = (W + 3) / 4;
+    const int64_t n = (int64_t)B * 3 * H * W;
+    DISPATCH_T(dtype, "lavt_col2im4", hipLaunchKernelGGL(col2im4_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, ST, (const T*)dcols, dimg, B, H, W, H4, W4));
+    LAVT_CHECK_LAUNCH("lavt_col2im4");
+    return LAVT_OK;
+}
+
+template <typename S> static int cast_from(const void* src, int dst_dtype, void* dst, int64_t n, hipStream_t st) {
+    if (dst_dtype == LAVT_F32) hipLaunchKernelGGL((cast_kernel<S, float>), dim3(ew_grid(n)), dim3(256), 0, st, (const S*)src, (float*)dst, n);
+    else hipLaunchKernelGGL((cast_kernel<S, bf16>), dim3(ew_grid(n)), dim3(256), 0, st, (const S*)src, (bf16*)dst, n);
+    return 0;
+}
+extern "C" int lavt_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream) {
+    LAVT_CHECK_ARG(src && dst && n > 0 && (src_dtype | 1) == 1 && (dst_dtype | 1) == 1, "lavt_cast: bad arguments");
+    if (src_dtype == LAVT_F32) cast_from<float>(src, dst_dtype, dst, n, ST); else cast_from<bf16>(src, dst_dtype, dst, n, ST);
+    LAVT_CHECK_LAUNCH("lavt_cast");
+    return LAVT_OK;
+}
+template <typename S> static void transpose_from(const void* src, int dst_dtype, void* dst, int batch, int R, int Cc, hipStream_t st) {
+    dim3 grid(cdiv(Cc, 32), cdiv(R, 32), batch), block(32, 8);
+    if (dst_dtype == LAVT_F32) hipLaunchKernelGGL((transpose_kernel<S, float>), grid, block, 0, st, (const S*)src, (float*)dst, R, Cc);
+    else hipLaunchKernelGGL((transpose_kernel<S, bf16>), grid, block, 0, st, (const S*)src, (bf16*)dst, R, Cc);
+}
+extern "C" int lavt_nchw_to_nhwc(int src_dtype, const void* src, int dst_dtype, void* dst, int B, int C, int HW, void* stream) {
+    LAVT_CHECK_ARG(src && dst && B > 0 && C > 0 && HW > 0 && (src_dtype | 1) == 1 && (dst_dtype | 1) == 1, "lavt_nchw_to_nhwc: bad arguments");
+    if (src_dtype == LAVT_F32) transpose_from<float>(src, dst_dtype, dst, B, C, HW, ST); else transpose_from<bf16>(src, dst_dtype, dst, B, C, HW, ST);
+    LAVT_CHECK_LAUNCH("lavt_nchw_to_nhwc");
+    return LAVT_OK;
+}
+extern "C" int lavt_nhwc_to_nchw(int src_dtype, const void* src, int dst_dtype, void* dst, int B, int C, int HW, void* stream) {
+    LAVT_CHECK_ARG(src && dst && B > 0 && C > 0 && HW > 0 && (src_dtype | 1) == 1 && (dst_dtype | 1) == 1, "lavt_nhwc_to_nchw: bad arguments");
+    if (src_dtype == LAVT_F32) transpose_from<float>(src, dst_dtype, dst, B, HW, C, ST); else transpose_from<bf16>(src, dst_dtype, dst, B, HW, C, ST);
+    LAVT_CHECK_LAUNCH("lavt_nhwc_to_nchw");
+    return LAVT_OK;
+}
+extern "C" int lavt_pack_conv3x3(const float* w, int dtype, void* packed, int Cout, int Cin, void* stream) {
+    LAVT_CHECK_ARG(w && packed && Cout > 0 && Cin > 0, "lavt_pack_conv3x3: bad arguments");
+    const int64_t n = (int64_t)Cout * Cin * 9;
+    DISPATCH_T(dtype, "lavt_pack_conv3x3", hipLaunchKernelGGL(pack_conv3x3_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, ST, w, (T*)packed, Cout, Cin));
+    LAVT_CHECK_LAUNCH("lavt_pack_conv3x3");
+    return LAVT_OK;
+}
+extern "C" int lavt_cast_multi(const int64_t* desc, int count, int dst_dtype, void* stream) {
+    LAVT_CHECK_ARG(desc && count > 0 && (dst_dtype | 1) == 1, "lavt_cast_multi: bad arguments");
+    dim3 grid(64, count);
+    if (dst_dtype == LAVT_F32) hipLaunchKernelGGL(cast_multi_kernel<float>, grid, dim3(256), 0, ST, desc, count);
+    else hipLaunchKernelGGL(cast_multi_kernel<bf16>, grid, dim3(256), 0, ST, desc, count);
+    LAVT_CHECK_LAUNCH("lavt_cast_multi");
+    return LAVT_OK;
+}

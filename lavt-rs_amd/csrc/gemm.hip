@@ -1,0 +1,495 @@
+// Gather-GEMM kernels for gfx950 (MI355X): every Linear / 1x1 conv / 3x3 conv of the LAVT hot path,
+// forward, data gradient (NT family) and weight gradient (TN family).  See include/lavt_hip.h.
+//
+// Structure (both families): 256-thread workgroup = 4 waves in a 2x2 arrangement over a BMxBN output tile,
+// each wave owning (BM/2)x(BN/2) as 16x16 MFMA accumulators.  Operand tiles are staged
+// global -> registers -> LDS with one barrier per K tile (loads for tile t+1 are issued before the MFMAs of
+// tile t and written to the other LDS buffer after them), so HBM latency hides under the matrix work.
+//   bf16: v_mfma_f32_16x16x32_bf16, K tile 64 (128-byte LDS rows, XOR-swizzled 16-byte chunks -> conflict-free
+//         ds_read_b128 fragment reads); operands whose reduction index is the slow memory index ("k-major":
+//         x @ W data gradients and all weight gradients) are staged untransposed and read with the hardware
+//         transposing LDS read ds_read_b64_tr_b16.
+//   fp32: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) -- the parity path.
+// Row gather on the A side (window partition / shift / zero padding, 3x3 taps with zero halo, concat of two
+// sources) and row scatter + residual on the C side are folded into the tile loads / stores: no im2col,
+// no permute/roll/pad/cat copies ever touch HBM.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Cfg;
+template <> struct Cfg<bf16> { static constexpr int BK = 64, KSTEP = 32, EPC = 8, KC_LD = 64; };
+template <> struct Cfg<float> { static constexpr int BK = 16, KSTEP = 4, EPC = 4, KC_LD = 20; };
+constexpr int KM_PAD = 16;
+
+// ---- LDS addressing -----------------------------------------------------------------------------
+// "KC" tile: [rows][BK], k contiguous.  bf16 rows are 128 B = 8 chunks, chunk index XOR (row & 7).
+template <typename T> __device__ __forceinline__ int kc_off(int row, int chunk) {
+    if constexpr (std::is_same<T, bf16>::value) return row * 64 + ((chunk ^ (row & 7)) << 3);
+    else return row * 20 + (chunk << 2);
+}
+
+template <typename T> struct FragT;
+template <> struct FragT<bf16> { typedef bf16x8 type; };
+template <> struct FragT<float> { typedef float type; };
+
+// fragment of a KC tile: 16 rows starting at `row0`, k-step ks
+template <typename T> __device__ __forceinline__ typename FragT<T>::type frag_kc(const T* s, int row0, int ks, int lane) {
+    const int row = row0 + (lane & 15);
+    if constexpr (std::is_same<T, bf16>::value) return *reinterpret_cast<const bf16x8*>(s + kc_off<bf16>(row, ks * 4 + (lane >> 4)));
+    else return s[row * 20 + ks * 4 + (lane >> 4)];
+}
+// fragment of a "KM" tile stored [k][ld] (k-major): 16 columns starting at col0, k-step ks
+template <typename T> __device__ __forceinline__ typename FragT<T>::type frag_km(const T* s, int ld, int col0, int ks, int lane) {
+    if constexpr (std::is_same<T, bf16>::value) {
+        const int k = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2);
+        const bf16* p = s + k * ld + col0 + 4 * (lane & 3);
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * ld));
+        bf16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    } else {
+        return s[(ks * 4 + (lane >> 4)) * ld + col0 + (lane & 15)];
+    }
+}
+template <typename T> __device__ __forceinline__ f32x4 mfma16(typename FragT<T>::type a, typename FragT<T>::type b, f32x4 c) {
+    if constexpr (std::is_same<T, bf16>::value) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 zero16() { return make_uint4(0, 0, 0, 0); }
+
+__device__ __forceinline__ float apply_act(int act, float v) {
+    switch (act) {
+        case LAVT_ACT_GELU: return gelu_f(v);
+        case LAVT_ACT_RELU: return fmaxf(v, 0.f);
+        case LAVT_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+// ================================================================================================
+//                                           NT family
+// ================================================================================================
+template <typename T, int BM, int BN, bool BKM>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const lavt_gemm_nt_t p) {
+    constexpr int BK = Cfg<T>::BK, EPC = Cfg<T>::EPC, KSTEPS = BK / Cfg<T>::KSTEP;
+    constexpr int CPR = BK / EPC;               // 16-byte chunks per k-row
+    constexpr int A_RPP = 256 / CPR, A_PASSES = BM / A_RPP;
+    constexpr int BKC_PASSES = BN / A_RPP;
+    constexpr int BKM_CPR = BN / EPC, BKM_RPP = 256 / BKM_CPR, BKM_PASSES = BK / BKM_RPP;
+    constexpr int B_PASSES = BKM ? BKM_PASSES : BKC_PASSES;
+    constexpr int A_TILE = BM * Cfg<T>::KC_LD;
+    constexpr int B_LD = BN + KM_PAD;
+    constexpr int B_TILE = BKM ? BK * B_LD : BN * Cfg<T>::KC_LD;
+    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+    static_assert(A_PASSES >= 1 && B_PASSES >= 1, "tile too small for 256 threads");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    T* sA[2] = {smem, smem + A_TILE + B_TILE};
+    T* sB[2] = {smem + A_TILE, smem + 2 * A_TILE + B_TILE};
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int bz = blockIdx.y;
+
+    const T* A = reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.strideA;
+    const T* A2 = reinterpret_cast<const T*>(p.A2);
+    const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.strideB;
+    const bool conv = p.conv_kc > 0;
+    const int HW = p.conv_h * p.conv_w;
+
+    // ---- per-thread A rows -------------------------------------------------------------------
+    const int a_chunk = tid % CPR, a_row0 = tid / CPR;
+    int a_src[A_PASSES];          // source row (plain / mapped), -1 = zeros
+    short a_y[A_PASSES], a_x[A_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        const int m = m0 + a_row0 + i * A_RPP;
+        int src = -1;
+        if (m < p.M) src = p.a_rowmap ? p.a_rowmap[m] : m;
+        a_src[i] = src;
+        if (conv && src >= 0) {
+            const int pix = src % HW;
+            a_y[i] = (short)(pix / p.conv_w);
+            a_x[i] = (short)(pix % p.conv_w);
+        } else { a_y[i] = 0; a_x[i] = 0; }
+    }
+    const int b_chunk = BKM ? tid % BKM_CPR : a_chunk;
+    const int b_row0 = BKM ? tid / BKM_CPR : a_row0;
+
+    uint4 ra[A_PASSES], rb[B_PASSES];
+
+    auto load_tiles = [&](int kt) {
+        // A
+        const int k = kt * BK + a_chunk * EPC;
+        int tap = 0, kin = k, dy = 0, dx = 0;
+        if (conv) {
+            tap = k / p.conv_kc; kin = k - tap * p.conv_kc;
+            dy = tap / 3 - 1; dx = tap % 3 - 1;
+            if (p.conv_flip) { dy = -dy; dx = -dx; }
+        }
+        const bool second = (p.A2 != nullptr) && kin >= p.a_split;
+        const T* base = second ? A2 : A;
+        const int64_t ld = second ? p.lda2 : p.lda;
+        const int kk = second ? kin - p.a_split : kin;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            int src = a_src[i];
+            if (conv && src >= 0) {
+                const int y = a_y[i] + dy, x = a_x[i] + dx;
+                src = (y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) ? src + dy * p.conv_w + dx : -1;
+            }
+            ra[i] = (src >= 0 && k < p.K) ? ldg16(base + (int64_t)src * ld + kk) : zero16();
+        }
+        // B
+        if constexpr (!BKM) {
+#pragma unroll
+            for (int i = 0; i < B_PASSES; ++i) {
+                const int n = n0 + b_row0 + i * A_RPP;
+                rb[i] = (n < p.N && k < p.K) ? ldg16(B + (int64_t)n * p.ldb + k) : zero16();
+            }
+        } else {
+            const int n = n0 + b_chunk * EPC;
+#pragma unroll
+            for (int i = 0; i < B_PASSES; ++i) {
+                const int kb = kt * BK + b_row0 + i * BKM_RPP;
+                int64_t off;
+                if (conv) { const int t2 = kb / p.conv_kc; off = (int64_t)(kb - t2 * p.conv_kc) * p.ldb + (int64_t)t2 * p.b_tap_stride; }
+                else off = (int64_t)kb * p.ldb;
+                rb[i] = (kb < p.K && n < p.N) ? ldg16(B + off + n) : zero16();
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i)
+            *reinterpret_cast<uint4*>(sA[buf] + kc_off<T>(a_row0 + i * A_RPP, a_chunk)) = ra[i];
+        if constexpr (!BKM) {
+#pragma unroll
+            for (int i = 0; i < B_PASSES; ++i)
+                *reinterpret_cast<uint4*>(sB[buf] + kc_off<T>(b_row0 + i * A_RPP, b_chunk)) = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_PASSES; ++i)
+                *reinterpret_cast<uint4*>(sB[buf] + (b_row0 + i * BKM_RPP) * B_LD + b_chunk * EPC) = rb[i];
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ktiles = (p.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ktiles) load_tiles(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            typename FragT<T>::type fa[MI], fb[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = frag_kc<T>(sA[cur], wm * WM + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                if constexpr (BKM) fb[j] = frag_km<T>(sB[cur], B_LD, wn * WN + j * 16, ks, lane);
+                else fb[j] = frag_kc<T>(sB[cur], wn * WN + j * 16, ks, lane);
+            }
+            // swapped operands: accumulator rows = n (4 consecutive per lane), columns = m
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = mfma16<T>(fb[j], fa[i], acc[i][j]);
+        }
+        if (kt + 1 < ktiles) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
+    const float* rscale = p.row_scale ? p.row_scale + (int64_t)bz * p.strideRowScale : nullptr;
+    const int64_t c_off = (int64_t)bz * p.strideC;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * WM + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int orow = p.c_rowmap ? p.c_rowmap[m] : m;
+        if (orow < 0) continue;
+        const float rs = rscale ? rscale[p.row_scale_div > 1 ? m / p.row_scale_div : m] : 1.f;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * WN + j * 16 + 4 * (lane >> 4);
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = p.alpha * acc[i][j][r];
+                if (bias && n + r < p.N) v[r] += bias[n + r];
+                v[r] *= rs;
+            }
+            const bool full = (n + 3 < p.N);
+            if (p.Cpre) {
+                T* cp = reinterpret_cast<T*>(p.Cpre) + (int64_t)orow * p.ldcpre + n;
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = from_f<T>(v[r]);
+            }
+            if (p.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
+            }
+            if (p.R) {
+                const T* rp = reinterpret_cast<const T*>(p.R) + (int64_t)orow * p.ldr + n;
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += to_f<T>(rp[r]);
+            }
+            const bool second = p.C2 != nullptr && n >= p.c_split;
+            const int64_t ldc = second ? p.ldc2 : p.ldc;
+            const int nn = second ? n - p.c_split : n;
+            if (p.c_f32) {
+                float* cp = reinterpret_cast<float*>(second ? p.C2 : p.C) + c_off + (int64_t)orow * ldc + nn;
+                if (full) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                else for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = v[r];
+            } else {
+                T* cp = reinterpret_cast<T*>(second ? p.C2 : p.C) + c_off + (int64_t)orow * ldc + nn;
+                if (full) {
+                    if constexpr (std::is_same<T, float>::value) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                    else *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                } else for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = from_f<T>(v[r]);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, bool BKM> int launch_nt(const lavt_gemm_nt_t& p, hipStream_t st) {
+    constexpr int BK = Cfg<T>::BK;
+    constexpr int A_TILE = BM * Cfg<T>::KC_LD;
+    constexpr int B_TILE = BKM ? BK * (BN + KM_PAD) : BN * Cfg<T>::KC_LD;
+    const size_t lds = 2 * (size_t)(A_TILE + B_TILE) * sizeof(T);
+    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, BKM>), grid, dim3(256), lds, st, p);
+    LAVT_CHECK_LAUNCH("lavt_gemm_nt");
+    return LAVT_OK;
+}
+template <typename T> int dispatch_nt(const lavt_gemm_nt_t& p, hipStream_t st) {
+    const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
+    const bool big = tiles128 >= 192 && p.N > 64;
+    if (p.b_kmajor) return big ? launch_nt<T, 128, 128, true>(p, st) : launch_nt<T, 64, 64, true>(p, st);
+    return big ? launch_nt<T, 128, 128, false>(p, st) : launch_nt<T, 64, 64, false>(p, st);
+}
+
+// ================================================================================================
+//                                           TN family
+// ================================================================================================
+template <typename T, int BI, int BJ>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const lavt_gemm_tn_t p, int kt_per_split) {
+    constexpr int BK = Cfg<T>::BK, EPC = Cfg<T>::EPC, KSTEPS = BK / Cfg<T>::KSTEP;
+    constexpr int A_LD = BI + KM_PAD, B_LD = BJ + KM_PAD;
+    constexpr int A_CPR = BI / EPC, A_RPP = 256 / A_CPR, A_PASSES = BK / A_RPP;
+    constexpr int B_CPR = BJ / EPC, B_RPP = 256 / B_CPR, B_PASSES = BK / B_RPP;
+    constexpr int A_TILE = BK * A_LD, B_TILE = BK * B_LD;
+    constexpr int WI = BI / 2, WJ = BJ / 2, II = WI / 16, JJ = WJ / 16;
+    static_assert(A_PASSES >= 1 && B_PASSES >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    T* sA[2] = {smem, smem + A_TILE + B_TILE};
+    T* sB[2] = {smem + A_TILE, smem + 2 * A_TILE + B_TILE};
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int tiles_j = (p.J + BJ - 1) / BJ;
+    const int tile_i = blockIdx.x / tiles_j, tile_j = blockIdx.x % tiles_j;
+    const int i0 = tile_i * BI, j0 = tile_j * BJ;
+    const int bz = blockIdx.y;
+    const int ktiles = (p.K + BK - 1) / BK;
+    const int kt_begin = blockIdx.z * kt_per_split;
+    const int kt_end = min(ktiles, kt_begin + kt_per_split);
+    if (kt_begin >= kt_end) return;
+
+    const T* A = reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.strideA;
+    const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.strideB;
+    const T* B2 = reinterpret_cast<const T*>(p.B2);
+    const bool conv = p.conv_kc > 0;
+
+    const int a_chunk = tid % A_CPR, a_row0 = tid / A_CPR;
+    const int b_chunk = tid % B_CPR, b_row0 = tid / B_CPR;
+    const int ia = i0 + a_chunk * EPC;          // first column of this thread's A chunk
+    const int jb = j0 + b_chunk * EPC;
+    // column-dependent B source (conv tap, concat split) is fixed per thread
+    int tap = 0, jc = jb, dy = 0, dx = 0;
+    if (conv) { tap = jb / p.conv_kc; jc = jb - tap * p.conv_kc; dy = tap / 3 - 1; dx = tap % 3 - 1; }
+    const bool b_second = (p.B2 != nullptr) && jc >= p.b_split;
+    const T* Bsrc = b_second ? B2 : B;
+    const int64_t ldb = b_second ? p.ldb2 : p.ldb;
+    const int jcc = b_second ? jc - p.b_split : jc;
+
+    uint4 ra[A_PASSES], rb[B_PASSES];
+    auto load_tiles = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            const int k = kt * BK + a_row0 + i * A_RPP;
+            int src = -1;
+            if (k < p.K) src = p.a_rowmap ? p.a_rowmap[k] : k;
+            ra[i] = (src >= 0 && ia < p.I) ? ldg16(A + (int64_t)src * p.lda + ia) : zero16();
+            if (p.a_rowscale && src >= 0) {
+                const float sc = p.a_rowscale[p.a_rowscale_div > 1 ? k / p.a_rowscale_div : k];
+                float f[EPC];
+                chunk_to_f<T>(ra[i], f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) f[e] *= sc;
+                ra[i] = f_to_chunk<T>(f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) {
+            const int k = kt * BK + b_row0 + i * B_RPP;
+            int src = -1;
+            if (k < p.K) {
+                src = p.b_rowmap ? p.b_rowmap[k] : k;
+                if (conv && src >= 0) {
+                    const int pix = src % (p.conv_h * p.conv_w);
+                    const int y = pix / p.conv_w + dy, x = pix % p.conv_w + dx;
+                    src = (y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) ? src + dy * p.conv_w + dx : -1;
+                }
+            }
+            rb[i] = (src >= 0 && jb < p.J) ? ldg16(Bsrc + (int64_t)src * ldb + jcc) : zero16();
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i)
+            *reinterpret_cast<uint4*>(sA[buf] + (a_row0 + i * A_RPP) * A_LD + a_chunk * EPC) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i)
+            *reinterpret_cast<uint4*>(sB[buf] + (b_row0 + i * B_RPP) * B_LD + b_chunk * EPC) = rb[i];
+    };
+
+    f32x4 acc[II][JJ];
+#pragma unroll
+    for (int i = 0; i < II; ++i)
+#pragma unroll
+        for (int j = 0; j < JJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
+    const bool do_colsum = (p.colsum != nullptr) && tile_j == 0 && tid < BI;
+
+    load_tiles(kt_begin);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) load_tiles(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            typename FragT<T>::type fa[II], fb[JJ];
+#pragma unroll
+            for (int i = 0; i < II; ++i) fa[i] = frag_km<T>(sA[cur], A_LD, wi * WI + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < JJ; ++j) fb[j] = frag_km<T>(sB[cur], B_LD, wj * WJ + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < II; ++i)
+#pragma unroll
+                for (int j = 0; j < JJ; ++j) acc[i][j] = mfma16<T>(fa[i], fb[j], acc[i][j]);
+        }
+        if (do_colsum) {
+            const T* col = sA[cur] + tid;
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) csum += to_f<T>(col[k * A_LD]);
+        }
+        if (kt + 1 < kt_end) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* C = p.C + (int64_t)bz * p.strideC;
+#pragma unroll
+    for (int i = 0; i < II; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ii = i0 + wi * WI + i * 16 + 4 * (lane >> 4) + r;
+            if (ii >= p.I) continue;
+#pragma unroll
+            for (int j = 0; j < JJ; ++j) {
+                const int jj = j0 + wj * WJ + j * 16 + (lane & 15);
+                if (jj >= p.J) continue;
+                int64_t col = jj;
+                if (p.c_conv_permute) { const int t2 = jj / p.conv_kc; col = (int64_t)(jj - t2 * p.conv_kc) * 9 + t2; }
+                atomicAdd(C + (int64_t)ii * p.ldc + col, p.alpha * acc[i][j][r]);
+            }
+        }
+    }
+    if (do_colsum && i0 + tid < p.I) atomicAdd(p.colsum + (int64_t)bz * p.strideColsum + i0 + tid, csum);
+}
+
+template <typename T, int BI, int BJ> int launch_tn(const lavt_gemm_tn_t& p, hipStream_t st) {
+    constexpr int BK = Cfg<T>::BK;
+    const size_t lds = 2 * (size_t)(BK * (BI + KM_PAD) + BK * (BJ + KM_PAD)) * sizeof(T);
+    const int tiles = cdiv(p.I, BI) * cdiv(p.J, BJ);
+    const int ktiles = cdiv(p.K, BK);
+    int split = p.split_k;
+    if (split <= 0) {
+        split = (int)(768 / ((long)tiles * p.batch));
+        if (split < 1) split = 1;
+        const int max_split = (ktiles + 3) / 4;        // at least 4 K tiles per workgroup
+        if (split > max_split) split = max_split;
+        if (split < 1) split = 1;
+    }
+    if (split > ktiles) split = ktiles;
+    const int per = cdiv(ktiles, split);
+    split = cdiv(ktiles, per);
+    dim3 grid(tiles, p.batch, split);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, BI, BJ>), grid, dim3(256), lds, st, p, per);
+    LAVT_CHECK_LAUNCH("lavt_gemm_tn");
+    return LAVT_OK;
+}
+template <typename T> int dispatch_tn(const lavt_gemm_tn_t& p, hipStream_t st) {
+    const bool big = p.I >= 128 && p.J >= 128 && (long)cdiv(p.I, 128) * cdiv(p.J, 128) * p.batch >= 16;
+    return big ? launch_tn<T, 128, 128>(p, st) : launch_tn<T, 64, 64>(p, st);
+}
+
+}  // namespace
+
+extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
+    LAVT_CHECK_ARG(pp != nullptr, "lavt_gemm_nt: null params");
+    lavt_gemm_nt_t p = *pp;
+    LAVT_CHECK_ARG(p.dtype == LAVT_F32 || p.dtype == LAVT_BF16, "lavt_gemm_nt: bad dtype %d", p.dtype);
+    const int epc = p.dtype == LAVT_F32 ? 4 : 8;
+    LAVT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.batch >= 1, "lavt_gemm_nt: bad shape M=%d N=%d K=%d batch=%d", p.M, p.N, p.K, p.batch);
+    LAVT_CHECK_ARG(p.K % epc == 0, "lavt_gemm_nt: K=%d must be a multiple of %d", p.K, epc);
+    LAVT_CHECK_ARG(p.A && p.B && p.C, "lavt_gemm_nt: null operand");
+    LAVT_CHECK_ARG(p.lda % epc == 0 && p.ldb % epc == 0, "lavt_gemm_nt: lda/ldb must be multiples of %d", epc);
+    LAVT_CHECK_ARG(p.ldc % 4 == 0, "lavt_gemm_nt: ldc must be a multiple of 4");
+    LAVT_CHECK_ARG(!p.b_kmajor || p.N % epc == 0, "lavt_gemm_nt: k-major B needs N %% %d == 0", epc);
+    LAVT_CHECK_ARG(!p.A2 || (p.a_split % epc == 0 && p.lda2 % epc == 0), "lavt_gemm_nt: bad a_split");
+    LAVT_CHECK_ARG(!p.C2 || p.c_split % 4 == 0, "lavt_gemm_nt: bad c_split");
+    if (p.conv_kc > 0) {
+        LAVT_CHECK_ARG(p.K == 9 * p.conv_kc && p.conv_kc % epc == 0 && p.conv_h > 0 && p.conv_w > 0, "lavt_gemm_nt: bad conv geometry");
+        LAVT_CHECK_ARG(p.M % (p.conv_h * p.conv_w) == 0, "lavt_gemm_nt: conv rows %d not a multiple of H*W", p.M);
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return p.dtype == LAVT_F32 ? dispatch_nt<float>(p, st) : dispatch_nt<bf16>(p, st);
+}
+
+extern "C" int lavt_gemm_tn(const lavt_gemm_tn_t* pp, void* stream) {
+    LAVT_CHECK_ARG(pp != nullptr, "lavt_gemm_tn: null params");
+    lavt_gemm_tn_t p = *pp;
+    LAVT_CHECK_ARG(p.dtype == LAVT_F32 || p.dtype == LAVT_BF16, "lavt_gemm_tn: bad dtype %d", p.dtype);
+    const int epc = p.dtype == LAVT_F32 ? 4 : 8;
+    LAVT_CHECK_ARG(p.I > 0 && p.J > 0 && p.K > 0 && p.batch >= 1, "lavt_gemm_tn: bad shape");
+    LAVT_CHECK_ARG(p.I % epc == 0 && p.J % epc == 0, "lavt_gemm_tn: I=%d, J=%d must be multiples of %d", p.I, p.J, epc);
+    LAVT_CHECK_ARG(p.A && p.B && p.C, "lavt_gemm_tn: null operand");
+    LAVT_CHECK_ARG(p.lda % epc == 0 && p.ldb % epc == 0, "lavt_gemm_tn: lda/ldb must be multiples of %d", epc);
+    LAVT_CHECK_ARG(!p.B2 || (p.b_split % epc == 0 && p.ldb2 % epc == 0), "lavt_gemm_tn: bad b_split");
+    if (p.conv_kc > 0)
+        LAVT_CHECK_ARG(p.J == 9 * p.conv_kc && p.conv_kc % epc == 0 && p.conv_h > 0 && p.conv_w > 0, "lavt_gemm_tn: bad conv geometry");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return p.dtype == LAVT_F32 ? dispatch_tn<float>(p, st) : dispatch_tn<bf16>(p, st);
+}

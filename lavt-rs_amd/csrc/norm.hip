@@ -1,0 +1,390 @@
+// LayerNorm (optionally fused with the PatchMerging 2x2 gather) and the per-channel statistics /
+// normalisation kernels behind InstanceNorm1d (PWAM) and BatchNorm2d(+ReLU) (decoder).  All HBM-bound:
+// 16-byte accesses, one wave per LayerNorm row (row kept in registers, fp32 math), wave-shuffle reductions.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXE = 32;   // floats of one row held per lane: covers C <= 2048
+
+// ---------------------------------------------------------------------------------------------- LayerNorm
+template <typename T>
+__device__ __forceinline__ const T* ln_src(const T* x, const int32_t* gather, int64_t row, int C, int col, bool& ok) {
+    if (!gather) { ok = true; return x + row * C + col; }
+    const int cq = C >> 2, q = col / cq;
+    const int src = gather[row * 4 + q];
+    ok = src >= 0;
+    return x + (int64_t)src * cq + (col - q * cq);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const int32_t* __restrict__ gather,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int rows, int C, float eps) {
+    constexpr int EPC = Chunk<T>::N, MAXC = LN_MAXE / EPC;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = C / EPC;
+    float v[LN_MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        float f[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = 0.f;
+        if (ch < nchunk) {
+            bool ok;
+            const T* src = ln_src<T>(x, gather, row, C, ch * EPC, ok);
+            if (ok) chunk_to_f<T>(*reinterpret_cast<const uint4*>(src), f);
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { v[c * EPC + e] = f[e]; s += f[e]; }
+    }
+    const float mu = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (lane + 64 * c < nchunk)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { const float d = v[c * EPC + e] - mu; q += d * d; }
+    const float rs = rsqrtf(wave_sum(q) / C + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+            float f[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] = (v[c * EPC + e] - mu) * rs * gamma[ch * EPC + e] + beta[ch * EPC + e];
+            *reinterpret_cast<uint4*>(y + row * C + ch * EPC) = f_to_chunk<T>(f);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const int32_t* __restrict__ gather, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int rows, int C) {
+    constexpr int EPC = Chunk<T>::N, MAXC = LN_MAXE / EPC;
+    const int lane = threadIdx.x & 63;
+    const int nchunk = C / EPC;
+    float dg[LN_MAXE], db[LN_MAXE];
+#pragma unroll
+    for (int e = 0; e < LN_MAXE; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[LN_MAXE], g[LN_MAXE];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            float fx[EPC], fg[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { fx[e] = 0.f; fg[e] = 0.f; }
+            if (ch < nchunk) {
+                bool ok;
+                const T* src = ln_src<T>(x, gather, row, C, ch * EPC, ok);
+                if (ok) chunk_to_f<T>(*reinterpret_cast<const uint4*>(src), fx);
+                chunk_to_f<T>(*reinterpret_cast<const uint4*>(dy + row * C + ch * EPC), fg);
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int k = c * EPC + e;
+                const bool live = ch < nchunk;
+                xh[k] = live ? (fx[e] - mu) * rs : 0.f;
+                const float gg = live ? fg[e] * gamma[ch * EPC + e] : 0.f;
+                g[k] = gg;
+                s1 += gg; s2 += gg * xh[k];
+                dg[k] += fg[e] * xh[k];
+                db[k] += fg[e];
+            }
+        }
+        s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunk) {
+                float f[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) f[e] = rs * (g[c * EPC + e] - s1 - xh[c * EPC + e] * s2);
+                if (!gather) *reinterpret_cast<uint4*>(dx + row * C + ch * EPC) = f_to_chunk<T>(f);
+                else {
+                    const int cq = C >> 2, col = ch * EPC, qd = col / cq;
+                    const int src = gather[row * 4 + qd];
+                    if (src >= 0) *reinterpret_cast<uint4*>(dx + (int64_t)src * cq + (col - qd * cq)) = f_to_chunk<T>(f);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { atomicAdd(dgamma + ch * EPC + e, dg[c * EPC + e]); atomicAdd(dbeta + ch * EPC + e, db[c * EPC + e]); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- column statistics
+// grid: (row blocks, groups).  Thread t owns chunk column t % cpr and walks rows t / cpr, + 256/cpr, ...
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, const T* __restrict__ xin, const T* __restrict__ yout,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const T* __restrict__ mul, int relu, float* __restrict__ o1,
+                                                       float* __restrict__ o2, int rows, int C, int rows_per_block) {
+    // !BWD: a = x; o1 += sum x, o2 += sum x^2.     BWD: a = dy; g = dy (*mul) (masked y>0); o1 += sum g, o2 += sum g*xhat
+    constexpr int EPC = Chunk<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = reinterpret_cast<float*>(smem_raw);       // [256][2*EPC]
+    const int cpr = C / EPC;
+    const int g = blockIdx.y;
+    const int r_begin = blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    // chunk columns are walked in slabs of 256 when cpr > 256 is impossible here (C <= 2048 -> cpr <= 512)
+    for (int cbase = 0; cbase < cpr; cbase += 256) {
+        const int span = min(256, cpr - cbase);
+        const int tc = threadIdx.x % span, tr = threadIdx.x / span, rstep = 256 / span;
+        if (tr < rstep) {
+            const int col = (cbase + tc) * EPC;
+            float mu[EPC], rs[EPC];
+            if (BWD) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { mu[e] = mean[(int64_t)g * C + col + e]; rs[e] = rstd[(int64_t)g * C + col + e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+            for (int r = r_begin + tr; r < r_end; r += rstep) {
+                const int64_t off = ((int64_t)g * rows + r) * C + col;
+                float f[EPC];
+                chunk_to_f<T>(*reinterpret_cast<const uint4*>(a + off), f);
+                if (!BWD) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
+                } else {
+                    float fx[EPC];
+                    chunk_to_f<T>(*reinterpret_cast<const uint4*>(xin + off), fx);
+                    if (mul) {
+                        float fm[EPC];
+                        chunk_to_f<T>(*reinterpret_cast<const uint4*>(mul + off), fm);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) f[e] *= fm[e];
+                    }
+                    if (relu) {
+                        float fy[EPC];
+                        chunk_to_f<T>(*reinterpret_cast<const uint4*>(yout + off), fy);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) if (!(fy[e] > 0.f)) f[e] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) { s1[e] += f[e]; s2[e] += f[e] * (fx[e] - mu[e]) * rs[e]; }
+                }
+            }
+        }
+        // reduce the rstep row-lanes that share a chunk column
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { red[threadIdx.x * 2 * EPC + e] = s1[e]; red[threadIdx.x * 2 * EPC + EPC + e] = s2[e]; }
+        __syncthreads();
+        if (threadIdx.x < span) {
+            float t1[EPC], t2[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
+            for (int k = 0; k < rstep; ++k)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    t1[e] += red[(k * span + threadIdx.x) * 2 * EPC + e];
+                    t2[e] += red[(k * span + threadIdx.x) * 2 * EPC + EPC + e];
+                }
+            const int col = (cbase + threadIdx.x) * EPC;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { atomicAdd(o1 + (int64_t)g * C + col + e, t1[e]); atomicAdd(o2 + (int64_t)g * C + col + e, t2[e]); }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void stats_finalize_kernel(const float* sum, const float* sumsq, float count, float eps, float* mean, float* rstd,
+                                      float* running_mean, float* running_var, float momentum, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float mu = sum[i] / count;
+    const float var = fmaxf(sumsq[i] / count - mu * mu, 0.f);
+    mean[i] = mu;
+    rstd[i] = rsqrtf(var + eps);
+    if (running_mean) running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * mu;
+    if (running_var) running_var[i] = (1.f - momentum) * running_var[i] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const T* __restrict__ mul, int relu, T* __restrict__ y, int rows, int C, int64_t nchunks) {
+    constexpr int EPC = Chunk<T>::N;
+    const int cpr = C / EPC;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % cpr) * EPC;
+        const int64_t g = (i / cpr) / rows;
+        float f[EPC];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + i * EPC), f);
+        float fm[EPC];
+        if (mul) chunk_to_f<T>(*reinterpret_cast<const uint4*>(mul + i * EPC), fm);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float v = (f[e] - mean[g * C + col + e]) * rstd[g * C + col + e];
+            if (gamma) v = v * gamma[col + e] + beta[col + e];
+            if (mul) v *= fm[e];
+            if (relu) v = fmaxf(v, 0.f);
+            f[e] = v;
+        }
+        *reinterpret_cast<uint4*>(y + i * EPC) = f_to_chunk<T>(f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yout,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const T* __restrict__ mul, int relu, const float* __restrict__ s1,
+                                                             const float* __restrict__ s2, float inv_count, T* __restrict__ dx,
+                                                             T* __restrict__ dmul, int rows, int C, int64_t nchunks) {
+    constexpr int EPC = Chunk<T>::N;
+    const int cpr = C / EPC;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % cpr) * EPC;
+        const int64_t g = (i / cpr) / rows;
+        float fg[EPC], fx[EPC], fm[EPC], fy[EPC], fdm[EPC];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(dy + i * EPC), fg);
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + i * EPC), fx);
+        if (mul) chunk_to_f<T>(*reinterpret_cast<const uint4*>(mul + i * EPC), fm);
+        if (relu) chunk_to_f<T>(*reinterpret_cast<const uint4*>(yout + i * EPC), fy);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int64_t sc = g * C + col + e;
+            const float rs = rstd[sc];
+            const float xh = (fx[e] - mean[sc]) * rs;
+            float gg = fg[e];
+            if (mul) { fdm[e] = gg * (gamma ? xh * gamma[col + e] + beta[col + e] : xh); gg *= fm[e]; }
+            if (relu && !(fy[e] > 0.f)) gg = 0.f;
+            const float ga = gamma ? gamma[col + e] : 1.f;
+            fg[e] = ga * rs * (gg - s1[sc] * inv_count - xh * s2[sc] * inv_count);
+        }
+        *reinterpret_cast<uint4*>(dx + i * EPC) = f_to_chunk<T>(fg);
+        if (mul && dmul) *reinterpret_cast<uint4*>(dmul + i * EPC) = f_to_chunk<T>(fdm);
+    }
+}
+
+inline int ew_grid(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+
+}  // namespace
+
+#define DISPATCH_T(dtype, NAME, ...)                                   \
+    if (dtype == LAVT_F32) { using T = float; __VA_ARGS__; }           \
+    else if (dtype == LAVT_BF16) { using T = bf16; __VA_ARGS__; }      \
+    else { lavt_set_error(NAME ": bad dtype %d", dtype); return LAVT_ERR_INVALID; }
+
+extern "C" int lavt_layernorm_fwd(int dtype, const void* x, const int32_t* gather, const float* gamma, const float* beta, void* y,
+                                  float* mean, float* rstd, int rows, int C, float eps, void* stream) {
+    const int epc = dtype == LAVT_F32 ? 4 : 8;
+    LAVT_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0, "lavt_layernorm_fwd: bad arguments");
+    LAVT_CHECK_ARG(C > 0 && C <= 2048 && C % epc == 0 && (!gather || (C / 4) % epc == 0), "lavt_layernorm_fwd: unsupported C=%d", C);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, "lavt_layernorm_fwd",
+               hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const T*)x, gather, gamma, beta, (T*)y, mean, rstd, rows, C, eps));
+    LAVT_CHECK_LAUNCH("lavt_layernorm_fwd");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
+                                  const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int C,
+                                  void* stream) {
+    const int epc = dtype == LAVT_F32 ? 4 : 8;
+    LAVT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "lavt_layernorm_bwd: bad arguments");
+    LAVT_CHECK_ARG(C > 0 && C <= 2048 && C % epc == 0 && (!gather || (C / 4) % epc == 0), "lavt_layernorm_bwd: unsupported C=%d", C);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int blocks = cdiv(rows, 4 * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    DISPATCH_T(dtype, "lavt_layernorm_bwd",
+               hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C));
+    LAVT_CHECK_LAUNCH("lavt_layernorm_bwd");
+    return LAVT_OK;
+}
+
+static int stats_launch_geometry(int rows, int groups, int* rows_per_block) {
+    int blocks = cdiv(rows, 64);
+    const int cap = 1024 / (groups > 0 ? groups : 1) + 1;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    *rows_per_block = cdiv(rows, blocks);
+    return cdiv(rows, *rows_per_block);
+}
+
+extern "C" int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq, int groups, int rows, int C, void* stream) {
+    const int epc = dtype == LAVT_F32 ? 4 : 8;
+    LAVT_CHECK_ARG(x && sum && sumsq && groups > 0 && rows > 0 && C > 0 && C % epc == 0, "lavt_colstats: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rpb;
+    const int blocks = stats_launch_geometry(rows, groups, &rpb);
+    DISPATCH_T(dtype, "lavt_colstats",
+               hipLaunchKernelGGL((colstats_kernel<T, false>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
+                                  (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, 0, sum, sumsq, rows, C, rpb));
+    LAVT_CHECK_LAUNCH("lavt_colstats");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_stats_finalize(const float* sum, const float* sumsq, float count, float eps, float* mean, float* rstd,
+                                   float* running_mean, float* running_var, float momentum, int n, void* stream) {
+    LAVT_CHECK_ARG(sum && sumsq && mean && rstd && n > 0 && count > 0, "lavt_stats_finalize: bad arguments");
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sum, sumsq, count, eps, mean, rstd, running_mean, running_var, momentum, n);
+    LAVT_CHECK_LAUNCH("lavt_stats_finalize");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_norm_apply(int dtype, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               const void* mul, int relu, void* y, int groups, int rows, int C, void* stream) {
+    const int epc = dtype == LAVT_F32 ? 4 : 8;
+    LAVT_CHECK_ARG(x && mean && rstd && y && groups > 0 && rows > 0 && C % epc == 0 && (!gamma == !beta), "lavt_norm_apply: bad arguments");
+    const int64_t nchunks = (int64_t)groups * rows * (C / epc);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, "lavt_norm_apply",
+               hipLaunchKernelGGL(norm_apply_kernel<T>, dim3(ew_grid(nchunks)), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, (const T*)mul, relu, (T*)y, rows, C, nchunks));
+    LAVT_CHECK_LAUNCH("lavt_norm_apply");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_norm_bwd_stats(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, const void* mul, int relu, float* s1, float* s2,
+                                   int groups, int rows, int C, void* stream) {
+    (void)gamma; (void)beta;
+    const int epc = dtype == LAVT_F32 ? 4 : 8;
+    LAVT_CHECK_ARG(dy && x && mean && rstd && s1 && s2 && (!relu || y) && groups > 0 && rows > 0 && C % epc == 0, "lavt_norm_bwd_stats: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rpb;
+    const int blocks = stats_launch_geometry(rows, groups, &rpb);
+    DISPATCH_T(dtype, "lavt_norm_bwd_stats",
+               hipLaunchKernelGGL((colstats_kernel<T, true>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
+                                  (const T*)dy, (const T*)x, (const T*)y, mean, rstd, (const T*)mul, relu, s1, s2, rows, C, rpb));
+    LAVT_CHECK_LAUNCH("lavt_norm_bwd_stats");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_norm_bwd_apply(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, const void* mul, int relu, const float* s1, const float* s2,
+                                   float count, void* dx, void* dmul, int groups, int rows, int C, void* stream) {
+    const int epc = dtype == LAVT_F32 ? 4 : 8;
+    LAVT_CHECK_ARG(dy && x && mean && rstd && s1 && s2 && dx && (!relu || y) && count > 0 && C % epc == 0, "lavt_norm_bwd_apply: bad arguments");
+    const int64_t nchunks = (int64_t)groups * rows * (C / epc);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, "lavt_norm_bwd_apply",
+               hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(ew_grid(nchunks)), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y, mean, rstd, gamma, beta,
+                                  (const T*)mul, relu, s1, s2, 1.f / count, (T*)dx, (T*)dmul, rows, C, nchunks));
+    LAVT_CHECK_LAUNCH("lavt_norm_bwd_apply");
+    return LAVT_OK;
+}

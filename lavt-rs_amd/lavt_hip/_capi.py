@@ -1,0 +1,117 @@
+"""ctypes binding of liblavt_hip.so (C ABI declared in include/lavt_hip.h).
+
+There is NO fallback: if the shared library is missing the import raises, and every call that
+returns a non-zero status raises RuntimeError with the library's error string.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "liblavt_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C lavt-rs_amd/csrc` (or __graft_entry__.build()). "
+        "The LAVT HIP path has no CPU/eager fallback.")
+lib = C.CDLL(LIB_PATH)
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class GemmNT(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
+        ("A", vp), ("lda", i64), ("strideA", i64), ("A2", vp), ("lda2", i64), ("a_split", i32), ("a_rowmap", vp),
+        ("conv_h", i32), ("conv_w", i32), ("conv_kc", i32), ("conv_flip", i32),
+        ("B", vp), ("ldb", i64), ("strideB", i64), ("b_kmajor", i32), ("b_tap_stride", i64),
+        ("alpha", f32), ("bias", vp), ("strideBias", i64), ("row_scale", vp), ("strideRowScale", i64), ("row_scale_div", i32), ("act", i32),
+        ("Cpre", vp), ("ldcpre", i64), ("R", vp), ("ldr", i64),
+        ("C", vp), ("ldc", i64), ("strideC", i64), ("C2", vp), ("ldc2", i64), ("c_split", i32), ("c_rowmap", vp),
+        ("c_f32", i32),
+    ]
+
+
+class GemmTN(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("I", i32), ("J", i32), ("K", i32), ("batch", i32),
+        ("A", vp), ("lda", i64), ("strideA", i64), ("a_rowmap", vp), ("a_rowscale", vp), ("a_rowscale_div", i32),
+        ("B", vp), ("ldb", i64), ("strideB", i64), ("B2", vp), ("ldb2", i64), ("b_split", i32), ("b_rowmap", vp),
+        ("conv_h", i32), ("conv_w", i32), ("conv_kc", i32),
+        ("alpha", f32), ("C", vp), ("ldc", i64), ("strideC", i64), ("c_conv_permute", i32), ("split_k", i32),
+        ("colsum", vp), ("strideColsum", i64),
+    ]
+
+
+# every symbol include/lavt_hip.h declares, with its argument types (tests check this list against the header)
+_PROTOTYPES = {
+    "lavt_abi_version": [],
+    "lavt_gemm_nt": [C.POINTER(GemmNT), vp],
+    "lavt_gemm_tn": [C.POINTER(GemmTN), vp],
+    "lavt_window_attn_fwd": [i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, f32, vp],
+    "lavt_window_attn_bwd": [i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "lavt_relpos_expand": [vp, vp, i32, i32, vp],
+    "lavt_relpos_reduce": [vp, vp, i32, i32, vp],
+    "lavt_layernorm_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "lavt_layernorm_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "lavt_colstats": [i32, vp, vp, vp, i32, i32, i32, vp],
+    "lavt_stats_finalize": [vp, vp, f32, f32, vp, vp, vp, vp, f32, i32, vp],
+    "lavt_norm_apply": [i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp],
+    "lavt_norm_bwd_stats": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp],
+    "lavt_norm_bwd_apply": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, f32, vp, vp, i32, i32, i32, vp],
+    "lavt_act_bwd": [i32, i32, vp, vp, vp, i64, vp],
+    "lavt_gate_fwd": [i32, vp, vp, vp, vp, i64, vp],
+    "lavt_gate_bwd": [i32, vp, vp, vp, vp, vp, i64, vp],
+    "lavt_rowsoftmax_fwd": [i32, vp, vp, i64, i32, i32, vp],
+    "lavt_rowsoftmax_bwd": [i32, vp, vp, vp, i64, i32, i32, vp],
+    "lavt_bilinear_fwd": [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "lavt_bilinear_bwd": [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "lavt_logits_up_fwd": [i32, vp, vp, i32, i32, i32, i32, i32, vp],
+    "lavt_logits_up_bwd": [i32, vp, vp, i32, i32, i32, i32, i32, vp],
+    "lavt_cls_head_fwd": [i32, vp, vp, vp, vp, i64, i32, vp],
+    "lavt_cls_head_bwd": [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "lavt_im2col4": [i32, vp, vp, i32, i32, i32, vp],
+    "lavt_col2im4": [i32, vp, vp, i32, i32, i32, vp],
+    "lavt_cast": [i32, vp, i32, vp, i64, vp],
+    "lavt_nchw_to_nhwc": [i32, vp, i32, vp, i32, i32, i32, vp],
+    "lavt_nhwc_to_nchw": [i32, vp, i32, vp, i32, i32, i32, vp],
+    "lavt_pack_conv3x3": [vp, i32, vp, i32, i32, vp],
+    "lavt_cast_multi": [vp, i32, i32, vp],
+}
+for _name, _args in _PROTOTYPES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = header/library mismatch: fail loudly
+    _fn.argtypes = _args
+    _fn.restype = C.c_int
+lib.lavt_last_error.restype = C.c_char_p
+lib.lavt_last_error.argtypes = []
+
+EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"liblavt_hip: rc={rc}: {lib.lavt_last_error().decode()}")
+
+
+def dt(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise TypeError(f"liblavt_hip computes in float32 or bfloat16, not {t}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses CPU tensors: there is no CPU path."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("liblavt_hip operates on GPU memory only (got a CPU tensor); there is no CPU fallback")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,657 @@
+"""Autograd-aware host wrappers over the liblavt_hip C ABI.
+
+Each torch.autograd.Function below launches hand-written gfx950 kernels through ctypes on the
+current HIP stream, with raw device pointers taken from torch tensors (torch is the allocator and
+stream provider only).  There is no alternative implementation: CPU tensors raise.
+
+Activations are 2-D [rows, channels] tensors in the compute dtype (float32 = exact parity path,
+bfloat16 = MFMA throughput path).  Parameters stay fp32 nn.Parameters (reference state-dict);
+bf16 compute copies are produced by `weight()` and cached per parameter version.  All parameter
+gradients are produced in fp32.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _capi as K
+
+KV_LD = 32          # padded word axis of PWAM keys/values (N_l <= 32)
+
+
+# ------------------------------------------------------------------------------------------ weights
+class _WeightCache:
+    """compute-dtype copies of fp32 parameters: 'lin' = [N,K] matrix view, 'conv3' = [Cout][9][Cin]."""
+
+    def __init__(self):
+        self.store = {}
+        self.epoch = 0
+
+    def invalidate(self):
+        self.epoch += 1
+
+    def get(self, p: torch.Tensor, dtype: torch.dtype, kind: str = "lin") -> torch.Tensor:
+        if kind == "lin" and dtype == torch.float32:
+            return p.detach().reshape(p.shape[0], -1)
+        key = (id(p), dtype, kind)
+        ent = self.store.get(key)
+        stamp = (p._version, p.data_ptr(), self.epoch)
+        if ent is not None and ent[0] == stamp:
+            return ent[1]
+        src = p.detach()
+        if kind == "lin":
+            out = ent[1] if ent is not None and ent[1].numel() == src.numel() else torch.empty(src.shape[0], src.numel() // src.shape[0], dtype=dtype, device=src.device)
+            K.check(K.lib.lavt_cast(K.F32, K.ptr(src), K.dt(dtype), K.ptr(out), src.numel(), K.stream()))
+        elif kind == "conv3":
+            cout, cin = src.shape[0], src.shape[1]
+            out = ent[1] if ent is not None and ent[1].numel() == src.numel() else torch.empty(cout, 9 * cin, dtype=dtype, device=src.device)
+            K.check(K.lib.lavt_pack_conv3x3(K.ptr(src), K.dt(dtype), K.ptr(out), cout, cin, K.stream()))
+        else:
+            raise KeyError(kind)
+        self.store[key] = (stamp, out)
+        return out
+
+
+weights = _WeightCache()
+
+
+def _f32(p: Optional[torch.Tensor]):
+    if p is None:
+        return None
+    assert p.dtype == torch.float32 and p.is_contiguous()
+    return p.detach()
+
+
+# ------------------------------------------------------------------------------------------ raw launches
+def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, strideB=0, strideC=0, A2=None, lda2=0,
+            a_split=0, a_rowmap=None, conv=None, b_kmajor=False, b_tap_stride=0, alpha=1.0, bias=None, strideBias=0,
+            row_scale=None, strideRowScale=0, row_scale_div=1, act=K.ACT_NONE, Cpre=None, ldcpre=0, R=None, ldr=0, C2=None, ldc2=0,
+            c_split=0, c_rowmap=None, c_f32=False, a_off=0, b_off=0, c_off=0):
+    """A/B/Cout are tensors; *_off are element offsets into them (column sub-blocks)."""
+    es = 4 if dtype == torch.float32 else 2
+    p = K.GemmNT()
+    p.dtype, p.M, p.N, p.K, p.batch = K.dt(dtype), M, N, Kd, batch
+    p.A, p.lda, p.strideA = K.ptr(A) + a_off * es, lda, strideA
+    p.A2, p.lda2, p.a_split = K.ptr(A2), lda2, a_split
+    p.a_rowmap = K.ptr(a_rowmap)
+    if conv is not None:
+        p.conv_h, p.conv_w, p.conv_kc, p.conv_flip = conv
+    p.B, p.ldb, p.strideB, p.b_kmajor, p.b_tap_stride = K.ptr(B) + b_off * es, ldb, strideB, int(b_kmajor), b_tap_stride
+    p.alpha, p.bias, p.strideBias = alpha, K.ptr(bias), strideBias
+    p.row_scale, p.strideRowScale, p.row_scale_div, p.act = K.ptr(row_scale), strideRowScale, row_scale_div, act
+    p.Cpre, p.ldcpre, p.R, p.ldr = K.ptr(Cpre), ldcpre, K.ptr(R), ldr
+    p.C, p.ldc, p.strideC = K.ptr(Cout) + c_off * (4 if c_f32 else es), ldc, strideC
+    p.C2, p.ldc2, p.c_split = K.ptr(C2), ldc2, c_split
+    p.c_rowmap, p.c_f32 = K.ptr(c_rowmap), int(c_f32)
+    K.check(K.lib.lavt_gemm_nt(C.byref(p), K.stream()))
+
+
+def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, strideB=0, strideC=0, a_rowmap=None,
+            a_rowscale=None, a_rowscale_div=1, B2=None, ldb2=0, b_split=0, b_rowmap=None, conv=None, alpha=1.0, c_conv_permute=False, colsum=None,
+            strideColsum=0, a_off=0, b_off=0, c_off=0):
+    es = 4 if dtype == torch.float32 else 2
+    assert Cout.dtype == torch.float32
+    p = K.GemmTN()
+    p.dtype, p.I, p.J, p.K, p.batch = K.dt(dtype), I, J, Kd, batch
+    p.A, p.lda, p.strideA, p.a_rowmap = K.ptr(A) + a_off * es, lda, strideA, K.ptr(a_rowmap)
+    p.a_rowscale, p.a_rowscale_div = K.ptr(a_rowscale), a_rowscale_div
+    p.B, p.ldb, p.strideB = K.ptr(B) + b_off * es, ldb, strideB
+    p.B2, p.ldb2, p.b_split, p.b_rowmap = K.ptr(B2), ldb2, b_split, K.ptr(b_rowmap)
+    if conv is not None:
+        p.conv_h, p.conv_w, p.conv_kc = conv
+    p.alpha, p.C, p.ldc, p.strideC = alpha, K.ptr(Cout) + c_off * 4, ldc, strideC
+    p.c_conv_permute, p.split_k = int(c_conv_permute), 0
+    p.colsum, p.strideColsum = K.ptr(colsum), strideColsum
+    K.check(K.lib.lavt_gemm_tn(C.byref(p), K.stream()))
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if x.dtype == dtype:
+        return x
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    K.check(K.lib.lavt_cast(K.dt(x.dtype), K.ptr(x.contiguous()), K.dt(dtype), K.ptr(out), x.numel(), K.stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ Linear (+gather/scatter/act/residual)
+@dataclass
+class LinOpts:
+    act: int = K.ACT_NONE
+    in_map: Optional[torch.Tensor] = None      # GEMM row m reads x[in_map[m]] (-1 = zeros)
+    out_map: Optional[torch.Tensor] = None     # GEMM row m writes y[out_map[m]] (-1 = dropped)
+    rows: Optional[int] = None                 # number of GEMM rows (default: x rows)
+    out_rows: Optional[int] = None             # rows of y (default: GEMM rows)
+    zero_init: bool = False                    # y rows not covered by out_map must read 0
+    row_scale: Optional[torch.Tensor] = None   # fp32 factor of GEMM row m: row_scale[m // row_scale_div] (language mask, DropPath)
+    row_scale_div: int = 1
+
+
+class _Linear(torch.autograd.Function):
+    """y[out_map[m]] = act((x[in_map[m]] @ W^T + b) * row_scale[m // div]) + residual[out_map[m]]"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, o: LinOpts):
+        x = x.contiguous()
+        dtype = x.dtype
+        Wc = weights.get(weight, dtype, "lin")
+        N, Kd = Wc.shape
+        assert x.shape[1] == Kd, f"linear: x has {x.shape[1]} channels, weight expects {Kd}"
+        M = o.rows if o.rows is not None else x.shape[0]
+        assert o.row_scale is None or o.act == K.ACT_NONE
+        out_rows = o.out_rows if o.out_rows is not None else M
+        y = (torch.zeros if o.zero_init else torch.empty)(out_rows, N, dtype=dtype, device=x.device)
+        pre = torch.empty_like(y) if o.act != K.ACT_NONE else None
+        if residual is not None:
+            residual = residual.contiguous()
+            assert residual.shape == y.shape and residual.dtype == dtype
+        gemm_nt(dtype, M, N, Kd, x, Kd, Wc, Kd, y, N, a_rowmap=o.in_map, bias=_f32(bias), row_scale=o.row_scale, row_scale_div=o.row_scale_div, act=o.act,
+                Cpre=pre, ldcpre=N, R=residual, ldr=N, c_rowmap=o.out_map)
+        ctx.o, ctx.M, ctx.has_bias, ctx.has_res = o, M, bias is not None, residual is not None
+        ctx.save_for_backward(x, weight, pre)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, pre = ctx.saved_tensors
+        o, M = ctx.o, ctx.M
+        dtype = x.dtype
+        dy = dy.contiguous()
+        g = dy
+        if o.act != K.ACT_NONE:
+            g = torch.empty_like(dy)
+            K.check(K.lib.lavt_act_bwd(K.dt(dtype), o.act, K.ptr(dy), K.ptr(pre), K.ptr(g), dy.numel(), K.stream()))
+        Wc = weights.get(weight, dtype, "lin")
+        N, Kd = Wc.shape
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (torch.zeros if o.in_map is not None else torch.empty)(x.shape, dtype=dtype, device=x.device)
+            gemm_nt(dtype, M, Kd, N, g, N, Wc, Kd, dx, Kd, a_rowmap=o.out_map, b_kmajor=True, row_scale=o.row_scale,
+                    row_scale_div=o.row_scale_div, c_rowmap=o.in_map)
+        if ctx.needs_input_grad[1]:
+            dW = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = torch.zeros(N, dtype=torch.float32, device=x.device)
+            gemm_tn(dtype, N, Kd, M, g, N, x, Kd, dW, Kd, a_rowmap=o.out_map, a_rowscale=o.row_scale, a_rowscale_div=o.row_scale_div,
+                    b_rowmap=o.in_map, colsum=db)
+            dW = dW.view(weight.shape)
+        d_res = dy if ctx.has_res and ctx.needs_input_grad[3] else None
+        return dx, dW, db, d_res, None
+
+
+def linear(x, weight, bias=None, residual=None, **kw):
+    return _Linear.apply(x, weight, bias, residual, LinOpts(**kw))
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, gather, rows, C, eps):
+        x = x.contiguous()
+        y = torch.empty(rows, C, dtype=x.dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        K.check(K.lib.lavt_layernorm_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(gather), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), K.ptr(y),
+                                         K.ptr(mean), K.ptr(rstd), rows, C, eps, K.stream()))
+        ctx.save_for_backward(x, gamma, mean, rstd, gather)
+        ctx.rows, ctx.C = rows, C
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd, gather = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.zeros(ctx.C, dtype=torch.float32, device=x.device)
+        db = torch.zeros_like(dg)
+        K.check(K.lib.lavt_layernorm_bwd(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(gather), K.ptr(_f32(gamma)), K.ptr(mean), K.ptr(rstd),
+                                         K.ptr(dx), K.ptr(dg), K.ptr(db), ctx.rows, ctx.C, K.stream()))
+        return dx, dg, db, None, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, gather=None):
+    """x [rows, C]; with gather (int32 [rows_out, 4]) the input row is the concat of 4 source rows of x (PatchMerging)."""
+    if gather is None:
+        return _LayerNorm.apply(x, gamma, beta, None, x.shape[0], x.shape[1], eps)
+    return _LayerNorm.apply(x, gamma, beta, gather, gather.shape[0], 4 * x.shape[1], eps)
+
+
+# ------------------------------------------------------------------------------------------ window attention core
+class _WindowAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, table, region, ws, heads):
+        qkv = qkv.contiguous()
+        N = ws * ws
+        C3 = qkv.shape[1]
+        Cc = C3 // 3
+        nwin = qkv.shape[0] // N
+        dev = qkv.device
+        dense = torch.empty(heads, N, N, dtype=torch.float32, device=dev)
+        K.check(K.lib.lavt_relpos_expand(K.ptr(_f32(table)), K.ptr(dense), ws, heads, K.stream()))
+        out = torch.empty(nwin * N, Cc, dtype=qkv.dtype, device=dev)
+        lse = torch.empty(nwin, heads, N, dtype=torch.float32, device=dev)
+        nw_img = region.shape[0] if region is not None else 0
+        scale = float((Cc // heads) ** -0.5)
+        K.check(K.lib.lavt_window_attn_fwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), K.ptr(region), nw_img, K.ptr(out), K.ptr(lse),
+                                           nwin, N, heads, Cc // heads, scale, K.stream()))
+        ctx.save_for_backward(qkv, dense, region, out, lse)
+        ctx.dims = (ws, heads, nwin, N, Cc, nw_img, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, dense, region, out, lse = ctx.saved_tensors
+        ws, heads, nwin, N, Cc, nw_img, scale = ctx.dims
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        ddense = torch.zeros_like(dense)
+        K.check(K.lib.lavt_window_attn_bwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), K.ptr(region), nw_img, K.ptr(out), K.ptr(dout),
+                                           K.ptr(lse), K.ptr(dqkv), K.ptr(ddense), nwin, N, heads, Cc // heads, scale, K.stream()))
+        dtable = torch.zeros((2 * ws - 1) ** 2, heads, dtype=torch.float32, device=qkv.device)
+        K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense), K.ptr(dtable), ws, heads, K.stream()))
+        return dqkv, dtable, None, None, None
+
+
+def window_attention(qkv, table, region, ws, heads):
+    return _WindowAttn.apply(qkv, table, region, ws, heads)
+
+
+# ------------------------------------------------------------------------------------------ Instance / Batch norm
+def _stats(x, groups, rows, Cc):
+    s = torch.zeros(2, groups, Cc, dtype=torch.float32, device=x.device)
+    K.check(K.lib.lavt_colstats(K.dt(x.dtype), K.ptr(x), K.ptr(s[0]), K.ptr(s[1]), groups, rows, Cc, K.stream()))
+    return s
+
+
+class _InstanceNorm(torch.autograd.Function):
+    """y = IN_over_rows(x) (* mul); x [B*T, C], statistics per (b, c) over the T rows (lib/backbone.py:1311-1327)."""
+
+    @staticmethod
+    def forward(ctx, x, mul, B, T):
+        x = x.contiguous()
+        Cc = x.shape[1]
+        s = _stats(x, B, T, Cc)
+        mean = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        K.check(K.lib.lavt_stats_finalize(K.ptr(s[0]), K.ptr(s[1]), float(T), 1e-5, K.ptr(mean), K.ptr(rstd), None, None, 0.0, B * Cc, K.stream()))
+        if mul is not None:
+            mul = mul.contiguous()
+        y = torch.empty_like(x)
+        K.check(K.lib.lavt_norm_apply(K.dt(x.dtype), K.ptr(x), K.ptr(mean), K.ptr(rstd), None, None, K.ptr(mul), 0, K.ptr(y), B, T, Cc, K.stream()))
+        ctx.save_for_backward(x, mul, mean, rstd)
+        ctx.dims = (B, T, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mul, mean, rstd = ctx.saved_tensors
+        B, T, Cc = ctx.dims
+        dy = dy.contiguous()
+        s = torch.zeros(2, B, Cc, dtype=torch.float32, device=x.device)
+        d = K.dt(x.dtype)
+        K.check(K.lib.lavt_norm_bwd_stats(d, K.ptr(dy), K.ptr(x), None, K.ptr(mean), K.ptr(rstd), None, None, K.ptr(mul), 0,
+                                          K.ptr(s[0]), K.ptr(s[1]), B, T, Cc, K.stream()))
+        dx = torch.empty_like(x)
+        dmul = torch.empty_like(x) if mul is not None else None
+        K.check(K.lib.lavt_norm_bwd_apply(d, K.ptr(dy), K.ptr(x), None, K.ptr(mean), K.ptr(rstd), None, None, K.ptr(mul), 0,
+                                          K.ptr(s[0]), K.ptr(s[1]), float(T), K.ptr(dx), K.ptr(dmul), B, T, Cc, K.stream()))
+        return dx, dmul, None, None
+
+
+def instance_norm(x, B, T, mul=None):
+    return _InstanceNorm.apply(x, mul, B, T)
+
+
+class _BatchNormRelu(torch.autograd.Function):
+    """BatchNorm2d + ReLU on NHWC rows [R, C].  training: batch statistics (all-reduced over `group` when given =
+    SyncBatchNorm semantics, train.py:589), running stats updated in place; eval: running statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, group):
+        x = x.contiguous()
+        R, Cc = x.shape
+        dev = x.device
+        mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        count = float(R)
+        if training:
+            s = _stats(x, 1, R, Cc)
+            if group is not None:
+                import torch.distributed as dist
+                dist.all_reduce(s, group=group)
+                count = float(R * dist.get_world_size(group))
+            K.check(K.lib.lavt_stats_finalize(K.ptr(s[0]), K.ptr(s[1]), count, eps, K.ptr(mean), K.ptr(rstd), K.ptr(running_mean),
+                                              K.ptr(running_var), momentum, Cc, K.stream()))
+        else:
+            # eval: mean = running_mean, var = running_var  (sum = mean, sumsq = var + mean^2, count = 1)
+            s = torch.stack([running_mean, running_var + running_mean * running_mean])
+            K.check(K.lib.lavt_stats_finalize(K.ptr(s[0]), K.ptr(s[1]), 1.0, eps, K.ptr(mean), K.ptr(rstd), None, None, 0.0, Cc, K.stream()))
+        y = torch.empty_like(x)
+        K.check(K.lib.lavt_norm_apply(K.dt(x.dtype), K.ptr(x), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), None, 1,
+                                      K.ptr(y), 1, R, Cc, K.stream()))
+        ctx.save_for_backward(x, y, gamma, beta, mean, rstd)
+        ctx.cfg = (training, count, group)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, count, group = ctx.cfg
+        R, Cc = x.shape
+        dy = dy.contiguous()
+        d = K.dt(x.dtype)
+        s = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)
+        K.check(K.lib.lavt_norm_bwd_stats(d, K.ptr(dy), K.ptr(x), K.ptr(y), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)),
+                                          None, 1, K.ptr(s[0]), K.ptr(s[1]), 1, R, Cc, K.stream()))
+        dgamma, dbeta = s[1].clone(), s[0].clone()          # local sums: DDP averages parameter grads later
+        if not training:
+            s.zero_()                                       # running statistics are constants: no batch terms
+        elif group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(s, group=group)
+        dx = torch.empty_like(x)
+        K.check(K.lib.lavt_norm_bwd_apply(d, K.ptr(dy), K.ptr(x), K.ptr(y), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)),
+                                          None, 1, K.ptr(s[0]), K.ptr(s[1]), count, K.ptr(dx), None, 1, R, Cc, K.stream()))
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batch_norm_relu(x, bn: torch.nn.modules.batchnorm._BatchNorm):
+    """`bn` is the module holding the parameters/buffers (nn.BatchNorm2d, or nn.SyncBatchNorm after
+    convert_sync_batchnorm -> statistics are all-reduced over its process group)."""
+    import torch.distributed as dist
+    group = None
+    if isinstance(bn, torch.nn.SyncBatchNorm) and bn.training and dist.is_available() and dist.is_initialized():
+        group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+        if dist.get_world_size(group) == 1:
+            group = None
+    training = bn.training or bn.running_mean is None
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BatchNormRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                                bn.momentum if bn.momentum is not None else 0.1, bn.eps, group)
+
+
+# ------------------------------------------------------------------------------------------ language gate
+class _Gate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gpre, r):
+        x, gpre, r = x.contiguous(), gpre.contiguous(), r.contiguous()
+        out = torch.empty_like(x)
+        K.check(K.lib.lavt_gate_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(gpre), K.ptr(r), K.ptr(out), x.numel(), K.stream()))
+        ctx.save_for_backward(gpre, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        gpre, r = ctx.saved_tensors
+        d = d.contiguous()
+        dg, dr = torch.empty_like(gpre), torch.empty_like(r)
+        K.check(K.lib.lavt_gate_bwd(K.dt(d.dtype), K.ptr(d), K.ptr(gpre), K.ptr(r), K.ptr(dg), K.ptr(dr), d.numel(), K.stream()))
+        return d, dg, dr
+
+
+def gate(x, gpre, r):
+    """x + tanh(gpre) * r   (lib/backbone.py:669 with the Tanh of res_gate folded in)"""
+    return _Gate.apply(x, gpre, r)
+
+
+# ------------------------------------------------------------------------------------------ PWAM pixel-word attention
+class _PwamAttn(torch.autograd.Function):
+    """softmax_words(q k^T * C^-1/2 + maskbias) v   per sample and head group (lib/backbone.py:1349-1363).
+    q [B*T, C]; k, v [B*KV_LD, C] (rows >= n_l are zero); maskbias fp32 [B, KV_LD]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, maskbias, B, T, n_l, G):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        dtype, dev = q.dtype, q.device
+        Cc = q.shape[1]
+        c = Cc // G
+        alpha = float(Cc ** -0.5)
+        o = torch.empty_like(q)
+        Ps = []
+        for g in range(G):
+            S = torch.empty(B * T, KV_LD, dtype=dtype, device=dev)
+            gemm_nt(dtype, T, KV_LD, c, q, Cc, k, Cc, S, KV_LD, batch=B, strideA=T * Cc, strideB=KV_LD * Cc, strideC=T * KV_LD,
+                    alpha=alpha, bias=maskbias, strideBias=KV_LD, a_off=g * c, b_off=g * c)
+            P = torch.empty_like(S)
+            K.check(K.lib.lavt_rowsoftmax_fwd(K.dt(dtype), K.ptr(S), K.ptr(P), B * T, n_l, KV_LD, K.stream()))
+            gemm_nt(dtype, T, c, KV_LD, P, KV_LD, v, Cc, o, Cc, batch=B, strideA=T * KV_LD, strideB=KV_LD * Cc, strideC=T * Cc,
+                    b_kmajor=True, b_off=g * c, c_off=g * c)
+            Ps.append(P)
+        ctx.save_for_backward(q, k, v, *Ps)
+        ctx.dims = (B, T, n_l, G, Cc, alpha)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, *Ps = ctx.saved_tensors
+        B, T, n_l, G, Cc, alpha = ctx.dims
+        dtype, dev = q.dtype, q.device
+        c = Cc // G
+        do = do.contiguous()
+        dq = torch.empty_like(q)
+        dk = torch.zeros(B * KV_LD, Cc, dtype=torch.float32, device=dev)
+        dv = torch.zeros_like(dk)
+        for g in range(G):
+            P = Ps[g]
+            dP = torch.empty_like(P)
+            gemm_nt(dtype, T, KV_LD, c, do, Cc, v, Cc, dP, KV_LD, batch=B, strideA=T * Cc, strideB=KV_LD * Cc, strideC=T * KV_LD,
+                    a_off=g * c, b_off=g * c)
+            dS = torch.empty_like(P)
+            K.check(K.lib.lavt_rowsoftmax_bwd(K.dt(dtype), K.ptr(P), K.ptr(dP), K.ptr(dS), B * T, n_l, KV_LD, K.stream()))
+            gemm_nt(dtype, T, c, KV_LD, dS, KV_LD, k, Cc, dq, Cc, batch=B, strideA=T * KV_LD, strideB=KV_LD * Cc, strideC=T * Cc,
+                    b_kmajor=True, alpha=alpha, b_off=g * c, c_off=g * c)
+            gemm_tn(dtype, KV_LD, c, T, dS, KV_LD, q, Cc, dk, Cc, batch=B, strideA=T * KV_LD, strideB=T * Cc, strideC=KV_LD * Cc,
+                    alpha=alpha, b_off=g * c, c_off=g * c)
+            gemm_tn(dtype, KV_LD, c, T, P, KV_LD, do, Cc, dv, Cc, batch=B, strideA=T * KV_LD, strideB=T * Cc, strideC=KV_LD * Cc,
+                    b_off=g * c, c_off=g * c)
+        return dq, cast(dk, dtype), cast(dv, dtype), None, None, None, None, None
+
+
+def pwam_attention(q, k, v, maskbias, B, T, n_l, G):
+    return _PwamAttn.apply(q, k, v, maskbias, B, T, n_l, G)
+
+
+# ------------------------------------------------------------------------------------------ layout changes
+class _Transpose(torch.autograd.Function):
+    """[B, R, Cc] -> [B, Cc, R] (both contiguous) with optional dtype change; used for NCHW<->NHWC at the boundary."""
+
+    @staticmethod
+    def forward(ctx, x, out_dtype):
+        x = x.contiguous()
+        B, R, Cc = x.shape
+        y = torch.empty(B, Cc, R, dtype=out_dtype, device=x.device)
+        # nchw_to_nhwc(B, C=R, HW=Cc): src [B][R][Cc] -> dst [B][Cc][R]
+        K.check(K.lib.lavt_nchw_to_nhwc(K.dt(x.dtype), K.ptr(x), K.dt(out_dtype), K.ptr(y), B, R, Cc, K.stream()))
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        B, Cc, R = dy.shape
+        dx = torch.empty(B, R, Cc, dtype=ctx.in_dtype, device=dy.device)
+        K.check(K.lib.lavt_nchw_to_nhwc(K.dt(dy.dtype), K.ptr(dy), K.dt(ctx.in_dtype), K.ptr(dx), B, Cc, R, K.stream()))
+        return dx, None
+
+
+def transpose_last2(x, out_dtype=None):
+    return _Transpose.apply(x, out_dtype or x.dtype)
+
+
+class _Cast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.in_dtype = x.dtype
+        return cast(x.contiguous(), dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return cast(dy.contiguous(), ctx.in_dtype), None
+
+
+def cast_ad(x, dtype):
+    return x if x.dtype == dtype else _Cast.apply(x, dtype)
+
+
+# ------------------------------------------------------------------------------------------ patch embed
+class _PatchEmbed(torch.autograd.Function):
+    """Conv2d(3->C0, k4, s4) on an NCHW fp32 image, zero padded to a multiple of 4 (lib/backbone.py:315-324)."""
+
+    @staticmethod
+    def forward(ctx, img, weight, bias, dtype):
+        img = img.contiguous().float()
+        B, _, H, W = img.shape
+        H4, W4 = (H + 3) // 4, (W + 3) // 4
+        cols = torch.empty(B * H4 * W4, 48, dtype=dtype, device=img.device)
+        K.check(K.lib.lavt_im2col4(K.dt(dtype), K.ptr(img), K.ptr(cols), B, H, W, K.stream()))
+        Wc = weights.get(weight, dtype, "lin")
+        C0 = Wc.shape[0]
+        y = torch.empty(B * H4 * W4, C0, dtype=dtype, device=img.device)
+        gemm_nt(dtype, B * H4 * W4, C0, 48, cols, 48, Wc, 48, y, C0, bias=_f32(bias))
+        ctx.save_for_backward(cols, weight)
+        ctx.dims = (B, H, W, dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, weight = ctx.saved_tensors
+        B, H, W, dtype = ctx.dims
+        dy = dy.contiguous()
+        M, C0 = dy.shape
+        dimg = None
+        if ctx.needs_input_grad[0]:
+            Wc = weights.get(weight, dtype, "lin")
+            dcols = torch.empty_like(cols)
+            gemm_nt(dtype, M, 48, C0, dy, C0, Wc, 48, dcols, 48, b_kmajor=True)
+            dimg = torch.empty(B, 3, H, W, dtype=torch.float32, device=dy.device)
+            K.check(K.lib.lavt_col2im4(K.dt(dtype), K.ptr(dcols), K.ptr(dimg), B, H, W, K.stream()))
+        dW = torch.zeros(C0, 48, dtype=torch.float32, device=dy.device)
+        db = torch.zeros(C0, dtype=torch.float32, device=dy.device)
+        gemm_tn(dtype, C0, 48, M, dy, C0, cols, 48, dW, 48, colsum=db)
+        return dimg, dW.view(weight.shape), db, None
+
+
+def patch_embed(img, weight, bias, dtype):
+    return _PatchEmbed.apply(img, weight, bias, dtype)
+
+
+# ------------------------------------------------------------------------------------------ decoder pieces
+class _Conv3x3(torch.autograd.Function):
+    """3x3 / pad 1 / no-bias convolution over NHWC rows, input = channel concat of x1 and (optional) x2."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, B, H, W):
+        x1 = x1.contiguous()
+        dtype = x1.dtype
+        C1 = x1.shape[1]
+        C2 = 0
+        if x2 is not None:
+            x2 = x2.contiguous()
+            C2 = x2.shape[1]
+        Wp = weights.get(weight, dtype, "conv3")
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        assert Cin == C1 + C2, f"conv3x3: weight expects {Cin} input channels, got {C1}+{C2}"
+        M = B * H * W
+        y = torch.empty(M, Cout, dtype=dtype, device=x1.device)
+        gemm_nt(dtype, M, Cout, 9 * Cin, x1, C1, Wp, 9 * Cin, y, Cout, A2=x2, lda2=C2, a_split=C1, conv=(H, W, Cin, 0))
+        ctx.save_for_backward(x1, x2, weight)
+        ctx.dims = (B, H, W, C1, C2, Cout)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, weight = ctx.saved_tensors
+        B, H, W, C1, C2, Cout = ctx.dims
+        dtype = x1.dtype
+        Cin = C1 + C2
+        M = B * H * W
+        dy = dy.contiguous()
+        Wp = weights.get(weight, dtype, "conv3")
+        dx1 = dx2 = None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
+            dx1 = torch.empty_like(x1)
+            dx2 = torch.empty_like(x2) if x2 is not None else None
+            gemm_nt(dtype, M, Cin, 9 * Cout, dy, Cout, Wp, 9 * Cin, dx1, C1, conv=(H, W, Cout, 1), b_kmajor=True, b_tap_stride=Cin,
+                    C2=dx2, ldc2=C2, c_split=C1)
+        dW = torch.zeros(Cout, Cin * 9, dtype=torch.float32, device=dy.device)
+        gemm_tn(dtype, Cout, 9 * Cin, M, dy, Cout, x1, C1, dW, 9 * Cin, B2=x2, ldb2=C2, b_split=C1, conv=(H, W, Cin), c_conv_permute=True)
+        return dx1, dx2, dW.view(weight.shape), None, None, None
+
+
+def conv3x3(x1, x2, weight, B, H, W):
+    return _Conv3x3.apply(x1, x2, weight, B, H, W)
+
+
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, B, Hi, Wi, Ho, Wo):
+        x = x.contiguous()
+        Cc = x.shape[1]
+        y = torch.empty(B * Ho * Wo, Cc, dtype=x.dtype, device=x.device)
+        K.check(K.lib.lavt_bilinear_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(y), B, Hi, Wi, Ho, Wo, Cc, K.stream()))
+        ctx.dims = (B, Hi, Wi, Ho, Wo, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Hi, Wi, Ho, Wo, Cc = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty(B * Hi * Wi, Cc, dtype=dy.dtype, device=dy.device)
+        K.check(K.lib.lavt_bilinear_bwd(K.dt(dy.dtype), K.ptr(dy), K.ptr(dx), B, Hi, Wi, Ho, Wo, Cc, K.stream()))
+        return dx, None, None, None, None, None
+
+
+def bilinear(x, B, Hi, Wi, Ho, Wo):
+    return _Bilinear.apply(x, B, Hi, Wi, Ho, Wo)
+
+
+class _ClsHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        R, Cc = x.shape
+        y = torch.empty(R, 2, dtype=x.dtype, device=x.device)
+        K.check(K.lib.lavt_cls_head_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(_f32(weight)), K.ptr(_f32(bias)), K.ptr(y), R, Cc, K.stream()))
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        R, Cc = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)
+        db = torch.zeros(2, dtype=torch.float32, device=x.device)
+        K.check(K.lib.lavt_cls_head_bwd(K.dt(x.dtype), K.ptr(x), K.ptr(dy), K.ptr(_f32(weight)), K.ptr(dx), K.ptr(dw), K.ptr(db), R, Cc, K.stream()))
+        return dx, dw.view(weight.shape), db
+
+
+def cls_head(x, weight, bias):
+    assert weight.shape[0] == 2
+    return _ClsHead.apply(x, weight, bias)
+
+
+class _LogitsUp(torch.autograd.Function):
+    """NHWC [B*Hi*Wi, 2] -> NCHW fp32 [B, 2, Ho, Wo] bilinear, align_corners=True (lib/_utils.py:21)."""
+
+    @staticmethod
+    def forward(ctx, x, B, Hi, Wi, Ho, Wo):
+        x = x.contiguous()
+        y = torch.empty(B, 2, Ho, Wo, dtype=torch.float32, device=x.device)
+        K.check(K.lib.lavt_logits_up_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(y), B, Hi, Wi, Ho, Wo, K.stream()))
+        ctx.dims = (B, Hi, Wi, Ho, Wo, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Hi, Wi, Ho, Wo, dtype = ctx.dims
+        dy = dy.contiguous().float()
+        dx = torch.empty(B * Hi * Wi, 2, dtype=dtype, device=dy.device)
+        K.check(K.lib.lavt_logits_up_bwd(K.dt(dtype), K.ptr(dy), K.ptr(dx), B, Hi, Wi, Ho, Wo, K.stream()))
+        return dx, None, None, None, None, None
+
+
+def logits_upsample(x, B, Hi, Wi, Ho, Wo):
+    return _LogitsUp.apply(x, B, Hi, Wi, Ho, Wo)

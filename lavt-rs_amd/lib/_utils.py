@@ -1,0 +1,77 @@
+"""Top-level LAVT modules with the reference's forward signatures (lib/_utils.py:10-108).
+
+    LAVT(backbone, classifier).forward(x, l_feats, l_mask)        -> (B, 2, H, W) fp32 logits
+    LAVTOne(backbone, classifier, args).forward(x, text, l_mask)  (BERT inside)
+
+The backbone / decoder arithmetic is liblavt_hip; the final align_corners bilinear upsample writes
+the NCHW fp32 logits directly.  BERT (the absent ./bert package of the reference) is not part of the
+hot path: LAVTOne uses `bert.modeling_bert.BertModel` when importable, else transformers' BertModel.
+"""
+import os
+
+import torch
+from torch import nn
+
+from lavt_hip import ops
+from lavt_hip.runtime import compute_dtype
+from .mask_predictor import nchw_rows
+
+
+def _upsample_logits(y, size):
+    """y: (B, 2, h, w)-shaped decoder output -> (B, 2, H, W) fp32, bilinear align_corners=True (lib/_utils.py:21)."""
+    B, _, h, w = y.shape
+    return ops.logits_upsample(nchw_rows(y, y.dtype), B, h, w, int(size[0]), int(size[1]))
+
+
+class _LAVTSimpleDecode(nn.Module):
+    def __init__(self, backbone, classifier):
+        super().__init__()
+        self.backbone = backbone
+        self.classifier = classifier
+
+    def forward(self, x, l_feats, l_mask):
+        input_shape = x.shape[-2:]
+        x_c1, x_c2, x_c3, x_c4 = self.backbone(x, l_feats, l_mask)
+        y = self.classifier(x_c4, x_c3, x_c2, x_c1)
+        return _upsample_logits(y, input_shape)
+
+
+class LAVT(_LAVTSimpleDecode):
+    pass
+
+
+def _build_text_encoder(args):
+    ck = getattr(args, "ck_bert", "bert-base-uncased")
+    try:
+        from bert.modeling_bert import BertModel          # the reference's vendored HF v3.0.2 copy, if the user has it
+        enc = BertModel.from_pretrained(ck)
+    except ImportError:
+        from transformers import BertConfig, BertModel
+        enc = BertModel.from_pretrained(ck) if os.path.isdir(str(ck)) else BertModel(BertConfig())
+    enc.pooler = None
+    return enc
+
+
+class _LAVTOneSimpleDecode(nn.Module):
+    def __init__(self, backbone, classifier, args):
+        super().__init__()
+        self.backbone = backbone
+        self.classifier = classifier
+        self.text_encoder = _build_text_encoder(args)
+        self.lazy_pred = bool(getattr(args, "lazy_pred", False))
+
+    def forward(self, x, text, l_mask):
+        input_shape = x.shape[-2:]
+        l_feats = self.text_encoder(text, attention_mask=l_mask)[0].permute(0, 2, 1)      # (B, 768, N_l)
+        l_mask = l_mask.unsqueeze(dim=-1)
+        features = self.backbone(x, l_feats, l_mask)
+        if self.lazy_pred:
+            x_c1, (x_c2, x_c3, x_c4) = None, features
+        else:
+            x_c1, x_c2, x_c3, x_c4 = features
+        y = self.classifier(x_c4, x_c3, x_c2, x_c1)
+        return _upsample_logits(y, input_shape)
+
+
+class LAVTOne(_LAVTOneSimpleDecode):
+    pass

@@ -1,0 +1,241 @@
+"""GPU parity of the drop-in modules (lavt-rs_amd/lib/*) against (a) the golden vectors captured from the real
+reference and (b) the CPU oracle, forward and backward.  fp32 compute: logits within 1e-3 and identical argmax
+mask on decisive pixels (BASELINE.json north_star); bf16 compute: looser, stated per test."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lavt_hip.detweights import det_inputs, fill_state_dict_
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def randn(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator("cpu").manual_seed(seed))
+
+
+def close(got, ref, tol, name=""):
+    got = got.detach().float().cpu()
+    ref = torch.as_tensor(np.asarray(ref)).float()
+    assert got.shape == ref.shape, f"{name}: {tuple(got.shape)} vs {tuple(ref.shape)}"
+    err = float((got - ref).abs().max())
+    assert err <= tol, f"{name}: max abs err {err:.3e} > {tol:.1e}"
+
+
+ARGS = SimpleNamespace(swin_type="tiny")
+
+
+@pytest.fixture(autouse=True)
+def _fp32():
+    import lavt_hip
+    lavt_hip.set_compute_dtype(torch.float32)
+    yield
+    lavt_hip.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("tag", ["15_w12", "28_w7", "10_w7"])
+@pytest.mark.parametrize("shifted", [0, 1])
+def test_swin_block_golden(golden, tag, shifted):
+    from lib.backbone import SwinTransformerBlock
+    g = golden(f"block_{tag}_s{shifted}")
+    C, nH, ws, H, B = (int(g[k]) for k in ("C", "nH", "ws", "H", "B"))
+    blk = SwinTransformerBlock(C, nH, ws, shift_size=(ws // 2 if shifted else 0)).eval()
+    fill_state_dict_(blk)
+    blk.to(DEV)
+    blk.H = blk.W = H
+    y = blk(randn(int(g["seed"]), B, H * H, C).to(DEV))
+    close(y, g["y"], 2e-4, "swin block")
+
+
+@pytest.mark.parametrize("tag", ["even", "odd"])
+def test_patch_merging_golden(golden, tag):
+    from lib.backbone import PatchMerging
+    g = golden(f"patch_merging_{tag}")
+    H, W, C, B = (int(g[k]) for k in ("H", "W", "C", "B"))
+    pm = PatchMerging(C).eval()
+    fill_state_dict_(pm)
+    pm.to(DEV)
+    close(pm(randn(int(g["seed"]), B, H * W, C).to(DEV), H, W), g["y"], 1e-4, "patch merging")
+
+
+def test_patch_embed_golden(golden):
+    from lib.backbone import PatchEmbed
+    g = golden("patch_embed")
+    pe = PatchEmbed(4, 3, int(g["C"]), torch.nn.LayerNorm).eval()
+    fill_state_dict_(pe)
+    pe.to(DEV)
+    y = pe(randn(int(g["seed"]), *g["shape"].tolist()).to(DEV))
+    close(y, g["y"], 1e-4, "patch embed")
+
+
+@pytest.mark.parametrize("G", [1, 2])
+def test_pwam_golden(golden, G):
+    from lib.backbone import PWAM
+    g = golden(f"pwam_g{G}")
+    C, T = int(g["C"]), int(g["T"])
+    pw = PWAM(C, C, 768, C, C, num_heads=G, dropout=0.0).eval()
+    fill_state_dict_(pw)
+    pw.to(DEV)
+    x, l = randn(int(g["seeds"][0]), 2, T, C).to(DEV), randn(int(g["seeds"][1]), 2, 768, 20).to(DEV)
+    m = torch.zeros(2, 20, 1)
+    for b, n in enumerate(g["valid"].tolist()):
+        m[b, :n] = 1
+    m = m.to(DEV)
+    close(pw.image_lang_att(x, l, m), g["lang"], 2e-4, "sila")
+    close(pw(x, l, m), g["y"], 2e-4, "pwam")
+
+
+def test_stage_golden(golden):
+    from lib.backbone import MMBasicLayer, PatchMerging
+    g = golden("stage_10x9")
+    st = MMBasicLayer(dim=64, depth=2, num_heads=2, window_size=7, drop_path=0.0, downsample=PatchMerging, num_heads_fusion=1,
+                      fusion_drop=0.0, args=ARGS).eval()
+    fill_state_dict_(st)
+    st.to(DEV)
+    x, l = randn(int(g["seeds"][0]), 2, 90, 64).to(DEV), randn(int(g["seeds"][1]), 2, 768, 20).to(DEV)
+    m = torch.zeros(2, 20, 1)
+    for b, n in enumerate(g["valid"].tolist()):
+        m[b, :n] = 1
+    r, H, W, xd, Wh, Ww = st(x, 10, 9, l, m.to(DEV))
+    assert [H, W, Wh, Ww] == g["hw"].tolist()
+    close(r, g["r"], 3e-4, "stage feature")
+    close(xd, g["x_down"], 3e-4, "stage downsampled")
+
+
+def test_decoder_golden(golden):
+    from lib.mask_predictor import SimpleDecoding
+    g = golden("decoder_c64")
+    dec = SimpleDecoding(64, ARGS)
+    fill_state_dict_(dec)
+    dec.to(DEV)
+    feats = [randn(int(s), 2, c, hw, hw).to(DEV) for s, (c, hw) in zip(g["seeds"], ((64, 4), (32, 8), (16, 16), (8, 32)))]
+    close(dec.eval()(*feats), g["y_eval"], 2e-4, "decoder eval")
+    close(dec.train()(*feats), g["y_train"], 3e-4, "decoder train-mode BN")
+
+
+def _build(embed_dim, depths, heads, ws, dpr=0.3):
+    from lib._utils import LAVT
+    from lib.backbone import MultiModalSwinTransformer
+    from lib.mask_predictor import SimpleDecoding
+    bb = MultiModalSwinTransformer(embed_dim=embed_dim, depths=depths, num_heads=heads, window_size=ws, drop_path_rate=dpr, args=ARGS)
+    model = LAVT(bb, SimpleDecoding(8 * embed_dim, ARGS))
+    fill_state_dict_(model)
+    return model.to(DEV)
+
+
+def test_e2e_swin_t_224_golden(golden):
+    """BASELINE config 1: Swin-T LAVT, 1x224x224, 20 tokens (12 valid): logits <= 1e-3, mask identical on decisive pixels."""
+    g = golden("e2e_swin_t_224")
+    model = _build(96, [2, 2, 6, 2], [3, 6, 12, 24], 7).eval()
+    x, l, _, tgt = det_inputs(1, 224, 20, seed=int(g["seed"]))
+    m = torch.zeros(1, 20, 1)
+    m[0, : int(g["valid"])] = 1
+    with torch.no_grad():
+        feats = model.backbone(x.to(DEV), l.to(DEV), m.to(DEV))
+        logits = model(x.to(DEV), l.to(DEV), m.to(DEV))
+    close(feats[0][:, :, ::4, ::4], g["c1"], 1e-3, "c1")
+    close(feats[1][:, :, ::2, ::2], g["c2"], 1e-3, "c2")
+    close(feats[2], g["c3"], 1e-3, "c3")
+    close(feats[3], g["c4"], 1e-3, "c4")
+    close(logits, g["logits"], 1e-3, "logits")
+    ref_logits = torch.as_tensor(g["logits"])
+    decisive = (ref_logits[:, 1] - ref_logits[:, 0]).abs() > 2e-3
+    ref_mask = torch.as_tensor(np.unpackbits(g["mask"])[: 224 * 224].reshape(1, 224, 224)).bool()
+    pred = logits.argmax(1).bool().cpu()
+    assert torch.equal(pred[decisive], ref_mask[decisive]), "argmax mask differs on decisive pixels"
+    ties = int((~decisive).sum())
+    I, U = int((pred & tgt.bool()).sum()), int((pred | tgt.bool()).sum())
+    assert abs(I - int(g["I"])) <= ties and abs(U - int(g["U"])) <= ties
+    loss = F.cross_entropy(logits.cpu(), tgt, weight=torch.tensor([0.9, 1.1]))
+    assert abs(float(loss) - float(g["loss"])) < 1e-4
+
+
+def test_e2e_swin_b_w12_golden(golden):
+    g = golden("e2e_swin_b_w12_96")
+    model = _build(128, [2, 2, 18, 2], [4, 8, 16, 32], 12).eval()
+    x, l, m, tgt = det_inputs(2, 96, 20, seed=int(g["seed"]))
+    with torch.no_grad():
+        logits = model(x.to(DEV), l.to(DEV), m.to(DEV))
+    close(logits, g["logits"], 1e-3, "swin-b w12 logits")
+
+
+def grad_digest(t, n=24):
+    f = t.detach().reshape(-1).double().cpu()
+    step = max(f.numel() // (n // 2), 1)
+    samp = torch.cat([f[: n // 2], f[::step][: n // 2]])
+    samp = F.pad(samp, (0, n - samp.numel()))
+    return torch.cat([torch.stack([f.norm(), f.sum()]), samp]).float()
+
+
+def test_e2e_micro_train_grads_golden(golden):
+    """Train-mode forward + weighted CE + backward: every parameter gradient vs digests captured from the reference."""
+    g = golden("e2e_tiny_train")
+    model = _build(32, [2, 2, 2, 2], [1, 2, 4, 8], 7, dpr=0.0).train()
+    x, l, m, tgt = det_inputs(2, 64, 20, seed=int(g["seed"]))
+    x, l = x.to(DEV).requires_grad_(True), l.to(DEV).requires_grad_(True)
+    logits = model(x, l, m.to(DEV))
+    close(logits, g["logits"], 1e-3, "micro logits")
+    loss = F.cross_entropy(logits, tgt.to(DEV), weight=torch.tensor([0.9, 1.1], device=DEV))
+    assert abs(float(loss) - float(g["loss"])) < 1e-4
+    loss.backward()
+    nograd = set(g["nograd"].tolist())
+    bad = []
+    for k, p in model.named_parameters():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        ref = torch.as_tensor(g["g|" + k])
+        err = float((grad_digest(p.grad) - ref).abs().max())
+        if not err <= 2e-3 * max(float(ref[0]), 1e-6) + 5e-6:
+            bad.append((k, err, float(ref[0])))
+    assert not bad, f"{len(bad)} parameter gradients off: {bad[:8]}"
+    for name, t in (("dx", x.grad), ("dl", l.grad)):
+        ref = torch.as_tensor(g[name])
+        assert float((grad_digest(t) - ref).abs().max()) <= 2e-3 * float(ref[0]) + 5e-6, name
+
+
+def test_e2e_bf16_close_to_fp32(golden):
+    """bf16 compute path vs the fp32 golden logits: the reference's own CPU-autocast bf16 differs from fp32 by 2.5e-3 max
+    (logit sigma 0.026); our deterministic weights give O(1) logits, so the gate is relative:
+    max |dlogit| <= 6% of the logit range and mask agreement >= 97% on decisive pixels."""
+    import lavt_hip
+    g = golden("e2e_swin_t_224")
+    model = _build(96, [2, 2, 6, 2], [3, 6, 12, 24], 7).eval()
+    x, l, _, tgt = det_inputs(1, 224, 20, seed=int(g["seed"]))
+    m = torch.zeros(1, 20, 1)
+    m[0, : int(g["valid"])] = 1
+    with lavt_hip.use_dtype(torch.bfloat16), torch.no_grad():
+        logits = model(x.to(DEV), l.to(DEV), m.to(DEV)).cpu()
+    ref = torch.as_tensor(g["logits"])
+    rng = float(ref.max() - ref.min())
+    err = float((logits - ref).abs().max())
+    assert err <= 0.06 * rng, f"bf16 logits off by {err:.3e} (range {rng:.3e})"
+    decisive = (ref[:, 1] - ref[:, 0]).abs() > 0.05 * rng
+    agree = float((logits.argmax(1)[decisive] == ref.argmax(1)[decisive]).float().mean())
+    assert agree >= 0.97, f"bf16 mask agreement {agree:.4f}"
+
+
+def test_state_dict_roundtrip_and_keys():
+    from conftest import GOLDEN
+    model = _build(96, [2, 2, 6, 2], [3, 6, 12, 24], 7)
+    keys = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in model.state_dict().items())
+    assert keys == open(os.path.join(GOLDEN, "state_dict_keys_swin_t.txt")).read().split()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+
+
+def test_product_never_imports_oracle():
+    import sys
+    import lib.segmentation  # noqa: F401
+    import lavt_hip.ops  # noqa: F401
+    mods = [m for m in sys.modules if m.startswith("lib.") or m.startswith("lavt_hip")]
+    for name in mods:
+        src = getattr(sys.modules[name], "__file__", None)
+        if src and src.endswith(".py"):
+            text = open(src).read()
+            assert "import oracle" not in text and "from oracle" not in text, name

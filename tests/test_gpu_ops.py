@@ -1,0 +1,345 @@
+"""GPU parity of every liblavt_hip op (through the C ABI) against plain fp32 PyTorch-on-CPU statements of
+the same op (autograd gives the gradient oracle).  fp32 path: tight tolerances (exact-fp32 MFMA);
+bf16 path: tolerance relative to the output scale (bf16 has 8 significant bits).
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (run with -m 'not gpu' elsewhere)"
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator("cpu").manual_seed(seed)) * scale
+
+
+def tol(dtype, ref, f32=2e-4, bf16=3e-2):
+    scale = float(ref.abs().max())
+    return f32 * max(scale, 1.0) if dtype == torch.float32 else bf16 * max(scale, 1e-3)
+
+
+def assert_close(got, ref, dtype, name="", f32=2e-4, bf16=3e-2):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    err = float((got - ref).abs().max())
+    t = tol(dtype, ref, f32, bf16)
+    assert math.isfinite(err) and err <= t, f"{name}: max abs err {err:.3e} > {t:.3e} (ref scale {float(ref.abs().max()):.3e})"
+
+
+def run_pair(hip_fn, ref_fn, inputs, dtype, requires=None, f32=2e-4, bf16=3e-2, name=""):
+    """inputs: dict name -> (cpu fp32 tensor, kind) with kind in {'act','param','const'}.
+    act tensors are cast to `dtype` on the GPU, params stay fp32.  Compares outputs and all gradients."""
+    from lavt_hip import ops
+    d = dev()
+    cpu, gpu = {}, {}
+    for k, (t, kind) in inputs.items():
+        if kind == "const":
+            cpu[k], gpu[k] = t, (t.to(d) if isinstance(t, torch.Tensor) else t)
+            continue
+        c = t.clone()
+        if kind == "act" and dtype == torch.bfloat16:
+            c = c.to(torch.bfloat16).float()          # both sides start from the same rounded activations
+        c.requires_grad_(True)
+        g = c.detach().to(d)
+        if kind == "act":
+            g = g.to(dtype)
+        g.requires_grad_(True)
+        cpu[k], gpu[k] = c, g
+    ops.weights.invalidate()
+    y_ref = ref_fn(**cpu)
+    y = hip_fn(**gpu)
+    assert_close(y, y_ref, dtype, name + " forward", f32, bf16)
+    go = rnd(*y_ref.shape, seed=99)
+    if dtype == torch.bfloat16:
+        go = go.to(torch.bfloat16).float()
+    y_ref.backward(go)
+    y.backward(go.to(d).to(y.dtype))
+    torch.cuda.synchronize()
+    for k, (t, kind) in inputs.items():
+        if kind == "const":
+            continue
+        assert gpu[k].grad is not None, f"{name}: no grad for {k}"
+        assert_close(gpu[k].grad, cpu[k].grad, dtype, f"{name} grad[{k}]", f32 * 5, bf16 * 1.5)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,Kd", [(300, 200, 96), (3072, 1024, 128), (77, 24, 48), (640, 384, 512)])
+def test_linear_plain(dtype, M, N, Kd):
+    from lavt_hip import ops
+    inputs = {"x": (rnd(M, Kd, seed=1), "act"), "w": (rnd(N, Kd, seed=2, scale=Kd ** -0.5), "param"), "b": (rnd(N, seed=3), "param")}
+    run_pair(lambda x, w, b: ops.linear(x, w, b), lambda x, w, b: F.linear(x, w, b), inputs, dtype, name=f"linear {M}x{N}x{Kd}")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_linear_gelu_residual(dtype):
+    from lavt_hip import ops
+    from lavt_hip._capi import ACT_GELU, ACT_RELU
+    M, N, Kd = 520, 256, 64
+    inputs = {"x": (rnd(M, Kd, seed=1), "act"), "w": (rnd(N, Kd, seed=2, scale=Kd ** -0.5), "param"), "b": (rnd(N, seed=3), "param"),
+              "r": (rnd(M, N, seed=4), "act")}
+    run_pair(lambda x, w, b, r: ops.linear(x, w, b, residual=r, act=ACT_GELU),
+             lambda x, w, b, r: F.gelu(F.linear(x, w, b)) + r, inputs, dtype, name="linear+gelu+res")
+    inputs = {"x": inputs["x"], "w": inputs["w"]}
+    run_pair(lambda x, w: ops.linear(x, w, None, act=ACT_RELU), lambda x, w: F.relu(F.linear(x, w)), inputs, dtype, name="linear+relu")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,W,ws,shift", [(2, 10, 9, 7, 3), (1, 15, 15, 12, 6), (2, 14, 14, 7, 0), (2, 24, 24, 12, 6)])
+def test_linear_window_gather_scatter(dtype, B, H, W, ws, shift):
+    """qkv-style gather (zero rows for padding) and proj-style scatter + residual + per-sample DropPath factor."""
+    from lavt_hip import ops, rowmaps
+    C, N = 64, 96
+    wmap_np = rowmaps.window_map_np(B, H, W, ws, shift)
+    wmap = torch.from_numpy(wmap_np).to(dev())
+    idx = torch.from_numpy(wmap_np.astype(np.int64))
+    M = idx.numel()
+
+    def ref_gather(x, w, b):
+        xz = torch.cat([x, torch.zeros(1, x.shape[1])], 0)
+        return F.linear(xz[idx], w, b)          # idx -1 -> the appended zero row
+    inputs = {"x": (rnd(B * H * W, C, seed=1), "act"), "w": (rnd(N, C, seed=2, scale=C ** -0.5), "param"), "b": (rnd(N, seed=3), "param")}
+    run_pair(lambda x, w, b: ops.linear(x, w, b, in_map=wmap, rows=M), ref_gather, inputs, dtype, name="gather linear")
+
+    fac = torch.tensor([0.0, 1.0 / 0.7][:B] if B > 1 else [1.0 / 0.7])
+    fac_d = fac.to(dev())
+
+    def ref_scatter(a, w, b, r):
+        y = F.linear(a, w, b) * fac.repeat_interleave(M // B)[:, None]
+        keep = idx >= 0
+        out = r.clone()
+        out = out.index_add(0, idx[keep], y[keep])
+        return out
+    inputs = {"a": (rnd(M, N, seed=5), "act"), "w": (rnd(C, N, seed=6, scale=N ** -0.5), "param"), "b": (rnd(C, seed=7), "param"),
+              "r": (rnd(B * H * W, C, seed=8), "act")}
+    run_pair(lambda a, w, b, r: ops.linear(a, w, b, residual=r, out_map=wmap, rows=M, out_rows=B * H * W, row_scale=fac_d, row_scale_div=M // B),
+             ref_scatter, inputs, dtype, name="scatter linear")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(2, 9, 7, 64, 32, 64), (1, 30, 30, 128, 0, 128), (2, 16, 16, 384, 96, 128), (2, 64, 64, 64, 32, 256)])
+def test_conv3x3(dtype, B, H, W, C1, C2, Cout):
+    from lavt_hip import ops
+    Cin = C1 + C2
+    inputs = {"x1": (rnd(B * H * W, C1, seed=1), "act"), "w": (rnd(Cout, Cin, 3, 3, seed=3, scale=(9 * Cin) ** -0.5), "param")}
+    if C2:
+        inputs["x2"] = (rnd(B * H * W, C2, seed=2), "act")
+
+    def ref(x1, w, x2=None):
+        x = x1 if x2 is None else torch.cat([x1, x2], 1)
+        y = F.conv2d(x.view(B, H, W, Cin).permute(0, 3, 1, 2), w, padding=1)
+        return y.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    run_pair(lambda x1, w, x2=None: ops.conv3x3(x1, x2, w, B, H, W), ref, inputs, dtype, name="conv3x3", bf16=4e-2)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("ws,heads,H,shift", [(7, 3, 14, 3), (7, 2, 14, 0), (12, 4, 24, 6), (12, 2, 12, 6)])
+def test_window_attention(dtype, ws, heads, H, shift):
+    from lavt_hip import ops, rowmaps
+    from oracle import lavt_oracle as O
+    N, C = ws * ws, heads * 32
+    nW = (H // ws) ** 2
+    Bw = 2 * nW
+    region_np = rowmaps.region_ids_np(H, H, ws, shift) if shift else None
+    region = torch.from_numpy(region_np).to(dev()) if shift else None
+    mask = O.shift_mask(H, H, ws, shift) if shift else None
+    idx = O.rel_pos_index(ws).reshape(-1)
+
+    def ref(qkv, table):
+        q, k, v = qkv.view(Bw, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+        a = (q * 32 ** -0.5) @ k.transpose(-1, -2) + table[idx].view(N, N, heads).permute(2, 0, 1)[None]
+        if mask is not None:
+            a = (a.view(Bw // nW, nW, heads, N, N) + mask[None, :, None]).view(Bw, heads, N, N)
+        return (a.softmax(-1) @ v).transpose(1, 2).reshape(Bw * N, C)
+    inputs = {"qkv": (rnd(Bw * N, 3 * C, seed=1), "act"), "table": (rnd((2 * ws - 1) ** 2, heads, seed=2, scale=0.5), "param")}
+    run_pair(lambda qkv, table: ops.window_attention(qkv, table, region, ws, heads), ref, inputs, dtype, name="window attention")
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,C", [(50, 96), (333, 128), (64, 1024), (9, 2048)])
+def test_layernorm(dtype, rows, C):
+    from lavt_hip import ops
+    inputs = {"x": (rnd(rows, C, seed=1) + 0.3, "act"), "g": (1 + 0.1 * rnd(C, seed=2), "param"), "b": (0.1 * rnd(C, seed=3), "param")}
+    run_pair(lambda x, g, b: ops.layer_norm(x, g, b), lambda x, g, b: F.layer_norm(x, (C,), g, b), inputs, dtype, name="layernorm")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 6, 32), (2, 7, 5, 64), (1, 15, 15, 128)])
+def test_merge_layernorm(dtype, B, H, W, C):
+    from lavt_hip import ops, rowmaps
+    gm = torch.from_numpy(rowmaps.merge_map_np(B, H, W)).to(dev())
+
+    def ref(x, g, b):
+        z = F.pad(x.view(B, H, W, C), (0, 0, 0, W % 2, 0, H % 2))
+        z = torch.cat([z[:, 0::2, 0::2], z[:, 1::2, 0::2], z[:, 0::2, 1::2], z[:, 1::2, 1::2]], -1).reshape(-1, 4 * C)
+        return F.layer_norm(z, (4 * C,), g, b)
+    inputs = {"x": (rnd(B * H * W, C, seed=1), "act"), "g": (1 + 0.1 * rnd(4 * C, seed=2), "param"), "b": (0.1 * rnd(4 * C, seed=3), "param")}
+    run_pair(lambda x, g, b: ops.layer_norm(x, g, b, gather=gm), ref, inputs, dtype, name="merge layernorm")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,T,C,with_mul", [(2, 90, 64, False), (2, 3136, 96, True), (1, 225, 1024, True)])
+def test_instance_norm(dtype, B, T, C, with_mul):
+    from lavt_hip import ops
+
+    def ref(x, mul=None):
+        z = x.view(B, T, C)
+        y = (z - z.mean(1, keepdim=True)) / torch.sqrt(z.var(1, unbiased=False, keepdim=True) + 1e-5)
+        y = y.reshape(B * T, C)
+        return y * mul if mul is not None else y
+    inputs = {"x": (rnd(B * T, C, seed=1) * 2 + 0.5, "act")}
+    if with_mul:
+        inputs["mul"] = (rnd(B * T, C, seed=2), "act")
+    run_pair(lambda x, mul=None: ops.instance_norm(x, B, T, mul=mul), ref, inputs, dtype, name="instance norm", bf16=5e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm_relu(dtype, training):
+    from lavt_hip import ops
+    R, C = 2 * 12 * 12, 64
+    bn_ref = torch.nn.BatchNorm2d(C)
+    bn_hip = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        for bn in (bn_ref, bn_hip):
+            bn.weight.copy_(1 + 0.2 * rnd(C, seed=2)); bn.bias.copy_(0.2 * rnd(C, seed=3))
+            bn.running_mean.copy_(0.1 * rnd(C, seed=4)); bn.running_var.copy_(1 + 0.3 * rnd(C, seed=5).abs())
+    bn_ref.train(training); bn_hip.train(training)
+    bn_hip.to(dev())
+    x = rnd(R, C, seed=1) * 1.5 + 0.2
+    xc = (x.to(dtype).float() if dtype == torch.bfloat16 else x).clone().requires_grad_(True)
+    xg = xc.detach().to(dev()).to(dtype).requires_grad_(True)
+    y_ref = F.relu(bn_ref(xc.view(2, 12, 12, C).permute(0, 3, 1, 2))).permute(0, 2, 3, 1).reshape(R, C)
+    y = ops.batch_norm_relu(xg, bn_hip)
+    assert_close(y, y_ref, dtype, "bn forward", bf16=4e-2)
+    go = rnd(R, C, seed=9)
+    y_ref.backward(go)
+    y.backward(go.to(dev()).to(dtype))
+    assert_close(xg.grad, xc.grad, dtype, "bn dx", 1e-3, 5e-2)
+    assert_close(bn_hip.weight.grad, bn_ref.weight.grad, dtype, "bn dgamma", 1e-3, 5e-2)
+    assert_close(bn_hip.bias.grad, bn_ref.bias.grad, dtype, "bn dbeta", 1e-3, 5e-2)
+    if training:
+        assert_close(bn_hip.running_mean, bn_ref.running_mean, torch.float32, "running_mean", 1e-4 if dtype == torch.float32 else 2e-2)
+        assert_close(bn_hip.running_var, bn_ref.running_var, torch.float32, "running_var", 1e-4 if dtype == torch.float32 else 3e-2)
+        assert int(bn_hip.num_batches_tracked) == 1
+
+
+# ------------------------------------------------------------------------------------------------ PWAM pieces
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("G", [1, 2])
+def test_pwam_attention(dtype, G):
+    from lavt_hip import ops
+    B, T, C, n_l, LD = 2, 90, 64, 20, 32
+    valid = [9, 15]
+    m = torch.zeros(B, n_l)
+    for b, n in enumerate(valid):
+        m[b, :n] = 1
+    maskbias = torch.full((B, LD), -1e4)
+    maskbias[:, :n_l] = 1e4 * m - 1e4
+
+    def pad(t):       # (B*LD, C) with rows >= n_l (and masked words) zero, as the K/V projections produce
+        z = torch.zeros(B, LD, C)
+        z[:, :n_l] = t.view(B, n_l, C) * m[:, :, None]
+        return z.view(B * LD, C)
+
+    def ref(q, k, v):
+        qh = q.view(B, T, G, C // G).transpose(1, 2)
+        kh = k.view(B, LD, G, C // G)[:, :n_l].permute(0, 2, 3, 1)
+        vh = v.view(B, LD, G, C // G)[:, :n_l].transpose(1, 2)
+        s = (qh @ kh) * C ** -0.5 + (1e4 * m[:, None, None, :] - 1e4)
+        return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B * T, C)
+    inputs = {"q": (rnd(B * T, C, seed=1), "act"), "k": (pad(rnd(B * n_l, C, seed=2)), "act"), "v": (pad(rnd(B * n_l, C, seed=3)), "act")}
+    mb = maskbias.to(dev())
+    # gradients of k/v are only meaningful on valid rows: compare through a masked loss by masking the reference grads too
+    from lavt_hip import ops as _o
+    d = dev()
+    cpu = {k: t.clone().requires_grad_(True) for k, (t, _) in inputs.items()}
+    if dtype == torch.bfloat16:
+        cpu = {k: t.detach().to(torch.bfloat16).float().requires_grad_(True) for k, t in cpu.items()}
+    gpu = {k: t.detach().to(d).to(dtype).requires_grad_(True) for k, t in cpu.items()}
+    y_ref = ref(**cpu)
+    y = _o.pwam_attention(gpu["q"], gpu["k"], gpu["v"], mb, B, T, n_l, G)
+    assert_close(y, y_ref, dtype, "pwam attention")
+    go = rnd(B * T, C, seed=7)
+    y_ref.backward(go)
+    y.backward(go.to(d).to(dtype))
+    rowmask = torch.zeros(B, LD, 1)
+    rowmask[:, :n_l] = m[:, :, None]
+    rowmask = rowmask.view(B * LD, 1)
+    assert_close(gpu["q"].grad, cpu["q"].grad, dtype, "pwam dq", 1e-3)
+    assert_close(gpu["k"].grad.float().cpu() * rowmask, cpu["k"].grad * rowmask, dtype, "pwam dk", 1e-3)
+    assert_close(gpu["v"].grad.float().cpu() * rowmask, cpu["v"].grad * rowmask, dtype, "pwam dv", 1e-3)
+    assert float((gpu["k"].grad.float().cpu() * (1 - rowmask)).abs().max()) == 0.0      # masked / padded words get exactly 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gate(dtype):
+    from lavt_hip import ops
+    n = (300, 64)
+    inputs = {"x": (rnd(*n, seed=1), "act"), "g": (rnd(*n, seed=2), "act"), "r": (rnd(*n, seed=3), "act")}
+    run_pair(lambda x, g, r: ops.gate(x, g, r), lambda x, g, r: x + torch.tanh(g) * r, inputs, dtype, name="gate")
+
+
+# ------------------------------------------------------------------------------------------------ decoder / boundary pieces
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo", [(4, 4, 8, 8), (15, 15, 30, 30), (7, 5, 14, 9), (3, 3, 3, 7)])
+def test_bilinear(dtype, Hi, Wi, Ho, Wo):
+    from lavt_hip import ops
+    B, C = 2, 32
+
+    def ref(x):
+        y = F.interpolate(x.view(B, Hi, Wi, C).permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=True)
+        return y.permute(0, 2, 3, 1).reshape(B * Ho * Wo, C)
+    run_pair(lambda x: ops.bilinear(x, B, Hi, Wi, Ho, Wo), ref, {"x": (rnd(B * Hi * Wi, C, seed=1), "act")}, dtype, name="bilinear")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_cls_head_and_logits_up(dtype):
+    from lavt_hip import ops
+    B, h, w, C, H, W = 2, 14, 12, 64, 56, 48
+
+    def ref(x, wt, b):
+        y = F.conv2d(x.view(B, h, w, C).permute(0, 3, 1, 2), wt, b)
+        return F.interpolate(y, size=(H, W), mode="bilinear", align_corners=True)
+    inputs = {"x": (rnd(B * h * w, C, seed=1), "act"), "wt": (rnd(2, C, 1, 1, seed=2, scale=C ** -0.5), "param"), "b": (rnd(2, seed=3), "param")}
+    run_pair(lambda x, wt, b: ops.logits_upsample(ops.cls_head(x, wt, b), B, h, w, H, W), ref, inputs, dtype, name="cls head + upsample")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_patch_embed(dtype):
+    from lavt_hip import ops
+    B, H, W, C0 = 2, 30, 27, 48
+
+    def ref(img, wt, b):
+        x = F.pad(img, (0, (-W) % 4, 0, (-H) % 4))
+        return F.conv2d(x, wt, b, stride=4).flatten(2).transpose(1, 2).reshape(-1, C0)
+    inputs = {"img": (rnd(B, 3, H, W, seed=1), "param"), "wt": (rnd(C0, 3, 4, 4, seed=2, scale=48 ** -0.5), "param"), "b": (rnd(C0, seed=3), "param")}
+    run_pair(lambda img, wt, b: ops.patch_embed(img, wt, b, dtype), ref, inputs, dtype, name="patch embed")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_transpose_boundary(dtype):
+    from lavt_hip import ops
+    x = rnd(2, 70, 45, seed=1)
+    run_pair(lambda x: ops.transpose_last2(x), lambda x: x.transpose(1, 2).contiguous(), {"x": (x, "act")}, dtype, name="transpose")
+
+
+def test_cpu_tensor_is_refused():
+    from lavt_hip import ops
+    with pytest.raises(RuntimeError, match="GPU memory only"):
+        ops.linear(torch.zeros(8, 8), torch.zeros(8, 8))

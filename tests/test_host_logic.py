@@ -1,0 +1,107 @@
+"""CPU tests (-m "not gpu"): host logic of the product (row maps, factories, state-dict keys), that the C-ABI
+library loads and exports every symbol of include/lavt_hip.h, and that the product refuses to run without a GPU."""
+import os
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, ROOT
+from lavt_hip import rowmaps
+from oracle import lavt_oracle as O
+
+
+@pytest.mark.parametrize("B,H,W,ws,shift", [(2, 10, 9, 7, 3), (1, 15, 15, 12, 6), (2, 14, 14, 7, 0), (1, 30, 30, 12, 6), (1, 7, 7, 7, 3)])
+def test_window_map_matches_pad_roll_partition(B, H, W, ws, shift):
+    """The gather table reproduces pad -> roll -> window_partition, and doubles as the reverse scatter."""
+    C = 3
+    x = torch.arange(B * H * W * C, dtype=torch.float32).view(B, H, W, C) + 1
+    Hp, Wp = rowmaps.padded(H, ws), rowmaps.padded(W, ws)
+    u = F.pad(x, (0, 0, 0, Wp - W, 0, Hp - H))
+    if shift:
+        u = torch.roll(u, (-shift, -shift), (1, 2))
+    win = u.view(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, C)
+    m = torch.from_numpy(rowmaps.window_map_np(B, H, W, ws, shift).astype(np.int64))
+    flat = torch.cat([x.view(-1, C), torch.zeros(1, C)])
+    assert torch.equal(flat[m], win)
+    real = m[m >= 0]
+    assert real.numel() == B * H * W and torch.equal(real.sort().values, torch.arange(B * H * W))   # each token exactly once
+
+
+@pytest.mark.parametrize("H,ws", [(126, 7), (36, 12), (24, 12), (7, 7), (14, 7), (30, 12)])
+def test_region_ids_match_golden_masks(golden, H, ws):
+    ids = torch.from_numpy(rowmaps.region_ids_np(H, H, ws, ws // 2).astype(np.int64))
+    mask = torch.where(ids[:, :, None] == ids[:, None, :], 0.0, -100.0)
+    assert torch.equal(mask, O.shift_mask(rowmaps.padded(H, ws), rowmaps.padded(H, ws), ws, ws // 2))
+    g = golden("shift_masks")
+    key = f"m_{rowmaps.padded(H, ws)}_{ws}"
+    if key in g.files and H == rowmaps.padded(H, ws):
+        assert np.array_equal(np.packbits((mask != 0).numpy().reshape(-1)), g[key])
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 8, 6), (2, 7, 5), (1, 15, 15)])
+def test_merge_map(B, H, W):
+    C = 2
+    x = torch.arange(B * H * W * C, dtype=torch.float32).view(B, H, W, C) + 1
+    z = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    ref = torch.cat([z[:, 0::2, 0::2], z[:, 1::2, 0::2], z[:, 0::2, 1::2], z[:, 1::2, 1::2]], -1).reshape(-1, 4 * C)
+    m = torch.from_numpy(rowmaps.merge_map_np(B, H, W).astype(np.int64))
+    flat = torch.cat([x.view(-1, C), torch.zeros(1, C)])
+    assert torch.equal(flat[m].reshape(-1, 4 * C), ref)
+
+
+def test_library_exports_every_declared_symbol():
+    from lavt_hip import _capi
+    header = open(os.path.join(ROOT, "include", "lavt_hip.h")).read()
+    declared = set(re.findall(r"\b(lavt_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_capi.EXPORTED), declared ^ set(_capi.EXPORTED)
+    for name in declared:
+        assert hasattr(_capi.lib, name), f"liblavt_hip.so does not export {name}"
+    assert _capi.lib.lavt_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirrors of the parameter structs have one field per header member, in order."""
+    from lavt_hip import _capi
+    header = open(os.path.join(ROOT, "include", "lavt_hip.h")).read()
+    for cname, st in (("lavt_gemm_nt", _capi.GemmNT), ("lavt_gemm_tn", _capi.GemmTN)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s_t;" % (cname, cname), header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                names.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", part.strip())[0])
+        assert names == [f[0] for f in st._fields_], (cname, names, [f[0] for f in st._fields_])
+
+
+@pytest.mark.parametrize("variant,keys_file,w12", [("tiny", "state_dict_keys_swin_t.txt", False), ("base", "state_dict_keys_swin_b_w12.txt", True)])
+def test_factory_state_dict_keys(variant, keys_file, w12):
+    from lib import segmentation
+    model = segmentation.lavt("", SimpleNamespace(swin_type=variant, window12=w12))
+    keys = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in model.state_dict().items())
+    assert keys == open(os.path.join(GOLDEN, keys_file)).read().split()
+    nodecay = [n for n, _ in model.backbone.named_parameters() if "norm" in n or "relative_position_bias_table" in n]
+    assert nodecay and all(hasattr(model, a) for a in ("backbone", "classifier"))
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a GPU: no CPU / eager fallback exists."""
+    from lib import segmentation
+    from lavt_hip.detweights import det_inputs
+    model = segmentation.lavt("", SimpleNamespace(swin_type="tiny")).eval()
+    x, l, m, _ = det_inputs(1, 64, 20)
+    with pytest.raises(RuntimeError, match="GPU memory only"):
+        model(x, l, m)
+
+
+def test_sync_bn_conversion_is_seen():
+    from lib.mask_predictor import SimpleDecoding
+    dec = torch.nn.SyncBatchNorm.convert_sync_batchnorm(SimpleDecoding(64, SimpleNamespace()))
+    assert isinstance(dec.bn1_4, torch.nn.SyncBatchNorm) and "bn1_4.running_var" in dec.state_dict()
