@@ -50,8 +50,8 @@ def run_pair(hip_fn, ref_fn, inputs, dtype, requires=None, f32=2e-4, bf16=3e-2, 
             cpu[k], gpu[k] = t, (t.to(d) if isinstance(t, torch.Tensor) else t)
             continue
         c = t.clone()
-        if kind == "act" and dtype == torch.bfloat16:
-            c = c.to(torch.bfloat16).float()          # both sides start from the same rounded activations
+        if dtype == torch.bfloat16:
+            c = c.to(torch.bfloat16).float()          # both sides start from the same bf16-representable values
         c.requires_grad_(True)
         g = c.detach().to(d)
         if kind == "act":
