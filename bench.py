@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""LAVT hot-path benchmark on MI355X.   python bench.py --gpus N --steps K --warmup W
+(N > 1: launched by torch.distributed.run, one rank per GPU, RCCL.)
+
+Workload (BASELINE.json metric: train images/s, 480x480 Swin-B LAVT): Swin-B window-12 LAVT, bf16 compute,
+batch 2 per GPU (configs[2] of BASELINE.json, the per-GPU shard of the headline config; weak scaling), synthetic
+480x480 images + 20-token language embeddings, deterministic random-init weights.  One step = forward +
+weighted cross-entropy + backward (+ gradient all-reduce when N > 1); the optimizer is excluded.
+
+Prints ONE JSON line on rank 0 with the driver's contract plus
+  "roofline":     the dominant kernel (bf16 MFMA implicit-GEMM 3x3 conv, decoder conv2_2 shape) timed live with HIP events,
+  "cpu_baseline": the CPU oracle (oracle/lavt_oracle.py, a port of the reference) timed on the host cores (N=1, rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "lavt-rs_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FWD_GFLOP_PER_IMAGE = {"swin_b_w12_480": 394.57, "swin_t_w7_480": 172.43}      # SURVEY.md 8 (2*MAC, padded tokens counted)
+BF16_DENSE_PEAK_TFLOPS = 2500.0                                                 # MI355X_MICROARCH.md (dense, no sparsity)
+
+WORKLOADS = {
+    "swin_b_w12_480_b2": dict(variant="base", window12=True, batch=2, size=480, flops="swin_b_w12_480"),
+    "swin_t_w7_480_b8": dict(variant="tiny", window12=False, batch=8, size=480, flops="swin_t_w7_480"),
+}
+
+
+def build_model(cfg, device, drop_path=0.3):
+    from types import SimpleNamespace
+    from lavt_hip.detweights import fill_state_dict_
+    from lib import segmentation
+    args = SimpleNamespace(swin_type=cfg["variant"], window12=cfg["window12"], drop_path_rate=drop_path)
+    model = segmentation.lavt("", args)
+    fill_state_dict_(model)
+    return model.to(device)
+
+
+def measure_dominant_kernel(device, iters=20):
+    """Decoder conv2_2 of Swin-B at batch 2: implicit GEMM M=2*120*120, N=512, K=9*512, bf16 MFMA.  Algorithmic flops
+    per launch = 2*M*N*K; duration = HIP events around `iters` back-to-back launches on the launch stream."""
+    from lavt_hip import ops
+    B, H, W, Cin, Cout = 2, 120, 120, 512, 512
+    x = torch.randn(B * H * W, Cin, device=device).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, device=device) * (9 * Cin) ** -0.5
+    with torch.no_grad():
+        for _ in range(3):
+            y = ops.conv3x3(x, None, w, B, H, W)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            y = ops.conv3x3(x, None, w, B, H, W)
+        e1.record()
+        torch.cuda.synchronize()
+    del y
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * B * H * W * Cout * 9 * Cin
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_nt_kernel<bf16,128,128> (conv3x3 512->512 @120x120, batch 2)", "achieved": round(achieved, 2),
+            "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4),
+            "avg_launch_us": round(ms * 1e3, 2), "flops_per_launch": flops, "traffic": None}
+
+
+def cpu_baseline(cfg, budget_s=25.0):
+    """The CPU oracle (fp32 port of the reference path) on this host: one forward+backward of ONE image of the workload."""
+    from lavt_hip.detweights import det_inputs, det_tensor
+    from oracle import lavt_oracle as O
+    keys = os.path.join(ROOT, "tests", "golden", "state_dict_keys_swin_b_w12.txt" if cfg["variant"] == "base" else "state_dict_keys_swin_t.txt")
+    sd = {}
+    for line in open(keys):
+        k, shp = line.strip().split("|")
+        if k.endswith("relative_position_index"):
+            continue
+        shape = tuple(int(s) for s in shp.split("x")) if shp else ()
+        t = det_tensor(k, shape, torch.long if k.endswith("num_batches_tracked") else torch.float32)
+        sd[k] = t.requires_grad_(True) if t.dtype.is_floating_point and "running_" not in k else t
+    x, l, m, tgt = det_inputs(1, cfg["size"], 20, seed=1234)
+    ws = 12 if cfg["window12"] else 7
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        loss = O.weighted_ce(O.lavt_forward(sd, x, l, m, cfg["variant"], ws, training=True), tgt)
+        loss.backward()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s * 0.5 or n >= 3:
+            break
+    return {"value": round(n / el, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} x (1 image {cfg['size']}x{cfg['size']}, fp32 forward+CE+backward of the CPU oracle), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="swin_b_w12_480_b2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--drop-path", type=float, default=0.3)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world == 1:
+        print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import lavt_hip
+    from lavt_hip.detweights import det_inputs
+    from lavt_hip.engine import TrainStep
+    cfg = WORKLOADS[a.workload]
+    lavt_hip.set_compute_dtype(a.dtype)
+    model = build_model(cfg, device, a.drop_path)
+    if world > 1:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)       # train.py:589
+    model.train()
+    x, l, m, tgt = det_inputs(cfg["batch"], cfg["size"], 20, seed=1234 + rank)
+    step = TrainStep(model, x.to(device), l.to(device), m.to(device), tgt.to(device), world=world, use_graph=not a.no_graph)
+    step.warmup_and_capture()
+
+    for _ in range(a.warmup):
+        step.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(step.loss)
+
+    if rank == 0:
+        images = cfg["batch"] * world * a.steps
+        value = images / elapsed
+        ms = elapsed / a.steps * 1e3
+        train_tflops = 3.0 * FWD_GFLOP_PER_IMAGE[cfg["flops"]] * 1e-3 * value
+        out = {
+            "metric": "train images/sec (480x480 Swin-B LAVT, fwd+bwd)" if cfg["variant"] == "base" else "train images/sec (480x480 Swin-T LAVT, fwd+bwd)",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": a.workload, "global_batch": cfg["batch"] * world, "image": cfg["size"], "n_l": 20,
+                       "parallelism": f"dp{world}", "hip_graph": bool(step.captured), "drop_path": a.drop_path,
+                       "loss": round(loss, 5), "step_tflops_3x_fwd": round(train_tflops, 2),
+                       "mfma_frac_of_step": round(train_tflops / world / BF16_DENSE_PEAK_TFLOPS, 4)},
+        }
+        try:
+            out["roofline"] = measure_dominant_kernel(device)
+        except Exception as e:  # noqa: BLE001
+            out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

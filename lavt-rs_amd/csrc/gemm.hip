@@ -13,6 +13,8 @@
 // Row gather on the A side (window partition / shift / zero padding, 3x3 taps with zero halo, concat of two
 // sources) and row scatter + residual on the C side are folded into the tile loads / stores: no im2col,
 // no permute/roll/pad/cat copies ever touch HBM.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -276,13 +278,27 @@ template <typename T, int BM, int BN, bool BKM> int launch_nt(const lavt_gemm_nt
     constexpr int B_TILE = BKM ? BK * (BN + KM_PAD) : BN * Cfg<T>::KC_LD;
     const size_t lds = 2 * (size_t)(A_TILE + B_TILE) * sizeof(T);
     dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch);
+    static bool attr_set = false;      // > 64 KiB of dynamic LDS must be requested once per kernel
+    if (!attr_set && lds > 65536) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN, BKM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            lavt_set_error("lavt_gemm_nt: cannot reserve %zu bytes of LDS", lds);
+            return LAVT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
     hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, BKM>), grid, dim3(256), lds, st, p);
     LAVT_CHECK_LAUNCH("lavt_gemm_nt");
     return LAVT_OK;
 }
+// LAVT_GEMM_TILE=128|64 forces a tile configuration (tests exercise both); unset = shape heuristic.
+static int forced_tile() {
+    const char* e = getenv("LAVT_GEMM_TILE");
+    return e ? atoi(e) : 0;
+}
 template <typename T> int dispatch_nt(const lavt_gemm_nt_t& p, hipStream_t st) {
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
-    const bool big = tiles128 >= 192 && p.N > 64;
+    const int force = forced_tile();
+    const bool big = force ? force == 128 : (tiles128 >= 192 && p.N > 64);
     if (p.b_kmajor) return big ? launch_nt<T, 128, 128, true>(p, st) : launch_nt<T, 64, 64, true>(p, st);
     return big ? launch_nt<T, 128, 128, false>(p, st) : launch_nt<T, 64, 64, false>(p, st);
 }
@@ -446,12 +462,21 @@ template <typename T, int BI, int BJ> int launch_tn(const lavt_gemm_tn_t& p, hip
     const int per = cdiv(ktiles, split);
     split = cdiv(ktiles, per);
     dim3 grid(tiles, p.batch, split);
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, BI, BJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            lavt_set_error("lavt_gemm_tn: cannot reserve %zu bytes of LDS", lds);
+            return LAVT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
     hipLaunchKernelGGL((gemm_tn_kernel<T, BI, BJ>), grid, dim3(256), lds, st, p, per);
     LAVT_CHECK_LAUNCH("lavt_gemm_tn");
     return LAVT_OK;
 }
 template <typename T> int dispatch_tn(const lavt_gemm_tn_t& p, hipStream_t st) {
-    const bool big = p.I >= 128 && p.J >= 128 && (long)cdiv(p.I, 128) * cdiv(p.J, 128) * p.batch >= 16;
+    const int force = forced_tile();
+    const bool big = force ? force == 128 : (p.I >= 128 && p.J >= 128 && (long)cdiv(p.I, 128) * cdiv(p.J, 128) * p.batch >= 16);
     return big ? launch_tn<T, 128, 128>(p, st) : launch_tn<T, 64, 64>(p, st);
 }
 

@@ -1,0 +1,70 @@
+"""Step harness reproducing the reference caller's sequence (train.py:199-229) on the HIP model:
+
+    zero grads -> out = model(image, l, l_mask) -> F.cross_entropy(out, target, weight=[0.9, 1.1]) -> backward
+    -> gradient all-reduce (world > 1)
+
+The whole step is ~2,000 kernel launches for Swin-B; issued from Python it is launch-bound, so on one GPU the
+step is captured once into a hipGraph (torch.cuda.CUDAGraph on the stream our C-ABI launches go to) and
+replayed: weight casts, DropPath masks, BatchNorm running-stat updates all happen inside the graph.
+With world > 1 the collectives (SyncBN statistics, gradient buckets) stay outside graphs (RCCL calls are
+issued eagerly) and the step runs eagerly with the bucketed all-reduce overlapping backward.
+"""
+import sys
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .ddp import GradBuckets
+
+
+class TrainStep:
+    def __init__(self, model, image, l_feats, l_mask, target, world=1, use_graph=True, bucket_mib=64.0):
+        self.model = model
+        dev = image.device
+        self.x, self.l, self.m, self.t = image, l_feats, l_mask, target
+        self.w = torch.tensor([0.9, 1.1], device=dev)                    # losses.py:7-11
+        self.buckets = GradBuckets(model, bucket_mib=bucket_mib)
+        self.world = world
+        self.graph = None
+        self.loss = None
+        self.use_graph = use_graph and world == 1
+        self.captured = False
+
+    def _body(self):
+        ops.weights.invalidate()                 # re-cast weights inside the step (they change every optimizer step)
+        self.buckets.zero()
+        out = self.model(self.x, self.l, self.m)
+        loss = F.cross_entropy(out, self.t, weight=self.w)
+        loss.backward()
+        return loss.detach()
+
+    def warmup_and_capture(self, eager_iters=3):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(eager_iters):
+                self.loss = self._body()
+                self.buckets.finish()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        if not self.use_graph:
+            return
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.loss = self._body()
+            self.graph = g
+            self.captured = True
+        except Exception as e:                                   # noqa: BLE001  (report and keep the eager path)
+            print(f"[lavt_hip.engine] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
+            self.graph = None
+            torch.cuda.synchronize()
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.loss = self._body()
+            self.buckets.finish()
+        return self.loss

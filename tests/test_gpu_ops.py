@@ -85,6 +85,25 @@ def test_linear_plain(dtype, M, N, Kd):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("tile", ["128", "64"])
+def test_gemm_forced_tiles(dtype, tile, monkeypatch):
+    """Both tile configurations of every GEMM family (NT k-contiguous, NT k-major, TN) and of the implicit-GEMM conv."""
+    from lavt_hip import ops
+    monkeypatch.setenv("LAVT_GEMM_TILE", tile)
+    M, N, Kd = 700, 328, 264
+    inputs = {"x": (rnd(M, Kd, seed=1), "act"), "w": (rnd(N, Kd, seed=2, scale=Kd ** -0.5), "param"), "b": (rnd(N, seed=3), "param")}
+    run_pair(lambda x, w, b: ops.linear(x, w, b), lambda x, w, b: F.linear(x, w, b), inputs, dtype, name=f"linear tile {tile}")
+    B, H, W, C1, C2, Cout = 2, 13, 11, 96, 32, 136
+    inputs = {"x1": (rnd(B * H * W, C1, seed=1), "act"), "x2": (rnd(B * H * W, C2, seed=2), "act"),
+              "w": (rnd(Cout, C1 + C2, 3, 3, seed=3, scale=(9 * (C1 + C2)) ** -0.5), "param")}
+
+    def ref(x1, w, x2):
+        y = F.conv2d(torch.cat([x1, x2], 1).view(B, H, W, C1 + C2).permute(0, 3, 1, 2), w, padding=1)
+        return y.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    run_pair(lambda x1, w, x2: ops.conv3x3(x1, x2, w, B, H, W), ref, inputs, dtype, name=f"conv tile {tile}", bf16=4e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_linear_gelu_residual(dtype):
     from lavt_hip import ops
     from lavt_hip._capi import ACT_GELU, ACT_RELU
