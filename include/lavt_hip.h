@@ -140,21 +140,22 @@ int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * Shifted-window attention core (WindowAttention.forward, lib/backbone.py:123-140; mask :634-652).
  * qkv: [nwin*N][3C] in windowed row order (columns s*C + h*32 + d, s in {q,k,v}), head_dim = C/heads.
- * out: [nwin*N][C].  bias: dense fp32 [heads][N][N] (from lavt_relpos_expand).  region: optional int8
+ * out: [nwin*N][C].  bias: dense fp32 [heads][N][bias_ld] (from lavt_relpos_expand; bias_ld = N rounded up to a multiple
+ * of 16 -- 64 for 7x7, 160 for 12x12 windows -- lets the bf16 MFMA kernels run; padding columns hold -1e30).  region: optional int8
  * [nw_img][N] region ids of the shift mask (window w uses row w % nw_img); unequal ids add -100.
  * lse: fp32 [nwin][heads][N] log-sum-exp of each score row (saved for backward).
- * Backward: dqkv [nwin*N][3C] (every element written), dbias fp32 [heads][N][N] accumulated with atomics.
+ * Backward: dqkv [nwin*N][3C] (every element written), dbias fp32 [heads][N][bias_ld] accumulated with atomics.
  * ------------------------------------------------------------------------------------------- */
-int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, const int8_t* region, int nw_img, void* out,
+int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out,
                          float* lse, int nwin, int N, int heads, int head_dim, float scale, void* stream);
-int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, const int8_t* region, int nw_img,
+int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img,
                          const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int nwin, int N,
                          int heads, int head_dim, float scale, void* stream);
 
-/* relative_position_bias_table[(2ws-1)^2][heads] -> dense bias[heads][N][N] (lib/backbone.py:89-103,125-127)
+/* relative_position_bias_table[(2ws-1)^2][heads] -> dense bias[heads][N][ld] (lib/backbone.py:89-103,125-127)
  * and its transpose (dense gradient -> table gradient, deterministic, accumulates into dtable). */
-int lavt_relpos_expand(const float* table, float* dense, int ws, int heads, void* stream);
-int lavt_relpos_reduce(const float* ddense, float* dtable, int ws, int heads, void* stream);
+int lavt_relpos_expand(const float* table, float* dense, int ws, int heads, int ld, void* stream);
+int lavt_relpos_reduce(const float* ddense, float* dtable, int ws, int heads, int ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the channel dimension (nn.LayerNorm, eps 1e-5; lib/backbone.py:201,243,285,328,510).

@@ -5,6 +5,8 @@
 // formulation in attention_mfma.hip takes a shape, for LAVT_BF16 as well (bf16 storage, fp32 math).
 // K and V of the window live in LDS for the whole workgroup; each wave owns query rows i = wave, wave+4, ...
 // and spreads the key index j over its 64 lanes, so the softmax row reductions are wave shuffles.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -28,7 +30,7 @@ __device__ __forceinline__ void load_kv(const T* qkv, int64_t row0, int C, int h
 template <typename T, int NJ>
 __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
                                                               const int8_t* __restrict__ region, int nw_img, T* __restrict__ out,
-                                                              float* __restrict__ lse, int N, int heads, float scale) {
+                                                              float* __restrict__ lse, int N, int heads, float scale, int bias_ld) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* Ks = reinterpret_cast<float*>(smem_raw);
     float* Vs = Ks + N * KV_LD;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const T* __restric
     load_kv<T>(qkv, row0, C, h, N, Ks, Vs, Qs, scale);
     __syncthreads();
     const int8_t* reg = region ? region + (int64_t)(w % nw_img) * N : nullptr;
-    const float* bh = bias + (int64_t)h * N * N;
+    const float* bh = bias + (int64_t)h * N * bias_ld;
     float* P = Pw + wave * NJ * 64;
 
     int rid_j[NJ];
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const T* __restric
                 const float* k = Ks + j * KV_LD;
 #pragma unroll
                 for (int d = 0; d < HD; ++d) a = fmaf(q[d], k[d], a);
-                a += bh[(int64_t)i * N + j];
+                a += bh[(int64_t)i * bias_ld + j];
                 if (rid_j[t] != rid_i) a += -100.0f;
             }
             s[t] = a;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
                                                               const int8_t* __restrict__ region, int nw_img,
                                                               const T* __restrict__ out, const T* __restrict__ dout,
                                                               const float* __restrict__ lse, T* __restrict__ dqkv,
-                                                              float* __restrict__ dbias, int N, int heads, float scale) {
+                                                              float* __restrict__ dbias, int N, int heads, float scale, int bias_ld) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* Ks = reinterpret_cast<float*>(smem_raw);
     float* Vs = Ks + N * KV_LD;
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
     for (int e = threadIdx.x; e < N * KV_LD; e += blockDim.x) { dKs[e] = 0.f; dVs[e] = 0.f; }
     __syncthreads();
     const int8_t* reg = region ? region + (int64_t)(w % nw_img) * N : nullptr;
-    const float* bh = bias + (int64_t)h * N * N;
-    float* dbh = dbias + (int64_t)h * N * N;
+    const float* bh = bias + (int64_t)h * N * bias_ld;
+    float* dbh = dbias + (int64_t)h * N * bias_ld;
     float* dS = Sw + wave * NJ * 64;
     float* dOr = Dw + wave * HD;
 
@@ -148,11 +150,11 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
                 const float* v = Vs + j * KV_LD;
 #pragma unroll
                 for (int d = 0; d < HD; ++d) { a = fmaf(q[d], k[d], a); dp = fmaf(dOr[d], v[d], dp); }
-                a += bh[(int64_t)i * N + j];
+                a += bh[(int64_t)i * bias_ld + j];
                 if (rid_j[t] != rid_i) a += -100.0f;
                 const float pj = __expf(a - l);
                 ds = pj * (dp - dl);
-                atomicAdd(dbh + (int64_t)i * N + j, ds);
+                atomicAdd(dbh + (int64_t)i * bias_ld + j, ds);
 #pragma unroll
                 for (int d = 0; d < HD; ++d) {
                     dv[t][d] = fmaf(pj, dOr[d], dv[t][d]);
@@ -192,54 +194,57 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
 }
 
 // relative position bias: table[(2ws-1)^2][heads] <-> dense[heads][N][N]
-__global__ void relpos_expand_kernel(const float* __restrict__ table, float* __restrict__ dense, int ws, int heads) {
+__global__ void relpos_expand_kernel(const float* __restrict__ table, float* __restrict__ dense, int ws, int heads, int ld) {
     const int N = ws * ws;
-    const int64_t total = (int64_t)heads * N * N;
+    const int64_t total = (int64_t)heads * N * ld;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int j = e % N, i = (e / N) % N, h = e / ((int64_t)N * N);
+        const int j = e % ld, i = (e / ld) % N, h = e / ((int64_t)N * ld);
         const int idx = (i / ws - j / ws + ws - 1) * (2 * ws - 1) + (i % ws - j % ws + ws - 1);
-        dense[e] = table[idx * heads + h];
+        dense[e] = j < N ? table[idx * heads + h] : -1e30f;       // padding columns can never win a softmax
     }
 }
-// one thread per (table row, head): sums the dense gradient over every (i,j) pair that maps to it -- deterministic
-__global__ void relpos_reduce_kernel(const float* __restrict__ ddense, float* __restrict__ dtable, int ws, int heads) {
+// one wave per (table row, head): lanes stride over the (i,j) pairs that map to it, wave-shuffle sum -- deterministic
+__global__ void relpos_reduce_kernel(const float* __restrict__ ddense, float* __restrict__ dtable, int ws, int heads, int ld) {
     const int R = (2 * ws - 1) * (2 * ws - 1), N = ws * ws;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (e >= R * heads) return;
     const int h = e % heads, idx = e / heads;
     const int dr = idx / (2 * ws - 1) - (ws - 1), dc = idx % (2 * ws - 1) - (ws - 1);   // (ri - rj, ci - cj)
+    const int r0 = max(0, -dr), nr = min(ws, ws - dr) - r0, c0 = max(0, -dc), nc = min(ws, ws - dc) - c0;
     float s = 0.f;
-    for (int rj = max(0, -dr); rj < min(ws, ws - dr); ++rj)
-        for (int cj = max(0, -dc); cj < min(ws, ws - dc); ++cj) {
-            const int i = (rj + dr) * ws + (cj + dc), j = rj * ws + cj;
-            s += ddense[((int64_t)h * N + i) * N + j];
-        }
-    dtable[idx * heads + h] += s;
+    for (int t = lane; t < nr * nc; t += 64) {
+        const int rj = r0 + t / nc, cj = c0 + t % nc;
+        const int i = (rj + dr) * ws + (cj + dc), j = rj * ws + cj;
+        s += ddense[((int64_t)h * N + i) * ld + j];
+    }
+    s = wave_sum(s);
+    if (lane == 0) dtable[idx * heads + h] += s;
 }
 
 template <typename T>
-int launch_fwd(const void* qkv, const float* bias, const int8_t* region, int nw_img, void* out, float* lse, int nwin, int N,
+int launch_fwd(const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out, float* lse, int nwin, int N,
                int heads, float scale, hipStream_t st) {
     const int NJ = (N + 63) / 64;
     const size_t lds = (size_t)(3 * N * KV_LD + 4 * NJ * 64) * sizeof(float);
     dim3 grid(nwin * heads);
 #define L(NJ_)                                                                                                              \
     hipLaunchKernelGGL((window_attn_fwd_kernel<T, NJ_>), grid, dim3(256), lds, st, (const T*)qkv, bias, region, nw_img, \
-                       (T*)out, lse, N, heads, scale)
+                       (T*)out, lse, N, heads, scale, bias_ld)
     if (NJ == 1) L(1); else if (NJ == 2) L(2); else if (NJ == 3) L(3); else { lavt_set_error("lavt_window_attn_fwd: N=%d > 192 not supported by this kernel", N); return LAVT_ERR_INVALID; }
 #undef L
     LAVT_CHECK_LAUNCH("lavt_window_attn_fwd");
     return LAVT_OK;
 }
 template <typename T>
-int launch_bwd(const void* qkv, const float* bias, const int8_t* region, int nw_img, const void* out, const void* dout,
+int launch_bwd(const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, const void* out, const void* dout,
                const float* lse, void* dqkv, float* dbias, int nwin, int N, int heads, float scale, hipStream_t st) {
     const int NJ = (N + 63) / 64;
     const size_t lds = (size_t)(5 * N * KV_LD + 4 * NJ * 64 + 4 * HD) * sizeof(float);
     dim3 grid(nwin * heads);
 #define L(NJ_)                                                                                                              \
     hipLaunchKernelGGL((window_attn_bwd_kernel<T, NJ_>), grid, dim3(256), lds, st, (const T*)qkv, bias, region, nw_img, \
-                       (const T*)out, (const T*)dout, lse, (T*)dqkv, dbias, N, heads, scale)
+                       (const T*)out, (const T*)dout, lse, (T*)dqkv, dbias, N, heads, scale, bias_ld)
     if (NJ == 1) L(1); else if (NJ == 2) L(2); else if (NJ == 3) L(3); else { lavt_set_error("lavt_window_attn_bwd: N=%d > 192 not supported by this kernel", N); return LAVT_ERR_INVALID; }
 #undef L
     LAVT_CHECK_LAUNCH("lavt_window_attn_bwd");
@@ -248,41 +253,54 @@ int launch_bwd(const void* qkv, const float* bias, const int8_t* region, int nw_
 
 }  // namespace
 
-extern "C" int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, const int8_t* region, int nw_img, void* out,
+int lavt_window_attn_fwd_mfma(const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out, float* lse,
+                              int nwin, int N, int heads, float scale, hipStream_t st);
+int lavt_window_attn_bwd_mfma(const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, const void* out,
+                              const void* dout, const float* lse, void* dqkv, float* dbias, int nwin, int N, int heads, float scale,
+                              hipStream_t st);
+// LAVT_ATTN_SIMPLE=1 forces the VALU formulation for bf16 too (A/B tests of the MFMA kernels)
+static bool use_mfma(int dtype, int N, int bias_ld) {
+    const char* e = getenv("LAVT_ATTN_SIMPLE");
+    return dtype == LAVT_BF16 && N <= 160 && bias_ld >= (N <= 64 ? 64 : 160) && !(e && e[0] == '1');
+}
+
+extern "C" int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out,
                                     float* lse, int nwin, int N, int heads, int head_dim, float scale, void* stream) {
     LAVT_CHECK_ARG(head_dim == HD, "lavt_window_attn_fwd: head_dim %d != 32", head_dim);
-    LAVT_CHECK_ARG(qkv && bias && out && lse && nwin > 0 && N > 0 && heads > 0, "lavt_window_attn_fwd: bad arguments");
+    LAVT_CHECK_ARG(qkv && bias && out && lse && nwin > 0 && N > 0 && heads > 0 && bias_ld >= N, "lavt_window_attn_fwd: bad arguments");
     LAVT_CHECK_ARG(!region || nw_img > 0, "lavt_window_attn_fwd: region needs nw_img");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == LAVT_F32) return launch_fwd<float>(qkv, bias, region, nw_img, out, lse, nwin, N, heads, scale, st);
-    if (dtype == LAVT_BF16) return launch_fwd<bf16>(qkv, bias, region, nw_img, out, lse, nwin, N, heads, scale, st);
+    if (use_mfma(dtype, N, bias_ld)) return lavt_window_attn_fwd_mfma(qkv, bias, bias_ld, region, nw_img, out, lse, nwin, N, heads, scale, st);
+    if (dtype == LAVT_F32) return launch_fwd<float>(qkv, bias, bias_ld, region, nw_img, out, lse, nwin, N, heads, scale, st);
+    if (dtype == LAVT_BF16) return launch_fwd<bf16>(qkv, bias, bias_ld, region, nw_img, out, lse, nwin, N, heads, scale, st);
     lavt_set_error("lavt_window_attn_fwd: bad dtype %d", dtype);
     return LAVT_ERR_INVALID;
 }
 
-extern "C" int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, const int8_t* region, int nw_img,
+extern "C" int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img,
                                     const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int nwin,
                                     int N, int heads, int head_dim, float scale, void* stream) {
     LAVT_CHECK_ARG(head_dim == HD, "lavt_window_attn_bwd: head_dim %d != 32", head_dim);
-    LAVT_CHECK_ARG(qkv && bias && out && dout && lse && dqkv && dbias && nwin > 0 && N > 0 && heads > 0, "lavt_window_attn_bwd: bad arguments");
+    LAVT_CHECK_ARG(qkv && bias && out && dout && lse && dqkv && dbias && nwin > 0 && N > 0 && heads > 0 && bias_ld >= N, "lavt_window_attn_bwd: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == LAVT_F32) return launch_bwd<float>(qkv, bias, region, nw_img, out, dout, lse, dqkv, dbias, nwin, N, heads, scale, st);
-    if (dtype == LAVT_BF16) return launch_bwd<bf16>(qkv, bias, region, nw_img, out, dout, lse, dqkv, dbias, nwin, N, heads, scale, st);
+    if (use_mfma(dtype, N, bias_ld)) return lavt_window_attn_bwd_mfma(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, dbias, nwin, N, heads, scale, st);
+    if (dtype == LAVT_F32) return launch_bwd<float>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, dbias, nwin, N, heads, scale, st);
+    if (dtype == LAVT_BF16) return launch_bwd<bf16>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, dbias, nwin, N, heads, scale, st);
     lavt_set_error("lavt_window_attn_bwd: bad dtype %d", dtype);
     return LAVT_ERR_INVALID;
 }
 
-extern "C" int lavt_relpos_expand(const float* table, float* dense, int ws, int heads, void* stream) {
-    LAVT_CHECK_ARG(table && dense && ws > 0 && heads > 0, "lavt_relpos_expand: bad arguments");
-    const int64_t total = (int64_t)heads * ws * ws * ws * ws;
-    hipLaunchKernelGGL(relpos_expand_kernel, dim3(cdiv(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, dense, ws, heads);
+extern "C" int lavt_relpos_expand(const float* table, float* dense, int ws, int heads, int ld, void* stream) {
+    LAVT_CHECK_ARG(table && dense && ws > 0 && heads > 0 && ld >= ws * ws, "lavt_relpos_expand: bad arguments");
+    const int64_t total = (int64_t)heads * ws * ws * ld;
+    hipLaunchKernelGGL(relpos_expand_kernel, dim3(cdiv(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, dense, ws, heads, ld);
     LAVT_CHECK_LAUNCH("lavt_relpos_expand");
     return LAVT_OK;
 }
-extern "C" int lavt_relpos_reduce(const float* ddense, float* dtable, int ws, int heads, void* stream) {
-    LAVT_CHECK_ARG(ddense && dtable && ws > 0 && heads > 0, "lavt_relpos_reduce: bad arguments");
+extern "C" int lavt_relpos_reduce(const float* ddense, float* dtable, int ws, int heads, int ld, void* stream) {
+    LAVT_CHECK_ARG(ddense && dtable && ws > 0 && heads > 0 && ld >= ws * ws, "lavt_relpos_reduce: bad arguments");
     const int total = (2 * ws - 1) * (2 * ws - 1) * heads;
-    hipLaunchKernelGGL(relpos_reduce_kernel, dim3(cdiv(total, 128)), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), ddense, dtable, ws, heads);
+    hipLaunchKernelGGL(relpos_reduce_kernel, dim3(cdiv(total, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ddense, dtable, ws, heads, ld);
     LAVT_CHECK_LAUNCH("lavt_relpos_reduce");
     return LAVT_OK;
 }

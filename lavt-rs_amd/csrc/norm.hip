@@ -121,12 +121,36 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
         }
     }
+    // block reduction of the four waves' partial sums through LDS, then ONE atomic per channel per workgroup
+    __shared__ float red[3 * 2048];
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        const int ch = lane + 64 * c;
-        if (ch < nchunk)
+    for (int pass = 0; pass < 2; ++pass) {
+        float* part = pass == 0 ? dg : db;
+        float* dst = pass == 0 ? dgamma : dbeta;
+        __syncthreads();
+        if (wave > 0) {
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) { atomicAdd(dgamma + ch * EPC + e, dg[c * EPC + e]); atomicAdd(dbeta + ch * EPC + e, db[c * EPC + e]); }
+            for (int c = 0; c < MAXC; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < nchunk)
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) red[(wave - 1) * 2048 + ch * EPC + e] = part[c * EPC + e];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < nchunk)
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const int col = ch * EPC + e;
+                        atomicAdd(dst + col, part[c * EPC + e] + red[col] + red[2048 + col] + red[4096 + col]);
+                    }
+            }
+        }
     }
 }
 
@@ -309,7 +333,7 @@ extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     LAVT_CHECK_ARG(C > 0 && C <= 2048 && C % epc == 0 && (!gather || (C / 4) % epc == 0), "lavt_layernorm_bwd: unsupported C=%d", C);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int blocks = cdiv(rows, 4 * 8);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     DISPATCH_T(dtype, "lavt_layernorm_bwd",
                hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C));

@@ -226,29 +226,30 @@ class _WindowAttn(torch.autograd.Function):
         Cc = C3 // 3
         nwin = qkv.shape[0] // N
         dev = qkv.device
-        dense = torch.empty(heads, N, N, dtype=torch.float32, device=dev)
-        K.check(K.lib.lavt_relpos_expand(K.ptr(_f32(table)), K.ptr(dense), ws, heads, K.stream()))
+        ld = 64 if N <= 64 else -(-N // 32) * 32   # 64 / 160: padded key axis (pairs of 16-wide MFMA tiles); padding holds -1e30
+        dense = torch.empty(heads, N, ld, dtype=torch.float32, device=dev)
+        K.check(K.lib.lavt_relpos_expand(K.ptr(_f32(table)), K.ptr(dense), ws, heads, ld, K.stream()))
         out = torch.empty(nwin * N, Cc, dtype=qkv.dtype, device=dev)
         lse = torch.empty(nwin, heads, N, dtype=torch.float32, device=dev)
         nw_img = region.shape[0] if region is not None else 0
         scale = float((Cc // heads) ** -0.5)
-        K.check(K.lib.lavt_window_attn_fwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), K.ptr(region), nw_img, K.ptr(out), K.ptr(lse),
+        K.check(K.lib.lavt_window_attn_fwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(lse),
                                            nwin, N, heads, Cc // heads, scale, K.stream()))
         ctx.save_for_backward(qkv, dense, region, out, lse)
-        ctx.dims = (ws, heads, nwin, N, Cc, nw_img, scale)
+        ctx.dims = (ws, heads, nwin, N, Cc, nw_img, scale, ld)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, dense, region, out, lse = ctx.saved_tensors
-        ws, heads, nwin, N, Cc, nw_img, scale = ctx.dims
+        ws, heads, nwin, N, Cc, nw_img, scale, ld = ctx.dims
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         ddense = torch.zeros_like(dense)
-        K.check(K.lib.lavt_window_attn_bwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), K.ptr(region), nw_img, K.ptr(out), K.ptr(dout),
+        K.check(K.lib.lavt_window_attn_bwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout),
                                            K.ptr(lse), K.ptr(dqkv), K.ptr(ddense), nwin, N, heads, Cc // heads, scale, K.stream()))
         dtable = torch.zeros((2 * ws - 1) ** 2, heads, dtype=torch.float32, device=qkv.device)
-        K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense), K.ptr(dtable), ws, heads, K.stream()))
+        K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense), K.ptr(dtable), ws, heads, ld, K.stream()))
         return dqkv, dtable, None, None, None
 
 
