@@ -93,8 +93,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const lavt_gemm_nt_t p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
-    T* sA[2] = {smem, smem + A_TILE + B_TILE};
-    T* sB[2] = {smem + A_TILE, smem + 2 * A_TILE + B_TILE};
+    constexpr int STAGE = A_TILE + B_TILE;      // stage s: A at s*STAGE, B at s*STAGE + A_TILE (plain offsets keep the LDS address space)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -129,6 +128,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const lavt_gemm_nt_t p) {
     const int b_row0 = BKM ? tid / BKM_CPR : a_row0;
 
     uint4 ra[A_PASSES], rb[B_PASSES];
+    uint32_t va = 0, vb = 0;       // validity bits of the staged chunks: loads are UNCONDITIONAL (clamped address) so that they
+                                   // stay in flight across the MFMAs; invalid chunks are zeroed when written to LDS
 
     auto load_tiles = [&](int kt) {
         // A
@@ -143,21 +144,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const lavt_gemm_nt_t p) {
         const T* base = second ? A2 : A;
         const int64_t ld = second ? p.lda2 : p.lda;
         const int kk = second ? kin - p.a_split : kin;
+        va = 0;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             int src = a_src[i];
-            if (conv && src >= 0) {
+            if (conv) {
                 const int y = a_y[i] + dy, x = a_x[i] + dx;
-                src = (y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) ? src + dy * p.conv_w + dx : -1;
+                src = (src >= 0 && y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) ? src + dy * p.conv_w + dx : -1;
             }
-            ra[i] = (src >= 0 && k < p.K) ? ldg16(base + (int64_t)src * ld + kk) : zero16();
+            const bool ok = src >= 0 && k < p.K;
+            ra[i] = ldg16(ok ? base + (int64_t)src * ld + kk : A);
+            va |= (ok ? 1u : 0u) << i;
         }
         // B
+        vb = 0;
         if constexpr (!BKM) {
 #pragma unroll
             for (int i = 0; i < B_PASSES; ++i) {
                 const int n = n0 + b_row0 + i * A_RPP;
-                rb[i] = (n < p.N && k < p.K) ? ldg16(B + (int64_t)n * p.ldb + k) : zero16();
+                const bool ok = n < p.N && k < p.K;
+                rb[i] = ldg16(ok ? B + (int64_t)n * p.ldb + k : B);
+                vb |= (ok ? 1u : 0u) << i;
             }
         } else {
             const int n = n0 + b_chunk * EPC;
@@ -167,22 +174,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const lavt_gemm_nt_t p) {
                 int64_t off;
                 if (conv) { const int t2 = kb / p.conv_kc; off = (int64_t)(kb - t2 * p.conv_kc) * p.ldb + (int64_t)t2 * p.b_tap_stride; }
                 else off = (int64_t)kb * p.ldb;
-                rb[i] = (kb < p.K && n < p.N) ? ldg16(B + off + n) : zero16();
+                const bool ok = kb < p.K && n < p.N;
+                rb[i] = ldg16(ok ? B + off + n : B);
+                vb |= (ok ? 1u : 0u) << i;
             }
         }
     };
     auto store_tiles = [&](int buf) {
+        T* dA = smem + buf * STAGE;
+        T* dB = dA + A_TILE;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i)
-            *reinterpret_cast<uint4*>(sA[buf] + kc_off<T>(a_row0 + i * A_RPP, a_chunk)) = ra[i];
+            *reinterpret_cast<uint4*>(dA + kc_off<T>(a_row0 + i * A_RPP, a_chunk)) = ((va >> i) & 1u) ? ra[i] : zero16();
         if constexpr (!BKM) {
 #pragma unroll
             for (int i = 0; i < B_PASSES; ++i)
-                *reinterpret_cast<uint4*>(sB[buf] + kc_off<T>(b_row0 + i * A_RPP, b_chunk)) = rb[i];
+                *reinterpret_cast<uint4*>(dB + kc_off<T>(b_row0 + i * A_RPP, b_chunk)) = ((vb >> i) & 1u) ? rb[i] : zero16();
         } else {
 #pragma unroll
             for (int i = 0; i < B_PASSES; ++i)
-                *reinterpret_cast<uint4*>(sB[buf] + (b_row0 + i * BKM_RPP) * B_LD + b_chunk * EPC) = rb[i];
+                *reinterpret_cast<uint4*>(dB + (b_row0 + i * BKM_RPP) * B_LD + b_chunk * EPC) = ((vb >> i) & 1u) ? rb[i] : zero16();
         }
     };
 
@@ -199,22 +210,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const lavt_gemm_nt_t p) {
     for (int kt = 0; kt < ktiles; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < ktiles) load_tiles(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);           // global loads of tile kt+1 are issued before, and consumed after, the MFMAs
+        typename FragT<T>::type fa[KSTEPS][MI], fb[KSTEPS][NI];
+        const T* cA = smem + cur * STAGE;
+        const T* cB = cA + A_TILE;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            typename FragT<T>::type fa[MI], fb[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[i] = frag_kc<T>(sA[cur], wm * WM + i * 16, ks, lane);
+            for (int i = 0; i < MI; ++i) fa[ks][i] = frag_kc<T>(cA, wm * WM + i * 16, ks, lane);
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                if constexpr (BKM) fb[j] = frag_km<T>(sB[cur], B_LD, wn * WN + j * 16, ks, lane);
-                else fb[j] = frag_kc<T>(sB[cur], wn * WN + j * 16, ks, lane);
+                if constexpr (BKM) fb[ks][j] = frag_km<T>(cB, B_LD, wn * WN + j * 16, ks, lane);
+                else fb[ks][j] = frag_kc<T>(cB, wn * WN + j * 16, ks, lane);
             }
-            // swapped operands: accumulator rows = n (4 consecutive per lane), columns = m
+        }
+        // swapped operands: accumulator rows = n (4 consecutive per lane), columns = m
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = mfma16<T>(fb[j], fa[i], acc[i][j]);
-        }
+                for (int j = 0; j < NI; ++j) acc[i][j] = mfma16<T>(fb[ks][j], fa[ks][i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < ktiles) store_tiles(cur ^ 1);
         __syncthreads();
     }
@@ -318,8 +335,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const lavt_gemm_tn_t p, in
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
-    T* sA[2] = {smem, smem + A_TILE + B_TILE};
-    T* sB[2] = {smem + A_TILE, smem + 2 * A_TILE + B_TILE};
+    constexpr int STAGE = A_TILE + B_TILE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
@@ -350,44 +366,55 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const lavt_gemm_tn_t p, in
     const int jcc = b_second ? jc - p.b_split : jc;
 
     uint4 ra[A_PASSES], rb[B_PASSES];
+    uint32_t va = 0, vb = 0;
+    float asc[A_PASSES];
     auto load_tiles = [&](int kt) {
+        va = 0; vb = 0;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             const int k = kt * BK + a_row0 + i * A_RPP;
-            int src = -1;
-            if (k < p.K) src = p.a_rowmap ? p.a_rowmap[k] : k;
-            ra[i] = (src >= 0 && ia < p.I) ? ldg16(A + (int64_t)src * p.lda + ia) : zero16();
-            if (p.a_rowscale && src >= 0) {
-                const float sc = p.a_rowscale[p.a_rowscale_div > 1 ? k / p.a_rowscale_div : k];
-                float f[EPC];
-                chunk_to_f<T>(ra[i], f);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) f[e] *= sc;
-                ra[i] = f_to_chunk<T>(f);
-            }
+            const bool in = k < p.K;
+            const int kc = in ? k : 0;
+            const int src = p.a_rowmap ? p.a_rowmap[kc] : kc;
+            const bool ok = in && src >= 0 && ia < p.I;
+            ra[i] = ldg16(ok ? A + (int64_t)src * p.lda + ia : A);
+            va |= (ok ? 1u : 0u) << i;
+            asc[i] = p.a_rowscale ? p.a_rowscale[p.a_rowscale_div > 1 ? kc / p.a_rowscale_div : kc] : 1.f;
         }
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
             const int k = kt * BK + b_row0 + i * B_RPP;
-            int src = -1;
-            if (k < p.K) {
-                src = p.b_rowmap ? p.b_rowmap[k] : k;
-                if (conv && src >= 0) {
-                    const int pix = src % (p.conv_h * p.conv_w);
-                    const int y = pix / p.conv_w + dy, x = pix % p.conv_w + dx;
-                    src = (y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) ? src + dy * p.conv_w + dx : -1;
-                }
+            const bool in = k < p.K;
+            const int kc = in ? k : 0;
+            int src = p.b_rowmap ? p.b_rowmap[kc] : kc;
+            if (conv) {
+                const int pix = (src >= 0 ? src : 0) % (p.conv_h * p.conv_w);
+                const int y = pix / p.conv_w + dy, x = pix % p.conv_w + dx;
+                src = (src >= 0 && y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) ? src + dy * p.conv_w + dx : -1;
             }
-            rb[i] = (src >= 0 && jb < p.J) ? ldg16(Bsrc + (int64_t)src * ldb + jcc) : zero16();
+            const bool ok = in && src >= 0 && jb < p.J;
+            rb[i] = ldg16(ok ? Bsrc + (int64_t)src * ldb + jcc : Bsrc);
+            vb |= (ok ? 1u : 0u) << i;
         }
     };
     auto store_tiles = [&](int buf) {
+        T* dA = smem + buf * STAGE;
+        T* dB = dA + A_TILE;
 #pragma unroll
-        for (int i = 0; i < A_PASSES; ++i)
-            *reinterpret_cast<uint4*>(sA[buf] + (a_row0 + i * A_RPP) * A_LD + a_chunk * EPC) = ra[i];
+        for (int i = 0; i < A_PASSES; ++i) {
+            uint4 v = ((va >> i) & 1u) ? ra[i] : zero16();
+            if (p.a_rowscale) {
+                float f[EPC];
+                chunk_to_f<T>(v, f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) f[e] *= asc[i];
+                v = f_to_chunk<T>(f);
+            }
+            *reinterpret_cast<uint4*>(dA + (a_row0 + i * A_RPP) * A_LD + a_chunk * EPC) = v;
+        }
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i)
-            *reinterpret_cast<uint4*>(sB[buf] + (b_row0 + i * B_RPP) * B_LD + b_chunk * EPC) = rb[i];
+            *reinterpret_cast<uint4*>(dB + (b_row0 + i * B_RPP) * B_LD + b_chunk * EPC) = ((vb >> i) & 1u) ? rb[i] : zero16();
     };
 
     f32x4 acc[II][JJ];
@@ -404,20 +431,26 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const lavt_gemm_tn_t p, in
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
         if (kt + 1 < kt_end) load_tiles(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        typename FragT<T>::type fa[KSTEPS][II], fb[KSTEPS][JJ];
+        const T* cA = smem + cur * STAGE;
+        const T* cB = cA + A_TILE;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            typename FragT<T>::type fa[II], fb[JJ];
 #pragma unroll
-            for (int i = 0; i < II; ++i) fa[i] = frag_km<T>(sA[cur], A_LD, wi * WI + i * 16, ks, lane);
+            for (int i = 0; i < II; ++i) fa[ks][i] = frag_km<T>(cA, A_LD, wi * WI + i * 16, ks, lane);
 #pragma unroll
-            for (int j = 0; j < JJ; ++j) fb[j] = frag_km<T>(sB[cur], B_LD, wj * WJ + j * 16, ks, lane);
+            for (int j = 0; j < JJ; ++j) fb[ks][j] = frag_km<T>(cB, B_LD, wj * WJ + j * 16, ks, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
             for (int i = 0; i < II; ++i)
 #pragma unroll
-                for (int j = 0; j < JJ; ++j) acc[i][j] = mfma16<T>(fa[i], fb[j], acc[i][j]);
-        }
+                for (int j = 0; j < JJ; ++j) acc[i][j] = mfma16<T>(fa[ks][i], fb[ks][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
         if (do_colsum) {
-            const T* col = sA[cur] + tid;
+            const T* col = cA + tid;
 #pragma unroll 8
             for (int k = 0; k < BK; ++k) csum += to_f<T>(col[k * A_LD]);
         }

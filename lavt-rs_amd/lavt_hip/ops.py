@@ -10,6 +10,7 @@ bf16 compute copies are produced by `weight()` and cached per parameter version.
 gradients are produced in fp32.
 """
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import Optional
 
@@ -36,20 +37,25 @@ class _WeightCache:
             return p.detach().reshape(p.shape[0], -1)
         key = (id(p), dtype, kind)
         ent = self.store.get(key)
+        if ent is not None and ent[2]() is not p:          # id() reuse after the old parameter died
+            ent = None
         stamp = (p._version, p.data_ptr(), self.epoch)
         if ent is not None and ent[0] == stamp:
             return ent[1]
         src = p.detach()
         if kind == "lin":
-            out = ent[1] if ent is not None and ent[1].numel() == src.numel() else torch.empty(src.shape[0], src.numel() // src.shape[0], dtype=dtype, device=src.device)
-            K.check(K.lib.lavt_cast(K.F32, K.ptr(src), K.dt(dtype), K.ptr(out), src.numel(), K.stream()))
+            shape = (src.shape[0], src.numel() // src.shape[0])
         elif kind == "conv3":
-            cout, cin = src.shape[0], src.shape[1]
-            out = ent[1] if ent is not None and ent[1].numel() == src.numel() else torch.empty(cout, 9 * cin, dtype=dtype, device=src.device)
-            K.check(K.lib.lavt_pack_conv3x3(K.ptr(src), K.dt(dtype), K.ptr(out), cout, cin, K.stream()))
+            shape = (src.shape[0], 9 * src.shape[1])
         else:
             raise KeyError(kind)
-        self.store[key] = (stamp, out)
+        # keep the same storage across refreshes (static addresses for hipGraph replays)
+        out = ent[1] if ent is not None and tuple(ent[1].shape) == shape else torch.empty(shape, dtype=dtype, device=src.device)
+        if kind == "lin":
+            K.check(K.lib.lavt_cast(K.F32, K.ptr(src), K.dt(dtype), K.ptr(out), src.numel(), K.stream()))
+        else:
+            K.check(K.lib.lavt_pack_conv3x3(K.ptr(src), K.dt(dtype), K.ptr(out), src.shape[0], src.shape[1], K.stream()))
+        self.store[key] = (stamp, out, weakref.ref(p))
         return out
 
 
