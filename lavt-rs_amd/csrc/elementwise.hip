@@ -388,8 +388,8 @@ extern "C" int lavt_cls_head_bwd(int dtype, const void* x, const void* dy, const
     const int cpr = C / EPC_OF(dtype);
     LAVT_CHECK_ARG(x && dy && w && dx && dw && db && rows > 0 && C % EPC_OF(dtype) == 0 && cpr <= 256, "lavt_cls_head_bwd: bad arguments");
     const int rstep = 256 / cpr;
-    int blocks = cdiv(rows, (long)rstep * 16);
-    if (blocks > 1024) blocks = 1024;
+    int blocks = cdiv(rows, (long)rstep * 64);
+    if (blocks > 128) blocks = 128;       // few workgroups: each ends with 2*C atomics
     if (blocks < 1) blocks = 1;
     DISPATCH_T(dtype, "lavt_cls_head_bwd", hipLaunchKernelGGL(cls_head_bwd_kernel<T>, dim3(blocks), dim3(256), 0, ST, (const T*)x, (const T*)dy, w, (T*)dx, dw, db, rows, C));
     LAVT_CHECK_LAUNCH("lavt_cls_head_bwd");

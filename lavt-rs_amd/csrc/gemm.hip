@@ -315,7 +315,9 @@ static int forced_tile() {
 template <typename T> int dispatch_nt(const lavt_gemm_nt_t& p, hipStream_t st) {
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
     const int force = forced_tile();
-    const bool big = force ? force == 128 : (tiles128 >= 192 && p.N > 64);
+    // measured on MI355X (tools/gemm_bench.py): 64x64 tiles win on every backbone GEMM of the batch-2 step (they are latency-bound:
+    // more workgroups per CU hide it better); 128x128 pays only once there are >= 3 full waves of tiles (decoder convs)
+    const bool big = force ? force == 128 : (tiles128 >= 768 && p.N >= 128);
     if (p.b_kmajor) return big ? launch_nt<T, 128, 128, true>(p, st) : launch_nt<T, 64, 64, true>(p, st);
     return big ? launch_nt<T, 128, 128, false>(p, st) : launch_nt<T, 64, 64, false>(p, st);
 }
@@ -509,7 +511,7 @@ template <typename T, int BI, int BJ> int launch_tn(const lavt_gemm_tn_t& p, hip
 }
 template <typename T> int dispatch_tn(const lavt_gemm_tn_t& p, hipStream_t st) {
     const int force = forced_tile();
-    const bool big = force ? force == 128 : (p.I >= 128 && p.J >= 128 && (long)cdiv(p.I, 128) * cdiv(p.J, 128) * p.batch >= 16);
+    const bool big = force ? force == 128 : (p.I >= 256 && p.J >= 1024 && p.K >= 8192);
     return big ? launch_tn<T, 128, 128>(p, st) : launch_tn<T, 64, 64>(p, st);
 }
 

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the gather-GEMM families on the shapes of the Swin-B w12 / batch-2 step (run on the GPU box).
+Reports TFLOP/s per tile configuration (LAVT_GEMM_TILE) so the dispatch heuristic in csrc/gemm.hip can be tuned."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "lavt-rs_amd"))
+import torch  # noqa: E402
+from lavt_hip import ops  # noqa: E402
+
+dev = "cuda:0"
+bf = torch.bfloat16
+
+
+def timeit(fn, iters=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def nt(M, N, K, kmajor=False):
+    A = torch.randn(M, K, device=dev).to(bf)
+    B = torch.randn((K, N) if kmajor else (N, K), device=dev).to(bf)
+    C = torch.empty(M, N, device=dev, dtype=bf)
+    return lambda: ops.gemm_nt(bf, M, N, K, A, K, B, N if kmajor else K, C, N, b_kmajor=kmajor)
+
+
+def tn(I, J, K):
+    A = torch.randn(K, I, device=dev).to(bf)
+    B = torch.randn(K, J, device=dev).to(bf)
+    C = torch.zeros(I, J, device=dev)
+    return lambda: ops.gemm_tn(bf, I, J, K, A, I, B, J, C, J)
+
+
+SHAPES = [
+    ("qkv s2", "nt", 2592, 1536, 512), ("proj s2", "nt", 2592, 512, 512), ("fc1 s2", "nt", 1800, 2048, 512), ("fc2 s2", "nt", 1800, 512, 2048),
+    ("qkv s0", "nt", 28800, 384, 128), ("fc1 s0", "nt", 28800, 512, 128), ("fc2 s0", "nt", 28800, 128, 512), ("fc1 s1", "nt", 7200, 1024, 256),
+    ("fc1 s3", "nt", 450, 4096, 1024), ("fc2 s3", "nt", 450, 1024, 4096),
+    ("d-qkv s2", "ntk", 2592, 512, 1536), ("d-fc1 s2", "ntk", 1800, 512, 2048), ("d-fc2 s2", "ntk", 1800, 2048, 512), ("d-fc2 s0", "ntk", 28800, 512, 128),
+    ("w-qkv s2", "tn", 1536, 512, 2592), ("w-fc1 s2", "tn", 2048, 512, 1800), ("w-fc2 s2", "tn", 512, 2048, 1800), ("w-fc1 s0", "tn", 512, 128, 28800),
+    ("w-qkv s0", "tn", 384, 128, 28800), ("w-fc1 s3", "tn", 4096, 1024, 450), ("w-pwam s0", "tn", 128, 128, 28800),
+]
+
+for name, kind, a, b, c in SHAPES:
+    res = []
+    for tile in ("64", "128"):
+        os.environ["LAVT_GEMM_TILE"] = tile
+        fn = nt(a, b, c) if kind == "nt" else nt(a, b, c, True) if kind == "ntk" else tn(a, b, c)
+        t = timeit(fn)
+        res.append((tile, t * 1e6, 2.0 * a * b * c / t / 1e12))
+    os.environ.pop("LAVT_GEMM_TILE")
+    fn = nt(a, b, c) if kind == "nt" else nt(a, b, c, True) if kind == "ntk" else tn(a, b, c)
+    t = timeit(fn)
+    print(f"{name:10s} {kind:3s} {a:6d} {b:5d} {c:5d} | " + " | ".join(f"t{tile}: {us:7.1f} us {tf:6.1f} TF" for tile, us, tf in res) + f" | auto: {t * 1e6:7.1f} us")
