@@ -17,25 +17,33 @@ __device__ __forceinline__ const T* ln_src(const T* x, const int32_t* gather, in
     return x + (int64_t)src * cq + (col - q * cq);
 }
 
-template <typename T>
+// LPR = lanes per row (16 / 32 / 64): a wave normalises 64/LPR rows at once so that narrow rows (C = 96..256) still use
+// every lane; reductions are xor-shuffles inside the LPR-lane group.
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int LPR>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const int32_t* __restrict__ gather,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                             int rows, int C, float eps) {
-    constexpr int EPC = Chunk<T>::N, MAXC = LN_MAXE / EPC;
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    constexpr int EPC = Chunk<T>::N, MAXC = LPR == 64 ? LN_MAXE / EPC : 1, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, lir = lane % LPR;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row < rows;
     const int nchunk = C / EPC;
-    float v[LN_MAXE];
+    float v[MAXC * EPC];
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
-        const int ch = lane + 64 * c;
+        const int ch = lir + LPR * c;
         float f[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) f[e] = 0.f;
-        if (ch < nchunk) {
+        if (live && ch < nchunk) {
             bool ok;
             const T* src = ln_src<T>(x, gather, row, C, ch * EPC, ok);
             if (ok) chunk_to_f<T>(*reinterpret_cast<const uint4*>(src), f);
@@ -43,18 +51,19 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < EPC; ++e) { v[c * EPC + e] = f[e]; s += f[e]; }
     }
-    const float mu = wave_sum(s) / C;
+    const float mu = group_sum<LPR>(s) / C;
     float q = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
-        if (lane + 64 * c < nchunk)
+        if (lir + LPR * c < nchunk)
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { const float d = v[c * EPC + e] - mu; q += d * d; }
-    const float rs = rsqrtf(wave_sum(q) / C + eps);
-    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    const float rs = rsqrtf(group_sum<LPR>(q) / C + eps);
+    if (!live) return;
+    if (lir == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
-        const int ch = lane + 64 * c;
+        const int ch = lir + LPR * c;
         if (ch < nchunk) {
             float f[EPC];
 #pragma unroll
@@ -64,29 +73,34 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     }
 }
 
-template <typename T>
+template <typename T, int LPR>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const int32_t* __restrict__ gather, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int rows, int C) {
-    constexpr int EPC = Chunk<T>::N, MAXC = LN_MAXE / EPC;
-    const int lane = threadIdx.x & 63;
+    constexpr int EPC = Chunk<T>::N, MAXC = LPR == 64 ? LN_MAXE / EPC : 1, RPW = 64 / LPR;   // dispatch: LPR < 64 only when one chunk per lane suffices
+    const int lane = threadIdx.x & 63, lir = lane % LPR, wave = threadIdx.x >> 6;
     const int nchunk = C / EPC;
-    float dg[LN_MAXE], db[LN_MAXE];
+    const int cpl = (nchunk + LPR - 1) / LPR;          // chunks per lane actually used (<= MAXC by dispatch)
+    float dg[MAXC * EPC], db[MAXC * EPC];
 #pragma unroll
-    for (int e = 0; e < LN_MAXE; ++e) { dg[e] = 0.f; db[e] = 0.f; }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        float xh[LN_MAXE], g[LN_MAXE];
+    for (int e = 0; e < MAXC * EPC; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+    const int64_t rstride = (int64_t)gridDim.x * 4 * RPW;
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += rstride) {
+        const int64_t row = row0 + lane / LPR;
+        const bool live = row < rows;
+        const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
+        float xh[MAXC * EPC], g[MAXC * EPC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
-            const int ch = lane + 64 * c;
+            const int ch = lir + LPR * c;
+            const bool on = live && c < cpl && ch < nchunk;
             float fx[EPC], fg[EPC];
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { fx[e] = 0.f; fg[e] = 0.f; }
-            if (ch < nchunk) {
+            if (on) {
                 bool ok;
                 const T* src = ln_src<T>(x, gather, row, C, ch * EPC, ok);
                 if (ok) chunk_to_f<T>(*reinterpret_cast<const uint4*>(src), fx);
@@ -95,20 +109,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 const int k = c * EPC + e;
-                const bool live = ch < nchunk;
-                xh[k] = live ? (fx[e] - mu) * rs : 0.f;
-                const float gg = live ? fg[e] * gamma[ch * EPC + e] : 0.f;
+                xh[k] = on ? (fx[e] - mu) * rs : 0.f;
+                const float gg = on ? fg[e] * gamma[ch * EPC + e] : 0.f;
                 g[k] = gg;
                 s1 += gg; s2 += gg * xh[k];
                 dg[k] += fg[e] * xh[k];
                 db[k] += fg[e];
             }
         }
-        s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+        s1 = group_sum<LPR>(s1) / C; s2 = group_sum<LPR>(s2) / C;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < nchunk) {
+            const int ch = lir + LPR * c;
+            if (live && c < cpl && ch < nchunk) {
                 float f[EPC];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) f[e] = rs * (g[c * EPC + e] - s1 - xh[c * EPC + e] * s2);
@@ -121,29 +134,33 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
         }
     }
-    // block reduction of the four waves' partial sums through LDS, then ONE atomic per channel per workgroup
+    // sum the RPW row groups of the wave, then the four waves through LDS, then ONE atomic per channel per workgroup
+#pragma unroll
+    for (int e = 0; e < MAXC * EPC; ++e) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) { dg[e] += __shfl_xor(dg[e], o, 64); db[e] += __shfl_xor(db[e], o, 64); }
+    }
     __shared__ float red[3 * 2048];
-    const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         float* part = pass == 0 ? dg : db;
         float* dst = pass == 0 ? dgamma : dbeta;
         __syncthreads();
-        if (wave > 0) {
+        if (wave > 0 && lane < LPR) {
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {
-                const int ch = lane + 64 * c;
-                if (ch < nchunk)
+                const int ch = lir + LPR * c;
+                if (c < cpl && ch < nchunk)
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) red[(wave - 1) * 2048 + ch * EPC + e] = part[c * EPC + e];
             }
         }
         __syncthreads();
-        if (wave == 0) {
+        if (wave == 0 && lane < LPR) {
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {
-                const int ch = lane + 64 * c;
-                if (ch < nchunk)
+                const int ch = lir + LPR * c;
+                if (c < cpl && ch < nchunk)
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
                         const int col = ch * EPC + e;
@@ -319,8 +336,10 @@ extern "C" int lavt_layernorm_fwd(int dtype, const void* x, const int32_t* gathe
     LAVT_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0, "lavt_layernorm_fwd: bad arguments");
     LAVT_CHECK_ARG(C > 0 && C <= 2048 && C % epc == 0 && (!gather || (C / 4) % epc == 0), "lavt_layernorm_fwd: unsupported C=%d", C);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    DISPATCH_T(dtype, "lavt_layernorm_fwd",
-               hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const T*)x, gather, gamma, beta, (T*)y, mean, rstd, rows, C, eps));
+    const int nchunk = C / epc;
+#define LN_FWD(LPR_) hipLaunchKernelGGL((layernorm_fwd_kernel<T, LPR_>), dim3(cdiv(rows, 4 * (64 / LPR_))), dim3(256), 0, st, (const T*)x, gather, gamma, beta, (T*)y, mean, rstd, rows, C, eps)
+    DISPATCH_T(dtype, "lavt_layernorm_fwd", if (nchunk <= 16) LN_FWD(16); else if (nchunk <= 32) LN_FWD(32); else LN_FWD(64));
+#undef LN_FWD
     LAVT_CHECK_LAUNCH("lavt_layernorm_fwd");
     return LAVT_OK;
 }
@@ -332,11 +351,14 @@ extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     LAVT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "lavt_layernorm_bwd: bad arguments");
     LAVT_CHECK_ARG(C > 0 && C <= 2048 && C % epc == 0 && (!gather || (C / 4) % epc == 0), "lavt_layernorm_bwd: unsupported C=%d", C);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int blocks = cdiv(rows, 4 * 8);
-    if (blocks > 512) blocks = 512;
+    const int nchunk = C / epc;
+    const int lpr = nchunk <= 16 ? 16 : nchunk <= 32 ? 32 : 64;
+    int blocks = cdiv(rows, 4 * (64 / lpr) * 4);
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    DISPATCH_T(dtype, "lavt_layernorm_bwd",
-               hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C));
+#define LN_BWD(LPR_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C)
+    DISPATCH_T(dtype, "lavt_layernorm_bwd", if (lpr == 16) LN_BWD(16); else if (lpr == 32) LN_BWD(32); else LN_BWD(64));
+#undef LN_BWD
     LAVT_CHECK_LAUNCH("lavt_layernorm_bwd");
     return LAVT_OK;
 }

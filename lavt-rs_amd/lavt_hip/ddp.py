@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    def __init__(self, module: torch.nn.Module, bucket_mib: float = 64.0, group=None, broadcast_params: bool = True):
+    def __init__(self, module: torch.nn.Module, bucket_mib: float = 64.0, group=None, broadcast_params: bool = True, fused_accumulation: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
@@ -57,6 +57,9 @@ class GradBuckets:
         self.works = []
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        if fused_accumulation:          # weight-gradient kernels accumulate straight into `flat` (lavt_hip.ops.sinks)
+            from . import ops
+            ops.sinks.set(self.params, on_ready=self._on_grad)
         if broadcast_params and self.world > 1:
             for p in module.parameters():
                 dist.broadcast(p.data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .ddp import GradBuckets
+from .runtime import compute_dtype
 
 
 class TrainStep:
@@ -24,7 +25,7 @@ class TrainStep:
         dev = image.device
         self.x, self.l, self.m, self.t = image, l_feats, l_mask, target
         self.w = torch.tensor([0.9, 1.1], device=dev)                    # losses.py:7-11
-        self.buckets = GradBuckets(model, bucket_mib=bucket_mib)
+        self.buckets = GradBuckets(model, bucket_mib=bucket_mib, fused_accumulation=True)
         self.world = world
         self.graph = None
         self.loss = None
@@ -32,7 +33,7 @@ class TrainStep:
         self.captured = False
 
     def _body(self):
-        ops.weights.invalidate()                 # re-cast weights inside the step (they change every optimizer step)
+        ops.weights.refresh_all()                # re-cast weights inside the step (they change every optimizer step)
         self.buckets.zero()
         out = self.model(self.x, self.l, self.m)
         loss = F.cross_entropy(out, self.t, weight=self.w)
@@ -48,6 +49,7 @@ class TrainStep:
                 self.buckets.finish()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        ops.weights.build_multicast(compute_dtype())
         if not self.use_graph:
             return
         try:

@@ -59,7 +59,78 @@ class _WeightCache:
         return out
 
 
+    # ---- one-launch refresh of every cached 'lin' copy (the per-parameter casts are ~140 tiny launches per step) ----
+    def build_multicast(self, dtype):
+        """Call after a warm-up step: collects every live (param, 'lin') entry of `dtype` into a device descriptor table."""
+        ents = [(k, e) for k, e in self.store.items() if k[1] == dtype and k[2] == "lin" and e[2]() is not None]
+        if not ents:
+            self.multi = None
+            return
+        dev = ents[0][1][1].device
+        desc = torch.tensor([[e[2]().data_ptr(), e[1].data_ptr(), e[1].numel()] for _, e in ents], dtype=torch.int64)
+        self.multi = (dtype, desc.to(dev), [k for k, _ in ents])
+
+    def refresh_all(self):
+        """Start of a step: make every compute copy current (1 launch for all Linear weights + 1 per 3x3 conv)."""
+        self.epoch += 1
+        multi = getattr(self, "multi", None)
+        done = set()
+        if multi is not None:
+            dtype, desc, keys = multi
+            if all(k in self.store and self.store[k][2]() is not None for k in keys):      # parameters still alive and cached
+                K.check(K.lib.lavt_cast_multi(K.ptr(desc), desc.shape[0], K.dt(dtype), K.stream()))
+                for k in keys:
+                    st, out, ref = self.store[k]
+                    p = ref()
+                    self.store[k] = ((p._version, p.data_ptr(), self.epoch), out, ref)
+                    done.add(k)
+            else:
+                self.multi = None
+        for k, (st, out, ref) in list(self.store.items()):
+            p = ref()
+            if p is None:
+                del self.store[k]
+            elif k not in done:
+                self.get(p, k[1], k[2])
+
+
 weights = _WeightCache()
+
+
+class _GradSinks:
+    """Fused gradient accumulation: when a parameter has a sink (an fp32 view of a flat gradient buffer that the step
+    harness zeroes once per step), weight-gradient kernels accumulate straight into it and the autograd Function returns
+    None for that parameter -- no per-parameter zero-fill, no AccumulateGrad add.  `on_ready(param)` tells the bucketed
+    all-reduce that the parameter's gradient is complete.  Without sinks the ops return ordinary gradient tensors."""
+
+    def __init__(self):
+        self.map = {}
+        self.on_ready = None
+
+    def set(self, params, on_ready=None):
+        self.map = {id(p): (weakref.ref(p), p.grad) for p in params if p.grad is not None}
+        self.on_ready = on_ready
+
+    def clear(self):
+        self.map, self.on_ready = {}, None
+
+    def buf(self, p, shape):
+        """-> (fp32 buffer of `shape` to accumulate into, is_sink)"""
+        ent = self.map.get(id(p)) if p is not None else None
+        if ent is not None and ent[0]() is p:
+            return ent[1].view(shape), True
+        return torch.zeros(shape, dtype=torch.float32, device=p.device), False
+
+    def done(self, p, buf, is_sink):
+        """value to return from backward for parameter p"""
+        if not is_sink:
+            return buf.view(p.shape)
+        if self.on_ready is not None:
+            self.on_ready(p)
+        return None
+
+
+sinks = _GradSinks()
 
 
 def _f32(p: Optional[torch.Tensor]):
@@ -153,13 +224,13 @@ class _Linear(torch.autograd.Function):
             assert residual.shape == y.shape and residual.dtype == dtype
         gemm_nt(dtype, M, N, Kd, x, Kd, Wc, Kd, y, N, a_rowmap=o.in_map, bias=_f32(bias), row_scale=o.row_scale, row_scale_div=o.row_scale_div, act=o.act,
                 Cpre=pre, ldcpre=N, R=residual, ldr=N, c_rowmap=o.out_map)
-        ctx.o, ctx.M, ctx.has_bias, ctx.has_res = o, M, bias is not None, residual is not None
-        ctx.save_for_backward(x, weight, pre)
+        ctx.o, ctx.M, ctx.has_res = o, M, residual is not None
+        ctx.save_for_backward(x, weight, pre, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, pre = ctx.saved_tensors
+        x, weight, pre, bias = ctx.saved_tensors
         o, M = ctx.o, ctx.M
         dtype = x.dtype
         dy = dy.contiguous()
@@ -171,16 +242,19 @@ class _Linear(torch.autograd.Function):
         N, Kd = Wc.shape
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = (torch.zeros if o.in_map is not None else torch.empty)(x.shape, dtype=dtype, device=x.device)
+            dx = torch.empty(x.shape, dtype=dtype, device=x.device)     # in_map scatters cover every source row exactly once
             gemm_nt(dtype, M, Kd, N, g, N, Wc, Kd, dx, Kd, a_rowmap=o.out_map, b_kmajor=True, row_scale=o.row_scale,
                     row_scale_div=o.row_scale_div, c_rowmap=o.in_map)
         if ctx.needs_input_grad[1]:
-            dW = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = torch.zeros(N, dtype=torch.float32, device=x.device)
-            gemm_tn(dtype, N, Kd, M, g, N, x, Kd, dW, Kd, a_rowmap=o.out_map, a_rowscale=o.row_scale, a_rowscale_div=o.row_scale_div,
-                    b_rowmap=o.in_map, colsum=db)
-            dW = dW.view(weight.shape)
+            wbuf, wsink = sinks.buf(weight, (N, Kd))
+            bbuf = bsink = None
+            if bias is not None and ctx.needs_input_grad[2]:
+                bbuf, bsink = sinks.buf(bias, (N,))
+            gemm_tn(dtype, N, Kd, M, g, N, x, Kd, wbuf, Kd, a_rowmap=o.out_map, a_rowscale=o.row_scale, a_rowscale_div=o.row_scale_div,
+                    b_rowmap=o.in_map, colsum=bbuf)
+            dW = sinks.done(weight, wbuf, wsink)
+            if bbuf is not None:
+                db = sinks.done(bias, bbuf, bsink)
         d_res = dy if ctx.has_res and ctx.needs_input_grad[3] else None
         return dx, dW, db, d_res, None
 
@@ -199,20 +273,20 @@ class _LayerNorm(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         K.check(K.lib.lavt_layernorm_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(gather), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), K.ptr(y),
                                          K.ptr(mean), K.ptr(rstd), rows, C, eps, K.stream()))
-        ctx.save_for_backward(x, gamma, mean, rstd, gather)
+        ctx.save_for_backward(x, gamma, mean, rstd, gather, beta)
         ctx.rows, ctx.C = rows, C
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, mean, rstd, gather = ctx.saved_tensors
+        x, gamma, mean, rstd, gather, beta = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dg = torch.zeros(ctx.C, dtype=torch.float32, device=x.device)
-        db = torch.zeros_like(dg)
+        dg, gs = sinks.buf(gamma, (ctx.C,))
+        db, bs = sinks.buf(beta, (ctx.C,))
         K.check(K.lib.lavt_layernorm_bwd(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(gather), K.ptr(_f32(gamma)), K.ptr(mean), K.ptr(rstd),
                                          K.ptr(dx), K.ptr(dg), K.ptr(db), ctx.rows, ctx.C, K.stream()))
-        return dx, dg, db, None, None, None, None
+        return dx, sinks.done(gamma, dg, gs), sinks.done(beta, db, bs), None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, gather=None):
@@ -241,22 +315,22 @@ class _WindowAttn(torch.autograd.Function):
         scale = float((Cc // heads) ** -0.5)
         K.check(K.lib.lavt_window_attn_fwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(lse),
                                            nwin, N, heads, Cc // heads, scale, K.stream()))
-        ctx.save_for_backward(qkv, dense, region, out, lse)
+        ctx.save_for_backward(qkv, dense, region, out, lse, table)
         ctx.dims = (ws, heads, nwin, N, Cc, nw_img, scale, ld)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, dense, region, out, lse = ctx.saved_tensors
+        qkv, dense, region, out, lse, table = ctx.saved_tensors
         ws, heads, nwin, N, Cc, nw_img, scale, ld = ctx.dims
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         ddense = torch.zeros_like(dense)
         K.check(K.lib.lavt_window_attn_bwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout),
                                            K.ptr(lse), K.ptr(dqkv), K.ptr(ddense), nwin, N, heads, Cc // heads, scale, K.stream()))
-        dtable = torch.zeros((2 * ws - 1) ** 2, heads, dtype=torch.float32, device=qkv.device)
+        dtable, ts = sinks.buf(table, ((2 * ws - 1) ** 2, heads))
         K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense), K.ptr(dtable), ws, heads, ld, K.stream()))
-        return dqkv, dtable, None, None, None
+        return dqkv, sinks.done(table, dtable, ts), None, None, None
 
 
 def window_attention(qkv, table, region, ws, heads):
@@ -516,13 +590,13 @@ class _PatchEmbed(torch.autograd.Function):
         C0 = Wc.shape[0]
         y = torch.empty(B * H4 * W4, C0, dtype=dtype, device=img.device)
         gemm_nt(dtype, B * H4 * W4, C0, 48, cols, 48, Wc, 48, y, C0, bias=_f32(bias))
-        ctx.save_for_backward(cols, weight)
+        ctx.save_for_backward(cols, weight, bias)
         ctx.dims = (B, H, W, dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        cols, weight = ctx.saved_tensors
+        cols, weight, bias = ctx.saved_tensors
         B, H, W, dtype = ctx.dims
         dy = dy.contiguous()
         M, C0 = dy.shape
@@ -533,10 +607,10 @@ class _PatchEmbed(torch.autograd.Function):
             gemm_nt(dtype, M, 48, C0, dy, C0, Wc, 48, dcols, 48, b_kmajor=True)
             dimg = torch.empty(B, 3, H, W, dtype=torch.float32, device=dy.device)
             K.check(K.lib.lavt_col2im4(K.dt(dtype), K.ptr(dcols), K.ptr(dimg), B, H, W, K.stream()))
-        dW = torch.zeros(C0, 48, dtype=torch.float32, device=dy.device)
-        db = torch.zeros(C0, dtype=torch.float32, device=dy.device)
+        dW, wsink = sinks.buf(weight, (C0, 48))
+        db, bsink = sinks.buf(bias, (C0,))
         gemm_tn(dtype, C0, 48, M, dy, C0, cols, 48, dW, 48, colsum=db)
-        return dimg, dW.view(weight.shape), db, None
+        return dimg, sinks.done(weight, dW, wsink), sinks.done(bias, db, bsink), None
 
 
 def patch_embed(img, weight, bias, dtype):
@@ -581,9 +655,9 @@ class _Conv3x3(torch.autograd.Function):
             dx2 = torch.empty_like(x2) if x2 is not None else None
             gemm_nt(dtype, M, Cin, 9 * Cout, dy, Cout, Wp, 9 * Cin, dx1, C1, conv=(H, W, Cout, 1), b_kmajor=True, b_tap_stride=Cin,
                     C2=dx2, ldc2=C2, c_split=C1)
-        dW = torch.zeros(Cout, Cin * 9, dtype=torch.float32, device=dy.device)
+        dW, wsink = sinks.buf(weight, (Cout, Cin * 9))
         gemm_tn(dtype, Cout, 9 * Cin, M, dy, Cout, x1, C1, dW, 9 * Cin, B2=x2, ldb2=C2, b_split=C1, conv=(H, W, Cin), c_conv_permute=True)
-        return dx1, dx2, dW.view(weight.shape), None, None, None
+        return dx1, dx2, sinks.done(weight, dW, wsink), None, None, None
 
 
 def conv3x3(x1, x2, weight, B, H, W):
@@ -620,19 +694,19 @@ class _ClsHead(torch.autograd.Function):
         R, Cc = x.shape
         y = torch.empty(R, 2, dtype=x.dtype, device=x.device)
         K.check(K.lib.lavt_cls_head_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(_f32(weight)), K.ptr(_f32(bias)), K.ptr(y), R, Cc, K.stream()))
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, bias = ctx.saved_tensors
         R, Cc = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dw = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)
-        db = torch.zeros(2, dtype=torch.float32, device=x.device)
+        dw, wsink = sinks.buf(weight, (2, Cc))
+        db, bsink = sinks.buf(bias, (2,))
         K.check(K.lib.lavt_cls_head_bwd(K.dt(x.dtype), K.ptr(x), K.ptr(dy), K.ptr(_f32(weight)), K.ptr(dx), K.ptr(dw), K.ptr(db), R, Cc, K.stream()))
-        return dx, dw.view(weight.shape), db
+        return dx, sinks.done(weight, dw, wsink), sinks.done(bias, db, bsink)
 
 
 def cls_head(x, weight, bias):

@@ -111,6 +111,9 @@ class DropPath(nn.Module):
     def factors(self, B, device):
         if self.drop_prob == 0. or not self.training:
             return None
+        pre = getattr(self, "_batched", None)          # the backbone draws all blocks' factors in one shot per forward
+        if pre:
+            return pre.pop(0)
         keep = 1.0 - self.drop_prob
         return torch.floor(keep + torch.rand(B, device=device, dtype=torch.float32)) / keep
 
@@ -367,9 +370,24 @@ class MultiModalSwinTransformer(nn.Module):
             from lavt_hip.checkpoint import load_swin_checkpoint
             load_swin_checkpoint(self, pretrained)
 
+    def _draw_drop_path(self, B, device):
+        """All DropPath factors of one forward (two per block: attention branch, MLP branch) with 4 launches instead of 4 per draw."""
+        dps = [blk.drop_path for layer in self.layers for blk in layer.blocks]
+        live = [d for d in dps if self.training and d.drop_prob > 0.]
+        if not live:
+            return
+        keep = getattr(self, "_dp_keep", None)
+        if keep is None or keep.device != device or keep.shape[0] != 2 * len(live):
+            keep = torch.tensor([1.0 - d.drop_prob for d in live for _ in (0, 1)], dtype=torch.float32, device=device)[:, None]
+            self._dp_keep = keep
+        f = torch.floor(keep + torch.rand(2 * len(live), B, device=device, dtype=torch.float32)) / keep
+        for i, d in enumerate(live):
+            d._batched = [f[2 * i], f[2 * i + 1]]
+
     def forward(self, x, l, l_mask):
         dtype = compute_dtype()
         B = x.shape[0]
+        self._draw_drop_path(B, x.device)
         t, Wh, Ww = self.patch_embed.tokens(x, dtype)
         t = t.view(B, Wh * Ww, self.embed_dim)
         outs = []
