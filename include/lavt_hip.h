@@ -96,6 +96,8 @@ typedef struct lavt_gemm_nt {
     int32_t c_split;
     const int32_t* c_rowmap;
     int32_t c_f32;
+    const void* zeros; /* optional: >= 16 bytes of zeros in device memory; enables the LDS-DMA pipeline kernel (bf16) */
+    int32_t epi_lds;   /* set by the library (LAVT_GEMM_EPI=lds): stage the C tile through LDS for full-row stores */
 } lavt_gemm_nt_t;
 
 int lavt_gemm_nt(const lavt_gemm_nt_t* p, void* stream);
@@ -133,6 +135,7 @@ typedef struct lavt_gemm_tn {
     int32_t split_k;
     float* colsum;
     int64_t strideColsum;
+    const void* zeros; /* optional zero page, as in lavt_gemm_nt_t */
 } lavt_gemm_tn_t;
 
 int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);

@@ -15,64 +15,11 @@
 // no permute/roll/pad/cat copies ever touch HBM.
 #include <stdlib.h>
 
-#include "common.h"
+#include "gemm_common.h"
+
+using namespace lavt_gemm;
 
 namespace {
-
-template <typename T> struct Cfg;
-template <> struct Cfg<bf16> { static constexpr int BK = 64, KSTEP = 32, EPC = 8, KC_LD = 64; };
-template <> struct Cfg<float> { static constexpr int BK = 16, KSTEP = 4, EPC = 4, KC_LD = 20; };
-constexpr int KM_PAD = 16;
-
-// ---- LDS addressing -----------------------------------------------------------------------------
-// "KC" tile: [rows][BK], k contiguous.  bf16 rows are 128 B = 8 chunks, chunk index XOR (row & 7).
-template <typename T> __device__ __forceinline__ int kc_off(int row, int chunk) {
-    if constexpr (std::is_same<T, bf16>::value) return row * 64 + ((chunk ^ (row & 7)) << 3);
-    else return row * 20 + (chunk << 2);
-}
-
-template <typename T> struct FragT;
-template <> struct FragT<bf16> { typedef bf16x8 type; };
-template <> struct FragT<float> { typedef float type; };
-
-// fragment of a KC tile: 16 rows starting at `row0`, k-step ks
-template <typename T> __device__ __forceinline__ typename FragT<T>::type frag_kc(const T* s, int row0, int ks, int lane) {
-    const int row = row0 + (lane & 15);
-    if constexpr (std::is_same<T, bf16>::value) return *reinterpret_cast<const bf16x8*>(s + kc_off<bf16>(row, ks * 4 + (lane >> 4)));
-    else return s[row * 20 + ks * 4 + (lane >> 4)];
-}
-// fragment of a "KM" tile stored [k][ld] (k-major): 16 columns starting at col0, k-step ks
-template <typename T> __device__ __forceinline__ typename FragT<T>::type frag_km(const T* s, int ld, int col0, int ks, int lane) {
-    if constexpr (std::is_same<T, bf16>::value) {
-        const int k = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2);
-        const bf16* p = s + k * ld + col0 + 4 * (lane & 3);
-        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * ld));
-        bf16x8 r;
-        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-        return r;
-    } else {
-        return s[(ks * 4 + (lane >> 4)) * ld + col0 + (lane & 15)];
-    }
-}
-template <typename T> __device__ __forceinline__ f32x4 mfma16(typename FragT<T>::type a, typename FragT<T>::type b, f32x4 c) {
-    if constexpr (std::is_same<T, bf16>::value) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
-__device__ __forceinline__ uint4 zero16() { return make_uint4(0, 0, 0, 0); }
-
-__device__ __forceinline__ float apply_act(int act, float v) {
-    switch (act) {
-        case LAVT_ACT_GELU: return gelu_f(v);
-        case LAVT_ACT_RELU: return fmaxf(v, 0.f);
-        case LAVT_ACT_TANH: return tanhf(v);
-        default: return v;
-    }
-}
 
 // ================================================================================================
 //                                           NT family
@@ -98,7 +45,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const lavt_gemm_nt_t p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int tile_id = xcd_tile_id(blockIdx.x, gridDim.x);
+    const int tile_m = tile_id / tiles_n, tile_n = tile_id % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int bz = blockIdx.y;
 
@@ -236,57 +184,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const lavt_gemm_nt_t p) {
         __syncthreads();
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------
-    const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
-    const float* rscale = p.row_scale ? p.row_scale + (int64_t)bz * p.strideRowScale : nullptr;
-    const int64_t c_off = (int64_t)bz * p.strideC;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * WM + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        const int orow = p.c_rowmap ? p.c_rowmap[m] : m;
-        if (orow < 0) continue;
-        const float rs = rscale ? rscale[p.row_scale_div > 1 ? m / p.row_scale_div : m] : 1.f;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = n0 + wn * WN + j * 16 + 4 * (lane >> 4);
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = p.alpha * acc[i][j][r];
-                if (bias && n + r < p.N) v[r] += bias[n + r];
-                v[r] *= rs;
-            }
-            const bool full = (n + 3 < p.N);
-            if (p.Cpre) {
-                T* cp = reinterpret_cast<T*>(p.Cpre) + (int64_t)orow * p.ldcpre + n;
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = from_f<T>(v[r]);
-            }
-            if (p.act) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
-            }
-            if (p.R) {
-                const T* rp = reinterpret_cast<const T*>(p.R) + (int64_t)orow * p.ldr + n;
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += to_f<T>(rp[r]);
-            }
-            const bool second = p.C2 != nullptr && n >= p.c_split;
-            const int64_t ldc = second ? p.ldc2 : p.ldc;
-            const int nn = second ? n - p.c_split : n;
-            if (p.c_f32) {
-                float* cp = reinterpret_cast<float*>(second ? p.C2 : p.C) + c_off + (int64_t)orow * ldc + nn;
-                if (full) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-                else for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = v[r];
-            } else {
-                T* cp = reinterpret_cast<T*>(second ? p.C2 : p.C) + c_off + (int64_t)orow * ldc + nn;
-                if (full) {
-                    if constexpr (std::is_same<T, float>::value) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-                    else *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                } else for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = from_f<T>(v[r]);
-            }
+    if constexpr (std::is_same<T, bf16>::value) {
+        if (p.epi_lds && !(p.c_f32 || (p.ldc % 8) || (p.C2 && (p.ldc2 % 8 || p.c_split % 8)) || (p.R && p.ldr % 8) || (p.Cpre && p.ldcpre % 8))) {
+            nt_epilogue_lds<BM, BN, MI, NI>(p, acc, reinterpret_cast<bf16*>(smem), m0, n0, wm * WM, wn * WN, tid, lane, bz);
+            return;
         }
     }
+    nt_epilogue<T, MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
 }
 
 template <typename T, int BM, int BN, bool BKM> int launch_nt(const lavt_gemm_nt_t& p, hipStream_t st) {
@@ -517,6 +421,8 @@ template <typename T> int dispatch_tn(const lavt_gemm_tn_t& p, hipStream_t st) {
 
 }  // namespace
 
+int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st);
+
 extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
     LAVT_CHECK_ARG(pp != nullptr, "lavt_gemm_nt: null params");
     lavt_gemm_nt_t p = *pp;
@@ -534,7 +440,11 @@ extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
         LAVT_CHECK_ARG(p.K == 9 * p.conv_kc && p.conv_kc % epc == 0 && p.conv_h > 0 && p.conv_w > 0, "lavt_gemm_nt: bad conv geometry");
         LAVT_CHECK_ARG(p.M % (p.conv_h * p.conv_w) == 0, "lavt_gemm_nt: conv rows %d not a multiple of H*W", p.M);
     }
+    LAVT_CHECK_ARG((!p.R || p.ldr % 4 == 0) && (!p.Cpre || p.ldcpre % 4 == 0), "lavt_gemm_nt: ldr/ldcpre must be multiples of 4");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    { const char* e = getenv("LAVT_GEMM_EPI"); p.epi_lds = (e && e[0] == 'l') ? 1 : 0; }
+    const int rc2 = lavt_gemm_nt_v2(p, st);          // bf16 LDS-DMA pipeline (gemm_v2.hip); 1 = not applicable
+    if (rc2 != 1) return rc2;
     return p.dtype == LAVT_F32 ? dispatch_nt<float>(p, st) : dispatch_nt<bf16>(p, st);
 }
 

@@ -1,0 +1,207 @@
+// Shared tile / fragment helpers of the gather-GEMM kernels (gemm.hip: register-staged v1; gemm_v2.hip: LDS-DMA pipeline).
+#pragma once
+#include "common.h"
+
+namespace lavt_gemm {
+
+template <typename T> struct Cfg;
+template <> struct Cfg<bf16> { static constexpr int BK = 64, KSTEP = 32, EPC = 8, KC_LD = 64; };
+template <> struct Cfg<float> { static constexpr int BK = 16, KSTEP = 4, EPC = 4, KC_LD = 20; };
+constexpr int KM_PAD = 16;
+
+// ---- LDS addressing -----------------------------------------------------------------------------
+// "KC" tile: [rows][BK], k contiguous.  bf16 rows are 128 B = 8 chunks, chunk index XOR (row & 7).
+template <typename T> __device__ __forceinline__ int kc_off(int row, int chunk) {
+    if constexpr (std::is_same<T, bf16>::value) return row * 64 + ((chunk ^ (row & 7)) << 3);
+    else return row * 20 + (chunk << 2);
+}
+
+template <typename T> struct FragT;
+template <> struct FragT<bf16> { typedef bf16x8 type; };
+template <> struct FragT<float> { typedef float type; };
+
+// fragment of a KC tile: 16 rows starting at `row0`, k-step ks
+template <typename T> __device__ __forceinline__ typename FragT<T>::type frag_kc(const T* s, int row0, int ks, int lane) {
+    const int row = row0 + (lane & 15);
+    if constexpr (std::is_same<T, bf16>::value) return *reinterpret_cast<const bf16x8*>(s + kc_off<bf16>(row, ks * 4 + (lane >> 4)));
+    else return s[row * 20 + ks * 4 + (lane >> 4)];
+}
+// fragment of a "KM" tile stored [k][ld] (k-major): 16 columns starting at col0, k-step ks
+template <typename T> __device__ __forceinline__ typename FragT<T>::type frag_km(const T* s, int ld, int col0, int ks, int lane) {
+    if constexpr (std::is_same<T, bf16>::value) {
+        const int k = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2);
+        const bf16* p = s + k * ld + col0 + 4 * (lane & 3);
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * ld));
+        bf16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    } else {
+        return s[(ks * 4 + (lane >> 4)) * ld + col0 + (lane & 15)];
+    }
+}
+template <typename T> __device__ __forceinline__ f32x4 mfma16(typename FragT<T>::type a, typename FragT<T>::type b, f32x4 c) {
+    if constexpr (std::is_same<T, bf16>::value) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 zero16() { return make_uint4(0, 0, 0, 0); }
+
+__device__ __forceinline__ float apply_act(int act, float v) {
+    switch (act) {
+        case LAVT_ACT_GELU: return gelu_f(v);
+        case LAVT_ACT_RELU: return fmaxf(v, 0.f);
+        case LAVT_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+
+// ---- XCD-aware workgroup -> tile order ----------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2): blocks b and b+8 share an L2.  Give each
+// XCD a CONTIGUOUS range of logical tiles (n fastest), so the tiles resident on one XCD share A row-panels and the whole
+// of B instead of every XCD streaming every panel (bijective for any grid size; speed only, never correctness).
+__device__ __forceinline__ int xcd_tile_id(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, i = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+// ---- NT epilogue shared by both generations: accumulators hold C^T tiles (rows = 4 consecutive n per lane, column = m) ----
+template <typename T, int MI, int NI>
+__device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz) {
+    const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
+    const float* rscale = p.row_scale ? p.row_scale + (int64_t)bz * p.strideRowScale : nullptr;
+    const int64_t c_off = (int64_t)bz * p.strideC;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m_base + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int orow = p.c_rowmap ? p.c_rowmap[m] : m;
+        if (orow < 0) continue;
+        const float rs = rscale ? rscale[p.row_scale_div > 1 ? m / p.row_scale_div : m] : 1.f;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n_base + j * 16 + 4 * (lane >> 4);
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = p.alpha * acc[i][j][r];
+                if (bias && n + r < p.N) v[r] += bias[n + r];
+                v[r] *= rs;
+            }
+            const bool full = (n + 3 < p.N);
+            if (p.Cpre) {
+                T* cp = reinterpret_cast<T*>(p.Cpre) + (int64_t)orow * p.ldcpre + n;
+                if (full) {
+                    if constexpr (std::is_same<T, float>::value) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                    else *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                } else for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = from_f<T>(v[r]);
+            }
+            if (p.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
+            }
+            if (p.R) {
+                const T* rp = reinterpret_cast<const T*>(p.R) + (int64_t)orow * p.ldr + n;
+                if (full) {
+                    if constexpr (std::is_same<T, float>::value) { const float4 q = *reinterpret_cast<const float4*>(rp); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
+                    else { const uint2 q = *reinterpret_cast<const uint2*>(rp); v[0] += __uint_as_float(q.x << 16); v[1] += __uint_as_float(q.x & 0xFFFF0000u); v[2] += __uint_as_float(q.y << 16); v[3] += __uint_as_float(q.y & 0xFFFF0000u); }
+                } else for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += to_f<T>(rp[r]);
+            }
+            const bool second = p.C2 != nullptr && n >= p.c_split;
+            const int64_t ldc = second ? p.ldc2 : p.ldc;
+            const int nn = second ? n - p.c_split : n;
+            if (p.c_f32) {
+                float* cp = reinterpret_cast<float*>(second ? p.C2 : p.C) + c_off + (int64_t)orow * ldc + nn;
+                if (full) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                else for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = v[r];
+            } else {
+                T* cp = reinterpret_cast<T*>(second ? p.C2 : p.C) + c_off + (int64_t)orow * ldc + nn;
+                if (full) {
+                    if constexpr (std::is_same<T, float>::value) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                    else *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                } else for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = from_f<T>(v[r]);
+            }
+        }
+    }
+}
+
+
+// ---- bf16 NT epilogue staged through LDS: full-row 16-byte stores -------------------------------------------------------
+// The direct epilogue above issues 8-byte stores that touch 16 different rows per wave-instruction (32-B segments): the
+// store tail is issue-bound (cdna_hip_programming.md T21).  Here the C tile goes registers -> LDS ([BM][BN+8] bf16) -> global
+// as 16 B per lane, 4 full 256-B rows per wave-instruction; the residual is read with the same coalesced pattern.
+template <int BM, int BN, int MI, int NI>
+__device__ __forceinline__ void nt_epilogue_lds(const lavt_gemm_nt_t& p, f32x4 (&acc)[MI][NI], bf16* sC, int m0, int n0, int wm_off, int wn_off,
+                                                int tid, int lane, int bz) {
+    constexpr int LD = BN + 8, CPR = BN / 8, CHUNKS = BM * CPR;
+    const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
+    const float* rscale = p.row_scale ? p.row_scale + (int64_t)bz * p.strideRowScale : nullptr;
+    const int64_t c_off = (int64_t)bz * p.strideC;
+    float rs[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm_off + i * 16 + (lane & 15);
+        rs[i] = (rscale && m < p.M) ? rscale[p.row_scale_div > 1 ? m / p.row_scale_div : m] : 1.f;
+    }
+    const int npass = p.Cpre ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        const bool pre = p.Cpre && pass == 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int ml = wm_off + i * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int nl = wn_off + j * 16 + 4 * (lane >> 4);
+                const int n = n0 + nl;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = p.alpha * acc[i][j][r];
+                    if (bias && n + r < p.N) v[r] += bias[n + r];
+                    v[r] *= rs[i];
+                    if (!pre && p.act) v[r] = apply_act(p.act, v[r]);
+                }
+                *reinterpret_cast<uint2*>(sC + ml * LD + nl) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < CHUNKS; idx += 256) {
+            const int row = idx / CPR, c = idx - row * CPR;
+            const int m = m0 + row, n = n0 + c * 8;
+            if (m >= p.M || n >= p.N) continue;
+            const int orow = p.c_rowmap ? p.c_rowmap[m] : m;
+            if (orow < 0) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(sC + row * LD + c * 8);
+            const bool full = n + 8 <= p.N;
+            bf16* dst;
+            if (pre) dst = reinterpret_cast<bf16*>(p.Cpre) + (int64_t)orow * p.ldcpre + n;
+            else {
+                const bool second = p.C2 != nullptr && n >= p.c_split;
+                dst = reinterpret_cast<bf16*>(second ? p.C2 : p.C) + c_off + (int64_t)orow * (second ? p.ldc2 : p.ldc) + (second ? n - p.c_split : n);
+            }
+            if (!pre && p.R) {
+                const bf16* rp = reinterpret_cast<const bf16*>(p.R) + (int64_t)orow * p.ldr + n;
+                float a[8], b[8];
+                chunk_to_f<bf16>(v, a);
+                if (full) chunk_to_f<bf16>(*reinterpret_cast<const uint4*>(rp), b);
+                else for (int e = 0; e < 8; ++e) b[e] = n + e < p.N ? to_f<bf16>(rp[e]) : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += b[e];
+                v = f_to_chunk<bf16>(a);
+            }
+            if (full) *reinterpret_cast<uint4*>(dst) = v;
+            else {
+                const bf16* sv = reinterpret_cast<const bf16*>(&v);
+                for (int e = 0; e < 8; ++e) if (n + e < p.N) dst[e] = sv[e];
+            }
+        }
+    }
+}
+
+}  // namespace lavt_gemm

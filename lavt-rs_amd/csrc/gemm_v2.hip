@@ -1,0 +1,293 @@
+// Gather-GEMM, second generation (bf16): LDS-DMA multi-stage pipeline.
+//
+// Why: at batch 2/GPU the backbone GEMMs of Swin-B are small (M ~ 1.8-2.6 k rows).  Measured on MI355X
+// (tools/gemm_bench.py), the register-staged kernel of gemm.hip is either L2-bandwidth bound (64x64 tiles: 32 flop/B
+// of L2->LDS traffic) or latency bound (128x128 tiles, one workgroup per CU, one K tile in flight).  This kernel keeps
+// the 128x128 tile (64 flop/B) and hides the latency with a 3-deep ring of K tiles filled by
+// `global_load_lds_dwordx4` (HBM/L2 -> LDS directly, no VGPR staging), counted `s_waitcnt vmcnt(N)` so that later tiles
+// stay in flight across the single raw `s_barrier` per K tile:
+//
+//     prologue: DMA tile 0 -> stage 0, tile 1 -> stage 1
+//     for kt:   s_waitcnt vmcnt(L)   (tile kt landed; tile kt+1 may still fly)        L = DMA instructions / wave / tile
+//               s_barrier            (everyone's tile kt landed; everyone done reading tile kt-1)
+//               DMA tile kt+2 -> stage (kt+2)%3   (= the stage tile kt-1 occupied)
+//               16 ds_read_b128 + 32 MFMA on stage kt%3
+//
+// The LDS image is lane-linear per DMA instruction (wave-uniform base + lane*16 B), so the XOR swizzle that makes the
+// fragment reads conflict-free is applied to the per-lane SOURCE address (each lane fetches the logical chunk that
+// belongs at its physical position); row gathers (window maps, 3x3 taps, concat) are per-lane source addresses too.
+// Rows / chunks that must read zero (padding, halo, tails) fetch from a caller-provided zero page (`p.zeros`).
+#include <stdlib.h>
+
+#include "gemm_common.h"
+
+using namespace lavt_gemm;
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+__device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ---- transposing LDS reads issued from inline asm --------------------------------------------------------------------
+// hipcc puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr builtin while LDS-DMA is in flight (it cannot tell the stages
+// apart), which would serialise the pipeline.  Asm reads are invisible to that pass; we wait for them ourselves:
+// issue all reads of a K tile ("=v" outputs), then ONE statement `s_waitcnt lgkmcnt(0)` that names every destination "+v"
+// (so no consumer can be scheduled above it), then sched_barrier (cdna_hip_programming.md rule 18 / 5.7 form ii).
+// All 2*NF reads of one k-step share one address VGPR: they differ by compile-time byte offsets.
+typedef unsigned long long u64;
+// One statement = all transposing reads of a K tile (both k-steps) + the wait, early-clobber outputs: the compiler can
+// neither copy a destination before its data has landed nor schedule a consumer above the wait (5.7 form i).
+// Reads differ by compile-time byte offsets from one address VGPR: fragment stride SF, second 4-row block HO, k-step KO.
+template <int NF, int SF, int HO, int KO>
+__device__ __forceinline__ void tr_read_tile(unsigned addr, u64 (&l0)[NF], u64 (&h0)[NF], u64 (&l1)[NF], u64 (&h1)[NF]) {
+    static_assert(NF == 2 || NF == 4, "NF");
+    if constexpr (NF == 4) {
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:%c18\n\t"
+            "ds_read_b64_tr_b16 %2, %16 offset:%c17\n\tds_read_b64_tr_b16 %3, %16 offset:%c17+%c18\n\t"
+            "ds_read_b64_tr_b16 %4, %16 offset:2*%c17\n\tds_read_b64_tr_b16 %5, %16 offset:2*%c17+%c18\n\t"
+            "ds_read_b64_tr_b16 %6, %16 offset:3*%c17\n\tds_read_b64_tr_b16 %7, %16 offset:3*%c17+%c18\n\t"
+            "ds_read_b64_tr_b16 %8, %16 offset:%c19\n\tds_read_b64_tr_b16 %9, %16 offset:%c19+%c18\n\t"
+            "ds_read_b64_tr_b16 %10, %16 offset:%c19+%c17\n\tds_read_b64_tr_b16 %11, %16 offset:%c19+%c17+%c18\n\t"
+            "ds_read_b64_tr_b16 %12, %16 offset:%c19+2*%c17\n\tds_read_b64_tr_b16 %13, %16 offset:%c19+2*%c17+%c18\n\t"
+            "ds_read_b64_tr_b16 %14, %16 offset:%c19+3*%c17\n\tds_read_b64_tr_b16 %15, %16 offset:%c19+3*%c17+%c18\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(l0[0]), "=&v"(h0[0]), "=&v"(l0[1]), "=&v"(h0[1]), "=&v"(l0[2]), "=&v"(h0[2]), "=&v"(l0[3]), "=&v"(h0[3]),
+              "=&v"(l1[0]), "=&v"(h1[0]), "=&v"(l1[1]), "=&v"(h1[1]), "=&v"(l1[2]), "=&v"(h1[2]), "=&v"(l1[3]), "=&v"(h1[3])
+            : "v"(addr), "n"(SF), "n"(HO), "n"(KO)
+            : "memory");
+    } else {
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%c10\n\t"
+            "ds_read_b64_tr_b16 %2, %8 offset:%c9\n\tds_read_b64_tr_b16 %3, %8 offset:%c9+%c10\n\t"
+            "ds_read_b64_tr_b16 %4, %8 offset:%c11\n\tds_read_b64_tr_b16 %5, %8 offset:%c11+%c10\n\t"
+            "ds_read_b64_tr_b16 %6, %8 offset:%c11+%c9\n\tds_read_b64_tr_b16 %7, %8 offset:%c11+%c9+%c10\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(l0[0]), "=&v"(h0[0]), "=&v"(l0[1]), "=&v"(h0[1]), "=&v"(l1[0]), "=&v"(h1[0]), "=&v"(l1[1]), "=&v"(h1[1])
+            : "v"(addr), "n"(SF), "n"(HO), "n"(KO)
+            : "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 frag_from(u64 lo, u64 hi) {
+    typedef __attribute__((__vector_size__(2 * sizeof(u64)))) u64 u64x2;
+    u64x2 v = {lo, hi};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
+}
+
+template <int BM, int BN, bool BKM, int STAGES, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_nt_t p) {
+    using T = bf16;
+    constexpr int BK = 64, EPC = 8;
+    constexpr int WAVES_N = WAVES / 2;                       // wave grid: 2 (M) x WAVES/2 (N)
+    constexpr int A_INSTR = BM / (8 * WAVES);                // DMA instructions per wave per K tile for A (8 rows x 8 chunks each)
+    constexpr int B_LD = BN + KM_PAD;                        // k-major B row (elements)
+    constexpr int B_CH = B_LD / EPC;                         // chunks per k-major row
+    constexpr int B_INSTR = BKM ? (BK * B_CH + 64 * WAVES - 1) / (64 * WAVES) : BN / (8 * WAVES);
+    constexpr int L = A_INSTR + B_INSTR;
+    constexpr int A_BYTES = BM * BK * 2;
+    constexpr int B_BYTES = BKM ? B_INSTR * WAVES * 1024 : BN * BK * 2;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int WM = BM / 2, WN = BN / WAVES_N, MI = WM / 16, NI = WN / 16;
+    static_assert(A_INSTR >= 1 && B_INSTR >= 1 && MI >= 1 && NI >= 1, "tile too small for this many waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_id = xcd_tile_id(blockIdx.x, gridDim.x);
+    const int tile_m = tile_id / tiles_n, tile_n = tile_id % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int bz = blockIdx.y;
+
+    const T* A = reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.strideA;
+    const T* A2 = reinterpret_cast<const T*>(p.A2);
+    const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.strideB;
+    const T* Z = reinterpret_cast<const T*>(p.zeros);
+    const bool conv = p.conv_kc > 0;
+    const int HW = p.conv_h * p.conv_w;
+
+    // ---- per-lane DMA geometry ------------------------------------------------------------------------------
+    // k-contiguous tiles: instruction ii covers rows ii*8 .. ii*8+7; lane -> row ii*8 + lane/8, physical chunk lane%8,
+    // logical chunk (lane%8) ^ (row%8) = (lane%8) ^ (lane/8): constant per lane.
+    const int cl = (lane & 7) ^ (lane >> 3);
+    int a_src[A_INSTR];
+    short a_y[A_INSTR], a_x[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int m = m0 + (wave * A_INSTR + i) * 8 + (lane >> 3);
+        int src = -1;
+        if (m < p.M) src = p.a_rowmap ? p.a_rowmap[m] : m;
+        a_src[i] = src;
+        if (conv && src >= 0) { const int pix = src % HW; a_y[i] = (short)(pix / p.conv_w); a_x[i] = (short)(pix % p.conv_w); }
+        else { a_y[i] = 0; a_x[i] = 0; }
+    }
+    int b_row[B_INSTR], b_col[B_INSTR];          // KC: b_row = n (or -1); KM: b_row = k row in tile (or -1), b_col = n (or -1)
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        if constexpr (!BKM) {
+            const int n = n0 + (wave * B_INSTR + i) * 8 + (lane >> 3);
+            b_row[i] = n < p.N ? n : -1;
+            b_col[i] = 0;
+        } else {
+            const int q = (wave * B_INSTR + i) * 64 + lane;
+            const int kr = q / B_CH, cc = q - kr * B_CH;
+            const int n = n0 + cc * EPC;
+            const bool ok = kr < BK && cc * EPC < BN && n < p.N;
+            b_row[i] = ok ? kr : -1;
+            b_col[i] = n;
+        }
+    }
+
+    auto issue = [&](int kt, int stage) {
+        char* sbase = smem + stage * STAGE_BYTES;
+        // A
+        const int k = kt * BK + cl * EPC;
+        int kin = k, dy = 0, dx = 0;
+        if (conv) {
+            const int tap = k / p.conv_kc;
+            kin = k - tap * p.conv_kc;
+            dy = tap / 3 - 1; dx = tap % 3 - 1;
+            if (p.conv_flip) { dy = -dy; dx = -dx; }
+        }
+        const bool second = (p.A2 != nullptr) && kin >= p.a_split;
+        const T* base = second ? A2 : A;
+        const int64_t ld = second ? p.lda2 : p.lda;
+        const int kk = second ? kin - p.a_split : kin;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            int src = a_src[i];
+            if (conv) {
+                const int y = a_y[i] + dy, x = a_x[i] + dx;
+                src = (src >= 0 && y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) ? src + dy * p.conv_w + dx : -1;
+            }
+            const T* g = (src >= 0 && k < p.K) ? base + (int64_t)src * ld + kk : Z;
+            dma16(g, sbase + (wave * A_INSTR + i) * 1024);
+        }
+        // B
+        char* sb = sbase + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const T* g = Z;
+            if constexpr (!BKM) {
+                if (b_row[i] >= 0 && k < p.K) g = B + (int64_t)b_row[i] * p.ldb + k;
+            } else {
+                const int kb = kt * BK + b_row[i];
+                if (b_row[i] >= 0 && kb < p.K) {
+                    int64_t off;
+                    if (conv) { const int t2 = kb / p.conv_kc; off = (int64_t)(kb - t2 * p.conv_kc) * p.ldb + (int64_t)t2 * p.b_tap_stride; }
+                    else off = (int64_t)kb * p.ldb;
+                    g = B + off + b_col[i];
+                }
+            }
+            dma16(g, sb + (wave * B_INSTR + i) * 1024);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ktiles = (p.K + BK - 1) / BK;
+    issue(0, 0);
+    if (STAGES > 2 && ktiles > 1) issue(1, 1);
+    for (int kt = 0; kt < ktiles; ++kt) {
+        if (STAGES > 2 && kt + 1 < ktiles) wait_vmcnt<L>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < ktiles) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        const T* cA = reinterpret_cast<const T*>(smem + (kt % STAGES) * STAGE_BYTES);
+        const T* cB = reinterpret_cast<const T*>(smem + (kt % STAGES) * STAGE_BYTES + A_BYTES);
+        bf16x8 fa[2][MI], fb[2][NI];
+        if constexpr (BKM) {
+            // lane address of (k-step 0, fragment 0): row 8*(lane>>4) + ((lane&15)>>2), column wn*WN + 4*(lane&3)
+            const unsigned a0 = lds_addr(cB) + (unsigned)(((8 * (lane >> 4) + ((lane & 15) >> 2)) * B_LD + wn * WN + 4 * (lane & 3)) * 2);
+            u64 l0[NI], h0[NI], l1[NI], h1[NI];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[ks][i] = frag_kc<T>(cA, wm * WM + i * 16, ks, lane);
+            tr_read_tile<NI, 32, 4 * B_LD * 2, 32 * B_LD * 2>(a0, l0, h0, l1, h1);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) { fb[0][j] = frag_from(l0[j], h0[j]); fb[1][j] = frag_from(l1[j], h1[j]); }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[ks][i] = frag_kc<T>(cA, wm * WM + i * 16, ks, lane);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) fb[ks][j] = frag_kc<T>(cB, wn * WN + j * 16, ks, lane);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = mfma16<T>(fb[ks][j], fa[ks][i], acc[i][j]);
+    }
+    if (!p.epi_lds || p.c_f32 || (p.ldc % 8) || (p.C2 && (p.ldc2 % 8 || p.c_split % 8)) || (p.R && p.ldr % 8) || (p.Cpre && p.ldcpre % 8))
+        nt_epilogue<T, MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
+    else
+        nt_epilogue_lds<BM, BN, MI, NI>(p, acc, reinterpret_cast<bf16*>(smem), m0, n0, wm * WM, wn * WN, tid, lane, bz);
+}
+
+template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
+    constexpr int B_INSTR = BKM ? (64 * ((BN + KM_PAD) / 8) + 64 * WAVES - 1) / (64 * WAVES) : BN / (8 * WAVES);
+    constexpr size_t lds = STAGES * (size_t)(BM * 128 + (BKM ? B_INSTR * WAVES * 1024 : BN * 128));
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            lavt_set_error("lavt_gemm_nt(v2): cannot reserve %zu bytes of LDS", lds);
+            return LAVT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch);
+    hipLaunchKernelGGL((gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES>), grid, dim3(WAVES * 64), lds, st, p);
+    LAVT_CHECK_LAUNCH("lavt_gemm_nt(v2)");
+    return LAVT_OK;
+}
+
+}  // namespace
+
+// returns 1 when the problem is not for this kernel (caller falls back to gemm.hip), else a LAVT status
+int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
+    if (p.dtype != LAVT_BF16 || p.zeros == nullptr) return 1;
+    const char* e = getenv("LAVT_GEMM_V2");
+    if (e && e[0] == '0') return 1;
+    if (p.lda % 8 || p.ldb % 8 || (p.A2 && p.lda2 % 8)) return 1;
+    // Dispatch measured on MI355X (tools/gemm_bench.py, hipGraph-timed): 128x128 tile with 8 waves (2 per SIMD: one wave's DMA issue and
+    // LDS reads hide under the other's MFMAs) and a 2-stage ring (64-80 KiB -> 2 workgroups per CU) once there are >= 200 such tiles;
+    // otherwise 64x64 tiles / 4 waves (5 workgroups per CU), 3 stages only for long-K problems with few tiles.
+    const char* t = getenv("LAVT_GEMM_TILE");
+    const int force = t ? atoi(t) : 0;
+    const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
+    const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;
+    const bool big = force ? force == 128 : (tiles128 >= 200 && p.N >= 128);
+    const char* sg = getenv("LAVT_GEMM_STAGES");
+    const int stages = sg ? atoi(sg) : (big ? 2 : (tiles64 < 300 && p.K >= 2048 ? 3 : 2));
+    const char* wv = getenv("LAVT_GEMM_WAVES");
+    const int waves = wv ? atoi(wv) : 8;
+#define GO(BM_, BN_, KM_, ST_, WV_) return launch_nt_v2<BM_, BN_, KM_, ST_, WV_>(p, st)
+    if (big) {
+        if (waves == 8) {
+            if (stages == 2) { if (p.b_kmajor) GO(128, 128, true, 2, 8); else GO(128, 128, false, 2, 8); }
+            if (p.b_kmajor) GO(128, 128, true, 3, 8); else GO(128, 128, false, 3, 8);
+        }
+        if (stages == 2) { if (p.b_kmajor) GO(128, 128, true, 2, 4); else GO(128, 128, false, 2, 4); }
+        if (p.b_kmajor) GO(128, 128, true, 3, 4); else GO(128, 128, false, 3, 4);
+    }
+    if (stages == 2) { if (p.b_kmajor) GO(64, 64, true, 2, 4); else GO(64, 64, false, 2, 4); }
+    if (p.b_kmajor) GO(64, 64, true, 3, 4); else GO(64, 64, false, 3, 4);
+#undef GO
+}

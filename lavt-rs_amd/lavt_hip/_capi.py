@@ -31,7 +31,7 @@ class GemmNT(C.Structure):
         ("alpha", f32), ("bias", vp), ("strideBias", i64), ("row_scale", vp), ("strideRowScale", i64), ("row_scale_div", i32), ("act", i32),
         ("Cpre", vp), ("ldcpre", i64), ("R", vp), ("ldr", i64),
         ("C", vp), ("ldc", i64), ("strideC", i64), ("C2", vp), ("ldc2", i64), ("c_split", i32), ("c_rowmap", vp),
-        ("c_f32", i32),
+        ("c_f32", i32), ("zeros", vp), ("epi_lds", i32),
     ]
 
 
@@ -42,7 +42,7 @@ class GemmTN(C.Structure):
         ("B", vp), ("ldb", i64), ("strideB", i64), ("B2", vp), ("ldb2", i64), ("b_split", i32), ("b_rowmap", vp),
         ("conv_h", i32), ("conv_w", i32), ("conv_kc", i32),
         ("alpha", f32), ("C", vp), ("ldc", i64), ("strideC", i64), ("c_conv_permute", i32), ("split_k", i32),
-        ("colsum", vp), ("strideColsum", i64),
+        ("colsum", vp), ("strideColsum", i64), ("zeros", vp),
     ]
 
 

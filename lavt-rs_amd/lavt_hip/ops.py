@@ -140,6 +140,17 @@ def _f32(p: Optional[torch.Tensor]):
     return p.detach()
 
 
+_ZERO_PAGES = {}
+
+
+def _zero_page(device):
+    """256 zero bytes per device: source of every chunk that must read 0 in the LDS-DMA GEMM (padding rows, conv halo, tails)."""
+    z = _ZERO_PAGES.get(device)
+    if z is None:
+        z = _ZERO_PAGES[device] = torch.zeros(64, dtype=torch.float32, device=device)
+    return z.data_ptr()
+
+
 # ------------------------------------------------------------------------------------------ raw launches
 def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, strideB=0, strideC=0, A2=None, lda2=0,
             a_split=0, a_rowmap=None, conv=None, b_kmajor=False, b_tap_stride=0, alpha=1.0, bias=None, strideBias=0,
@@ -161,6 +172,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.C, p.ldc, p.strideC = K.ptr(Cout) + c_off * (4 if c_f32 else es), ldc, strideC
     p.C2, p.ldc2, p.c_split = K.ptr(C2), ldc2, c_split
     p.c_rowmap, p.c_f32 = K.ptr(c_rowmap), int(c_f32)
+    p.zeros = _zero_page(A.device)
     K.check(K.lib.lavt_gemm_nt(C.byref(p), K.stream()))
 
 
@@ -180,6 +192,7 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.alpha, p.C, p.ldc, p.strideC = alpha, K.ptr(Cout) + c_off * 4, ldc, strideC
     p.c_conv_permute, p.split_k = int(c_conv_permute), 0
     p.colsum, p.strideColsum = K.ptr(colsum), strideColsum
+    p.zeros = _zero_page(A.device)
     K.check(K.lib.lavt_gemm_tn(C.byref(p), K.stream()))
 
 

@@ -13,17 +13,24 @@ dev = "cuda:0"
 bf = torch.bfloat16
 
 
-def timeit(fn, iters=30):
+def timeit(fn, iters=20, reps=5):
+    """GPU time per launch: the launches are captured into a hipGraph (no Python/ctypes time between kernels)."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(reps):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+    return e0.elapsed_time(e1) / (iters * reps) * 1e-3
 
 
 def nt(M, N, K, kmajor=False):
@@ -41,6 +48,7 @@ def tn(I, J, K):
 
 
 SHAPES = [
+    ("conv2_2", "nt", 28800, 512, 4608), ("conv1_2-ish", "nt", 28800, 512, 5760), ("conv @60", "nt", 7200, 512, 4608),
     ("qkv s2", "nt", 2592, 1536, 512), ("proj s2", "nt", 2592, 512, 512), ("fc1 s2", "nt", 1800, 2048, 512), ("fc2 s2", "nt", 1800, 512, 2048),
     ("qkv s0", "nt", 28800, 384, 128), ("fc1 s0", "nt", 28800, 512, 128), ("fc2 s0", "nt", 28800, 128, 512), ("fc1 s1", "nt", 7200, 1024, 256),
     ("fc1 s3", "nt", 450, 4096, 1024), ("fc2 s3", "nt", 450, 1024, 4096),
@@ -51,12 +59,16 @@ SHAPES = [
 
 for name, kind, a, b, c in SHAPES:
     res = []
-    for tile in ("64", "128"):
+    for tile, stages, v2, wv in (("64", "3", "0", "4"), ("64", "2", "1", "4"), ("64", "3", "1", "4"), ("128", "2", "1", "4"), ("128", "2", "1", "8"), ("128", "3", "1", "8")):
         os.environ["LAVT_GEMM_TILE"] = tile
+        os.environ["LAVT_GEMM_STAGES"] = stages
+        os.environ["LAVT_GEMM_V2"] = v2
+        os.environ["LAVT_GEMM_WAVES"] = wv
         fn = nt(a, b, c) if kind == "nt" else nt(a, b, c, True) if kind == "ntk" else tn(a, b, c)
         t = timeit(fn)
-        res.append((tile, t * 1e6, 2.0 * a * b * c / t / 1e12))
-    os.environ.pop("LAVT_GEMM_TILE")
+        res.append((("v2" if v2 == "1" else "v1") + "-" + tile + ("s" + stages + "w" + wv if v2 == "1" else ""), t * 1e6, 2.0 * a * b * c / t / 1e12))
+    for k in ("LAVT_GEMM_TILE", "LAVT_GEMM_STAGES", "LAVT_GEMM_V2", "LAVT_GEMM_WAVES"):
+        os.environ.pop(k)
     fn = nt(a, b, c) if kind == "nt" else nt(a, b, c, True) if kind == "ntk" else tn(a, b, c)
     t = timeit(fn)
-    print(f"{name:10s} {kind:3s} {a:6d} {b:5d} {c:5d} | " + " | ".join(f"t{tile}: {us:7.1f} us {tf:6.1f} TF" for tile, us, tf in res) + f" | auto: {t * 1e6:7.1f} us")
+    print(f"{name:9s} {kind:3s} {a:6d} {b:5d} {c:5d} | " + " | ".join(f"{tile}: {us:5.1f}us {tf:4.0f}" for tile, us, tf in res) + f" | auto: {t * 1e6:5.1f}us")
