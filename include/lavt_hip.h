@@ -136,6 +136,8 @@ typedef struct lavt_gemm_tn {
     float* colsum;
     int64_t strideColsum;
     const void* zeros; /* optional zero page, as in lavt_gemm_nt_t */
+    int32_t a_rowscale_binary; /* 1: a_rowscale holds only 0 and ONE non-zero value which the caller folded into alpha (row masks) */
+    int32_t accumulate;        /* 1: C += (atomics) even without split-K; 0: C may be overwritten when the reduction is not split */
 } lavt_gemm_tn_t;
 
 int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);
@@ -171,26 +173,28 @@ int lavt_relpos_reduce(const float* ddense, float* dtable, int ws, int heads, in
 int lavt_layernorm_fwd(int dtype, const void* x, const int32_t* gather, const float* gamma, const float* beta, void* y,
                        float* mean, float* rstd, int rows, int C, float eps, void* stream);
 int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
-                       const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int C,
-                       void* stream);
+                       const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats,
+                       int rows, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-channel statistics over rows, and the normalisations built on them:
  *   InstanceNorm1d over all H*W positions (PWAM f_query / W, lib/backbone.py:1311-1327): groups = batch;
  *   BatchNorm2d (+ReLU) of the decoder (lib/mask_predictor.py:19-37; SyncBN = all-reduce of sums between the calls).
  * lavt_colstats: x [groups][rows][C] -> sum, sumsq fp32 [groups][C] (accumulated: pass zeroed buffers).
+ * ws / ws_floats (here, in lavt_norm_bwd_stats and lavt_layernorm_bwd): optional fp32 scratch of >= 1025*groups*2*C floats; with it the
+ *   per-workgroup partial sums are written out and reduced by a second tiny kernel instead of contending atomics on the same C addresses.
  * lavt_norm_apply: y = ((x-mean)*rstd*gamma + beta) (*mul) with optional ReLU; mean/rstd [groups][C]; gamma/beta/mul optional.
  * lavt_norm_bwd_stats: s1 += sum(g), s2 += sum(g*xhat) with g = dy (*mul) masked by relu (y>0);  [groups][C].
  * lavt_norm_bwd_apply: dx = gamma*rstd*(g - s1/n - xhat*s2/n); dmul = dy*xhat_affine (optional).
  * ------------------------------------------------------------------------------------------- */
-int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq, int groups, int rows, int C, void* stream);
+int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq, float* ws, int64_t ws_floats, int groups, int rows, int C, void* stream);
 int lavt_stats_finalize(const float* sum, const float* sumsq, float count, float eps, float* mean, float* rstd,
                         float* running_mean, float* running_var, float momentum, int n, void* stream);
 int lavt_norm_apply(int dtype, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const void* mul, int relu, void* y, int groups, int rows, int C, void* stream);
 int lavt_norm_bwd_stats(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
                         const float* gamma, const float* beta, const void* mul, int relu, float* s1, float* s2,
-                        int groups, int rows, int C, void* stream);
+                        float* ws, int64_t ws_floats, int groups, int rows, int C, void* stream);
 int lavt_norm_bwd_apply(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
                         const float* gamma, const float* beta, const void* mul, int relu, const float* s1, const float* s2,
                         float count, void* dx, void* dmul, int groups, int rows, int C, void* stream);

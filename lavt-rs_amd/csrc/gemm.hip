@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const lavt_gemm_tn_t p, in
             ra[i] = ldg16(ok ? A + (int64_t)src * p.lda + ia : A);
             va |= (ok ? 1u : 0u) << i;
             asc[i] = p.a_rowscale ? p.a_rowscale[p.a_rowscale_div > 1 ? kc / p.a_rowscale_div : kc] : 1.f;
+            if (p.a_rowscale_binary && asc[i] != 0.f) asc[i] = 1.f;
         }
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
@@ -391,7 +392,8 @@ template <typename T, int BI, int BJ> int launch_tn(const lavt_gemm_tn_t& p, hip
     const int ktiles = cdiv(p.K, BK);
     int split = p.split_k;
     if (split <= 0) {
-        split = (int)(768 / ((long)tiles * p.batch));
+        { const char* se = getenv("LAVT_TN_SPLIT"); if (se) split = atoi(se); }
+        if (split <= 0) split = (int)(768 / ((long)tiles * p.batch));
         if (split < 1) split = 1;
         const int max_split = (ktiles + 3) / 4;        // at least 4 K tiles per workgroup
         if (split > max_split) split = max_split;
@@ -422,6 +424,7 @@ template <typename T> int dispatch_tn(const lavt_gemm_tn_t& p, hipStream_t st) {
 }  // namespace
 
 int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st);
+int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st);
 
 extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
     LAVT_CHECK_ARG(pp != nullptr, "lavt_gemm_nt: null params");
@@ -461,5 +464,7 @@ extern "C" int lavt_gemm_tn(const lavt_gemm_tn_t* pp, void* stream) {
     if (p.conv_kc > 0)
         LAVT_CHECK_ARG(p.J == 9 * p.conv_kc && p.conv_kc % epc == 0 && p.conv_h > 0 && p.conv_w > 0, "lavt_gemm_tn: bad conv geometry");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rc2 = lavt_gemm_tn_v2(p, st);          // bf16 LDS-DMA kernel (gemm_v2.hip); 1 = not applicable
+    if (rc2 != 1) return rc2;
     return p.dtype == LAVT_F32 ? dispatch_tn<float>(p, st) : dispatch_tn<bf16>(p, st);
 }

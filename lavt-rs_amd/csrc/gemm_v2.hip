@@ -258,6 +258,186 @@ template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(cons
     return LAVT_OK;
 }
 
+
+// ================================================================================================ TN (weight gradients)
+// C[I,J] (+)= alpha * sum_k A[k][i] B[k][j]; both operands k-major: LDS tiles [64 k][cols+16] filled by LDS-DMA (2-stage ring),
+// every fragment read with the transposing LDS read (asm, one statement per operand per K tile).  Row masks (DropPath /
+// language mask of the forward) are honoured by fetching masked rows from the zero page; their common non-zero value is in alpha.
+template <int BI, int BJ, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_tn_t p, int kt_per_split) {
+    using T = bf16;
+    constexpr int BK = 64, EPC = 8;
+    constexpr int WAVES_J = WAVES / 2;
+    constexpr int A_LD = BI + KM_PAD, B_LD = BJ + KM_PAD, A_CH = A_LD / EPC, B_CH = B_LD / EPC;
+    constexpr int A_INSTR = (BK * A_CH + 64 * WAVES - 1) / (64 * WAVES), B_INSTR = (BK * B_CH + 64 * WAVES - 1) / (64 * WAVES);
+    constexpr int A_BYTES = A_INSTR * WAVES * 1024, B_BYTES = B_INSTR * WAVES * 1024, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int WI = BI / 2, WJ = BJ / WAVES_J, II = WI / 16, JJ = WJ / 16;
+    static_assert((II == 2 || II == 4) && (JJ == 2 || JJ == 4), "fragment counts");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave / WAVES_J, wj = wave % WAVES_J;
+    const int tiles_j = (p.J + BJ - 1) / BJ;
+    const int tile_i = blockIdx.x / tiles_j, tile_j = blockIdx.x % tiles_j;
+    const int i0 = tile_i * BI, j0 = tile_j * BJ;
+    const int bz = blockIdx.y;
+    const int ktiles = (p.K + BK - 1) / BK;
+    const int kt_begin = blockIdx.z * kt_per_split, kt_end = min(ktiles, kt_begin + kt_per_split);
+    if (kt_begin >= kt_end) return;
+
+    const T* A = reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.strideA;
+    const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.strideB;
+    const T* B2 = reinterpret_cast<const T*>(p.B2);
+    const T* Z = reinterpret_cast<const T*>(p.zeros);
+    const bool conv = p.conv_kc > 0;
+    const int HW = p.conv_h * p.conv_w;
+
+    // per-lane DMA geometry (constant over K tiles): LDS chunk q = (wave*INSTR + i)*64 + lane -> (k row, column chunk)
+    int a_kr[A_INSTR], a_col[A_INSTR], b_kr[B_INSTR], b_dy[B_INSTR], b_dx[B_INSTR];
+    const T* b_base[B_INSTR];
+    int64_t b_ld[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int q = (wave * A_INSTR + i) * 64 + lane, kr = q / A_CH, cc = q - kr * A_CH;
+        const bool ok = kr < BK && cc * EPC < BI && i0 + cc * EPC < p.I;
+        a_kr[i] = ok ? kr : -1;
+        a_col[i] = i0 + cc * EPC;
+    }
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int q = (wave * B_INSTR + i) * 64 + lane, kr = q / B_CH, cc = q - kr * B_CH;
+        const int jb = j0 + cc * EPC;
+        const bool ok = kr < BK && cc * EPC < BJ && jb < p.J;
+        b_kr[i] = ok ? kr : -1;
+        int jc = jb, dy = 0, dx = 0;
+        if (conv) { const int tap = jb / p.conv_kc; jc = jb - tap * p.conv_kc; dy = tap / 3 - 1; dx = tap % 3 - 1; }
+        const bool second = (p.B2 != nullptr) && jc >= p.b_split;
+        b_base[i] = (second ? B2 : B) + (second ? jc - p.b_split : jc);
+        b_ld[i] = second ? p.ldb2 : p.ldb;
+        b_dy[i] = dy; b_dx[i] = dx;
+    }
+    // source rows of the NEXT tile to issue are fetched one iteration ahead so the map loads never sit between a DMA and its wait
+    int a_src[A_INSTR], b_src[B_INSTR];
+    auto fetch_rows = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int k = kt * BK + a_kr[i];
+            int src = -1;
+            if (a_kr[i] >= 0 && k < p.K) {
+                src = p.a_rowmap ? p.a_rowmap[k] : k;
+                if (p.a_rowscale && p.a_rowscale[p.a_rowscale_div > 1 ? k / p.a_rowscale_div : k] == 0.f) src = -1;
+            }
+            a_src[i] = src;
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const int k = kt * BK + b_kr[i];
+            int src = -1;
+            if (b_kr[i] >= 0 && k < p.K) src = p.b_rowmap ? p.b_rowmap[k] : k;
+            b_src[i] = src;
+        }
+    };
+    auto issue = [&](int stage) {
+        char* sa = smem + stage * STAGE_BYTES;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i)
+            dma16(a_src[i] >= 0 ? A + (int64_t)a_src[i] * p.lda + a_col[i] : Z, sa + (wave * A_INSTR + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            int src = b_src[i];
+            if (conv && src >= 0) {
+                const int pix = src % HW;
+                const int y = pix / p.conv_w + b_dy[i], x = pix % p.conv_w + b_dx[i];
+                src = (y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) ? src + b_dy[i] * p.conv_w + b_dx[i] : -1;
+            }
+            dma16(src >= 0 ? b_base[i] + (int64_t)src * b_ld[i] : Z, sb + (wave * B_INSTR + i) * 1024);
+        }
+    };
+
+    f32x4 acc[II][JJ];
+#pragma unroll
+    for (int i = 0; i < II; ++i)
+#pragma unroll
+        for (int j = 0; j < JJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
+    const bool do_colsum = (p.colsum != nullptr) && tile_j == 0 && tid < BI;
+
+    fetch_rows(kt_begin);
+    issue(0);
+    if (kt_begin + 1 < kt_end) fetch_rows(kt_begin + 1);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < kt_end) {
+            issue(cur ^ 1);
+            if (kt + 2 < kt_end) fetch_rows(kt + 2);
+        }
+        const char* cA = smem + cur * STAGE_BYTES;
+        const char* cB = cA + A_BYTES;
+        const unsigned row_off = (unsigned)((8 * (lane >> 4) + ((lane & 15) >> 2)));
+        const unsigned aA = lds_addr(cA) + (row_off * A_LD + wi * WI + 4 * (lane & 3)) * 2;
+        const unsigned aB = lds_addr(cB) + (row_off * B_LD + wj * WJ + 4 * (lane & 3)) * 2;
+        u64 al0[II], ah0[II], al1[II], ah1[II], bl0[JJ], bh0[JJ], bl1[JJ], bh1[JJ];
+        tr_read_tile<II, 32, 4 * A_LD * 2, 32 * A_LD * 2>(aA, al0, ah0, al1, ah1);
+        tr_read_tile<JJ, 32, 4 * B_LD * 2, 32 * B_LD * 2>(aB, bl0, bh0, bl1, bh1);
+#pragma unroll
+        for (int i = 0; i < II; ++i)
+#pragma unroll
+            for (int j = 0; j < JJ; ++j) {
+                acc[i][j] = mfma16<T>(frag_from(al0[i], ah0[i]), frag_from(bl0[j], bh0[j]), acc[i][j]);
+                acc[i][j] = mfma16<T>(frag_from(al1[i], ah1[i]), frag_from(bl1[j], bh1[j]), acc[i][j]);
+            }
+        if (do_colsum) {
+            const T* col = reinterpret_cast<const T*>(cA) + tid;
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) csum += to_f<T>(col[k * A_LD]);
+        }
+    }
+
+    float* C = p.C + (int64_t)bz * p.strideC;
+    const bool atomic = gridDim.z > 1 || p.accumulate;
+#pragma unroll
+    for (int i = 0; i < II; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ii = i0 + wi * WI + i * 16 + 4 * (lane >> 4) + r;
+            if (ii >= p.I) continue;
+#pragma unroll
+            for (int j = 0; j < JJ; ++j) {
+                const int jj = j0 + wj * WJ + j * 16 + (lane & 15);
+                if (jj >= p.J) continue;
+                int64_t col = jj;
+                if (p.c_conv_permute) { const int t2 = jj / p.conv_kc; col = (int64_t)(jj - t2 * p.conv_kc) * 9 + t2; }
+                float* dst = C + (int64_t)ii * p.ldc + col;
+                if (atomic) atomicAdd(dst, p.alpha * acc[i][j][r]); else *dst = p.alpha * acc[i][j][r];
+            }
+        }
+    }
+    if (do_colsum && i0 + tid < p.I) atomicAdd(p.colsum + (int64_t)bz * p.strideColsum + i0 + tid, csum * p.alpha);
+}
+
+template <int BI, int BJ, int WAVES> int launch_tn_v2(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
+    constexpr int A_CH = (BI + KM_PAD) / 8, B_CH = (BJ + KM_PAD) / 8;
+    constexpr int A_INSTR = (64 * A_CH + 64 * WAVES - 1) / (64 * WAVES), B_INSTR = (64 * B_CH + 64 * WAVES - 1) / (64 * WAVES);
+    constexpr size_t lds = 2 * (size_t)(A_INSTR + B_INSTR) * WAVES * 1024;
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_kernel<BI, BJ, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            lavt_set_error("lavt_gemm_tn(v2): cannot reserve %zu bytes of LDS", lds);
+            return LAVT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int ktiles = cdiv(p.K, 64);
+    const int per = cdiv(ktiles, split);
+    dim3 grid(cdiv(p.I, BI) * cdiv(p.J, BJ), p.batch, cdiv(ktiles, per));
+    hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES>), grid, dim3(WAVES * 64), lds, st, p, per);
+    LAVT_CHECK_LAUNCH("lavt_gemm_tn(v2)");
+    return LAVT_OK;
+}
+
 }  // namespace
 
 // returns 1 when the problem is not for this kernel (caller falls back to gemm.hip), else a LAVT status
@@ -290,4 +470,33 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     if (stages == 2) { if (p.b_kmajor) GO(64, 64, true, 2, 4); else GO(64, 64, false, 2, 4); }
     if (p.b_kmajor) GO(64, 64, true, 3, 4); else GO(64, 64, false, 3, 4);
 #undef GO
+}
+
+int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st) {
+    if (p.dtype != LAVT_BF16 || p.zeros == nullptr) return 1;
+    const char* e = getenv("LAVT_GEMM_V2");
+    if (e && e[0] == '0') return 1;
+    if (p.lda % 8 || p.ldb % 8 || (p.B2 && p.ldb2 % 8)) return 1;
+    if (p.a_rowscale && !p.a_rowscale_binary) return 1;          // only 0 / constant masks can be folded into the row fetch
+    // Measured (tools/gemm_bench.py tn): the 64x64 / 4-wave tile wins on every weight-gradient shape of the step, the conv wgrads included
+    // (369 vs 230 TF/s for 128x128); the split-K factor trades workgroup count (latency hiding) against fp32 atomic traffic.
+    const char* t = getenv("LAVT_GEMM_TILE");
+    const int force = t ? atoi(t) : 0;
+    const int ktiles = cdiv(p.K, 64);
+    const long tiles64 = (long)cdiv(p.I, 64) * cdiv(p.J, 64) * p.batch;
+    const bool big = force == 128;
+    const long tiles = big ? (long)cdiv(p.I, 128) * cdiv(p.J, 128) * p.batch : tiles64;
+    int split = p.split_k;
+    { const char* se = getenv("LAVT_TN_SPLIT"); if (se) split = atoi(se); }
+    if (split <= 0) {
+        split = (int)((768 + tiles / 2) / tiles);         // ~3 workgroups per CU
+        const int long_k = (ktiles + 127) / 128;          // no workgroup walks more than ~128 K tiles
+        if (split < long_k) split = long_k;
+        const int max_split = (ktiles + 7) / 8;           // >= 8 K tiles per workgroup
+        if (split > max_split) split = max_split;
+        if (split < 1) split = 1;
+    }
+    if (split > ktiles) split = ktiles;
+    if (big) return launch_tn_v2<128, 128, 8>(p, split, st);
+    return launch_tn_v2<64, 64, 4>(p, split, st);
 }

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const int32_t* __restrict__ gather, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rows, int C) {
+                                                            float* __restrict__ partials, int rows, int C) {
     constexpr int EPC = Chunk<T>::N, MAXC = LPR == 64 ? LN_MAXE / EPC : 1, RPW = 64 / LPR;   // dispatch: LPR < 64 only when one chunk per lane suffices
     const int lane = threadIdx.x & 63, lir = lane % LPR, wave = threadIdx.x >> 6;
     const int nchunk = C / EPC;
@@ -164,11 +164,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
                         const int col = ch * EPC + e;
-                        atomicAdd(dst + col, part[c * EPC + e] + red[col] + red[2048 + col] + red[4096 + col]);
+                        const float tot = part[c * EPC + e] + red[col] + red[2048 + col] + red[4096 + col];
+                        // hundreds of workgroups adding to the SAME C addresses serialise in L2: write per-workgroup partials instead
+                        if (partials) partials[((int64_t)blockIdx.x * 2 + pass) * C + col] = tot;
+                        else atomicAdd(dst + col, tot);
                     }
             }
         }
     }
+}
+
+// sums [nblk][2][C] partials over nblk and accumulates into dgamma / dbeta (one thread per channel, coalesced across channels)
+__global__ void partials2_finalize_kernel(const float* __restrict__ partials, int nblk, int C, float* __restrict__ o0, float* __restrict__ o1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nblk; ++k) { a += partials[((int64_t)k * 2) * C + c]; b += partials[((int64_t)k * 2 + 1) * C + c]; }
+    o0[c] += a;
+    o1[c] += b;
 }
 
 // ---------------------------------------------------------------------------------------------- column statistics
@@ -177,7 +190,7 @@ template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, const T* __restrict__ xin, const T* __restrict__ yout,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const T* __restrict__ mul, int relu, float* __restrict__ o1,
-                                                       float* __restrict__ o2, int rows, int C, int rows_per_block) {
+                                                       float* __restrict__ o2, float* __restrict__ partials, int rows, int C, int rows_per_block) {
     // !BWD: a = x; o1 += sum x, o2 += sum x^2.     BWD: a = dy; g = dy (*mul) (masked y>0); o1 += sum g, o2 += sum g*xhat
     constexpr int EPC = Chunk<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -245,10 +258,29 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, 
                 }
             const int col = (cbase + threadIdx.x) * EPC;
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) { atomicAdd(o1 + (int64_t)g * C + col + e, t1[e]); atomicAdd(o2 + (int64_t)g * C + col + e, t2[e]); }
+            for (int e = 0; e < EPC; ++e) {
+                if (partials) {
+                    float* pp = partials + (((int64_t)blockIdx.x * gridDim.y + g) * 2) * C + col + e;
+                    pp[0] = t1[e]; pp[C] = t2[e];
+                } else { atomicAdd(o1 + (int64_t)g * C + col + e, t1[e]); atomicAdd(o2 + (int64_t)g * C + col + e, t2[e]); }
+            }
         }
         __syncthreads();
     }
+}
+
+// partials [nblk][groups][2][C]: o1[g][c] += sum_k partials[k][g][0][c], o2[g][c] += sum_k partials[k][g][1][c]
+__global__ void colstats_finalize_kernel(const float* __restrict__ partials, int nblk, int groups, int C, float* __restrict__ o1, float* __restrict__ o2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * C) return;
+    const int g = i / C, c = i - g * C;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+        const float* pp = partials + (((int64_t)k * groups + g) * 2) * C + c;
+        a += pp[0]; b += pp[C];
+    }
+    o1[i] += a;
+    o2[i] += b;
 }
 
 __global__ void stats_finalize_kernel(const float* sum, const float* sumsq, float count, float eps, float* mean, float* rstd,
@@ -345,8 +377,8 @@ extern "C" int lavt_layernorm_fwd(int dtype, const void* x, const int32_t* gathe
 }
 
 extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
-                                  const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int C,
-                                  void* stream) {
+                                  const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats,
+                                  int rows, int C, void* stream) {
     const int epc = dtype == LAVT_F32 ? 4 : 8;
     LAVT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "lavt_layernorm_bwd: bad arguments");
     LAVT_CHECK_ARG(C > 0 && C <= 2048 && C % epc == 0 && (!gather || (C / 4) % epc == 0), "lavt_layernorm_bwd: unsupported C=%d", C);
@@ -356,9 +388,11 @@ extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     int blocks = cdiv(rows, 4 * (64 / lpr) * 4);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-#define LN_BWD(LPR_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, C)
+    float* partials = (ws && ws_floats >= (int64_t)blocks * 2 * C) ? ws : nullptr;
+#define LN_BWD(LPR_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, rows, C)
     DISPATCH_T(dtype, "lavt_layernorm_bwd", if (lpr == 16) LN_BWD(16); else if (lpr == 32) LN_BWD(32); else LN_BWD(64));
 #undef LN_BWD
+    if (partials) hipLaunchKernelGGL(partials2_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, partials, blocks, C, dgamma, dbeta);
     LAVT_CHECK_LAUNCH("lavt_layernorm_bwd");
     return LAVT_OK;
 }
@@ -372,15 +406,17 @@ static int stats_launch_geometry(int rows, int groups, int* rows_per_block) {
     return cdiv(rows, *rows_per_block);
 }
 
-extern "C" int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq, int groups, int rows, int C, void* stream) {
+extern "C" int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq, float* ws, int64_t ws_floats, int groups, int rows, int C, void* stream) {
     const int epc = dtype == LAVT_F32 ? 4 : 8;
     LAVT_CHECK_ARG(x && sum && sumsq && groups > 0 && rows > 0 && C > 0 && C % epc == 0, "lavt_colstats: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rpb;
     const int blocks = stats_launch_geometry(rows, groups, &rpb);
+    float* partials = (ws && ws_floats >= (int64_t)blocks * groups * 2 * C) ? ws : nullptr;
     DISPATCH_T(dtype, "lavt_colstats",
                hipLaunchKernelGGL((colstats_kernel<T, false>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
-                                  (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, 0, sum, sumsq, rows, C, rpb));
+                                  (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, 0, sum, sumsq, partials, rows, C, rpb));
+    if (partials) hipLaunchKernelGGL(colstats_finalize_kernel, dim3(cdiv(groups * C, 128)), dim3(128), 0, st, partials, blocks, groups, C, sum, sumsq);
     LAVT_CHECK_LAUNCH("lavt_colstats");
     return LAVT_OK;
 }
@@ -407,16 +443,18 @@ extern "C" int lavt_norm_apply(int dtype, const void* x, const float* mean, cons
 
 extern "C" int lavt_norm_bwd_stats(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
                                    const float* gamma, const float* beta, const void* mul, int relu, float* s1, float* s2,
-                                   int groups, int rows, int C, void* stream) {
+                                   float* ws, int64_t ws_floats, int groups, int rows, int C, void* stream) {
     (void)gamma; (void)beta;
     const int epc = dtype == LAVT_F32 ? 4 : 8;
     LAVT_CHECK_ARG(dy && x && mean && rstd && s1 && s2 && (!relu || y) && groups > 0 && rows > 0 && C % epc == 0, "lavt_norm_bwd_stats: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rpb;
     const int blocks = stats_launch_geometry(rows, groups, &rpb);
+    float* partials = (ws && ws_floats >= (int64_t)blocks * groups * 2 * C) ? ws : nullptr;
     DISPATCH_T(dtype, "lavt_norm_bwd_stats",
                hipLaunchKernelGGL((colstats_kernel<T, true>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
-                                  (const T*)dy, (const T*)x, (const T*)y, mean, rstd, (const T*)mul, relu, s1, s2, rows, C, rpb));
+                                  (const T*)dy, (const T*)x, (const T*)y, mean, rstd, (const T*)mul, relu, s1, s2, partials, rows, C, rpb));
+    if (partials) hipLaunchKernelGGL(colstats_finalize_kernel, dim3(cdiv(groups * C, 128)), dim3(128), 0, st, partials, blocks, groups, C, s1, s2);
     LAVT_CHECK_LAUNCH("lavt_norm_bwd_stats");
     return LAVT_OK;
 }

@@ -42,7 +42,7 @@ class GemmTN(C.Structure):
         ("B", vp), ("ldb", i64), ("strideB", i64), ("B2", vp), ("ldb2", i64), ("b_split", i32), ("b_rowmap", vp),
         ("conv_h", i32), ("conv_w", i32), ("conv_kc", i32),
         ("alpha", f32), ("C", vp), ("ldc", i64), ("strideC", i64), ("c_conv_permute", i32), ("split_k", i32),
-        ("colsum", vp), ("strideColsum", i64), ("zeros", vp),
+        ("colsum", vp), ("strideColsum", i64), ("zeros", vp), ("a_rowscale_binary", i32), ("accumulate", i32),
     ]
 
 
@@ -56,11 +56,11 @@ _PROTOTYPES = {
     "lavt_relpos_expand": [vp, vp, i32, i32, i32, vp],
     "lavt_relpos_reduce": [vp, vp, i32, i32, i32, vp],
     "lavt_layernorm_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
-    "lavt_layernorm_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
-    "lavt_colstats": [i32, vp, vp, vp, i32, i32, i32, vp],
+    "lavt_layernorm_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+    "lavt_colstats": [i32, vp, vp, vp, vp, i64, i32, i32, i32, vp],
     "lavt_stats_finalize": [vp, vp, f32, f32, vp, vp, vp, vp, f32, i32, vp],
     "lavt_norm_apply": [i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp],
-    "lavt_norm_bwd_stats": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp],
+    "lavt_norm_bwd_stats": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, i32, i32, i32, vp],
     "lavt_norm_bwd_apply": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, f32, vp, vp, i32, i32, i32, vp],
     "lavt_act_bwd": [i32, i32, vp, vp, vp, i64, vp],
     "lavt_gate_fwd": [i32, vp, vp, vp, vp, i64, vp],

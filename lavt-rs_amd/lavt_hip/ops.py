@@ -143,6 +143,11 @@ def _f32(p: Optional[torch.Tensor]):
 _ZERO_PAGES = {}
 
 
+def _scratch(n_floats, device):
+    """fp32 scratch for two-stage reductions (fresh per call: stream-ordered reuse is the allocator's job)."""
+    return torch.empty(int(n_floats), dtype=torch.float32, device=device)
+
+
 def _zero_page(device):
     """256 zero bytes per device: source of every chunk that must read 0 in the LDS-DMA GEMM (padding rows, conv halo, tails)."""
     z = _ZERO_PAGES.get(device)
@@ -177,7 +182,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
 
 
 def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, strideB=0, strideC=0, a_rowmap=None,
-            a_rowscale=None, a_rowscale_div=1, B2=None, ldb2=0, b_split=0, b_rowmap=None, conv=None, alpha=1.0, c_conv_permute=False, colsum=None,
+            a_rowscale=None, a_rowscale_div=1, a_rowscale_binary=False, accumulate=False, B2=None, ldb2=0, b_split=0, b_rowmap=None, conv=None, alpha=1.0, c_conv_permute=False, colsum=None,
             strideColsum=0, a_off=0, b_off=0, c_off=0):
     es = 4 if dtype == torch.float32 else 2
     assert Cout.dtype == torch.float32
@@ -185,6 +190,7 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.dtype, p.I, p.J, p.K, p.batch = K.dt(dtype), I, J, Kd, batch
     p.A, p.lda, p.strideA, p.a_rowmap = K.ptr(A) + a_off * es, lda, strideA, K.ptr(a_rowmap)
     p.a_rowscale, p.a_rowscale_div = K.ptr(a_rowscale), a_rowscale_div
+    p.a_rowscale_binary, p.accumulate = int(a_rowscale_binary), int(accumulate)
     p.B, p.ldb, p.strideB = K.ptr(B) + b_off * es, ldb, strideB
     p.B2, p.ldb2, p.b_split, p.b_rowmap = K.ptr(B2), ldb2, b_split, K.ptr(b_rowmap)
     if conv is not None:
@@ -215,6 +221,7 @@ class LinOpts:
     zero_init: bool = False                    # y rows not covered by out_map must read 0
     row_scale: Optional[torch.Tensor] = None   # fp32 factor of GEMM row m: row_scale[m // row_scale_div] (language mask, DropPath)
     row_scale_div: int = 1
+    row_scale_value: float = 0.0               # if != 0: row_scale holds only 0 and this value (lets the wgrad kernel treat it as a row mask)
 
 
 class _Linear(torch.autograd.Function):
@@ -263,8 +270,9 @@ class _Linear(torch.autograd.Function):
             bbuf = bsink = None
             if bias is not None and ctx.needs_input_grad[2]:
                 bbuf, bsink = sinks.buf(bias, (N,))
+            binary = o.row_scale is not None and o.row_scale_value != 0.0
             gemm_tn(dtype, N, Kd, M, g, N, x, Kd, wbuf, Kd, a_rowmap=o.out_map, a_rowscale=o.row_scale, a_rowscale_div=o.row_scale_div,
-                    b_rowmap=o.in_map, colsum=bbuf)
+                    a_rowscale_binary=binary, alpha=o.row_scale_value if binary else 1.0, b_rowmap=o.in_map, colsum=bbuf)
             dW = sinks.done(weight, wbuf, wsink)
             if bbuf is not None:
                 db = sinks.done(bias, bbuf, bsink)
@@ -297,8 +305,9 @@ class _LayerNorm(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg, gs = sinks.buf(gamma, (ctx.C,))
         db, bs = sinks.buf(beta, (ctx.C,))
+        ws = _scratch(1025 * 2 * ctx.C, x.device)
         K.check(K.lib.lavt_layernorm_bwd(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(gather), K.ptr(_f32(gamma)), K.ptr(mean), K.ptr(rstd),
-                                         K.ptr(dx), K.ptr(dg), K.ptr(db), ctx.rows, ctx.C, K.stream()))
+                                         K.ptr(dx), K.ptr(dg), K.ptr(db), K.ptr(ws), ws.numel(), ctx.rows, ctx.C, K.stream()))
         return dx, sinks.done(gamma, dg, gs), sinks.done(beta, db, bs), None, None, None, None
 
 
@@ -353,7 +362,8 @@ def window_attention(qkv, table, region, ws, heads):
 # ------------------------------------------------------------------------------------------ Instance / Batch norm
 def _stats(x, groups, rows, Cc):
     s = torch.zeros(2, groups, Cc, dtype=torch.float32, device=x.device)
-    K.check(K.lib.lavt_colstats(K.dt(x.dtype), K.ptr(x), K.ptr(s[0]), K.ptr(s[1]), groups, rows, Cc, K.stream()))
+    ws = _scratch(1025 * groups * 2 * Cc, x.device)
+    K.check(K.lib.lavt_colstats(K.dt(x.dtype), K.ptr(x), K.ptr(s[0]), K.ptr(s[1]), K.ptr(ws), ws.numel(), groups, rows, Cc, K.stream()))
     return s
 
 
@@ -383,8 +393,9 @@ class _InstanceNorm(torch.autograd.Function):
         dy = dy.contiguous()
         s = torch.zeros(2, B, Cc, dtype=torch.float32, device=x.device)
         d = K.dt(x.dtype)
+        ws = _scratch(1025 * B * 2 * Cc, x.device)
         K.check(K.lib.lavt_norm_bwd_stats(d, K.ptr(dy), K.ptr(x), None, K.ptr(mean), K.ptr(rstd), None, None, K.ptr(mul), 0,
-                                          K.ptr(s[0]), K.ptr(s[1]), B, T, Cc, K.stream()))
+                                          K.ptr(s[0]), K.ptr(s[1]), K.ptr(ws), ws.numel(), B, T, Cc, K.stream()))
         dx = torch.empty_like(x)
         dmul = torch.empty_like(x) if mul is not None else None
         K.check(K.lib.lavt_norm_bwd_apply(d, K.ptr(dy), K.ptr(x), None, K.ptr(mean), K.ptr(rstd), None, None, K.ptr(mul), 0,
@@ -435,8 +446,9 @@ class _BatchNormRelu(torch.autograd.Function):
         dy = dy.contiguous()
         d = K.dt(x.dtype)
         s = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)
+        ws = _scratch(1025 * 2 * Cc, x.device)
         K.check(K.lib.lavt_norm_bwd_stats(d, K.ptr(dy), K.ptr(x), K.ptr(y), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)),
-                                          None, 1, K.ptr(s[0]), K.ptr(s[1]), 1, R, Cc, K.stream()))
+                                          None, 1, K.ptr(s[0]), K.ptr(s[1]), K.ptr(ws), ws.numel(), 1, R, Cc, K.stream()))
         dgamma, dbeta = s[1].clone(), s[0].clone()          # local sums: DDP averages parameter grads later
         if not training:
             s.zero_()                                       # running statistics are constants: no batch terms

@@ -63,11 +63,12 @@ class Mlp(nn.Module):
         self.fc1 = nn.Linear(in_features, hidden_features)
         self.fc2 = nn.Linear(hidden_features, out_features)
 
-    def forward(self, x, residual=None, row_scale=None, row_scale_div=1):
+    def forward(self, x, residual=None, row_scale=None, row_scale_div=1, row_scale_value=0.0):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         h = ops.linear(x2, self.fc1.weight, self.fc1.bias, act=ACT_GELU)
-        y = ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual, row_scale=row_scale, row_scale_div=row_scale_div)
+        y = ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual, row_scale=row_scale, row_scale_div=row_scale_div,
+                       row_scale_value=row_scale_value)
         return y.view(*shp[:-1], y.shape[-1])
 
 
@@ -147,11 +148,12 @@ class SwinTransformerBlock(nn.Module):
         qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, in_map=wmap, rows=M)
         o = ops.window_attention(qkv, a.relative_position_bias_table, region, ws, self.num_heads)
         f1 = self.drop_path.factors(B, dev)
+        dpv = 1.0 / (1.0 - self.drop_path.drop_prob) if self.drop_path.drop_prob < 1.0 else 0.0
         x2 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x2, out_map=wmap, rows=M, out_rows=B * L,
-                        row_scale=f1, row_scale_div=M // B)
+                        row_scale=f1, row_scale_div=M // B, row_scale_value=dpv)
         f2 = self.drop_path.factors(B, dev)
         h = ops.layer_norm(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        x2 = self.mlp(h, residual=x2, row_scale=f2, row_scale_div=L)
+        x2 = self.mlp(h, residual=x2, row_scale=f2, row_scale_div=L, row_scale_value=dpv)
         return x2.view(B, L, C)
 
 
@@ -219,7 +221,7 @@ class SpatialImageLanguageAttention(nn.Module):
         """x2 [B*T, C] -> IN(W(attn)) (* mul) as [B*T, C]."""
         G = self.num_heads
         q = ops.instance_norm(ops.linear(x2, self.f_query[0].weight, self.f_query[0].bias), B, T)
-        kw = dict(out_map=lang.kv_map, out_rows=B * ops.KV_LD, zero_init=True, row_scale=lang.mask_rows)
+        kw = dict(out_map=lang.kv_map, out_rows=B * ops.KV_LD, zero_init=True, row_scale=lang.mask_rows, row_scale_value=1.0)
         k = ops.linear(lang.lt, self.f_key[0].weight, self.f_key[0].bias, **kw)
         v = ops.linear(lang.lt, self.f_value[0].weight, self.f_value[0].bias, **kw)
         o = ops.pwam_attention(q, k, v, lang.maskbias, B, T, lang.n_l, G)

@@ -53,12 +53,25 @@ SHAPES = [
     ("qkv s0", "nt", 28800, 384, 128), ("fc1 s0", "nt", 28800, 512, 128), ("fc2 s0", "nt", 28800, 128, 512), ("fc1 s1", "nt", 7200, 1024, 256),
     ("fc1 s3", "nt", 450, 4096, 1024), ("fc2 s3", "nt", 450, 1024, 4096),
     ("d-qkv s2", "ntk", 2592, 512, 1536), ("d-fc1 s2", "ntk", 1800, 512, 2048), ("d-fc2 s2", "ntk", 1800, 2048, 512), ("d-fc2 s0", "ntk", 28800, 512, 128),
-    ("w-qkv s2", "tn", 1536, 512, 2592), ("w-fc1 s2", "tn", 2048, 512, 1800), ("w-fc2 s2", "tn", 512, 2048, 1800), ("w-fc1 s0", "tn", 512, 128, 28800),
+    ("w-conv2_2", "tn", 512, 4608, 28800), ("w-qkv s2", "tn", 1536, 512, 2592), ("w-fc1 s2", "tn", 2048, 512, 1800), ("w-fc2 s2", "tn", 512, 2048, 1800), ("w-fc1 s0", "tn", 512, 128, 28800),
     ("w-qkv s0", "tn", 384, 128, 28800), ("w-fc1 s3", "tn", 4096, 1024, 450), ("w-pwam s0", "tn", 128, 128, 28800),
 ]
 
 for name, kind, a, b, c in SHAPES:
+    if len(sys.argv) > 1 and kind != sys.argv[1]:
+        continue
     res = []
+    if kind == "tn":
+        for v2 in ("0", "1"):
+            for tile in ("64", "128"):
+                for sp in ("1", "2", "4", "8"):
+                    os.environ.update(LAVT_GEMM_TILE=tile, LAVT_TN_SPLIT=sp, LAVT_GEMM_V2=v2)
+                    t = timeit(tn(a, b, c), iters=5 if c > 20000 else 20)
+                    res.append((f"v{int(v2)+1}t{tile}/s{sp}", t * 1e6, 2.0 * a * b * c / t / 1e12))
+        for k in ("LAVT_GEMM_TILE", "LAVT_TN_SPLIT", "LAVT_GEMM_V2"):
+            os.environ.pop(k)
+        print(f"{name:9s} {kind:3s} {a:6d} {b:5d} {c:5d} | " + " | ".join(f"{k}: {us:5.1f}us" for k, us, tf in res))
+        continue
     for tile, stages, v2, wv in (("64", "3", "0", "4"), ("64", "2", "1", "4"), ("64", "3", "1", "4"), ("128", "2", "1", "4"), ("128", "2", "1", "8"), ("128", "3", "1", "8")):
         os.environ["LAVT_GEMM_TILE"] = tile
         os.environ["LAVT_GEMM_STAGES"] = stages
