@@ -174,14 +174,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
 }
 
-// sums [nblk][2][C] partials over nblk and accumulates into dgamma / dbeta (one thread per channel, coalesced across channels)
-__global__ void partials2_finalize_kernel(const float* __restrict__ partials, int nblk, int C, float* __restrict__ o0, float* __restrict__ o1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < nblk; ++k) { a += partials[((int64_t)k * 2) * C + c]; b += partials[((int64_t)k * 2 + 1) * C + c]; }
-    o0[c] += a;
-    o1[c] += b;
+// Second stage of the two-stage reductions: partials [nblk][W] (W = groups*2*C: per group first the C "sum-1" values, then the C
+// "sum-2" values) -> o1[g*C+c] += sum_k partials[k][(2g)*C+c], o2[g*C+c] += sum_k partials[k][(2g+1)*C+c].
+// 32 columns x 8 row-slices per workgroup: coalesced 128-B reads, 8-way parallel walk over nblk, LDS combine.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int W, int C,
+                                                              float* __restrict__ o1, float* __restrict__ o2) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int w = blockIdx.x * 32 + col;
+    float a = 0.f;
+    if (w < W)
+        for (int k = slice; k < nblk; k += 8) a += partials[(int64_t)k * W + w];
+    red[slice][col] = a;
+    __syncthreads();
+    if (slice == 0 && w < W) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][col];
+        const int g2 = w / C, c = w - g2 * C;          // g2 = 2*g + which
+        float* dst = (g2 & 1) ? o2 : o1;
+        dst[(int64_t)(g2 >> 1) * C + c] += t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- column statistics
@@ -267,20 +280,6 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, 
         }
         __syncthreads();
     }
-}
-
-// partials [nblk][groups][2][C]: o1[g][c] += sum_k partials[k][g][0][c], o2[g][c] += sum_k partials[k][g][1][c]
-__global__ void colstats_finalize_kernel(const float* __restrict__ partials, int nblk, int groups, int C, float* __restrict__ o1, float* __restrict__ o2) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= groups * C) return;
-    const int g = i / C, c = i - g * C;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < nblk; ++k) {
-        const float* pp = partials + (((int64_t)k * groups + g) * 2) * C + c;
-        a += pp[0]; b += pp[C];
-    }
-    o1[i] += a;
-    o2[i] += b;
 }
 
 __global__ void stats_finalize_kernel(const float* sum, const float* sumsq, float count, float eps, float* mean, float* rstd,
@@ -386,13 +385,13 @@ extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     const int nchunk = C / epc;
     const int lpr = nchunk <= 16 ? 16 : nchunk <= 32 ? 32 : 64;
     int blocks = cdiv(rows, 4 * (64 / lpr) * 4);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     float* partials = (ws && ws_floats >= (int64_t)blocks * 2 * C) ? ws : nullptr;
 #define LN_BWD(LPR_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, rows, C)
     DISPATCH_T(dtype, "lavt_layernorm_bwd", if (lpr == 16) LN_BWD(16); else if (lpr == 32) LN_BWD(32); else LN_BWD(64));
 #undef LN_BWD
-    if (partials) hipLaunchKernelGGL(partials2_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, partials, blocks, C, dgamma, dbeta);
+    if (partials) hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, partials, blocks, 2 * C, C, dgamma, dbeta);
     LAVT_CHECK_LAUNCH("lavt_layernorm_bwd");
     return LAVT_OK;
 }
@@ -416,7 +415,7 @@ extern "C" int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq,
     DISPATCH_T(dtype, "lavt_colstats",
                hipLaunchKernelGGL((colstats_kernel<T, false>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
                                   (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, 0, sum, sumsq, partials, rows, C, rpb));
-    if (partials) hipLaunchKernelGGL(colstats_finalize_kernel, dim3(cdiv(groups * C, 128)), dim3(128), 0, st, partials, blocks, groups, C, sum, sumsq);
+    if (partials) hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(groups * 2 * C, 32)), dim3(256), 0, st, partials, blocks, groups * 2 * C, C, sum, sumsq);
     LAVT_CHECK_LAUNCH("lavt_colstats");
     return LAVT_OK;
 }
@@ -454,7 +453,7 @@ extern "C" int lavt_norm_bwd_stats(int dtype, const void* dy, const void* x, con
     DISPATCH_T(dtype, "lavt_norm_bwd_stats",
                hipLaunchKernelGGL((colstats_kernel<T, true>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
                                   (const T*)dy, (const T*)x, (const T*)y, mean, rstd, (const T*)mul, relu, s1, s2, partials, rows, C, rpb));
-    if (partials) hipLaunchKernelGGL(colstats_finalize_kernel, dim3(cdiv(groups * C, 128)), dim3(128), 0, st, partials, blocks, groups, C, s1, s2);
+    if (partials) hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(groups * 2 * C, 32)), dim3(256), 0, st, partials, blocks, groups * 2 * C, C, s1, s2);
     LAVT_CHECK_LAUNCH("lavt_norm_bwd_stats");
     return LAVT_OK;
 }
