@@ -224,6 +224,15 @@ __global__ __launch_bounds__(256) void wattn_bwd_mfma(const bf16* __restrict__ q
                 int ri[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const int i = 16 * it + 4 * g + r; li[r] = ls[i]; di[r] = dl[i]; ri[r] = Rs[i]; }
+                // all bias values of this query tile are requested up front: one L2 round trip per tile instead of one per key tile
+                float bb[NT][4];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * it + 4 * g + r, j = 16 * t + c16;
+                        bb[t][r] = (i < N && j < N) ? bh[(int64_t)i * bias_ld + j] : 0.f;
+                    }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int j = 16 * t + c16;
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256) void wattn_bwd_mfma(const bf16* __restrict__ q
                         const int i = 16 * it + 4 * g + r;
                         float p = 0.f, ds = 0.f;
                         if (i < N && j < N) {
-                            float a = s[r] * scale + bh[(int64_t)i * bias_ld + j];
+                            float a = s[r] * scale + bb[t][r];
                             if (rj != ri[r]) a += -100.0f;
                             p = __expf(a - li[r]);
                             ds = p * (dp[r] - di[r]);

@@ -57,6 +57,7 @@ class GradBuckets:
         self.works = []
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.fused = fused_accumulation
         if fused_accumulation:          # weight-gradient kernels accumulate straight into `flat` (lavt_hip.ops.sinks)
             from . import ops
             ops.sinks.set(self.params, on_ready=self._on_grad)
@@ -103,6 +104,11 @@ class GradBuckets:
         chunk = self.flat[s:e]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            if self.fused:
+                from . import ops
+                for lst in ops.side.streams.values():       # fused wgrad kernels write the bucket from side streams
+                    for st in lst:
+                        self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
                 self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
         else:                                           # gloo (CPU tests): no AVG op

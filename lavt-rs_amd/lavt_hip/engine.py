@@ -38,6 +38,7 @@ class TrainStep:
         out = self.model(self.x, self.l, self.m)
         loss = F.cross_entropy(out, self.t, weight=self.w)
         loss.backward()
+        ops.side.join()                          # wgrad GEMMs ran on side streams: join before the step (or the graph capture) ends
         return loss.detach()
 
     def warmup_and_capture(self, eager_iters=3):
