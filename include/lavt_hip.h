@@ -98,6 +98,10 @@ typedef struct lavt_gemm_nt {
     int32_t c_f32;
     const void* zeros; /* optional: >= 16 bytes of zeros in device memory; enables the LDS-DMA pipeline kernel (bf16) */
     int32_t epi_lds;   /* set by the library (LAVT_GEMM_EPI=lds): stage the C tile through LDS for full-row stores */
+    /* 3-D generalisation of the implicit-GEMM convolution (Conv3d of SepTPWAM, lib/video_swin_transformer.py:1327-1460): rows are voxels of a
+     * (batch, conv_d, conv_h, conv_w) grid and the taps run over conv_kd x conv_kh x conv_kw (each 1 or 3, 'same' zero padding), kw fastest.
+     * All zero = the 2-D default (conv_d = 1, taps 1 x 3 x 3). */
+    int32_t conv_d, conv_kd, conv_kh, conv_kw;
 } lavt_gemm_nt_t;
 
 int lavt_gemm_nt(const lavt_gemm_nt_t* p, void* stream);
@@ -138,6 +142,7 @@ typedef struct lavt_gemm_tn {
     const void* zeros; /* optional zero page, as in lavt_gemm_nt_t */
     int32_t a_rowscale_binary; /* 1: a_rowscale holds only 0 and ONE non-zero value which the caller folded into alpha (row masks) */
     int32_t accumulate;        /* 1: C += (atomics) even without split-K; 0: C may be overwritten when the reduction is not split */
+    int32_t conv_d, conv_kd, conv_kh, conv_kw; /* 3-D taps, as in lavt_gemm_nt_t; c_conv_permute then stores column (tap,c) at c*taps+tap */
 } lavt_gemm_tn_t;
 
 int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);
@@ -157,10 +162,17 @@ int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, int bias
                          const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int nwin, int N,
                          int heads, int head_dim, float scale, void* stream);
 
-/* relative_position_bias_table[(2ws-1)^2][heads] -> dense bias[heads][N][ld] (lib/backbone.py:89-103,125-127)
+/* relative_position_bias_table[(2wd-1)(2wh-1)(2ww-1)][heads] -> dense bias[heads][N][ld]   (wd = 1 for the 2-D Swin; N <= wd*wh*ww tokens) (lib/backbone.py:89-103,125-127)
  * and its transpose (dense gradient -> table gradient, deterministic, accumulates into dtable). */
-int lavt_relpos_expand(const float* table, float* dense, int ws, int heads, int ld, void* stream);
-int lavt_relpos_reduce(const float* ddense, float* dtable, int ws, int heads, int ld, void* stream);
+int lavt_relpos_expand(const float* table, float* dense, int wd, int wh, int ww, int N, int heads, int ld, void* stream);
+int lavt_relpos_reduce(const float* ddense, float* dtable, int wd, int wh, int ww, int N, int heads, int ld, void* stream);
+/* Row softmax of attention scores for windows too large for the fused kernels (Video-Swin N = 392 / 1152; WindowAttention3D.forward,
+ * lib/video_swin_transformer.py:147-161): p[row][j] = softmax_j(s[row][j] + bias[i][j] + mask), i = row % rpw, window = row / rpw (rpw >= N rows
+ * per window, rows i >= N are padding and give p = 0); s already holds scale * q k^T (lavt_gemm_nt); padding columns of p (j >= N, up to ld)
+ * are written as 0.  Backward overwrites dp with ds. */
+int lavt_attn_softmax_fwd(int dtype, const void* s, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* p,
+                          int64_t rows, int rpw, int N, int ld, void* stream);
+int lavt_attn_softmax_bwd(int dtype, const void* p, void* dp, int64_t rows, int N, int ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the channel dimension (nn.LayerNorm, eps 1e-5; lib/backbone.py:201,243,285,328,510).
@@ -229,8 +241,8 @@ int lavt_col2im4(int dtype, const void* dcols, float* dimg, int B, int H, int W,
 int lavt_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
 int lavt_nchw_to_nhwc(int src_dtype, const void* src, int dst_dtype, void* dst, int B, int C, int HW, void* stream);
 int lavt_nhwc_to_nchw(int src_dtype, const void* src, int dst_dtype, void* dst, int B, int C, int HW, void* stream);
-/* conv weight fp32 [Cout][Cin][3][3] -> dtype [Cout][9][Cin] (compute copy used by lavt_gemm_nt) */
-int lavt_pack_conv3x3(const float* w, int dtype, void* packed, int Cout, int Cin, void* stream);
+/* conv weight fp32 [Cout][Cin][taps] (taps = 9 for 3x3, 27 for 3x3x3, ...) -> dtype [Cout][taps][Cin] (compute copy used by lavt_gemm_nt) */
+int lavt_pack_conv3x3(const float* w, int dtype, void* packed, int Cout, int Cin, int taps, void* stream);
 /* many small fp32 -> dtype casts in one launch: desc = int64 triples (src_ptr, dst_ptr, n) on the DEVICE */
 int lavt_cast_multi(const int64_t* desc, int count, int dst_dtype, void* stream);
 

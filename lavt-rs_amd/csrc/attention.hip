@@ -193,33 +193,97 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
     }
 }
 
-// relative position bias: table[(2ws-1)^2][heads] <-> dense[heads][N][N]
-__global__ void relpos_expand_kernel(const float* __restrict__ table, float* __restrict__ dense, int ws, int heads, int ld) {
-    const int N = ws * ws;
+// relative position bias: table[(2wd-1)(2wh-1)(2ww-1)][heads] <-> dense[heads][N][ld]   (wd = 1: the 2-D Swin table).
+// Token i of an N-token window has the coordinates of token i of the FULL (wd,wh,ww) window -- this reproduces the
+// reference's `relative_position_index[:N, :N]` slice for clipped video windows (lib/video_swin_transformer.py:150).
+__device__ __forceinline__ int relpos_index(int i, int j, int wd, int wh, int ww) {
+    const int di = i / (wh * ww), hi = (i / ww) % wh, wi = i % ww;
+    const int dj = j / (wh * ww), hj = (j / ww) % wh, wj = j % ww;
+    return ((di - dj + wd - 1) * (2 * wh - 1) + (hi - hj + wh - 1)) * (2 * ww - 1) + (wi - wj + ww - 1);
+}
+__global__ void relpos_expand_kernel(const float* __restrict__ table, float* __restrict__ dense, int wd, int wh, int ww, int N, int heads, int ld) {
     const int64_t total = (int64_t)heads * N * ld;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int j = e % ld, i = (e / ld) % N, h = e / ((int64_t)N * ld);
-        const int idx = (i / ws - j / ws + ws - 1) * (2 * ws - 1) + (i % ws - j % ws + ws - 1);
-        dense[e] = j < N ? table[idx * heads + h] : -1e30f;       // padding columns can never win a softmax
+        dense[e] = j < N ? table[relpos_index(i, j, wd, wh, ww) * heads + h] : -1e30f;       // padding columns can never win a softmax
     }
 }
-// one wave per (table row, head): lanes stride over the (i,j) pairs that map to it, wave-shuffle sum -- deterministic
-__global__ void relpos_reduce_kernel(const float* __restrict__ ddense, float* __restrict__ dtable, int ws, int heads, int ld) {
-    const int R = (2 * ws - 1) * (2 * ws - 1), N = ws * ws;
+// one wave per (table row, head): lanes stride over the query tokens i, the matching key j follows from the offsets -- deterministic
+__global__ void relpos_reduce_kernel(const float* __restrict__ ddense, float* __restrict__ dtable, int wd, int wh, int ww, int N, int heads, int ld) {
+    const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
     const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (e >= R * heads) return;
     const int h = e % heads, idx = e / heads;
-    const int dr = idx / (2 * ws - 1) - (ws - 1), dc = idx % (2 * ws - 1) - (ws - 1);   // (ri - rj, ci - cj)
-    const int r0 = max(0, -dr), nr = min(ws, ws - dr) - r0, c0 = max(0, -dc), nc = min(ws, ws - dc) - c0;
+    const int dw = idx % (2 * ww - 1) - (ww - 1), dh = (idx / (2 * ww - 1)) % (2 * wh - 1) - (wh - 1), dd = idx / ((2 * ww - 1) * (2 * wh - 1)) - (wd - 1);
     float s = 0.f;
-    for (int t = lane; t < nr * nc; t += 64) {
-        const int rj = r0 + t / nc, cj = c0 + t % nc;
-        const int i = (rj + dr) * ws + (cj + dc), j = rj * ws + cj;
-        s += ddense[((int64_t)h * N + i) * ld + j];
+    for (int i = lane; i < N; i += 64) {
+        const int zi = i / (wh * ww), yi = (i / ww) % wh, xi = i % ww;
+        const int zj = zi - dd, yj = yi - dh, xj = xi - dw;
+        if (zj < 0 || zj >= wd || yj < 0 || yj >= wh || xj < 0 || xj >= ww) continue;
+        const int j = (zj * wh + yj) * ww + xj;
+        if (j < N) s += ddense[((int64_t)h * N + i) * ld + j];
     }
     s = wave_sum(s);
     if (lane == 0) dtable[idx * heads + h] += s;
+}
+
+// ---- row softmax of attention scores for the composed (GEMM + softmax + GEMM) path used for windows too large for the
+// fused kernels (Video-Swin: N = 392 / 1152): p = softmax_j(s[i][j] + bias[i][j] + mask(region_i, region_j)), one wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(const T* __restrict__ s, const float* __restrict__ bias, int bias_ld,
+                                                               const int8_t* __restrict__ region, int nw_img, T* __restrict__ p,
+                                                               int64_t rows, int rpw, int N, int ld) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const int i = (int)(row % rpw);
+        const int64_t w = row / rpw;
+        const T* sr = s + row * ld;
+        T* pr = p + row * ld;
+        if (i >= N) {                       // padding row of a window whose token count was rounded up
+            for (int j = lane; j < ld; j += 64) pr[j] = from_f<T>(0.f);
+            continue;
+        }
+        const int8_t* reg = region ? region + (w % nw_img) * N : nullptr;
+        const int ri = reg ? reg[i] : 0;
+        float mx = -1e30f;
+        for (int j = lane; j < N; j += 64) {
+            float v = to_f<T>(sr[j]) + bias[(int64_t)i * bias_ld + j];
+            if (reg && reg[j] != ri) v += -100.0f;
+            mx = fmaxf(mx, v);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < N; j += 64) {
+            float v = to_f<T>(sr[j]) + bias[(int64_t)i * bias_ld + j];
+            if (reg && reg[j] != ri) v += -100.0f;
+            sum += __expf(v - mx);
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int j = lane; j < ld; j += 64) {
+            float v = 0.f;
+            if (j < N) {
+                v = to_f<T>(sr[j]) + bias[(int64_t)i * bias_ld + j];
+                if (reg && reg[j] != ri) v += -100.0f;
+                v = __expf(v - mx) * inv;
+            }
+            pr[j] = from_f<T>(v);
+        }
+    }
+}
+// ds = p * (dp - sum_j p dp), written over dp; padding columns stay 0
+template <typename T>
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const T* __restrict__ p, T* __restrict__ dp, int64_t rows, int N, int ld) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const T* pr = p + row * ld;
+        T* dr = dp + row * ld;
+        float dot = 0.f;
+        for (int j = lane; j < N; j += 64) dot += to_f<T>(pr[j]) * to_f<T>(dr[j]);
+        dot = wave_sum(dot);
+        for (int j = lane; j < ld; j += 64) dr[j] = from_f<T>(j < N ? to_f<T>(pr[j]) * (to_f<T>(dr[j]) - dot) : 0.f);
+    }
 }
 
 template <typename T>
@@ -290,17 +354,42 @@ extern "C" int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bia
     return LAVT_ERR_INVALID;
 }
 
-extern "C" int lavt_relpos_expand(const float* table, float* dense, int ws, int heads, int ld, void* stream) {
-    LAVT_CHECK_ARG(table && dense && ws > 0 && heads > 0 && ld >= ws * ws, "lavt_relpos_expand: bad arguments");
-    const int64_t total = (int64_t)heads * ws * ws * ld;
-    hipLaunchKernelGGL(relpos_expand_kernel, dim3(cdiv(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, dense, ws, heads, ld);
+extern "C" int lavt_relpos_expand(const float* table, float* dense, int wd, int wh, int ww, int N, int heads, int ld, void* stream) {
+    LAVT_CHECK_ARG(table && dense && wd > 0 && wh > 0 && ww > 0 && N > 0 && N <= wd * wh * ww && heads > 0 && ld >= N, "lavt_relpos_expand: bad arguments");
+    const int64_t total = (int64_t)heads * N * ld;
+    int blocks = cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(relpos_expand_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, dense, wd, wh, ww, N, heads, ld);
     LAVT_CHECK_LAUNCH("lavt_relpos_expand");
     return LAVT_OK;
 }
-extern "C" int lavt_relpos_reduce(const float* ddense, float* dtable, int ws, int heads, int ld, void* stream) {
-    LAVT_CHECK_ARG(ddense && dtable && ws > 0 && heads > 0 && ld >= ws * ws, "lavt_relpos_reduce: bad arguments");
-    const int total = (2 * ws - 1) * (2 * ws - 1) * heads;
-    hipLaunchKernelGGL(relpos_reduce_kernel, dim3(cdiv(total, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ddense, dtable, ws, heads, ld);
+extern "C" int lavt_relpos_reduce(const float* ddense, float* dtable, int wd, int wh, int ww, int N, int heads, int ld, void* stream) {
+    LAVT_CHECK_ARG(ddense && dtable && wd > 0 && wh > 0 && ww > 0 && N > 0 && N <= wd * wh * ww && heads > 0 && ld >= N, "lavt_relpos_reduce: bad arguments");
+    const int total = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1) * heads;
+    hipLaunchKernelGGL(relpos_reduce_kernel, dim3(cdiv(total, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ddense, dtable, wd, wh, ww, N, heads, ld);
     LAVT_CHECK_LAUNCH("lavt_relpos_reduce");
+    return LAVT_OK;
+}
+extern "C" int lavt_attn_softmax_fwd(int dtype, const void* s, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* p,
+                                     int64_t rows, int rpw, int N, int ld, void* stream) {
+    LAVT_CHECK_ARG(s && bias && p && rows > 0 && N > 0 && rpw >= N && ld >= N && bias_ld >= N && (!region || nw_img > 0), "lavt_attn_softmax_fwd: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int blocks = cdiv(rows, 4);
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == LAVT_F32) hipLaunchKernelGGL(attn_softmax_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)s, bias, bias_ld, region, nw_img, (float*)p, rows, rpw, N, ld);
+    else if (dtype == LAVT_BF16) hipLaunchKernelGGL(attn_softmax_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)s, bias, bias_ld, region, nw_img, (bf16*)p, rows, rpw, N, ld);
+    else { lavt_set_error("lavt_attn_softmax_fwd: bad dtype %d", dtype); return LAVT_ERR_INVALID; }
+    LAVT_CHECK_LAUNCH("lavt_attn_softmax_fwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_attn_softmax_bwd(int dtype, const void* p, void* dp, int64_t rows, int N, int ld, void* stream) {
+    LAVT_CHECK_ARG(p && dp && rows > 0 && N > 0 && ld >= N, "lavt_attn_softmax_bwd: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int blocks = cdiv(rows, 4);
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == LAVT_F32) hipLaunchKernelGGL(attn_softmax_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)p, (float*)dp, rows, N, ld);
+    else if (dtype == LAVT_BF16) hipLaunchKernelGGL(attn_softmax_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)p, (bf16*)dp, rows, N, ld);
+    else { lavt_set_error("lavt_attn_softmax_bwd: bad dtype %d", dtype); return LAVT_ERR_INVALID; }
+    LAVT_CHECK_LAUNCH("lavt_attn_softmax_bwd");
     return LAVT_OK;
 }

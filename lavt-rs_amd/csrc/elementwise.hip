@@ -288,11 +288,11 @@ template <typename S, typename D> __global__ void transpose_kernel(const S* src,
         if (r < R && c < Cc) d[(int64_t)c * R + r] = from_f<D>(tile[threadIdx.x][k]);
     }
 }
-template <typename T> __global__ void pack_conv3x3_kernel(const float* w, T* packed, int Cout, int Cin) {
-    const int64_t n = (int64_t)Cout * 9 * Cin;
+template <typename T> __global__ void pack_conv3x3_kernel(const float* w, T* packed, int Cout, int Cin, int taps) {
+    const int64_t n = (int64_t)Cout * taps * Cin;
     GRID_STRIDE(i, n) {
-        const int ci = (int)(i % Cin), tap = (int)((i / Cin) % 9), co = (int)(i / Cin / 9);
-        packed[i] = from_f<T>(w[((int64_t)co * Cin + ci) * 9 + tap]);
+        const int ci = (int)(i % Cin), tap = (int)((i / Cin) % taps), co = (int)(i / Cin / taps);
+        packed[i] = from_f<T>(w[((int64_t)co * Cin + ci) * taps + tap]);
     }
 }
 template <typename D> __global__ void cast_multi_kernel(const int64_t* desc, int count) {
@@ -440,10 +440,10 @@ extern "C" int lavt_nhwc_to_nchw(int src_dtype, const void* src, int dst_dtype, 
     LAVT_CHECK_LAUNCH("lavt_nhwc_to_nchw");
     return LAVT_OK;
 }
-extern "C" int lavt_pack_conv3x3(const float* w, int dtype, void* packed, int Cout, int Cin, void* stream) {
-    LAVT_CHECK_ARG(w && packed && Cout > 0 && Cin > 0, "lavt_pack_conv3x3: bad arguments");
-    const int64_t n = (int64_t)Cout * Cin * 9;
-    DISPATCH_T(dtype, "lavt_pack_conv3x3", hipLaunchKernelGGL(pack_conv3x3_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, ST, w, (T*)packed, Cout, Cin));
+extern "C" int lavt_pack_conv3x3(const float* w, int dtype, void* packed, int Cout, int Cin, int taps, void* stream) {
+    LAVT_CHECK_ARG(w && packed && Cout > 0 && Cin > 0 && taps > 0, "lavt_pack_conv3x3: bad arguments");
+    const int64_t n = (int64_t)Cout * Cin * taps;
+    DISPATCH_T(dtype, "lavt_pack_conv3x3", hipLaunchKernelGGL(pack_conv3x3_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, ST, w, (T*)packed, Cout, Cin, taps));
     LAVT_CHECK_LAUNCH("lavt_pack_conv3x3");
     return LAVT_OK;
 }

@@ -54,23 +54,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const lavt_gemm_nt_t p) {
     const T* A2 = reinterpret_cast<const T*>(p.A2);
     const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.strideB;
     const bool conv = p.conv_kc > 0;
-    const int HW = p.conv_h * p.conv_w;
+    const ConvGeom cg = conv_geom(p);
 
     // ---- per-thread A rows -------------------------------------------------------------------
     const int a_chunk = tid % CPR, a_row0 = tid / CPR;
     int a_src[A_PASSES];          // source row (plain / mapped), -1 = zeros
-    short a_y[A_PASSES], a_x[A_PASSES];
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
         const int m = m0 + a_row0 + i * A_RPP;
         int src = -1;
         if (m < p.M) src = p.a_rowmap ? p.a_rowmap[m] : m;
         a_src[i] = src;
-        if (conv && src >= 0) {
-            const int pix = src % HW;
-            a_y[i] = (short)(pix / p.conv_w);
-            a_x[i] = (short)(pix % p.conv_w);
-        } else { a_y[i] = 0; a_x[i] = 0; }
     }
     const int b_chunk = BKM ? tid % BKM_CPR : a_chunk;
     const int b_row0 = BKM ? tid / BKM_CPR : a_row0;
@@ -82,11 +76,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const lavt_gemm_nt_t p) {
     auto load_tiles = [&](int kt) {
         // A
         const int k = kt * BK + a_chunk * EPC;
-        int tap = 0, kin = k, dy = 0, dx = 0;
+        int kin = k, dz = 0, dy = 0, dx = 0;
         if (conv) {
-            tap = k / p.conv_kc; kin = k - tap * p.conv_kc;
-            dy = tap / 3 - 1; dx = tap % 3 - 1;
-            if (p.conv_flip) { dy = -dy; dx = -dx; }
+            const int tap = k / p.conv_kc;
+            kin = k - tap * p.conv_kc;
+            conv_tap(cg, tap, dz, dy, dx);
+            if (p.conv_flip) { dz = -dz; dy = -dy; dx = -dx; }
         }
         const bool second = (p.A2 != nullptr) && kin >= p.a_split;
         const T* base = second ? A2 : A;
@@ -96,10 +91,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const lavt_gemm_nt_t p) {
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             int src = a_src[i];
-            if (conv) {
-                const int y = a_y[i] + dy, x = a_x[i] + dx;
-                src = (src >= 0 && y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) ? src + dy * p.conv_w + dx : -1;
-            }
+            if (conv) src = conv_nbr(cg, src, dz, dy, dx);
             const bool ok = src >= 0 && k < p.K;
             ra[i] = ldg16(ok ? base + (int64_t)src * ld + kk : A);
             va |= (ok ? 1u : 0u) << i;
@@ -264,8 +256,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const lavt_gemm_tn_t p, in
     const int ia = i0 + a_chunk * EPC;          // first column of this thread's A chunk
     const int jb = j0 + b_chunk * EPC;
     // column-dependent B source (conv tap, concat split) is fixed per thread
-    int tap = 0, jc = jb, dy = 0, dx = 0;
-    if (conv) { tap = jb / p.conv_kc; jc = jb - tap * p.conv_kc; dy = tap / 3 - 1; dx = tap % 3 - 1; }
+    const ConvGeom cg = conv_geom(p);
+    int jc = jb, dz = 0, dy = 0, dx = 0;
+    if (conv) { const int tap = jb / p.conv_kc; jc = jb - tap * p.conv_kc; conv_tap(cg, tap, dz, dy, dx); }
     const bool b_second = (p.B2 != nullptr) && jc >= p.b_split;
     const T* Bsrc = b_second ? B2 : B;
     const int64_t ldb = b_second ? p.ldb2 : p.ldb;
@@ -294,11 +287,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const lavt_gemm_tn_t p, in
             const bool in = k < p.K;
             const int kc = in ? k : 0;
             int src = p.b_rowmap ? p.b_rowmap[kc] : kc;
-            if (conv) {
-                const int pix = (src >= 0 ? src : 0) % (p.conv_h * p.conv_w);
-                const int y = pix / p.conv_w + dy, x = pix % p.conv_w + dx;
-                src = (src >= 0 && y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) ? src + dy * p.conv_w + dx : -1;
-            }
+            if (conv) src = conv_nbr(cg, src, dz, dy, dx);
             const bool ok = in && src >= 0 && jb < p.J;
             rb[i] = ldg16(ok ? Bsrc + (int64_t)src * ldb + jcc : Bsrc);
             vb |= (ok ? 1u : 0u) << i;
@@ -377,7 +366,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const lavt_gemm_tn_t p, in
                 const int jj = j0 + wj * WJ + j * 16 + (lane & 15);
                 if (jj >= p.J) continue;
                 int64_t col = jj;
-                if (p.c_conv_permute) { const int t2 = jj / p.conv_kc; col = (int64_t)(jj - t2 * p.conv_kc) * 9 + t2; }
+                if (p.c_conv_permute) { const int t2 = jj / p.conv_kc; col = (int64_t)(jj - t2 * p.conv_kc) * cg.taps + t2; }
                 atomicAdd(C + (int64_t)ii * p.ldc + col, p.alpha * acc[i][j][r]);
             }
         }
@@ -440,8 +429,10 @@ extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
     LAVT_CHECK_ARG(!p.A2 || (p.a_split % epc == 0 && p.lda2 % epc == 0), "lavt_gemm_nt: bad a_split");
     LAVT_CHECK_ARG(!p.C2 || p.c_split % 4 == 0, "lavt_gemm_nt: bad c_split");
     if (p.conv_kc > 0) {
-        LAVT_CHECK_ARG(p.K == 9 * p.conv_kc && p.conv_kc % epc == 0 && p.conv_h > 0 && p.conv_w > 0, "lavt_gemm_nt: bad conv geometry");
-        LAVT_CHECK_ARG(p.M % (p.conv_h * p.conv_w) == 0, "lavt_gemm_nt: conv rows %d not a multiple of H*W", p.M);
+        const int taps = (p.conv_kd > 0 ? p.conv_kd : 1) * (p.conv_kh > 0 ? p.conv_kh : 3) * (p.conv_kw > 0 ? p.conv_kw : 3);
+        const int vox = (p.conv_d > 0 ? p.conv_d : 1) * p.conv_h * p.conv_w;
+        LAVT_CHECK_ARG(p.K == taps * p.conv_kc && p.conv_kc % epc == 0 && p.conv_h > 0 && p.conv_w > 0, "lavt_gemm_nt: bad conv geometry");
+        LAVT_CHECK_ARG(p.M % vox == 0, "lavt_gemm_nt: conv rows %d not a multiple of D*H*W", p.M);
     }
     LAVT_CHECK_ARG((!p.R || p.ldr % 4 == 0) && (!p.Cpre || p.ldcpre % 4 == 0), "lavt_gemm_nt: ldr/ldcpre must be multiples of 4");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -462,7 +453,8 @@ extern "C" int lavt_gemm_tn(const lavt_gemm_tn_t* pp, void* stream) {
     LAVT_CHECK_ARG(p.lda % epc == 0 && p.ldb % epc == 0, "lavt_gemm_tn: lda/ldb must be multiples of %d", epc);
     LAVT_CHECK_ARG(!p.B2 || (p.b_split % epc == 0 && p.ldb2 % epc == 0), "lavt_gemm_tn: bad b_split");
     if (p.conv_kc > 0)
-        LAVT_CHECK_ARG(p.J == 9 * p.conv_kc && p.conv_kc % epc == 0 && p.conv_h > 0 && p.conv_w > 0, "lavt_gemm_tn: bad conv geometry");
+        LAVT_CHECK_ARG(p.J == (p.conv_kd > 0 ? p.conv_kd : 1) * (p.conv_kh > 0 ? p.conv_kh : 3) * (p.conv_kw > 0 ? p.conv_kw : 3) * p.conv_kc &&
+                       p.conv_kc % epc == 0 && p.conv_h > 0 && p.conv_w > 0, "lavt_gemm_tn: bad conv geometry");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rc2 = lavt_gemm_tn_v2(p, st);          // bf16 LDS-DMA kernel (gemm_v2.hip); 1 = not applicable
     if (rc2 != 1) return rc2;

@@ -60,6 +60,30 @@ __device__ __forceinline__ float apply_act(int act, float v) {
 }
 
 
+// ---- implicit-GEMM convolution geometry (2-D 3x3 and the 3-D kernels of SepTPWAM) ---------------------------------------
+struct ConvGeom {
+    int d, h, w, kd, kh, kw, taps, vox;     // vox = d*h*w voxels per sample
+};
+template <typename P> __device__ __forceinline__ ConvGeom conv_geom(const P& p) {
+    ConvGeom g;
+    g.kh = p.conv_kh > 0 ? p.conv_kh : 3; g.kw = p.conv_kw > 0 ? p.conv_kw : 3; g.kd = p.conv_kd > 0 ? p.conv_kd : 1;
+    g.d = p.conv_d > 0 ? p.conv_d : 1; g.h = p.conv_h; g.w = p.conv_w;
+    g.taps = g.kd * g.kh * g.kw; g.vox = g.d * g.h * g.w;
+    return g;
+}
+__device__ __forceinline__ void conv_tap(const ConvGeom& g, int tap, int& dz, int& dy, int& dx) {
+    dx = tap % g.kw - (g.kw >> 1);
+    dy = (tap / g.kw) % g.kh - (g.kh >> 1);
+    dz = tap / (g.kw * g.kh) - (g.kd >> 1);
+}
+// source row of the (dz,dy,dx) neighbour of voxel row `src` (-1 outside the zero-padded volume or if src < 0)
+__device__ __forceinline__ int conv_nbr(const ConvGeom& g, int src, int dz, int dy, int dx) {
+    if (src < 0) return -1;
+    const int pix = src % g.vox;
+    const int z = pix / (g.h * g.w) + dz, y = (pix / g.w) % g.h + dy, x = pix % g.w + dx;
+    return (z >= 0 && z < g.d && y >= 0 && y < g.h && x >= 0 && x < g.w) ? src + (dz * g.h + dy) * g.w + dx : -1;
+}
+
 // ---- XCD-aware workgroup -> tile order ----------------------------------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2): blocks b and b+8 share an L2.  Give each
 // XCD a CONTIGUOUS range of logical tiles (n fastest), so the tiles resident on one XCD share A row-panels and the whole

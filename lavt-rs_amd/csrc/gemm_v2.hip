@@ -113,22 +113,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
     const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.strideB;
     const T* Z = reinterpret_cast<const T*>(p.zeros);
     const bool conv = p.conv_kc > 0;
-    const int HW = p.conv_h * p.conv_w;
+    const ConvGeom cg = conv_geom(p);
 
     // ---- per-lane DMA geometry ------------------------------------------------------------------------------
     // k-contiguous tiles: instruction ii covers rows ii*8 .. ii*8+7; lane -> row ii*8 + lane/8, physical chunk lane%8,
     // logical chunk (lane%8) ^ (row%8) = (lane%8) ^ (lane/8): constant per lane.
     const int cl = (lane & 7) ^ (lane >> 3);
     int a_src[A_INSTR];
-    short a_y[A_INSTR], a_x[A_INSTR];
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
         const int m = m0 + (wave * A_INSTR + i) * 8 + (lane >> 3);
         int src = -1;
         if (m < p.M) src = p.a_rowmap ? p.a_rowmap[m] : m;
         a_src[i] = src;
-        if (conv && src >= 0) { const int pix = src % HW; a_y[i] = (short)(pix / p.conv_w); a_x[i] = (short)(pix % p.conv_w); }
-        else { a_y[i] = 0; a_x[i] = 0; }
     }
     int b_row[B_INSTR], b_col[B_INSTR];          // KC: b_row = n (or -1); KM: b_row = k row in tile (or -1), b_col = n (or -1)
 #pragma unroll
@@ -151,12 +148,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         char* sbase = smem + stage * STAGE_BYTES;
         // A
         const int k = kt * BK + cl * EPC;
-        int kin = k, dy = 0, dx = 0;
+        int kin = k, dz = 0, dy = 0, dx = 0;
         if (conv) {
             const int tap = k / p.conv_kc;
             kin = k - tap * p.conv_kc;
-            dy = tap / 3 - 1; dx = tap % 3 - 1;
-            if (p.conv_flip) { dy = -dy; dx = -dx; }
+            conv_tap(cg, tap, dz, dy, dx);
+            if (p.conv_flip) { dz = -dz; dy = -dy; dx = -dx; }
         }
         const bool second = (p.A2 != nullptr) && kin >= p.a_split;
         const T* base = second ? A2 : A;
@@ -165,10 +162,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
             int src = a_src[i];
-            if (conv) {
-                const int y = a_y[i] + dy, x = a_x[i] + dx;
-                src = (src >= 0 && y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) ? src + dy * p.conv_w + dx : -1;
-            }
+            if (conv) src = conv_nbr(cg, src, dz, dy, dx);
             const T* g = (src >= 0 && k < p.K) ? base + (int64_t)src * ld + kk : Z;
             dma16(g, sbase + (wave * A_INSTR + i) * 1024);
         }
@@ -290,10 +284,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
     const T* B2 = reinterpret_cast<const T*>(p.B2);
     const T* Z = reinterpret_cast<const T*>(p.zeros);
     const bool conv = p.conv_kc > 0;
-    const int HW = p.conv_h * p.conv_w;
+    const ConvGeom cg = conv_geom(p);
 
     // per-lane DMA geometry (constant over K tiles): LDS chunk q = (wave*INSTR + i)*64 + lane -> (k row, column chunk)
-    int a_kr[A_INSTR], a_col[A_INSTR], b_kr[B_INSTR], b_dy[B_INSTR], b_dx[B_INSTR];
+    int a_kr[A_INSTR], a_col[A_INSTR], b_kr[B_INSTR], b_dz[B_INSTR], b_dy[B_INSTR], b_dx[B_INSTR];
     const T* b_base[B_INSTR];
     int64_t b_ld[B_INSTR];
 #pragma unroll
@@ -309,12 +303,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
         const int jb = j0 + cc * EPC;
         const bool ok = kr < BK && cc * EPC < BJ && jb < p.J;
         b_kr[i] = ok ? kr : -1;
-        int jc = jb, dy = 0, dx = 0;
-        if (conv) { const int tap = jb / p.conv_kc; jc = jb - tap * p.conv_kc; dy = tap / 3 - 1; dx = tap % 3 - 1; }
+        int jc = jb, dz = 0, dy = 0, dx = 0;
+        if (conv) { const int tap = jb / p.conv_kc; jc = jb - tap * p.conv_kc; conv_tap(cg, tap, dz, dy, dx); }
         const bool second = (p.B2 != nullptr) && jc >= p.b_split;
         b_base[i] = (second ? B2 : B) + (second ? jc - p.b_split : jc);
         b_ld[i] = second ? p.ldb2 : p.ldb;
-        b_dy[i] = dy; b_dx[i] = dx;
+        b_dz[i] = dz; b_dy[i] = dy; b_dx[i] = dx;
     }
     // source rows of the NEXT tile to issue are fetched one iteration ahead so the map loads never sit between a DMA and its wait
     int a_src[A_INSTR], b_src[B_INSTR];
@@ -346,11 +340,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
             int src = b_src[i];
-            if (conv && src >= 0) {
-                const int pix = src % HW;
-                const int y = pix / p.conv_w + b_dy[i], x = pix % p.conv_w + b_dx[i];
-                src = (y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) ? src + b_dy[i] * p.conv_w + b_dx[i] : -1;
-            }
+            if (conv) src = conv_nbr(cg, src, b_dz[i], b_dy[i], b_dx[i]);
             dma16(src >= 0 ? b_base[i] + (int64_t)src * b_ld[i] : Z, sb + (wave * B_INSTR + i) * 1024);
         }
     };
@@ -409,7 +399,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
                 const int jj = j0 + wj * WJ + j * 16 + (lane & 15);
                 if (jj >= p.J) continue;
                 int64_t col = jj;
-                if (p.c_conv_permute) { const int t2 = jj / p.conv_kc; col = (int64_t)(jj - t2 * p.conv_kc) * 9 + t2; }
+                if (p.c_conv_permute) { const int t2 = jj / p.conv_kc; col = (int64_t)(jj - t2 * p.conv_kc) * cg.taps + t2; }
                 float* dst = C + (int64_t)ii * p.ldc + col;
                 if (atomic) atomicAdd(dst, p.alpha * acc[i][j][r]); else *dst = p.alpha * acc[i][j][r];
             }

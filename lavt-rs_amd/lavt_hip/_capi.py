@@ -31,7 +31,7 @@ class GemmNT(C.Structure):
         ("alpha", f32), ("bias", vp), ("strideBias", i64), ("row_scale", vp), ("strideRowScale", i64), ("row_scale_div", i32), ("act", i32),
         ("Cpre", vp), ("ldcpre", i64), ("R", vp), ("ldr", i64),
         ("C", vp), ("ldc", i64), ("strideC", i64), ("C2", vp), ("ldc2", i64), ("c_split", i32), ("c_rowmap", vp),
-        ("c_f32", i32), ("zeros", vp), ("epi_lds", i32),
+        ("c_f32", i32), ("zeros", vp), ("epi_lds", i32), ("conv_d", i32), ("conv_kd", i32), ("conv_kh", i32), ("conv_kw", i32),
     ]
 
 
@@ -43,6 +43,7 @@ class GemmTN(C.Structure):
         ("conv_h", i32), ("conv_w", i32), ("conv_kc", i32),
         ("alpha", f32), ("C", vp), ("ldc", i64), ("strideC", i64), ("c_conv_permute", i32), ("split_k", i32),
         ("colsum", vp), ("strideColsum", i64), ("zeros", vp), ("a_rowscale_binary", i32), ("accumulate", i32),
+        ("conv_d", i32), ("conv_kd", i32), ("conv_kh", i32), ("conv_kw", i32),
     ]
 
 
@@ -53,8 +54,10 @@ _PROTOTYPES = {
     "lavt_gemm_tn": [C.POINTER(GemmTN), vp],
     "lavt_window_attn_fwd": [i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, f32, vp],
     "lavt_window_attn_bwd": [i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
-    "lavt_relpos_expand": [vp, vp, i32, i32, i32, vp],
-    "lavt_relpos_reduce": [vp, vp, i32, i32, i32, vp],
+    "lavt_relpos_expand": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "lavt_relpos_reduce": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "lavt_attn_softmax_fwd": [i32, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32, vp],
+    "lavt_attn_softmax_bwd": [i32, vp, vp, i64, i32, i32, vp],
     "lavt_layernorm_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "lavt_layernorm_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
     "lavt_colstats": [i32, vp, vp, vp, vp, i64, i32, i32, i32, vp],
@@ -78,7 +81,7 @@ _PROTOTYPES = {
     "lavt_cast": [i32, vp, i32, vp, i64, vp],
     "lavt_nchw_to_nhwc": [i32, vp, i32, vp, i32, i32, i32, vp],
     "lavt_nhwc_to_nchw": [i32, vp, i32, vp, i32, i32, i32, vp],
-    "lavt_pack_conv3x3": [vp, i32, vp, i32, i32, vp],
+    "lavt_pack_conv3x3": [vp, i32, vp, i32, i32, i32, vp],
     "lavt_cast_multi": [vp, i32, i32, vp],
 }
 for _name, _args in _PROTOTYPES.items():

@@ -46,8 +46,8 @@ class _WeightCache:
         src = p.detach()
         if kind == "lin":
             shape = (src.shape[0], src.numel() // src.shape[0])
-        elif kind == "conv3":
-            shape = (src.shape[0], 9 * src.shape[1])
+        elif kind == "conv3":                        # [Cout][Cin][taps...] -> [Cout][taps][Cin]
+            shape = (src.shape[0], src.numel() // src.shape[0])
         else:
             raise KeyError(kind)
         # keep the same storage across refreshes (static addresses for hipGraph replays)
@@ -55,7 +55,8 @@ class _WeightCache:
         if kind == "lin":
             K.check(K.lib.lavt_cast(K.F32, K.ptr(src), K.dt(dtype), K.ptr(out), src.numel(), K.stream()))
         else:
-            K.check(K.lib.lavt_pack_conv3x3(K.ptr(src), K.dt(dtype), K.ptr(out), src.shape[0], src.shape[1], K.stream()))
+            K.check(K.lib.lavt_pack_conv3x3(K.ptr(src), K.dt(dtype), K.ptr(out), src.shape[0], src.shape[1],
+                                            src.numel() // (src.shape[0] * src.shape[1]), K.stream()))
         self.store[key] = (stamp, out, weakref.ref(p))
         return out
 
@@ -217,7 +218,9 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.A2, p.lda2, p.a_split = K.ptr(A2), lda2, a_split
     p.a_rowmap = K.ptr(a_rowmap)
     if conv is not None:
-        p.conv_h, p.conv_w, p.conv_kc, p.conv_flip = conv
+        p.conv_h, p.conv_w, p.conv_kc, p.conv_flip = conv[:4]
+        if len(conv) > 4:
+            p.conv_d, p.conv_kd, p.conv_kh, p.conv_kw = conv[4:8]
     p.B, p.ldb, p.strideB, p.b_kmajor, p.b_tap_stride = K.ptr(B) + b_off * es, ldb, strideB, int(b_kmajor), b_tap_stride
     p.alpha, p.bias, p.strideBias = alpha, K.ptr(bias), strideBias
     p.row_scale, p.strideRowScale, p.row_scale_div, p.act = K.ptr(row_scale), strideRowScale, row_scale_div, act
@@ -242,7 +245,9 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.B, p.ldb, p.strideB = K.ptr(B) + b_off * es, ldb, strideB
     p.B2, p.ldb2, p.b_split, p.b_rowmap = K.ptr(B2), ldb2, b_split, K.ptr(b_rowmap)
     if conv is not None:
-        p.conv_h, p.conv_w, p.conv_kc = conv
+        p.conv_h, p.conv_w, p.conv_kc = conv[:3]
+        if len(conv) > 3:
+            p.conv_d, p.conv_kd, p.conv_kh, p.conv_kw = conv[3:7]
     p.alpha, p.C, p.ldc, p.strideC = alpha, K.ptr(Cout) + c_off * 4, ldc, strideC
     p.c_conv_permute, p.split_k = int(c_conv_permute), 0
     p.colsum, p.strideColsum = K.ptr(colsum), strideColsum
@@ -369,18 +374,28 @@ def layer_norm(x, gamma, beta, eps=1e-5, gather=None):
 
 
 # ------------------------------------------------------------------------------------------ window attention core
+def _win3(win):
+    """window spec -> (wd, wh, ww): int ws = 2-D Swin (1, ws, ws); tuple = Video-Swin window"""
+    return (1, win, win) if isinstance(win, int) else tuple(int(v) for v in win)
+
+
+FUSED_ATTN_MAX_N = 160          # one window's K/V (and P for backward) fit the fused kernels up to 12x12 = 144 (+pad) tokens
+
+
 class _WindowAttn(torch.autograd.Function):
+    """Fused kernels (N <= 160 tokens per window).  qkv [nwin*N, 3C] windowed rows."""
+
     @staticmethod
-    def forward(ctx, qkv, table, region, ws, heads):
+    def forward(ctx, qkv, table, region, win, heads, N):
         qkv = qkv.contiguous()
-        N = ws * ws
+        wd, wh, ww = win
         C3 = qkv.shape[1]
         Cc = C3 // 3
         nwin = qkv.shape[0] // N
         dev = qkv.device
         ld = 64 if N <= 64 else -(-N // 32) * 32   # 64 / 160: padded key axis (pairs of 16-wide MFMA tiles); padding holds -1e30
         dense = torch.empty(heads, N, ld, dtype=torch.float32, device=dev)
-        K.check(K.lib.lavt_relpos_expand(K.ptr(_f32(table)), K.ptr(dense), ws, heads, ld, K.stream()))
+        K.check(K.lib.lavt_relpos_expand(K.ptr(_f32(table)), K.ptr(dense), wd, wh, ww, N, heads, ld, K.stream()))
         out = torch.empty(nwin * N, Cc, dtype=qkv.dtype, device=dev)
         lse = torch.empty(nwin, heads, N, dtype=torch.float32, device=dev)
         nw_img = region.shape[0] if region is not None else 0
@@ -388,25 +403,107 @@ class _WindowAttn(torch.autograd.Function):
         K.check(K.lib.lavt_window_attn_fwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(lse),
                                            nwin, N, heads, Cc // heads, scale, K.stream()))
         ctx.save_for_backward(qkv, dense, region, out, lse, table)
-        ctx.dims = (ws, heads, nwin, N, Cc, nw_img, scale, ld)
+        ctx.dims = (win, heads, nwin, N, Cc, nw_img, scale, ld)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, dense, region, out, lse, table = ctx.saved_tensors
-        ws, heads, nwin, N, Cc, nw_img, scale, ld = ctx.dims
+        win, heads, nwin, N, Cc, nw_img, scale, ld = ctx.dims
+        wd, wh, ww = win
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         ddense = torch.zeros_like(dense)
         K.check(K.lib.lavt_window_attn_bwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout),
                                            K.ptr(lse), K.ptr(dqkv), K.ptr(ddense), nwin, N, heads, Cc // heads, scale, K.stream()))
-        dtable, ts = sinks.buf(table, ((2 * ws - 1) ** 2, heads))
-        K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense), K.ptr(dtable), ws, heads, ld, K.stream()))
-        return dqkv, sinks.done(table, dtable, ts), None, None, None
+        dtable, ts = sinks.buf(table, ((2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1), heads))
+        K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense), K.ptr(dtable), wd, wh, ww, N, heads, ld, K.stream()))
+        return dqkv, sinks.done(table, dtable, ts), None, None, None, None
 
 
-def window_attention(qkv, table, region, ws, heads):
-    return _WindowAttn.apply(qkv, table, region, ws, heads)
+class _WindowAttnComposed(torch.autograd.Function):
+    """Windows too large for the fused kernels (Video-Swin: 8x7x7 = 392, 8x12x12 = 1152 tokens): per head
+    S = scale q k^T (batched gather-GEMM over windows) -> bias + shift mask + softmax (lavt_attn_softmax) -> P v (GEMM).
+    Scores are materialised ([nwin, N, N] per head): correct for any N and both dtypes; a streaming (flash-style) MFMA kernel
+    for these sizes is future work.  Windows whose token count is not a multiple of 8 are zero-padded per window."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, region, win, heads, N):
+        dtype, dev = qkv.dtype, qkv.device
+        wd, wh, ww = win
+        C3 = qkv.shape[1]
+        Cc = C3 // 3
+        nwin = qkv.shape[0] // N
+        Np = -(-N // 8) * 8
+        if Np != N:
+            qkv = torch.nn.functional.pad(qkv.view(nwin, N, C3), (0, 0, 0, Np - N)).reshape(nwin * Np, C3)
+        qkv = qkv.contiguous()
+        dense = torch.empty(heads, N, Np, dtype=torch.float32, device=dev)
+        K.check(K.lib.lavt_relpos_expand(K.ptr(_f32(table)), K.ptr(dense), wd, wh, ww, N, heads, Np, K.stream()))
+        nw_img = region.shape[0] if region is not None else 0
+        scale = float((Cc // heads) ** -0.5)
+        out = torch.empty(nwin * Np, Cc, dtype=dtype, device=dev)
+        Ps = []
+        for h in range(heads):
+            S = torch.empty(nwin * Np, Np, dtype=dtype, device=dev)
+            gemm_nt(dtype, Np, Np, 32, qkv, C3, qkv, C3, S, Np, batch=nwin, strideA=Np * C3, strideB=Np * C3, strideC=Np * Np,
+                    alpha=scale, a_off=h * 32, b_off=Cc + h * 32)
+            P = torch.empty_like(S)
+            K.check(K.lib.lavt_attn_softmax_fwd(K.dt(dtype), K.ptr(S), K.ptr(dense[h]), Np, K.ptr(region), nw_img, K.ptr(P),
+                                                nwin * Np, Np, N, Np, K.stream()))
+            gemm_nt(dtype, Np, 32, Np, P, Np, qkv, C3, out, Cc, batch=nwin, strideA=Np * Np, strideB=Np * C3, strideC=Np * Cc,
+                    b_kmajor=True, b_off=2 * Cc + h * 32, c_off=h * 32)
+            Ps.append(P)
+        ctx.save_for_backward(qkv, dense, region, table, *Ps)
+        ctx.dims = (win, heads, nwin, N, Np, Cc, nw_img, scale)
+        return out if Np == N else out.view(nwin, Np, Cc)[:, :N].reshape(nwin * N, Cc)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, dense, region, table, *Ps = ctx.saved_tensors
+        win, heads, nwin, N, Np, Cc, nw_img, scale = ctx.dims
+        wd, wh, ww = win
+        dtype, dev = qkv.dtype, qkv.device
+        C3 = 3 * Cc
+        if Np != N:
+            dout = torch.nn.functional.pad(dout.reshape(nwin, N, Cc), (0, 0, 0, Np - N)).reshape(nwin * Np, Cc)
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        ddense = torch.empty(heads, N, Np, dtype=torch.float32, device=dev)
+        for h in range(heads):
+            P = Ps[h]
+            dS = torch.empty_like(P)                 # first dP, then overwritten with dS
+            gemm_nt(dtype, Np, Np, 32, dout, Cc, qkv, C3, dS, Np, batch=nwin, strideA=Np * Cc, strideB=Np * C3, strideC=Np * Np,
+                    a_off=h * 32, b_off=2 * Cc + h * 32)
+            K.check(K.lib.lavt_attn_softmax_bwd(K.dt(dtype), K.ptr(P), K.ptr(dS), nwin * Np, N, Np, K.stream()))
+            ddense[h] = dS.view(nwin, Np, Np)[:, :N].float().sum(0)          # bias gradient: sum over windows (tiny; fallback path)
+            # dQ = scale dS K
+            gemm_nt(dtype, Np, 32, Np, dS, Np, qkv, C3, dqkv, C3, batch=nwin, strideA=Np * Np, strideB=Np * C3, strideC=Np * C3,
+                    b_kmajor=True, alpha=scale, b_off=Cc + h * 32, c_off=h * 32)
+            # dK = scale dS^T Q ; dV = P^T dO   (fp32 outputs of the wgrad family, then cast into the qkv gradient)
+            dk = torch.zeros(nwin, Np, 32, dtype=torch.float32, device=dev)
+            dv = torch.zeros_like(dk)
+            gemm_tn(dtype, Np, 32, Np, dS, Np, qkv, C3, dk, 32, batch=nwin, strideA=Np * Np, strideB=Np * C3, strideC=Np * 32,
+                    alpha=scale, b_off=h * 32)
+            gemm_tn(dtype, Np, 32, Np, P, Np, dout, Cc, dv, 32, batch=nwin, strideA=Np * Np, strideB=Np * Cc, strideC=Np * 32, b_off=h * 32)
+            dq3 = dqkv.view(nwin * Np, 3, Cc)
+            dq3[:, 1, h * 32:(h + 1) * 32] = dk.view(nwin * Np, 32).to(dtype)
+            dq3[:, 2, h * 32:(h + 1) * 32] = dv.view(nwin * Np, 32).to(dtype)
+        dtable, ts = sinks.buf(table, ((2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1), heads))
+        K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense), K.ptr(dtable), wd, wh, ww, N, heads, Np, K.stream()))
+        if Np != N:
+            dqkv = dqkv.view(nwin, Np, C3)[:, :N].reshape(nwin * N, C3)
+        return dqkv, sinks.done(table, dtable, ts), None, None, None, None
+
+
+def window_attention(qkv, table, region, win, heads, N=None):
+    """win: int ws (2-D) or (wd, wh, ww); N: tokens per window (default: the full window; smaller for clipped video windows)."""
+    win = _win3(win)
+    if N is None:
+        N = win[0] * win[1] * win[2]
+    if N <= FUSED_ATTN_MAX_N:
+        return _WindowAttn.apply(qkv, table, region, win, heads, N)
+    return _WindowAttnComposed.apply(qkv, table, region, win, heads, N)
 
 
 # ------------------------------------------------------------------------------------------ Instance / Batch norm
@@ -693,11 +790,12 @@ def patch_embed(img, weight, bias, dtype):
 
 
 # ------------------------------------------------------------------------------------------ decoder pieces
-class _Conv3x3(torch.autograd.Function):
-    """3x3 / pad 1 / no-bias convolution over NHWC rows, input = channel concat of x1 and (optional) x2."""
+class _ConvTaps(torch.autograd.Function):
+    """'same'-padded convolution over NHWC / NDHWC rows as an implicit GEMM: 3x3 (decoder, no bias) or kd x kh x kw with bias
+    (Conv3d of SepTPWAM); the input may be the channel concat of x1 and x2; optional fused GELU (pre-activation saved)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, B, H, W):
+    def forward(ctx, x1, x2, weight, bias, B, D, H, W, act):
         x1 = x1.contiguous()
         dtype = x1.dtype
         C1 = x1.shape[1]
@@ -707,37 +805,58 @@ class _Conv3x3(torch.autograd.Function):
             C2 = x2.shape[1]
         Wp = weights.get(weight, dtype, "conv3")
         Cout, Cin = weight.shape[0], weight.shape[1]
-        assert Cin == C1 + C2, f"conv3x3: weight expects {Cin} input channels, got {C1}+{C2}"
-        M = B * H * W
+        ks = tuple(weight.shape[2:])
+        kd, kh, kw = (1,) + ks if len(ks) == 2 else ks
+        taps = kd * kh * kw
+        assert Cin == C1 + C2, f"conv: weight expects {Cin} input channels, got {C1}+{C2}"
+        M = B * D * H * W
         y = torch.empty(M, Cout, dtype=dtype, device=x1.device)
-        gemm_nt(dtype, M, Cout, 9 * Cin, x1, C1, Wp, 9 * Cin, y, Cout, A2=x2, lda2=C2, a_split=C1, conv=(H, W, Cin, 0))
-        ctx.save_for_backward(x1, x2, weight)
-        ctx.dims = (B, H, W, C1, C2, Cout)
+        pre = torch.empty_like(y) if act != K.ACT_NONE else None
+        gemm_nt(dtype, M, Cout, taps * Cin, x1, C1, Wp, taps * Cin, y, Cout, A2=x2, lda2=C2, a_split=C1,
+                conv=(H, W, Cin, 0, D, kd, kh, kw), bias=_f32(bias), act=act, Cpre=pre, ldcpre=Cout)
+        ctx.save_for_backward(x1, x2, weight, bias, pre)
+        ctx.dims = (B, D, H, W, C1, C2, Cout, kd, kh, kw, act)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x1, x2, weight = ctx.saved_tensors
-        B, H, W, C1, C2, Cout = ctx.dims
+        x1, x2, weight, bias, pre = ctx.saved_tensors
+        B, D, H, W, C1, C2, Cout, kd, kh, kw, act = ctx.dims
         dtype = x1.dtype
         Cin = C1 + C2
-        M = B * H * W
+        taps = kd * kh * kw
+        M = B * D * H * W
         dy = dy.contiguous()
+        if act != K.ACT_NONE:
+            g = torch.empty_like(dy)
+            K.check(K.lib.lavt_act_bwd(K.dt(dtype), act, K.ptr(dy), K.ptr(pre), K.ptr(g), dy.numel(), K.stream()))
+            dy = g
         Wp = weights.get(weight, dtype, "conv3")
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             dx1 = torch.empty_like(x1)
             dx2 = torch.empty_like(x2) if x2 is not None else None
-            gemm_nt(dtype, M, Cin, 9 * Cout, dy, Cout, Wp, 9 * Cin, dx1, C1, conv=(H, W, Cout, 1), b_kmajor=True, b_tap_stride=Cin,
-                    C2=dx2, ldc2=C2, c_split=C1)
-        dW, wsink = sinks.buf(weight, (Cout, Cin * 9))
-        side.run(lambda: gemm_tn(dtype, Cout, 9 * Cin, M, dy, Cout, x1, C1, dW, 9 * Cin, B2=x2, ldb2=C2, b_split=C1, conv=(H, W, Cin),
-                                 c_conv_permute=True), (dy, x1, x2), wsink)
-        return dx1, dx2, sinks.done(weight, dW, wsink), None, None, None
+            gemm_nt(dtype, M, Cin, taps * Cout, dy, Cout, Wp, taps * Cin, dx1, C1, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
+                    b_tap_stride=Cin, C2=dx2, ldc2=C2, c_split=C1)
+        dW, wsink = sinks.buf(weight, (Cout, Cin * taps))
+        db = bsink = None
+        if bias is not None:
+            db, bsink = sinks.buf(bias, (Cout,))
+        side.run(lambda: gemm_tn(dtype, Cout, taps * Cin, M, dy, Cout, x1, C1, dW, taps * Cin, B2=x2, ldb2=C2, b_split=C1,
+                                 conv=(H, W, Cin, D, kd, kh, kw), c_conv_permute=True, colsum=db), (dy, x1, x2), wsink and (db is None or bsink))
+        return (dx1, dx2, sinks.done(weight, dW, wsink), sinks.done(bias, db, bsink) if bias is not None else None,
+                None, None, None, None, None)
 
 
 def conv3x3(x1, x2, weight, B, H, W):
-    return _Conv3x3.apply(x1, x2, weight, B, H, W)
+    return _ConvTaps.apply(x1, x2, weight, None, B, 1, H, W, K.ACT_NONE)
+
+
+def conv3d(x, weight, bias, B, D, H, W, act=K.ACT_NONE):
+    """Conv3d(stride 1, 'same' zero padding, kernel sizes 1 or 3 per axis) on NDHWC rows [B*D*H*W, Cin]."""
+    if weight.shape[2:] == (1, 1, 1):
+        return linear(x, weight, bias, act=act)
+    return _ConvTaps.apply(x, None, weight, bias, B, D, H, W, act)
 
 
 class _Bilinear(torch.autograd.Function):

@@ -23,6 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "lavt-rs_amd"))
 from lavt_hip.detweights import det_inputs, det_tensor, fill_state_dict_  # noqa: E402
+sys.path.remove(os.path.join(ROOT, "lavt-rs_amd"))     # from here on `lib` must resolve to the REFERENCE (a namespace package loses to ours)
 
 REF = "/root/reference"
 
@@ -112,7 +113,8 @@ def grad_digest(t, n=24):
 # ----------------------------------------------------------------------------- cases
 def main():
     ap = argparse.ArgumentParser()
-    ap.parse_args()
+    ap.add_argument("--only-video", action="store_true")
+    cli = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     _install_shims()
@@ -121,6 +123,9 @@ def main():
     from lib import backbone as rb
     from lib import mask_predictor as rmp
     from lib import _utils as ru
+    if cli.only_video:
+        video_cases(args)
+        return
 
     # --- window attention, with/without mask, both window sizes ------------------------------
     for tag, C, nH, ws, Bw, Hp in (("w7", 96, 3, 7, 8, 14), ("w12", 128, 4, 12, 4, 24)):
@@ -270,6 +275,94 @@ def main():
     save("e2e_tiny_train", seed=99, logits=logits, loss=float(loss), dx=grad_digest(x.grad), dl=grad_digest(l.grad),
          nograd=np.array(nograd), **digests)
     print("   tiny: params without grad:", nograd)
+    video_cases(args)
+
+
+def video_cases(args_base):
+    """Golden vectors of the video path (lib/video_swin_transformer.py), driven through the reference's own classes."""
+    import lib.video_swin_transformer as rv
+    from lib import mask_predictor as rmp
+    rv.sr_ratio = [1, 1, 1, 1]                    # the shipped file reads an undefined global (SURVEY.md B2); set from outside
+
+    # --- 3-D shift masks ---------------------------------------------------------------------------------------
+    packs = {}
+    for tag, (Dp, Hp, Wp, win, shift) in {"a": (8, 14, 14, (8, 7, 7), (0, 3, 3)), "b": (16, 14, 14, (8, 7, 7), (4, 3, 3)),
+                                          "c": (16, 7, 7, (8, 7, 7), (4, 0, 0)), "d": (4, 12, 24, (4, 12, 12), (0, 6, 6))}.items():
+        mk = rv.compute_mask(Dp, Hp, Wp, win, shift, "cpu")
+        packs["m_" + tag] = np.packbits((mk != 0).numpy().reshape(-1))
+        packs["n_" + tag] = np.array(mk.shape)
+        packs["cfg_" + tag] = np.array([Dp, Hp, Wp, *win, *shift])
+    save("video_masks", **packs)
+
+    # --- Video-Swin blocks: full window, clipped window (T=3: index-slice quirk), temporal shift (T=16) ------------------
+    for tag, (B, D, H, W) in {"t8": (1, 8, 10, 9), "t3": (1, 3, 10, 9), "t16": (1, 16, 7, 7)}.items():
+        for shifted in (0, 1):
+            window = (8, 7, 7)
+            blk = rv.SwinTransformerBlock3D(64, 2, window, shift_size=tuple(w // 2 for w in window) if shifted else (0, 0, 0)).eval()
+            fill_state_dict_(blk)
+            x = randn(71, B, D, H, W, 64)
+            win, shift = rv.get_window_size((D, H, W), window, tuple(w // 2 for w in window))
+            Dp, Hp, Wp = (int(np.ceil(n / w)) * w for n, w in zip((D, H, W), win))
+            mask = rv.compute_mask(Dp, Hp, Wp, win, shift, "cpu")
+            with torch.no_grad():
+                y = blk(x, mask)
+            save(f"vblock_{tag}_s{shifted}", dims=np.array([B, D, H, W]), seed=71, y=y)
+
+    # --- SepTPWAM, README recipe -----------------------------------------------------------------------------------
+    va = ref_args("--sep_t_pwam", "--conv3d_kernel_size_t", "3-3-3", "--conv3d_kernel_size_s", "1-1-1", "--w_t3x3_s1x1", "--mm_t3x3_s1x1")
+    sp = rv.SepTPWAM(32, 32, 768, 32, 32, num_heads=1, dropout=0.0, conv3d_kernel_size_t=(3, 3, 3), conv3d_kernel_size_s=(1, 1, 1),
+                     w_t3x3_s1x1=True, mm_t3x3_s1x1=True, args=va).eval()
+    fill_state_dict_(sp)
+    x, l = randn(81, 2, 4, 6, 5, 32), randn(82, 2, 768, 20)
+    lm = torch.zeros(2, 20, 1)
+    lm[0, :6] = 1
+    lm[1, :17] = 1
+    with torch.no_grad():
+        y = sp(x, l, lm)
+    save("sep_t_pwam", seeds=np.array([81, 82]), valid=np.array([6, 17]), y=y)
+
+    # --- end to end micro video models (PWAM default, SepTPWAM recipe): forward + every parameter gradient ---------------
+    for tag, a in (("pwam", ref_args()), ("sept", va)):
+        bb = rv.MultiModalSwinTransformer3D(patch_size=(1, 4, 4), embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8],
+                                            window_size=(8, 7, 7), drop_path_rate=0.0, patch_norm=True, out_indices=(0, 1, 2, 3),
+                                            use_checkpoint=False, num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=a)
+        bb.init_weights()
+        dec = rmp.SimpleDecoding(256, a)
+        model = nn.ModuleDict({"backbone": bb, "classifier": dec})
+        fill_state_dict_(model)
+        keys = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in model.state_dict().items())
+        with open(os.path.join(HERE, f"state_dict_keys_video_micro_{tag}.txt"), "w") as f:
+            f.write("\n".join(keys) + "\n")
+        model.train()
+        # batch 2 on purpose: with batch 1 PyTorch's CPU instance_norm backward mis-reads a channels-last-strided grad_output
+        # (the permute+view after f_query_t/f_query_s hands it one), so a batch-1 CPU run of the reference does not give the
+        # gradient of its own forward; batch 2 does (checked against float64 and a hand-written normalisation).
+        frames, l, lm, tgt = det_inputs(2, 64, 22, seed=123, frames=4)
+        frames.requires_grad_(True)
+        l.requires_grad_(True)
+        feats = bb(frames.permute(0, 2, 1, 3, 4), l, lm)                      # what _LAVTVideoSimpleDecode.forward does (lib/_utils.py:97-106)
+        logits = F.interpolate(dec(feats[3], feats[2], feats[1], feats[0]), size=frames.shape[-2:], mode="bilinear", align_corners=True)
+        loss = F.cross_entropy(logits, tgt, weight=torch.tensor([0.9, 1.1]))
+        loss.backward()
+        digests, nograd = {}, []
+        for k, p_ in model.named_parameters():
+            if p_.grad is None:
+                nograd.append(k)
+            else:
+                digests["g|" + k] = grad_digest(p_.grad)
+        save(f"e2e_video_micro_{tag}", seed=123, logits=logits, loss=float(loss.detach()), dframes=grad_digest(frames.grad), dl=grad_digest(l.grad),
+             nograd=np.array(nograd), **digests)
+        print(f"   video micro {tag}: params without grad: {nograd}")
+
+    # --- state-dict key list of the Video-Swin-B model (factory shapes) ------------------------------------------------------
+    for tag, a in (("pwam", ref_args("--swin_type", "base")), ("sept", ref_args("--swin_type", "base", "--sep_t_pwam", "--conv3d_kernel_size_t", "3-3-3",
+                                                                                   "--conv3d_kernel_size_s", "1-1-1", "--w_t3x3_s1x1", "--mm_t3x3_s1x1"))):
+        bb = rv.MultiModalSwinTransformer3D(patch_size=(1, 4, 4), embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=(8, 7, 7),
+                                            drop_path_rate=0.3, patch_norm=True, out_indices=(0, 1, 2, 3), use_checkpoint=False,
+                                            num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=a)
+        keys = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in bb.state_dict().items())
+        with open(os.path.join(HERE, f"state_dict_keys_video_swin_b_{tag}.txt"), "w") as f:
+            f.write("\n".join(keys) + "\n")
 
 
 def _ref_mask(rb, Hp, Wp, ws):

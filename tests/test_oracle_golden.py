@@ -3,6 +3,7 @@
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from lavt_hip.detweights import det_inputs, det_tensor
 from oracle import lavt_oracle as O
@@ -255,3 +256,98 @@ def test_e2e_micro_train_grads(golden):
     for name, t in (("dx", x.grad), ("dl", l.grad)):
         ref = torch.as_tensor(g[name])
         assert float((grad_digest(t) - ref).abs().max()) <= 2e-4 * float(ref[0]) + 1e-7
+
+
+# ================================================================================================ video path
+from oracle import lavt_video_oracle as OV  # noqa: E402
+
+
+def sd_from_keys(keys_file):
+    import os
+    from conftest import GOLDEN
+    sd = {}
+    for line in open(os.path.join(GOLDEN, keys_file)):
+        k, shp = line.strip().split("|")
+        if k.endswith("relative_position_index"):
+            continue
+        shape = tuple(int(s) for s in shp.split("x")) if shp else ()
+        sd[k] = det_tensor(k, shape, torch.long if k.endswith("num_batches_tracked") else torch.float32)
+    return sd
+
+
+def test_video_masks(golden):
+    g = golden("video_masks")
+    for tag in "abcd":
+        Dp, Hp, Wp, wd, wh, ww, sd_, sh, sw = g["cfg_" + tag].tolist()
+        m = OV.shift_mask_3d(Dp, Hp, Wp, (wd, wh, ww), (sd_, sh, sw))
+        assert list(m.shape) == g["n_" + tag].tolist()
+        assert np.array_equal(np.packbits((m != 0).numpy().reshape(-1)), g["m_" + tag])
+
+
+def vblock_spec(C, nH, window):
+    s = block_spec(C, nH, 7)
+    s["attn.relative_position_bias_table"] = ((2 * window[0] - 1) * (2 * window[1] - 1) * (2 * window[2] - 1), nH)
+    return s
+
+
+@pytest.mark.parametrize("tag", ["t8", "t3", "t16"])
+@pytest.mark.parametrize("shifted", [0, 1])
+def test_video_block(golden, tag, shifted):
+    g = golden(f"vblock_{tag}_s{shifted}")
+    B, D, H, W = g["dims"].tolist()
+    sd = {"b." + k: v for k, v in gen_sd(vblock_spec(64, 2, (8, 7, 7))).items()}
+    x = randn(int(g["seed"]), B, D, H, W, 64)
+    close(OV.swin_block_3d(sd, "b", x, 2, (8, 7, 7), bool(shifted)), g["y"], 1e-4)
+
+
+def sept_spec(C, p=""):
+    s = {}
+    for k, ks in (("temporal_vis_project.0", 3), ("spatial_vis_project.0", 1), ("f_query_t.0", 3), ("f_query_s.0", 1), ("W_t.0", 3), ("W_s.0", 1),
+                  ("project_mm_t.0", 3), ("project_mm_s.0", 1)):
+        s[p + k + ".weight"] = (C, C, ks, ks, ks)
+        s[p + k + ".bias"] = (C,)
+    for k in ("f_key.0", "f_value.0"):
+        s[p + k + ".weight"] = (C, 768, 1)
+        s[p + k + ".bias"] = (C,)
+    return s
+
+
+def test_video_sep_t_pwam(golden):
+    g = golden("sep_t_pwam")
+    sd = {"f." + k: v for k, v in gen_sd(sept_spec(32)).items()}
+    x, l = randn(int(g["seeds"][0]), 2, 4, 6, 5, 32), randn(int(g["seeds"][1]), 2, 768, 20)
+    m = torch.zeros(2, 20, 1)
+    for b, n in enumerate(g["valid"].tolist()):
+        m[b, :n] = 1
+    close(OV.sep_t_pwam(sd, "f", x, l, m), g["y"], 1e-4)
+
+
+@pytest.mark.parametrize("tag", ["pwam", "sept"])
+def test_video_e2e_micro_train_grads(golden, tag):
+    """The oracle runs in float64 here: the digests hold a plain sum of each gradient, and through 27-tap convolutions plus
+    instance norms a float32 run carries ~1e-2 of cancellation noise in it (the reference's float32 run sits within 1e-3 of
+    the float64 value).  Fixture batch is 2 -- see make_golden.py for the batch-1 PyTorch CPU instance-norm backward defect."""
+    g = golden(f"e2e_video_micro_{tag}")
+    sd = sd_from_keys(f"state_dict_keys_video_micro_{tag}.txt")
+    dt = torch.float64
+    params = {k: v.clone().to(dt).requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    full = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    full.update(params)
+    frames, l, m, tgt = det_inputs(2, 64, 22, seed=int(g["seed"]), frames=4)
+    frames, l, m = frames.to(dt).requires_grad_(True), l.to(dt).requires_grad_(True), m.to(dt)
+    logits = OV.lavt_video_forward(full, frames, l, m, "micro", (8, 7, 7), sep_t=(tag == "sept"), training=True)
+    close(logits.detach().float(), g["logits"], 3e-4)
+    loss = F.cross_entropy(logits, tgt, weight=torch.tensor([0.9, 1.1], dtype=dt))
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    nograd = set(g["nograd"].tolist())
+    tol = 2e-3
+    for k, p in params.items():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+            continue
+        ref = torch.as_tensor(g["g|" + k])
+        assert float((grad_digest(p.grad.float()) - ref).abs().max()) <= tol * max(float(ref[0]), 1e-6) + 3e-6, k
+    for name, t in (("dframes", frames.grad), ("dl", l.grad)):
+        ref = torch.as_tensor(g[name])
+        assert float((grad_digest(t.float()) - ref).abs().max()) <= tol * float(ref[0]) + 3e-6
