@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, 
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const T* __restrict__ mul, int relu, float* __restrict__ o1,
                                                        float* __restrict__ o2, float* __restrict__ partials, int rows, int C, int rows_per_block) {
-    // !BWD: a = x; o1 += sum x, o2 += sum x^2.     BWD: a = dy; g = dy (*mul) (masked y>0); o1 += sum g, o2 += sum g*xhat
+    // !BWD: a = x; o1 += sum (x-K), o2 += sum (x-K)^2, K = x[g][0][:].     BWD: a = dy; g = dy (*mul) (masked y>0); o1 += sum g, o2 += sum g*xhat
     constexpr int EPC = Chunk<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = reinterpret_cast<float*>(smem_raw);       // [256][2*EPC]
@@ -224,6 +224,10 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, 
             if (BWD) {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) { mu[e] = mean[(int64_t)g * C + col + e]; rs[e] = rstd[(int64_t)g * C + col + e]; }
+            } else {
+                // shifted sums: accumulate (x - K) and (x - K)^2 with K = the group's first row, so that the variance does not
+                // come out of E[x^2] - E[x]^2 of large-mean data (colstats_center_kernel undoes the shift)
+                chunk_to_f<T>(*reinterpret_cast<const uint4*>(a + (int64_t)g * rows * C + col), mu);
             }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, 
                 chunk_to_f<T>(*reinterpret_cast<const uint4*>(a + off), f);
                 if (!BWD) {
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
+                    for (int e = 0; e < EPC; ++e) { const float d = f[e] - mu[e]; s1[e] += d; s2[e] += d * d; }
                 } else {
                     float fx[EPC];
                     chunk_to_f<T>(*reinterpret_cast<const uint4*>(xin + off), fx);
@@ -282,12 +286,24 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, 
     }
 }
 
-__global__ void stats_finalize_kernel(const float* sum, const float* sumsq, float count, float eps, float* mean, float* rstd,
+// shifted sums (s1 = sum (x-K), s2 = sum (x-K)^2 over the group's `rows` rows) -> sum x and the centred second moment M2 = sum (x - mean)^2
+template <typename T>
+__global__ void colstats_center_kernel(const T* __restrict__ x, float* __restrict__ o1, float* __restrict__ o2, int rows, int C, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = i / C, c = i - g * C;
+    const float k = to_f<T>(x[(int64_t)g * rows * C + c]);
+    const float s1 = o1[i], s2 = o2[i];
+    o1[i] = s1 + (float)rows * k;
+    o2[i] = fmaxf(s2 - s1 * s1 / (float)rows, 0.f);
+}
+
+__global__ void stats_finalize_kernel(const float* sum, const float* m2, float count, float eps, float* mean, float* rstd,
                                       float* running_mean, float* running_var, float momentum, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float mu = sum[i] / count;
-    const float var = fmaxf(sumsq[i] / count - mu * mu, 0.f);
+    const float var = m2[i] / count;
     mean[i] = mu;
     rstd[i] = rsqrtf(var + eps);
     if (running_mean) running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * mu;
@@ -416,6 +432,8 @@ extern "C" int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq,
                hipLaunchKernelGGL((colstats_kernel<T, false>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
                                   (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, 0, sum, sumsq, partials, rows, C, rpb));
     if (partials) hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(groups * 2 * C, 32)), dim3(256), 0, st, partials, blocks, groups * 2 * C, C, sum, sumsq);
+    DISPATCH_T(dtype, "lavt_colstats",
+               hipLaunchKernelGGL(colstats_center_kernel<T>, dim3(cdiv(groups * C, 256)), dim3(256), 0, st, (const T*)x, sum, sumsq, rows, C, groups * C));
     LAVT_CHECK_LAUNCH("lavt_colstats");
     return LAVT_OK;
 }

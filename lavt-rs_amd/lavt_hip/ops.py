@@ -567,16 +567,20 @@ class _BatchNormRelu(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         count = float(R)
         if training:
-            s = _stats(x, 1, R, Cc)
+            s = _stats(x, 1, R, Cc)                          # [sum x, centred second moment] of the local rows
             if group is not None:
                 import torch.distributed as dist
-                dist.all_reduce(s, group=group)
-                count = float(R * dist.get_world_size(group))
+                world = dist.get_world_size(group)
+                local_mean = s[0] / R
+                dist.all_reduce(s[0], group=group)
+                count = float(R * world)
+                s[1] += R * (local_mean - s[0] / count) ** 2      # re-centre about the global mean, then the moments add up
+                dist.all_reduce(s[1], group=group)
             K.check(K.lib.lavt_stats_finalize(K.ptr(s[0]), K.ptr(s[1]), count, eps, K.ptr(mean), K.ptr(rstd), K.ptr(running_mean),
                                               K.ptr(running_var), momentum, Cc, K.stream()))
         else:
-            # eval: mean = running_mean, var = running_var  (sum = mean, sumsq = var + mean^2, count = 1)
-            s = torch.stack([running_mean, running_var + running_mean * running_mean])
+            # eval: mean = running_mean, var = running_var  (sum = mean, m2 = var, count = 1)
+            s = torch.stack([running_mean, running_var])
             K.check(K.lib.lavt_stats_finalize(K.ptr(s[0]), K.ptr(s[1]), 1.0, eps, K.ptr(mean), K.ptr(rstd), None, None, 0.0, Cc, K.stream()))
         y = torch.empty_like(x)
         K.check(K.lib.lavt_norm_apply(K.dt(x.dtype), K.ptr(x), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), None, 1,

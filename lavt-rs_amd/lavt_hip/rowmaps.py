@@ -64,9 +64,46 @@ def kv_pad_map_np(B: int, n_l: int, ld: int) -> np.ndarray:
     return (np.arange(B)[:, None] * ld + np.arange(n_l)[None, :]).reshape(-1).astype(np.int32)
 
 
+# ---- Video-Swin: (D, H, W) token volumes, (wd, wh, ww) windows ----------------------------------------------------------
+def clip_window(size, window, shift=None):
+    """lib/video_swin_transformer.py:70-83: on an axis whose extent is <= the window, the window is clipped to it and the shift zeroed."""
+    win = tuple(s if s <= w else w for s, w in zip(size, window))
+    if shift is None:
+        return win
+    return win, tuple(0 if s <= w else sh for s, w, sh in zip(size, window, shift))
+
+
+def window_map3d_np(B: int, D: int, H: int, W: int, win, shift) -> np.ndarray:
+    """3-D twin of window_map_np: windowed rows ordered (b, window d/h/w index, position d/h/w in window)
+    (lib/video_swin_transformer.py:39-52); source token = ((b*D + z)*H + y)*W + x, -1 = zero padding (:236-241).
+    `win` / `shift` are the already clipped values."""
+    (wd, wh, ww), (sd, sh, sw) = win, shift
+    Dp, Hp, Wp = padded(D, wd), padded(H, wh), padded(W, ww)
+    zs, ys, xs = (np.arange(Dp) + sd) % Dp, (np.arange(Hp) + sh) % Hp, (np.arange(Wp) + sw) % Wp
+    ok = (zs[:, None, None] < D) & (ys[None, :, None] < H) & (xs[None, None, :] < W)
+    src = np.where(ok, (zs[:, None, None] * H + ys[None, :, None]) * W + xs[None, None, :], -1)            # (Dp, Hp, Wp)
+    win_rows = src.reshape(Dp // wd, wd, Hp // wh, wh, Wp // ww, ww).transpose(0, 2, 4, 1, 3, 5).reshape(-1)
+    out = np.where(win_rows[None, :] >= 0, win_rows[None, :] + (np.arange(B) * D * H * W)[:, None], -1)
+    return out.reshape(-1).astype(np.int32)
+
+
+def region_ids3d_np(D: int, H: int, W: int, win, shift) -> np.ndarray:
+    """int8 [nW][N]: 9*g(d) + 3*g(h) + g(w) on the padded volume (compute_mask, lib/video_swin_transformer.py:315-328:
+    slices [0,-w) | [-w,-s) | [-s,end) per axis; with s == 0 the last slice is the whole axis)."""
+    (wd, wh, ww), (sd, sh, sw) = win, shift
+    Dp, Hp, Wp = padded(D, wd), padded(H, wh), padded(W, ww)
+
+    def g(n, w, s):
+        r = np.arange(n)
+        return np.where(r < n - w, 0, np.where(r < n - s, 1, 2)) if s > 0 else np.full(n, 2)
+    ids = 9 * g(Dp, wd, sd)[:, None, None] + 3 * g(Hp, wh, sh)[None, :, None] + g(Wp, ww, sw)[None, None, :]
+    return ids.reshape(Dp // wd, wd, Hp // wh, wh, Wp // ww, ww).transpose(0, 2, 4, 1, 3, 5).reshape(-1, wd * wh * ww).astype(np.int8)
+
+
 @functools.lru_cache(maxsize=256)
 def _cached(kind, args, device):
-    fn = {"window": window_map_np, "region": region_ids_np, "merge": merge_map_np, "kvpad": kv_pad_map_np}[kind]
+    fn = {"window": window_map_np, "region": region_ids_np, "merge": merge_map_np, "kvpad": kv_pad_map_np,
+          "window3d": window_map3d_np, "region3d": region_ids3d_np}[kind]
     return torch.from_numpy(fn(*args)).to(device)
 
 
@@ -84,3 +121,11 @@ def merge_map(B, H, W, device):
 
 def kv_pad_map(B, n_l, ld, device):
     return _cached("kvpad", (B, n_l, ld), str(device))
+
+
+def window_map3d(B, D, H, W, win, shift, device):
+    return _cached("window3d", (B, D, H, W, tuple(win), tuple(shift)), str(device))
+
+
+def region_ids3d(D, H, W, win, shift, device):
+    return _cached("region3d", (D, H, W, tuple(win), tuple(shift)), str(device))

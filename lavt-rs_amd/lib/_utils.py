@@ -75,3 +75,37 @@ class _LAVTOneSimpleDecode(nn.Module):
 
 class LAVTOne(_LAVTOneSimpleDecode):
     pass
+
+
+class _LAVTVideoSimpleDecode(nn.Module):
+    """Reference lib/_utils.py:76-108: clip (B, T, 3, H, W) + token ids (B, N_l) + attention mask (B, N_l) -> (B*T, 2, H, W) logits.
+    BERT runs inside (it is outside the hot path, as for LAVTOne); `forward_backbone` is the hot path proper on language features."""
+
+    def __init__(self, backbone, classifier, args):
+        super().__init__()
+        self.backbone = backbone
+        self.classifier = classifier
+        self.text_encoder = _build_text_encoder(args)
+        self.lazy_pred = bool(getattr(args, "lazy_pred", False))
+        self.seg_last = bool(getattr(args, "seg_last", False))
+
+    def forward_backbone(self, x, l_feats, l_mask):
+        """x (B, T, 3, H, W); l_feats (B, 768, N_l); l_mask (B, N_l, 1)"""
+        input_shape = x.shape[-2:]
+        features = self.backbone(x.permute(0, 2, 1, 3, 4), l_feats, l_mask)          # (B, 3, T, H, W) view; the patch embed reads frames
+        if self.lazy_pred:
+            x_c1, (x_c2, x_c3, x_c4) = None, features
+        else:
+            x_c1, x_c2, x_c3, x_c4 = features
+        y = self.classifier(x_c4, x_c3, x_c2, x_c1)
+        if self.seg_last:
+            return y
+        return _upsample_logits(y, input_shape)
+
+    def forward(self, x, text, l_mask):
+        l_feats = self.text_encoder(text, attention_mask=l_mask)[0].permute(0, 2, 1)      # (B, 768, N_l)
+        return self.forward_backbone(x, l_feats, l_mask.unsqueeze(dim=-1))
+
+
+class LAVTVideo(_LAVTVideoSimpleDecode):
+    pass

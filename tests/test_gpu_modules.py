@@ -239,3 +239,100 @@ def test_product_never_imports_oracle():
         if src and src.endswith(".py"):
             text = open(src).read()
             assert "import oracle" not in text and "from oracle" not in text, name
+
+
+# ================================================================================================ video path
+def grad_digest_nosum(t):
+    d = grad_digest(t)
+    return torch.cat([d[:1], d[2:]])          # entry 1 is a plain sum: ~1e-2 of fp32 cancellation noise through 27-tap convs + instance norms
+
+
+@pytest.mark.parametrize("tag", ["t8", "t3", "t16"])
+@pytest.mark.parametrize("shifted", [0, 1])
+def test_video_block_golden(golden, tag, shifted):
+    """Video-Swin block: full 8x7x7 window (392 tokens), clipped temporal window (T=3, 147 tokens, index-slice quirk), temporal shift (T=16)"""
+    from lib.video_swin_transformer import SwinTransformerBlock3D
+    g = golden(f"vblock_{tag}_s{shifted}")
+    B, D, H, W = g["dims"].tolist()
+    blk = SwinTransformerBlock3D(64, 2, (8, 7, 7), (4, 3, 3) if shifted else (0, 0, 0)).eval()
+    fill_state_dict_(blk)
+    blk.to(DEV)
+    y = blk(randn(int(g["seed"]), B, D, H, W, 64).to(DEV))
+    close(y, g["y"], 2e-4, "video swin block")
+
+
+def test_video_sep_t_pwam_golden(golden):
+    from lib.video_swin_transformer import SepTPWAM
+    g = golden("sep_t_pwam")
+    va = SimpleNamespace()
+    sp = SepTPWAM(32, 32, 768, 32, 32, num_heads=1, dropout=0.0, conv3d_kernel_size_t=(3, 3, 3), conv3d_kernel_size_s=(1, 1, 1),
+                  w_t3x3_s1x1=True, mm_t3x3_s1x1=True, args=va).eval()
+    fill_state_dict_(sp)
+    sp.to(DEV)
+    x, l = randn(int(g["seeds"][0]), 2, 4, 6, 5, 32), randn(int(g["seeds"][1]), 2, 768, 20)
+    m = torch.zeros(2, 20, 1)
+    for b, n in enumerate(g["valid"].tolist()):
+        m[b, :n] = 1
+    close(sp(x.to(DEV), l.to(DEV), m.to(DEV)), g["y"], 2e-4, "SepTPWAM")
+
+
+def _build_video(tag):
+    from lib.mask_predictor import SimpleDecoding
+    from lib.video_swin_transformer import MultiModalSwinTransformer3D
+    flags = dict(sep_t_pwam=True, conv3d_kernel_size_t="3-3-3", conv3d_kernel_size_s="1-1-1", w_t3x3_s1x1=True, mm_t3x3_s1x1=True) if tag == "sept" else {}
+    a = SimpleNamespace(**flags)
+    bb = MultiModalSwinTransformer3D(patch_size=(1, 4, 4), embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=(8, 7, 7),
+                                     drop_path_rate=0.0, patch_norm=True, out_indices=(0, 1, 2, 3), use_checkpoint=False,
+                                     num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=a)
+    model = torch.nn.ModuleDict({"backbone": bb, "classifier": SimpleDecoding(256, a)})
+    fill_state_dict_(model)
+    return model.to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["pwam", "sept"])
+def test_video_e2e_micro_train_grads_golden(golden, tag):
+    """Train-mode clip forward (Video-Swin + PWAM | SepTPWAM + gate + decoder + upsample) + weighted CE + backward vs the reference"""
+    from lib._utils import _upsample_logits
+    g = golden(f"e2e_video_micro_{tag}")
+    model = _build_video(tag).train()
+    keys = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in model.state_dict().items())
+    assert keys == open(os.path.join(os.path.dirname(__file__), "golden", f"state_dict_keys_video_micro_{tag}.txt")).read().split()
+    frames, l, m, tgt = det_inputs(2, 64, 22, seed=int(g["seed"]), frames=4)
+    frames, l = frames.to(DEV).requires_grad_(True), l.to(DEV).requires_grad_(True)
+    f = model["backbone"](frames.permute(0, 2, 1, 3, 4), l, m.to(DEV))
+    logits = _upsample_logits(model["classifier"](f[3], f[2], f[1], f[0]), frames.shape[-2:])
+    close(logits, g["logits"], 1e-3, "video micro logits")
+    loss = F.cross_entropy(logits, tgt.to(DEV), weight=torch.tensor([0.9, 1.1], device=DEV))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
+    loss.backward()
+    nograd = set(g["nograd"].tolist())
+    bad = []
+    for k, p in model.named_parameters():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        ref = torch.as_tensor(g["g|" + k])
+        ref = torch.cat([ref[:1], ref[2:]])
+        err = float((grad_digest_nosum(p.grad) - ref).abs().max())
+        if not err <= 3e-3 * max(float(ref[0]), 1e-6) + 5e-6:
+            bad.append((k, err, float(ref[0])))
+    assert not bad, f"{len(bad)} parameter gradients off: {bad[:8]}"
+    for name, t in (("dframes", frames.grad), ("dl", l.grad)):
+        ref = torch.as_tensor(g[name])
+        ref = torch.cat([ref[:1], ref[2:]])
+        assert float((grad_digest_nosum(t) - ref).abs().max()) <= 3e-3 * float(ref[0]) + 5e-6, name
+
+
+@pytest.mark.parametrize("tag", ["pwam", "sept"])
+def test_video_bf16_close_to_fp32(golden, tag):
+    import lavt_hip
+    from lib._utils import _upsample_logits
+    g = golden(f"e2e_video_micro_{tag}")
+    model = _build_video(tag).train()            # train mode: the fixture's logits were taken with batch-statistics BatchNorm
+    frames, l, m, _ = det_inputs(2, 64, 22, seed=int(g["seed"]), frames=4)
+    with lavt_hip.use_dtype(torch.bfloat16), torch.no_grad():
+        f = model["backbone"](frames.to(DEV).permute(0, 2, 1, 3, 4), l.to(DEV), m.to(DEV))
+        logits = _upsample_logits(model["classifier"](f[3], f[2], f[1], f[0]), frames.shape[-2:]).cpu()
+    ref = torch.as_tensor(g["logits"])
+    rng = float(ref.max() - ref.min())
+    assert float((logits - ref).abs().max()) <= 0.08 * rng

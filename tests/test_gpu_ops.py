@@ -164,6 +164,24 @@ def test_conv3x3(dtype, B, H, W, C1, C2, Cout):
     run_pair(lambda x1, w, x2=None: ops.conv3x3(x1, x2, w, B, H, W), ref, inputs, dtype, name="conv3x3", bf16=4e-2)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout,ks", [(2, 4, 6, 5, 32, 32, (3, 3, 3)), (1, 8, 9, 7, 64, 32, (3, 1, 1)), (1, 3, 8, 8, 32, 64, (1, 3, 3)),
+                                                 (2, 4, 2, 2, 256, 256, (3, 3, 3)), (1, 8, 24, 24, 128, 128, (3, 3, 3))])
+def test_conv3d(dtype, B, D, H, W, Cin, Cout, ks):
+    """Conv3d (stride 1, 'same' padding, bias, optional GELU) of SepTPWAM as an implicit GEMM over NDHWC rows
+    (lib/video_swin_transformer.py:1331-1343)"""
+    from lavt_hip import ops
+    from lavt_hip._capi import ACT_GELU
+    taps = ks[0] * ks[1] * ks[2]
+    inputs = {"x": (rnd(B * D * H * W, Cin, seed=1), "act"), "w": (rnd(Cout, Cin, *ks, seed=3, scale=(taps * Cin) ** -0.5), "param"),
+              "b": (0.1 * rnd(Cout, seed=4), "param")}
+
+    def ref(x, w, b):
+        y = F.conv3d(x.view(B, D, H, W, Cin).permute(0, 4, 1, 2, 3), w, b, padding=tuple(k // 2 for k in ks))
+        return F.gelu(y.permute(0, 2, 3, 4, 1).reshape(B * D * H * W, Cout))
+    run_pair(lambda x, w, b: ops.conv3d(x, w, b, B, D, H, W, act=ACT_GELU), ref, inputs, dtype, name="conv3d", bf16=4e-2)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("ws,heads,H,shift", [(7, 3, 14, 3), (7, 2, 14, 0), (12, 4, 24, 6), (12, 2, 12, 6)])
@@ -186,6 +204,33 @@ def test_window_attention(dtype, ws, heads, H, shift):
         return (a.softmax(-1) @ v).transpose(1, 2).reshape(Bw * N, C)
     inputs = {"qkv": (rnd(Bw * N, 3 * C, seed=1), "act"), "table": (rnd((2 * ws - 1) ** 2, heads, seed=2, scale=0.5), "param")}
     run_pair(lambda qkv, table: ops.window_attention(qkv, table, region, ws, heads), ref, inputs, dtype, name="window attention")
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("dims,window,heads,shifted", [((8, 14, 7), (8, 7, 7), 2, 1), ((8, 7, 7), (8, 7, 7), 1, 0), ((3, 14, 14), (8, 7, 7), 2, 1),
+                                                       ((16, 7, 7), (8, 7, 7), 2, 1), ((4, 12, 12), (8, 12, 12), 1, 0)])
+def test_window_attention_3d(dtype, dims, window, heads, shifted):
+    """Video-Swin windows: 392 / 576 tokens (composed path), 147 tokens of a clipped window (fused path; the bias is the
+    top-left block of the FULL window's index matrix, lib/video_swin_transformer.py:150)"""
+    from lavt_hip import ops, rowmaps
+    from oracle import lavt_video_oracle as OV
+    win, shift = rowmaps.clip_window(dims, window, tuple(w // 2 for w in window) if shifted else (0, 0, 0))
+    N, C = win[0] * win[1] * win[2], heads * 32
+    nW = (dims[0] // win[0]) * (dims[1] // win[1]) * (dims[2] // win[2])
+    Bw = 2 * nW
+    moved = any(shift)
+    region = torch.from_numpy(rowmaps.region_ids3d_np(*dims, win, shift)).to(dev()) if moved else None
+    mask = OV.shift_mask_3d(*dims, win, shift) if moved else None
+    idx = OV.rel_pos_index_3d(*window)[:N, :N].reshape(-1)
+    R = (2 * window[0] - 1) * (2 * window[1] - 1) * (2 * window[2] - 1)
+
+    def ref(qkv, table):
+        q, k, v = qkv.view(Bw, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+        a = (q * 32 ** -0.5) @ k.transpose(-1, -2) + table[idx].view(N, N, heads).permute(2, 0, 1)[None]
+        if mask is not None:
+            a = (a.view(Bw // nW, nW, heads, N, N) + mask[None, :, None]).view(Bw, heads, N, N)
+        return (a.softmax(-1) @ v).transpose(1, 2).reshape(Bw * N, C)
+    inputs = {"qkv": (rnd(Bw * N, 3 * C, seed=1), "act"), "table": (rnd(R, heads, seed=2, scale=0.5), "param")}
+    run_pair(lambda qkv, table: ops.window_attention(qkv, table, region, window, heads, N=N), ref, inputs, dtype, name="window attention 3d")
 
 
 # ------------------------------------------------------------------------------------------------ norms

@@ -105,3 +105,47 @@ def test_sync_bn_conversion_is_seen():
     from lib.mask_predictor import SimpleDecoding
     dec = torch.nn.SyncBatchNorm.convert_sync_batchnorm(SimpleDecoding(64, SimpleNamespace()))
     assert isinstance(dec.bn1_4, torch.nn.SyncBatchNorm) and "bn1_4.running_var" in dec.state_dict()
+
+
+# ---------------------------------------------------------------------------------------------------- video row maps
+@pytest.mark.parametrize("dims,window", [((8, 10, 9), (8, 7, 7)), ((3, 10, 9), (8, 7, 7)), ((16, 7, 7), (8, 7, 7)), ((4, 13, 24), (4, 12, 12))])
+@pytest.mark.parametrize("shifted", [0, 1])
+def test_window_map3d_matches_pad_roll_partition(dims, window, shifted):
+    """lib/video_swin_transformer.py:230-262: pad -> roll -> window_partition as one row map (+ the region table vs the oracle mask)"""
+    from oracle import lavt_video_oracle as OV
+    B, (D, H, W) = 2, dims
+    win, shift = rowmaps.clip_window(dims, window, tuple(w // 2 for w in window) if shifted else (0, 0, 0))
+    assert (win, shift) == OV.clip_window(dims, window, tuple(w // 2 for w in window) if shifted else (0, 0, 0))
+    tok = torch.arange(B * D * H * W, dtype=torch.float32).view(B, D, H, W, 1) + 1          # 0 marks padding
+    Dp, Hp, Wp = (rowmaps.padded(n, w) for n, w in zip(dims, win))
+    u = torch.nn.functional.pad(tok, (0, 0, 0, Wp - W, 0, Hp - H, 0, Dp - D))
+    if any(shift):
+        u = torch.roll(u, tuple(-s for s in shift), (1, 2, 3))
+    xw = u.view(B, Dp // win[0], win[0], Hp // win[1], win[1], Wp // win[2], win[2], 1).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1)
+    m = rowmaps.window_map3d_np(B, D, H, W, win, shift)
+    assert np.array_equal(m, xw.numpy().astype(np.int64) - 1)
+    cover = m[m >= 0]
+    assert len(np.unique(cover)) == B * D * H * W == len(cover)
+    if any(shift):
+        reg = rowmaps.region_ids3d_np(D, H, W, win, shift)
+        mask = OV.shift_mask_3d(Dp, Hp, Wp, win, shift)
+        assert np.array_equal(reg[:, :, None] != reg[:, None, :], (mask != 0).numpy())
+
+
+SEPT_FLAGS = dict(sep_t_pwam=True, conv3d_kernel_size_t="3-3-3", conv3d_kernel_size_s="1-1-1", w_t3x3_s1x1=True, mm_t3x3_s1x1=True)
+
+
+@pytest.mark.parametrize("tag,flags", [("pwam", {}), ("sept", SEPT_FLAGS)])
+def test_video_factory_state_dict_keys(tag, flags):
+    """lavt_video builds the reference's parameter set (names + shapes) for Video-Swin-B, default PWAM and the README SepTPWAM recipe"""
+    from lib import segmentation
+    model = segmentation.lavt_video("", SimpleNamespace(swin_type="base", **flags))
+    keys = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in model.backbone.state_dict().items())
+    assert keys == open(os.path.join(GOLDEN, f"state_dict_keys_video_swin_b_{tag}.txt")).read().split()      # backbone of the reference factory
+    assert {k.split(".")[0] for k in model.state_dict()} == {"backbone", "classifier", "text_encoder"}
+
+
+def test_video_unsupported_fusions_fail_loudly():
+    from lib import segmentation
+    with pytest.raises(NotImplementedError):
+        segmentation.lavt_video("", SimpleNamespace(swin_type="tiny", ts_pwam=True, conv3d_kernel_size="3-1-1"))
