@@ -118,8 +118,12 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force = os.environ.get("LAVT_FORCE_COLLECTIVES", "0") == "1"          # dev: run the N>1 code path (SyncBN + bucketed all-reduce) in a 1-rank group
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     import lavt_hip
@@ -128,11 +132,11 @@ def main():
     cfg = WORKLOADS[a.workload]
     lavt_hip.set_compute_dtype(a.dtype)
     model = build_model(cfg, device, a.drop_path)
-    if world > 1:
+    if world > 1 or force:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)       # train.py:589
     model.train()
     x, l, m, tgt = det_inputs(cfg["batch"], cfg["size"], 20, seed=1234 + rank)
-    step = TrainStep(model, x.to(device), l.to(device), m.to(device), tgt.to(device), world=world, use_graph=not a.no_graph)
+    step = TrainStep(model, x.to(device), l.to(device), m.to(device), tgt.to(device), world=2 if force else world, use_graph=not a.no_graph)
     step.warmup_and_capture()
 
     for _ in range(a.warmup):
@@ -175,7 +179,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

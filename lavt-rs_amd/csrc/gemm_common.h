@@ -63,12 +63,23 @@ __device__ __forceinline__ float apply_act(int act, float v) {
 // ---- implicit-GEMM convolution geometry (2-D 3x3 and the 3-D kernels of SepTPWAM) ---------------------------------------
 struct ConvGeom {
     int d, h, w, kd, kh, kw, taps, vox;     // vox = d*h*w voxels per sample
+    float inv_vox, inv_hw, inv_w;           // reciprocals for fdiv()
 };
+// n / d for 0 <= n < 2^23 with a precomputed float reciprocal: one multiply + a +-1 fix-up instead of the ~35-instruction
+// exact integer division sequence (these sit in the K loops of the conv kernels, once per DMA instruction per K tile)
+__device__ __forceinline__ int fdiv(int n, int d, float inv) {
+    int q = (int)((float)n * inv);
+    const int r = n - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
 template <typename P> __device__ __forceinline__ ConvGeom conv_geom(const P& p) {
     ConvGeom g;
     g.kh = p.conv_kh > 0 ? p.conv_kh : 3; g.kw = p.conv_kw > 0 ? p.conv_kw : 3; g.kd = p.conv_kd > 0 ? p.conv_kd : 1;
     g.d = p.conv_d > 0 ? p.conv_d : 1; g.h = p.conv_h; g.w = p.conv_w;
     g.taps = g.kd * g.kh * g.kw; g.vox = g.d * g.h * g.w;
+    g.inv_vox = 1.0f / (float)(g.vox > 0 ? g.vox : 1); g.inv_hw = 1.0f / (float)(g.h * g.w > 0 ? g.h * g.w : 1); g.inv_w = 1.0f / (float)(g.w > 0 ? g.w : 1);
     return g;
 }
 __device__ __forceinline__ void conv_tap(const ConvGeom& g, int tap, int& dz, int& dy, int& dx) {
@@ -76,12 +87,21 @@ __device__ __forceinline__ void conv_tap(const ConvGeom& g, int tap, int& dz, in
     dy = (tap / g.kw) % g.kh - (g.kh >> 1);
     dz = tap / (g.kw * g.kh) - (g.kd >> 1);
 }
+// (z, y, x) of voxel row `src` >= 0 inside its sample
+__device__ __forceinline__ void conv_coords(const ConvGeom& g, int src, int& z, int& y, int& x) {
+    const int pix = src - fdiv(src, g.vox, g.inv_vox) * g.vox;
+    z = fdiv(pix, g.h * g.w, g.inv_hw);
+    const int rem = pix - z * g.h * g.w;
+    y = fdiv(rem, g.w, g.inv_w);
+    x = rem - y * g.w;
+}
 // source row of the (dz,dy,dx) neighbour of voxel row `src` (-1 outside the zero-padded volume or if src < 0)
 __device__ __forceinline__ int conv_nbr(const ConvGeom& g, int src, int dz, int dy, int dx) {
     if (src < 0) return -1;
-    const int pix = src % g.vox;
-    const int z = pix / (g.h * g.w) + dz, y = (pix / g.w) % g.h + dy, x = pix % g.w + dx;
-    return (z >= 0 && z < g.d && y >= 0 && y < g.h && x >= 0 && x < g.w) ? src + (dz * g.h + dy) * g.w + dx : -1;
+    int z, y, x;
+    conv_coords(g, src, z, y, x);
+    z += dz; y += dy; x += dx;
+    return ((unsigned)z < (unsigned)g.d && (unsigned)y < (unsigned)g.h && (unsigned)x < (unsigned)g.w) ? src + (dz * g.h + dy) * g.w + dx : -1;
 }
 
 // ---- XCD-aware workgroup -> tile order ----------------------------------------------------------------------------

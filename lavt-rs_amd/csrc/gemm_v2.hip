@@ -83,8 +83,15 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
 }
 
-template <int BM, int BN, bool BKM, int STAGES, int WAVES>
+// SIMPLE = no conv taps, no concat source, K % 64 == 0: every lane's DMA source is a fixed pointer that advances by a constant per K tile,
+// so the K loop carries ~3 instructions per DMA instead of the general path's address arithmetic (which made small GEMMs issue-bound:
+// ~220 VALU/SALU instructions per K tile on the one wave a SIMD holds, measured 0.78 us per K tile at M=2592, N=512).
+// MODE 2 = convolution taps with Cin (and the concat split) a multiple of the 64-wide K tile: the tap of a K tile is wave-uniform and walks
+// forward with the K loop (no division), the lanes' voxel coordinates are computed once, so a neighbour fetch is three range checks and one
+// address add.  MODE 0 (anything else) decodes every K tile from scratch.
+template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE>
 __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_nt_t p) {
+    constexpr bool SIMPLE = MODE == 1, CONVFAST = MODE == 2;
     using T = bf16;
     constexpr int BK = 64, EPC = 8;
     constexpr int WAVES_N = WAVES / 2;                       // wave grid: 2 (M) x WAVES/2 (N)
@@ -144,7 +151,98 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         }
     }
 
+    // SIMPLE: per-lane running pointers (invalid rows / columns point at the zero page with step 0)
+    const T* a_ptr[A_INSTR];
+    const T* b_ptr[B_INSTR];
+    int64_t b_step[B_INSTR];
+    int a_step[A_INSTR];
+    if constexpr (SIMPLE) {
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            a_ptr[i] = a_src[i] >= 0 ? A + (int64_t)a_src[i] * p.lda + cl * EPC : Z;
+            a_step[i] = a_src[i] >= 0 ? BK : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            if constexpr (!BKM) {
+                b_ptr[i] = b_row[i] >= 0 ? B + (int64_t)b_row[i] * p.ldb + cl * EPC : Z;
+                b_step[i] = b_row[i] >= 0 ? BK : 0;
+            } else {
+                b_ptr[i] = b_row[i] >= 0 ? B + (int64_t)b_row[i] * p.ldb + b_col[i] : Z;
+                b_step[i] = b_row[i] >= 0 ? (int64_t)BK * p.ldb : 0;
+            }
+        }
+    }
+    auto issue_simple = [&](int stage) {
+        char* sbase = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            dma16(a_ptr[i], sbase + (wave * A_INSTR + i) * 1024);
+            a_ptr[i] += a_step[i];
+        }
+        char* sb = sbase + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            dma16(b_ptr[i], sb + (wave * B_INSTR + i) * 1024);
+            b_ptr[i] += b_step[i];
+        }
+    };
+    // CONVFAST: lane coordinates (invalid rows sit far outside the volume), running tap cursor, per-lane constant parts of the B address
+    int a_z[A_INSTR], a_y[A_INSTR], a_x[A_INSTR];
+    int64_t b_lane_off[B_INSTR];
+    int c_kin = 0, c_tap = 0, c_dz = 0, c_dy = 0, c_dx = 0;
+    if constexpr (CONVFAST) {
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            a_z[i] = a_y[i] = a_x[i] = -(1 << 20);
+            if (a_src[i] >= 0) conv_coords(cg, a_src[i], a_z[i], a_y[i], a_x[i]);
+        }
+        conv_tap(cg, 0, c_dz, c_dy, c_dx);
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            if constexpr (!BKM) {
+                b_ptr[i] = b_row[i] >= 0 ? B + (int64_t)b_row[i] * p.ldb + cl * EPC : Z;
+                b_step[i] = b_row[i] >= 0 ? BK : 0;
+            } else {
+                b_lane_off[i] = b_row[i] >= 0 ? (int64_t)b_row[i] * p.ldb + b_col[i] : -1;
+            }
+        }
+    }
+    auto issue_conv = [&](int stage) {
+        char* sbase = smem + stage * STAGE_BYTES;
+        const int dz = p.conv_flip ? -c_dz : c_dz, dy = p.conv_flip ? -c_dy : c_dy, dx = p.conv_flip ? -c_dx : c_dx;
+        const int delta = (dz * cg.h + dy) * cg.w + dx;
+        const bool second = (p.A2 != nullptr) && c_kin >= p.a_split;                 // wave-uniform: a_split % 64 == 0
+        const T* base = (second ? A2 + (c_kin - p.a_split) : A + c_kin) + cl * EPC;
+        const int64_t ld = second ? p.lda2 : p.lda;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int z = a_z[i] + dz, y = a_y[i] + dy, x = a_x[i] + dx;
+            const bool ok = (unsigned)z < (unsigned)cg.d && (unsigned)y < (unsigned)cg.h && (unsigned)x < (unsigned)cg.w;
+            dma16(ok ? base + (int64_t)(a_src[i] + delta) * ld : Z, sbase + (wave * A_INSTR + i) * 1024);
+        }
+        char* sb = sbase + A_BYTES;
+        if constexpr (!BKM) {
+#pragma unroll
+            for (int i = 0; i < B_INSTR; ++i) {
+                dma16(b_ptr[i], sb + (wave * B_INSTR + i) * 1024);
+                b_ptr[i] += b_step[i];
+            }
+        } else {
+            const T* bb = B + (int64_t)c_kin * p.ldb + (int64_t)c_tap * p.b_tap_stride;
+#pragma unroll
+            for (int i = 0; i < B_INSTR; ++i) dma16(b_lane_off[i] >= 0 ? bb + b_lane_off[i] : Z, sb + (wave * B_INSTR + i) * 1024);
+        }
+        // advance the cursor to the next K tile
+        c_kin += BK;
+        if (c_kin >= p.conv_kc) {
+            c_kin = 0; ++c_tap;
+            if (++c_dx > (cg.kw >> 1)) { c_dx = -(cg.kw >> 1); if (++c_dy > (cg.kh >> 1)) { c_dy = -(cg.kh >> 1); ++c_dz; } }
+        }
+    };
     auto issue = [&](int kt, int stage) {
+        if constexpr (SIMPLE) { issue_simple(stage); return; }
+        if constexpr (CONVFAST) { issue_conv(stage); return; }
         char* sbase = smem + stage * STAGE_BYTES;
         // A
         const int k = kt * BK + cl * EPC;
@@ -235,21 +333,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         nt_epilogue_lds<BM, BN, MI, NI>(p, acc, reinterpret_cast<bf16*>(smem), m0, n0, wm * WM, wn * WN, tid, lane, bz);
 }
 
-template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
+template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE> int launch_nt_v2_(const lavt_gemm_nt_t& p, hipStream_t st) {
     constexpr int B_INSTR = BKM ? (64 * ((BN + KM_PAD) / 8) + 64 * WAVES - 1) / (64 * WAVES) : BN / (8 * WAVES);
     constexpr size_t lds = STAGES * (size_t)(BM * 128 + (BKM ? B_INSTR * WAVES * 1024 : BN * 128));
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             lavt_set_error("lavt_gemm_nt(v2): cannot reserve %zu bytes of LDS", lds);
             return LAVT_ERR_LAUNCH;
         }
         attr_set = true;
     }
     dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch);
-    hipLaunchKernelGGL((gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES>), grid, dim3(WAVES * 64), lds, st, p);
+    hipLaunchKernelGGL((gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE>), grid, dim3(WAVES * 64), lds, st, p);
     LAVT_CHECK_LAUNCH("lavt_gemm_nt(v2)");
     return LAVT_OK;
+}
+template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
+    static const bool general_only = getenv("LAVT_GEMM_GENERAL") != nullptr;
+    const bool simple = p.conv_kc <= 0 && p.A2 == nullptr && p.K % 64 == 0;
+    const bool convfast = p.conv_kc > 0 && p.conv_kc % 64 == 0 && (p.A2 == nullptr || p.a_split % 64 == 0);
+    if (simple && !general_only) return launch_nt_v2_<BM, BN, BKM, STAGES, WAVES, 1>(p, st);
+    if (convfast && !general_only) return launch_nt_v2_<BM, BN, BKM, STAGES, WAVES, 2>(p, st);
+    return launch_nt_v2_<BM, BN, BKM, STAGES, WAVES, 0>(p, st);
 }
 
 
@@ -310,36 +416,41 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
         b_ld[i] = second ? p.ldb2 : p.ldb;
         b_dz[i] = dz; b_dy[i] = dy; b_dx[i] = dx;
     }
-    // source rows of the NEXT tile to issue are fetched one iteration ahead so the map loads never sit between a DMA and its wait
-    int a_src[A_INSTR], b_src[B_INSTR];
+    // Source rows of the NEXT tile to issue are fetched one iteration ahead: the raw map / mask values are only LOADED here (clamped
+    // addresses, no dependent use) and turned into row indices inside issue(), after the loop-top wait -- so the loads overlap the
+    // MFMAs of the current tile instead of stalling in front of them.
+    int a_raw[A_INSTR], b_raw[B_INSTR];
+    float a_rs[A_INSTR];
+    bool a_ok[A_INSTR], b_ok[B_INSTR];
+    const float inv_rsdiv = 1.0f / (float)(p.a_rowscale_div > 1 ? p.a_rowscale_div : 1);
     auto fetch_rows = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
             const int k = kt * BK + a_kr[i];
-            int src = -1;
-            if (a_kr[i] >= 0 && k < p.K) {
-                src = p.a_rowmap ? p.a_rowmap[k] : k;
-                if (p.a_rowscale && p.a_rowscale[p.a_rowscale_div > 1 ? k / p.a_rowscale_div : k] == 0.f) src = -1;
-            }
-            a_src[i] = src;
+            a_ok[i] = a_kr[i] >= 0 && k < p.K;
+            const int kc = a_ok[i] ? k : 0;
+            a_raw[i] = p.a_rowmap ? p.a_rowmap[kc] : kc;
+            a_rs[i] = p.a_rowscale ? p.a_rowscale[p.a_rowscale_div > 1 ? fdiv(kc, p.a_rowscale_div, inv_rsdiv) : kc] : 1.f;
         }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
             const int k = kt * BK + b_kr[i];
-            int src = -1;
-            if (b_kr[i] >= 0 && k < p.K) src = p.b_rowmap ? p.b_rowmap[k] : k;
-            b_src[i] = src;
+            b_ok[i] = b_kr[i] >= 0 && k < p.K;
+            const int kc = b_ok[i] ? k : 0;
+            b_raw[i] = p.b_rowmap ? p.b_rowmap[kc] : kc;
         }
     };
     auto issue = [&](int stage) {
         char* sa = smem + stage * STAGE_BYTES;
         char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_INSTR; ++i)
-            dma16(a_src[i] >= 0 ? A + (int64_t)a_src[i] * p.lda + a_col[i] : Z, sa + (wave * A_INSTR + i) * 1024);
+        for (int i = 0; i < A_INSTR; ++i) {
+            const bool ok = a_ok[i] && a_rs[i] != 0.f && a_raw[i] >= 0;
+            dma16(ok ? A + (int64_t)a_raw[i] * p.lda + a_col[i] : Z, sa + (wave * A_INSTR + i) * 1024);
+        }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            int src = b_src[i];
+            int src = b_ok[i] ? b_raw[i] : -1;
             if (conv) src = conv_nbr(cg, src, b_dz[i], b_dy[i], b_dx[i]);
             dma16(src >= 0 ? b_base[i] + (int64_t)src * b_ld[i] : Z, sb + (wave * B_INSTR + i) * 1024);
         }

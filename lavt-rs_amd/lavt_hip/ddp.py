@@ -16,10 +16,14 @@ Replaces `torch.nn.parallel.DistributedDataParallel(model, find_unused_parameter
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of 475 MB fp32 (Swin-B) is ~5 ms, comparable
 to the backward itself at batch 2/GPU, hence large buckets (default 64 MiB: few, large collectives) and overlap.
 """
+import os
 from typing import List, Optional
 
 import torch
 import torch.distributed as dist
+
+# LAVT_FORCE_COLLECTIVES=1: issue the collectives even in a 1-rank group (exercises the RCCL / stream plumbing on a 1-GPU box)
+FORCE_COLLECTIVES = os.environ.get("LAVT_FORCE_COLLECTIVES", "0") == "1"
 
 
 class GradBuckets:
@@ -98,7 +102,7 @@ class GradBuckets:
 
     def _launch(self, b):
         self.launched[b] = True
-        if self.world == 1:
+        if self.world == 1 and not (FORCE_COLLECTIVES and dist.is_initialized()):
             return
         s, e = self.buckets[b]
         chunk = self.flat[s:e]
@@ -126,7 +130,7 @@ class GradBuckets:
                 w[1].div_(self.world)
             else:
                 w.wait()
-        if self.comm_stream is not None and self.world > 1:
+        if self.comm_stream is not None and (self.world > 1 or FORCE_COLLECTIVES):
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.works = []
 

@@ -619,7 +619,8 @@ def batch_norm_relu(x, bn: torch.nn.modules.batchnorm._BatchNorm):
     group = None
     if isinstance(bn, torch.nn.SyncBatchNorm) and bn.training and dist.is_available() and dist.is_initialized():
         group = bn.process_group if bn.process_group is not None else dist.group.WORLD
-        if dist.get_world_size(group) == 1:
+        from .ddp import FORCE_COLLECTIVES
+        if dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES:
             group = None
     training = bn.training or bn.running_mean is None
     if training and bn.num_batches_tracked is not None:
