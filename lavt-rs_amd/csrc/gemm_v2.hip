@@ -360,10 +360,27 @@ template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(cons
 
 
 // ================================================================================================ TN (weight gradients)
-// C[I,J] (+)= alpha * sum_k A[k][i] B[k][j]; both operands k-major: LDS tiles [64 k][cols+16] filled by LDS-DMA (2-stage ring),
-// every fragment read with the transposing LDS read (asm, one statement per operand per K tile).  Row masks (DropPath /
-// language mask of the forward) are honoured by fetching masked rows from the zero page; their common non-zero value is in alpha.
-template <int BI, int BJ, int WAVES>
+// C[I,J] (+)= alpha * sum_k A[k][i] B[k][j]; both operands k-major: LDS tiles [64 k][cols+16] filled by LDS-DMA through a STAGES-deep
+// ring, every fragment read with the transposing LDS read (asm, one statement per operand per K tile).  The operands stream from HBM
+// (every K tile is new data), so one tile in flight leaves the full HBM latency exposed per K tile (measured 0.9 us with the 2-stage
+// ring); with S stages S-2 further tiles stay in flight across the loop-top wait.
+//
+// Row maps (window order <-> token order) and the DropPath / language row mask are per-K-row side inputs.  A register load of them
+// would have to be the YOUNGEST outstanding vector-memory op when it is needed, and vmcnt retires in order -- waiting for it drains the
+// whole ring.  So (MAPS = true) they travel through LDS as well: a 4-byte-per-lane DMA per wave per K tile, issued 2(S-1) tiles ahead
+// into an 8-slot ring, read back with ds_read when the tile's row addresses are formed.  Every wave issues the same number of
+// vector-memory ops per tile (ND tile DMAs + 1 map DMA), which is what makes the counted waits valid.
+template <int G> __device__ __forceinline__ void wait_groups(int g) {      // leave g groups of G vector-memory ops in flight
+    if (g <= 0) wait_vmcnt<0>();
+    else if (g == 1) wait_vmcnt<G>();
+    else if (g == 2) wait_vmcnt<2 * G>();
+    else wait_vmcnt<3 * G>();
+}
+__device__ __forceinline__ void dma4(const void* src, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 4, 0, 0);
+}
+
+template <int BI, int BJ, int WAVES, int STAGES, bool MAPS>
 __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_tn_t p, int kt_per_split) {
     using T = bf16;
     constexpr int BK = 64, EPC = 8;
@@ -372,9 +389,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
     constexpr int A_INSTR = (BK * A_CH + 64 * WAVES - 1) / (64 * WAVES), B_INSTR = (BK * B_CH + 64 * WAVES - 1) / (64 * WAVES);
     constexpr int A_BYTES = A_INSTR * WAVES * 1024, B_BYTES = B_INSTR * WAVES * 1024, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int WI = BI / 2, WJ = BJ / WAVES_J, II = WI / 16, JJ = WJ / 16;
+    constexpr int G = A_INSTR + B_INSTR + (MAPS ? 1 : 0);              // vector-memory ops per wave per K tile
+    constexpr int AHEAD = 2 * (STAGES - 1);                              // map DMA runs this many tiles ahead of the compute
+    constexpr int NSLOT = AHEAD + 1, SLOT_BYTES = 768;                   // map ring: [slot][a_map | a_rowscale | b_map][64] (+ one 256 B spare for waves >= 3)
     static_assert((II == 2 || II == 4) && (JJ == 2 || JJ == 4), "fragment counts");
+    static_assert(STAGES >= 2 && STAGES <= 4 && 3 * G <= 63, "pipeline depth");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const maps = smem + STAGES * STAGE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave / WAVES_J, wj = wave % WAVES_J;
     const int tiles_j = (p.J + BJ - 1) / BJ;
@@ -384,6 +406,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
     const int ktiles = (p.K + BK - 1) / BK;
     const int kt_begin = blockIdx.z * kt_per_split, kt_end = min(ktiles, kt_begin + kt_per_split);
     if (kt_begin >= kt_end) return;
+    const int n = kt_end - kt_begin;
 
     const T* A = reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.strideA;
     const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.strideB;
@@ -416,41 +439,52 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
         b_ld[i] = second ? p.ldb2 : p.ldb;
         b_dz[i] = dz; b_dy[i] = dy; b_dx[i] = dx;
     }
-    // Source rows of the NEXT tile to issue are fetched one iteration ahead: the raw map / mask values are only LOADED here (clamped
-    // addresses, no dependent use) and turned into row indices inside issue(), after the loop-top wait -- so the loads overlap the
-    // MFMAs of the current tile instead of stalling in front of them.
-    int a_raw[A_INSTR], b_raw[B_INSTR];
-    float a_rs[A_INSTR];
-    bool a_ok[A_INSTR], b_ok[B_INSTR];
+
+    // ---- side inputs of tile t (relative to kt_begin) -> map ring slot t % NSLOT: wave 0 a_rowmap, 1 a_rowscale, 2 b_rowmap, others spare
     const float inv_rsdiv = 1.0f / (float)(p.a_rowscale_div > 1 ? p.a_rowscale_div : 1);
-    auto fetch_rows = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) {
-            const int k = kt * BK + a_kr[i];
-            a_ok[i] = a_kr[i] >= 0 && k < p.K;
-            const int kc = a_ok[i] ? k : 0;
-            a_raw[i] = p.a_rowmap ? p.a_rowmap[kc] : kc;
-            a_rs[i] = p.a_rowscale ? p.a_rowscale[p.a_rowscale_div > 1 ? fdiv(kc, p.a_rowscale_div, inv_rsdiv) : kc] : 1.f;
-        }
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            const int k = kt * BK + b_kr[i];
-            b_ok[i] = b_kr[i] >= 0 && k < p.K;
-            const int kc = b_ok[i] ? k : 0;
-            b_raw[i] = p.b_rowmap ? p.b_rowmap[kc] : kc;
+    auto map_dma = [&](int t) {
+        if constexpr (MAPS) {
+            int k = (kt_begin + t) * BK + lane;
+            k = k < p.K ? k : p.K - 1;
+            const void* src = Z;
+            if (wave == 0 && p.a_rowmap) src = p.a_rowmap + k;
+            if (wave == 1 && p.a_rowscale) src = p.a_rowscale + (p.a_rowscale_div > 1 ? fdiv(k, p.a_rowscale_div, inv_rsdiv) : k);
+            if (wave == 2 && p.b_rowmap) src = p.b_rowmap + k;
+            dma4(src, wave < 3 ? maps + (t % NSLOT) * SLOT_BYTES + wave * 256 : maps + NSLOT * SLOT_BYTES);
         }
     };
-    auto issue = [&](int stage) {
-        char* sa = smem + stage * STAGE_BYTES;
+    auto issue = [&](int t) {
+        char* sa = smem + (t % STAGES) * STAGE_BYTES;
         char* sb = sa + A_BYTES;
+        const int kbase = (kt_begin + t) * BK;
+        const int* m_a = reinterpret_cast<const int*>(maps + (t % NSLOT) * SLOT_BYTES);
+        const float* m_rs = reinterpret_cast<const float*>(maps + (t % NSLOT) * SLOT_BYTES + 256);
+        const int* m_b = reinterpret_cast<const int*>(maps + (t % NSLOT) * SLOT_BYTES + 512);
+        int a_src[A_INSTR], b_src[B_INSTR];
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
-            const bool ok = a_ok[i] && a_rs[i] != 0.f && a_raw[i] >= 0;
-            dma16(ok ? A + (int64_t)a_raw[i] * p.lda + a_col[i] : Z, sa + (wave * A_INSTR + i) * 1024);
+            const int kr = a_kr[i] >= 0 ? a_kr[i] : 0, k = kbase + kr;
+            int src = k;
+            bool ok = a_kr[i] >= 0 && k < p.K;
+            if constexpr (MAPS) {
+                if (p.a_rowmap) src = m_a[kr];
+                if (p.a_rowscale) ok = ok && m_rs[kr] != 0.f;
+            }
+            a_src[i] = (ok && src >= 0) ? src : -1;
         }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            int src = b_ok[i] ? b_raw[i] : -1;
+            const int kr = b_kr[i] >= 0 ? b_kr[i] : 0, k = kbase + kr;
+            int src = k;
+            if constexpr (MAPS) { if (p.b_rowmap) src = m_b[kr]; }
+            b_src[i] = (b_kr[i] >= 0 && k < p.K) ? src : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i)
+            dma16(a_src[i] >= 0 ? A + (int64_t)a_src[i] * p.lda + a_col[i] : Z, sa + (wave * A_INSTR + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            int src = b_src[i];
             if (conv) src = conv_nbr(cg, src, b_dz[i], b_dy[i], b_dx[i]);
             dma16(src >= 0 ? b_base[i] + (int64_t)src * b_ld[i] : Z, sb + (wave * B_INSTR + i) * 1024);
         }
@@ -464,18 +498,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
     float csum = 0.f;
     const bool do_colsum = (p.colsum != nullptr) && tile_j == 0 && tid < BI;
 
-    fetch_rows(kt_begin);
-    issue(0);
-    if (kt_begin + 1 < kt_end) fetch_rows(kt_begin + 1);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
+    // prologue: side inputs of the first AHEAD tiles, then the first STAGES-1 data tiles (each followed by one map DMA: uniform groups)
+    if constexpr (MAPS) {
+        for (int t = 0; t < AHEAD; ++t) map_dma(t);
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < kt_end) {
-            issue(cur ^ 1);
-            if (kt + 2 < kt_end) fetch_rows(kt + 2);
-        }
-        const char* cA = smem + cur * STAGE_BYTES;
+    }
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < n) { issue(t); map_dma(t + AHEAD); }
+
+    for (int j = 0; j < n; ++j) {
+        wait_groups<G>(min(STAGES - 2, n - 1 - j));
+        __builtin_amdgcn_s_barrier();
+        if (j + STAGES - 1 < n) { issue(j + STAGES - 1); map_dma(j + STAGES - 1 + AHEAD); }
+        const char* cA = smem + (j % STAGES) * STAGE_BYTES;
         const char* cB = cA + A_BYTES;
         const unsigned row_off = (unsigned)((8 * (lane >> 4) + ((lane & 15) >> 2)));
         const unsigned aA = lds_addr(cA) + (row_off * A_LD + wi * WI + 4 * (lane & 3)) * 2;
@@ -486,9 +522,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
 #pragma unroll
         for (int i = 0; i < II; ++i)
 #pragma unroll
-            for (int j = 0; j < JJ; ++j) {
-                acc[i][j] = mfma16<T>(frag_from(al0[i], ah0[i]), frag_from(bl0[j], bh0[j]), acc[i][j]);
-                acc[i][j] = mfma16<T>(frag_from(al1[i], ah1[i]), frag_from(bl1[j], bh1[j]), acc[i][j]);
+            for (int jj = 0; jj < JJ; ++jj) {
+                acc[i][jj] = mfma16<T>(frag_from(al0[i], ah0[i]), frag_from(bl0[jj], bh0[jj]), acc[i][jj]);
+                acc[i][jj] = mfma16<T>(frag_from(al1[i], ah1[i]), frag_from(bl1[jj], bh1[jj]), acc[i][jj]);
             }
         if (do_colsum) {
             const T* col = reinterpret_cast<const T*>(cA) + tid;
@@ -519,13 +555,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
     if (do_colsum && i0 + tid < p.I) atomicAdd(p.colsum + (int64_t)bz * p.strideColsum + i0 + tid, csum * p.alpha);
 }
 
-template <int BI, int BJ, int WAVES> int launch_tn_v2(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
+template <int BI, int BJ, int WAVES, int STAGES, bool MAPS> int launch_tn_v2_(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
     constexpr int A_CH = (BI + KM_PAD) / 8, B_CH = (BJ + KM_PAD) / 8;
     constexpr int A_INSTR = (64 * A_CH + 64 * WAVES - 1) / (64 * WAVES), B_INSTR = (64 * B_CH + 64 * WAVES - 1) / (64 * WAVES);
-    constexpr size_t lds = 2 * (size_t)(A_INSTR + B_INSTR) * WAVES * 1024;
+    constexpr size_t lds = STAGES * (size_t)(A_INSTR + B_INSTR) * WAVES * 1024 + (MAPS ? (2 * (STAGES - 1) + 1) * 768 + 256 : 0);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_kernel<BI, BJ, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             lavt_set_error("lavt_gemm_tn(v2): cannot reserve %zu bytes of LDS", lds);
             return LAVT_ERR_LAUNCH;
         }
@@ -534,9 +570,15 @@ template <int BI, int BJ, int WAVES> int launch_tn_v2(const lavt_gemm_tn_t& p, i
     const int ktiles = cdiv(p.K, 64);
     const int per = cdiv(ktiles, split);
     dim3 grid(cdiv(p.I, BI) * cdiv(p.J, BJ), p.batch, cdiv(ktiles, per));
-    hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES>), grid, dim3(WAVES * 64), lds, st, p, per);
+    hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS>), grid, dim3(WAVES * 64), lds, st, p, per);
     LAVT_CHECK_LAUNCH("lavt_gemm_tn(v2)");
     return LAVT_OK;
+}
+template <int BI, int BJ, int WAVES> int launch_tn_v2(const lavt_gemm_tn_t& p, int split, int stages, hipStream_t st) {
+    const bool maps = p.a_rowmap || p.a_rowscale || p.b_rowmap;
+    if (stages <= 2) return maps ? launch_tn_v2_<BI, BJ, WAVES, 2, true>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 2, false>(p, split, st);
+    if (stages == 3) return maps ? launch_tn_v2_<BI, BJ, WAVES, 3, true>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 3, false>(p, split, st);
+    return maps ? launch_tn_v2_<BI, BJ, WAVES, 4, true>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 4, false>(p, split, st);
 }
 
 }  // namespace
@@ -598,6 +640,8 @@ int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st) {
         if (split < 1) split = 1;
     }
     if (split > ktiles) split = ktiles;
-    if (big) return launch_tn_v2<128, 128, 8>(p, split, st);
-    return launch_tn_v2<64, 64, 4>(p, split, st);
+    const char* sg = getenv("LAVT_TN_STAGES");
+    const int stages = sg ? atoi(sg) : 2;          // measured: 3 stages cost a resident workgroup per CU and lose end to end
+    if (big) return launch_tn_v2<128, 128, 8>(p, split, stages > 3 ? 3 : stages, st);
+    return launch_tn_v2<64, 64, 4>(p, split, stages, st);
 }
