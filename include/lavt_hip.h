@@ -154,13 +154,19 @@ int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);
  * of 16 -- 64 for 7x7, 160 for 12x12 windows -- lets the bf16 MFMA kernels run; padding columns hold -1e30).  region: optional int8
  * [nw_img][N] region ids of the shift mask (window w uses row w % nw_img); unequal ids add -100.
  * lse: fp32 [nwin][heads][N] log-sum-exp of each score row (saved for backward).
- * Backward: dqkv [nwin*N][3C] (every element written), dbias fp32 [heads][N][bias_ld] accumulated with atomics.
+ * Backward: dqkv [nwin*N][3C] (every element written); dbias fp32 [heads][N][bias_ld] accumulates the dense relative-position-bias
+ *   gradient (reduce it to the table with lavt_relpos_reduce).  Optional accelerators for the bf16 MFMA kernel (all or none):
+ *   table = relative_position_bias_table fp32 [(2wd-1)(2wh-1)(2ww-1)][heads] with the FULL window shape (wd, wh, ww) (wd = 1 for the 2-D
+ *   Swin; the kernel keeps the head's table column in LDS instead of reading the dense bias), and ws = fp32 scratch of
+ *   >= nwin*heads*N*bias_ld floats (each (window, head) writes its dS slab with plain stores; a second kernel sums the slabs into dbias:
+ *   no atomics, deterministic).  Without them the exact-fp32 formulation with global atomics runs.
  * ------------------------------------------------------------------------------------------- */
 int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out,
                          float* lse, int nwin, int N, int heads, int head_dim, float scale, void* stream);
 int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img,
-                         const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int nwin, int N,
-                         int heads, int head_dim, float scale, void* stream);
+                         const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, const float* table,
+                         float* ws, int64_t ws_floats, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim, float scale,
+                         void* stream);
 
 /* relative_position_bias_table[(2wd-1)(2wh-1)(2ww-1)][heads] -> dense bias[heads][N][ld]   (wd = 1 for the 2-D Swin; N <= wd*wh*ww tokens) (lib/backbone.py:89-103,125-127)
  * and its transpose (dense gradient -> table gradient, deterministic, accumulates into dtable). */

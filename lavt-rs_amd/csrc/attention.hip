@@ -90,12 +90,21 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const T* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+// relative position bias: table[(2wd-1)(2wh-1)(2ww-1)][heads] <-> dense[heads][N][ld]   (wd = 1: the 2-D Swin table).
+// Token i of an N-token window has the coordinates of token i of the FULL (wd,wh,ww) window -- this reproduces the
+// reference's `relative_position_index[:N, :N]` slice for clipped video windows (lib/video_swin_transformer.py:150).
+__device__ __forceinline__ int relpos_index(int i, int j, int wd, int wh, int ww) {
+    const int di = i / (wh * ww), hi = (i / ww) % wh, wi = i % ww;
+    const int dj = j / (wh * ww), hj = (j / ww) % wh, wj = j % ww;
+    return ((di - dj + wd - 1) * (2 * wh - 1) + (hi - hj + wh - 1)) * (2 * ww - 1) + (wi - wj + ww - 1);
+}
 template <typename T, int NJ>
 __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
                                                               const int8_t* __restrict__ region, int nw_img,
                                                               const T* __restrict__ out, const T* __restrict__ dout,
                                                               const float* __restrict__ lse, T* __restrict__ dqkv,
-                                                              float* __restrict__ dbias, int N, int heads, float scale, int bias_ld) {
+                                                              float* __restrict__ dbias, int N, int heads, float scale, int bias_ld,
+                                                              float* __restrict__ dtable, int wd, int wh, int ww) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* Ks = reinterpret_cast<float*>(smem_raw);
     float* Vs = Ks + N * KV_LD;
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
     __syncthreads();
     const int8_t* reg = region ? region + (int64_t)(w % nw_img) * N : nullptr;
     const float* bh = bias + (int64_t)h * N * bias_ld;
-    float* dbh = dbias + (int64_t)h * N * bias_ld;
+    float* dbh = dbias ? dbias + (int64_t)h * N * bias_ld : nullptr;
     float* dS = Sw + wave * NJ * 64;
     float* dOr = Dw + wave * HD;
 
@@ -154,7 +163,8 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
                 if (rid_j[t] != rid_i) a += -100.0f;
                 const float pj = __expf(a - l);
                 ds = pj * (dp - dl);
-                atomicAdd(dbh + (int64_t)i * bias_ld + j, ds);
+                if (dtable) atomicAdd(dtable + (int64_t)relpos_index(i, j, wd, wh, ww) * heads + h, ds);      // parity path: plain global atomics
+                else atomicAdd(dbh + (int64_t)i * bias_ld + j, ds);
 #pragma unroll
                 for (int d = 0; d < HD; ++d) {
                     dv[t][d] = fmaf(pj, dOr[d], dv[t][d]);
@@ -193,14 +203,6 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
     }
 }
 
-// relative position bias: table[(2wd-1)(2wh-1)(2ww-1)][heads] <-> dense[heads][N][ld]   (wd = 1: the 2-D Swin table).
-// Token i of an N-token window has the coordinates of token i of the FULL (wd,wh,ww) window -- this reproduces the
-// reference's `relative_position_index[:N, :N]` slice for clipped video windows (lib/video_swin_transformer.py:150).
-__device__ __forceinline__ int relpos_index(int i, int j, int wd, int wh, int ww) {
-    const int di = i / (wh * ww), hi = (i / ww) % wh, wi = i % ww;
-    const int dj = j / (wh * ww), hj = (j / ww) % wh, wj = j % ww;
-    return ((di - dj + wd - 1) * (2 * wh - 1) + (hi - hj + wh - 1)) * (2 * ww - 1) + (wi - wj + ww - 1);
-}
 __global__ void relpos_expand_kernel(const float* __restrict__ table, float* __restrict__ dense, int wd, int wh, int ww, int N, int heads, int ld) {
     const int64_t total = (int64_t)heads * N * ld;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -302,13 +304,13 @@ int launch_fwd(const void* qkv, const float* bias, int bias_ld, const int8_t* re
 }
 template <typename T>
 int launch_bwd(const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, const void* out, const void* dout,
-               const float* lse, void* dqkv, float* dbias, int nwin, int N, int heads, float scale, hipStream_t st) {
+               const float* lse, void* dqkv, float* dbias, float* dtable, int wd, int wh, int ww, int nwin, int N, int heads, float scale, hipStream_t st) {
     const int NJ = (N + 63) / 64;
     const size_t lds = (size_t)(5 * N * KV_LD + 4 * NJ * 64 + 4 * HD) * sizeof(float);
     dim3 grid(nwin * heads);
 #define L(NJ_)                                                                                                              \
     hipLaunchKernelGGL((window_attn_bwd_kernel<T, NJ_>), grid, dim3(256), lds, st, (const T*)qkv, bias, region, nw_img, \
-                       (const T*)out, (const T*)dout, lse, (T*)dqkv, dbias, N, heads, scale, bias_ld)
+                       (const T*)out, (const T*)dout, lse, (T*)dqkv, dbias, N, heads, scale, bias_ld, dtable, wd, wh, ww)
     if (NJ == 1) L(1); else if (NJ == 2) L(2); else if (NJ == 3) L(3); else { lavt_set_error("lavt_window_attn_bwd: N=%d > 192 not supported by this kernel", N); return LAVT_ERR_INVALID; }
 #undef L
     LAVT_CHECK_LAUNCH("lavt_window_attn_bwd");
@@ -319,9 +321,9 @@ int launch_bwd(const void* qkv, const float* bias, int bias_ld, const int8_t* re
 
 int lavt_window_attn_fwd_mfma(const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out, float* lse,
                               int nwin, int N, int heads, float scale, hipStream_t st);
-int lavt_window_attn_bwd_mfma(const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, const void* out,
-                              const void* dout, const float* lse, void* dqkv, float* dbias, int nwin, int N, int heads, float scale,
-                              hipStream_t st);
+int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, const void* out, const void* dout,
+                              const float* lse, void* dqkv, float* dbias, int bias_ld, float* ws, int wd, int wh, int ww, int nwin, int N,
+                              int heads, float scale, hipStream_t st);
 // LAVT_ATTN_SIMPLE=1 forces the VALU formulation for bf16 too (A/B tests of the MFMA kernels)
 static bool use_mfma(int dtype, int N, int bias_ld) {
     const char* e = getenv("LAVT_ATTN_SIMPLE");
@@ -342,14 +344,18 @@ extern "C" int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bia
 }
 
 extern "C" int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img,
-                                    const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int nwin,
-                                    int N, int heads, int head_dim, float scale, void* stream) {
+                                    const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, const float* table,
+                                    float* ws, int64_t ws_floats, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim,
+                                    float scale, void* stream) {
     LAVT_CHECK_ARG(head_dim == HD, "lavt_window_attn_bwd: head_dim %d != 32", head_dim);
     LAVT_CHECK_ARG(qkv && bias && out && dout && lse && dqkv && dbias && nwin > 0 && N > 0 && heads > 0 && bias_ld >= N, "lavt_window_attn_bwd: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (use_mfma(dtype, N, bias_ld)) return lavt_window_attn_bwd_mfma(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, dbias, nwin, N, heads, scale, st);
-    if (dtype == LAVT_F32) return launch_bwd<float>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, dbias, nwin, N, heads, scale, st);
-    if (dtype == LAVT_BF16) return launch_bwd<bf16>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, dbias, nwin, N, heads, scale, st);
+    // the bf16 MFMA kernel takes the bias values from an LDS copy of the table and needs one fp32 [N][bias_ld] slab per (window, head)
+    const bool fast = use_mfma(dtype, N, bias_ld) && table && ws && wd > 0 && wh > 0 && ww > 0 && N <= wd * wh * ww &&
+                      ws_floats >= (int64_t)nwin * heads * N * bias_ld;
+    if (fast) return lavt_window_attn_bwd_mfma(qkv, table, region, nw_img, out, dout, lse, dqkv, dbias, bias_ld, ws, wd, wh, ww, nwin, N, heads, scale, st);
+    if (dtype == LAVT_F32) return launch_bwd<float>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, dbias, nullptr, 0, 0, 0, nwin, N, heads, scale, st);
+    if (dtype == LAVT_BF16) return launch_bwd<bf16>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, dbias, nullptr, 0, 0, 0, nwin, N, heads, scale, st);
     lavt_set_error("lavt_window_attn_bwd: bad dtype %d", dtype);
     return LAVT_ERR_INVALID;
 }

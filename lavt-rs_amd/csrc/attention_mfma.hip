@@ -12,6 +12,8 @@
 //   of a thread always hits the same (i, j) and is summed over the chunk's windows IN REGISTERS, one atomic per
 //   element per workgroup at the end instead of one per window); P and dS go to LDS as bf16; phase 2 forms
 //   dV = P^T dO, dK = dS^T Q, dQ = dS K with MFMA, reading the k-major operands with the transposing LDS read.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -145,47 +147,57 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
 }
 
 // ================================================================================================ backward
+// One workgroup (4 waves) per (head, chunk of windows); per window Q, K, V, dO sit in LDS (rows >= N zero) and everything else stays in
+// registers -- no P / dS matrices in LDS, no barrier between the phases:
+//   pass 1 (a wave owns KEY tiles jt):   S = Q K^T and dP = dO V^T tile by tile, un-transposed (lane: key j = lane & 15, queries 4g+r);
+//            the P / dS accumulators of two consecutive query tiles ARE the A operands (k = 32 queries) of
+//            dV[jt] += P^T dO and dK[jt] += dS^T Q, whose B operands come from the transposing LDS read of dO / Q.
+//   pass 2 (a wave owns QUERY tiles it): S^T = K Q^T and dP^T = V dO^T (lane: query i = lane & 15, keys 4g+r, as in the forward);
+//            dS^T of two key tiles is the B operand of dQ^T[it] += K^T dS^T; the bias is read as float4 along j.
+// P / dS are recomputed in the second pass (4 extra MFMAs per tile pair) instead of being exchanged through LDS: the kernel went from
+// 159 KB of LDS (one workgroup per CU) to ~55 KB.  The relative-position-bias gradient is binned in an LDS histogram over the table
+// index (idx = base[i] - base[j] + centre) and flushed with one global atomic per table entry per workgroup; the dense [heads][N][ld]
+// gradient (dbias) is only written when no table pointer is given.
 constexpr int R_LD = 40;        // bf16 elements per LDS row of Q / K / V / dO (80 B rows, 16-byte aligned chunks)
 
-template <int NT>
-__global__ __launch_bounds__(256) void wattn_bwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ bias, int bias_ld,
+template <int NT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void wattn_bwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                       const int8_t* __restrict__ region, int nw_img, const bf16* __restrict__ out,
                                                       const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                      bf16* __restrict__ dqkv, float* __restrict__ dbias, int nwin, int N, int heads,
-                                                      float scale, int win_per_block) {
-    constexpr int NP = NT * 16, P_LD = NP + 8, KS = NP / 32;
-    constexpr int KK = (NT + 3) / 4;                       // query tiles per wave (NT >= number of query tiles)
+                                                      bf16* __restrict__ dqkv, float* __restrict__ slab, int slab_ld,
+                                                      int wd, int wh, int ww, int nwin, int N, int heads, float scale, int win_per_block) {
+    constexpr int KS = (NT + 1) / 2, NP = KS * 32;         // tiles are consumed in pairs (k = 32)
+    constexpr int TPW = (NT + WAVES - 1) / WAVES;          // tiles owned by a wave
+    constexpr int NTHR = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16* Qs = reinterpret_cast<bf16*>(smem_raw);
     bf16* Ks = Qs + NP * R_LD;
     bf16* Vs = Ks + NP * R_LD;
     bf16* Os = Vs + NP * R_LD;                             // dO
-    bf16* Ps = Os + NP * R_LD;                             // [NP][P_LD]
-    bf16* Ss = Ps + NP * P_LD;                             // dS
-    float* dl = reinterpret_cast<float*>(Ss + NP * P_LD);  // delta_i
+    float* dl = reinterpret_cast<float*>(Os + NP * R_LD);  // delta_i = sum_d dO*O
     float* ls = dl + NP;                                   // lse_i
-    uint8_t* Rs = reinterpret_cast<uint8_t*>(ls + NP);
+    int* bs = reinterpret_cast<int*>(ls + NP);             // table-index base of token i
+    uint8_t* Rs = reinterpret_cast<uint8_t*>(bs + NP);
+    float* tab = reinterpret_cast<float*>(Rs + NP);        // this head's column of the bias table, [(2wd-1)(2wh-1)(2ww-1)]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int h = blockIdx.x % heads, chunk = blockIdx.x / heads;
     const int C = heads * HD;
     const int QT = (N + 15) / 16;
-    const float* bh = bias + (int64_t)h * N * bias_ld;
-
-    f32x4 db[KK][NT];
-#pragma unroll
-    for (int k = 0; k < KK; ++k)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) db[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // P / dS rows beyond the last query tile are read by the k-loops of dV / dK: keep them zero for the whole kernel
-    for (int e = tid; e < NP * P_LD; e += 256) { Ps[e] = (bf16)0.f; Ss[e] = (bf16)0.f; }
+    const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
+    const int centre = ((wd - 1) * (2 * wh - 1) + (wh - 1)) * (2 * ww - 1) + (ww - 1);
+    for (int e = tid; e < R; e += NTHR) tab[e] = table[(int64_t)e * heads + h];
+    for (int e = tid; e < NP; e += NTHR) {
+        const int dz = e / (wh * ww), hy = (e / ww) % wh, wx = e % ww;
+        bs[e] = (dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx;
+    }
 
     const int w_end = min(nwin, (chunk + 1) * win_per_block);
     for (int w = chunk * win_per_block; w < w_end; ++w) {
         __syncthreads();
-        // ---- stage Q, K, V, dO (rows >= N are zero), delta_i = sum_d dO*O, lse_i, region ids ----------------------
+        // ---- stage Q, K, V, dO (rows >= N are zero), delta_i, lse_i, region ids ------------------------------------
         const bf16* base = qkv + (int64_t)w * N * 3 * C + h * HD;
-        for (int e = tid; e < NP * 4; e += 256) {
+        for (int e = tid; e < NP * 4; e += NTHR) {
             const int row = e >> 2, c = e & 3;
             uint4 q = make_uint4(0, 0, 0, 0), k = q, v = q, d = q, o = q;
             if (row < N) {
@@ -210,113 +222,155 @@ __global__ __launch_bounds__(256) void wattn_bwd_mfma(const bf16* __restrict__ q
             part += __shfl_xor(part, 2, 64);
             if (c == 0) { dl[row] = part; ls[row] = row < N ? lse[((int64_t)w * heads + h) * N + row] : 0.f; }
         }
-        for (int e = tid; e < NP; e += 256) Rs[e] = (region && e < N) ? (uint8_t)region[(int64_t)(w % nw_img) * N + e] : 0;
+        for (int e = tid; e < NP; e += NTHR) Rs[e] = (region && e < N) ? (uint8_t)region[(int64_t)(w % nw_img) * N + e] : 0;
         __syncthreads();
 
-        // ---- phase 1: P and dS tiles (rows i = 4g+r of the query tile, column j = lane & 15) ------------------------
+        // ---- pass 1: dV, dK of the key tiles this wave owns -----------------------------------------------------------
+#pragma unroll 1
+        for (int m = 0; m < TPW; ++m) {
+            const int jt = wave + WAVES * m;
+            if (jt >= NT || 16 * jt >= N) break;
+            const int j = 16 * jt + c16;
+            const bf16x8 kfr = lds_row8(Ks, R_LD, j, 8 * g);
+            const bf16x8 vfr = lds_row8(Vs, R_LD, j, 8 * g);
+            const int rj = Rs[j];
+            f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dk[2] = {dv[0], dv[0]};
+            const int bj = bs[j] - centre;                 // bias[i][j] = tab[bs[i] - bs[j] + centre]
 #pragma unroll
-        for (int k = 0; k < KK; ++k) {
-            const int it = wave + 4 * k;
-            if (it < QT) {
-                const bf16x8 qf = lds_row8(Qs, R_LD, 16 * it + c16, 8 * g);
-                const bf16x8 of = lds_row8(Os, R_LD, 16 * it + c16, 8 * g);
-                float li[4], di[4];
-                int ri[4];
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 pp, dp8;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const int i = 16 * it + 4 * g + r; li[r] = ls[i]; di[r] = dl[i]; ri[r] = Rs[i]; }
-                // all bias values of this query tile are requested up front: one L2 round trip per tile instead of one per key tile
-                float bb[NT][4];
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 16 * it + 4 * g + r, j = 16 * t + c16;
-                        bb[t][r] = (i < N && j < N) ? bh[(int64_t)i * bias_ld + j] : 0.f;
-                    }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int j = 16 * t + c16;
-                    const bf16x8 kfr = lds_row8(Ks, R_LD, j, 8 * g);
-                    const bf16x8 vfr = lds_row8(Vs, R_LD, j, 8 * g);
+                for (int half = 0; half < 2; ++half) {
+                    const int it = 2 * ks + half;
+                    const bf16x8 qf = lds_row8(Qs, R_LD, 16 * it + c16, 8 * g);
+                    const bf16x8 of = lds_row8(Os, R_LD, 16 * it + c16, 8 * g);
                     const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kfr, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, vfr, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    const int rj = Rs[j];
+                    // per-query constants of the 4 rows this lane holds: three vector LDS reads (rows >= N hold lse = delta = 0)
+                    const int i0 = 16 * it + 4 * g;
+                    const float4 l4 = *reinterpret_cast<const float4*>(ls + i0), d4 = *reinterpret_cast<const float4*>(dl + i0);
+                    const uint32_t ri4 = *reinterpret_cast<const uint32_t*>(Rs + i0);
+                    const int4 bi4 = *reinterpret_cast<const int4*>(bs + i0);
+                    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const float bb[4] = {tab[bi4.x - bj], tab[bi4.y - bj], tab[bi4.z - bj], tab[bi4.w - bj]};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int i = 16 * it + 4 * g + r;
-                        float p = 0.f, ds = 0.f;
-                        if (i < N && j < N) {
-                            float a = s[r] * scale + bb[t][r];
-                            if (rj != ri[r]) a += -100.0f;
-                            p = __expf(a - li[r]);
-                            ds = p * (dp[r] - di[r]);
-                        }
-                        db[k][t][r] += ds;
-                        Ps[i * P_LD + j] = (bf16)p;
-                        Ss[i * P_LD + j] = (bf16)ds;
+                        float a = s[r] * scale + bb[r];
+                        a += ((int)((ri4 >> (8 * r)) & 0xFF) != rj) ? -100.0f : 0.f;
+                        float p = __expf(a - lv[r]);
+                        p = (i0 + r < N && j < N) ? p : 0.f;              // branch-free: padded rows / columns contribute exactly zero
+                        const float ds = p * (dp[r] - dvv[r]);
+                        pp[half * 4 + r] = (bf16)p;
+                        dp8[half * 4 + r] = (bf16)ds;
+                    }
+                }
+                // B operands [k = query i][n = d]: transposing reads of dO / Q, k-slot (g, jj) <-> i = 32 ks + 16 (jj >> 2) + 4 g + (jj & 3)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int off = (32 * ks + 4 * g + (c16 >> 2)) * R_LD + 16 * u + 4 * (c16 & 3);
+                    const bf16x8 ot = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Os + off)),
+                                            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Os + off + 16 * R_LD)));
+                    const bf16x8 qt = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Qs + off)),
+                                            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Qs + off + 16 * R_LD)));
+                    dv[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pp, ot, dv[u], 0, 0, 0);
+                    dk[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dp8, qt, dk[u], 0, 0, 0);
+                }
+            }
+            // C[m = key 4g+r][n = d = c16 (+16u)]
+            bf16* dst = dqkv + (int64_t)w * N * 3 * C + h * HD + c16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jj = 16 * jt + 4 * g + r;
+                if (jj < N) {
+                    bf16* row = dst + (int64_t)jj * 3 * C;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        row[C + 16 * u] = (bf16)(dk[u][r] * scale);
+                        row[2 * C + 16 * u] = (bf16)dv[u][r];
                     }
                 }
             }
         }
-        __syncthreads();
 
-        // ---- phase 2: dV = P^T dO, dK = scale dS^T Q (NT x 2 tiles each), dQ = scale dS K (QT x 2 tiles) -------------
-        const int n_kv = NT * 2, n_all = 2 * n_kv + QT * 2;
-        for (int idx = wave; idx < n_all; idx += 4) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (idx < 2 * n_kv) {
-                const bool is_k = idx >= n_kv;
-                const int id = is_k ? idx - n_kv : idx;
-                const int jt = id >> 1, u = id & 1;
-                const bf16* Am = is_k ? Ss : Ps;           // A[row j][k = i]  = M[i][j]  (k-major)
-                const bf16* Bm = is_k ? Qs : Os;           // B[k = i][col d]  (k-major)
+        // ---- pass 2: dQ of the query tiles this wave owns; bias gradient -------------------------------------------------
+#pragma unroll 1
+        for (int m = 0; m < TPW; ++m) {
+            const int it = wave + WAVES * m;
+            if (it >= QT) break;
+            const int i = 16 * it + c16;
+            const bool vi = i < N;
+            const bf16x8 qfb = lds_row8(Qs, R_LD, i, 8 * g);
+            const bf16x8 ofb = lds_row8(Os, R_LD, i, 8 * g);
+            const float li = ls[i], di = dl[i];
+            const int ri = Rs[i], bi = bs[i] + centre;
+            f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_kmajor8(Am, P_LD, 32 * ks, 16 * jt, lane),
-                                                                  lds_kmajor8(Bm, R_LD, 32 * ks, 16 * u, lane), acc, 0, 0, 0);
-                const float f = is_k ? scale : 1.f;
-                bf16* dst = dqkv + (int64_t)w * N * 3 * C + (is_k ? C : 2 * C) + h * HD + 16 * u + c16;
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 ds8;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * jt + 4 * g + r;
-                    if (j < N) dst[(int64_t)j * 3 * C] = (bf16)(acc[r] * f);
+                for (int half = 0; half < 2; ++half) {
+                    const int jt = 2 * ks + half, j0 = 16 * jt + 4 * g;
+                    const bf16x8 ka = lds_row8(Ks, R_LD, 16 * jt + c16, 8 * g);
+                    const bf16x8 va = lds_row8(Vs, R_LD, 16 * jt + c16, 8 * g);
+                    const f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qfb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const f32x4 dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, ofb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const uint32_t rj4 = *reinterpret_cast<const uint32_t*>(Rs + j0);
+                    const int4 bj4 = *reinterpret_cast<const int4*>(bs + j0);
+                    const int bj[4] = {bj4.x, bj4.y, bj4.z, bj4.w};
+                    const float bb[4] = {tab[bi - bj[0]], tab[bi - bj[1]], tab[bi - bj[2]], tab[bi - bj[3]]};
+                    float dsr[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float a = st[r] * scale + bb[r];
+                        a += ((int)((rj4 >> (8 * r)) & 0xFF) != ri) ? -100.0f : 0.f;
+                        float p = __expf(a - li);
+                        const bool ok = vi && j0 + r < N;
+                        p = ok ? p : 0.f;
+                        const float ds = p * (dpt[r] - di);
+                        dsr[r] = ds;
+                        ds8[half * 4 + r] = (bf16)ds;
+                    }
+                    // dS of this (window, head) goes to its own fp32 slab (plain 16-byte stores); wattn_dbias_sum adds the slabs up.
+                    // (LDS float atomics for an in-kernel histogram cost 37 of 57 us per window-head; global atomics were as bad.)
+                    if (vi && j0 + 3 < slab_ld)
+                        *reinterpret_cast<float4*>(slab + (((int64_t)w * heads + h) * N + i) * slab_ld + j0) = make_float4(dsr[0], dsr[1], dsr[2], dsr[3]);
                 }
-            } else {
-                const int id = idx - 2 * n_kv;
-                const int it = id >> 1, u = id & 1;
+                // A operand [m = d][k = key j]: transposing read of K, k-slot (g, jj) <-> j = 32 ks + 16 (jj >> 2) + 4 g + (jj & 3)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row8(Ss, P_LD, 16 * it + c16, 32 * ks + 8 * g),
-                                                                  lds_kmajor8(Ks, R_LD, 32 * ks, 16 * u, lane), acc, 0, 0, 0);
-                bf16* dst = dqkv + (int64_t)w * N * 3 * C + h * HD + 16 * u + c16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * it + 4 * g + r;
-                    if (i < N) dst[(int64_t)i * 3 * C] = (bf16)(acc[r] * scale);
+                for (int u = 0; u < 2; ++u) {
+                    const int off = (32 * ks + 4 * g + (c16 >> 2)) * R_LD + 16 * u + 4 * (c16 & 3);
+                    const bf16x8 kt = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Ks + off)),
+                                            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Ks + off + 16 * R_LD)));
+                    dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, ds8, dq[u], 0, 0, 0);
                 }
             }
-        }
-    }
-    // ---- relative-position-bias gradient: one atomic per (i, j) per workgroup -----------------------------------
-    float* dbh = dbias + (int64_t)h * N * bias_ld;
+            // C[m = d = 4g+r (+16u)][n = query c16]: 4 consecutive channels per lane
+            if (vi) {
+                bf16* dst = dqkv + ((int64_t)w * N + i) * 3 * C + h * HD + 4 * g;
 #pragma unroll
-    for (int k = 0; k < KK; ++k) {
-        const int it = wave + 4 * k;
-        if (it < QT) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * it + 4 * g + r, j = 16 * t + c16;
-                    if (i < N && j < N) atomicAdd(dbh + (int64_t)i * bias_ld + j, db[k][t][r]);
-                }
+                for (int u = 0; u < 2; ++u)
+                    *reinterpret_cast<uint2*>(dst + 16 * u) = make_uint2(pack_bf16x2(dq[u][0] * scale, dq[u][1] * scale), pack_bf16x2(dq[u][2] * scale, dq[u][3] * scale));
+            }
         }
     }
 }
 
-template <int NT> size_t bwd_lds_bytes() {
-    constexpr int NP = NT * 16, P_LD = NP + 8;
-    return (size_t)4 * NP * R_LD * 2 + (size_t)2 * NP * P_LD * 2 + (size_t)2 * NP * 4 + NP;
+// dbias[h][i][j] += sum over windows of the per-(window, head) dS slabs (deterministic; one float4 column per thread)
+__global__ void wattn_dbias_sum(const float* __restrict__ slab, float* __restrict__ dbias, int nwin, int64_t per_window4) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= per_window4) return;
+    const float4* s = reinterpret_cast<const float4*>(slab) + e;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = 0; w < nwin; ++w) { const float4 v = s[(int64_t)w * per_window4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    float4* d = reinterpret_cast<float4*>(dbias) + e;
+    float4 o = *d;
+    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    *d = o;
+}
+
+template <int NT> size_t bwd_lds_bytes(int R) {
+    constexpr int NP = ((NT + 1) / 2) * 32;
+    return (size_t)4 * NP * R_LD * 2 + (size_t)3 * NP * 4 + NP + (size_t)R * 4 + 16;
 }
 
 }  // namespace
@@ -333,31 +387,38 @@ int lavt_window_attn_fwd_mfma(const void* qkv, const float* bias, int bias_ld, c
     return LAVT_OK;
 }
 
-int lavt_window_attn_bwd_mfma(const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, const void* out,
-                              const void* dout, const float* lse, void* dqkv, float* dbias, int nwin, int N, int heads, float scale,
-                              hipStream_t st) {
-    const int NT = N <= 64 ? 4 : 10;
-    if (N > 160 || bias_ld < N) { lavt_set_error("lavt_window_attn_bwd(mfma): N=%d bias_ld=%d unsupported", N, bias_ld); return LAVT_ERR_INVALID; }
-    // ~2 workgroups per CU; each sums its windows' bias gradient in registers before touching memory
-    int wpb = (int)(((long)nwin * heads + 511) / 512);
+int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, const void* out, const void* dout,
+                              const float* lse, void* dqkv, float* dbias, int bias_ld, float* ws, int wd, int wh, int ww, int nwin, int N,
+                              int heads, float scale, hipStream_t st) {
+    if (N > 160 || !table || !dbias || !ws || bias_ld % 4) { lavt_set_error("lavt_window_attn_bwd(mfma): N=%d (<= 160), table, dbias and scratch required", N); return LAVT_ERR_INVALID; }
+    const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
+    // >= 2 workgroups per CU when there is that much work
+    int wpb = (int)(((long)nwin * heads + 767) / 768);
     if (wpb < 1) wpb = 1;
     const int chunks = cdiv(nwin, wpb);
     dim3 grid(chunks * heads);
-    if (NT == 4) {
-        hipLaunchKernelGGL(wattn_bwd_mfma<4>, grid, dim3(256), bwd_lds_bytes<4>(), st, (const bf16*)qkv, bias, bias_ld, region, nw_img, (const bf16*)out,
-                           (const bf16*)dout, lse, (bf16*)dqkv, dbias, nwin, N, heads, scale, wpb);
-    } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_bwd_mfma<10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds_bytes<10>()) != hipSuccess) {
-                lavt_set_error("lavt_window_attn_bwd(mfma): cannot reserve %zu bytes of LDS", bwd_lds_bytes<10>());
-                return LAVT_ERR_LAUNCH;
-            }
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(wattn_bwd_mfma<10>, grid, dim3(256), bwd_lds_bytes<10>(), st, (const bf16*)qkv, bias, bias_ld, region, nw_img, (const bf16*)out,
-                           (const bf16*)dout, lse, (bf16*)dqkv, dbias, nwin, N, heads, scale, wpb);
-    }
+#define LAVT_BWD(NT_, WV_)                                                                                                                   \
+    do {                                                                                                                                     \
+        const size_t lds = bwd_lds_bytes<NT_>(R);                                                                                            \
+        static size_t reserved = 0;                                                                                                          \
+        if (lds > 65536 && lds > reserved) {                                                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_bwd_mfma<NT_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+                lavt_set_error("lavt_window_attn_bwd(mfma): cannot reserve %zu bytes of LDS", lds);                                          \
+                return LAVT_ERR_LAUNCH;                                                                                                      \
+            }                                                                                                                                \
+            reserved = lds;                                                                                                                  \
+        }                                                                                                                                    \
+        hipLaunchKernelGGL((wattn_bwd_mfma<NT_, WV_>), grid, dim3(WV_ * 64), lds, st, (const bf16*)qkv, table, region, nw_img,              \
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, ws, bias_ld, wd, wh, ww, nwin, N, heads, scale, wpb);     \
+    } while (0)
+    static const int waves = getenv("LAVT_ATTN_BWD_WAVES") ? atoi(getenv("LAVT_ATTN_BWD_WAVES")) : 8;
+    if (N <= 64) LAVT_BWD(4, 4);
+    else if (N <= 144) { if (waves == 8) LAVT_BWD(9, 8); else LAVT_BWD(9, 4); }
+    else { if (waves == 8) LAVT_BWD(10, 8); else LAVT_BWD(10, 4); }
+#undef LAVT_BWD
     LAVT_CHECK_LAUNCH("lavt_window_attn_bwd(mfma)");
+    const int64_t per_window4 = (int64_t)heads * N * bias_ld / 4;
+    hipLaunchKernelGGL(wattn_dbias_sum, dim3(cdiv(per_window4, 256)), dim3(256), 0, st, ws, dbias, nwin, per_window4);
+    LAVT_CHECK_LAUNCH("lavt_window_attn_bwd(dbias sum)");
     return LAVT_OK;
 }

@@ -414,8 +414,10 @@ class _WindowAttn(torch.autograd.Function):
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         ddense = torch.zeros_like(dense)
+        ws = torch.empty(nwin * heads * N * ld, dtype=torch.float32, device=qkv.device) if qkv.dtype == torch.bfloat16 else None
         K.check(K.lib.lavt_window_attn_bwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout),
-                                           K.ptr(lse), K.ptr(dqkv), K.ptr(ddense), nwin, N, heads, Cc // heads, scale, K.stream()))
+                                           K.ptr(lse), K.ptr(dqkv), K.ptr(ddense), K.ptr(_f32(table)), K.ptr(ws), ws.numel() if ws is not None else 0,
+                                           wd, wh, ww, nwin, N, heads, Cc // heads, scale, K.stream()))
         dtable, ts = sinks.buf(table, ((2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1), heads))
         K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense), K.ptr(dtable), wd, wh, ww, N, heads, ld, K.stream()))
         return dqkv, sinks.done(table, dtable, ts), None, None, None, None
