@@ -154,6 +154,7 @@ int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);
  * of 16 -- 64 for 7x7, 160 for 12x12 windows -- lets the bf16 MFMA kernels run; padding columns hold -1e30).  region: optional int8
  * [nw_img][N] region ids of the shift mask (window w uses row w % nw_img); unequal ids add -100.
  * lse: fp32 [nwin][heads][N] log-sum-exp of each score row (saved for backward).
+ * Forward, optional: table / (wd, wh, ww) as described for the backward (the bf16 MFMA kernel reads the bias from the table).
  * Backward: dqkv [nwin*N][3C] (every element written); dbias fp32 [heads][N][bias_ld] accumulates the dense relative-position-bias
  *   gradient (reduce it to the table with lavt_relpos_reduce).  Optional accelerators for the bf16 MFMA kernel (all or none):
  *   table = relative_position_bias_table fp32 [(2wd-1)(2wh-1)(2ww-1)][heads] with the FULL window shape (wd, wh, ww) (wd = 1 for the 2-D
@@ -162,7 +163,8 @@ int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);
  *   no atomics, deterministic).  Without them the exact-fp32 formulation with global atomics runs.
  * ------------------------------------------------------------------------------------------- */
 int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out,
-                         float* lse, int nwin, int N, int heads, int head_dim, float scale, void* stream);
+                         float* lse, const float* table, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim, float scale,
+                         void* stream);
 int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img,
                          const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, const float* table,
                          float* ws, int64_t ws_floats, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim, float scale,

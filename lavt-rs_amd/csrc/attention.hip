@@ -319,8 +319,8 @@ int launch_bwd(const void* qkv, const float* bias, int bias_ld, const int8_t* re
 
 }  // namespace
 
-int lavt_window_attn_fwd_mfma(const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out, float* lse,
-                              int nwin, int N, int heads, float scale, hipStream_t st);
+int lavt_window_attn_fwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, void* out, float* lse,
+                              int wd, int wh, int ww, int nwin, int N, int heads, float scale, hipStream_t st);
 int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, const void* out, const void* dout,
                               const float* lse, void* dqkv, float* dbias, int bias_ld, float* ws, int wd, int wh, int ww, int nwin, int N,
                               int heads, float scale, hipStream_t st);
@@ -331,12 +331,14 @@ static bool use_mfma(int dtype, int N, int bias_ld) {
 }
 
 extern "C" int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out,
-                                    float* lse, int nwin, int N, int heads, int head_dim, float scale, void* stream) {
+                                    float* lse, const float* table, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim,
+                                    float scale, void* stream) {
     LAVT_CHECK_ARG(head_dim == HD, "lavt_window_attn_fwd: head_dim %d != 32", head_dim);
     LAVT_CHECK_ARG(qkv && bias && out && lse && nwin > 0 && N > 0 && heads > 0 && bias_ld >= N, "lavt_window_attn_fwd: bad arguments");
     LAVT_CHECK_ARG(!region || nw_img > 0, "lavt_window_attn_fwd: region needs nw_img");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (use_mfma(dtype, N, bias_ld)) return lavt_window_attn_fwd_mfma(qkv, bias, bias_ld, region, nw_img, out, lse, nwin, N, heads, scale, st);
+    if (use_mfma(dtype, N, bias_ld) && table && wd > 0 && wh > 0 && ww > 0 && N <= wd * wh * ww)
+        return lavt_window_attn_fwd_mfma(qkv, table, region, nw_img, out, lse, wd, wh, ww, nwin, N, heads, scale, st);
     if (dtype == LAVT_F32) return launch_fwd<float>(qkv, bias, bias_ld, region, nw_img, out, lse, nwin, N, heads, scale, st);
     if (dtype == LAVT_BF16) return launch_fwd<bf16>(qkv, bias, bias_ld, region, nw_img, out, lse, nwin, N, heads, scale, st);
     lavt_set_error("lavt_window_attn_fwd: bad dtype %d", dtype);

@@ -45,74 +45,90 @@ __device__ __forceinline__ bf16x8 zero8() {
 __device__ __forceinline__ bf16x8 ldg8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
 // ================================================================================================ forward
-constexpr int V_LD = 36;        // bf16 elements per LDS row of V (72 B: 8-byte aligned rows, spreads banks)
+// One workgroup (4 waves) per (window, head).  Q, K, V are staged once into LDS by all 256 threads (one round of 16-byte loads in
+// flight instead of the per-wave, per-row latency chain of a one-wave-per-pair kernel: measured 25 us per layer whatever the size);
+// the head's column of the relative-position table sits in LDS too (bias[i][j] = tab[base[i] - base[j] + centre]), so the query-tile loop
+// touches no global memory except its stores.  A wave owns query tiles it = wave, wave + 4, ...; it keeps the K fragments (A operand of
+// S^T = K Q^T) and the V^T fragments (A operand of O^T = V^T P^T, transposing LDS read) in registers for all its tiles.
+// S^T puts one query per lane column: softmax reductions are in-register + two shuffles, and the un-normalised P^T accumulators of two
+// key tiles are directly the B operand of the second MFMA (no LDS round trip for P).
+constexpr int F_LD = 40;        // bf16 elements per LDS row of Q / K / V (80 B)
 
 template <int NT>
-__global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ bias, int bias_ld,
+__global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                       const int8_t* __restrict__ region, int nw_img, bf16* __restrict__ out,
-                                                      float* __restrict__ lse, int nwin, int N, int heads, float scale) {
-    constexpr int NP = NT * 16, KS = NT / 2;
-    constexpr int WAVE_LDS = NP * V_LD * 2 + NP;            // V image + region ids (bytes)
+                                                      float* __restrict__ lse, int wd, int wh, int ww, int nwin, int N, int heads, float scale) {
+    constexpr int KS = (NT + 1) / 2, NP = KS * 32;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
-    bf16* Vs = reinterpret_cast<bf16*>(smem_raw + wave * ((WAVE_LDS + 15) / 16 * 16));
-    uint8_t* Rs = reinterpret_cast<uint8_t*>(Vs + NP * V_LD);
-    const int pair = blockIdx.x * 4 + wave;
-    const bool live = pair < nwin * heads;
-    const int w = live ? pair / heads : 0, h = live ? pair % heads : 0;
+    bf16* Qs = reinterpret_cast<bf16*>(smem_raw);
+    bf16* Ks = Qs + NP * F_LD;
+    bf16* Vs = Ks + NP * F_LD;
+    int* bs = reinterpret_cast<int*>(Vs + NP * F_LD);
+    uint8_t* Rs = reinterpret_cast<uint8_t*>(bs + NP);
+    float* tab = reinterpret_cast<float*>(Rs + NP);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int w = blockIdx.x / heads, h = blockIdx.x % heads;
     const int C = heads * HD;
-    const bf16* base = qkv + (int64_t)w * N * 3 * C + h * HD;          // + row * 3C (+C for k, +2C for v)
+    const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
+    const int centre = ((wd - 1) * (2 * wh - 1) + (wh - 1)) * (2 * ww - 1) + (ww - 1);
+    const bf16* base = qkv + (int64_t)w * N * 3 * C + h * HD;
 
-    // ---- stage V (and the region ids) -----------------------------------------------------------------
-    for (int e = lane; e < NP * 8; e += 64) {
-        const int row = e >> 3, c = e & 7;
-        uint2 v = make_uint2(0, 0);
-        if (live && row < N) v = *reinterpret_cast<const uint2*>(base + (int64_t)row * 3 * C + 2 * C + c * 4);
-        *reinterpret_cast<uint2*>(Vs + row * V_LD + c * 4) = v;
+    for (int e = tid; e < NP * 4; e += 256) {
+        const int row = e >> 2, c = e & 3;
+        uint4 q = make_uint4(0, 0, 0, 0), k = q, v = q;
+        if (row < N) {
+            const bf16* r = base + (int64_t)row * 3 * C + c * 8;
+            q = *reinterpret_cast<const uint4*>(r);
+            k = *reinterpret_cast<const uint4*>(r + C);
+            v = *reinterpret_cast<const uint4*>(r + 2 * C);
+        }
+        *reinterpret_cast<uint4*>(Qs + row * F_LD + c * 8) = q;
+        *reinterpret_cast<uint4*>(Ks + row * F_LD + c * 8) = k;
+        *reinterpret_cast<uint4*>(Vs + row * F_LD + c * 8) = v;
     }
-    for (int e = lane; e < NP; e += 64) Rs[e] = (live && region && e < N) ? (uint8_t)region[(int64_t)(w % nw_img) * N + e] : 0;
+    for (int e = tid; e < NP; e += 256) {
+        const int dz = e / (wh * ww), hy = (e / ww) % wh, wx = e % ww;
+        bs[e] = (dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx;
+        Rs[e] = (region && e < N) ? (uint8_t)region[(int64_t)(w % nw_img) * N + e] : 0;
+    }
+    for (int e = tid; e < R; e += 256) tab[e] = table[(int64_t)e * heads + h];
     __syncthreads();
-    if (!live) return;
 
-    // ---- K fragments (A operand of S^T = K Q^T) and V^T fragments (A operand of O^T = V^T P^T) -------------
+    const int QT = (N + 15) / 16;
+    if (wave >= QT) return;
     bf16x8 kf[NT], vf[2][KS];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int j = 16 * t + c16;
-        kf[t] = j < N ? ldg8(base + (int64_t)j * 3 * C + C + 8 * g) : zero8();
-    }
+    for (int t = 0; t < NT; ++t) kf[t] = lds_row8(Ks, F_LD, 16 * t + c16, 8 * g);
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             // k-slot (g, jj) <-> key j = 32 ks + 16 (jj >> 2) + 4 g + (jj & 3): matches the accumulator rows of tiles 2ks, 2ks+1
-            const bf16* p = Vs + (32 * ks + 4 * g + (c16 >> 2)) * V_LD + 16 * u + 4 * (c16 & 3);
+            const bf16* p = Vs + (32 * ks + 4 * g + (c16 >> 2)) * F_LD + 16 * u + 4 * (c16 & 3);
             vf[u][ks] = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p),
-                              __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * V_LD)));
+                              __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * F_LD)));
         }
 
-    const int QT = (N + 15) / 16;
-    const float* bh = bias + (int64_t)h * N * bias_ld;
-    for (int it = 0; it < QT; ++it) {
+    for (int it = wave; it < QT; it += 4) {
         const int i = 16 * it + c16;
         const bool vi = i < N;
-        const bf16x8 qf = vi ? ldg8(base + (int64_t)i * 3 * C + 8 * g) : zero8();
-        const int rid_i = Rs[vi ? i : 0];
-        f32x4 s[NT];
+        const bf16x8 qf = lds_row8(Qs, F_LD, i, 8 * g);
+        const int rid_i = Rs[i], bi = bs[i] + centre;
+        f32x4 s[2 * KS];
         float mx = -1e30f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        for (int t = 0; t < 2 * KS; ++t) {
+            if (t < NT) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            else s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int j0 = 16 * t + 4 * g;
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (vi) b = *reinterpret_cast<const float4*>(bh + (int64_t)i * bias_ld + j0);     // columns >= N hold -1e30
+            const int4 bj = *reinterpret_cast<const int4*>(bs + j0);
             const uint32_t rj = *reinterpret_cast<const uint32_t*>(Rs + j0);
-            const float bb[4] = {b.x, b.y, b.z, b.w};
+            const float bb[4] = {tab[bi - bj.x], tab[bi - bj.y], tab[bi - bj.z], tab[bi - bj.w]};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = s[t][r] * scale + bb[r];
-                if ((int)((rj >> (8 * r)) & 0xFF) != rid_i) v += -100.0f;
-                if (j0 + r >= N) v = -1e30f;
+                v += ((int)((rj >> (8 * r)) & 0xFF) != rid_i) ? -100.0f : 0.f;
+                v = (j0 + r < N) ? v : -1e30f;
                 s[t][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -121,7 +137,7 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < 2 * KS; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float p = __expf(s[t][r] - mx); s[t][r] = p; sum += p; }
         sum += __shfl_xor(sum, 16, 64);
@@ -355,17 +371,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void wattn_bwd_mfma(const bf16* __re
     }
 }
 
-// dbias[h][i][j] += sum over windows of the per-(window, head) dS slabs (deterministic; one float4 column per thread)
-__global__ void wattn_dbias_sum(const float* __restrict__ slab, float* __restrict__ dbias, int nwin, int64_t per_window4) {
+// dbias[h][i][j] += sum over windows of the per-(window, head) dS slabs: one float4 column per thread, blockIdx.y walks a group of windows
+// (one group: plain read-modify-write, deterministic; several groups: their partial sums meet in dbias through atomics)
+__global__ void wattn_dbias_sum(const float* __restrict__ slab, float* __restrict__ dbias, int nwin, int per_group, int64_t per_window4) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= per_window4) return;
+    const int w0 = blockIdx.y * per_group, w1 = min(nwin, w0 + per_group);
     const float4* s = reinterpret_cast<const float4*>(slab) + e;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int w = 0; w < nwin; ++w) { const float4 v = s[(int64_t)w * per_window4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
-    float4* d = reinterpret_cast<float4*>(dbias) + e;
-    float4 o = *d;
-    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-    *d = o;
+    for (int w = w0; w < w1; ++w) { const float4 v = s[(int64_t)w * per_window4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    float* d = dbias + 4 * e;
+    if (gridDim.y == 1) {
+        float4 o = *reinterpret_cast<float4*>(d);
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        *reinterpret_cast<float4*>(d) = o;
+    } else {
+        atomicAdd(d, a.x); atomicAdd(d + 1, a.y); atomicAdd(d + 2, a.z); atomicAdd(d + 3, a.w);
+    }
 }
 
 template <int NT> size_t bwd_lds_bytes(int R) {
@@ -375,14 +397,22 @@ template <int NT> size_t bwd_lds_bytes(int R) {
 
 }  // namespace
 
-int lavt_window_attn_fwd_mfma(const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out, float* lse,
-                              int nwin, int N, int heads, float scale, hipStream_t st) {
-    const int NT = N <= 64 ? 4 : 10;
-    if (N > 160 || bias_ld < NT * 16 || bias_ld % 4) { lavt_set_error("lavt_window_attn_fwd(mfma): N=%d bias_ld=%d unsupported", N, bias_ld); return LAVT_ERR_INVALID; }
-    const int blocks = cdiv((long)nwin * heads, 4);
-    const size_t wave_lds = (size_t)((NT * 16 * V_LD * 2 + NT * 16 + 15) / 16 * 16);
-    if (NT == 4) hipLaunchKernelGGL(wattn_fwd_mfma<4>, dim3(blocks), dim3(256), 4 * wave_lds, st, (const bf16*)qkv, bias, bias_ld, region, nw_img, (bf16*)out, lse, nwin, N, heads, scale);
-    else hipLaunchKernelGGL(wattn_fwd_mfma<10>, dim3(blocks), dim3(256), 4 * wave_lds, st, (const bf16*)qkv, bias, bias_ld, region, nw_img, (bf16*)out, lse, nwin, N, heads, scale);
+int lavt_window_attn_fwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, void* out, float* lse,
+                              int wd, int wh, int ww, int nwin, int N, int heads, float scale, hipStream_t st) {
+    if (N > 160 || !table) { lavt_set_error("lavt_window_attn_fwd(mfma): N=%d (<= 160) with the bias table required", N); return LAVT_ERR_INVALID; }
+    const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
+    dim3 grid(nwin * heads);
+#define LAVT_FWD(NT_)                                                                                                                        \
+    do {                                                                                                                                     \
+        constexpr int NP = ((NT_ + 1) / 2) * 32;                                                                                             \
+        const size_t lds = (size_t)3 * NP * F_LD * 2 + (size_t)NP * 4 + NP + (size_t)R * 4 + 16;                                             \
+        hipLaunchKernelGGL(wattn_fwd_mfma<NT_>, grid, dim3(256), lds, st, (const bf16*)qkv, table, region, nw_img, (bf16*)out, lse, wd, wh,  \
+                           ww, nwin, N, heads, scale);                                                                                       \
+    } while (0)
+    if (N <= 64) LAVT_FWD(4);
+    else if (N <= 144) LAVT_FWD(9);
+    else LAVT_FWD(10);
+#undef LAVT_FWD
     LAVT_CHECK_LAUNCH("lavt_window_attn_fwd(mfma)");
     return LAVT_OK;
 }
@@ -411,14 +441,21 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
         hipLaunchKernelGGL((wattn_bwd_mfma<NT_, WV_>), grid, dim3(WV_ * 64), lds, st, (const bf16*)qkv, table, region, nw_img,              \
                            (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, ws, bias_ld, wd, wh, ww, nwin, N, heads, scale, wpb);     \
     } while (0)
-    static const int waves = getenv("LAVT_ATTN_BWD_WAVES") ? atoi(getenv("LAVT_ATTN_BWD_WAVES")) : 8;
+    // 8 waves share one window-head when all of them fit the chip in one round at one workgroup per CU (163 VGPRs); else 4 waves, 2 per CU
+    static const int force_waves = getenv("LAVT_ATTN_BWD_WAVES") ? atoi(getenv("LAVT_ATTN_BWD_WAVES")) : 0;
+    const int waves = force_waves ? force_waves : ((long)chunks * heads <= 256 ? 8 : 4);
     if (N <= 64) LAVT_BWD(4, 4);
     else if (N <= 144) { if (waves == 8) LAVT_BWD(9, 8); else LAVT_BWD(9, 4); }
     else { if (waves == 8) LAVT_BWD(10, 8); else LAVT_BWD(10, 4); }
 #undef LAVT_BWD
     LAVT_CHECK_LAUNCH("lavt_window_attn_bwd(mfma)");
     const int64_t per_window4 = (int64_t)heads * N * bias_ld / 4;
-    hipLaunchKernelGGL(wattn_dbias_sum, dim3(cdiv(per_window4, 256)), dim3(256), 0, st, ws, dbias, nwin, per_window4);
+    const int bx = cdiv(per_window4, 256);
+    int groups = 1024 / bx;                                   // ~1k workgroups in total
+    if (groups > nwin / 4) groups = nwin / 4;                 // >= 4 windows per group
+    if (groups < 1 || nwin <= 32) groups = 1;                 // few windows: one deterministic pass
+    const int per_group = cdiv(nwin, groups);
+    hipLaunchKernelGGL(wattn_dbias_sum, dim3(bx, cdiv(nwin, per_group)), dim3(256), 0, st, ws, dbias, nwin, per_group, per_window4);
     LAVT_CHECK_LAUNCH("lavt_window_attn_bwd(dbias sum)");
     return LAVT_OK;
 }

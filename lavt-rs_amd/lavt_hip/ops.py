@@ -401,7 +401,7 @@ class _WindowAttn(torch.autograd.Function):
         nw_img = region.shape[0] if region is not None else 0
         scale = float((Cc // heads) ** -0.5)
         K.check(K.lib.lavt_window_attn_fwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(lse),
-                                           nwin, N, heads, Cc // heads, scale, K.stream()))
+                                           K.ptr(_f32(table)), wd, wh, ww, nwin, N, heads, Cc // heads, scale, K.stream()))
         ctx.save_for_backward(qkv, dense, region, out, lse, table)
         ctx.dims = (win, heads, nwin, N, Cc, nw_img, scale, ld)
         return out
