@@ -240,6 +240,15 @@ int lavt_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi
 /* final logits: NHWC [B,Hi,Wi,2] (dtype) -> NCHW fp32 [B,2,Ho,Wo] (lib/_utils.py:21) and its gradient */
 int lavt_logits_up_fwd(int dtype, const void* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, void* stream);
 int lavt_logits_up_bwd(int dtype, const float* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, void* stream);
+/* The caller's step right after the path, fused: bilinear upsample (align_corners) of the 2-class low-resolution logits
+ * x NHWC [B,Hi,Wi,2] to (Ho, Wo) + class-weighted cross-entropy against target int64 [B,Ho,Wo] (losses.py:7-11, weights (w0, w1);
+ * targets other than 0 / 1 are ignored) + the I / U pixel counts of train.py:64-76 (prediction = argmax, class 0 on ties).
+ * The [B,2,Ho,Wo] logits are never materialised.  out4 = {loss, sum of weights, I, U} (device, fp32); ws: >= 4*2048 floats of scratch.
+ * Backward: dx NHWC [B,Hi,Wi,2] = dloss[0] (device scalar, NULL = 1) * d loss / d x, recomputed from x (gather form, no atomics). */
+int lavt_upsample_ce_fwd(int dtype, const void* x, const int64_t* target, float w0, float w1, float* ws, int64_t ws_floats, float* out4,
+                         int B, int Hi, int Wi, int Ho, int Wo, void* stream);
+int lavt_upsample_ce_bwd(int dtype, const void* x, const int64_t* target, float w0, float w1, const float* out4, const float* dloss,
+                         void* dx, int B, int Hi, int Wi, int Ho, int Wo, void* stream);
 /* classifier head conv1_1: 1x1 conv hidden->2 with bias (lib/mask_predictor.py:50,99) */
 int lavt_cls_head_fwd(int dtype, const void* x, const float* w, const float* b, void* y, int64_t rows, int C, void* stream);
 int lavt_cls_head_bwd(int dtype, const void* x, const void* dy, const float* w, void* dx, float* dw, float* db,

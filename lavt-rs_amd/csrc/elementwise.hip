@@ -156,6 +156,110 @@ template <typename T> __global__ void bilinear_bwd_kernel(const T* dy, T* dx, in
     }
 }
 // logits: NHWC [B,Hi,Wi,2] (T) -> NCHW fp32 [B,2,Ho,Wo]
+// ---- fused final step of the caller: bilinear upsample (align_corners) of the 2-class low-resolution logits + class-weighted
+// cross-entropy (losses.py:7-11: F.cross_entropy(out, target, weight=[0.9, 1.1])) + the I / U pixel counts of train.py:64-76.
+// The (B, 2, H, W) logits are never written: every full-resolution pixel is recomputed from its four low-resolution neighbours.
+struct UpCe { float up0, up1, lse; };
+template <typename T>
+__device__ __forceinline__ UpCe upce_at(const T* base, int Wi, int y0, int y1, float ly, int x0, int x1, float lx) {
+    const T* r0 = base + ((int64_t)y0 * Wi) * 2;
+    const T* r1 = base + ((int64_t)y1 * Wi) * 2;
+    const float a0 = to_f<T>(r0[x0 * 2]), a1 = to_f<T>(r0[x0 * 2 + 1]), b0 = to_f<T>(r0[x1 * 2]), b1 = to_f<T>(r0[x1 * 2 + 1]);
+    const float c0 = to_f<T>(r1[x0 * 2]), c1 = to_f<T>(r1[x0 * 2 + 1]), d0 = to_f<T>(r1[x1 * 2]), d1 = to_f<T>(r1[x1 * 2 + 1]);
+    UpCe u;
+    u.up0 = (1.f - ly) * ((1.f - lx) * a0 + lx * b0) + ly * ((1.f - lx) * c0 + lx * d0);
+    u.up1 = (1.f - ly) * ((1.f - lx) * a1 + lx * b1) + ly * ((1.f - lx) * c1 + lx * d1);
+    const float m = fmaxf(u.up0, u.up1);
+    u.lse = m + logf(expf(u.up0 - m) + expf(u.up1 - m));
+    return u;
+}
+// partial[blk] = {sum w*nll, sum w, I, U}
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_ce_fwd_kernel(const T* __restrict__ x, const int64_t* __restrict__ target, float w0, float w1,
+                                                              float* __restrict__ partial, int B, int Hi, int Wi, int Ho, int Wo, float sh, float sw) {
+    const int64_t n = (int64_t)B * Ho * Wo;
+    float num = 0.f, den = 0.f, inter = 0.f, uni = 0.f;
+    GRID_STRIDE(i, n) {
+        const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho), b = (int)(i / Wo / Ho);
+        int y0, y1, x0, x1; float ly, lx;
+        bl_coord(yo, sh, Hi, y0, y1, ly);
+        bl_coord(xo, sw, Wi, x0, x1, lx);
+        const UpCe u = upce_at<T>(x + (int64_t)b * Hi * Wi * 2, Wi, y0, y1, ly, x0, x1, lx);
+        const int64_t t = target[i];
+        if (t == 0 || t == 1) {                                  // anything else is ignored, like F.cross_entropy's ignore_index
+            const float w = t ? w1 : w0;
+            num += w * (u.lse - (t ? u.up1 : u.up0));
+            den += w;
+        }
+        const bool pred = u.up1 > u.up0, tgt = t == 1;            // argmax picks class 0 on ties
+        inter += (pred && tgt) ? 1.f : 0.f;
+        uni += (pred || tgt) ? 1.f : 0.f;
+    }
+    __shared__ float red[4][4];
+    num = wave_sum(num); den = wave_sum(den); inter = wave_sum(inter); uni = wave_sum(uni);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = num; red[wave][1] = den; red[wave][2] = inter; red[wave][3] = uni; }
+    __syncthreads();
+    if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+// out = {loss, sum w, I, U}
+__global__ __launch_bounds__(256) void upsample_ce_finish_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ out) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < nblk; b += 256)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += partial[b * 4 + k];
+    __shared__ float red[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = wave_sum(a[k]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[threadIdx.x >> 6][k] = a[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        out[0] = v[1] > 0.f ? v[0] / v[1] : 0.f;
+        out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+    }
+}
+// dx[b, yi, xi, c] = dloss / sum_w * sum over the full-resolution pixels that sampled (yi, xi) of coef * w_t * (softmax_c - [c == t])
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(const T* __restrict__ x, const int64_t* __restrict__ target, float w0, float w1,
+                                                              const float* __restrict__ stats, const float* __restrict__ dloss, T* __restrict__ dx,
+                                                              int B, int Hi, int Wi, int Ho, int Wo, float sh, float sw) {
+    const int64_t n = (int64_t)B * Hi * Wi;
+    const float gscale = (stats[1] > 0.f ? 1.f / stats[1] : 0.f) * (dloss ? dloss[0] : 1.f);
+    GRID_STRIDE(i, n) {
+        const int xi = (int)(i % Wi), yi = (int)((i / Wi) % Hi), b = (int)(i / Wi / Hi);
+        int ylo, yhi, xlo, xhi;
+        bl_range(yi, sh, Hi, Ho, ylo, yhi);
+        bl_range(xi, sw, Wi, Wo, xlo, xhi);
+        const T* base = x + (int64_t)b * Hi * Wi * 2;
+        float a0 = 0.f, a1 = 0.f;
+        for (int yo = ylo; yo <= yhi; ++yo) {
+            int y0, y1; float ly;
+            bl_coord(yo, sh, Hi, y0, y1, ly);
+            const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int xo = xlo; xo <= xhi; ++xo) {
+                int x0, x1; float lx;
+                bl_coord(xo, sw, Wi, x0, x1, lx);
+                const float wx = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
+                if (wx == 0.f) continue;
+                const int64_t t = target[((int64_t)b * Ho + yo) * Wo + xo];
+                if (t != 0 && t != 1) continue;
+                const UpCe u = upce_at<T>(base, Wi, y0, y1, ly, x0, x1, lx);
+                const float w = (t ? w1 : w0) * wy * wx;
+                a0 += w * (expf(u.up0 - u.lse) - (t == 0 ? 1.f : 0.f));
+                a1 += w * (expf(u.up1 - u.lse) - (t == 1 ? 1.f : 0.f));
+            }
+        }
+        dx[i * 2] = from_f<T>(a0 * gscale);
+        dx[i * 2 + 1] = from_f<T>(a1 * gscale);
+    }
+}
+
 template <typename T> __global__ void logits_up_fwd_kernel(const T* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, float sh, float sw) {
     const int64_t n = (int64_t)B * Ho * Wo;
     GRID_STRIDE(i, n) {
@@ -373,6 +477,26 @@ extern "C" int lavt_logits_up_bwd(int dtype, const float* dy, void* dx, int B, i
     const int64_t n = (int64_t)B * Hi * Wi;
     DISPATCH_T(dtype, "lavt_logits_up_bwd", hipLaunchKernelGGL(logits_up_bwd_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, ST, dy, (T*)dx, B, Hi, Wi, Ho, Wo, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
     LAVT_CHECK_LAUNCH("lavt_logits_up_bwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_upsample_ce_fwd(int dtype, const void* x, const int64_t* target, float w0, float w1, float* ws, int64_t ws_floats,
+                                    float* out4, int B, int Hi, int Wi, int Ho, int Wo, void* stream) {
+    LAVT_CHECK_ARG(x && target && ws && out4 && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "lavt_upsample_ce_fwd: bad arguments");
+    const int64_t n = (int64_t)B * Ho * Wo;
+    int blocks = (int)((n + 1023) / 1024);
+    if (blocks > 2048) blocks = 2048;
+    LAVT_CHECK_ARG(ws_floats >= (int64_t)blocks * 4, "lavt_upsample_ce_fwd: scratch of %d floats needed", blocks * 4);
+    DISPATCH_T(dtype, "lavt_upsample_ce_fwd", hipLaunchKernelGGL(upsample_ce_fwd_kernel<T>, dim3(blocks), dim3(256), 0, ST, (const T*)x, target, w0, w1, ws, B, Hi, Wi, Ho, Wo, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
+    hipLaunchKernelGGL(upsample_ce_finish_kernel, dim3(1), dim3(256), 0, ST, ws, blocks, out4);
+    LAVT_CHECK_LAUNCH("lavt_upsample_ce_fwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_upsample_ce_bwd(int dtype, const void* x, const int64_t* target, float w0, float w1, const float* out4, const float* dloss,
+                                    void* dx, int B, int Hi, int Wi, int Ho, int Wo, void* stream) {
+    LAVT_CHECK_ARG(x && target && out4 && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "lavt_upsample_ce_bwd: bad arguments");
+    const int64_t n = (int64_t)B * Hi * Wi;
+    DISPATCH_T(dtype, "lavt_upsample_ce_bwd", hipLaunchKernelGGL(upsample_ce_bwd_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, ST, (const T*)x, target, w0, w1, out4, dloss, (T*)dx, B, Hi, Wi, Ho, Wo, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
+    LAVT_CHECK_LAUNCH("lavt_upsample_ce_bwd");
     return LAVT_OK;
 }
 extern "C" int lavt_cls_head_fwd(int dtype, const void* x, const float* w, const float* b, void* y, int64_t rows, int C, void* stream) {

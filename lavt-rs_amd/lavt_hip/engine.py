@@ -20,7 +20,7 @@ from .runtime import compute_dtype
 
 
 class TrainStep:
-    def __init__(self, model, image, l_feats, l_mask, target, world=1, use_graph=True, bucket_mib=64.0):
+    def __init__(self, model, image, l_feats, l_mask, target, world=1, use_graph=True, bucket_mib=64.0, fused_loss=True):
         self.model = model
         dev = image.device
         self.x, self.l, self.m, self.t = image, l_feats, l_mask, target
@@ -31,12 +31,18 @@ class TrainStep:
         self.loss = None
         self.use_graph = use_graph and world == 1
         self.captured = False
+        self.fused_loss = fused_loss and hasattr(model, "forward_lowres")
+        self.stats = None                        # fused loss: [loss, sum of weights, I, U] of the last step (device tensor)
 
     def _body(self):
         ops.weights.refresh_all()                # re-cast weights inside the step (they change every optimizer step)
         self.buckets.zero()
-        out = self.model(self.x, self.l, self.m)
-        loss = F.cross_entropy(out, self.t, weight=self.w)
+        if self.fused_loss:                       # upsample + weighted CE (+ I/U) fused: the (B,2,H,W) logits are never written
+            from lib._utils import fused_loss
+            loss, self.stats = fused_loss(self.model.forward_lowres(self.x, self.l, self.m), self.t, (0.9, 1.1))
+        else:
+            out = self.model(self.x, self.l, self.m)
+            loss = F.cross_entropy(out, self.t, weight=self.w)
         loss.backward()
         ops.side.join()                          # wgrad GEMMs ran on side streams: join before the step (or the graph capture) ends
         return loss.detach()

@@ -938,3 +938,37 @@ class _LogitsUp(torch.autograd.Function):
 
 def logits_upsample(x, B, Hi, Wi, Ho, Wo):
     return _LogitsUp.apply(x, B, Hi, Wi, Ho, Wo)
+
+
+# ------------------------------------------------------------------------------------------ fused upsample + weighted CE (+ I/U counts)
+class _UpsampleCE(torch.autograd.Function):
+    """loss = F.cross_entropy(F.interpolate(y, (Ho, Wo), bilinear, align_corners=True), target, weight=(w0, w1)) on the low-resolution
+    2-class logits rows x [B*Hi*Wi, 2] (lib/_utils.py:21 + losses.py:7-11) without materialising the upsampled logits.
+    Returns (loss, stats) with stats = [loss, sum of weights, I, U] (train.py:64-76 pixel counts of the argmax mask)."""
+
+    @staticmethod
+    def forward(ctx, x, target, B, Hi, Wi, Ho, Wo, w0, w1):
+        x = x.contiguous()
+        target = target.contiguous()
+        assert target.dtype == torch.int64 and target.numel() == B * Ho * Wo
+        out4 = torch.empty(4, dtype=torch.float32, device=x.device)
+        ws = _scratch(4 * 2048, x.device)
+        K.check(K.lib.lavt_upsample_ce_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(target), float(w0), float(w1), K.ptr(ws), ws.numel(), K.ptr(out4),
+                                           B, Hi, Wi, Ho, Wo, K.stream()))
+        ctx.save_for_backward(x, target, out4)
+        ctx.dims = (B, Hi, Wi, Ho, Wo, float(w0), float(w1))
+        ctx.mark_non_differentiable(out4)
+        return out4[0].clone(), out4
+
+    @staticmethod
+    def backward(ctx, dloss, _dstats):
+        x, target, out4 = ctx.saved_tensors
+        B, Hi, Wi, Ho, Wo, w0, w1 = ctx.dims
+        dx = torch.empty_like(x)
+        dl = dloss.contiguous().float().reshape(1)
+        K.check(K.lib.lavt_upsample_ce_bwd(K.dt(x.dtype), K.ptr(x), K.ptr(target), w0, w1, K.ptr(out4), K.ptr(dl), K.ptr(dx), B, Hi, Wi, Ho, Wo, K.stream()))
+        return dx, None, None, None, None, None, None, None, None
+
+
+def upsample_cross_entropy(x, target, B, Hi, Wi, Ho, Wo, weight=(0.9, 1.1)):
+    return _UpsampleCE.apply(x, target, B, Hi, Wi, Ho, Wo, weight[0], weight[1])

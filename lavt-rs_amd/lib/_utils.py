@@ -23,17 +23,27 @@ def _upsample_logits(y, size):
     return ops.logits_upsample(nchw_rows(y, y.dtype), B, h, w, int(size[0]), int(size[1]))
 
 
+def fused_loss(y, target, weight=(0.9, 1.1)):
+    """The caller's `criterion(model(...), target)` (train.py:221-224; losses.py:7-11) on the LOW-resolution decoder output y
+    ((B, 2, h, w)-shaped): bilinear upsample to target.shape[-2:] + weighted cross-entropy + I/U counts in one kernel pair.
+    -> (loss, stats[loss, sum of weights, I, U])"""
+    B, _, h, w = y.shape
+    return ops.upsample_cross_entropy(nchw_rows(y, y.dtype), target, B, h, w, int(target.shape[-2]), int(target.shape[-1]), weight)
+
+
 class _LAVTSimpleDecode(nn.Module):
     def __init__(self, backbone, classifier):
         super().__init__()
         self.backbone = backbone
         self.classifier = classifier
 
-    def forward(self, x, l_feats, l_mask):
-        input_shape = x.shape[-2:]
+    def forward_lowres(self, x, l_feats, l_mask):
+        """decoder output before the final upsample, (B, 2, H/4, W/4)-shaped: feed it to `fused_loss`"""
         x_c1, x_c2, x_c3, x_c4 = self.backbone(x, l_feats, l_mask)
-        y = self.classifier(x_c4, x_c3, x_c2, x_c1)
-        return _upsample_logits(y, input_shape)
+        return self.classifier(x_c4, x_c3, x_c2, x_c1)
+
+    def forward(self, x, l_feats, l_mask):
+        return _upsample_logits(self.forward_lowres(x, l_feats, l_mask), x.shape[-2:])
 
 
 class LAVT(_LAVTSimpleDecode):

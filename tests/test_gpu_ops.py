@@ -407,3 +407,35 @@ def test_cpu_tensor_is_refused():
     from lavt_hip import ops
     with pytest.raises(RuntimeError, match="GPU memory only"):
         ops.linear(torch.zeros(8, 8), torch.zeros(8, 8))
+
+
+# ------------------------------------------------------------------------------------------------ fused upsample + CE + I/U
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,Hi,Wi,Ho,Wo", [(2, 16, 16, 64, 64), (1, 30, 30, 120, 117), (2, 7, 9, 28, 36), (1, 120, 120, 480, 480)])
+def test_upsample_cross_entropy(dtype, B, Hi, Wi, Ho, Wo):
+    """fused bilinear(align_corners) upsample + F.cross_entropy(weight=[0.9, 1.1]) + I/U counts vs the unfused torch ops
+    (lib/_utils.py:21, losses.py:7-11, train.py:64-76); some targets carry the ignore value"""
+    from lavt_hip import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B * Hi * Wi, 2, generator=g)
+    tgt = torch.randint(0, 2, (B, Ho, Wo), generator=g)
+    tgt[0, :2, :3] = -100
+    if dtype == torch.bfloat16:
+        x = x.to(dtype).float()
+    xr = x.clone().requires_grad_(True)
+    up = F.interpolate(xr.view(B, Hi, Wi, 2).permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=True)
+    ref = F.cross_entropy(up, tgt, weight=torch.tensor([0.9, 1.1]))
+    (3.0 * ref).backward()
+    pred = up.argmax(1)
+    I, U = int(((pred == 1) & (tgt == 1)).sum()), int(((pred == 1) | (tgt == 1)).sum())
+    xg = x.to(dev()).to(dtype).requires_grad_(True)
+    loss, stats = ops.upsample_cross_entropy(xg, tgt.to(dev()), B, Hi, Wi, Ho, Wo, (0.9, 1.1))
+    (3.0 * loss).backward()
+    stats = stats.cpu()
+    assert abs(float(loss) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref)))
+    assert abs(float(stats[1]) - float(torch.tensor([0.9, 1.1])[tgt[tgt >= 0]].sum())) <= 1e-3 * float(stats[1])
+    # identical inputs on both sides; a pixel whose two upsampled logits agree to the last ulp may flip with the FMA contraction (1 of 173 541 seen)
+    assert abs(int(stats[2]) - I) <= 2 and abs(int(stats[3]) - U) <= 2
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    err = float((xg.grad.float().cpu() - xr.grad).abs().max()) / float(xr.grad.abs().max())
+    assert err <= tol, err
