@@ -5,7 +5,7 @@
 Workload (BASELINE.json metric: train images/s, 480x480 Swin-B LAVT): Swin-B window-12 LAVT, bf16 compute,
 batch 2 per GPU (configs[2] of BASELINE.json, the per-GPU shard of the headline config; weak scaling), synthetic
 480x480 images + 20-token language embeddings, deterministic random-init weights.  One step = forward +
-weighted cross-entropy + backward (+ gradient all-reduce when N > 1); the optimizer is excluded.
+weighted cross-entropy (fused with the final upsample: lavt_upsample_ce_*) + backward (+ gradient all-reduce when N > 1); the optimizer is excluded.
 
 Prints ONE JSON line on rank 0 with the driver's contract plus
   "roofline":     the dominant kernel (bf16 MFMA implicit-GEMM 3x3 conv, decoder conv2_2 shape) timed live with HIP events,
@@ -169,7 +169,7 @@ def main():
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": a.workload, "global_batch": cfg["batch"] * world, "image": cfg["size"], "n_l": 20,
                        "parallelism": f"dp{world}", "hip_graph": bool(step.captured), "drop_path": a.drop_path,
-                       "loss": round(loss, 5), "step_tflops_3x_fwd": round(train_tflops, 2),
+                       "loss": round(loss, 5), "loss_kernel": "fused upsample+CE" if step.fused_loss else "torch CE", "step_tflops_3x_fwd": round(train_tflops, 2),
                        "mfma_frac_of_step": round(train_tflops / world / BF16_DENSE_PEAK_TFLOPS, 4)},
         }
         try:
