@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--drop-path", type=float, default=0.3)
     a = ap.parse_args()
 
@@ -156,6 +157,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     loss = float(step.loss)
+    opt_ms = None
+    if rank == 0 and not a.no_optimizer:
+        # the caller's optimizer step (train.py:688-700), reported separately: fused multi-tensor AdamW over the same gradients
+        from lavt_hip.optim import FusedAdamW, lavt_param_groups
+        opt = FusedAdamW(lavt_param_groups(model), lr=0.0, weight_decay=1e-2, total_steps=1000)      # lr 0: leaves the weights alone
+        opt.step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            opt.step(check_tables=False)
+        e1.record()
+        torch.cuda.synchronize()
+        opt_ms = e0.elapsed_time(e1) / 10
 
     if rank == 0:
         images = cfg["batch"] * world * a.steps
@@ -169,7 +184,7 @@ def main():
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": a.workload, "global_batch": cfg["batch"] * world, "image": cfg["size"], "n_l": 20,
                        "parallelism": f"dp{world}", "hip_graph": bool(step.captured), "drop_path": a.drop_path,
-                       "loss": round(loss, 5), "loss_kernel": "fused upsample+CE" if step.fused_loss else "torch CE", "step_tflops_3x_fwd": round(train_tflops, 2),
+                       "loss": round(loss, 5), "loss_kernel": "fused upsample+CE" if step.fused_loss else "torch CE", "optimizer_ms_separate": None if opt_ms is None else round(opt_ms, 3), "step_tflops_3x_fwd": round(train_tflops, 2),
                        "mfma_frac_of_step": round(train_tflops / world / BF16_DENSE_PEAK_TFLOPS, 4)},
         }
         try:

@@ -265,6 +265,12 @@ int lavt_nhwc_to_nchw(int src_dtype, const void* src, int dst_dtype, void* dst, 
 int lavt_pack_conv3x3(const float* w, int dtype, void* packed, int Cout, int Cin, int taps, void* stream);
 /* many small fp32 -> dtype casts in one launch: desc = int64 triples (src_ptr, dst_ptr, n) on the DEVICE */
 int lavt_cast_multi(const int64_t* desc, int count, int dst_dtype, void* stream);
+/* The caller's optimizer step (train.py:688-700: torch.optim.AdamW, amsgrad off, + LambdaLR((1 - it/T)^0.9)) as one
+ * multi-tensor launch.  desc: int64 [count][5] = {param, grad, exp_avg, exp_avg_sq (fp32 device pointers), numel}; hyper: fp32 [count][5] =
+ * {base lr, weight decay, beta1, beta2, eps} (both tables in device memory); step: device fp32 scalar = optimizer steps taken so far,
+ * incremented by the call (so a captured hipGraph keeps advancing its schedule); lr = base lr * (1 - step/total_steps)^power, or the
+ * base lr when total_steps <= 0.  Update rule identical to torch.optim.AdamW (decoupled decay, bias-corrected moments). */
+int lavt_adamw_step(const int64_t* desc, const float* hyper, int count, float* step, float total_steps, float power, void* stream);
 
 #ifdef __cplusplus
 }

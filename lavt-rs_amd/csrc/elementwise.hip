@@ -399,6 +399,47 @@ template <typename T> __global__ void pack_conv3x3_kernel(const float* w, T* pac
         packed[i] = from_f<T>(w[((int64_t)co * Cin + ci) * taps + tap]);
     }
 }
+// ---- multi-tensor AdamW with the poly learning-rate schedule of the caller (train.py:688-700: torch.optim.AdamW + LambdaLR((1 - it/T)^0.9)).
+// One launch for the whole parameter list: blockIdx.y = tensor, descriptor {param, grad, exp_avg, exp_avg_sq, numel} (fp32 pointers),
+// per-tensor hyper-parameters {base_lr, weight_decay, beta1, beta2, eps}.  The step counter lives on the device (incremented by
+// adamw_tick_kernel), so the optimizer step can be part of the captured hipGraph and still advance its schedule on every replay.
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const int64_t* __restrict__ desc, const float* __restrict__ hyper, int count,
+                                                          const float* __restrict__ step, float total_steps, float power) {
+    const int t = blockIdx.y;
+    if (t >= count) return;
+    float* p = reinterpret_cast<float*>(desc[5 * t]);
+    const float* g = reinterpret_cast<const float*>(desc[5 * t + 1]);
+    float* m = reinterpret_cast<float*>(desc[5 * t + 2]);
+    float* v = reinterpret_cast<float*>(desc[5 * t + 3]);
+    const int64_t n = desc[5 * t + 4];
+    const float b1 = hyper[5 * t + 2], b2 = hyper[5 * t + 3], eps = hyper[5 * t + 4], wd = hyper[5 * t + 1];
+    const float k = step[0];                                       // optimizer steps taken so far
+    const float sched = total_steps > 0.f ? powf(fmaxf(1.f - k / total_steps, 0.f), power) : 1.f;
+    const float lr = hyper[5 * t] * sched;
+    const float bc1 = 1.f - powf(b1, k + 1.f), bc2 = 1.f - powf(b2, k + 1.f);
+    const float step_size = lr / bc1, rbc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        pp *= decay;
+        mm = b1 * mm + (1.f - b1) * gg;
+        vv = b2 * vv + (1.f - b2) * gg * gg;
+        pp -= step_size * mm / (sqrtf(vv) * rbc2 + eps);
+    };
+    const bool vec = ((desc[5 * t] | desc[5 * t + 1] | desc[5 * t + 2] | desc[5 * t + 3]) & 15) == 0;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        GRID_STRIDE(i, n4) {
+            float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+            const float4 gg = reinterpret_cast<const float4*>(g)[i];
+            upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+            reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+        }
+        for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) upd(p[i], g[i], m[i], v[i]);
+    } else {
+        GRID_STRIDE(i, n) upd(p[i], g[i], m[i], v[i]);
+    }
+}
+__global__ void adamw_tick_kernel(float* step) { step[0] += 1.f; }
+
 template <typename D> __global__ void cast_multi_kernel(const int64_t* desc, int count) {
     // blockIdx.y = tensor; grid-stride over its elements
     const int t = blockIdx.y;
@@ -577,5 +618,13 @@ extern "C" int lavt_cast_multi(const int64_t* desc, int count, int dst_dtype, vo
     if (dst_dtype == LAVT_F32) hipLaunchKernelGGL(cast_multi_kernel<float>, grid, dim3(256), 0, ST, desc, count);
     else hipLaunchKernelGGL(cast_multi_kernel<bf16>, grid, dim3(256), 0, ST, desc, count);
     LAVT_CHECK_LAUNCH("lavt_cast_multi");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_adamw_step(const int64_t* desc, const float* hyper, int count, float* step, float total_steps, float power, void* stream) {
+    LAVT_CHECK_ARG(desc && hyper && step && count > 0, "lavt_adamw_step: bad arguments");
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(256, count), dim3(256), 0, ST, desc, hyper, count, step, total_steps, power);      // small tensors: surplus workgroups exit at once
+    hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, ST, step);
+    LAVT_CHECK_LAUNCH("lavt_adamw_step");
     return LAVT_OK;
 }

@@ -439,3 +439,69 @@ def test_upsample_cross_entropy(dtype, B, Hi, Wi, Ho, Wo):
     tol = 1e-5 if dtype == torch.float32 else 1e-2
     err = float((xg.grad.float().cpu() - xr.grad).abs().max()) / float(xr.grad.abs().max())
     assert err <= tol, err
+
+
+# ------------------------------------------------------------------------------------------------ fused AdamW + poly schedule
+def _adamw_problem():
+    g = torch.Generator().manual_seed(11)
+    shapes = [(33, 17), (128,), (5, 3, 3, 3), (1000, 64), (7,)]
+    params = [torch.randn(*s, generator=g) for s in shapes]
+    grads = [[torch.randn(*s, generator=g) * (0.1 + k) for s in shapes] for k in range(6)]
+    return params, grads
+
+
+def test_fused_adamw_matches_torch():
+    """lavt_adamw_step vs torch.optim.AdamW + LambdaLR((1 - it/T)^0.9) (train.py:688-700): 6 steps, 3 groups (one without weight decay)"""
+    from lavt_hip.optim import FusedAdamW
+    params, grads = _adamw_problem()
+    T = 10
+
+    def groups(ps):
+        return [{"params": ps[:2], "weight_decay": 0.0}, {"params": ps[2:4]}, {"params": ps[4:], "lr": 3e-3}]
+    ref_p = [torch.nn.Parameter(p.clone()) for p in params]
+    ref = torch.optim.AdamW(groups(ref_p), lr=1e-2, weight_decay=0.05)
+    sched = torch.optim.lr_scheduler.LambdaLR(ref, lambda x: (1 - x / T) ** 0.9)
+    our_p = [torch.nn.Parameter(p.clone().to(dev())) for p in params]
+    ours = FusedAdamW(groups(our_p), lr=1e-2, weight_decay=0.05, total_steps=T, power=0.9)
+    for k in range(6):
+        for p, q, gr in zip(ref_p, our_p, grads[k]):
+            p.grad = gr.clone()
+            q.grad = gr.clone().to(dev())
+        ref.step()
+        sched.step()
+        ours.step()
+        for p, q in zip(ref_p, our_p):
+            err = float((q.detach().cpu() - p.detach()).abs().max())
+            assert err <= 2e-6 * max(1.0, float(p.abs().max())), (k, err)
+    assert ours.steps_taken() == 6 and abs(ours.current_lr_factor() - (1 - 6 / T) ** 0.9) < 1e-6
+    sd = ours.state_dict()
+    assert set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"} and sd["lavt_schedule"]["steps_taken"] == 6
+    again = FusedAdamW(groups([torch.nn.Parameter(p.detach().clone()) for p in our_p]), lr=1e-2, weight_decay=0.05)
+    again.load_state_dict(sd)
+    assert again.steps_taken() == 6 and again.total_steps == T
+
+
+def test_fused_adamw_in_hip_graph():
+    """the device-side step counter keeps the schedule moving when the optimizer step is replayed from a captured hipGraph"""
+    from lavt_hip.optim import FusedAdamW
+    params, grads = _adamw_problem()
+    eager_p = [torch.nn.Parameter(p.clone().to(dev())) for p in params]
+    graph_p = [torch.nn.Parameter(p.clone().to(dev())) for p in params]
+    for ps in (eager_p, graph_p):
+        for q, gr in zip(ps, grads[0]):
+            q.grad = gr.clone().to(dev())
+    eager = FusedAdamW(eager_p, lr=1e-2, total_steps=8)
+    captured = FusedAdamW(graph_p, lr=1e-2, total_steps=8)
+    for _ in range(4):
+        eager.step()
+    captured.step()                                   # builds the tables outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        captured.step(check_tables=False)
+    for _ in range(3):                                # capture itself executes nothing
+        g.replay()
+    torch.cuda.synchronize()
+    assert captured.steps_taken() == 4
+    for p, q in zip(eager_p, graph_p):
+        assert float((p - q).abs().max()) <= 1e-7 * max(1.0, float(p.abs().max()))
