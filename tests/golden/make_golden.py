@@ -114,6 +114,7 @@ def grad_digest(t, n=24):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only-video", action="store_true")
+    ap.add_argument("--only-checkpoint", action="store_true")
     cli = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -125,6 +126,9 @@ def main():
     from lib import _utils as ru
     if cli.only_video:
         video_cases(args)
+        return
+    if cli.only_checkpoint:
+        checkpoint_cases()
         return
 
     # --- window attention, with/without mask, both window sizes ------------------------------
@@ -276,6 +280,7 @@ def main():
          nograd=np.array(nograd), **digests)
     print("   tiny: params without grad:", nograd)
     video_cases(args)
+    checkpoint_cases()
 
 
 def video_cases(args_base):
@@ -385,6 +390,54 @@ def _ref_mask(rb, Hp, Wp, ws):
     st.fusion = lambda x, l, m: x
     st(torch.zeros(1, Hp * Wp, 1), Hp, Wp, None, None)
     return captured["m"]
+
+
+
+def checkpoint_cases():
+    """Checkpoint surgery of the reference loaders on a synthetic checkpoint (mmcv_custom/checkpoint.py:287-360, video :759-805/:830-844)."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(HERE))
+    from synth_ckpt import synthetic_swin_checkpoint
+    import lib.backbone as rb
+    import lib.video_swin_transformer as rv
+    from lib.mmcv_custom import load_checkpoint
+    import logging
+    a = ref_args()
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        # 2-D: window-5 tables into a window-7 model, 'module.backbone.' prefixes
+        path = os.path.join(td, "swin2d.pth")
+        torch.save({"state_dict": synthetic_swin_checkpoint()}, path)
+        bb = rb.MultiModalSwinTransformer(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=7, ape=False, drop_path_rate=0.0,
+                                          patch_norm=True, use_checkpoint=False, num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=a)
+        fill_state_dict_(bb)
+        load_checkpoint(bb, path, strict=False, logger=logging.getLogger("ref"))
+        sd = bb.state_dict()
+        for k in ("layers.0.blocks.1.attn.relative_position_bias_table", "layers.3.blocks.0.attn.relative_position_bias_table",
+                  "layers.2.blocks.1.attn.qkv.weight", "patch_embed.proj.weight", "layers.1.blocks.0.mlp.fc1.weight"):
+            out["swin2d|" + k] = sd[k].clone()
+        # 3-D from a 2-D checkpoint (inflate) and from a 3-D checkpoint (temporal sum of the patch embedding)
+        rv.sr_ratio = [1, 1, 1, 1]
+        for tag, ck in (("inflate", {"model": synthetic_swin_checkpoint(prefix="")}),
+                        ("video3d", {"state_dict": {("backbone." + k): v for k, v in synthetic_swin_checkpoint(prefix="", patch_t=2, ws=7, index_n=392).items()}})):
+            path = os.path.join(td, tag + ".pth")
+            if tag == "video3d":      # a 3-D checkpoint carries (2Wd-1)(2Wh-1)(2Ww-1) tables already
+                for k in list(ck["state_dict"]):
+                    if "relative_position_bias_table" in k:
+                        ck["state_dict"][k] = ck["state_dict"][k].repeat(15, 1)
+            torch.save(ck, path)
+            b3 = rv.MultiModalSwinTransformer3D(pretrained=path, pretrained2d=(tag == "inflate"), patch_size=(1, 4, 4), embed_dim=32, depths=[2, 2, 2, 2],
+                                                num_heads=[1, 2, 4, 8], window_size=(8, 7, 7), drop_path_rate=0.0, patch_norm=True, out_indices=(0, 1, 2, 3),
+                                                use_checkpoint=False, num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=a)
+            fill_state_dict_(b3)
+            if tag == "inflate":
+                b3.inflate_weights()
+            else:
+                b3.init_weights()
+            sd = b3.state_dict()
+            for k in ("layers.0.blocks.1.attn.relative_position_bias_table", "layers.2.blocks.0.attn.qkv.weight", "patch_embed.proj.weight"):
+                out[tag + "|" + k] = sd[k].clone()
+    save("checkpoint_surgery", **out)
 
 
 if __name__ == "__main__":

@@ -149,3 +149,53 @@ def test_video_unsupported_fusions_fail_loudly():
     from lib import segmentation
     with pytest.raises(NotImplementedError):
         segmentation.lavt_video("", SimpleNamespace(swin_type="tiny", ts_pwam=True, conv3d_kernel_size="3-1-1"))
+
+
+# ---------------------------------------------------------------------------------------------------- checkpoint surgery
+def test_checkpoint_loaders_match_reference(golden, tmp_path):
+    """lavt_hip.checkpoint vs the reference's loaders run on the same synthetic checkpoints (mmcv_custom/checkpoint.py:287-360: prefix
+    stripping + bicubic table resize; video_swin_transformer.py:759-805 inflate, :830-844 temporal sum of the 3-D patch embedding)"""
+    from lavt_hip import checkpoint as ck
+    from lavt_hip.detweights import fill_state_dict_
+    from lib.backbone import MultiModalSwinTransformer
+    from lib.video_swin_transformer import MultiModalSwinTransformer3D
+    from synth_ckpt import synthetic_swin_checkpoint
+    g = golden("checkpoint_surgery")
+    a = SimpleNamespace()
+    path = str(tmp_path / "swin2d.pth")
+    torch.save({"state_dict": synthetic_swin_checkpoint()}, path)
+    bb = MultiModalSwinTransformer(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=7, ape=False, drop_path_rate=0.0,
+                                   patch_norm=True, use_checkpoint=False, num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=a)
+    fill_state_dict_(bb)
+    missing, unexpected = ck.load_swin_checkpoint(bb, path)
+    assert unexpected == ["norm.weight"] and "layers.0.fusion.vis_project.0.weight" in missing and "layers.0.blocks.0.attn.qkv.weight" not in missing
+    sd = bb.state_dict()
+    for k in [k for k in g.files if k.startswith("swin2d|")]:
+        assert np.array_equal(sd[k.split("|")[1]].numpy(), g[k]), k
+    for tag, ckd in (("inflate", {"model": synthetic_swin_checkpoint(prefix="")}),
+                     ("video3d", {"state_dict": {("backbone." + k): v for k, v in synthetic_swin_checkpoint(prefix="", patch_t=2, ws=7, index_n=392).items()}})):
+        if tag == "video3d":
+            for k in list(ckd["state_dict"]):
+                if "relative_position_bias_table" in k:
+                    ckd["state_dict"][k] = ckd["state_dict"][k].repeat(15, 1)
+        path = str(tmp_path / (tag + ".pth"))
+        torch.save(ckd, path)
+        b3 = MultiModalSwinTransformer3D(patch_size=(1, 4, 4), embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=(8, 7, 7),
+                                         drop_path_rate=0.0, patch_norm=True, out_indices=(0, 1, 2, 3), use_checkpoint=False,
+                                         num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=a)
+        fill_state_dict_(b3)
+        ck.load_video_swin_checkpoint(b3, path, inflate_2d=(tag == "inflate"))
+        sd = b3.state_dict()
+        for k in [k for k in g.files if k.startswith(tag + "|")]:
+            assert np.array_equal(sd[k.split("|")[1]].numpy(), g[k]), k
+
+
+def test_init_weights_loads_a_checkpoint_path(tmp_path):
+    """the factories' `pretrained` argument goes through the same loaders (lib/segmentation.py:59-64)"""
+    from lib import segmentation
+    from synth_ckpt import synthetic_swin_checkpoint
+    path = str(tmp_path / "swin_tiny_window5.pth")
+    torch.save({"model": synthetic_swin_checkpoint(embed=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), prefix="")}, path)
+    model = segmentation.lavt(path, SimpleNamespace(swin_type="tiny"))
+    want = synthetic_swin_checkpoint(embed=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), prefix="")["layers.2.blocks.3.attn.qkv.weight"]
+    assert torch.equal(model.backbone.layers[2].blocks[3].attn.qkv.weight.detach(), want)
