@@ -59,6 +59,7 @@ class GradBuckets:
             self.expected[self.bucket_of[p]] += 1
         self.launched = [False] * len(self.buckets)
         self.works = []
+        self._seen = set()
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self.fused = fused_accumulation
@@ -81,6 +82,7 @@ class GradBuckets:
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self.works = []
+        self._seen = set()
 
     def _is_view(self, p):
         lo = self.flat.data_ptr()
@@ -95,6 +97,12 @@ class GradBuckets:
         p.grad = self.flat[off:off + p.numel()].view_as(p)
 
     def _on_grad(self, p):
+        # A parameter can report twice in one backward: once from the fused-accumulation path (ops.sinks.done, right after its
+        # weight-gradient kernel is enqueued) and once from autograd's post-accumulate hook, which PyTorch also runs when the
+        # op returned no gradient tensor.  Count each parameter once per step, or a bucket is reduced before it is complete.
+        if id(p) in self._seen:
+            return
+        self._seen.add(id(p))
         b = self.bucket_of[p]
         self.pending[b] += 1
         if self.pending[b] == self.expected[b] and not self.launched[b]:
@@ -106,7 +114,10 @@ class GradBuckets:
             return
         s, e = self.buckets[b]
         chunk = self.flat[s:e]
-        if self.comm_stream is not None:
+        mode = os.environ.get("LAVT_DDP_MODE", "async_side")
+        if self.comm_stream is not None and mode == "sync_main":
+            dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
+        elif self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             if self.fused:
                 from . import ops
@@ -114,7 +125,10 @@ class GradBuckets:
                     for st in lst:
                         self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
-                self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+                if mode == "sync_side":
+                    dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
+                else:
+                    self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
         else:                                           # gloo (CPU tests): no AVG op
             w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.works.append((w, chunk))

@@ -6,9 +6,14 @@
 The whole step is ~2,000 kernel launches for Swin-B; issued from Python it is launch-bound, so on one GPU the
 step is captured once into a hipGraph (torch.cuda.CUDAGraph on the stream our C-ABI launches go to) and
 replayed: weight casts, DropPath masks, BatchNorm running-stat updates all happen inside the graph.
-With world > 1 the collectives (SyncBN statistics, gradient buckets) stay outside graphs (RCCL calls are
-issued eagerly) and the step runs eagerly with the bucketed all-reduce overlapping backward.
+With world > 1 the same capture includes the collectives: the SyncBN statistic all-reduces on the capture stream and the
+bucketed gradient all-reduces on the communication stream (forked from / joined to the capture stream with events), so a
+replay issues forward, backward and the overlapped RCCL all-reduces without any Python in between.  RCCL supports stream
+capture (its collectives become graph kernel nodes); `tools/nccl_graph_probe.py` and tests/test_gpu_modules.py exercise the
+mechanics on one GPU in a 1-rank group.  LAVT_DDP_GRAPH=0 (or a failed capture) falls back to eager launching, where the
+step is bound by the ~23 ms of host-side launch work.
 """
+import os
 import sys
 
 import torch
@@ -29,7 +34,7 @@ class TrainStep:
         self.world = world
         self.graph = None
         self.loss = None
-        self.use_graph = use_graph and world == 1
+        self.use_graph = use_graph and (world == 1 or os.environ.get("LAVT_DDP_GRAPH", "1") != "0")
         self.captured = False
         self.fused_loss = fused_loss and hasattr(model, "forward_lowres")
         self.stats = None                        # fused loss: [loss, sum of weights, I, U] of the last step (device tensor)
@@ -45,6 +50,7 @@ class TrainStep:
             loss = F.cross_entropy(out, self.t, weight=self.w)
         loss.backward()
         ops.side.join()                          # wgrad GEMMs ran on side streams: join before the step (or the graph capture) ends
+        self.buckets.finish()                    # stragglers (never-used parameters) + join of the communication stream
         return loss.detach()
 
     def warmup_and_capture(self, eager_iters=3):
@@ -53,7 +59,6 @@ class TrainStep:
         with torch.cuda.stream(s):
             for _ in range(eager_iters):
                 self.loss = self._body()
-                self.buckets.finish()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         ops.weights.build_multicast(compute_dtype())
@@ -75,5 +80,4 @@ class TrainStep:
             self.graph.replay()
         else:
             self.loss = self._body()
-            self.buckets.finish()
         return self.loss

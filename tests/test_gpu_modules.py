@@ -336,3 +336,42 @@ def test_video_bf16_close_to_fp32(golden, tag):
     ref = torch.as_tensor(g["logits"])
     rng = float(ref.max() - ref.min())
     assert float((logits - ref).abs().max()) <= 0.08 * rng
+
+
+# ================================================================================================ DDP plumbing on one GPU
+def test_ddp_step_graph_equals_eager_in_one_rank_group():
+    """The N>1 code path (SyncBN statistic all-reduces, bucketed gradient all-reduces on the communication stream) run in a 1-rank RCCL
+    group, eagerly and captured into a hipGraph: identical gradients.  (Multi-rank behaviour itself is covered by the gloo tests.)"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LAVT_FORCE_COLLECTIVES="1")
+        sys.path[:0] = [%r, %r]
+        import lavt_hip
+        from types import SimpleNamespace
+        from lavt_hip.detweights import det_inputs, fill_state_dict_
+        from lavt_hip.engine import TrainStep
+        from lib import segmentation
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        lavt_hip.set_compute_dtype(torch.bfloat16)
+        res = []
+        for use_graph in (False, True):
+            model = segmentation.lavt("", SimpleNamespace(swin_type="tiny", drop_path_rate=0.0))
+            fill_state_dict_(model)
+            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model.cuda()).train()
+            x, l, m, t = det_inputs(2, 96, 20, seed=3)
+            step = TrainStep(model, x.cuda(), l.cuda(), m.cuda(), t.cuda(), world=2, use_graph=use_graph)
+            step.warmup_and_capture(eager_iters=2)
+            assert step.captured == use_graph, "capture failed"
+            step.step(); step.step()
+            torch.cuda.synchronize()
+            res.append((float(step.loss), step.buckets.flat.clone()))
+        dist.destroy_process_group()
+        (l0, g0), (l1, g1) = res
+        err = float((g0 - g1).abs().max()) / float(g0.abs().max())
+        print("RESULT", l0, l1, err)
+        assert abs(l0 - l1) < 1e-6 and err < 1e-6, (l0, l1, err)
+    """) % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lavt-rs_amd"), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]

@@ -199,3 +199,23 @@ def test_init_weights_loads_a_checkpoint_path(tmp_path):
     model = segmentation.lavt(path, SimpleNamespace(swin_type="tiny"))
     want = synthetic_swin_checkpoint(embed=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), prefix="")["layers.2.blocks.3.attn.qkv.weight"]
     assert torch.equal(model.backbone.layers[2].blocks[3].attn.qkv.weight.detach(), want)
+
+
+def test_grad_buckets_count_each_parameter_once():
+    """A parameter may report 'gradient ready' twice per backward (fused accumulation + autograd's post-accumulate hook, which PyTorch runs
+    even when the op returned no gradient tensor): a bucket must not launch before ALL of its parameters have reported."""
+    from lavt_hip.ddp import GradBuckets
+    net = torch.nn.Sequential(*[torch.nn.Linear(8, 8) for _ in range(4)])
+    gb = GradBuckets(net, bucket_mib=1.0)
+    assert len(gb.buckets) == 1
+    gb.zero()
+    ps = list(net.parameters())
+    for p in ps[: len(ps) // 2]:
+        gb._on_grad(p)
+        gb._on_grad(p)                     # second report of the same parameter
+    assert gb.launched == [False] and gb.pending == [len(ps) // 2]
+    for p in ps[len(ps) // 2:]:
+        gb._on_grad(p)
+    assert gb.launched == [True]
+    gb.zero()
+    assert gb.pending == [0] and gb.launched == [False]
