@@ -139,6 +139,19 @@ def main():
     x, l, m, tgt = det_inputs(cfg["batch"], cfg["size"], 20, seed=1234 + rank)
     step = TrainStep(model, x.to(device), l.to(device), m.to(device), tgt.to(device), world=2 if force else world, use_graph=not a.no_graph)
     step.warmup_and_capture()
+    if world > 1 and step.captured:
+        # first replays of a graph that contains RCCL collectives: bound the damage if a rank never comes back (cannot be tried on the 1-GPU box)
+        import threading
+        done = threading.Event()
+
+        def _watch():
+            if not done.wait(300.0):
+                print("[bench] the captured multi-rank step did not complete within 300 s; set LAVT_DDP_GRAPH=0 to launch eagerly", file=sys.stderr, flush=True)
+                os._exit(5)
+        threading.Thread(target=_watch, daemon=True).start()
+        step.step()
+        torch.cuda.synchronize()
+        done.set()
 
     for _ in range(a.warmup):
         step.step()
