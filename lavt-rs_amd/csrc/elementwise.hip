@@ -325,12 +325,12 @@ template <typename T> __global__ __launch_bounds__(256) void cls_head_bwd_kernel
     constexpr int EPC = Chunk<T>::N;
     const int cpr = C / EPC;
     const int tc = threadIdx.x % cpr, tr = threadIdx.x / cpr, rstep = blockDim.x / cpr;
-    if (tr >= rstep) return;
+    const bool live = tr < rstep;
     float w0[EPC], w1[EPC], g0[EPC], g1[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { w0[e] = w[tc * EPC + e]; w1[e] = w[C + tc * EPC + e]; g0[e] = 0.f; g1[e] = 0.f; }
     float b0 = 0.f, b1 = 0.f;
-    for (int64_t row = (int64_t)blockIdx.x * rstep + tr; row < rows; row += (int64_t)gridDim.x * rstep) {
+    for (int64_t row = (int64_t)blockIdx.x * rstep + tr; live && row < rows; row += (int64_t)gridDim.x * rstep) {
         const float d0 = to_f<T>(dy[row * 2]), d1 = to_f<T>(dy[row * 2 + 1]);
         float f[EPC], o[EPC];
         chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + row * C + tc * EPC), f);
@@ -339,9 +339,18 @@ template <typename T> __global__ __launch_bounds__(256) void cls_head_bwd_kernel
         *reinterpret_cast<uint4*>(dx + row * C + tc * EPC) = f_to_chunk<T>(o);
         if (tc == 0) { b0 += d0; b1 += d1; }
     }
+    // combine the row-lanes of the workgroup in LDS first: 2*C (+2) atomics per workgroup instead of per row-lane
+    __shared__ float red[2 * 2048 + 2];
+    for (int e = threadIdx.x; e < 2 * C + 2; e += blockDim.x) red[e] = 0.f;
+    __syncthreads();
+    if (live) {
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { atomicAdd(dw + tc * EPC + e, g0[e]); atomicAdd(dw + C + tc * EPC + e, g1[e]); }
-    if (tc == 0) { atomicAdd(db, b0); atomicAdd(db + 1, b1); }
+        for (int e = 0; e < EPC; ++e) { atomicAdd(red + tc * EPC + e, g0[e]); atomicAdd(red + C + tc * EPC + e, g1[e]); }
+        if (tc == 0) { atomicAdd(red + 2 * C, b0); atomicAdd(red + 2 * C + 1, b1); }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) atomicAdd(dw + e, red[e]);
+    if (threadIdx.x < 2) atomicAdd(db + threadIdx.x, red[2 * C + threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------- patch-embed im2col (4x4 / stride 4)
@@ -551,10 +560,10 @@ extern "C" int lavt_cls_head_fwd(int dtype, const void* x, const float* w, const
 extern "C" int lavt_cls_head_bwd(int dtype, const void* x, const void* dy, const float* w, void* dx, float* dw, float* db,
                                  int64_t rows, int C, void* stream) {
     const int cpr = C / EPC_OF(dtype);
-    LAVT_CHECK_ARG(x && dy && w && dx && dw && db && rows > 0 && C % EPC_OF(dtype) == 0 && cpr <= 256, "lavt_cls_head_bwd: bad arguments");
+    LAVT_CHECK_ARG(x && dy && w && dx && dw && db && rows > 0 && C % EPC_OF(dtype) == 0 && cpr <= 256 && C <= 2048, "lavt_cls_head_bwd: bad arguments");
     const int rstep = 256 / cpr;
-    int blocks = cdiv(rows, (long)rstep * 64);
-    if (blocks > 128) blocks = 128;       // few workgroups: each ends with 2*C atomics
+    int blocks = cdiv(rows, (long)rstep * 16);
+    if (blocks > 512) blocks = 512;       // each workgroup ends with 2*C atomics (after an LDS combine of its row-lanes)
     if (blocks < 1) blocks = 1;
     DISPATCH_T(dtype, "lavt_cls_head_bwd", hipLaunchKernelGGL(cls_head_bwd_kernel<T>, dim3(blocks), dim3(256), 0, ST, (const T*)x, (const T*)dy, w, (T*)dx, dw, db, rows, C));
     LAVT_CHECK_LAUNCH("lavt_cls_head_bwd");

@@ -310,28 +310,41 @@ __global__ void stats_finalize_kernel(const float* sum, const float* m2, float c
     if (running_var) running_var[i] = (1.f - momentum) * running_var[i] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
 }
 
+// Apply kernels: a thread owns one 16-byte channel chunk of a group and walks rows, so the per-channel constants (mean, rstd, gamma, beta,
+// backward sums) sit in registers instead of being re-fetched for every element (the element-indexed form ran at ~0.9 TB/s on the
+// 28 800 x 512 decoder maps).  grid = (row blocks, groups); columns beyond 256 chunks are walked in slabs.
 template <typename T>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const T* __restrict__ mul, int relu, T* __restrict__ y, int rows, int C, int64_t nchunks) {
+                                                         const T* __restrict__ mul, int relu, T* __restrict__ y, int rows, int C, int rows_per_block) {
     constexpr int EPC = Chunk<T>::N;
-    const int cpr = C / EPC;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % cpr) * EPC;
-        const int64_t g = (i / cpr) / rows;
-        float f[EPC];
-        chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + i * EPC), f);
-        float fm[EPC];
-        if (mul) chunk_to_f<T>(*reinterpret_cast<const uint4*>(mul + i * EPC), fm);
+    const int cpr = C / EPC, g = blockIdx.y;
+    const int r_begin = blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
+    for (int cbase = 0; cbase < cpr; cbase += 256) {
+        const int span = min(256, cpr - cbase);
+        const int tc = threadIdx.x % span, tr = threadIdx.x / span, rstep = 256 / span;
+        if (tr >= rstep) continue;
+        const int col = (cbase + tc) * EPC;
+        float mu[EPC], rs[EPC], ga[EPC], be[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            float v = (f[e] - mean[g * C + col + e]) * rstd[g * C + col + e];
-            if (gamma) v = v * gamma[col + e] + beta[col + e];
-            if (mul) v *= fm[e];
-            if (relu) v = fmaxf(v, 0.f);
-            f[e] = v;
+            mu[e] = mean[(int64_t)g * C + col + e]; rs[e] = rstd[(int64_t)g * C + col + e];
+            ga[e] = gamma ? gamma[col + e] : 1.f; be[e] = gamma ? beta[col + e] : 0.f;
         }
-        *reinterpret_cast<uint4*>(y + i * EPC) = f_to_chunk<T>(f);
+        for (int r = r_begin + tr; r < r_end; r += rstep) {
+            const int64_t off = ((int64_t)g * rows + r) * C + col;
+            float f[EPC], fm[EPC];
+            chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + off), f);
+            if (mul) chunk_to_f<T>(*reinterpret_cast<const uint4*>(mul + off), fm);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float v = (f[e] - mu[e]) * rs[e] * ga[e] + be[e];
+                if (mul) v *= fm[e];
+                if (relu) v = fmaxf(v, 0.f);
+                f[e] = v;
+            }
+            *reinterpret_cast<uint4*>(y + off) = f_to_chunk<T>(f);
+        }
     }
 }
 
@@ -341,31 +354,49 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const T* __restrict__ mul, int relu, const float* __restrict__ s1,
                                                              const float* __restrict__ s2, float inv_count, T* __restrict__ dx,
-                                                             T* __restrict__ dmul, int rows, int C, int64_t nchunks) {
+                                                             T* __restrict__ dmul, int rows, int C, int rows_per_block) {
     constexpr int EPC = Chunk<T>::N;
-    const int cpr = C / EPC;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % cpr) * EPC;
-        const int64_t g = (i / cpr) / rows;
-        float fg[EPC], fx[EPC], fm[EPC], fy[EPC], fdm[EPC];
-        chunk_to_f<T>(*reinterpret_cast<const uint4*>(dy + i * EPC), fg);
-        chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + i * EPC), fx);
-        if (mul) chunk_to_f<T>(*reinterpret_cast<const uint4*>(mul + i * EPC), fm);
-        if (relu) chunk_to_f<T>(*reinterpret_cast<const uint4*>(yout + i * EPC), fy);
+    const int cpr = C / EPC, g = blockIdx.y;
+    const int r_begin = blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
+    for (int cbase = 0; cbase < cpr; cbase += 256) {
+        const int span = min(256, cpr - cbase);
+        const int tc = threadIdx.x % span, tr = threadIdx.x / span, rstep = 256 / span;
+        if (tr >= rstep) continue;
+        const int col = (cbase + tc) * EPC;
+        float mu[EPC], rs[EPC], ga[EPC], be[EPC], a1[EPC], a2[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const int64_t sc = g * C + col + e;
-            const float rs = rstd[sc];
-            const float xh = (fx[e] - mean[sc]) * rs;
-            float gg = fg[e];
-            if (mul) { fdm[e] = gg * (gamma ? xh * gamma[col + e] + beta[col + e] : xh); gg *= fm[e]; }
-            if (relu && !(fy[e] > 0.f)) gg = 0.f;
-            const float ga = gamma ? gamma[col + e] : 1.f;
-            fg[e] = ga * rs * (gg - s1[sc] * inv_count - xh * s2[sc] * inv_count);
+            const int64_t sc = (int64_t)g * C + col + e;
+            mu[e] = mean[sc]; rs[e] = rstd[sc]; a1[e] = s1[sc] * inv_count; a2[e] = s2[sc] * inv_count;
+            ga[e] = gamma ? gamma[col + e] : 1.f; be[e] = gamma ? beta[col + e] : 0.f;
         }
-        *reinterpret_cast<uint4*>(dx + i * EPC) = f_to_chunk<T>(fg);
-        if (mul && dmul) *reinterpret_cast<uint4*>(dmul + i * EPC) = f_to_chunk<T>(fdm);
+        for (int r = r_begin + tr; r < r_end; r += rstep) {
+            const int64_t off = ((int64_t)g * rows + r) * C + col;
+            float fg[EPC], fx[EPC], fm[EPC], fy[EPC], fdm[EPC];
+            chunk_to_f<T>(*reinterpret_cast<const uint4*>(dy + off), fg);
+            chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + off), fx);
+            if (mul) chunk_to_f<T>(*reinterpret_cast<const uint4*>(mul + off), fm);
+            if (relu) chunk_to_f<T>(*reinterpret_cast<const uint4*>(yout + off), fy);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float xh = (fx[e] - mu[e]) * rs[e];
+                float gg = fg[e];
+                if (mul) { fdm[e] = gg * (xh * ga[e] + be[e]); gg *= fm[e]; }
+                if (relu && !(fy[e] > 0.f)) gg = 0.f;
+                fg[e] = ga[e] * rs[e] * (gg - a1[e] - xh * a2[e]);
+            }
+            *reinterpret_cast<uint4*>(dx + off) = f_to_chunk<T>(fg);
+            if (mul && dmul) *reinterpret_cast<uint4*>(dmul + off) = f_to_chunk<T>(fdm);
+        }
     }
+}
+
+// rows per workgroup for the apply kernels: ~2k workgroups in total, at least one full pass of the 256 threads over their rows
+static int apply_rows_per_block(int rows, int groups, int C, int epc) {
+    const int cpr = C / epc, span = cpr < 256 ? cpr : 256, rstep = 256 / span;
+    int rpb = cdiv((long)rows * groups, 2048);
+    if (rpb < 4 * rstep) rpb = 4 * rstep;
+    return rpb;
 }
 
 inline int ew_grid(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
@@ -450,10 +481,10 @@ extern "C" int lavt_norm_apply(int dtype, const void* x, const float* mean, cons
                                const void* mul, int relu, void* y, int groups, int rows, int C, void* stream) {
     const int epc = dtype == LAVT_F32 ? 4 : 8;
     LAVT_CHECK_ARG(x && mean && rstd && y && groups > 0 && rows > 0 && C % epc == 0 && (!gamma == !beta), "lavt_norm_apply: bad arguments");
-    const int64_t nchunks = (int64_t)groups * rows * (C / epc);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rpb = apply_rows_per_block(rows, groups, C, epc);
     DISPATCH_T(dtype, "lavt_norm_apply",
-               hipLaunchKernelGGL(norm_apply_kernel<T>, dim3(ew_grid(nchunks)), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, (const T*)mul, relu, (T*)y, rows, C, nchunks));
+               hipLaunchKernelGGL(norm_apply_kernel<T>, dim3(cdiv(rows, rpb), groups), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, (const T*)mul, relu, (T*)y, rows, C, rpb));
     LAVT_CHECK_LAUNCH("lavt_norm_apply");
     return LAVT_OK;
 }
@@ -481,11 +512,11 @@ extern "C" int lavt_norm_bwd_apply(int dtype, const void* dy, const void* x, con
                                    float count, void* dx, void* dmul, int groups, int rows, int C, void* stream) {
     const int epc = dtype == LAVT_F32 ? 4 : 8;
     LAVT_CHECK_ARG(dy && x && mean && rstd && s1 && s2 && dx && (!relu || y) && count > 0 && C % epc == 0, "lavt_norm_bwd_apply: bad arguments");
-    const int64_t nchunks = (int64_t)groups * rows * (C / epc);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rpb = apply_rows_per_block(rows, groups, C, epc);
     DISPATCH_T(dtype, "lavt_norm_bwd_apply",
-               hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(ew_grid(nchunks)), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y, mean, rstd, gamma, beta,
-                                  (const T*)mul, relu, s1, s2, 1.f / count, (T*)dx, (T*)dmul, rows, C, nchunks));
+               hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(cdiv(rows, rpb), groups), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y, mean, rstd, gamma, beta,
+                                  (const T*)mul, relu, s1, s2, 1.f / count, (T*)dx, (T*)dmul, rows, C, rpb));
     LAVT_CHECK_LAUNCH("lavt_norm_bwd_apply");
     return LAVT_OK;
 }
