@@ -73,16 +73,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     }
 }
 
-template <typename T, int LPR>
+template <typename T, int LPR, int CPL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const int32_t* __restrict__ gather, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ partials, int rows, int C) {
-    constexpr int EPC = Chunk<T>::N, MAXC = LPR == 64 ? LN_MAXE / EPC : 1, RPW = 64 / LPR;   // dispatch: LPR < 64 only when one chunk per lane suffices
+    // CPL = chunks per lane (compile time: the row arrays are exactly as large as needed; LPR < 64 only with CPL == 1)
+    constexpr int EPC = Chunk<T>::N, MAXC = CPL, RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, lir = lane % LPR, wave = threadIdx.x >> 6;
     const int nchunk = C / EPC;
-    const int cpl = (nchunk + LPR - 1) / LPR;          // chunks per lane actually used (<= MAXC by dispatch)
+    constexpr int cpl = CPL;
     float dg[MAXC * EPC], db[MAXC * EPC];
 #pragma unroll
     for (int e = 0; e < MAXC * EPC; ++e) { dg[e] = 0.f; db[e] = 0.f; }
@@ -431,12 +432,15 @@ extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nchunk = C / epc;
     const int lpr = nchunk <= 16 ? 16 : nchunk <= 32 ? 32 : 64;
-    int blocks = cdiv(rows, 4 * (64 / lpr) * 4);
-    if (blocks > 512) blocks = 512;
+    const int cpl = cdiv(nchunk, lpr);                       // 1 (C <= 512 bf16 / 256 fp32), 2, or up to 4 / 8
+    int blocks = cdiv(rows, 4 * (64 / lpr) * 2);             // two rows per wave: the step's LayerNorms have 450 .. 28 800 rows
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     float* partials = (ws && ws_floats >= (int64_t)blocks * 2 * C) ? ws : nullptr;
-#define LN_BWD(LPR_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, rows, C)
-    DISPATCH_T(dtype, "lavt_layernorm_bwd", if (lpr == 16) LN_BWD(16); else if (lpr == 32) LN_BWD(32); else LN_BWD(64));
+#define LN_BWD(LPR_, CPL_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_, CPL_>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, rows, C)
+    DISPATCH_T(dtype, "lavt_layernorm_bwd",
+               if (lpr == 16) LN_BWD(16, 1); else if (lpr == 32) LN_BWD(32, 1);
+               else if (cpl == 1) LN_BWD(64, 1); else if (cpl == 2) LN_BWD(64, 2); else if (cpl <= 4) LN_BWD(64, 4); else LN_BWD(64, 8));
 #undef LN_BWD
     if (partials) hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, partials, blocks, 2 * C, C, dgamma, dbeta);
     LAVT_CHECK_LAUNCH("lavt_layernorm_bwd");
