@@ -25,12 +25,16 @@ for p in (ROOT, os.path.join(ROOT, "lavt-rs_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FWD_GFLOP_PER_IMAGE = {"swin_b_w12_480": 394.57, "swin_t_w7_480": 172.43}      # SURVEY.md 8 (2*MAC, padded tokens counted)
+FWD_GFLOP_PER_IMAGE = {"swin_b_w12_480": 394.57, "swin_t_w7_480": 172.43,        # SURVEY.md 8 (2*MAC, padded tokens counted)
+                       "video_swin_b_t8_384": 2071.5 / 8, "video_swin_b_t8_384_sept": 3115.2 / 8}   # per frame (G/clip / 8)
 BF16_DENSE_PEAK_TFLOPS = 2500.0                                                 # MI355X_MICROARCH.md (dense, no sparsity)
 
 WORKLOADS = {
     "swin_b_w12_480_b2": dict(variant="base", window12=True, batch=2, size=480, flops="swin_b_w12_480"),
     "swin_t_w7_480_b8": dict(variant="tiny", window12=False, batch=8, size=480, flops="swin_t_w7_480"),
+    # BASELINE.json configs[3]: Video-Swin-B LAVT, one clip of T=8 frames at 384x384 per GPU (metric counts frames); PWAM / README SepTPWAM recipe
+    "video_swin_b_t8_384": dict(variant="base", video=True, frames=8, batch=1, size=384, flops="video_swin_b_t8_384", sept=False),
+    "video_swin_b_t8_384_sept": dict(variant="base", video=True, frames=8, batch=1, size=384, flops="video_swin_b_t8_384_sept", sept=True),
 }
 
 
@@ -38,10 +42,35 @@ def build_model(cfg, device, drop_path=0.3):
     from types import SimpleNamespace
     from lavt_hip.detweights import fill_state_dict_
     from lib import segmentation
-    args = SimpleNamespace(swin_type=cfg["variant"], window12=cfg["window12"], drop_path_rate=drop_path)
-    model = segmentation.lavt("", args)
+    if cfg.get("video"):
+        flags = dict(sep_t_pwam=True, conv3d_kernel_size_t="3-3-3", conv3d_kernel_size_s="1-1-1", w_t3x3_s1x1=True, mm_t3x3_s1x1=True) if cfg["sept"] else {}
+        from lib.mask_predictor import SimpleDecoding
+        from lib.video_swin_transformer import MultiModalSwinTransformer3D
+        a = SimpleNamespace(**flags)
+        bb = MultiModalSwinTransformer3D(patch_size=(1, 4, 4), embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=(8, 7, 7),
+                                         drop_path_rate=drop_path, patch_norm=True, out_indices=(0, 1, 2, 3), num_heads_fusion=[1, 1, 1, 1], args=a)
+        model = _VideoStep(bb, SimpleDecoding(1024, a))         # lavt_video without the BERT encoder: language features are the input, as for `lavt`
+    else:
+        args = SimpleNamespace(swin_type=cfg["variant"], window12=cfg["window12"], drop_path_rate=drop_path)
+        model = segmentation.lavt("", args)
     fill_state_dict_(model)
     return model.to(device)
+
+
+class _VideoStep(torch.nn.Module):
+    """LAVTVideo.forward_backbone as a (clip, l_feats, l_mask) -> low-resolution logits module for the step harness"""
+
+    def __init__(self, backbone, classifier):
+        super().__init__()
+        self.backbone, self.classifier = backbone, classifier
+
+    def forward_lowres(self, x, l, m):
+        f = self.backbone(x.permute(0, 2, 1, 3, 4), l, m)
+        return self.classifier(f[3], f[2], f[1], f[0])
+
+    def forward(self, x, l, m):
+        from lib._utils import _upsample_logits
+        return _upsample_logits(self.forward_lowres(x, l, m), x.shape[-2:])
 
 
 def measure_dominant_kernel(device, iters=20):
@@ -136,7 +165,7 @@ def main():
     if world > 1 or force:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)       # train.py:589
     model.train()
-    x, l, m, tgt = det_inputs(cfg["batch"], cfg["size"], 20, seed=1234 + rank)
+    x, l, m, tgt = det_inputs(cfg["batch"], cfg["size"], 20, seed=1234 + rank, frames=cfg.get("frames", 0))
     step = TrainStep(model, x.to(device), l.to(device), m.to(device), tgt.to(device), world=2 if force else world, use_graph=not a.no_graph)
     step.warmup_and_capture()
     if world > 1 and step.captured:
@@ -186,12 +215,13 @@ def main():
         opt_ms = e0.elapsed_time(e1) / 10
 
     if rank == 0:
-        images = cfg["batch"] * world * a.steps
+        images = cfg["batch"] * max(cfg.get("frames", 0), 1) * world * a.steps
         value = images / elapsed
         ms = elapsed / a.steps * 1e3
         train_tflops = 3.0 * FWD_GFLOP_PER_IMAGE[cfg["flops"]] * 1e-3 * value
         out = {
-            "metric": "train images/sec (480x480 Swin-B LAVT, fwd+bwd)" if cfg["variant"] == "base" else "train images/sec (480x480 Swin-T LAVT, fwd+bwd)",
+            "metric": ("train frames/sec (384x384 Video-Swin-B LAVT, T=8, fwd+bwd)" if cfg.get("video") else
+                       "train images/sec (480x480 Swin-B LAVT, fwd+bwd)" if cfg["variant"] == "base" else "train images/sec (480x480 Swin-T LAVT, fwd+bwd)"),
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
@@ -204,7 +234,7 @@ def main():
             out["roofline"] = measure_dominant_kernel(device)
         except Exception as e:  # noqa: BLE001
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not cfg.get("video"):
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

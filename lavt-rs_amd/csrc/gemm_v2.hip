@@ -602,6 +602,10 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     const char* wv = getenv("LAVT_GEMM_WAVES");
     const int waves = wv ? atoi(wv) : 8;
 #define GO(BM_, BN_, KM_, ST_, WV_) return launch_nt_v2<BM_, BN_, KM_, ST_, WV_>(p, st)
+    // 128x256 tile, 8 waves of 64x64: fewer LDS bytes (DMA fill and fragment reads) per MFMA than 128x128; for the long-K, many-tile problems
+    const long tiles256 = (long)cdiv(p.M, 128) * cdiv(p.N, 256) * p.batch;
+    const bool wide = force ? force == 256 : (getenv("LAVT_GEMM_WIDE") != nullptr && tiles256 >= 256 && p.N % 256 == 0 && p.K >= 1024);
+    if (wide) { if (p.b_kmajor) GO(128, 256, true, 2, 8); else GO(128, 256, false, 2, 8); }
     if (big) {
         if (waves == 8) {
             if (stages == 2) { if (p.b_kmajor) GO(128, 128, true, 2, 8); else GO(128, 128, false, 2, 8); }
