@@ -146,6 +146,11 @@ typedef struct lavt_gemm_tn {
 } lavt_gemm_tn_t;
 
 int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);
+/* n (<= 4) independent problems of the family in one call, e.g. the four weight gradients of a Swin block: when they qualify (bf16, no
+ * conv taps / concat, batch 1, together >= 256 64x64 output tiles) they run as ONE launch without split-K -- every output element then has
+ * a single writer, and with accumulate == 0 it is stored plainly instead of added through fp32 atomics; otherwise they are issued one by
+ * one exactly as lavt_gemm_tn would. */
+int lavt_gemm_tn_grouped(const lavt_gemm_tn_t* probs, int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Shifted-window attention core (WindowAttention.forward, lib/backbone.py:123-140; mask :634-652).

@@ -460,3 +460,21 @@ extern "C" int lavt_gemm_tn(const lavt_gemm_tn_t* pp, void* stream) {
     if (rc2 != 1) return rc2;
     return p.dtype == LAVT_F32 ? dispatch_tn<float>(p, st) : dispatch_tn<bf16>(p, st);
 }
+
+int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st);
+// n independent weight-gradient problems issued together: one grouped launch without split-K when they qualify (bf16, plain / row-mapped
+// operands, >= 256 output tiles in total), else one lavt_gemm_tn call each.  Results are identical either way up to fp32 summation order.
+extern "C" int lavt_gemm_tn_grouped(const lavt_gemm_tn_t* probs, int n, void* stream) {
+    LAVT_CHECK_ARG(probs != nullptr && n >= 1, "lavt_gemm_tn_grouped: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    bool ok = true;
+    for (int i = 0; i < n; ++i) ok = ok && probs[i].A && probs[i].B && probs[i].C && probs[i].I > 0 && probs[i].J > 0 && probs[i].K > 0;
+    LAVT_CHECK_ARG(ok, "lavt_gemm_tn_grouped: null operand / bad shape");
+    const int rc = lavt_gemm_tn_grouped_v2(probs, n, st);
+    if (rc != 1) return rc;
+    for (int i = 0; i < n; ++i) {
+        const int r = lavt_gemm_tn(&probs[i], stream);
+        if (r != LAVT_OK) return r;
+    }
+    return LAVT_OK;
+}

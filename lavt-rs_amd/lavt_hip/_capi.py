@@ -52,6 +52,7 @@ _PROTOTYPES = {
     "lavt_abi_version": [],
     "lavt_gemm_nt": [C.POINTER(GemmNT), vp],
     "lavt_gemm_tn": [C.POINTER(GemmTN), vp],
+    "lavt_gemm_tn_grouped": [C.POINTER(GemmTN), i32, vp],
     "lavt_window_attn_fwd": [i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "lavt_window_attn_bwd": [i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "lavt_relpos_expand": [vp, vp, i32, i32, i32, i32, i32, i32, vp],

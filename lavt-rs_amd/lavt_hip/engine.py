@@ -36,6 +36,7 @@ class TrainStep:
         self.loss = None
         self.use_graph = use_graph and (world == 1 or os.environ.get("LAVT_DDP_GRAPH", "1") != "0")
         self.captured = False
+        ops.wgrads.enabled = True                # one weight gradient per parameter per step into the zeroed flat buffer: grouped, plainly stored
         self.fused_loss = fused_loss and hasattr(model, "forward_lowres")
         self.stats = None                        # fused loss: [loss, sum of weights, I, U] of the last step (device tensor)
 
@@ -49,6 +50,7 @@ class TrainStep:
             out = self.model(self.x, self.l, self.m)
             loss = F.cross_entropy(out, self.t, weight=self.w)
         loss.backward()
+        ops.wgrads.flush()                       # weight-gradient GEMMs still queued for a grouped launch
         ops.side.join()                          # wgrad GEMMs ran on side streams: join before the step (or the graph capture) ends
         self.buckets.finish()                    # stragglers (never-used parameters) + join of the communication stream
         return loss.detach()

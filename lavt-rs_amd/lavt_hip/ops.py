@@ -234,7 +234,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
 
 def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, strideB=0, strideC=0, a_rowmap=None,
             a_rowscale=None, a_rowscale_div=1, a_rowscale_binary=False, accumulate=False, B2=None, ldb2=0, b_split=0, b_rowmap=None, conv=None, alpha=1.0, c_conv_permute=False, colsum=None,
-            strideColsum=0, a_off=0, b_off=0, c_off=0):
+            strideColsum=0, a_off=0, b_off=0, c_off=0, defer=None):
     es = 4 if dtype == torch.float32 else 2
     assert Cout.dtype == torch.float32
     p = K.GemmTN()
@@ -252,7 +252,47 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.c_conv_permute, p.split_k = int(c_conv_permute), 0
     p.colsum, p.strideColsum = K.ptr(colsum), strideColsum
     p.zeros = _zero_page(A.device)
+    if defer is not None:
+        defer.add(p, (A, B, Cout, a_rowmap, a_rowscale, b_rowmap, colsum))
+        return
     K.check(K.lib.lavt_gemm_tn(C.byref(p), K.stream()))
+
+
+class _WgradQueue:
+    """Weight-gradient GEMMs of consecutive backward ops (the four Linear layers of a Swin block) are collected and issued as ONE grouped
+    launch (lavt_gemm_tn_grouped): together they fill the chip without split-K, so the gradients are stored plainly instead of going
+    through fp32 atomics.  Only used when gradients accumulate into the step harness' flat buffer (ops.sinks) in `exclusive` mode: every
+    parameter receives exactly one weight gradient per step into a buffer that was zeroed at the start of the step, so store == accumulate.
+    `on_ready` notifications (DDP buckets) are held back until the group has been enqueued."""
+
+    def __init__(self):
+        self.enabled = False
+        self.items, self.keep, self.ready = [], [], []
+
+    def active(self):
+        return self.enabled and sinks.map and os.environ.get("LAVT_WGRAD_GROUP", "1") != "0"
+
+    def add(self, p, tensors):
+        self.items.append(p)
+        self.keep.append(tensors)
+        if len(self.items) == 4:
+            self.flush()
+
+    def notify(self, param):
+        self.ready.append(param)
+
+    def flush(self):
+        if self.items:
+            arr = (K.GemmTN * len(self.items))(*self.items)
+            K.check(K.lib.lavt_gemm_tn_grouped(arr, len(self.items), K.stream()))
+        ready = self.ready
+        self.items, self.keep, self.ready = [], [], []
+        for prm in ready:
+            if sinks.on_ready is not None:
+                sinks.on_ready(prm)
+
+
+wgrads = _WgradQueue()
 
 
 def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -324,13 +364,22 @@ class _Linear(torch.autograd.Function):
             if bias is not None and ctx.needs_input_grad[2]:
                 bbuf, bsink = sinks.buf(bias, (N,))
             binary = o.row_scale is not None and o.row_scale_value != 0.0
-            side.run(lambda: gemm_tn(dtype, N, Kd, M, g, N, x, Kd, wbuf, Kd, a_rowmap=o.out_map, a_rowscale=o.row_scale,
-                                     a_rowscale_div=o.row_scale_div, a_rowscale_binary=binary,
-                                     alpha=o.row_scale_value if binary else 1.0, b_rowmap=o.in_map, colsum=bbuf),
-                     (g, x), wsink and (bbuf is None or bsink))
-            dW = sinks.done(weight, wbuf, wsink)
-            if bbuf is not None:
-                db = sinks.done(bias, bbuf, bsink)
+            grouped = wgrads.active() and wsink and (bbuf is None or bsink) and dtype == torch.bfloat16 and (o.row_scale is None or binary)
+            if grouped:                         # joins the block's grouped launch; the parameters report ready when it is enqueued
+                gemm_tn(dtype, N, Kd, M, g, N, x, Kd, wbuf, Kd, a_rowmap=o.out_map, a_rowscale=o.row_scale, a_rowscale_div=o.row_scale_div,
+                        a_rowscale_binary=binary, alpha=o.row_scale_value if binary else 1.0, b_rowmap=o.in_map, colsum=bbuf, defer=wgrads)
+                wgrads.notify(weight)
+                if bbuf is not None:
+                    wgrads.notify(bias)
+                dW = db = None
+            else:
+                side.run(lambda: gemm_tn(dtype, N, Kd, M, g, N, x, Kd, wbuf, Kd, a_rowmap=o.out_map, a_rowscale=o.row_scale,
+                                         a_rowscale_div=o.row_scale_div, a_rowscale_binary=binary,
+                                         alpha=o.row_scale_value if binary else 1.0, b_rowmap=o.in_map, colsum=bbuf),
+                         (g, x), wsink and (bbuf is None or bsink))
+                dW = sinks.done(weight, wbuf, wsink)
+                if bbuf is not None:
+                    db = sinks.done(bias, bbuf, bsink)
         d_res = dy if ctx.has_res and ctx.needs_input_grad[3] else None
         return dx, dW, db, d_res, None
 

@@ -505,3 +505,39 @@ def test_fused_adamw_in_hip_graph():
     assert captured.steps_taken() == 4
     for p, q in zip(eager_p, graph_p):
         assert float((p - q).abs().max()) <= 1e-7 * max(1.0, float(p.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------ grouped weight-gradient launch
+def test_gemm_tn_grouped_matches_individual():
+    """lavt_gemm_tn_grouped (one launch, no split-K, plain stores) vs the same problems through lavt_gemm_tn: a Swin block's four weight
+    gradients incl. a gathered operand, a row mask folded into alpha and a bias column sum"""
+    import ctypes as C
+    from lavt_hip import _capi as K, ops
+    g = torch.Generator().manual_seed(21)
+    M, Mw, Cc = 1800, 2592, 512
+    bf = torch.bfloat16
+    wmap = torch.randint(0, M, (Mw,), generator=g, dtype=torch.int32).to(dev())
+    mask = (torch.rand(2, generator=g) > 0.3).float().to(dev())               # per-sample DropPath mask (0 / 1), value folded into alpha
+    probs = []          # (I, J, Kd, A, B, kwargs)
+    def mk(rows, cols):
+        return (torch.randn(rows, cols, generator=g) * 0.5).to(dev()).to(bf)
+    probs.append((4 * Cc, Cc, M, mk(M, 4 * Cc), mk(M, Cc), dict()))                                              # fc1
+    probs.append((Cc, 4 * Cc, M, mk(M, Cc), mk(M, 4 * Cc), dict(a_rowscale=mask, a_rowscale_div=M // 2, a_rowscale_binary=True, alpha=1.25)))   # fc2 + DropPath
+    probs.append((3 * Cc, Cc, Mw, mk(Mw, 3 * Cc), mk(M, Cc), dict(b_rowmap=wmap)))                               # qkv (gathered input)
+    probs.append((Cc, Cc, Mw, mk(M, Cc), mk(Mw, Cc), dict(a_rowmap=wmap)))                                       # proj (gathered gradient)
+    outs_ref, outs_grp, structs, keep = [], [], [], []
+    class _Q:
+        def add(self, p, t): structs.append(p); keep.append(t)
+    for I, J, Kd, A, B, kw in probs:
+        ref = torch.zeros(I, J, device=dev()); cs_ref = torch.zeros(I, device=dev())
+        ops.gemm_tn(bf, I, J, Kd, A, I, B, J, ref, J, colsum=cs_ref, **kw)
+        out = torch.zeros(I, J, device=dev()); cs = torch.zeros(I, device=dev())
+        ops.gemm_tn(bf, I, J, Kd, A, I, B, J, out, J, colsum=cs, defer=_Q(), **kw)
+        outs_ref.append((ref, cs_ref)); outs_grp.append((out, cs))
+    arr = (K.GemmTN * len(structs))(*structs)
+    K.check(K.lib.lavt_gemm_tn_grouped(arr, len(structs), K.stream()))
+    torch.cuda.synchronize()
+    for (r, cr), (o, co) in zip(outs_ref, outs_grp):
+        scale = float(r.abs().max())
+        assert float((r - o).abs().max()) <= 2e-3 * scale, float((r - o).abs().max()) / scale        # fp32 summation order only
+        assert float((cr - co).abs().max()) <= 2e-3 * float(cr.abs().max())
