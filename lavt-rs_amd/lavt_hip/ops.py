@@ -605,6 +605,16 @@ def instance_norm(x, B, T, mul=None):
     return _InstanceNorm.apply(x, mul, B, T)
 
 
+def combine_rank_stats(allst: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
+    """allst [world, 2, ...]: every rank's (sum x, centred second moment M2 = sum (x - mean_rank)^2) over its `rows_per_rank` rows
+    -> [2, ...] the same two quantities over all ranks' rows (parallel-variance combination; no E[x^2] - E[x]^2 anywhere)."""
+    world = allst.shape[0]
+    tot = allst[:, 0].sum(0)
+    gmean = tot / float(rows_per_rank * world)
+    m2 = allst[:, 1].sum(0) + rows_per_rank * ((allst[:, 0] / rows_per_rank - gmean) ** 2).sum(0)
+    return torch.stack([tot, m2])
+
+
 class _BatchNormRelu(torch.autograd.Function):
     """BatchNorm2d + ReLU on NHWC rows [R, C].  training: batch statistics (all-reduced over `group` when given =
     SyncBatchNorm semantics, train.py:589), running stats updated in place; eval: running statistics."""
@@ -620,13 +630,14 @@ class _BatchNormRelu(torch.autograd.Function):
         if training:
             s = _stats(x, 1, R, Cc)                          # [sum x, centred second moment] of the local rows
             if group is not None:
+                # ONE collective: gather every rank's (sum, centred M2) and combine them locally (Chan et al.): with equal row counts
+                # per rank, sum = sum_r sum_r and M2 = sum_r M2_r + R * sum_r (mean_r - mean)^2
                 import torch.distributed as dist
                 world = dist.get_world_size(group)
-                local_mean = s[0] / R
-                dist.all_reduce(s[0], group=group)
+                allst = torch.empty(world, 2, 1, Cc, dtype=torch.float32, device=dev)
+                dist.all_gather_into_tensor(allst, s.contiguous(), group=group)
                 count = float(R * world)
-                s[1] += R * (local_mean - s[0] / count) ** 2      # re-centre about the global mean, then the moments add up
-                dist.all_reduce(s[1], group=group)
+                s = combine_rank_stats(allst, R)
             K.check(K.lib.lavt_stats_finalize(K.ptr(s[0]), K.ptr(s[1]), count, eps, K.ptr(mean), K.ptr(rstd), K.ptr(running_mean),
                                               K.ptr(running_var), momentum, Cc, K.stream()))
         else:

@@ -219,3 +219,17 @@ def test_grad_buckets_count_each_parameter_once():
     assert gb.launched == [True]
     gb.zero()
     assert gb.pending == [0] and gb.launched == [False]
+
+
+def test_syncbn_rank_statistics_combination():
+    """SyncBN forward: the ranks' (sum, centred M2) pairs, gathered with ONE collective, combine to the statistics of the whole batch --
+    also when the channel means are large compared with the spread (no E[x^2] - E[x]^2 cancellation)"""
+    from lavt_hip.ops import combine_rank_stats
+    g = torch.Generator().manual_seed(0)
+    world, R, C = 3, 50, 7
+    x = torch.randn(world, R, C, generator=g, dtype=torch.float64) * 0.01 + 100.0 * torch.arange(1, C + 1)
+    per_rank = torch.stack([torch.stack([x[r].sum(0), ((x[r] - x[r].mean(0)) ** 2).sum(0)]) for r in range(world)]).float()
+    s = combine_rank_stats(per_rank, R)
+    flat = x.reshape(world * R, C)
+    assert torch.allclose(s[0].double(), flat.sum(0), rtol=1e-6)
+    assert torch.allclose(s[1].double(), ((flat - flat.mean(0)) ** 2).sum(0), rtol=2e-3)
