@@ -180,12 +180,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // 32 columns x 8 row-slices per workgroup: coalesced 128-B reads, 8-way parallel walk over nblk, LDS combine.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int W, int C,
                                                               float* __restrict__ o1, float* __restrict__ o2) {
+    // blockIdx.y splits the nblk partial rows when there are many of them (the pieces then meet in the output through atomics)
     __shared__ float red[8][33];
     const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int w = blockIdx.x * 32 + col;
+    const int per = (nblk + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * per, k1 = min(nblk, k0 + per);
     float a = 0.f;
     if (w < W)
-        for (int k = slice; k < nblk; k += 8) a += partials[(int64_t)k * W + w];
+        for (int k = k0 + slice; k < k1; k += 8) a += partials[(int64_t)k * W + w];
     red[slice][col] = a;
     __syncthreads();
     if (slice == 0 && w < W) {
@@ -194,9 +196,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
         for (int k = 0; k < 8; ++k) t += red[k][col];
         const int g2 = w / C, c = w - g2 * C;          // g2 = 2*g + which
         float* dst = (g2 & 1) ? o2 : o1;
-        dst[(int64_t)(g2 >> 1) * C + c] += t;
+        if (gridDim.y > 1) atomicAdd(dst + (int64_t)(g2 >> 1) * C + c, t);
+        else dst[(int64_t)(g2 >> 1) * C + c] += t;
     }
 }
+static inline dim3 reduce_partials_grid(int nblk, int W) { return dim3(cdiv(W, 32), nblk >= 128 ? 4 : (nblk >= 48 ? 2 : 1)); }
 
 // ---------------------------------------------------------------------------------------------- column statistics
 // grid: (row blocks, groups).  Thread t owns chunk column t % cpr and walks rows t / cpr, + 256/cpr, ...
@@ -442,7 +446,7 @@ extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, cons
                if (lpr == 16) LN_BWD(16, 1); else if (lpr == 32) LN_BWD(32, 1);
                else if (cpl == 1) LN_BWD(64, 1); else if (cpl == 2) LN_BWD(64, 2); else if (cpl <= 4) LN_BWD(64, 4); else LN_BWD(64, 8));
 #undef LN_BWD
-    if (partials) hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, partials, blocks, 2 * C, C, dgamma, dbeta);
+    if (partials) hipLaunchKernelGGL(reduce_partials_kernel, reduce_partials_grid(blocks, 2 * C), dim3(256), 0, st, partials, blocks, 2 * C, C, dgamma, dbeta);
     LAVT_CHECK_LAUNCH("lavt_layernorm_bwd");
     return LAVT_OK;
 }
@@ -466,7 +470,7 @@ extern "C" int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq,
     DISPATCH_T(dtype, "lavt_colstats",
                hipLaunchKernelGGL((colstats_kernel<T, false>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
                                   (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, 0, sum, sumsq, partials, rows, C, rpb));
-    if (partials) hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(groups * 2 * C, 32)), dim3(256), 0, st, partials, blocks, groups * 2 * C, C, sum, sumsq);
+    if (partials) hipLaunchKernelGGL(reduce_partials_kernel, reduce_partials_grid(blocks, groups * 2 * C), dim3(256), 0, st, partials, blocks, groups * 2 * C, C, sum, sumsq);
     DISPATCH_T(dtype, "lavt_colstats",
                hipLaunchKernelGGL(colstats_center_kernel<T>, dim3(cdiv(groups * C, 256)), dim3(256), 0, st, (const T*)x, sum, sumsq, rows, C, groups * C));
     LAVT_CHECK_LAUNCH("lavt_colstats");
@@ -506,7 +510,7 @@ extern "C" int lavt_norm_bwd_stats(int dtype, const void* dy, const void* x, con
     DISPATCH_T(dtype, "lavt_norm_bwd_stats",
                hipLaunchKernelGGL((colstats_kernel<T, true>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
                                   (const T*)dy, (const T*)x, (const T*)y, mean, rstd, (const T*)mul, relu, s1, s2, partials, rows, C, rpb));
-    if (partials) hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(groups * 2 * C, 32)), dim3(256), 0, st, partials, blocks, groups * 2 * C, C, s1, s2);
+    if (partials) hipLaunchKernelGGL(reduce_partials_kernel, reduce_partials_grid(blocks, groups * 2 * C), dim3(256), 0, st, partials, blocks, groups * 2 * C, C, s1, s2);
     LAVT_CHECK_LAUNCH("lavt_norm_bwd_stats");
     return LAVT_OK;
 }
