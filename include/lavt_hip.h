@@ -159,21 +159,25 @@ int lavt_gemm_tn_grouped(const lavt_gemm_tn_t* probs, int n, void* stream);
  * of 16 -- 64 for 7x7, 160 for 12x12 windows -- lets the bf16 MFMA kernels run; padding columns hold -1e30).  region: optional int8
  * [nw_img][N] region ids of the shift mask (window w uses row w % nw_img); unequal ids add -100.
  * lse: fp32 [nwin][heads][N] log-sum-exp of each score row (saved for backward).
- * Forward, optional: table / (wd, wh, ww) as described for the backward (the bf16 MFMA kernel reads the bias from the table).
- * Backward: dqkv [nwin*N][3C] (every element written); dbias fp32 [heads][N][bias_ld] accumulates the dense relative-position-bias
- *   gradient (reduce it to the table with lavt_relpos_reduce).  Optional accelerators for the bf16 MFMA kernel (all or none):
- *   table = relative_position_bias_table fp32 [(2wd-1)(2wh-1)(2ww-1)][heads] with the FULL window shape (wd, wh, ww) (wd = 1 for the 2-D
- *   Swin; the kernel keeps the head's table column in LDS instead of reading the dense bias), and ws = fp32 scratch of
- *   >= nwin*heads*N*bias_ld floats (each (window, head) writes its dS slab with plain stores; a second kernel sums the slabs into dbias:
- *   no atomics, deterministic).  Without them the exact-fp32 formulation with global atomics runs.
+ * table = relative_position_bias_table fp32 [(2wd-1)(2wh-1)(2ww-1)][heads] with the FULL window shape (wd, wh, ww) (wd = 1 for the 2-D Swin;
+ *   a clipped video window has N < wd*wh*ww tokens and uses the top-left block of the index matrix).  The bf16 MFMA kernels (N <= 160)
+ *   keep the head's table column in LDS and never read the dense bias: `bias` may then be NULL; lavt_attn_uses_table(dtype, N) tells.
+ * Backward: dqkv [nwin*N][3C] (every element written); dtable accumulates the table gradient.  bf16 MFMA kernel: every (window, head)
+ *   writes its fp32 dS slab into ws (lavt_window_attn_bwd_ws floats; bias_ld = N rounded up to 64 / a multiple of 32) with plain stores;
+ *   two small kernels sum the slabs over windows, bin them by relative-position index and add the result to dtable (LDS float atomics inside the attention
+ *   kernel measured 37 of 57 us per window-head).  Exact-fp32 kernel: global atomics into dtable; needs the dense `bias`.
  * ------------------------------------------------------------------------------------------- */
 int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out,
                          float* lse, const float* table, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim, float scale,
                          void* stream);
 int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img,
-                         const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, const float* table,
+                         const void* out, const void* dout, const float* lse, void* dqkv, const float* table, float* dtable,
                          float* ws, int64_t ws_floats, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim, float scale,
                          void* stream);
+/* 1 when lavt_window_attn_fwd/bwd take the bias from the table for this (dtype, N) -- no dense bias / lavt_relpos_expand needed */
+int lavt_attn_uses_table(int dtype, int N);
+/* floats of scratch (`ws`) lavt_window_attn_bwd wants for these shapes: dS slabs + per-workgroup table histograms (0 for the exact-fp32 kernel) */
+int64_t lavt_window_attn_bwd_ws(int dtype, int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww);
 
 /* relative_position_bias_table[(2wd-1)(2wh-1)(2ww-1)][heads] -> dense bias[heads][N][ld]   (wd = 1 for the 2-D Swin; N <= wd*wh*ww tokens) (lib/backbone.py:89-103,125-127)
  * and its transpose (dense gradient -> table gradient, deterministic, accumulates into dtable). */

@@ -322,8 +322,9 @@ int launch_bwd(const void* qkv, const float* bias, int bias_ld, const int8_t* re
 int lavt_window_attn_fwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, void* out, float* lse,
                               int wd, int wh, int ww, int nwin, int N, int heads, float scale, hipStream_t st);
 int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, const void* out, const void* dout,
-                              const float* lse, void* dqkv, float* dbias, int bias_ld, float* ws, int wd, int wh, int ww, int nwin, int N,
+                              const float* lse, void* dqkv, float* dtable, int bias_ld, float* ws, int wd, int wh, int ww, int nwin, int N,
                               int heads, float scale, hipStream_t st);
+int64_t lavt_window_attn_bwd_ws_mfma(int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww);
 // LAVT_ATTN_SIMPLE=1 forces the VALU formulation for bf16 too (A/B tests of the MFMA kernels)
 static bool use_mfma(int dtype, int N, int bias_ld) {
     const char* e = getenv("LAVT_ATTN_SIMPLE");
@@ -334,11 +335,12 @@ extern "C" int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bia
                                     float* lse, const float* table, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim,
                                     float scale, void* stream) {
     LAVT_CHECK_ARG(head_dim == HD, "lavt_window_attn_fwd: head_dim %d != 32", head_dim);
-    LAVT_CHECK_ARG(qkv && bias && out && lse && nwin > 0 && N > 0 && heads > 0 && bias_ld >= N, "lavt_window_attn_fwd: bad arguments");
+    LAVT_CHECK_ARG(qkv && out && lse && nwin > 0 && N > 0 && heads > 0 && bias_ld >= N, "lavt_window_attn_fwd: bad arguments");
     LAVT_CHECK_ARG(!region || nw_img > 0, "lavt_window_attn_fwd: region needs nw_img");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (use_mfma(dtype, N, bias_ld) && table && wd > 0 && wh > 0 && ww > 0 && N <= wd * wh * ww)
         return lavt_window_attn_fwd_mfma(qkv, table, region, nw_img, out, lse, wd, wh, ww, nwin, N, heads, scale, st);
+    LAVT_CHECK_ARG(bias != nullptr, "lavt_window_attn_fwd: the exact-fp32 kernel needs the dense bias (lavt_relpos_expand)");
     if (dtype == LAVT_F32) return launch_fwd<float>(qkv, bias, bias_ld, region, nw_img, out, lse, nwin, N, heads, scale, st);
     if (dtype == LAVT_BF16) return launch_fwd<bf16>(qkv, bias, bias_ld, region, nw_img, out, lse, nwin, N, heads, scale, st);
     lavt_set_error("lavt_window_attn_fwd: bad dtype %d", dtype);
@@ -346,21 +348,27 @@ extern "C" int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bia
 }
 
 extern "C" int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img,
-                                    const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, const float* table,
+                                    const void* out, const void* dout, const float* lse, void* dqkv, const float* table, float* dtable,
                                     float* ws, int64_t ws_floats, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim,
                                     float scale, void* stream) {
     LAVT_CHECK_ARG(head_dim == HD, "lavt_window_attn_bwd: head_dim %d != 32", head_dim);
-    LAVT_CHECK_ARG(qkv && bias && out && dout && lse && dqkv && dbias && nwin > 0 && N > 0 && heads > 0 && bias_ld >= N, "lavt_window_attn_bwd: bad arguments");
+    LAVT_CHECK_ARG(qkv && out && dout && lse && dqkv && table && dtable && nwin > 0 && N > 0 && heads > 0, "lavt_window_attn_bwd: bad arguments");
+    LAVT_CHECK_ARG(wd > 0 && wh > 0 && ww > 0 && N <= wd * wh * ww, "lavt_window_attn_bwd: window shape (wd, wh, ww) must cover N tokens");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // the bf16 MFMA kernel takes the bias values from an LDS copy of the table and needs one fp32 [N][bias_ld] slab per (window, head)
-    const bool fast = use_mfma(dtype, N, bias_ld) && table && ws && wd > 0 && wh > 0 && ww > 0 && N <= wd * wh * ww &&
-                      ws_floats >= (int64_t)nwin * heads * N * bias_ld;
-    if (fast) return lavt_window_attn_bwd_mfma(qkv, table, region, nw_img, out, dout, lse, dqkv, dbias, bias_ld, ws, wd, wh, ww, nwin, N, heads, scale, st);
-    if (dtype == LAVT_F32) return launch_bwd<float>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, dbias, nullptr, 0, 0, 0, nwin, N, heads, scale, st);
-    if (dtype == LAVT_BF16) return launch_bwd<bf16>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, dbias, nullptr, 0, 0, 0, nwin, N, heads, scale, st);
+    const bool fast = use_mfma(dtype, N, bias_ld) && ws && ws_floats >= lavt_window_attn_bwd_ws_mfma(nwin, N, heads, bias_ld, wd, wh, ww);
+    if (fast) return lavt_window_attn_bwd_mfma(qkv, table, region, nw_img, out, dout, lse, dqkv, dtable, bias_ld, ws, wd, wh, ww, nwin, N, heads, scale, st);
+    LAVT_CHECK_ARG(bias && bias_ld >= N, "lavt_window_attn_bwd: the exact-fp32 kernel needs the dense bias (lavt_relpos_expand)");
+    if (dtype == LAVT_F32) return launch_bwd<float>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, nullptr, dtable, wd, wh, ww, nwin, N, heads, scale, st);
+    if (dtype == LAVT_BF16) return launch_bwd<bf16>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, nullptr, dtable, wd, wh, ww, nwin, N, heads, scale, st);
     lavt_set_error("lavt_window_attn_bwd: bad dtype %d", dtype);
     return LAVT_ERR_INVALID;
 }
+
+extern "C" int64_t lavt_window_attn_bwd_ws(int dtype, int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww) {
+    return use_mfma(dtype, N, bias_ld) ? lavt_window_attn_bwd_ws_mfma(nwin, N, heads, bias_ld, wd, wh, ww) : 0;
+}
+extern "C" int lavt_attn_uses_table(int dtype, int N) { return use_mfma(dtype, N, N <= 64 ? 64 : 160) ? 1 : 0; }
 
 extern "C" int lavt_relpos_expand(const float* table, float* dense, int wd, int wh, int ww, int N, int heads, int ld, void* stream) {
     LAVT_CHECK_ARG(table && dense && wd > 0 && wh > 0 && ww > 0 && N > 0 && N <= wd * wh * ww && heads > 0 && ld >= N, "lavt_relpos_expand: bad arguments");

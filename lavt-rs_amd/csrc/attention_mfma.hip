@@ -371,23 +371,68 @@ __global__ __launch_bounds__(WAVES * 64, 2) void wattn_bwd_mfma(const bf16* __re
     }
 }
 
-// dbias[h][i][j] += sum over windows of the per-(window, head) dS slabs: one float4 column per thread, blockIdx.y walks a group of windows
-// (one group: plain read-modify-write, deterministic; several groups: their partial sums meet in dbias through atomics)
-__global__ void wattn_dbias_sum(const float* __restrict__ slab, float* __restrict__ dbias, int nwin, int per_group, int64_t per_window4) {
-    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (e >= per_window4) return;
-    const int w0 = blockIdx.y * per_group, w1 = min(nwin, w0 + per_group);
-    const float4* s = reinterpret_cast<const float4*>(slab) + e;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int w = w0; w < w1; ++w) { const float4 v = s[(int64_t)w * per_window4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
-    float* d = dbias + 4 * e;
-    if (gridDim.y == 1) {
-        float4 o = *reinterpret_cast<float4*>(d);
-        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-        *reinterpret_cast<float4*>(d) = o;
-    } else {
-        atomicAdd(d, a.x); atomicAdd(d + 1, a.y); atomicAdd(d + 2, a.z); atomicAdd(d + 3, a.w);
+// Table gradient straight from the per-(window, head) dS slabs: dtable[idx][h] += sum_w sum_{(i,j): idx(i,j) = idx} slab[w][h][i][j].
+// grid = (row chunks, heads, window groups).  A wave walks rows i of its chunk, lanes cover the keys j (coalesced row reads), the sum over
+// the group's windows stays in registers; the (i, j) -> table-index binning then costs one LDS atomic per (i, j) per workgroup (not per
+// window), and one global atomic per touched table entry per workgroup.
+__global__ __launch_bounds__(256) void wattn_dtable_kernel(const float* __restrict__ slab, float* __restrict__ part, int slab_ld, int wd, int wh,
+                                                           int ww, int nwin, int N, int heads, int rows_per_block, int win_per_group) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
+    const int centre = ((wd - 1) * (2 * wh - 1) + (wh - 1)) * (2 * ww - 1) + (ww - 1);
+    float* hist = reinterpret_cast<float*>(smem_raw);
+    int* bs = reinterpret_cast<int*>(hist + R);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y;
+    for (int e = tid; e < R; e += 256) hist[e] = 0.f;
+    for (int e = tid; e < N; e += 256) {
+        const int dz = e / (wh * ww), hy = (e / ww) % wh, wx = e % ww;
+        bs[e] = (dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx;
     }
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    const int w0 = blockIdx.z * win_per_group, w1 = min(nwin, w0 + win_per_group);
+    const int64_t wstride = (int64_t)heads * N * slab_ld;
+    for (int i = r0 + wave; i < r1; i += 4) {
+        const float* row = slab + ((int64_t)w0 * heads + h) * N * slab_ld + (int64_t)i * slab_ld;
+        const int bi = bs[i] + centre;
+        // eight windows at a time: eight independent loads in flight per lane and key
+        for (int j = lane; j < N; j += 64) {
+            const float* q = row + j;
+            float acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+            int w = w0;
+            for (; w + 7 < w1; w += 8, q += 8 * wstride)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += q[u * wstride];
+            for (; w < w1; ++w, q += wstride) acc[0] += *q;
+            atomicAdd(hist + (bi - bs[j]), ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])));
+        }
+    }
+    __syncthreads();
+    // this workgroup's histogram -> part[(z * chunks + chunk) * heads + h][R] (contiguous, plain stores); wattn_dtable_finish adds the pieces up.
+    // (Flushing with atomics straight into dtable[R][heads] puts every lane in a different 64-byte segment: ~17x below the atomic rate.)
+    float* dst = part + (((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * heads + h) * R;
+    for (int e = tid; e < R; e += 256) dst[e] = hist[e];
+}
+__global__ void wattn_dtable_finish(const float* __restrict__ part, float* __restrict__ dtable, int pieces, int per_z, int heads, int R) {
+    // blockIdx.z walks a group of per-workgroup histograms (8 loads in flight per thread); the groups meet in dtable through atomics
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y;
+    if (e >= R) return;
+    const int k0 = blockIdx.z * per_z, k1 = min(pieces, k0 + per_z);
+    const float* q = part + ((int64_t)k0 * heads + h) * R + e;
+    const int64_t st = (int64_t)heads * R;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    int k = k0;
+    for (; k + 7 < k1; k += 8, q += 8 * st)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += q[u * st];
+    for (; k < k1; ++k, q += st) acc[0] += *q;
+    const float a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    if (gridDim.z > 1) atomicAdd(dtable + (int64_t)e * heads + h, a);
+    else dtable[(int64_t)e * heads + h] += a;
 }
 
 template <int NT> size_t bwd_lds_bytes(int R) {
@@ -417,10 +462,24 @@ int lavt_window_attn_fwd_mfma(const void* qkv, const float* table, const int8_t*
     return LAVT_OK;
 }
 
+static void dtable_geometry(int nwin, int N, int heads, int* rpb, int* wgroups, int* wpg) {
+    *rpb = cdiv(N * heads, 1024);                             // rows per workgroup: ~1k (row chunk, head) workgroups
+    if (*rpb < 4) *rpb = 4;
+    const int g = cdiv(nwin, 32);                             // <= 32 windows summed per workgroup
+    *wpg = cdiv(nwin, g);
+    *wgroups = cdiv(nwin, *wpg);
+}
+int64_t lavt_window_attn_bwd_ws_mfma(int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww) {
+    int rpb, wgroups, wpg;
+    dtable_geometry(nwin, N, heads, &rpb, &wgroups, &wpg);
+    const int64_t R = (int64_t)(2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
+    return (int64_t)nwin * heads * N * bias_ld + (int64_t)wgroups * cdiv(N, rpb) * heads * R;
+}
+
 int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, const void* out, const void* dout,
-                              const float* lse, void* dqkv, float* dbias, int bias_ld, float* ws, int wd, int wh, int ww, int nwin, int N,
+                              const float* lse, void* dqkv, float* dtable, int bias_ld, float* ws, int wd, int wh, int ww, int nwin, int N,
                               int heads, float scale, hipStream_t st) {
-    if (N > 160 || !table || !dbias || !ws || bias_ld % 4) { lavt_set_error("lavt_window_attn_bwd(mfma): N=%d (<= 160), table, dbias and scratch required", N); return LAVT_ERR_INVALID; }
+    if (N > 160 || !table || !dtable || !ws || bias_ld % 4) { lavt_set_error("lavt_window_attn_bwd(mfma): N=%d (<= 160), table, dtable and scratch required", N); return LAVT_ERR_INVALID; }
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
     // >= 2 workgroups per CU when there is that much work
     int wpb = (int)(((long)nwin * heads + 767) / 768);
@@ -449,13 +508,13 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     else { if (waves == 8) LAVT_BWD(10, 8); else LAVT_BWD(10, 4); }
 #undef LAVT_BWD
     LAVT_CHECK_LAUNCH("lavt_window_attn_bwd(mfma)");
-    const int64_t per_window4 = (int64_t)heads * N * bias_ld / 4;
-    const int bx = cdiv(per_window4, 256);
-    int groups = 1024 / bx;                                   // ~1k workgroups in total
-    if (groups > nwin / 4) groups = nwin / 4;                 // >= 4 windows per group
-    if (groups < 1 || nwin <= 32) groups = 1;                 // few windows: one deterministic pass
-    const int per_group = cdiv(nwin, groups);
-    hipLaunchKernelGGL(wattn_dbias_sum, dim3(bx, cdiv(nwin, per_group)), dim3(256), 0, st, ws, dbias, nwin, per_group, per_window4);
-    LAVT_CHECK_LAUNCH("lavt_window_attn_bwd(dbias sum)");
+    int rpb, wgroups, wpg;
+    dtable_geometry(nwin, N, heads, &rpb, &wgroups, &wpg);
+    float* part = ws + (int64_t)nwin * heads * N * bias_ld;   // after the slabs: [wgroups * chunks][heads][R]
+    hipLaunchKernelGGL(wattn_dtable_kernel, dim3(cdiv(N, rpb), heads, wgroups), dim3(256), (size_t)(R + N) * 4, st, ws, part, bias_ld, wd, wh, ww, nwin,
+                       N, heads, rpb, wpg);
+    const int pieces = wgroups * cdiv(N, rpb), per_z = 16;
+    hipLaunchKernelGGL(wattn_dtable_finish, dim3(cdiv(R, 256), heads, cdiv(pieces, per_z)), dim3(256), 0, st, part, dtable, pieces, per_z, heads, R);
+    LAVT_CHECK_LAUNCH("lavt_window_attn_bwd(table gradient)");
     return LAVT_OK;
 }

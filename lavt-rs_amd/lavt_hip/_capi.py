@@ -55,6 +55,8 @@ _PROTOTYPES = {
     "lavt_gemm_tn_grouped": [C.POINTER(GemmTN), i32, vp],
     "lavt_window_attn_fwd": [i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "lavt_window_attn_bwd": [i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "lavt_attn_uses_table": [i32, i32],
+    "lavt_window_attn_bwd_ws": [i32, i32, i32, i32, i32, i32, i32, i32],
     "lavt_relpos_expand": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lavt_relpos_reduce": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lavt_attn_softmax_fwd": [i32, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32, vp],
@@ -93,6 +95,7 @@ for _name, _args in _PROTOTYPES.items():
     _fn.argtypes = _args
     _fn.restype = C.c_int
 lib.lavt_last_error.restype = C.c_char_p
+lib.lavt_window_attn_bwd_ws.restype = C.c_int64
 lib.lavt_last_error.argtypes = []
 
 EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)

@@ -442,9 +442,11 @@ class _WindowAttn(torch.autograd.Function):
         Cc = C3 // 3
         nwin = qkv.shape[0] // N
         dev = qkv.device
-        ld = 64 if N <= 64 else -(-N // 32) * 32   # 64 / 160: padded key axis (pairs of 16-wide MFMA tiles); padding holds -1e30
-        dense = torch.empty(heads, N, ld, dtype=torch.float32, device=dev)
-        K.check(K.lib.lavt_relpos_expand(K.ptr(_f32(table)), K.ptr(dense), wd, wh, ww, N, heads, ld, K.stream()))
+        ld = 64 if N <= 64 else -(-N // 32) * 32   # 64 / 160: padded key axis (pairs of 16-wide MFMA tiles)
+        dense = None
+        if not K.lib.lavt_attn_uses_table(K.dt(qkv.dtype), N):      # exact-fp32 kernels read the dense bias (padding columns hold -1e30)
+            dense = torch.empty(heads, N, ld, dtype=torch.float32, device=dev)
+            K.check(K.lib.lavt_relpos_expand(K.ptr(_f32(table)), K.ptr(dense), wd, wh, ww, N, heads, ld, K.stream()))
         out = torch.empty(nwin * N, Cc, dtype=qkv.dtype, device=dev)
         lse = torch.empty(nwin, heads, N, dtype=torch.float32, device=dev)
         nw_img = region.shape[0] if region is not None else 0
@@ -462,13 +464,12 @@ class _WindowAttn(torch.autograd.Function):
         wd, wh, ww = win
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
-        ddense = torch.zeros_like(dense)
-        ws = torch.empty(nwin * heads * N * ld, dtype=torch.float32, device=qkv.device) if qkv.dtype == torch.bfloat16 else None
-        K.check(K.lib.lavt_window_attn_bwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout),
-                                           K.ptr(lse), K.ptr(dqkv), K.ptr(ddense), K.ptr(_f32(table)), K.ptr(ws), ws.numel() if ws is not None else 0,
-                                           wd, wh, ww, nwin, N, heads, Cc // heads, scale, K.stream()))
+        nws = int(K.lib.lavt_window_attn_bwd_ws(K.dt(qkv.dtype), nwin, N, heads, ld, wd, wh, ww))
+        ws = torch.empty(nws, dtype=torch.float32, device=qkv.device) if nws > 0 else None                      # dS slabs + table histograms
         dtable, ts = sinks.buf(table, ((2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1), heads))
-        K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense), K.ptr(dtable), wd, wh, ww, N, heads, ld, K.stream()))
+        K.check(K.lib.lavt_window_attn_bwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout),
+                                           K.ptr(lse), K.ptr(dqkv), K.ptr(_f32(table)), K.ptr(dtable), K.ptr(ws), ws.numel() if ws is not None else 0,
+                                           wd, wh, ww, nwin, N, heads, Cc // heads, scale, K.stream()))
         return dqkv, sinks.done(table, dtable, ts), None, None, None, None
 
 

@@ -345,7 +345,7 @@ def test_ddp_step_graph_equals_eager_in_one_rank_group():
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
         import os, sys, torch, torch.distributed as dist
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 400), RANK="0", WORLD_SIZE="1", LAVT_FORCE_COLLECTIVES="1")
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() %% 400), RANK="0", WORLD_SIZE="1", LAVT_FORCE_COLLECTIVES="1")
         sys.path[:0] = [%r, %r]
         import lavt_hip
         from types import SimpleNamespace

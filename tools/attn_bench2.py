@@ -14,10 +14,10 @@ def run(nwin, heads, ws, iters=20):
     dense[:, :, N:] = -1e30
     out = torch.empty(nwin * N, C, device=dev, dtype=bf); lse = torch.empty(nwin, heads, N, device=dev)
     dout = torch.randn_like(out); dqkv = torch.empty_like(qkv)
-    ddense = torch.zeros(heads, N, ld, device=dev); wsb = torch.empty(nwin * heads * N * ld, device=dev); table = torch.randn((2 * ws - 1) ** 2, heads, device=dev) * 0.1
+    dtable = torch.zeros((2 * ws - 1) ** 2, heads, device=dev); wsb = torch.empty(int(K.lib.lavt_window_attn_bwd_ws(K.dt(bf), nwin, N, heads, ld, 1, ws, ws)), device=dev); table = torch.randn((2 * ws - 1) ** 2, heads, device=dev) * 0.1
     st = K.stream()
     fwd = lambda: K.check(K.lib.lavt_window_attn_fwd(K.dt(bf), K.ptr(qkv), K.ptr(dense), ld, None, 0, K.ptr(out), K.ptr(lse), K.ptr(table), 1, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
-    bwd = lambda: K.check(K.lib.lavt_window_attn_bwd(K.dt(bf), K.ptr(qkv), K.ptr(dense), ld, None, 0, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(ddense), K.ptr(table), K.ptr(wsb), wsb.numel(), 1, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
+    bwd = lambda: K.check(K.lib.lavt_window_attn_bwd(K.dt(bf), K.ptr(qkv), K.ptr(dense), ld, None, 0, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(table), K.ptr(dtable), K.ptr(wsb), wsb.numel(), 1, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
     res = []
     for fn in (fwd, bwd):
         for _ in range(3): fn()
