@@ -452,9 +452,63 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
             dma4(src, wave < 3 ? maps + (t % NSLOT) * SLOT_BYTES + wave * 256 : maps + NSLOT * SLOT_BYTES);
         }
     };
+    // !MAPS: the K rows are consecutive, so every lane keeps running source pointers (A, and B without taps) and, for conv taps, the
+    // running (z, y, x) of its K row -- advanced by 64 rows per tile with a wrap test instead of three divisions per DMA per tile
+    // (the conv weight-gradient K loop was instruction-bound: ~200 VALU instructions per K tile per wave against 8 MFMAs).
+    const T* a_run[A_INSTR];
+    const T* b_run[B_INSTR];
+    int a_k[A_INSTR], b_k[B_INSTR], b_z[B_INSTR], b_y[B_INSTR], b_x[B_INSTR], b_delta[B_INSTR];
+    if constexpr (!MAPS) {
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            a_k[i] = a_kr[i] >= 0 ? kt_begin * BK + a_kr[i] : (1 << 30);               // dead lanes sit beyond K for good
+            a_run[i] = A + (int64_t)(a_kr[i] >= 0 ? a_k[i] : 0) * p.lda + a_col[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            b_k[i] = b_kr[i] >= 0 ? kt_begin * BK + b_kr[i] : (1 << 30);
+            const int k0 = b_kr[i] >= 0 ? b_k[i] : 0;
+            b_delta[i] = conv ? (b_dz[i] * cg.h + b_dy[i]) * cg.w + b_dx[i] : 0;
+            b_run[i] = b_base[i] + (int64_t)(k0 + b_delta[i]) * b_ld[i];
+            b_z[i] = b_y[i] = b_x[i] = 0;
+            if (conv) conv_coords(cg, k0, b_z[i], b_y[i], b_x[i]);
+        }
+    }
     auto issue = [&](int t) {
         char* sa = smem + (t % STAGES) * STAGE_BYTES;
         char* sb = sa + A_BYTES;
+        if constexpr (!MAPS) {
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) {
+                dma16(a_k[i] < p.K ? a_run[i] : Z, sa + (wave * A_INSTR + i) * 1024);
+                a_run[i] += (int64_t)BK * p.lda;
+                a_k[i] += BK;
+            }
+#pragma unroll
+            for (int i = 0; i < B_INSTR; ++i) {
+                bool ok = b_k[i] < p.K;
+                if (conv) {
+                    const int z = b_z[i] + b_dz[i], y = b_y[i] + b_dy[i], x = b_x[i] + b_dx[i];
+                    ok = ok && (unsigned)z < (unsigned)cg.d && (unsigned)y < (unsigned)cg.h && (unsigned)x < (unsigned)cg.w;
+                    // next tile: 64 rows further along x, carrying into y and z (and on into the next sample, whose z restarts at 0)
+                    b_x[i] += BK;
+                    if (b_x[i] >= cg.w) {
+                        const int q = fdiv(b_x[i], cg.w, cg.inv_w);
+                        b_x[i] -= q * cg.w;
+                        b_y[i] += q;
+                        if (b_y[i] >= cg.h) {
+                            const int q2 = b_y[i] / cg.h;
+                            b_y[i] -= q2 * cg.h;
+                            b_z[i] = (b_z[i] + q2) % cg.d;
+                        }
+                    }
+                }
+                dma16(ok ? b_run[i] : Z, sb + (wave * B_INSTR + i) * 1024);
+                b_run[i] += (int64_t)BK * b_ld[i];
+                b_k[i] += BK;
+            }
+            return;
+        }
         const int kbase = (kt_begin + t) * BK;
         const int* m_a = reinterpret_cast<const int*>(maps + (t % NSLOT) * SLOT_BYTES);
         const float* m_rs = reinterpret_cast<const float*>(maps + (t % NSLOT) * SLOT_BYTES + 256);
