@@ -272,6 +272,8 @@ int lavt_nchw_to_nhwc(int src_dtype, const void* src, int dst_dtype, void* dst, 
 int lavt_nhwc_to_nchw(int src_dtype, const void* src, int dst_dtype, void* dst, int B, int C, int HW, void* stream);
 /* conv weight fp32 [Cout][Cin][taps] (taps = 9 for 3x3, 27 for 3x3x3, ...) -> dtype [Cout][taps][Cin] (compute copy used by lavt_gemm_nt) */
 int lavt_pack_conv3x3(const float* w, int dtype, void* packed, int Cout, int Cin, int taps, void* stream);
+/* gradient counterpart: dw fp32 [Cout][Cin][taps] += packed fp32 [Cout][taps][Cin] (what lavt_gemm_tn writes without c_conv_permute) */
+int lavt_unpack_conv_grad(const float* packed, float* dw, int Cout, int Cin, int taps, void* stream);
 /* many small fp32 -> dtype casts in one launch: desc = int64 triples (src_ptr, dst_ptr, n) on the DEVICE */
 int lavt_cast_multi(const int64_t* desc, int count, int dst_dtype, void* stream);
 /* The caller's optimizer step (train.py:688-700: torch.optim.AdamW, amsgrad off, + LambdaLR((1 - it/T)^0.9)) as one

@@ -408,6 +408,15 @@ template <typename T> __global__ void pack_conv3x3_kernel(const float* w, T* pac
         packed[i] = from_f<T>(w[((int64_t)co * Cin + ci) * taps + tap]);
     }
 }
+// inverse of the packing for gradients: dw[co][ci][tap] += packed[co][tap][ci] (the conv weight-gradient GEMM writes the packed layout so that
+// its split-K atomics stay contiguous: scattered 4-byte atomics, 36 bytes apart for 9 taps, run ~17x below the contiguous atomic rate)
+__global__ void unpack_conv_grad_kernel(const float* __restrict__ packed, float* __restrict__ dw, int Cout, int Cin, int taps) {
+    const int64_t n = (int64_t)Cout * taps * Cin;
+    GRID_STRIDE(i, n) {
+        const int tap = (int)(i % taps), ci = (int)((i / taps) % Cin), co = (int)(i / taps / Cin);          // i walks dw (coalesced writes)
+        dw[i] += packed[((int64_t)co * taps + tap) * Cin + ci];
+    }
+}
 // ---- multi-tensor AdamW with the poly learning-rate schedule of the caller (train.py:688-700: torch.optim.AdamW + LambdaLR((1 - it/T)^0.9)).
 // One launch for the whole parameter list: blockIdx.y = tensor, descriptor {param, grad, exp_avg, exp_avg_sq, numel} (fp32 pointers),
 // per-tensor hyper-parameters {base_lr, weight_decay, beta1, beta2, eps}.  The step counter lives on the device (incremented by
@@ -619,6 +628,13 @@ extern "C" int lavt_pack_conv3x3(const float* w, int dtype, void* packed, int Co
     const int64_t n = (int64_t)Cout * Cin * taps;
     DISPATCH_T(dtype, "lavt_pack_conv3x3", hipLaunchKernelGGL(pack_conv3x3_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, ST, w, (T*)packed, Cout, Cin, taps));
     LAVT_CHECK_LAUNCH("lavt_pack_conv3x3");
+    return LAVT_OK;
+}
+extern "C" int lavt_unpack_conv_grad(const float* packed, float* dw, int Cout, int Cin, int taps, void* stream) {
+    LAVT_CHECK_ARG(packed && dw && Cout > 0 && Cin > 0 && taps > 0, "lavt_unpack_conv_grad: bad arguments");
+    const int64_t n = (int64_t)Cout * Cin * taps;
+    hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, packed, dw, Cout, Cin, taps);
+    LAVT_CHECK_LAUNCH("lavt_unpack_conv_grad");
     return LAVT_OK;
 }
 extern "C" int lavt_cast_multi(const int64_t* desc, int count, int dst_dtype, void* stream) {

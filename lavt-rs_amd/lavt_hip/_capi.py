@@ -77,6 +77,7 @@ _PROTOTYPES = {
     "lavt_bilinear_bwd": [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lavt_logits_up_fwd": [i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "lavt_logits_up_bwd": [i32, vp, vp, i32, i32, i32, i32, i32, vp],
+    "lavt_unpack_conv_grad": [vp, vp, i32, i32, i32, vp],
     "lavt_adamw_step": [vp, vp, i32, vp, f32, f32, vp],
     "lavt_upsample_ce_fwd": [i32, vp, vp, f32, f32, vp, i64, vp, i32, i32, i32, i32, i32, vp],
     "lavt_upsample_ce_bwd": [i32, vp, vp, f32, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp],

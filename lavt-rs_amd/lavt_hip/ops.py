@@ -910,8 +910,11 @@ class _ConvTaps(torch.autograd.Function):
         db = bsink = None
         if bias is not None:
             db, bsink = sinks.buf(bias, (Cout,))
-        side.run(lambda: gemm_tn(dtype, Cout, taps * Cin, M, dy, Cout, x1, C1, dW, taps * Cin, B2=x2, ldb2=C2, b_split=C1,
-                                 conv=(H, W, Cin, D, kd, kh, kw), c_conv_permute=True, colsum=db), (dy, x1, x2), wsink and (db is None or bsink))
+        # the GEMM writes [Cout][taps][Cin] (contiguous split-K atomics), a small kernel adds it into the [Cout][Cin][taps] gradient
+        packed = torch.zeros(Cout, taps * Cin, dtype=torch.float32, device=dy.device)
+        gemm_tn(dtype, Cout, taps * Cin, M, dy, Cout, x1, C1, packed, taps * Cin, B2=x2, ldb2=C2, b_split=C1,
+                conv=(H, W, Cin, D, kd, kh, kw), colsum=db)
+        K.check(K.lib.lavt_unpack_conv_grad(K.ptr(packed), K.ptr(dW), Cout, Cin, taps, K.stream()))
         return (dx1, dx2, sinks.done(weight, dW, wsink), sinks.done(bias, db, bsink) if bias is not None else None,
                 None, None, None, None, None)
 
