@@ -33,6 +33,12 @@ __device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <int G> __device__ __forceinline__ void wait_groups(int g) {      // leave g groups of G vector-memory ops in flight
+    if (g <= 0) wait_vmcnt<0>();
+    else if (g == 1) wait_vmcnt<G>();
+    else if (g == 2) wait_vmcnt<2 * G>();
+    else wait_vmcnt<3 * G>();
+}
 // ---- transposing LDS reads issued from inline asm --------------------------------------------------------------------
 // hipcc puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr builtin while LDS-DMA is in flight (it cannot tell the stages
 // apart), which would serialise the pipeline.  Asm reads are invisible to that pass; we wait for them ourselves:
@@ -291,10 +297,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ktiles = (p.K + BK - 1) / BK;
-    issue(0, 0);
-    if (STAGES > 2 && ktiles > 1) issue(1, 1);
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < ktiles) issue(t, t);
     for (int kt = 0; kt < ktiles; ++kt) {
-        if (STAGES > 2 && kt + 1 < ktiles) wait_vmcnt<L>(); else wait_vmcnt<0>();
+        wait_groups<L>(min(STAGES - 2, ktiles - 1 - kt));          // tile kt landed; up to STAGES-2 younger tiles stay in flight
         __builtin_amdgcn_s_barrier();
         if (kt + STAGES - 1 < ktiles) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
         const T* cA = reinterpret_cast<const T*>(smem + (kt % STAGES) * STAGE_BYTES);
@@ -370,12 +377,6 @@ template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(cons
 // whole ring.  So (MAPS = true) they travel through LDS as well: a 4-byte-per-lane DMA per wave per K tile, issued 2(S-1) tiles ahead
 // into an 8-slot ring, read back with ds_read when the tile's row addresses are formed.  Every wave issues the same number of
 // vector-memory ops per tile (ND tile DMAs + 1 map DMA), which is what makes the counted waits valid.
-template <int G> __device__ __forceinline__ void wait_groups(int g) {      // leave g groups of G vector-memory ops in flight
-    if (g <= 0) wait_vmcnt<0>();
-    else if (g == 1) wait_vmcnt<G>();
-    else if (g == 2) wait_vmcnt<2 * G>();
-    else wait_vmcnt<3 * G>();
-}
 __device__ __forceinline__ void dma4(const void* src, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 4, 0, 0);
 }
@@ -679,7 +680,11 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;
     const bool big = force ? force == 128 : (tiles128 >= 200 && p.N >= 128);
     const char* sg = getenv("LAVT_GEMM_STAGES");
-    const int stages = sg ? atoi(sg) : (big ? 2 : (tiles64 < 300 && p.K >= 2048 ? 3 : 2));
+    // Ring depth.  In isolation (operands L2-resident) 2 stages win everywhere; inside the training step the operands of the small
+    // GEMMs arrive cold from HBM / Infinity Cache and a 4-deep ring is worth 0.8 ms per step.  The many-tile long-K problems (decoder
+    // convolutions: every CU holds 2 workgroups and streams from L2) stay at 2 stages, which keeps two workgroups per CU resident.
+    const long wgs = big ? tiles128 : tiles64;
+    const int stages = sg ? atoi(sg) : (wgs >= 600 ? 2 : 4);
     const char* wv = getenv("LAVT_GEMM_WAVES");
     const int waves = wv ? atoi(wv) : 8;
 #define GO(BM_, BN_, KM_, ST_, WV_) return launch_nt_v2<BM_, BN_, KM_, ST_, WV_>(p, st)
@@ -690,13 +695,15 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     if (big) {
         if (waves == 8) {
             if (stages == 2) { if (p.b_kmajor) GO(128, 128, true, 2, 8); else GO(128, 128, false, 2, 8); }
-            if (p.b_kmajor) GO(128, 128, true, 3, 8); else GO(128, 128, false, 3, 8);
+            if (stages == 3) { if (p.b_kmajor) GO(128, 128, true, 3, 8); else GO(128, 128, false, 3, 8); }
+            if (p.b_kmajor) GO(128, 128, true, 4, 8); else GO(128, 128, false, 4, 8);
         }
         if (stages == 2) { if (p.b_kmajor) GO(128, 128, true, 2, 4); else GO(128, 128, false, 2, 4); }
         if (p.b_kmajor) GO(128, 128, true, 3, 4); else GO(128, 128, false, 3, 4);
     }
     if (stages == 2) { if (p.b_kmajor) GO(64, 64, true, 2, 4); else GO(64, 64, false, 2, 4); }
-    if (p.b_kmajor) GO(64, 64, true, 3, 4); else GO(64, 64, false, 3, 4);
+    if (stages == 3) { if (p.b_kmajor) GO(64, 64, true, 3, 4); else GO(64, 64, false, 3, 4); }
+    if (p.b_kmajor) GO(64, 64, true, 4, 4); else GO(64, 64, false, 4, 4);
 #undef GO
 }
 
