@@ -203,7 +203,9 @@ int lavt_layernorm_fwd(int dtype, const void* x, const int32_t* gather, const fl
                        float* mean, float* rstd, int rows, int C, float eps, void* stream);
 int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
                        const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats,
-                       int rows, int C, void* stream);
+                       const void* dres, int rows, int C, void* stream);
+/* dres (optional, [rows][C], not with gather): gradient of the residual stream that bypassed the LayerNorm (x -> LN(x) and x -> + ...):
+ * dx = LN'(dy) + dres in the same pass, instead of a separate element-wise add of the two gradients of x */
 
 /* ---------------------------------------------------------------------------------------------
  * Per-channel statistics over rows, and the normalisations built on them:

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const int32_t* __restrict__ gather, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float* __restrict__ partials, int rows, int C) {
+                                                            float* __restrict__ partials, const T* __restrict__ dres, int rows, int C) {
     // CPL = chunks per lane (compile time: the row arrays are exactly as large as needed; LPR < 64 only with CPL == 1)
     constexpr int EPC = Chunk<T>::N, MAXC = CPL, RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, lir = lane % LPR, wave = threadIdx.x >> 6;
@@ -126,6 +126,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 float f[EPC];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) f[e] = rs * (g[c * EPC + e] - s1 - xh[c * EPC + e] * s2);
+                if (dres) {                       // gradient of the residual branch that bypassed this LayerNorm: dx = LN'(dy) + dres (no gather form)
+                    float fr[EPC];
+                    chunk_to_f<T>(*reinterpret_cast<const uint4*>(dres + row * C + ch * EPC), fr);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) f[e] += fr[e];
+                }
                 if (!gather) *reinterpret_cast<uint4*>(dx + row * C + ch * EPC) = f_to_chunk<T>(f);
                 else {
                     const int cq = C >> 2, col = ch * EPC, qd = col / cq;
@@ -429,10 +435,11 @@ extern "C" int lavt_layernorm_fwd(int dtype, const void* x, const int32_t* gathe
 
 extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
                                   const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats,
-                                  int rows, int C, void* stream) {
+                                  const void* dres, int rows, int C, void* stream) {
     const int epc = dtype == LAVT_F32 ? 4 : 8;
     LAVT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "lavt_layernorm_bwd: bad arguments");
     LAVT_CHECK_ARG(C > 0 && C <= 2048 && C % epc == 0 && (!gather || (C / 4) % epc == 0), "lavt_layernorm_bwd: unsupported C=%d", C);
+    LAVT_CHECK_ARG(!(gather && dres), "lavt_layernorm_bwd: dres is not supported together with gather");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nchunk = C / epc;
     const int lpr = nchunk <= 16 ? 16 : nchunk <= 32 ? 32 : 64;
@@ -441,7 +448,7 @@ extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     float* partials = (ws && ws_floats >= (int64_t)blocks * 2 * C) ? ws : nullptr;
-#define LN_BWD(LPR_, CPL_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_, CPL_>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, rows, C)
+#define LN_BWD(LPR_, CPL_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_, CPL_>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, (const T*)dres, rows, C)
     DISPATCH_T(dtype, "lavt_layernorm_bwd",
                if (lpr == 16) LN_BWD(16, 1); else if (lpr == 32) LN_BWD(32, 1);
                else if (cpl == 1) LN_BWD(64, 1); else if (cpl == 2) LN_BWD(64, 2); else if (cpl <= 4) LN_BWD(64, 4); else LN_BWD(64, 8));

@@ -390,8 +390,12 @@ def linear(x, weight, bias=None, residual=None, **kw):
 
 # ------------------------------------------------------------------------------------------ LayerNorm
 class _LayerNorm(torch.autograd.Function):
+    """y = LN(x) (optionally over the PatchMerging 2x2 gather).  With `passthrough` the function also returns x itself: use that alias
+    for the residual branch (x + f(LN(x))) and the two gradients of x meet inside the LayerNorm backward kernel (dx = LN'(dy) + dres)
+    instead of in a separate element-wise add."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, gather, rows, C, eps):
+    def forward(ctx, x, gamma, beta, gather, rows, C, eps, passthrough):
         x = x.contiguous()
         y = torch.empty(rows, C, dtype=x.dtype, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -399,27 +403,36 @@ class _LayerNorm(torch.autograd.Function):
         K.check(K.lib.lavt_layernorm_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(gather), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), K.ptr(y),
                                          K.ptr(mean), K.ptr(rstd), rows, C, eps, K.stream()))
         ctx.save_for_backward(x, gamma, mean, rstd, gather, beta)
-        ctx.rows, ctx.C = rows, C
+        ctx.rows, ctx.C, ctx.passthrough = rows, C, passthrough
+        if passthrough:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma, mean, rstd, gather, beta = ctx.saved_tensors
         dy = dy.contiguous()
+        if dres is not None:
+            dres = dres.contiguous()
         dx = torch.empty_like(x)
         dg, gs = sinks.buf(gamma, (ctx.C,))
         db, bs = sinks.buf(beta, (ctx.C,))
         ws = _scratch(1025 * 2 * ctx.C, x.device)
         K.check(K.lib.lavt_layernorm_bwd(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(gather), K.ptr(_f32(gamma)), K.ptr(mean), K.ptr(rstd),
-                                         K.ptr(dx), K.ptr(dg), K.ptr(db), K.ptr(ws), ws.numel(), ctx.rows, ctx.C, K.stream()))
-        return dx, sinks.done(gamma, dg, gs), sinks.done(beta, db, bs), None, None, None, None
+                                         K.ptr(dx), K.ptr(dg), K.ptr(db), K.ptr(ws), ws.numel(), K.ptr(dres), ctx.rows, ctx.C, K.stream()))
+        return dx, sinks.done(gamma, dg, gs), sinks.done(beta, db, bs), None, None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, gather=None):
     """x [rows, C]; with gather (int32 [rows_out, 4]) the input row is the concat of 4 source rows of x (PatchMerging)."""
     if gather is None:
-        return _LayerNorm.apply(x, gamma, beta, None, x.shape[0], x.shape[1], eps)
-    return _LayerNorm.apply(x, gamma, beta, gather, gather.shape[0], 4 * x.shape[1], eps)
+        return _LayerNorm.apply(x, gamma, beta, None, x.shape[0], x.shape[1], eps, False)
+    return _LayerNorm.apply(x, gamma, beta, gather, gather.shape[0], 4 * x.shape[1], eps, False)
+
+
+def layer_norm_res(x, gamma, beta, eps=1e-5):
+    """-> (LN(x), x'): x' aliases x; feed it to the residual branch so that both gradients of x are summed inside the LN backward kernel"""
+    return _LayerNorm.apply(x, gamma, beta, None, x.shape[0], x.shape[1], eps, True)
 
 
 # ------------------------------------------------------------------------------------------ window attention core

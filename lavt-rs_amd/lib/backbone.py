@@ -144,7 +144,7 @@ class SwinTransformerBlock(nn.Module):
         region = rowmaps.region_ids(H, W, ws, s, dev) if s > 0 else None
         M = wmap.numel()
         a = self.attn
-        xn = ops.layer_norm(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        xn, x2 = ops.layer_norm_res(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps)     # x2: alias for the residual branch
         qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, in_map=wmap, rows=M)
         o = ops.window_attention(qkv, a.relative_position_bias_table, region, ws, self.num_heads)
         f1 = self.drop_path.factors(B, dev)
@@ -152,7 +152,7 @@ class SwinTransformerBlock(nn.Module):
         x2 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x2, out_map=wmap, rows=M, out_rows=B * L,
                         row_scale=f1, row_scale_div=M // B, row_scale_value=dpv)
         f2 = self.drop_path.factors(B, dev)
-        h = ops.layer_norm(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        h, x2 = ops.layer_norm_res(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         x2 = self.mlp(h, residual=x2, row_scale=f2, row_scale_div=L, row_scale_value=dpv)
         return x2.view(B, L, C)
 

@@ -91,7 +91,7 @@ class SwinTransformerBlock3D(nn.Module):
         region = rowmaps.region_ids3d(D, H, W, win, shift, dev) if any(s > 0 for s in shift) else None
         M = wmap.numel()
         a = self.attn
-        xn = ops.layer_norm(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        xn, x2 = ops.layer_norm_res(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps)     # x2: alias for the residual branch
         qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, in_map=wmap, rows=M)
         o = ops.window_attention(qkv, a.relative_position_bias_table, region, self.window_size, self.num_heads, N=win[0] * win[1] * win[2])
         f1 = self.drop_path.factors(B, dev)
@@ -99,7 +99,7 @@ class SwinTransformerBlock3D(nn.Module):
         x2 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x2, out_map=wmap, rows=M, out_rows=B * L,
                         row_scale=f1, row_scale_div=M // B, row_scale_value=dpv)
         f2 = self.drop_path.factors(B, dev)
-        h = ops.layer_norm(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        h, x2 = ops.layer_norm_res(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         x2 = self.mlp(h, residual=x2, row_scale=f2, row_scale_div=L, row_scale_value=dpv)
         return x2.view(B, D, H, W, C)
 
