@@ -100,7 +100,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
     constexpr bool SIMPLE = MODE == 1, CONVFAST = MODE == 2;
     using T = bf16;
     constexpr int BK = 64, EPC = 8;
-    constexpr int WAVES_N = WAVES / 2;                       // wave grid: 2 (M) x WAVES/2 (N)
+    constexpr int WAVES_M = WAVES == 16 ? 4 : 2;             // wave grid: WAVES_M (M) x WAVES_N (N); 16 waves: 4 x 4 waves of 64 x 64
+    constexpr int WAVES_N = WAVES / WAVES_M;
     constexpr int A_INSTR = BM / (8 * WAVES);                // DMA instructions per wave per K tile for A (8 rows x 8 chunks each)
     constexpr int B_LD = BN + KM_PAD;                        // k-major B row (elements)
     constexpr int B_CH = B_LD / EPC;                         // chunks per k-major row
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
     constexpr int A_BYTES = BM * BK * 2;
     constexpr int B_BYTES = BKM ? B_INSTR * WAVES * 1024 : BN * BK * 2;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int WM = BM / 2, WN = BN / WAVES_N, MI = WM / 16, NI = WN / 16;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NI = WN / 16;
     static_assert(A_INSTR >= 1 && B_INSTR >= 1 && MI >= 1 && NI >= 1, "tile too small for this many waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -692,6 +693,13 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     const long tiles256 = (long)cdiv(p.M, 128) * cdiv(p.N, 256) * p.batch;
     const bool wide = force ? force == 256 : (getenv("LAVT_GEMM_WIDE") != nullptr && tiles256 >= 256 && p.N % 256 == 0 && p.K >= 1024);
     if (wide) { if (p.b_kmajor) GO(128, 256, true, 2, 8); else GO(128, 256, false, 2, 8); }
+    // 256x256 tile, 16 waves (4 x 4 of 64x64), one workgroup per CU: 128 flop per byte of LDS fill.  The 128x128 tile cannot keep enough bytes
+    // in flight per CU to cover the L2 latency at the MFMA rate (160 KiB of LDS); measured 1.02 vs 0.82 PFLOP/s on the decoder conv shape.
+    // Only when its tiles fill the 256 CUs well (whole rounds at >= 80 %).
+    const long tiles256x = (long)cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch;
+    const long rounds = (tiles256x + 255) / 256;
+    const bool huge = force ? force == 512 : (!p.b_kmajor && p.N % 256 == 0 && p.K >= 1024 && tiles256x >= 128 && tiles256x * 10 >= rounds * 256 * 8);      // k-major B (data gradients): measured slower (423 vs 196 us)
+    if (huge) { if (p.b_kmajor) GO(256, 256, true, 2, 16); else GO(256, 256, false, 2, 16); }
     if (big) {
         if (waves == 8) {
             if (stages == 2) { if (p.b_kmajor) GO(128, 128, true, 2, 8); else GO(128, 128, false, 2, 8); }

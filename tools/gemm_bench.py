@@ -72,7 +72,7 @@ for name, kind, a, b, c in SHAPES:
             os.environ.pop(k)
         print(f"{name:9s} {kind:3s} {a:6d} {b:5d} {c:5d} | " + " | ".join(f"{k}: {us:5.1f}us" for k, us, tf in res))
         continue
-    for tile, stages, v2, wv in (("64", "3", "0", "4"), ("64", "2", "1", "4"), ("64", "3", "1", "4"), ("128", "2", "1", "4"), ("128", "2", "1", "8"), ("128", "3", "1", "8"), ("256", "2", "1", "8")):
+    for tile, stages, v2, wv in (("64", "3", "0", "4"), ("64", "2", "1", "4"), ("64", "3", "1", "4"), ("128", "2", "1", "4"), ("128", "2", "1", "8"), ("128", "3", "1", "8"), ("256", "2", "1", "8"), ("512", "2", "1", "16")):
         os.environ["LAVT_GEMM_TILE"] = tile
         os.environ["LAVT_GEMM_STAGES"] = stages
         os.environ["LAVT_GEMM_V2"] = v2
