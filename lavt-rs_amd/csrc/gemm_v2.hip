@@ -761,13 +761,16 @@ int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st) {
     const int force = t ? atoi(t) : 0;
     const int ktiles = cdiv(p.K, 64);
     const long tiles64 = (long)cdiv(p.I, 64) * cdiv(p.J, 64) * p.batch;
-    const bool big = force == 128;
+    const long tiles128 = (long)cdiv(p.I, 128) * cdiv(p.J, 128) * p.batch;
+    // conv weight gradients (long K, >= 128 tiles of 128x128): the larger tile halves the L2->LDS bytes per MFMA (measured 303 vs 357 us)
+    static const bool tn128 = getenv("LAVT_TN_BIG") == nullptr || getenv("LAVT_TN_BIG")[0] != '0';
+    const bool big = force ? force == 128 : (tn128 && p.conv_kc > 0 && tiles128 >= 128 && ktiles >= 64);
     const long tiles = big ? (long)cdiv(p.I, 128) * cdiv(p.J, 128) * p.batch : tiles64;
     int split = p.split_k;
     { const char* se = getenv("LAVT_TN_SPLIT"); if (se) split = atoi(se); }
     if (split <= 0) {
         static const int target = getenv("LAVT_TN_TARGET") ? atoi(getenv("LAVT_TN_TARGET")) : 768;
-        split = (int)((target + tiles / 2) / tiles);      // ~3 workgroups per CU
+        split = big ? (int)((384 + tiles / 2) / tiles) : (int)((target + tiles / 2) / tiles);      // ~3 (64-tile) / ~1.5 (128-tile) workgroups per CU
         const int long_k = (ktiles + 127) / 128;          // no workgroup walks more than ~128 K tiles
         if (split < long_k) split = long_k;
         const int max_split = (ktiles + 7) / 8;           // >= 8 K tiles per workgroup
