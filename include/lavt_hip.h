@@ -186,9 +186,10 @@ int lavt_relpos_reduce(const float* ddense, float* dtable, int wd, int wh, int w
 /* Row softmax of attention scores for windows too large for the fused kernels (Video-Swin N = 392 / 1152; WindowAttention3D.forward,
  * lib/video_swin_transformer.py:147-161): p[row][j] = softmax_j(s[row][j] + bias[i][j] + mask), i = row % rpw, window = row / rpw (rpw >= N rows
  * per window, rows i >= N are padding and give p = 0); s already holds scale * q k^T (lavt_gemm_nt); padding columns of p (j >= N, up to ld)
- * are written as 0.  Backward overwrites dp with ds. */
+ * are written as 0.  heads >= 1: rows come in blocks of rpw ordered (window, head): block b is window b / heads with bias[b % heads] (bias is
+ * [heads][N][bias_ld]); heads = 1 for one head at a time.  Backward overwrites dp with ds. */
 int lavt_attn_softmax_fwd(int dtype, const void* s, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* p,
-                          int64_t rows, int rpw, int N, int ld, void* stream);
+                          int64_t rows, int rpw, int N, int ld, int heads, void* stream);
 int lavt_attn_softmax_bwd(int dtype, const void* p, void* dp, int64_t rows, int N, int ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -235,11 +235,15 @@ __global__ void relpos_reduce_kernel(const float* __restrict__ ddense, float* __
 template <typename T>
 __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(const T* __restrict__ s, const float* __restrict__ bias, int bias_ld,
                                                                const int8_t* __restrict__ region, int nw_img, T* __restrict__ p,
-                                                               int64_t rows, int rpw, int N, int ld) {
+                                                               int64_t rows, int rpw, int N, int ld, int heads) {
+    // rows are ordered (window, head, token): block b = row / rpw is (window b / heads, head b % heads); bias is [heads][N][bias_ld]
     const int lane = threadIdx.x & 63;
+    const float* bias0 = bias;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
         const int i = (int)(row % rpw);
-        const int64_t w = row / rpw;
+        const int64_t blk = row / rpw;
+        const int64_t w = blk / heads;
+        bias = bias0 + (blk % heads) * (int64_t)N * bias_ld;
         const T* sr = s + row * ld;
         T* pr = p + row * ld;
         if (i >= N) {                       // padding row of a window whose token count was rounded up
@@ -387,13 +391,13 @@ extern "C" int lavt_relpos_reduce(const float* ddense, float* dtable, int wd, in
     return LAVT_OK;
 }
 extern "C" int lavt_attn_softmax_fwd(int dtype, const void* s, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* p,
-                                     int64_t rows, int rpw, int N, int ld, void* stream) {
-    LAVT_CHECK_ARG(s && bias && p && rows > 0 && N > 0 && rpw >= N && ld >= N && bias_ld >= N && (!region || nw_img > 0), "lavt_attn_softmax_fwd: bad arguments");
+                                     int64_t rows, int rpw, int N, int ld, int heads, void* stream) {
+    LAVT_CHECK_ARG(s && bias && p && rows > 0 && N > 0 && rpw >= N && ld >= N && bias_ld >= N && heads >= 1 && (!region || nw_img > 0), "lavt_attn_softmax_fwd: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int blocks = cdiv(rows, 4);
     if (blocks > 8192) blocks = 8192;
-    if (dtype == LAVT_F32) hipLaunchKernelGGL(attn_softmax_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)s, bias, bias_ld, region, nw_img, (float*)p, rows, rpw, N, ld);
-    else if (dtype == LAVT_BF16) hipLaunchKernelGGL(attn_softmax_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)s, bias, bias_ld, region, nw_img, (bf16*)p, rows, rpw, N, ld);
+    if (dtype == LAVT_F32) hipLaunchKernelGGL(attn_softmax_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)s, bias, bias_ld, region, nw_img, (float*)p, rows, rpw, N, ld, heads);
+    else if (dtype == LAVT_BF16) hipLaunchKernelGGL(attn_softmax_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)s, bias, bias_ld, region, nw_img, (bf16*)p, rows, rpw, N, ld, heads);
     else { lavt_set_error("lavt_attn_softmax_fwd: bad dtype %d", dtype); return LAVT_ERR_INVALID; }
     LAVT_CHECK_LAUNCH("lavt_attn_softmax_fwd");
     return LAVT_OK;

@@ -487,10 +487,11 @@ class _WindowAttn(torch.autograd.Function):
 
 
 class _WindowAttnComposed(torch.autograd.Function):
-    """Windows too large for the fused kernels (Video-Swin: 8x7x7 = 392, 8x12x12 = 1152 tokens): per head
-    S = scale q k^T (batched gather-GEMM over windows) -> bias + shift mask + softmax (lavt_attn_softmax) -> P v (GEMM).
-    Scores are materialised ([nwin, N, N] per head): correct for any N and both dtypes; a streaming (flash-style) MFMA kernel
-    for these sizes is future work.  Windows whose token count is not a multiple of 8 are zero-padded per window."""
+    """Windows too large for the fused kernels (Video-Swin: 8x7x7 = 392, 8x12x12 = 1152 tokens):
+    S = scale q k^T (gather-GEMM batched over (window, head)) -> bias + shift mask + softmax (lavt_attn_softmax) -> P v (GEMM).
+    qkv is first regrouped head-major ([nwin][heads][Np][q|k|v x 32]) so that every GEMM is ONE launch with a uniform batch stride.
+    Scores are materialised ([nwin*heads, Np, Np]): correct for any N and both dtypes; a streaming (flash-style) MFMA kernel for these
+    sizes is future work.  Windows whose token count is not a multiple of 8 are zero-padded per window."""
 
     @staticmethod
     def forward(ctx, qkv, table, region, win, heads, N):
@@ -500,64 +501,53 @@ class _WindowAttnComposed(torch.autograd.Function):
         Cc = C3 // 3
         nwin = qkv.shape[0] // N
         Np = -(-N // 8) * 8
+        q5 = qkv.view(nwin, N, 3, heads, 32)
         if Np != N:
-            qkv = torch.nn.functional.pad(qkv.view(nwin, N, C3), (0, 0, 0, Np - N)).reshape(nwin * Np, C3)
-        qkv = qkv.contiguous()
+            q5 = torch.nn.functional.pad(q5, (0, 0, 0, 0, 0, 0, 0, Np - N))
+        qh = q5.permute(0, 3, 1, 2, 4).contiguous().view(nwin * heads * Np, 96)            # rows (window, head, token); columns q | k | v
+        nb = nwin * heads
         dense = torch.empty(heads, N, Np, dtype=torch.float32, device=dev)
         K.check(K.lib.lavt_relpos_expand(K.ptr(_f32(table)), K.ptr(dense), wd, wh, ww, N, heads, Np, K.stream()))
         nw_img = region.shape[0] if region is not None else 0
         scale = float((Cc // heads) ** -0.5)
-        out = torch.empty(nwin * Np, Cc, dtype=dtype, device=dev)
-        Ps = []
-        for h in range(heads):
-            S = torch.empty(nwin * Np, Np, dtype=dtype, device=dev)
-            gemm_nt(dtype, Np, Np, 32, qkv, C3, qkv, C3, S, Np, batch=nwin, strideA=Np * C3, strideB=Np * C3, strideC=Np * Np,
-                    alpha=scale, a_off=h * 32, b_off=Cc + h * 32)
-            P = torch.empty_like(S)
-            K.check(K.lib.lavt_attn_softmax_fwd(K.dt(dtype), K.ptr(S), K.ptr(dense[h]), Np, K.ptr(region), nw_img, K.ptr(P),
-                                                nwin * Np, Np, N, Np, K.stream()))
-            gemm_nt(dtype, Np, 32, Np, P, Np, qkv, C3, out, Cc, batch=nwin, strideA=Np * Np, strideB=Np * C3, strideC=Np * Cc,
-                    b_kmajor=True, b_off=2 * Cc + h * 32, c_off=h * 32)
-            Ps.append(P)
-        ctx.save_for_backward(qkv, dense, region, table, *Ps)
+        S = torch.empty(nb * Np, Np, dtype=dtype, device=dev)
+        gemm_nt(dtype, Np, Np, 32, qh, 96, qh, 96, S, Np, batch=nb, strideA=Np * 96, strideB=Np * 96, strideC=Np * Np, alpha=scale, b_off=32)
+        P = torch.empty_like(S)
+        K.check(K.lib.lavt_attn_softmax_fwd(K.dt(dtype), K.ptr(S), K.ptr(dense), Np, K.ptr(region), nw_img, K.ptr(P), nb * Np, Np, N, Np, heads, K.stream()))
+        del S
+        oh = torch.empty(nb * Np, 32, dtype=dtype, device=dev)
+        gemm_nt(dtype, Np, 32, Np, P, Np, qh, 96, oh, 32, batch=nb, strideA=Np * Np, strideB=Np * 96, strideC=Np * 32, b_kmajor=True, b_off=64)
+        out = oh.view(nwin, heads, Np, 32)[:, :, :N].permute(0, 2, 1, 3).reshape(nwin * N, Cc)
+        ctx.save_for_backward(qh, dense, region, table, P)
         ctx.dims = (win, heads, nwin, N, Np, Cc, nw_img, scale)
-        return out if Np == N else out.view(nwin, Np, Cc)[:, :N].reshape(nwin * N, Cc)
+        return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, dense, region, table, *Ps = ctx.saved_tensors
+        qh, dense, region, table, P = ctx.saved_tensors
         win, heads, nwin, N, Np, Cc, nw_img, scale = ctx.dims
         wd, wh, ww = win
-        dtype, dev = qkv.dtype, qkv.device
-        C3 = 3 * Cc
+        dtype, dev = qh.dtype, qh.device
+        nb = nwin * heads
+        d4 = dout.reshape(nwin, N, heads, 32)
         if Np != N:
-            dout = torch.nn.functional.pad(dout.reshape(nwin, N, Cc), (0, 0, 0, Np - N)).reshape(nwin * Np, Cc)
-        dout = dout.contiguous()
-        dqkv = torch.empty_like(qkv)
-        ddense = torch.empty(heads, N, Np, dtype=torch.float32, device=dev)
-        for h in range(heads):
-            P = Ps[h]
-            dS = torch.empty_like(P)                 # first dP, then overwritten with dS
-            gemm_nt(dtype, Np, Np, 32, dout, Cc, qkv, C3, dS, Np, batch=nwin, strideA=Np * Cc, strideB=Np * C3, strideC=Np * Np,
-                    a_off=h * 32, b_off=2 * Cc + h * 32)
-            K.check(K.lib.lavt_attn_softmax_bwd(K.dt(dtype), K.ptr(P), K.ptr(dS), nwin * Np, N, Np, K.stream()))
-            ddense[h] = dS.view(nwin, Np, Np)[:, :N].float().sum(0)          # bias gradient: sum over windows (tiny; fallback path)
-            # dQ = scale dS K
-            gemm_nt(dtype, Np, 32, Np, dS, Np, qkv, C3, dqkv, C3, batch=nwin, strideA=Np * Np, strideB=Np * C3, strideC=Np * C3,
-                    b_kmajor=True, alpha=scale, b_off=Cc + h * 32, c_off=h * 32)
-            # dK = scale dS^T Q ; dV = P^T dO   (fp32 outputs of the wgrad family, then cast into the qkv gradient)
-            dk = torch.zeros(nwin, Np, 32, dtype=torch.float32, device=dev)
-            dv = torch.zeros_like(dk)
-            gemm_tn(dtype, Np, 32, Np, dS, Np, qkv, C3, dk, 32, batch=nwin, strideA=Np * Np, strideB=Np * C3, strideC=Np * 32,
-                    alpha=scale, b_off=h * 32)
-            gemm_tn(dtype, Np, 32, Np, P, Np, dout, Cc, dv, 32, batch=nwin, strideA=Np * Np, strideB=Np * Cc, strideC=Np * 32, b_off=h * 32)
-            dq3 = dqkv.view(nwin * Np, 3, Cc)
-            dq3[:, 1, h * 32:(h + 1) * 32] = dk.view(nwin * Np, 32).to(dtype)
-            dq3[:, 2, h * 32:(h + 1) * 32] = dv.view(nwin * Np, 32).to(dtype)
+            d4 = torch.nn.functional.pad(d4, (0, 0, 0, 0, 0, Np - N))
+        doh = d4.permute(0, 2, 1, 3).contiguous().view(nb * Np, 32)
+        dS = torch.empty_like(P)                 # first dP = dO V^T, then overwritten with dS
+        gemm_nt(dtype, Np, Np, 32, doh, 32, qh, 96, dS, Np, batch=nb, strideA=Np * 32, strideB=Np * 96, strideC=Np * Np, b_off=64)
+        K.check(K.lib.lavt_attn_softmax_bwd(K.dt(dtype), K.ptr(P), K.ptr(dS), nb * Np, N, Np, K.stream()))
+        ddense = dS.view(nwin, heads, Np, Np)[:, :, :N].float().sum(0)          # bias gradient: sum over windows (one reduction)
+        dqh = torch.empty(nb * Np, 96, dtype=dtype, device=dev)
+        # dQ = scale dS K
+        gemm_nt(dtype, Np, 32, Np, dS, Np, qh, 96, dqh, 96, batch=nb, strideA=Np * Np, strideB=Np * 96, strideC=Np * 96, b_kmajor=True, alpha=scale, b_off=32)
+        # dK = scale dS^T Q ; dV = P^T dO   (fp32 outputs of the wgrad family, then cast into the head-major gradient)
+        dkv = torch.zeros(2, nb * Np, 32, dtype=torch.float32, device=dev)
+        gemm_tn(dtype, Np, 32, Np, dS, Np, qh, 96, dkv[0], 32, batch=nb, strideA=Np * Np, strideB=Np * 96, strideC=Np * 32, alpha=scale)
+        gemm_tn(dtype, Np, 32, Np, P, Np, doh, 32, dkv[1], 32, batch=nb, strideA=Np * Np, strideB=Np * 32, strideC=Np * 32)
+        dqh.view(nb * Np, 3, 32)[:, 1:] = dkv.permute(1, 0, 2).to(dtype)
+        dqkv = dqh.view(nwin, heads, Np, 3, 32)[:, :, :N].permute(0, 2, 3, 1, 4).reshape(nwin * N, 3 * Cc)
         dtable, ts = sinks.buf(table, ((2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1), heads))
-        K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense), K.ptr(dtable), wd, wh, ww, N, heads, Np, K.stream()))
-        if Np != N:
-            dqkv = dqkv.view(nwin, Np, C3)[:, :N].reshape(nwin * N, C3)
+        K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense.contiguous()), K.ptr(dtable), wd, wh, ww, N, heads, Np, K.stream()))
         return dqkv, sinks.done(table, dtable, ts), None, None, None, None
 
 
