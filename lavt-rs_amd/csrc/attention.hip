@@ -232,63 +232,104 @@ __global__ void relpos_reduce_kernel(const float* __restrict__ ddense, float* __
 
 // ---- row softmax of attention scores for the composed (GEMM + softmax + GEMM) path used for windows too large for the
 // fused kernels (Video-Swin: N = 392 / 1152): p = softmax_j(s[i][j] + bias[i][j] + mask(region_i, region_j)), one wave per row.
+// One wave per row, the row held in registers as 16-byte chunks (lane owns chunks lane, lane + 64, ...: one pass over s, 16-byte
+// loads and stores; ld % (16 / sizeof(T)) == 0 and ld <= SM_KMAX * 64 chunks).
+constexpr int SM_KMAX = 6;
 template <typename T>
 __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(const T* __restrict__ s, const float* __restrict__ bias, int bias_ld,
                                                                const int8_t* __restrict__ region, int nw_img, T* __restrict__ p,
                                                                int64_t rows, int rpw, int N, int ld, int heads) {
     // rows are ordered (window, head, token): block b = row / rpw is (window b / heads, head b % heads); bias is [heads][N][bias_ld]
+    constexpr int EPC = Chunk<T>::N;
     const int lane = threadIdx.x & 63;
-    const float* bias0 = bias;
+    const int nch = ld / EPC;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
         const int i = (int)(row % rpw);
         const int64_t blk = row / rpw;
         const int64_t w = blk / heads;
-        bias = bias0 + (blk % heads) * (int64_t)N * bias_ld;
         const T* sr = s + row * ld;
         T* pr = p + row * ld;
         if (i >= N) {                       // padding row of a window whose token count was rounded up
-            for (int j = lane; j < ld; j += 64) pr[j] = from_f<T>(0.f);
+            float z[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) z[e] = 0.f;
+            for (int c = lane; c < nch; c += 64) *reinterpret_cast<uint4*>(pr + c * EPC) = f_to_chunk<T>(z);
             continue;
         }
+        const float* br = bias + ((blk % heads) * (int64_t)N + i) * bias_ld;
         const int8_t* reg = region ? region + (w % nw_img) * N : nullptr;
         const int ri = reg ? reg[i] : 0;
+        float v[SM_KMAX][EPC];
         float mx = -1e30f;
-        for (int j = lane; j < N; j += 64) {
-            float v = to_f<T>(sr[j]) + bias[(int64_t)i * bias_ld + j];
-            if (reg && reg[j] != ri) v += -100.0f;
-            mx = fmaxf(mx, v);
+#pragma unroll
+        for (int k = 0; k < SM_KMAX; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nch) {
+                chunk_to_f<T>(*reinterpret_cast<const uint4*>(sr + c * EPC), v[k]);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const int j = c * EPC + e;
+                    float x = -1e30f;
+                    if (j < N) {
+                        x = v[k][e] + br[j];
+                        if (reg && reg[j] != ri) x += -100.0f;
+                    }
+                    v[k][e] = x;
+                    mx = fmaxf(mx, x);
+                }
+            }
         }
         mx = wave_max(mx);
         float sum = 0.f;
-        for (int j = lane; j < N; j += 64) {
-            float v = to_f<T>(sr[j]) + bias[(int64_t)i * bias_ld + j];
-            if (reg && reg[j] != ri) v += -100.0f;
-            sum += __expf(v - mx);
-        }
+#pragma unroll
+        for (int k = 0; k < SM_KMAX; ++k)
+            if (lane + 64 * k < nch)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { const float ex = (lane + 64 * k) * EPC + e < N ? __expf(v[k][e] - mx) : 0.f; v[k][e] = ex; sum += ex; }
         sum = wave_sum(sum);
         const float inv = 1.f / sum;
-        for (int j = lane; j < ld; j += 64) {
-            float v = 0.f;
-            if (j < N) {
-                v = to_f<T>(sr[j]) + bias[(int64_t)i * bias_ld + j];
-                if (reg && reg[j] != ri) v += -100.0f;
-                v = __expf(v - mx) * inv;
+#pragma unroll
+        for (int k = 0; k < SM_KMAX; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nch) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[k][e] *= inv;
+                *reinterpret_cast<uint4*>(pr + c * EPC) = f_to_chunk<T>(v[k]);
             }
-            pr[j] = from_f<T>(v);
         }
     }
 }
-// ds = p * (dp - sum_j p dp), written over dp; padding columns stay 0
+// ds = p * (dp - sum_j p dp), in place on dp; padding columns of the row are written as 0
 template <typename T>
 __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const T* __restrict__ p, T* __restrict__ dp, int64_t rows, int N, int ld) {
+    constexpr int EPC = Chunk<T>::N;
     const int lane = threadIdx.x & 63;
+    const int nch = ld / EPC;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
         const T* pr = p + row * ld;
         T* dr = dp + row * ld;
+        float fp[SM_KMAX][EPC], fd[SM_KMAX][EPC];
         float dot = 0.f;
-        for (int j = lane; j < N; j += 64) dot += to_f<T>(pr[j]) * to_f<T>(dr[j]);
+#pragma unroll
+        for (int k = 0; k < SM_KMAX; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nch) {
+                chunk_to_f<T>(*reinterpret_cast<const uint4*>(pr + c * EPC), fp[k]);
+                chunk_to_f<T>(*reinterpret_cast<const uint4*>(dr + c * EPC), fd[k]);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) if (c * EPC + e < N) dot += fp[k][e] * fd[k][e];
+            }
+        }
         dot = wave_sum(dot);
-        for (int j = lane; j < ld; j += 64) dr[j] = from_f<T>(j < N ? to_f<T>(pr[j]) * (to_f<T>(dr[j]) - dot) : 0.f);
+#pragma unroll
+        for (int k = 0; k < SM_KMAX; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nch) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) fd[k][e] = c * EPC + e < N ? fp[k][e] * (fd[k][e] - dot) : 0.f;
+                *reinterpret_cast<uint4*>(dr + c * EPC) = f_to_chunk<T>(fd[k]);
+            }
+        }
     }
 }
 
@@ -393,6 +434,7 @@ extern "C" int lavt_relpos_reduce(const float* ddense, float* dtable, int wd, in
 extern "C" int lavt_attn_softmax_fwd(int dtype, const void* s, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* p,
                                      int64_t rows, int rpw, int N, int ld, int heads, void* stream) {
     LAVT_CHECK_ARG(s && bias && p && rows > 0 && N > 0 && rpw >= N && ld >= N && bias_ld >= N && heads >= 1 && (!region || nw_img > 0), "lavt_attn_softmax_fwd: bad arguments");
+    LAVT_CHECK_ARG(ld % (dtype == LAVT_F32 ? 4 : 8) == 0 && ld / (dtype == LAVT_F32 ? 4 : 8) <= SM_KMAX * 64, "lavt_attn_softmax_fwd: ld=%d must be a multiple of the 16-byte chunk and at most %d chunks", ld, SM_KMAX * 64);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int blocks = cdiv(rows, 4);
     if (blocks > 8192) blocks = 8192;
@@ -404,6 +446,7 @@ extern "C" int lavt_attn_softmax_fwd(int dtype, const void* s, const float* bias
 }
 extern "C" int lavt_attn_softmax_bwd(int dtype, const void* p, void* dp, int64_t rows, int N, int ld, void* stream) {
     LAVT_CHECK_ARG(p && dp && rows > 0 && N > 0 && ld >= N, "lavt_attn_softmax_bwd: bad arguments");
+    LAVT_CHECK_ARG(ld % (dtype == LAVT_F32 ? 4 : 8) == 0 && ld / (dtype == LAVT_F32 ? 4 : 8) <= SM_KMAX * 64, "lavt_attn_softmax_bwd: ld=%d must be a multiple of the 16-byte chunk and at most %d chunks", ld, SM_KMAX * 64);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int blocks = cdiv(rows, 4);
     if (blocks > 8192) blocks = 8192;
