@@ -94,9 +94,14 @@ def measure_dominant_kernel(device, iters=20):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * B * H * W * Cout * 9 * Cin
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_nt_kernel<bf16,128,128> (conv3x3 512->512 @120x120, batch 2)", "achieved": round(achieved, 2),
+    traffic = None          # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same kernel (profiles/pmc_dominant_kernel.json)
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")))["traffic_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        pass
+    return {"bound": "mfma", "kernel": "gemm_nt_v2_kernel<256,256,16 waves> implicit GEMM (conv3x3 512->512 @120x120, batch 2)", "achieved": round(achieved, 2),
             "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4),
-            "avg_launch_us": round(ms * 1e3, 2), "flops_per_launch": flops, "traffic": None}
+            "avg_launch_us": round(ms * 1e3, 2), "flops_per_launch": flops, "traffic": traffic}
 
 
 def cpu_baseline(cfg, budget_s=25.0):
