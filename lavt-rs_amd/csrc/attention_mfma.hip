@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
 constexpr int R_LD = 40;        // bf16 elements per LDS row of Q / K / V / dO (80 B rows, 16-byte aligned chunks)
 
 template <int NT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 2) void wattn_bwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void wattn_bwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                       const int8_t* __restrict__ region, int nw_img, const bf16* __restrict__ out,
                                                       const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                       bf16* __restrict__ dqkv, float* __restrict__ slab, int slab_ld,
@@ -500,9 +500,10 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
         hipLaunchKernelGGL((wattn_bwd_mfma<NT_, WV_>), grid, dim3(WV_ * 64), lds, st, (const bf16*)qkv, table, region, nw_img,              \
                            (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, ws, bias_ld, wd, wh, ww, nwin, N, heads, scale, wpb);     \
     } while (0)
-    // 8 waves share one window-head when all of them fit the chip in one round at one workgroup per CU (163 VGPRs); else 4 waves, 2 per CU
+    // 8 waves share one window-head, capped at 128 VGPRs so two workgroups (16 waves) sit on a CU: 5-9% faster than 4 waves x 2 at every
+    // stage shape of Swin-B w12 @480 (measured, tools/attn_bench2.py).  LAVT_ATTN_BWD_WAVES=4 keeps the 4-wave variant reachable.
     static const int force_waves = getenv("LAVT_ATTN_BWD_WAVES") ? atoi(getenv("LAVT_ATTN_BWD_WAVES")) : 0;
-    const int waves = force_waves ? force_waves : ((long)chunks * heads <= 256 ? 8 : 4);
+    const int waves = force_waves ? force_waves : 8;
     if (N <= 64) LAVT_BWD(4, 4);
     else if (N <= 144) { if (waves == 8) LAVT_BWD(9, 8); else LAVT_BWD(9, 4); }
     else { if (waves == 8) LAVT_BWD(10, 8); else LAVT_BWD(10, 4); }

@@ -80,6 +80,46 @@ __device__ __forceinline__ void tr_read_tile(unsigned addr, u64 (&l0)[NF], u64 (
     }
     __builtin_amdgcn_sched_barrier(0);
 }
+// Same, for the XOR-swizzled k-major tiles of tn_tile: one address VGPR per fragment (the swizzle permutes the fragments' 32-byte
+// slots differently in every lane, so they are no longer a compile-time stride apart); the second 4-row block (HO) and the second
+// k-step (KO) stay immediates because the swizzle ignores those row bits.
+template <int NF, int HO, int KO>
+__device__ __forceinline__ void tr_read_frags(const unsigned (&a)[NF], u64 (&l0)[NF], u64 (&h0)[NF], u64 (&l1)[NF], u64 (&h1)[NF]) {
+    static_assert(NF == 2 || NF == 4, "NF");
+    if constexpr (NF == 4) {
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:%c20\n\t"
+            "ds_read_b64_tr_b16 %2, %17\n\tds_read_b64_tr_b16 %3, %17 offset:%c20\n\t"
+            "ds_read_b64_tr_b16 %4, %18\n\tds_read_b64_tr_b16 %5, %18 offset:%c20\n\t"
+            "ds_read_b64_tr_b16 %6, %19\n\tds_read_b64_tr_b16 %7, %19 offset:%c20\n\t"
+            "ds_read_b64_tr_b16 %8, %16 offset:%c21\n\tds_read_b64_tr_b16 %9, %16 offset:%c21+%c20\n\t"
+            "ds_read_b64_tr_b16 %10, %17 offset:%c21\n\tds_read_b64_tr_b16 %11, %17 offset:%c21+%c20\n\t"
+            "ds_read_b64_tr_b16 %12, %18 offset:%c21\n\tds_read_b64_tr_b16 %13, %18 offset:%c21+%c20\n\t"
+            "ds_read_b64_tr_b16 %14, %19 offset:%c21\n\tds_read_b64_tr_b16 %15, %19 offset:%c21+%c20\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(l0[0]), "=&v"(h0[0]), "=&v"(l0[1]), "=&v"(h0[1]), "=&v"(l0[2]), "=&v"(h0[2]), "=&v"(l0[3]), "=&v"(h0[3]),
+              "=&v"(l1[0]), "=&v"(h1[0]), "=&v"(l1[1]), "=&v"(h1[1]), "=&v"(l1[2]), "=&v"(h1[2]), "=&v"(l1[3]), "=&v"(h1[3])
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(HO), "n"(KO)
+            : "memory");
+    } else {
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%c10\n\t"
+            "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:%c10\n\t"
+            "ds_read_b64_tr_b16 %4, %8 offset:%c11\n\tds_read_b64_tr_b16 %5, %8 offset:%c11+%c10\n\t"
+            "ds_read_b64_tr_b16 %6, %9 offset:%c11\n\tds_read_b64_tr_b16 %7, %9 offset:%c11+%c10\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(l0[0]), "=&v"(h0[0]), "=&v"(l0[1]), "=&v"(h0[1]), "=&v"(l1[0]), "=&v"(h1[0]), "=&v"(l1[1]), "=&v"(h1[1])
+            : "v"(a[0]), "v"(a[1]), "n"(HO), "n"(KO)
+            : "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+// 32-byte slot swizzle of a k-major [64][CH x 16 B] tile: the 16 K rows one transposing read touches (rows r, r+1, r+2, r+3 of four 8-row
+// blocks) land in different slots.  Uses row bits 0, 1, 3, 4 only, so rows r + 4 and r + 32 share the swizzle of row r.
+template <int CH> __device__ __forceinline__ int tn_swz(int kr) {
+    constexpr int FM = (CH / 2 - 1) < 15 ? (CH / 2 - 1) : 15;
+    return (((kr & 3) | ((kr >> 1) & 12)) & FM) << 1;
+}
 __device__ __forceinline__ bf16x8 frag_from(u64 lo, u64 hi) {
     typedef __attribute__((__vector_size__(2 * sizeof(u64)))) u64 u64x2;
     u64x2 v = {lo, hi};
@@ -387,11 +427,15 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
                                         const int nsplit, char* smem) {
     using T = bf16;
     constexpr int BK = 64, EPC = 8;
-    constexpr int WAVES_J = WAVES / 2;
-    constexpr int A_LD = BI + KM_PAD, B_LD = BJ + KM_PAD, A_CH = A_LD / EPC, B_CH = B_LD / EPC;
-    constexpr int A_INSTR = (BK * A_CH + 64 * WAVES - 1) / (64 * WAVES), B_INSTR = (BK * B_CH + 64 * WAVES - 1) / (64 * WAVES);
+    constexpr int WAVES_I = 2, WAVES_J = WAVES / WAVES_I;
+    // LDS tiles are k-major [BK][BI] / [BK][BJ] without padding; bank conflicts of the transposing reads are avoided by the tn_swz slot
+    // swizzle, applied on the DMA side through the source address each lane fetches (the LDS image of a DMA instruction is lane-linear).
+    // (A padded row -- 16 extra elements -- cost a third DMA instruction per operand per K tile whose lanes mostly fetched the zero page.)
+    constexpr int A_CH = BI / EPC, B_CH = BJ / EPC;
+    constexpr int A_INSTR = BK * A_CH / (64 * WAVES), B_INSTR = BK * B_CH / (64 * WAVES);
+    static_assert(A_INSTR * 64 * WAVES == BK * A_CH && B_INSTR * 64 * WAVES == BK * B_CH, "whole DMA instructions per operand tile");
     constexpr int A_BYTES = A_INSTR * WAVES * 1024, B_BYTES = B_INSTR * WAVES * 1024, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int WI = BI / 2, WJ = BJ / WAVES_J, II = WI / 16, JJ = WJ / 16;
+    constexpr int WI = BI / WAVES_I, WJ = BJ / WAVES_J, II = WI / 16, JJ = WJ / 16;
     constexpr int G = A_INSTR + B_INSTR + (MAPS ? 1 : 0);              // vector-memory ops per wave per K tile
     constexpr int AHEAD = 2 * (STAGES - 1);                              // map DMA runs this many tiles ahead of the compute
     constexpr int NSLOT = AHEAD + 1, SLOT_BYTES = 768;                   // map ring: [slot][a_map | a_rowscale | b_map][64] (+ one 256 B spare for waves >= 3)
@@ -422,16 +466,16 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
     int64_t b_ld[B_INSTR];
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
-        const int q = (wave * A_INSTR + i) * 64 + lane, kr = q / A_CH, cc = q - kr * A_CH;
-        const bool ok = kr < BK && cc * EPC < BI && i0 + cc * EPC < p.I;
+        const int q = (wave * A_INSTR + i) * 64 + lane, kr = q / A_CH, cc = (q - kr * A_CH) ^ tn_swz<A_CH>(kr);
+        const bool ok = i0 + cc * EPC < p.I;
         a_kr[i] = ok ? kr : -1;
         a_col[i] = i0 + cc * EPC;
     }
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
-        const int q = (wave * B_INSTR + i) * 64 + lane, kr = q / B_CH, cc = q - kr * B_CH;
+        const int q = (wave * B_INSTR + i) * 64 + lane, kr = q / B_CH, cc = (q - kr * B_CH) ^ tn_swz<B_CH>(kr);
         const int jb = j0 + cc * EPC;
-        const bool ok = kr < BK && cc * EPC < BJ && jb < p.J;
+        const bool ok = jb < p.J;
         b_kr[i] = ok ? kr : -1;
         int jc = jb, dz = 0, dy = 0, dx = 0;
         if (conv) { const int tap = jb / p.conv_kc; jc = jb - tap * p.conv_kc; conv_tap(cg, tap, dz, dy, dx); }
@@ -545,6 +589,16 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
         }
     };
 
+    // fragment read addresses relative to a stage's operand tile: K row of the lane, swizzled 32-byte slot of fragment i, 8-byte half
+    unsigned relA[II], relB[JJ];
+    {
+        const int row_off = 8 * (lane >> 4) + ((lane & 15) >> 2);
+        const int sA = tn_swz<A_CH>(row_off), sB = tn_swz<B_CH>(row_off);
+#pragma unroll
+        for (int i = 0; i < II; ++i) relA[i] = (unsigned)(row_off * BI + ((((wi * WI) / 8 + 2 * i) ^ sA) + ((lane & 3) >> 1)) * 8 + (lane & 1) * 4) * 2;
+#pragma unroll
+        for (int i = 0; i < JJ; ++i) relB[i] = (unsigned)(row_off * BJ + ((((wj * WJ) / 8 + 2 * i) ^ sB) + ((lane & 3) >> 1)) * 8 + (lane & 1) * 4) * 2;
+    }
     f32x4 acc[II][JJ];
 #pragma unroll
     for (int i = 0; i < II; ++i)
@@ -568,12 +622,15 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
         if (j + STAGES - 1 < n) { issue(j + STAGES - 1); map_dma(j + STAGES - 1 + AHEAD); }
         const char* cA = smem + (j % STAGES) * STAGE_BYTES;
         const char* cB = cA + A_BYTES;
-        const unsigned row_off = (unsigned)((8 * (lane >> 4) + ((lane & 15) >> 2)));
-        const unsigned aA = lds_addr(cA) + (row_off * A_LD + wi * WI + 4 * (lane & 3)) * 2;
-        const unsigned aB = lds_addr(cB) + (row_off * B_LD + wj * WJ + 4 * (lane & 3)) * 2;
+        const unsigned baseA = lds_addr(cA), baseB = lds_addr(cB);
+        unsigned aA[II], aB[JJ];
+#pragma unroll
+        for (int i = 0; i < II; ++i) aA[i] = baseA + relA[i];
+#pragma unroll
+        for (int i = 0; i < JJ; ++i) aB[i] = baseB + relB[i];
         u64 al0[II], ah0[II], al1[II], ah1[II], bl0[JJ], bh0[JJ], bl1[JJ], bh1[JJ];
-        tr_read_tile<II, 32, 4 * A_LD * 2, 32 * A_LD * 2>(aA, al0, ah0, al1, ah1);
-        tr_read_tile<JJ, 32, 4 * B_LD * 2, 32 * B_LD * 2>(aB, bl0, bh0, bl1, bh1);
+        tr_read_frags<II, 4 * BI * 2, 32 * BI * 2>(aA, al0, ah0, al1, ah1);
+        tr_read_frags<JJ, 4 * BJ * 2, 32 * BJ * 2>(aB, bl0, bh0, bl1, bh1);
 #pragma unroll
         for (int i = 0; i < II; ++i)
 #pragma unroll
@@ -582,9 +639,9 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
                 acc[i][jj] = mfma16<T>(frag_from(al1[i], ah1[i]), frag_from(bl1[jj], bh1[jj]), acc[i][jj]);
             }
         if (do_colsum) {
-            const T* col = reinterpret_cast<const T*>(cA) + tid;
+            const T* col = reinterpret_cast<const T*>(cA) + (tid & 7);
 #pragma unroll 8
-            for (int k = 0; k < BK; ++k) csum += to_f<T>(col[k * A_LD]);
+            for (int k = 0; k < BK; ++k) csum += to_f<T>(col[k * BI + (((tid >> 3) ^ tn_swz<A_CH>(k)) << 3)]);
         }
     }
 
@@ -639,9 +696,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_grouped_kernel(const Tn
 }
 
 template <int BI, int BJ, int WAVES, int STAGES, bool MAPS> int launch_tn_v2_(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
-    constexpr int A_CH = (BI + KM_PAD) / 8, B_CH = (BJ + KM_PAD) / 8;
-    constexpr int A_INSTR = (64 * A_CH + 64 * WAVES - 1) / (64 * WAVES), B_INSTR = (64 * B_CH + 64 * WAVES - 1) / (64 * WAVES);
-    constexpr size_t lds = STAGES * (size_t)(A_INSTR + B_INSTR) * WAVES * 1024 + (MAPS ? (2 * (STAGES - 1) + 1) * 768 + 256 : 0);
+    constexpr size_t lds = STAGES * (size_t)(64 * (BI + BJ) * 2) + (MAPS ? (2 * (STAGES - 1) + 1) * 768 + 256 : 0);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -740,9 +795,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     for (int i = n; i < TN_GROUP_MAX; ++i) { g.p[i] = probs[0]; g.tile_end[i] = tiles; }
     g.n = n;
     if (tiles < 256) return 1;                       // too few tiles to fill the chip without split-K
-    constexpr int A_CH = (64 + KM_PAD) / 8;
-    constexpr int INSTR = (64 * A_CH + 64 * 4 - 1) / (64 * 4);
-    const size_t lds = 2 * (size_t)(2 * INSTR) * 4 * 1024 + (maps ? 3 * 768 + 256 : 0);
+    const size_t lds = 2 * (size_t)(64 * (64 + 64) * 2) + (maps ? 3 * 768 + 256 : 0);
     if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true>), dim3(tiles), dim3(256), lds, st, g);
     else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, false>), dim3(tiles), dim3(256), lds, st, g);
     LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
@@ -765,7 +818,7 @@ int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st) {
     // conv weight gradients (long K, >= 128 tiles of 128x128): the larger tile halves the L2->LDS bytes per MFMA (measured 303 vs 357 us)
     static const bool tn128 = getenv("LAVT_TN_BIG") == nullptr || getenv("LAVT_TN_BIG")[0] != '0';
     const bool big = force ? force == 128 : (tn128 && p.conv_kc > 0 && tiles128 >= 128 && ktiles >= 64);
-    const long tiles = big ? (long)cdiv(p.I, 128) * cdiv(p.J, 128) * p.batch : tiles64;
+    const long tiles = big ? tiles128 : tiles64;
     int split = p.split_k;
     { const char* se = getenv("LAVT_TN_SPLIT"); if (se) split = atoi(se); }
     if (split <= 0) {
