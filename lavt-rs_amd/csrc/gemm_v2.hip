@@ -42,47 +42,12 @@ template <int G> __device__ __forceinline__ void wait_groups(int g) {      // le
 // ---- transposing LDS reads issued from inline asm --------------------------------------------------------------------
 // hipcc puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr builtin while LDS-DMA is in flight (it cannot tell the stages
 // apart), which would serialise the pipeline.  Asm reads are invisible to that pass; we wait for them ourselves:
-// issue all reads of a K tile ("=v" outputs), then ONE statement `s_waitcnt lgkmcnt(0)` that names every destination "+v"
-// (so no consumer can be scheduled above it), then sched_barrier (cdna_hip_programming.md rule 18 / 5.7 form ii).
-// All 2*NF reads of one k-step share one address VGPR: they differ by compile-time byte offsets.
+// (cdna_hip_programming.md rule 18).
 typedef unsigned long long u64;
-// One statement = all transposing reads of a K tile (both k-steps) + the wait, early-clobber outputs: the compiler can
-// neither copy a destination before its data has landed nor schedule a consumer above the wait (5.7 form i).
-// Reads differ by compile-time byte offsets from one address VGPR: fragment stride SF, second 4-row block HO, k-step KO.
-template <int NF, int SF, int HO, int KO>
-__device__ __forceinline__ void tr_read_tile(unsigned addr, u64 (&l0)[NF], u64 (&h0)[NF], u64 (&l1)[NF], u64 (&h1)[NF]) {
-    static_assert(NF == 2 || NF == 4, "NF");
-    if constexpr (NF == 4) {
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:%c18\n\t"
-            "ds_read_b64_tr_b16 %2, %16 offset:%c17\n\tds_read_b64_tr_b16 %3, %16 offset:%c17+%c18\n\t"
-            "ds_read_b64_tr_b16 %4, %16 offset:2*%c17\n\tds_read_b64_tr_b16 %5, %16 offset:2*%c17+%c18\n\t"
-            "ds_read_b64_tr_b16 %6, %16 offset:3*%c17\n\tds_read_b64_tr_b16 %7, %16 offset:3*%c17+%c18\n\t"
-            "ds_read_b64_tr_b16 %8, %16 offset:%c19\n\tds_read_b64_tr_b16 %9, %16 offset:%c19+%c18\n\t"
-            "ds_read_b64_tr_b16 %10, %16 offset:%c19+%c17\n\tds_read_b64_tr_b16 %11, %16 offset:%c19+%c17+%c18\n\t"
-            "ds_read_b64_tr_b16 %12, %16 offset:%c19+2*%c17\n\tds_read_b64_tr_b16 %13, %16 offset:%c19+2*%c17+%c18\n\t"
-            "ds_read_b64_tr_b16 %14, %16 offset:%c19+3*%c17\n\tds_read_b64_tr_b16 %15, %16 offset:%c19+3*%c17+%c18\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(l0[0]), "=&v"(h0[0]), "=&v"(l0[1]), "=&v"(h0[1]), "=&v"(l0[2]), "=&v"(h0[2]), "=&v"(l0[3]), "=&v"(h0[3]),
-              "=&v"(l1[0]), "=&v"(h1[0]), "=&v"(l1[1]), "=&v"(h1[1]), "=&v"(l1[2]), "=&v"(h1[2]), "=&v"(l1[3]), "=&v"(h1[3])
-            : "v"(addr), "n"(SF), "n"(HO), "n"(KO)
-            : "memory");
-    } else {
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%c10\n\t"
-            "ds_read_b64_tr_b16 %2, %8 offset:%c9\n\tds_read_b64_tr_b16 %3, %8 offset:%c9+%c10\n\t"
-            "ds_read_b64_tr_b16 %4, %8 offset:%c11\n\tds_read_b64_tr_b16 %5, %8 offset:%c11+%c10\n\t"
-            "ds_read_b64_tr_b16 %6, %8 offset:%c11+%c9\n\tds_read_b64_tr_b16 %7, %8 offset:%c11+%c9+%c10\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(l0[0]), "=&v"(h0[0]), "=&v"(l0[1]), "=&v"(h0[1]), "=&v"(l1[0]), "=&v"(h1[0]), "=&v"(l1[1]), "=&v"(h1[1])
-            : "v"(addr), "n"(SF), "n"(HO), "n"(KO)
-            : "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-// Same, for the XOR-swizzled k-major tiles of tn_tile: one address VGPR per fragment (the swizzle permutes the fragments' 32-byte
-// slots differently in every lane, so they are no longer a compile-time stride apart); the second 4-row block (HO) and the second
-// k-step (KO) stay immediates because the swizzle ignores those row bits.
+// One statement = all transposing reads of a K tile (both k-steps) + the wait, early-clobber outputs: the compiler can neither copy a
+// destination before its data has landed nor schedule a consumer above the wait (5.7 form i).  One address VGPR per fragment (the slot
+// swizzle of the k-major tiles permutes the fragments' 32-byte slots differently in every lane, so they are not a compile-time stride
+// apart); the second 4-row block (HO) and the second k-step (KO) are immediates because the swizzle ignores those row bits.
 template <int NF, int HO, int KO>
 __device__ __forceinline__ void tr_read_frags(const unsigned (&a)[NF], u64 (&l0)[NF], u64 (&h0)[NF], u64 (&l1)[NF], u64 (&h1)[NF]) {
     static_assert(NF == 2 || NF == 4, "NF");
@@ -114,6 +79,21 @@ __device__ __forceinline__ void tr_read_frags(const unsigned (&a)[NF], u64 (&l0)
     }
     __builtin_amdgcn_sched_barrier(0);
 }
+// One k-step (32 K rows) only: the 16-wave 256x256 tiles have 128 registers per lane and hold one k-step of operands at a time.
+template <int NF, int HO, int KOFF>
+__device__ __forceinline__ void tr_read_frags_step(const unsigned (&a)[NF], u64 (&l)[NF], u64 (&h)[NF]) {
+    static_assert(NF == 4, "NF");
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%c13\n\tds_read_b64_tr_b16 %1, %8 offset:%c13+%c12\n\t"
+        "ds_read_b64_tr_b16 %2, %9 offset:%c13\n\tds_read_b64_tr_b16 %3, %9 offset:%c13+%c12\n\t"
+        "ds_read_b64_tr_b16 %4, %10 offset:%c13\n\tds_read_b64_tr_b16 %5, %10 offset:%c13+%c12\n\t"
+        "ds_read_b64_tr_b16 %6, %11 offset:%c13\n\tds_read_b64_tr_b16 %7, %11 offset:%c13+%c12\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]), "=&v"(l[2]), "=&v"(h[2]), "=&v"(l[3]), "=&v"(h[3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(HO), "n"(KOFF)
+        : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 // 32-byte slot swizzle of a k-major [64][CH x 16 B] tile: the 16 K rows one transposing read touches (rows r, r+1, r+2, r+3 of four 8-row
 // blocks) land in different slots.  Uses row bits 0, 1, 3, 4 only, so rows r + 4 and r + 32 share the swizzle of row r.
 template <int CH> __device__ __forceinline__ int tn_swz(int kr) {
@@ -143,12 +123,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
     constexpr int WAVES_M = WAVES == 16 ? 4 : 2;             // wave grid: WAVES_M (M) x WAVES_N (N); 16 waves: 4 x 4 waves of 64 x 64
     constexpr int WAVES_N = WAVES / WAVES_M;
     constexpr int A_INSTR = BM / (8 * WAVES);                // DMA instructions per wave per K tile for A (8 rows x 8 chunks each)
-    constexpr int B_LD = BN + KM_PAD;                        // k-major B row (elements)
-    constexpr int B_CH = B_LD / EPC;                         // chunks per k-major row
-    constexpr int B_INSTR = BKM ? (BK * B_CH + 64 * WAVES - 1) / (64 * WAVES) : BN / (8 * WAVES);
+    constexpr int B_CH = BN / EPC;                           // chunks per k-major B row: [BK][BN] unpadded, 32-byte slots swizzled by tn_swz
+    constexpr int B_INSTR = BN / (8 * WAVES);                // (k-contiguous and k-major tiles both hold BN * BK elements)
     constexpr int L = A_INSTR + B_INSTR;
     constexpr int A_BYTES = BM * BK * 2;
-    constexpr int B_BYTES = BKM ? B_INSTR * WAVES * 1024 : BN * BK * 2;
+    constexpr int B_BYTES = BN * BK * 2;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NI = WN / 16;
     static_assert(A_INSTR >= 1 && B_INSTR >= 1 && MI >= 1 && NI >= 1, "tile too small for this many waves");
@@ -190,9 +169,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
             b_col[i] = 0;
         } else {
             const int q = (wave * B_INSTR + i) * 64 + lane;
-            const int kr = q / B_CH, cc = q - kr * B_CH;
+            const int kr = q / B_CH, cc = (q - kr * B_CH) ^ tn_swz<B_CH>(kr);
             const int n = n0 + cc * EPC;
-            const bool ok = kr < BK && cc * EPC < BN && n < p.N;
+            const bool ok = n < p.N;
             b_row[i] = ok ? kr : -1;
             b_col[i] = n;
         }
@@ -347,16 +326,51 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         if (kt + STAGES - 1 < ktiles) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
         const T* cA = reinterpret_cast<const T*>(smem + (kt % STAGES) * STAGE_BYTES);
         const T* cB = reinterpret_cast<const T*>(smem + (kt % STAGES) * STAGE_BYTES + A_BYTES);
+        if constexpr (WAVES == 16) {
+            // one k-step of fragments at a time (64 accumulator + 32 fragment registers of the 128 a lane has with 16 waves per workgroup)
+            unsigned ab[NI];
+            if constexpr (BKM) {
+                const int row_off = 8 * (lane >> 4) + ((lane & 15) >> 2), sw = tn_swz<B_CH>(row_off);
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    ab[j] = lds_addr(cB) + (unsigned)(row_off * BN + ((((wn * WN) / 8 + 2 * j) ^ sw) + ((lane & 3) >> 1)) * 8 + (lane & 1) * 4) * 2;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ga[MI], gb[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) ga[i] = frag_kc<T>(cA, wm * WM + i * 16, ks, lane);
+                if constexpr (BKM) {
+                    u64 l[NI], h[NI];
+                    if (ks == 0) tr_read_frags_step<NI, 4 * BN * 2, 0>(ab, l, h);
+                    else tr_read_frags_step<NI, 4 * BN * 2, 32 * BN * 2>(ab, l, h);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) gb[j] = frag_from(l[j], h[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) gb[j] = frag_kc<T>(cB, wn * WN + j * 16, ks, lane);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma16<T>(gb[j], ga[i], acc[i][j]);
+            }
+            continue;
+        }
         bf16x8 fa[2][MI], fb[2][NI];
         if constexpr (BKM) {
-            // lane address of (k-step 0, fragment 0): row 8*(lane>>4) + ((lane&15)>>2), column wn*WN + 4*(lane&3)
-            const unsigned a0 = lds_addr(cB) + (unsigned)(((8 * (lane >> 4) + ((lane & 15) >> 2)) * B_LD + wn * WN + 4 * (lane & 3)) * 2);
+            // lane address of (k-step 0, fragment j): row 8*(lane>>4) + ((lane&15)>>2), swizzled 32-byte slot of column wn*WN + 16*j, 8-byte half
+            const int row_off = 8 * (lane >> 4) + ((lane & 15) >> 2), sw = tn_swz<B_CH>(row_off);
+            unsigned ab[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                ab[j] = lds_addr(cB) + (unsigned)(row_off * BN + ((((wn * WN) / 8 + 2 * j) ^ sw) + ((lane & 3) >> 1)) * 8 + (lane & 1) * 4) * 2;
             u64 l0[NI], h0[NI], l1[NI], h1[NI];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int i = 0; i < MI; ++i) fa[ks][i] = frag_kc<T>(cA, wm * WM + i * 16, ks, lane);
-            tr_read_tile<NI, 32, 4 * B_LD * 2, 32 * B_LD * 2>(a0, l0, h0, l1, h1);
+            tr_read_frags<NI, 4 * BN * 2, 32 * BN * 2>(ab, l0, h0, l1, h1);
 #pragma unroll
             for (int j = 0; j < NI; ++j) { fb[0][j] = frag_from(l0[j], h0[j]); fb[1][j] = frag_from(l1[j], h1[j]); }
         } else {
@@ -382,8 +396,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
 }
 
 template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE> int launch_nt_v2_(const lavt_gemm_nt_t& p, hipStream_t st) {
-    constexpr int B_INSTR = BKM ? (64 * ((BN + KM_PAD) / 8) + 64 * WAVES - 1) / (64 * WAVES) : BN / (8 * WAVES);
-    constexpr size_t lds = STAGES * (size_t)(BM * 128 + (BKM ? B_INSTR * WAVES * 1024 : BN * 128));
+    constexpr size_t lds = STAGES * (size_t)(BM * 128 + BN * 128);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -753,7 +766,7 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     // Only when its tiles fill the 256 CUs well (whole rounds at >= 80 %).
     const long tiles256x = (long)cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch;
     const long rounds = (tiles256x + 255) / 256;
-    const bool huge = force ? force == 512 : (!p.b_kmajor && p.N % 256 == 0 && p.K >= 1024 && tiles256x >= 128 && tiles256x * 10 >= rounds * 256 * 8);      // k-major B (data gradients): measured slower (423 vs 196 us)
+    const bool huge = force ? force == 512 : (p.N % 256 == 0 && p.K >= 1024 && tiles256x >= 128 && tiles256x * 10 >= rounds * 256 * 8);
     if (huge) { if (p.b_kmajor) GO(256, 256, true, 2, 16); else GO(256, 256, false, 2, 16); }
     if (big) {
         if (waves == 8) {
@@ -795,6 +808,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     for (int i = n; i < TN_GROUP_MAX; ++i) { g.p[i] = probs[0]; g.tile_end[i] = tiles; }
     g.n = n;
     if (tiles < 256) return 1;                       // too few tiles to fill the chip without split-K
+    // (a 128x64 tile -- 3/4 of the operand bytes per flop -- measured slower on the stage-2 block: 13.34 vs 12.96 ms per step)
     const size_t lds = 2 * (size_t)(64 * (64 + 64) * 2) + (maps ? 3 * 768 + 256 : 0);
     if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true>), dim3(tiles), dim3(256), lds, st, g);
     else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, false>), dim3(tiles), dim3(256), lds, st, g);
