@@ -286,6 +286,20 @@ int lavt_cast_multi(const int64_t* desc, int count, int dst_dtype, void* stream)
  * base lr when total_steps <= 0.  Update rule identical to torch.optim.AdamW (decoupled decay, bias-corrected moments). */
 int lavt_adamw_step(const int64_t* desc, const float* hyper, int count, float* step, float total_steps, float power, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Text side (lavt_one / lavt_video carry BERT inside the model: lib/_utils.py:38-52; train.py:595-602; the encoder is HF transformers
+ * 3.0.2 `BertModel`, absent from the reference tree).  Its Linear / LayerNorm / GELU / attention GEMMs use the entry points above.
+ * lavt_bert_embed_fwd: out[r] = word[ids[r]] + type[token_type ? token_type[r] : 0] + pos[r % N]  (BertEmbeddings.forward before LayerNorm;
+ *   ids / token_type int64 [rows], tables fp32, out [rows][H] in `dtype`).  lavt_bert_embed_bwd scatter-adds dy into the three fp32 table
+ *   gradients (atomics; the buffers must hold the running sums, e.g. zeros).
+ * lavt_dropout: y = (keep ? x * scale : 0) + residual (nn.Dropout in training with a caller-drawn uint8 keep mask, scale = 1/(1-p); residual
+ *   optional: the `dropout(dense(h)) + input` of BertSelfOutput / BertOutput); without residual it is its own backward. */
+int lavt_bert_embed_fwd(int dtype, const int64_t* ids, const int64_t* token_type, const float* word, const float* pos, const float* type,
+                        void* out, int rows, int N, int H, void* stream);
+int lavt_bert_embed_bwd(int dtype, const void* dy, const int64_t* ids, const int64_t* token_type, float* dword, float* dpos, float* dtype_,
+                        int rows, int N, int H, void* stream);
+int lavt_dropout(int dtype, const void* x, const uint8_t* keep, float scale, const void* residual, void* y, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

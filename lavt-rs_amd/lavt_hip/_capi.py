@@ -69,6 +69,9 @@ _PROTOTYPES = {
     "lavt_norm_bwd_stats": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, i32, i32, i32, vp],
     "lavt_norm_bwd_apply": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, f32, vp, vp, i32, i32, i32, vp],
     "lavt_act_bwd": [i32, i32, vp, vp, vp, i64, vp],
+    "lavt_bert_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "lavt_bert_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "lavt_dropout": [i32, vp, vp, f32, vp, vp, i64, vp],
     "lavt_gate_fwd": [i32, vp, vp, vp, vp, i64, vp],
     "lavt_gate_bwd": [i32, vp, vp, vp, vp, vp, i64, vp],
     "lavt_rowsoftmax_fwd": [i32, vp, vp, i64, i32, i32, vp],

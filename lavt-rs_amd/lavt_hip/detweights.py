@@ -35,7 +35,7 @@ def det_tensor(name: str, shape, dtype=torch.float32, salt: int = 0) -> torch.Te
     def normal(std):
         return torch.from_numpy(g.standard_normal(shape).astype(np.float32) * np.float32(std))
 
-    is_norm = (".norm" in name or name.startswith("norm") or ".bn" in name or "patch_embed.norm" in name)
+    is_norm = (".norm" in name or name.startswith("norm") or ".bn" in name or "patch_embed.norm" in name or "LayerNorm" in name)
     if leaf == "running_mean":
         t = normal(0.1)
     elif leaf == "running_var":

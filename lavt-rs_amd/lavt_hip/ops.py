@@ -776,6 +776,139 @@ def pwam_attention(q, k, v, maskbias, B, T, n_l, G):
     return _PwamAttn.apply(q, k, v, maskbias, B, T, n_l, G)
 
 
+# ------------------------------------------------------------------------------------------ text side (BERT encoder of lavt_one / lavt_video)
+class _BertEmbed(torch.autograd.Function):
+    """word[ids] + token_type[tt] + position[0..N-1] (BertEmbeddings.forward before its LayerNorm; HF transformers 3.0.2 modeling_bert.py)."""
+
+    @staticmethod
+    def forward(ctx, ids, tt, word, pos, typ, N, dtype):
+        ids = ids.contiguous().view(-1).long()
+        tt = tt.contiguous().view(-1).long() if tt is not None else None
+        rows, H = ids.numel(), word.shape[1]
+        assert N <= pos.shape[0], f"bert_embed: {N} tokens but only {pos.shape[0]} positions"
+        out = torch.empty(rows, H, dtype=dtype, device=word.device)
+        K.check(K.lib.lavt_bert_embed_fwd(K.dt(dtype), K.ptr(ids), K.ptr(tt), K.ptr(_f32(word)), K.ptr(_f32(pos)), K.ptr(_f32(typ)), K.ptr(out),
+                                          rows, N, H, K.stream()))
+        ctx.save_for_backward(ids, tt, word, pos, typ)
+        ctx.N = N
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, tt, word, pos, typ = ctx.saved_tensors
+        dy = dy.contiguous()
+        dw, ws = sinks.buf(word, tuple(word.shape))
+        dp, ps = sinks.buf(pos, tuple(pos.shape))
+        dt_, ts = sinks.buf(typ, tuple(typ.shape))
+        K.check(K.lib.lavt_bert_embed_bwd(K.dt(dy.dtype), K.ptr(dy), K.ptr(ids), K.ptr(tt), K.ptr(dw), K.ptr(dp), K.ptr(dt_), ids.numel(), ctx.N,
+                                          word.shape[1], K.stream()))
+        return None, None, sinks.done(word, dw, ws), sinks.done(pos, dp, ps), sinks.done(typ, dt_, ts), None, None
+
+
+def bert_embed(ids, token_type_ids, word, pos, typ, N, dtype):
+    return _BertEmbed.apply(ids, token_type_ids, word, pos, typ, N, dtype)
+
+
+class _Dropout(torch.autograd.Function):
+    """y = dropout(x) (+ residual): the keep mask is drawn with torch's generator (so torch.manual_seed governs it, as for nn.Dropout),
+    the scaling / masking / residual add is one HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p):
+        x = x.contiguous()
+        keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device).bernoulli_(1.0 - p)
+        y = torch.empty_like(x)
+        if residual is not None:
+            residual = residual.contiguous()
+        K.check(K.lib.lavt_dropout(K.dt(x.dtype), K.ptr(x), K.ptr(keep), 1.0 / (1.0 - p), K.ptr(residual), K.ptr(y), x.numel(), K.stream()))
+        ctx.save_for_backward(keep)
+        ctx.scale, ctx.has_res = 1.0 / (1.0 - p), residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        keep, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        K.check(K.lib.lavt_dropout(K.dt(dy.dtype), K.ptr(dy), K.ptr(keep), ctx.scale, None, K.ptr(dx), dy.numel(), K.stream()))
+        return dx, (dy if ctx.has_res else None), None
+
+
+def dropout(x, p, training, residual=None):
+    """nn.Dropout(p)(x) [+ residual]; identity (plus the residual through `linear`'s epilogue upstream) when not training or p == 0"""
+    if not training or p <= 0.0:
+        assert residual is None, "fold the residual into the producing linear() when dropout is off"
+        return x
+    return _Dropout.apply(x, residual, float(p))
+
+
+class _MaskedSelfAttn(torch.autograd.Function):
+    """BertSelfAttention core: softmax(q k^T / sqrt(hd) + keybias) v per (sample, head); q, k, v [B*N, H] token-major, keybias fp32 [B, N]
+    (= (1 - attention_mask) * -10000).  Heads are regrouped head-major ([B][heads][Np][q|k|v x hd]) so that each GEMM is ONE batched launch;
+    the (sample, head) blocks go through lavt_attn_softmax as one "window" with B*heads "heads", whose dense bias carries the key mask.
+    Attention-probability dropout (p > 0 in training) is applied to P before the value GEMM."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, keybias, B, N, heads, p_drop):
+        dtype, dev = q.dtype, q.device
+        H = q.shape[1]
+        hd = H // heads
+        Np = -(-N // 8) * 8
+        nb = B * heads
+        x5 = torch.stack((q, k, v), dim=1).view(B, N, 3, heads, hd)
+        if Np != N:
+            x5 = torch.nn.functional.pad(x5, (0, 0, 0, 0, 0, 0, 0, Np - N))
+        qh = x5.permute(0, 3, 1, 2, 4).contiguous().view(nb * Np, 3 * hd)                  # rows (sample, head, token); columns q | k | v
+        dense = torch.zeros(B, heads, N, Np, dtype=torch.float32, device=dev)
+        dense[..., :N] = keybias.view(B, 1, 1, N)
+        scale = float(hd ** -0.5)
+        S = torch.empty(nb * Np, Np, dtype=dtype, device=dev)
+        gemm_nt(dtype, Np, Np, hd, qh, 3 * hd, qh, 3 * hd, S, Np, batch=nb, strideA=Np * 3 * hd, strideB=Np * 3 * hd, strideC=Np * Np, alpha=scale, b_off=hd)
+        P = torch.empty_like(S)
+        K.check(K.lib.lavt_attn_softmax_fwd(K.dt(dtype), K.ptr(S), K.ptr(dense), Np, None, 0, K.ptr(P), nb * Np, Np, N, Np, nb, K.stream()))
+        keep = None
+        Pd = P
+        if p_drop > 0.0:
+            keep = torch.empty(P.shape, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p_drop)
+            Pd = torch.empty_like(P)
+            K.check(K.lib.lavt_dropout(K.dt(dtype), K.ptr(P), K.ptr(keep), 1.0 / (1.0 - p_drop), None, K.ptr(Pd), P.numel(), K.stream()))
+        oh = torch.empty(nb * Np, hd, dtype=dtype, device=dev)
+        gemm_nt(dtype, Np, hd, Np, Pd, Np, qh, 3 * hd, oh, hd, batch=nb, strideA=Np * Np, strideB=Np * 3 * hd, strideC=Np * hd, b_kmajor=True, b_off=2 * hd)
+        out = oh.view(B, heads, Np, hd)[:, :, :N].permute(0, 2, 1, 3).reshape(B * N, H)
+        ctx.save_for_backward(qh, P, Pd if keep is not None else None, keep)
+        ctx.dims = (B, N, Np, heads, hd, scale, p_drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qh, P, Pd, keep = ctx.saved_tensors
+        B, N, Np, heads, hd, scale, p_drop = ctx.dims
+        dtype, dev = qh.dtype, qh.device
+        nb, H = B * heads, heads * hd
+        d4 = dout.reshape(B, N, heads, hd)
+        if Np != N:
+            d4 = torch.nn.functional.pad(d4, (0, 0, 0, 0, 0, Np - N))
+        doh = d4.permute(0, 2, 1, 3).contiguous().view(nb * Np, hd)
+        dS = torch.empty_like(P)                 # first dP = dO V^T, then overwritten with dS
+        gemm_nt(dtype, Np, Np, hd, doh, hd, qh, 3 * hd, dS, Np, batch=nb, strideA=Np * hd, strideB=Np * 3 * hd, strideC=Np * Np, b_off=2 * hd)
+        if keep is not None:
+            K.check(K.lib.lavt_dropout(K.dt(dtype), K.ptr(dS), K.ptr(keep), 1.0 / (1.0 - p_drop), None, K.ptr(dS), dS.numel(), K.stream()))
+        K.check(K.lib.lavt_attn_softmax_bwd(K.dt(dtype), K.ptr(P), K.ptr(dS), nb * Np, N, Np, K.stream()))
+        dqh = torch.empty(nb * Np, 3 * hd, dtype=dtype, device=dev)
+        gemm_nt(dtype, Np, hd, Np, dS, Np, qh, 3 * hd, dqh, 3 * hd, batch=nb, strideA=Np * Np, strideB=Np * 3 * hd, strideC=Np * 3 * hd, b_kmajor=True,
+                alpha=scale, b_off=hd)
+        dkv = torch.zeros(2, nb * Np, hd, dtype=torch.float32, device=dev)
+        gemm_tn(dtype, Np, hd, Np, dS, Np, qh, 3 * hd, dkv[0], hd, batch=nb, strideA=Np * Np, strideB=Np * 3 * hd, strideC=Np * hd, alpha=scale)
+        gemm_tn(dtype, Np, hd, Np, Pd if keep is not None else P, Np, doh, hd, dkv[1], hd, batch=nb, strideA=Np * Np, strideB=Np * hd, strideC=Np * hd)
+        dqh.view(nb * Np, 3, hd)[:, 1:] = dkv.permute(1, 0, 2).to(dtype)
+        d5 = dqh.view(B, heads, Np, 3, hd)[:, :, :N].permute(3, 0, 2, 1, 4).reshape(3, B * N, H)
+        return d5[0], d5[1], d5[2], None, None, None, None, None
+
+
+def masked_self_attention(q, k, v, keybias, B, N, heads, p_drop=0.0):
+    return _MaskedSelfAttn.apply(q, k, v, keybias, B, N, heads, float(p_drop))
+
+
 # ------------------------------------------------------------------------------------------ layout changes
 class _Transpose(torch.autograd.Function):
     """[B, R, Cc] -> [B, Cc, R] (both contiguous) with optional dtype change; used for NCHW<->NHWC at the boundary."""

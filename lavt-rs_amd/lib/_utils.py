@@ -51,13 +51,11 @@ class LAVT(_LAVTSimpleDecode):
 
 
 def _build_text_encoder(args):
+    """`BertModel.from_pretrained(args.ck_bert)` of the reference (lib/_utils.py:38-40), on the liblavt_hip encoder (bert/modeling_bert.py).
+    Without a checkpoint directory (no network here) the encoder is built with bert-base-uncased geometry and random weights."""
+    from bert.modeling_bert import BertConfig, BertModel
     ck = getattr(args, "ck_bert", "bert-base-uncased")
-    try:
-        from bert.modeling_bert import BertModel          # the reference's vendored HF v3.0.2 copy, if the user has it
-        enc = BertModel.from_pretrained(ck)
-    except ImportError:
-        from transformers import BertConfig, BertModel
-        enc = BertModel.from_pretrained(ck) if os.path.isdir(str(ck)) else BertModel(BertConfig())
+    enc = BertModel.from_pretrained(ck) if os.path.isdir(str(ck)) else BertModel(BertConfig())
     enc.pooler = None
     return enc
 

@@ -115,7 +115,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only-video", action="store_true")
     ap.add_argument("--only-checkpoint", action="store_true")
+    ap.add_argument("--only-bert", action="store_true")
     cli = ap.parse_args()
+    if cli.only_bert:
+        bert_cases()
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     _install_shims()
@@ -438,6 +442,46 @@ def checkpoint_cases():
             for k in ("layers.0.blocks.1.attn.relative_position_bias_table", "layers.2.blocks.0.attn.qkv.weight", "patch_embed.proj.weight"):
                 out[tag + "|" + k] = sd[k].clone()
     save("checkpoint_surgery", **out)
+
+
+BERT_MICRO = dict(vocab_size=64, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, max_position_embeddings=32,
+                  type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=1e-12, hidden_act="gelu")
+
+
+def bert_inputs(B, N, vocab, seed):
+    """ids / mask the way data/dataset_refer_bert.py:58-81 produces them: sentence b has a random length, zero-padded to N"""
+    g = torch.Generator("cpu").manual_seed(seed)
+    ids = torch.zeros(B, N, dtype=torch.long)
+    mask = torch.zeros(B, N, dtype=torch.long)
+    for b in range(B):
+        n = N if b == 0 else int(torch.randint(3, N, (1,), generator=g))
+        ids[b, :n] = torch.randint(1, vocab, (n,), generator=g)
+        mask[b, :n] = 1
+    return ids, mask
+
+
+def bert_cases():
+    """Text side: the reference's `bert.modeling_bert.BertModel` is an absent copy of HF transformers 3.0.2; the vectors come
+    from the `transformers.BertModel` installed in this image, on name-keyed deterministic weights (lavt_hip.detweights)."""
+    import transformers
+    from transformers import BertConfig, BertModel
+    m = BertModel(BertConfig(**BERT_MICRO), add_pooling_layer=False).eval()
+    fill_state_dict_(m)
+    for N in (20, 22):
+        ids, mask = bert_inputs(2, N, BERT_MICRO["vocab_size"], seed=40 + N)
+        m.zero_grad(set_to_none=True)
+        out = m(ids, attention_mask=mask)[0]
+        w = randn(7, *out.shape) * mask[..., None]          # the visual path only reads real-token features (PWAM masks keys / values)
+        (out * w).sum().backward()
+        grads = {k.replace(".", "__"): grad_digest(p.grad) for k, p in m.named_parameters()
+                 if k in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight", "embeddings.LayerNorm.weight",
+                          "encoder.layer.0.attention.self.query.weight", "encoder.layer.0.attention.self.key.bias",
+                          "encoder.layer.1.attention.output.dense.weight", "encoder.layer.1.intermediate.dense.weight",
+                          "encoder.layer.1.output.LayerNorm.bias")}
+        save(f"bert_micro_n{N}", ids=ids, mask=mask, out=out, w=w, transformers_version=np.array(transformers.__version__), **{"grad__" + k: v for k, v in grads.items()})
+    with open(os.path.join(HERE, "state_dict_keys_bert_micro.txt"), "w") as f:
+        for k, v in m.state_dict().items():
+            f.write(f"{k}|{'x'.join(str(d) for d in v.shape)}\n")
 
 
 if __name__ == "__main__":

@@ -418,3 +418,65 @@ def test_train_step_gradients_match_plain_autograd():
         ops.sinks.clear()
         ops.wgrads.enabled = False
         lavt_hip.set_compute_dtype(torch.float32)
+
+
+# ---------------------------------------------------------------------------------------------- text side
+def _bert_micro(dev):
+    global lavt_hip
+    import lavt_hip
+    from bert.modeling_bert import BertConfig, BertModel
+    cfg = BertConfig(vocab_size=64, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, max_position_embeddings=32,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = BertModel(cfg, add_pooling_layer=False)
+    fill_state_dict_(m)
+    return m.to(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [20, 22])
+def test_bert_micro_matches_golden_and_oracle(golden, N):
+    """bert.modeling_bert.BertModel on liblavt_hip (fp32) == the transformers.BertModel vectors and the CPU oracle: output and gradients"""
+    from oracle import bert_oracle as OB
+    g = golden(f"bert_micro_n{N}")
+    m = _bert_micro(DEV).train()          # dropout probabilities are 0 in the fixture config: train == eval arithmetic
+    keys = [ln.split("|")[0] for ln in open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_keys_bert_micro.txt"))]
+    assert list(m.state_dict().keys()) == keys
+    ids, mask = torch.as_tensor(g["ids"]).to(DEV), torch.as_tensor(g["mask"]).to(DEV)
+    with lavt_hip.use_dtype(torch.float32):
+        out = m(ids, attention_mask=mask)[0]
+        (out * torch.as_tensor(g["w"]).to(DEV)).sum().backward()
+    assert float((out.detach().cpu() - torch.as_tensor(g["out"])).abs().max()) < 1e-4
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref = OB.bert_forward(params, ids.cpu(), mask.cpu(), num_heads=2)
+    (ref * torch.as_tensor(g["w"])).sum().backward()
+    for k, p in m.named_parameters():
+        gr = params[k].grad
+        # (the key biases have an analytically zero gradient -- softmax is shift-invariant -- so both sides hold ~1e-6 of rounding noise there)
+        assert float((p.grad.cpu() - gr).abs().max()) <= 2e-4 * float(gr.abs().max()) + 5e-6, k
+
+
+@pytest.mark.gpu
+def test_bert_bf16_close_and_dropout_runs():
+    from oracle import bert_oracle as OB
+    m = _bert_micro(DEV).eval()
+    ids = torch.randint(1, 64, (2, 20), generator=torch.Generator().manual_seed(3)).to(DEV)
+    mask = torch.ones(2, 20, dtype=torch.long, device=DEV)
+    mask[1, 9:] = 0
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = OB.bert_forward(sd, ids.cpu(), mask.cpu(), num_heads=2)
+    with lavt_hip.use_dtype(torch.bfloat16):
+        out = m(ids, attention_mask=mask)[0]
+    real = mask.bool().cpu()
+    assert float((out.detach().cpu() - ref)[real].abs().max()) < 0.08 * float(ref.abs().max())
+    # training-mode dropout (p = 0.1 as in bert-base): keep masks scale the activations, gradients flow, E[out] stays near the eval output
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.1
+    m.train()
+    torch.manual_seed(0)
+    with lavt_hip.use_dtype(torch.float32):
+        o1 = m(ids, attention_mask=mask)[0]
+        o2 = m(ids, attention_mask=mask)[0]
+        o1.sum().backward()
+    assert float((o1 - o2).abs().max()) > 1e-3          # fresh masks per call
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())

@@ -351,3 +351,33 @@ def test_video_e2e_micro_train_grads(golden, tag):
     for name, t in (("dframes", frames.grad), ("dl", l.grad)):
         ref = torch.as_tensor(g[name])
         assert float((grad_digest(t.float()) - ref).abs().max()) <= tol * float(ref[0]) + 3e-6
+
+
+# ---------------------------------------------------------------------------------------------- text side
+from oracle import bert_oracle as OB  # noqa: E402
+
+
+@pytest.mark.parametrize("N", [20, 22])
+def test_bert_micro(golden, N):
+    """oracle/bert_oracle.py against vectors of the installed `transformers.BertModel` (the reference's `./bert` copy of transformers 3.0.2
+    is absent): last_hidden_state and gradient digests on name-keyed deterministic weights."""
+    g = golden(f"bert_micro_n{N}")
+    sd = sd_from_keys("state_dict_keys_bert_micro.txt")
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ids, mask = torch.as_tensor(g["ids"]), torch.as_tensor(g["mask"])
+    out = OB.bert_forward(params, ids, mask, num_heads=2)
+    close(out.detach(), g["out"], 2e-5)
+    (out * torch.as_tensor(g["w"])).sum().backward()
+    for key in g.files:
+        if not key.startswith("grad__"):
+            continue
+        k = key[len("grad__"):].replace("__", ".")
+        ref = torch.as_tensor(g[key])
+        assert float((grad_digest(params[k].grad) - ref).abs().max()) <= 1e-4 * max(float(ref[0]), 1e-6) + 3e-6, k
+
+
+def test_pad_ids():
+    ids, mask = OB.pad_ids([101, 7, 8, 9, 102], 8)
+    assert ids == [101, 7, 8, 9, 102, 0, 0, 0] and mask == [1, 1, 1, 1, 1, 0, 0, 0]
+    ids, mask = OB.pad_ids(range(1, 30), 20)
+    assert ids == list(range(1, 21)) and mask == [1] * 20
