@@ -233,3 +233,43 @@ def test_syncbn_rank_statistics_combination():
     flat = x.reshape(world * R, C)
     assert torch.allclose(s[0].double(), flat.sum(0), rtol=1e-6)
     assert torch.allclose(s[1].double(), ((flat - flat.mean(0)) ** 2).sum(0), rtol=2e-3)
+
+
+# ---------------------------------------------------------------------------------------------- host input pipeline
+_VOCAB = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "the", "man", "in", "a", "red", "shirt", "##s", "left", "person", "play", "##ing", "frisbee",
+          ",", ".", "'", "s", "woman", "2", "##nd", "from", "right", "cafe", "-", "top", "##most", "un", "##believ", "##able", "(", ")", "on", "!", "?",
+          "guy", "w", "/", "hat", "3", "##rd", "giraffe", "##s", "中", "国"]
+_SENTENCES = ["The man's red shirts, playing frisbee. 2nd from LEFT café", "woman on the right (top-most)!", "unbelievable giraffes?? 3rd guy w/ hat",
+              "  person\tin   a\nred shirt  ", "xyzzy the 中国 man", "", "a" * 120 + " man", "[SEP] the [MASK] man"]
+
+
+def test_bert_tokenizer_matches_transformers(tmp_path):
+    """bert.tokenization_bert.BertTokenizer against the installed transformers.BertTokenizer on a synthetic vocab (no vocab.txt ships offline)"""
+    import transformers
+    from bert.tokenization_bert import BertTokenizer, pad_ids
+    vf = tmp_path / "vocab.txt"
+    vf.write_text("\n".join(_VOCAB) + "\n", encoding="utf-8")
+    ours, theirs = BertTokenizer.from_pretrained(str(tmp_path)), transformers.BertTokenizer(str(vf))
+    for s in _SENTENCES:
+        assert ours.encode(text=s, add_special_tokens=True) == theirs.encode(s, add_special_tokens=True), s
+    ids, mask = pad_ids(ours.encode(_SENTENCES[0]), 20)
+    assert len(ids) == len(mask) == 20 and sum(mask) == min(20, len(ours.encode(_SENTENCES[0]))) and ids[0] == 2
+    ids, mask = pad_ids(ours.encode(_SENTENCES[1]), 5)
+    assert len(ids) == 5 and mask == [1] * 5
+
+
+def test_image_transforms():
+    """transforms.py of the reference on PIL: exact size, [0, 1] scaling, per-channel normalisation, nearest-neighbour targets"""
+    from PIL import Image
+    import transforms as T
+    rng = np.random.default_rng(0)
+    img = Image.fromarray(rng.integers(0, 256, (37, 53, 3), dtype=np.uint8), "RGB")
+    tgt = Image.fromarray((rng.random((37, 53)) > 0.5).astype(np.uint8), "P")
+    x, t = T.get_transform(48)(img, tgt)
+    assert x.shape == (3, 48, 48) and x.dtype == torch.float32 and t.shape == (48, 48) and t.dtype == torch.int64
+    assert set(t.unique().tolist()) <= {0, 1}
+    ref = torch.from_numpy(np.asarray(img.resize((48, 48), Image.BILINEAR)).transpose(2, 0, 1).copy()).float() / 255
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    assert torch.allclose(x, (ref - mean) / std, atol=1e-6)
+    same, _ = T.Resize(37, 53)(img, None)
+    assert np.array_equal(np.asarray(same), np.asarray(img))
