@@ -32,6 +32,8 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0                                                 
 WORKLOADS = {
     "swin_b_w12_480_b2": dict(variant="base", window12=True, batch=2, size=480, flops="swin_b_w12_480"),
     "swin_t_w7_480_b8": dict(variant="tiny", window12=False, batch=8, size=480, flops="swin_t_w7_480"),
+    # the same step with the BERT-base text encoder inside the model (`lavt_one`): token ids in, BERT trained with the rest
+    "lavt_one_swin_b_w12_480_b2": dict(variant="base", window12=True, batch=2, size=480, flops="swin_b_w12_480", one=True),
     # BASELINE.json configs[3]: Video-Swin-B LAVT, one clip of T=8 frames at 384x384 per GPU (metric counts frames); PWAM / README SepTPWAM recipe
     "video_swin_b_t8_384": dict(variant="base", video=True, frames=8, batch=1, size=384, flops="video_swin_b_t8_384", sept=False),
     "video_swin_b_t8_384_sept": dict(variant="base", video=True, frames=8, batch=1, size=384, flops="video_swin_b_t8_384_sept", sept=True),
@@ -52,7 +54,7 @@ def build_model(cfg, device, drop_path=0.3):
         model = _VideoStep(bb, SimpleDecoding(1024, a))         # lavt_video without the BERT encoder: language features are the input, as for `lavt`
     else:
         args = SimpleNamespace(swin_type=cfg["variant"], window12=cfg["window12"], drop_path_rate=drop_path)
-        model = segmentation.lavt("", args)
+        model = segmentation.lavt_one("", args) if cfg.get("one") else segmentation.lavt("", args)
     fill_state_dict_(model)
     return model.to(device)
 
@@ -171,6 +173,10 @@ def main():
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)       # train.py:589
     model.train()
     x, l, m, tgt = det_inputs(cfg["batch"], cfg["size"], 20, seed=1234 + rank, frames=cfg.get("frames", 0))
+    if cfg.get("one"):                      # token ids + attention mask instead of language features (data/dataset_refer_bert.py:58-81)
+        g = torch.Generator("cpu").manual_seed(4321 + rank)
+        m = m.squeeze(-1).long()
+        l = torch.randint(1000, 30000, m.shape, generator=g) * m
     step = TrainStep(model, x.to(device), l.to(device), m.to(device), tgt.to(device), world=2 if force else world, use_graph=not a.no_graph)
     step.warmup_and_capture()
     if world > 1 and step.captured:

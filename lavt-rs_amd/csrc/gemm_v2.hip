@@ -326,30 +326,24 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         if (kt + STAGES - 1 < ktiles) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
         const T* cA = reinterpret_cast<const T*>(smem + (kt % STAGES) * STAGE_BYTES);
         const T* cB = reinterpret_cast<const T*>(smem + (kt % STAGES) * STAGE_BYTES + A_BYTES);
-        if constexpr (WAVES == 16) {
-            // one k-step of fragments at a time (64 accumulator + 32 fragment registers of the 128 a lane has with 16 waves per workgroup)
+        if constexpr (WAVES == 16 && BKM) {
+            // one k-step of fragments at a time (64 accumulator + 32 fragment registers of the 128 a lane has with 16 waves per workgroup);
+            // the k-contiguous form below is plain ds_reads the compiler schedules itself (measured 137 vs 142 us on the decoder conv)
             unsigned ab[NI];
-            if constexpr (BKM) {
-                const int row_off = 8 * (lane >> 4) + ((lane & 15) >> 2), sw = tn_swz<B_CH>(row_off);
+            const int row_off = 8 * (lane >> 4) + ((lane & 15) >> 2), sw = tn_swz<B_CH>(row_off);
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    ab[j] = lds_addr(cB) + (unsigned)(row_off * BN + ((((wn * WN) / 8 + 2 * j) ^ sw) + ((lane & 3) >> 1)) * 8 + (lane & 1) * 4) * 2;
-            }
+            for (int j = 0; j < NI; ++j)
+                ab[j] = lds_addr(cB) + (unsigned)(row_off * BN + ((((wn * WN) / 8 + 2 * j) ^ sw) + ((lane & 3) >> 1)) * 8 + (lane & 1) * 4) * 2;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 ga[MI], gb[NI];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) ga[i] = frag_kc<T>(cA, wm * WM + i * 16, ks, lane);
-                if constexpr (BKM) {
-                    u64 l[NI], h[NI];
-                    if (ks == 0) tr_read_frags_step<NI, 4 * BN * 2, 0>(ab, l, h);
-                    else tr_read_frags_step<NI, 4 * BN * 2, 32 * BN * 2>(ab, l, h);
+                u64 l[NI], h[NI];
+                if (ks == 0) tr_read_frags_step<NI, 4 * BN * 2, 0>(ab, l, h);
+                else tr_read_frags_step<NI, 4 * BN * 2, 32 * BN * 2>(ab, l, h);
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) gb[j] = frag_from(l[j], h[j]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) gb[j] = frag_kc<T>(cB, wn * WN + j * 16, ks, lane);
-                }
+                for (int j = 0; j < NI; ++j) gb[j] = frag_from(l[j], h[j]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -800,6 +794,9 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     for (int i = 0; i < n; ++i) {
         const lavt_gemm_tn_t& p = probs[i];
         if (!tn_v2_eligible(p) || p.batch != 1 || p.conv_kc > 0 || p.B2 || p.I % 8 || p.J % 8) return 1;
+        // no split-K in here: a member with a long reduction (e.g. a stage-0 PWAM projection, K = 28 800 rows = 450 K tiles on a handful of
+        // tiles) would run serially inside one workgroup while short-K members (BERT layers, K = 40 rows) supply the tile count
+        if (cdiv(p.K, 64) > 128) return 1;
         maps = maps || p.a_rowmap || p.a_rowscale || p.b_rowmap;
         g.p[i] = p;
         tiles += cdiv(p.I, 64) * cdiv(p.J, 64);

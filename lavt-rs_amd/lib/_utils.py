@@ -68,8 +68,8 @@ class _LAVTOneSimpleDecode(nn.Module):
         self.text_encoder = _build_text_encoder(args)
         self.lazy_pred = bool(getattr(args, "lazy_pred", False))
 
-    def forward(self, x, text, l_mask):
-        input_shape = x.shape[-2:]
+    def forward_lowres(self, x, text, l_mask):
+        """token ids (B, N_l) + attention mask (B, N_l) -> decoder logits at 1/4 resolution (what the fused upsample + CE kernel consumes)"""
         l_feats = self.text_encoder(text, attention_mask=l_mask)[0].permute(0, 2, 1)      # (B, 768, N_l)
         l_mask = l_mask.unsqueeze(dim=-1)
         features = self.backbone(x, l_feats, l_mask)
@@ -77,8 +77,10 @@ class _LAVTOneSimpleDecode(nn.Module):
             x_c1, (x_c2, x_c3, x_c4) = None, features
         else:
             x_c1, x_c2, x_c3, x_c4 = features
-        y = self.classifier(x_c4, x_c3, x_c2, x_c1)
-        return _upsample_logits(y, input_shape)
+        return self.classifier(x_c4, x_c3, x_c2, x_c1)
+
+    def forward(self, x, text, l_mask):
+        return _upsample_logits(self.forward_lowres(x, text, l_mask), x.shape[-2:])
 
 
 class LAVTOne(_LAVTOneSimpleDecode):

@@ -480,3 +480,46 @@ def test_bert_bf16_close_and_dropout_runs():
         o1.sum().backward()
     assert float((o1 - o2).abs().max()) > 1e-3          # fresh masks per call
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.gpu
+def test_lavt_one_micro_matches_oracle_chain():
+    """`lavt_one` (token ids -> BERT -> backbone -> decoder -> upsample) on liblavt_hip vs the oracle chain bert_oracle -> lavt_oracle: logits,
+    loss, and gradients of a BERT parameter, a PWAM language projection and a backbone weight (the text side is trained with the rest)."""
+    import lavt_hip
+    from bert.modeling_bert import BertConfig, BertModel
+    from lib._utils import LAVTOne
+    from lib.backbone import MultiModalSwinTransformer
+    from lib.mask_predictor import SimpleDecoding
+    from oracle import bert_oracle as OB
+    from oracle import lavt_oracle as O
+    args = SimpleNamespace(lazy_pred=False)
+    bb = MultiModalSwinTransformer(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=7, drop_path_rate=0.0, args=args)
+    model = LAVTOne(bb, SimpleDecoding(256, args), SimpleNamespace(ck_bert="/nonexistent"))
+    model.text_encoder = BertModel(BertConfig(vocab_size=64, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=256,
+                                              max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), add_pooling_layer=False)
+    fill_state_dict_(model)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    x, _, m, tgt = det_inputs(2, 64, 20, seed=9)
+    mask = m.squeeze(-1).long()
+    ids = torch.randint(1, 64, mask.shape, generator=torch.Generator().manual_seed(5)) * mask
+    with lavt_hip.use_dtype(torch.float32):
+        logits = model(x.to(DEV), ids.to(DEV), mask.to(DEV))
+        loss = F.cross_entropy(logits, tgt.to(DEV), weight=torch.tensor([0.9, 1.1], device=DEV))
+        loss.backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    full = dict(sd)
+    full.update(params)
+    l_ref = OB.bert_forward(full, ids, mask, num_heads=12, prefix="text_encoder.").permute(0, 2, 1)
+    ref = O.lavt_forward(full, x, l_ref, m, "micro", 7, training=True)
+    ref_loss = O.weighted_ce(ref, tgt)
+    ref_loss.backward()
+    assert float((logits.detach().cpu() - ref.detach()).abs().max()) < 1e-3
+    assert abs(float(loss.detach()) - float(ref_loss)) < 1e-4
+    got = dict(model.named_parameters())
+    for k in ("text_encoder.encoder.layer.0.attention.self.query.weight", "text_encoder.embeddings.word_embeddings.weight",
+              "text_encoder.encoder.layer.0.output.dense.weight", "backbone.layers.0.fusion.image_lang_att.f_key.0.weight",
+              "backbone.layers.2.blocks.1.attn.qkv.weight"):
+        gr = params[k].grad
+        assert float((got[k].grad.cpu() - gr).abs().max()) <= 5e-3 * float(gr.abs().max()) + 1e-6, k
