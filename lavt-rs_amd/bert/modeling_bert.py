@@ -66,10 +66,8 @@ class BertSelfAttention(nn.Module):
         self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
 
     def forward(self, x, keybias, B, N):
-        q = ops.linear(x, self.query.weight, self.query.bias)
-        k = ops.linear(x, self.key.weight, self.key.bias)
-        v = ops.linear(x, self.value.weight, self.value.bias)
-        return ops.masked_self_attention(q, k, v, keybias, B, N, self.num_attention_heads, self.dropout.p if self.training else 0.0)
+        qkv = ops.linear_cat(x, (self.query, self.key, self.value))          # one GEMM over the stacked [3H, H] weight
+        return ops.masked_self_attention(qkv, keybias, B, N, self.num_attention_heads, self.dropout.p if self.training else 0.0)
 
 
 class _DenseDropAddNorm(nn.Module):

@@ -445,7 +445,7 @@ extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     const int lpr = nchunk <= 16 ? 16 : nchunk <= 32 ? 32 : 64;
     const int cpl = cdiv(nchunk, lpr);                       // 1 (C <= 512 bf16 / 256 fp32), 2, or up to 4 / 8
     int blocks = cdiv(rows, 4 * (64 / lpr) * 2);             // two rows per wave: the step's LayerNorms have 450 .. 28 800 rows
-    if (rows <= 256) blocks = cdiv(rows, 4 * (64 / lpr));    // a few dozen rows (BERT: 40-44 tokens): one row per wave, no serial second row
+    if (rows <= 256) blocks = cdiv(rows, 4 * (64 / lpr));    // a few dozen rows (BERT: 40-44 tokens): one row per wave (no gain at 1 800 rows: measured)    // a few dozen rows (BERT: 40-44 tokens): one row per wave, no serial second row
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     float* partials = (ws && ws_floats >= (int64_t)blocks * 2 * C) ? ws : nullptr;

@@ -61,6 +61,28 @@ class _WeightCache:
         return out
 
 
+    def get_cat(self, ps, dtype: torch.dtype) -> torch.Tensor:
+        """[sum N_i, K] compute copy of several Linear weights stacked along N (BERT's query / key / value): the per-parameter 'lin' entries
+        become row slices of ONE buffer, so the usual refresh (get / refresh_all's multi-cast) keeps the stacked matrix current for free."""
+        if dtype == torch.float32:                           # exact path: parameters are used in place, the stack is a copy per call
+            return torch.cat([p.detach().reshape(p.shape[0], -1) for p in ps], 0)
+        cats = self.__dict__.setdefault("cats", {})
+        key = tuple(id(p) for p in ps) + (dtype,)
+        ent = cats.get(key)
+        if ent is None or any(r() is not p for r, p in zip(ent[1], ps)):
+            kd = ps[0].numel() // ps[0].shape[0]
+            big = torch.empty(sum(p.shape[0] for p in ps), kd, dtype=dtype, device=ps[0].device)
+            off = 0
+            for p in ps:
+                self.store[(id(p), dtype, "lin")] = (None, big[off:off + p.shape[0]], weakref.ref(p))       # stale stamp: the next get() casts into the slice
+                off += p.shape[0]
+            ent = (big, [weakref.ref(p) for p in ps])
+            cats[key] = ent
+            self.multi = None                                # a descriptor table built earlier points at the old per-parameter copies
+        for p in ps:
+            self.get(p, dtype, "lin")
+        return ent[0]
+
     # ---- one-launch refresh of every cached 'lin' copy (the per-parameter casts are ~140 tiny launches per step) ----
     def build_multicast(self, dtype):
         """Call after a warm-up step: collects every live (param, 'lin') entry of `dtype` into a device descriptor table."""
@@ -382,6 +404,64 @@ class _Linear(torch.autograd.Function):
                     db = sinks.done(bias, bbuf, bsink)
         d_res = dy if ctx.has_res and ctx.needs_input_grad[3] else None
         return dx, dW, db, d_res, None
+
+
+class _LinearCat(torch.autograd.Function):
+    """[x W1^T + b1 | x W2^T + b2 | ...]: several Linear layers of the same input as ONE GEMM over the stacked weight (weights.get_cat) and
+    ONE data-gradient GEMM; the weight / bias gradients stay per parameter (column blocks of dy)."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        x = x.contiguous()
+        dtype = x.dtype
+        ws, bs = wb[0::2], wb[1::2]
+        Wc = weights.get_cat(ws, dtype)
+        Nt, Kd = Wc.shape
+        M = x.shape[0]
+        y = torch.empty(M, Nt, dtype=dtype, device=x.device)
+        bias = torch.cat([_f32(b) for b in bs]) if all(b is not None for b in bs) else None
+        gemm_nt(dtype, M, Nt, Kd, x, Kd, Wc, Kd, y, Nt, bias=bias)
+        ctx.save_for_backward(x, *wb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, *wb = ctx.saved_tensors
+        ws, bs = wb[0::2], wb[1::2]
+        dtype = x.dtype
+        dy = dy.contiguous()
+        Wc = weights.get_cat(ws, dtype)
+        Nt, Kd = Wc.shape
+        M = x.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm_nt(dtype, M, Kd, Nt, dy, Nt, Wc, Kd, dx, Kd, b_kmajor=True)
+        grads = []
+        off = 0
+        for w, b in zip(ws, bs):
+            n = w.shape[0]
+            wbuf, wsink = sinks.buf(w, (n, Kd))
+            bbuf, bsink = sinks.buf(b, (n,)) if b is not None else (None, True)
+            if wgrads.active() and wsink and bsink and dtype == torch.bfloat16:
+                gemm_tn(dtype, n, Kd, M, dy, Nt, x, Kd, wbuf, Kd, colsum=bbuf, a_off=off, defer=wgrads)
+                wgrads.notify(w)
+                if b is not None:
+                    wgrads.notify(b)
+                grads += [None, None]
+            else:
+                gemm_tn(dtype, n, Kd, M, dy, Nt, x, Kd, wbuf, Kd, colsum=bbuf, a_off=off)
+                grads += [sinks.done(w, wbuf, wsink), sinks.done(b, bbuf, bsink) if b is not None else None]
+            off += n
+        return (dx, *grads)
+
+
+def linear_cat(x, layers):
+    """layers: nn.Linear modules sharing the input x -> [M, sum out_features]"""
+    wb = []
+    for m in layers:
+        wb += [m.weight, m.bias]
+    return _LinearCat.apply(x, *wb)
 
 
 def linear(x, weight, bias=None, residual=None, **kw):
@@ -843,19 +923,19 @@ def dropout(x, p, training, residual=None):
 
 
 class _MaskedSelfAttn(torch.autograd.Function):
-    """BertSelfAttention core: softmax(q k^T / sqrt(hd) + keybias) v per (sample, head); q, k, v [B*N, H] token-major, keybias fp32 [B, N]
+    """BertSelfAttention core: softmax(q k^T / sqrt(hd) + keybias) v per (sample, head); qkv [B*N, 3H] token-major (q | k | v), keybias fp32 [B, N]
     (= (1 - attention_mask) * -10000).  Heads are regrouped head-major ([B][heads][Np][q|k|v x hd]) so that each GEMM is ONE batched launch;
     the (sample, head) blocks go through lavt_attn_softmax as one "window" with B*heads "heads", whose dense bias carries the key mask.
     Attention-probability dropout (p > 0 in training) is applied to P before the value GEMM."""
 
     @staticmethod
-    def forward(ctx, q, k, v, keybias, B, N, heads, p_drop):
-        dtype, dev = q.dtype, q.device
-        H = q.shape[1]
+    def forward(ctx, qkv, keybias, B, N, heads, p_drop):
+        dtype, dev = qkv.dtype, qkv.device
+        H = qkv.shape[1] // 3
         hd = H // heads
         Np = -(-N // 8) * 8
         nb = B * heads
-        x5 = torch.stack((q, k, v), dim=1).view(B, N, 3, heads, hd)
+        x5 = qkv.view(B, N, 3, heads, hd)
         if Np != N:
             x5 = torch.nn.functional.pad(x5, (0, 0, 0, 0, 0, 0, 0, Np - N))
         qh = x5.permute(0, 3, 1, 2, 4).contiguous().view(nb * Np, 3 * hd)                  # rows (sample, head, token); columns q | k | v
@@ -901,12 +981,13 @@ class _MaskedSelfAttn(torch.autograd.Function):
         gemm_tn(dtype, Np, hd, Np, dS, Np, qh, 3 * hd, dkv[0], hd, batch=nb, strideA=Np * Np, strideB=Np * 3 * hd, strideC=Np * hd, alpha=scale)
         gemm_tn(dtype, Np, hd, Np, Pd if keep is not None else P, Np, doh, hd, dkv[1], hd, batch=nb, strideA=Np * Np, strideB=Np * hd, strideC=Np * hd)
         dqh.view(nb * Np, 3, hd)[:, 1:] = dkv.permute(1, 0, 2).to(dtype)
-        d5 = dqh.view(B, heads, Np, 3, hd)[:, :, :N].permute(3, 0, 2, 1, 4).reshape(3, B * N, H)
-        return d5[0], d5[1], d5[2], None, None, None, None, None
+        dqkv = dqh.view(B, heads, Np, 3, hd)[:, :, :N].permute(0, 2, 3, 1, 4).reshape(B * N, 3 * H)
+        return dqkv, None, None, None, None, None
 
 
-def masked_self_attention(q, k, v, keybias, B, N, heads, p_drop=0.0):
-    return _MaskedSelfAttn.apply(q, k, v, keybias, B, N, heads, float(p_drop))
+def masked_self_attention(qkv, keybias, B, N, heads, p_drop=0.0):
+    """qkv [B*N, 3H]: columns q | k | v, each heads x head_dim (the layout of `linear_cat(x, (query, key, value))`)"""
+    return _MaskedSelfAttn.apply(qkv, keybias, B, N, heads, float(p_drop))
 
 
 # ------------------------------------------------------------------------------------------ layout changes
