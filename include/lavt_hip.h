@@ -191,6 +191,10 @@ int lavt_relpos_reduce(const float* ddense, float* dtable, int wd, int wh, int w
 int lavt_attn_softmax_fwd(int dtype, const void* s, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* p,
                           int64_t rows, int rpw, int N, int ld, int heads, void* stream);
 int lavt_attn_softmax_bwd(int dtype, const void* p, void* dp, int64_t rows, int N, int ld, void* stream);
+/* dense bias gradient of that path: out[h][i][j] (fp32 [heads][N][ld]) = sum_w ds[w][h][i][j], ds [nwin][heads][rpw][ld] in `dtype` (the `.sum(0)` over
+ * windows that autograd performs for the broadcast `attn + relative_position_bias.unsqueeze(0)`, lib/video_swin_transformer.py:151-153);
+ * feed the result to lavt_relpos_reduce. */
+int lavt_attn_dbias_sum(int dtype, const void* ds, float* out, int nwin, int heads, int N, int rpw, int ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the channel dimension (nn.LayerNorm, eps 1e-5; lib/backbone.py:201,243,285,328,510).

@@ -61,6 +61,7 @@ _PROTOTYPES = {
     "lavt_relpos_reduce": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lavt_attn_softmax_fwd": [i32, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32, i32, vp],
     "lavt_attn_softmax_bwd": [i32, vp, vp, i64, i32, i32, vp],
+    "lavt_attn_dbias_sum": [i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "lavt_layernorm_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "lavt_layernorm_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
     "lavt_colstats": [i32, vp, vp, vp, vp, i64, i32, i32, i32, vp],

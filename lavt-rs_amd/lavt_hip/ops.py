@@ -616,7 +616,8 @@ class _WindowAttnComposed(torch.autograd.Function):
         dS = torch.empty_like(P)                 # first dP = dO V^T, then overwritten with dS
         gemm_nt(dtype, Np, Np, 32, doh, 32, qh, 96, dS, Np, batch=nb, strideA=Np * 32, strideB=Np * 96, strideC=Np * Np, b_off=64)
         K.check(K.lib.lavt_attn_softmax_bwd(K.dt(dtype), K.ptr(P), K.ptr(dS), nb * Np, N, Np, K.stream()))
-        ddense = dS.view(nwin, heads, Np, Np)[:, :, :N].float().sum(0)          # bias gradient: sum over windows (one reduction)
+        ddense = torch.empty(heads, N, Np, dtype=torch.float32, device=dev)      # bias gradient: sum of dS over the windows
+        K.check(K.lib.lavt_attn_dbias_sum(K.dt(dtype), K.ptr(dS), K.ptr(ddense), nwin, heads, N, Np, Np, K.stream()))
         dqh = torch.empty(nb * Np, 96, dtype=dtype, device=dev)
         # dQ = scale dS K
         gemm_nt(dtype, Np, 32, Np, dS, Np, qh, 96, dqh, 96, batch=nb, strideA=Np * Np, strideB=Np * 96, strideC=Np * 96, b_kmajor=True, alpha=scale, b_off=32)
@@ -627,7 +628,7 @@ class _WindowAttnComposed(torch.autograd.Function):
         dqh.view(nb * Np, 3, 32)[:, 1:] = dkv.permute(1, 0, 2).to(dtype)
         dqkv = dqh.view(nwin, heads, Np, 3, 32)[:, :, :N].permute(0, 2, 3, 1, 4).reshape(nwin * N, 3 * Cc)
         dtable, ts = sinks.buf(table, ((2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1), heads))
-        K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense.contiguous()), K.ptr(dtable), wd, wh, ww, N, heads, Np, K.stream()))
+        K.check(K.lib.lavt_relpos_reduce(K.ptr(ddense), K.ptr(dtable), wd, wh, ww, N, heads, Np, K.stream()))
         return dqkv, sinks.done(table, dtable, ts), None, None, None, None
 
 
