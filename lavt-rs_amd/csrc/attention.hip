@@ -396,7 +396,7 @@ int64_t lavt_window_attn_bwd_ws_mfma(int nwin, int N, int heads, int bias_ld, in
 // LAVT_ATTN_SIMPLE=1 forces the VALU formulation for bf16 too (A/B tests of the MFMA kernels)
 static bool use_mfma(int dtype, int N, int bias_ld) {
     const char* e = getenv("LAVT_ATTN_SIMPLE");
-    return dtype == LAVT_BF16 && N <= 160 && bias_ld >= (N <= 64 ? 64 : 160) && !(e && e[0] == '1');
+    return dtype == LAVT_BF16 && N <= 400 && bias_ld >= (N <= 64 ? 64 : N <= 160 ? 160 : 416) && !(e && e[0] == '1');
 }
 
 extern "C" int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out,
@@ -436,7 +436,7 @@ extern "C" int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bia
 extern "C" int64_t lavt_window_attn_bwd_ws(int dtype, int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww) {
     return use_mfma(dtype, N, bias_ld) ? lavt_window_attn_bwd_ws_mfma(nwin, N, heads, bias_ld, wd, wh, ww) : 0;
 }
-extern "C" int lavt_attn_uses_table(int dtype, int N) { return use_mfma(dtype, N, N <= 64 ? 64 : 160) ? 1 : 0; }
+extern "C" int lavt_attn_uses_table(int dtype, int N) { return use_mfma(dtype, N, N <= 64 ? 64 : N <= 160 ? 160 : 416) ? 1 : 0; }
 
 extern "C" int lavt_relpos_expand(const float* table, float* dense, int wd, int wh, int ww, int N, int heads, int ld, void* stream) {
     LAVT_CHECK_ARG(table && dense && wd > 0 && wh > 0 && ww > 0 && N > 0 && N <= wd * wh * ww && heads > 0 && ld >= N, "lavt_relpos_expand: bad arguments");

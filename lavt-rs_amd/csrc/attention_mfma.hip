@@ -96,18 +96,25 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
 
     const int QT = (N + 15) / 16;
     if (wave >= QT) return;
-    bf16x8 kf[NT], vf[2][KS];
+    // Up to 10 key tiles (12x12 windows) the K and V^T fragments stay in registers for all query tiles of the wave; the 25-tile windows of
+    // Video-Swin (8x7x7 = 392 tokens) re-read them from LDS per query tile (their score block alone is 104 registers).
+    constexpr bool CACHE = NT <= 10;
+    constexpr int NC = CACHE ? NT : 1, KC = CACHE ? KS : 1;
+    bf16x8 kf[NC], vf[2][KC];
+    auto k_frag = [&](int t) { return lds_row8(Ks, F_LD, 16 * t + c16, 8 * g); };
+    auto v_frag = [&](int u, int ks) {
+        // k-slot (g, jj) <-> key j = 32 ks + 16 (jj >> 2) + 4 g + (jj & 3): matches the accumulator rows of tiles 2ks, 2ks+1
+        const bf16* p = Vs + (32 * ks + 4 * g + (c16 >> 2)) * F_LD + 16 * u + 4 * (c16 & 3);
+        return join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p), __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * F_LD)));
+    };
+    if constexpr (CACHE) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) kf[t] = lds_row8(Ks, F_LD, 16 * t + c16, 8 * g);
+        for (int t = 0; t < NT; ++t) kf[t] = k_frag(t);
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            // k-slot (g, jj) <-> key j = 32 ks + 16 (jj >> 2) + 4 g + (jj & 3): matches the accumulator rows of tiles 2ks, 2ks+1
-            const bf16* p = Vs + (32 * ks + 4 * g + (c16 >> 2)) * F_LD + 16 * u + 4 * (c16 & 3);
-            vf[u][ks] = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p),
-                              __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * F_LD)));
-        }
+            for (int ks = 0; ks < KS; ++ks) vf[u][ks] = v_frag(u, ks);
+    }
 
     for (int it = wave; it < QT; it += 4) {
         const int i = 16 * it + c16;
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
         float mx = -1e30f;
 #pragma unroll
         for (int t = 0; t < 2 * KS; ++t) {
-            if (t < NT) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            if (t < NT) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CACHE ? kf[CACHE ? t : 0] : k_frag(t), qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             else s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int j0 = 16 * t + 4 * g;
             const int4 bj = *reinterpret_cast<const int4*>(bs + j0);
@@ -149,8 +156,8 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
             bf16x8 pf;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16)s[2 * ks + (jj >> 2)][jj & 3];
-            o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0][ks], pf, o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[1][ks], pf, o[1], 0, 0, 0);
+            o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CACHE ? vf[0][CACHE ? ks : 0] : v_frag(0, ks), pf, o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CACHE ? vf[1][CACHE ? ks : 0] : v_frag(1, ks), pf, o[1], 0, 0, 0);
         }
         if (vi) {
             const float inv = 1.f / sum;
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
 constexpr int R_LD = 40;        // bf16 elements per LDS row of Q / K / V / dO (80 B rows, 16-byte aligned chunks)
 
 template <int NT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void wattn_bwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void wattn_bwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                       const int8_t* __restrict__ region, int nw_img, const bf16* __restrict__ out,
                                                       const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                       bf16* __restrict__ dqkv, float* __restrict__ slab, int slab_ld,
@@ -444,19 +451,28 @@ template <int NT> size_t bwd_lds_bytes(int R) {
 
 int lavt_window_attn_fwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, void* out, float* lse,
                               int wd, int wh, int ww, int nwin, int N, int heads, float scale, hipStream_t st) {
-    if (N > 160 || !table) { lavt_set_error("lavt_window_attn_fwd(mfma): N=%d (<= 160) with the bias table required", N); return LAVT_ERR_INVALID; }
+    if (N > 400 || !table) { lavt_set_error("lavt_window_attn_fwd(mfma): N=%d (<= 400) with the bias table required", N); return LAVT_ERR_INVALID; }
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
     dim3 grid(nwin * heads);
 #define LAVT_FWD(NT_)                                                                                                                        \
     do {                                                                                                                                     \
         constexpr int NP = ((NT_ + 1) / 2) * 32;                                                                                             \
         const size_t lds = (size_t)3 * NP * F_LD * 2 + (size_t)NP * 4 + NP + (size_t)R * 4 + 16;                                             \
+        static size_t reserved = 0;                                                                                                          \
+        if (lds > 65536 && lds > reserved) {                                                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_fwd_mfma<NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+                lavt_set_error("lavt_window_attn_fwd(mfma): cannot reserve %zu bytes of LDS", lds);                                          \
+                return LAVT_ERR_LAUNCH;                                                                                                      \
+            }                                                                                                                                \
+            reserved = lds;                                                                                                                  \
+        }                                                                                                                                    \
         hipLaunchKernelGGL(wattn_fwd_mfma<NT_>, grid, dim3(256), lds, st, (const bf16*)qkv, table, region, nw_img, (bf16*)out, lse, wd, wh,  \
                            ww, nwin, N, heads, scale);                                                                                       \
     } while (0)
     if (N <= 64) LAVT_FWD(4);
     else if (N <= 144) LAVT_FWD(9);
-    else LAVT_FWD(10);
+    else if (N <= 160) LAVT_FWD(10);
+    else LAVT_FWD(25);
 #undef LAVT_FWD
     LAVT_CHECK_LAUNCH("lavt_window_attn_fwd(mfma)");
     return LAVT_OK;
@@ -479,7 +495,7 @@ int64_t lavt_window_attn_bwd_ws_mfma(int nwin, int N, int heads, int bias_ld, in
 int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, const void* out, const void* dout,
                               const float* lse, void* dqkv, float* dtable, int bias_ld, float* ws, int wd, int wh, int ww, int nwin, int N,
                               int heads, float scale, hipStream_t st) {
-    if (N > 160 || !table || !dtable || !ws || bias_ld % 4) { lavt_set_error("lavt_window_attn_bwd(mfma): N=%d (<= 160), table, dtable and scratch required", N); return LAVT_ERR_INVALID; }
+    if (N > 400 || !table || !dtable || !ws || bias_ld % 4) { lavt_set_error("lavt_window_attn_bwd(mfma): N=%d (<= 400), table, dtable and scratch required", N); return LAVT_ERR_INVALID; }
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
     // >= 2 workgroups per CU when there is that much work
     int wpb = (int)(((long)nwin * heads + 767) / 768);
@@ -506,7 +522,8 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     const int waves = force_waves ? force_waves : 8;
     if (N <= 64) LAVT_BWD(4, 4);
     else if (N <= 144) { if (waves == 8) LAVT_BWD(9, 8); else LAVT_BWD(9, 4); }
-    else { if (waves == 8) LAVT_BWD(10, 8); else LAVT_BWD(10, 4); }
+    else if (N <= 160) { if (waves == 8) LAVT_BWD(10, 8); else LAVT_BWD(10, 4); }
+    else LAVT_BWD(25, 8);                  // Video-Swin 8x7x7 windows: 149 KB of LDS, one workgroup per CU
 #undef LAVT_BWD
     LAVT_CHECK_LAUNCH("lavt_window_attn_bwd(mfma)");
     int rpb, wgroups, wpg;

@@ -521,7 +521,8 @@ def _win3(win):
     return (1, win, win) if isinstance(win, int) else tuple(int(v) for v in win)
 
 
-FUSED_ATTN_MAX_N = 160          # one window's K/V (and P for backward) fit the fused kernels up to 12x12 = 144 (+pad) tokens
+FUSED_ATTN_MAX_N = 160          # exact-fp32 fused kernels: one window's K/V (and P for backward) up to 12x12 = 144 (+pad) tokens
+FUSED_ATTN_MAX_N_BF16 = 400     # bf16 MFMA kernels: Q/K/V(/dO) of a whole window in LDS up to 25 key tiles (Video-Swin 8x7x7 = 392 tokens)
 
 
 class _WindowAttn(torch.autograd.Function):
@@ -535,7 +536,7 @@ class _WindowAttn(torch.autograd.Function):
         Cc = C3 // 3
         nwin = qkv.shape[0] // N
         dev = qkv.device
-        ld = 64 if N <= 64 else -(-N // 32) * 32   # 64 / 160: padded key axis (pairs of 16-wide MFMA tiles)
+        ld = 64 if N <= 64 else (160 if N <= 160 else 416)   # padded key axis (pairs of 16-wide MFMA tiles); 416 = 13 pairs for 392-token video windows
         dense = None
         if not K.lib.lavt_attn_uses_table(K.dt(qkv.dtype), N):      # exact-fp32 kernels read the dense bias (padding columns hold -1e30)
             dense = torch.empty(heads, N, ld, dtype=torch.float32, device=dev)
@@ -637,7 +638,8 @@ def window_attention(qkv, table, region, win, heads, N=None):
     win = _win3(win)
     if N is None:
         N = win[0] * win[1] * win[2]
-    if N <= FUSED_ATTN_MAX_N:
+    if N <= FUSED_ATTN_MAX_N or (qkv.dtype == torch.bfloat16 and N <= FUSED_ATTN_MAX_N_BF16 and K.lib.lavt_attn_uses_table(K.dt(qkv.dtype), N)
+                                 and os.environ.get("LAVT_ATTN_COMPOSED", "0") != "1"):
         return _WindowAttn.apply(qkv, table, region, win, heads, N)
     return _WindowAttnComposed.apply(qkv, table, region, win, heads, N)
 

@@ -7,6 +7,8 @@ Run on the GPU box:  python -m pytest tests -m gpu -x -q
 import math
 
 import numpy as np
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -231,6 +233,12 @@ def test_window_attention_3d(dtype, dims, window, heads, shifted):
         return (a.softmax(-1) @ v).transpose(1, 2).reshape(Bw * N, C)
     inputs = {"qkv": (rnd(Bw * N, 3 * C, seed=1), "act"), "table": (rnd(R, heads, seed=2, scale=0.5), "param")}
     run_pair(lambda qkv, table: ops.window_attention(qkv, table, region, window, heads, N=N), ref, inputs, dtype, name="window attention 3d")
+    if dtype == torch.bfloat16 and 160 < N <= 400:          # bf16 routes these to the fused 25-tile kernels: keep the composed path covered too
+        os.environ["LAVT_ATTN_COMPOSED"] = "1"
+        try:
+            run_pair(lambda qkv, table: ops.window_attention(qkv, table, region, window, heads, N=N), ref, inputs, dtype, name="window attention 3d (composed)")
+        finally:
+            del os.environ["LAVT_ATTN_COMPOSED"]
 
 
 # ------------------------------------------------------------------------------------------------ norms
