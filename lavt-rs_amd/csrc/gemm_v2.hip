@@ -689,7 +689,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
 constexpr int TN_GROUP_MAX = 4;
 struct TnGroup {
     lavt_gemm_tn_t p[TN_GROUP_MAX];
-    int tile_end[TN_GROUP_MAX];
+    int tile_end[TN_GROUP_MAX];      // running count of workgroups (tiles x K splits) up to and including problem k
+    int split[TN_GROUP_MAX];         // K splits of problem k (1 = single writer per output element, plain stores)
     int n;
 };
 template <int BI, int BJ, int WAVES, int STAGES, bool MAPS>
@@ -697,9 +698,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_grouped_kernel(const Tn
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int k = 0;
     while (k + 1 < g.n && (int)blockIdx.x >= g.tile_end[k]) ++k;
-    const int tile = blockIdx.x - (k ? g.tile_end[k - 1] : 0);
+    const int local = blockIdx.x - (k ? g.tile_end[k - 1] : 0);
     const lavt_gemm_tn_t& p = g.p[k];
-    tn_tile<BI, BJ, WAVES, STAGES, MAPS>(p, tile, 0, 0, (p.K + 63) / 64, 1, smem);
+    const int ns = g.split[k], ktiles = (p.K + 63) / 64;
+    // the splits of a tile sit next to each other (local % ns): neighbours in time share the output tile's cache lines for their atomics
+    tn_tile<BI, BJ, WAVES, STAGES, MAPS>(p, local / ns, 0, local % ns, (ktiles + ns - 1) / ns, ns, smem);
 }
 
 template <int BI, int BJ, int WAVES, int STAGES, bool MAPS> int launch_tn_v2_(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
@@ -790,7 +793,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     if ((e && e[0] == '0') || n < 2 || n > TN_GROUP_MAX) return 1;
     TnGroup g;
     bool maps = false;
-    int tiles = 0;
+    int tiles = 0, ntiles = 0;
     for (int i = 0; i < n; ++i) {
         const lavt_gemm_tn_t& p = probs[i];
         if (!tn_v2_eligible(p) || p.batch != 1 || p.conv_kc > 0 || p.B2 || p.I % 8 || p.J % 8) return 1;
@@ -799,12 +802,23 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         if (cdiv(p.K, 64) > 128) return 1;
         maps = maps || p.a_rowmap || p.a_rowscale || p.b_rowmap;
         g.p[i] = p;
-        tiles += cdiv(p.I, 64) * cdiv(p.J, 64);
+        // A member whose C already holds the running sum (split_k < 0: the step harness' zeroed flat gradient buffer) may split a long reduction:
+        // the launch lasts as long as its longest serial chain of K tiles (~1 us each with one tile in flight), e.g. 41 for the window-ordered
+        // qkv / proj gradients of a stage-2 block against 29 for its fc1 / fc2.  Chains above `chain` K tiles are cut; the pieces meet through atomics.
+        static const int chain = getenv("LAVT_TNG_CHAIN") ? atoi(getenv("LAVT_TNG_CHAIN")) : 32;
+        const int ktiles = cdiv(p.K, 64);
+        int ns = (p.split_k < 0 && chain > 0) ? cdiv(ktiles, chain) : 1;
+        if (ns > 4) ns = 4;
+        const int per = cdiv(ktiles, ns);
+        ns = cdiv(ktiles, per);                      // no empty pieces
+        g.split[i] = ns;
+        ntiles += cdiv(p.I, 64) * cdiv(p.J, 64);
+        tiles += cdiv(p.I, 64) * cdiv(p.J, 64) * ns;
         g.tile_end[i] = tiles;
     }
-    for (int i = n; i < TN_GROUP_MAX; ++i) { g.p[i] = probs[0]; g.tile_end[i] = tiles; }
+    for (int i = n; i < TN_GROUP_MAX; ++i) { g.p[i] = probs[0]; g.tile_end[i] = tiles; g.split[i] = 1; }
     g.n = n;
-    if (tiles < 256) return 1;                       // too few tiles to fill the chip without split-K
+    if (ntiles < 256) return 1;                      // too few tiles to fill the chip without (more) split-K
     // (a 128x64 tile -- 3/4 of the operand bytes per flop -- measured slower on the stage-2 block: 13.34 vs 12.96 ms per step)
     const size_t lds = 2 * (size_t)(64 * (64 + 64) * 2) + (maps ? 3 * 768 + 256 : 0);
     if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true>), dim3(tiles), dim3(256), lds, st, g);

@@ -271,7 +271,7 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
         if len(conv) > 3:
             p.conv_d, p.conv_kd, p.conv_kh, p.conv_kw = conv[3:7]
     p.alpha, p.C, p.ldc, p.strideC = alpha, K.ptr(Cout) + c_off * 4, ldc, strideC
-    p.c_conv_permute, p.split_k = int(c_conv_permute), 0
+    p.c_conv_permute, p.split_k = int(c_conv_permute), (-1 if defer is not None else 0)     # deferred = into the zeroed flat gradient buffer: a grouped launch may split K
     p.colsum, p.strideColsum = K.ptr(colsum), strideColsum
     p.zeros = _zero_page(A.device)
     if defer is not None:
