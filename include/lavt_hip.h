@@ -149,9 +149,9 @@ int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);
 /* n (<= 4) independent problems of the family in one call, e.g. the four weight gradients of a Swin block: when they qualify (bf16, no
  * conv taps / concat, batch 1, together >= 256 64x64 output tiles) they run as ONE launch without split-K -- every output element then has
  * a single writer, and with accumulate == 0 it is stored plainly instead of added through fp32 atomics; otherwise they are issued one by
- * one exactly as lavt_gemm_tn would.  A member with split_k < 0 declares that its C (and colsum) already hold the running sum (e.g. zeros):
- * the grouped launch may then cut its reduction into up to 4 pieces that meet through atomics (the launch lasts as long as its longest
- * serial chain of K tiles). */
+ * one exactly as lavt_gemm_tn would.  A member with split_k < 0 declares that its C (and colsum) hold ZEROS, so that storing and adding
+ * give the same result: the grouped launch may then cut its reduction into up to 4 pieces that meet through atomics (the launch lasts as
+ * long as its longest serial chain of K tiles). */
 int lavt_gemm_tn_grouped(const lavt_gemm_tn_t* probs, int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -802,7 +802,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         if (cdiv(p.K, 64) > 128) return 1;
         maps = maps || p.a_rowmap || p.a_rowscale || p.b_rowmap;
         g.p[i] = p;
-        // A member whose C already holds the running sum (split_k < 0: the step harness' zeroed flat gradient buffer) may split a long reduction:
+        // A member whose C holds zeros (split_k < 0: the step harness' zeroed flat gradient buffer) may split a long reduction:
         // the launch lasts as long as its longest serial chain of K tiles (~1 us each with one tile in flight), e.g. 41 for the window-ordered
         // qkv / proj gradients of a stage-2 block against 29 for its fc1 / fc2.  Chains above `chain` K tiles are cut; the pieces meet through atomics.
         static const int chain = getenv("LAVT_TNG_CHAIN") ? atoi(getenv("LAVT_TNG_CHAIN")) : 32;

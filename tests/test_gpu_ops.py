@@ -517,8 +517,9 @@ def test_fused_adamw_in_hip_graph():
 
 # ------------------------------------------------------------------------------------------------ grouped weight-gradient launch
 def test_gemm_tn_grouped_matches_individual():
-    """lavt_gemm_tn_grouped (one launch, no split-K, plain stores) vs the same problems through lavt_gemm_tn: a Swin block's four weight
-    gradients incl. a gathered operand, a row mask folded into alpha and a bias column sum"""
+    """lavt_gemm_tn_grouped (one launch; the deferred members declare zeroed outputs, so the 41-K-tile qkv / proj reductions are cut in two and
+    meet through atomics while fc1 / fc2 store plainly) vs the same problems through lavt_gemm_tn: a Swin block's four weight gradients incl.
+    a gathered operand, a row mask folded into alpha and a bias column sum"""
     import ctypes as C
     from lavt_hip import _capi as K, ops
     g = torch.Generator().manual_seed(21)
