@@ -550,3 +550,57 @@ def test_gemm_tn_grouped_matches_individual():
         scale = float(r.abs().max())
         assert float((r - o).abs().max()) <= 2e-3 * scale, float((r - o).abs().max()) / scale        # fp32 summation order only
         assert float((cr - co).abs().max()) <= 2e-3 * float(cr.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ text side + composed-attention helpers
+@pytest.mark.parametrize("dtype", DT)
+def test_bert_embed(dtype):
+    """lavt_bert_embed_fwd/bwd vs three nn.Embedding lookups and their scatter-add gradients (repeated ids and positions collide)"""
+    from lavt_hip import ops
+    B, N, H, V = 3, 20, 96, 50
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(0, V, (B, N), generator=g)
+    ids[1, 5:9] = ids[0, 2]                      # repeated ids
+    tt = torch.randint(0, 2, (B, N), generator=g)
+    ps = [torch.nn.Parameter(rnd(V, H, seed=1).to(dev())), torch.nn.Parameter(rnd(32, H, seed=2).to(dev())), torch.nn.Parameter(rnd(2, H, seed=3).to(dev()))]
+    out = ops.bert_embed(ids.to(dev()), tt.to(dev()), ps[0], ps[1], ps[2], N, dtype)
+    w = rnd(B * N, H, seed=5).to(dev())
+    (out.float() * w).sum().backward()
+    ref_p = [p.detach().clone().requires_grad_(True) for p in ps]
+    ref = (ref_p[0][ids.to(dev())] + ref_p[2][tt.to(dev())] + ref_p[1][:N][None]).view(B * N, H)
+    (ref * (w.to(dtype).float() if dtype == torch.bfloat16 else w)).sum().backward()
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-6
+    assert float((out.float() - ref).abs().max()) <= tol * float(ref.abs().max())
+    for p, r in zip(ps, ref_p):
+        assert float((p.grad - r.grad).abs().max()) <= 1e-5 * float(r.grad.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_dropout(dtype):
+    """lavt_dropout: kept elements scaled by 1/(1-p) (+ residual), dropped ones zero; backward uses the same mask"""
+    from lavt_hip import ops
+    torch.manual_seed(11)
+    x = rnd(64, 96, seed=1).to(dev()).to(dtype).requires_grad_(True)
+    r = rnd(64, 96, seed=2).to(dev()).to(dtype).requires_grad_(True)
+    y = ops.dropout(x, 0.25, True, residual=r)
+    y.sum().backward()
+    kept = x.grad != 0                           # the backward applies the same keep mask: gradient 1/(1-p) on kept elements, 0 elsewhere
+    assert 0.6 < float(kept.float().mean()) < 0.9
+    assert float((x.grad.float()[kept] - 1 / 0.75).abs().max()) < 1e-2
+    ref = r.detach().float() + kept.float() * x.detach().float() / 0.75
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-6
+    assert float((y.detach().float() - ref).abs().max()) <= tol * float(ref.abs().max())
+    assert float((r.grad.float() - 1).abs().max()) == 0.0
+    assert ops.dropout(x, 0.25, False) is x
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attn_dbias_sum(dtype):
+    """lavt_attn_dbias_sum: sum over windows of the score gradients, padded rows skipped"""
+    from lavt_hip import _capi as K
+    nwin, heads, N, rpw, ld = 5, 3, 21, 24, 24
+    ds = rnd(nwin, heads, rpw, ld, seed=8).to(dev()).to(dtype)
+    out = torch.full((heads, N, ld), 7.0, device=dev())
+    K.check(K.lib.lavt_attn_dbias_sum(K.dt(dtype), K.ptr(ds), K.ptr(out), nwin, heads, N, rpw, ld, K.stream()))
+    ref = ds.float()[:, :, :N].sum(0)
+    assert float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max())

@@ -57,31 +57,36 @@ SHAPES = [
     ("w-qkv s0", "tn", 384, 128, 28800), ("w-fc1 s3", "tn", 4096, 1024, 450), ("w-pwam s0", "tn", 128, 128, 28800),
 ]
 
-for name, kind, a, b, c in SHAPES:
-    if len(sys.argv) > 1 and kind != sys.argv[1]:
-        continue
-    res = []
-    if kind == "tn":
-        for v2 in ("0", "1"):
-            for tile in ("64", "128"):
-                for sp in ("1", "2", "4", "8"):
-                    os.environ.update(LAVT_GEMM_TILE=tile, LAVT_TN_SPLIT=sp, LAVT_GEMM_V2=v2)
-                    t = timeit(tn(a, b, c), iters=5 if c > 20000 else 20)
-                    res.append((f"v{int(v2)+1}t{tile}/s{sp}", t * 1e6, 2.0 * a * b * c / t / 1e12))
-        for k in ("LAVT_GEMM_TILE", "LAVT_TN_SPLIT", "LAVT_GEMM_V2"):
+def main():
+    for name, kind, a, b, c in SHAPES:
+        if len(sys.argv) > 1 and kind != sys.argv[1]:
+            continue
+        res = []
+        if kind == "tn":
+            for v2 in ("0", "1"):
+                for tile in ("64", "128"):
+                    for sp in ("1", "2", "4", "8"):
+                        os.environ.update(LAVT_GEMM_TILE=tile, LAVT_TN_SPLIT=sp, LAVT_GEMM_V2=v2)
+                        t = timeit(tn(a, b, c), iters=5 if c > 20000 else 20)
+                        res.append((f"v{int(v2)+1}t{tile}/s{sp}", t * 1e6, 2.0 * a * b * c / t / 1e12))
+            for k in ("LAVT_GEMM_TILE", "LAVT_TN_SPLIT", "LAVT_GEMM_V2"):
+                os.environ.pop(k)
+            print(f"{name:9s} {kind:3s} {a:6d} {b:5d} {c:5d} | " + " | ".join(f"{k}: {us:5.1f}us" for k, us, tf in res))
+            continue
+        for tile, stages, v2, wv in (("64", "3", "0", "4"), ("64", "2", "1", "4"), ("64", "3", "1", "4"), ("128", "2", "1", "4"), ("128", "2", "1", "8"), ("128", "3", "1", "8"), ("256", "2", "1", "8"), ("512", "2", "1", "16")):
+            os.environ["LAVT_GEMM_TILE"] = tile
+            os.environ["LAVT_GEMM_STAGES"] = stages
+            os.environ["LAVT_GEMM_V2"] = v2
+            os.environ["LAVT_GEMM_WAVES"] = wv
+            fn = nt(a, b, c) if kind == "nt" else nt(a, b, c, True) if kind == "ntk" else tn(a, b, c)
+            t = timeit(fn)
+            res.append((("v2" if v2 == "1" else "v1") + "-" + tile + ("s" + stages + "w" + wv if v2 == "1" else ""), t * 1e6, 2.0 * a * b * c / t / 1e12))
+        for k in ("LAVT_GEMM_TILE", "LAVT_GEMM_STAGES", "LAVT_GEMM_V2", "LAVT_GEMM_WAVES"):
             os.environ.pop(k)
-        print(f"{name:9s} {kind:3s} {a:6d} {b:5d} {c:5d} | " + " | ".join(f"{k}: {us:5.1f}us" for k, us, tf in res))
-        continue
-    for tile, stages, v2, wv in (("64", "3", "0", "4"), ("64", "2", "1", "4"), ("64", "3", "1", "4"), ("128", "2", "1", "4"), ("128", "2", "1", "8"), ("128", "3", "1", "8"), ("256", "2", "1", "8"), ("512", "2", "1", "16")):
-        os.environ["LAVT_GEMM_TILE"] = tile
-        os.environ["LAVT_GEMM_STAGES"] = stages
-        os.environ["LAVT_GEMM_V2"] = v2
-        os.environ["LAVT_GEMM_WAVES"] = wv
         fn = nt(a, b, c) if kind == "nt" else nt(a, b, c, True) if kind == "ntk" else tn(a, b, c)
         t = timeit(fn)
-        res.append((("v2" if v2 == "1" else "v1") + "-" + tile + ("s" + stages + "w" + wv if v2 == "1" else ""), t * 1e6, 2.0 * a * b * c / t / 1e12))
-    for k in ("LAVT_GEMM_TILE", "LAVT_GEMM_STAGES", "LAVT_GEMM_V2", "LAVT_GEMM_WAVES"):
-        os.environ.pop(k)
-    fn = nt(a, b, c) if kind == "nt" else nt(a, b, c, True) if kind == "ntk" else tn(a, b, c)
-    t = timeit(fn)
-    print(f"{name:9s} {kind:3s} {a:6d} {b:5d} {c:5d} | " + " | ".join(f"{tile}: {us:5.1f}us {tf:4.0f}" for tile, us, tf in res) + f" | auto: {t * 1e6:5.1f}us")
+        print(f"{name:9s} {kind:3s} {a:6d} {b:5d} {c:5d} | " + " | ".join(f"{tile}: {us:5.1f}us {tf:4.0f}" for tile, us, tf in res) + f" | auto: {t * 1e6:5.1f}us")
+
+
+if __name__ == "__main__":
+    main()
