@@ -744,7 +744,10 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     const int force = t ? atoi(t) : 0;
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
     const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;
-    const bool big = force ? force == 128 : (tiles128 >= 200 && p.N >= 128);
+    // long reductions on few tiles (3-D convolutions of SepTPWAM: K = 27 C on 144 tiles of 128x128) also take the 128x128 tile: a launch lasts as
+    // long as its serial chain of K tiles, and the larger tile moves half the bytes per K tile and flop
+    static const int big_long = getenv("LAVT_GEMM_BIG_LONG") ? atoi(getenv("LAVT_GEMM_BIG_LONG")) : 128;
+    const bool big = force ? force == 128 : ((tiles128 >= 200 || (big_long > 0 && p.K >= 64 * 64 && tiles128 >= big_long)) && p.N >= 128);
     const char* sg = getenv("LAVT_GEMM_STAGES");
     // Ring depth.  In isolation (operands L2-resident) 2 stages win everywhere; inside the training step the operands of the small
     // GEMMs arrive cold from HBM / Infinity Cache and a 4-deep ring is worth 0.8 ms per step.  The many-tile long-K problems (decoder
