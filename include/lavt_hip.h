@@ -158,14 +158,14 @@ int lavt_gemm_tn_grouped(const lavt_gemm_tn_t* probs, int n, void* stream);
  * Shifted-window attention core (WindowAttention.forward, lib/backbone.py:123-140; mask :634-652).
  * qkv: [nwin*N][3C] in windowed row order (columns s*C + h*32 + d, s in {q,k,v}), head_dim = C/heads.
  * out: [nwin*N][C].  bias: dense fp32 [heads][N][bias_ld] (from lavt_relpos_expand; bias_ld = N rounded up to a multiple
- * of 16 -- 64 for 7x7, 160 for 12x12 windows -- lets the bf16 MFMA kernels run; padding columns hold -1e30).  region: optional int8
+ * of 16 -- 64 for 7x7, 160 for 12x12, 416 for the 392-token 8x7x7 video windows -- lets the bf16 MFMA kernels run; padding columns hold -1e30).  region: optional int8
  * [nw_img][N] region ids of the shift mask (window w uses row w % nw_img); unequal ids add -100.
  * lse: fp32 [nwin][heads][N] log-sum-exp of each score row (saved for backward).
  * table = relative_position_bias_table fp32 [(2wd-1)(2wh-1)(2ww-1)][heads] with the FULL window shape (wd, wh, ww) (wd = 1 for the 2-D Swin;
- *   a clipped video window has N < wd*wh*ww tokens and uses the top-left block of the index matrix).  The bf16 MFMA kernels (N <= 160)
- *   keep the head's table column in LDS and never read the dense bias: `bias` may then be NULL; lavt_attn_uses_table(dtype, N) tells.
+ *   a clipped video window has N < wd*wh*ww tokens and uses the top-left block of the index matrix).  The bf16 MFMA kernels (N <= 400: Q, K, V(, dO) of a whole window in LDS;
+ *   WindowAttention3D.forward, lib/video_swin_transformer.py:137-168, with its default 8x7x7 window included) keep the head's table column in LDS and never read the dense bias: `bias` may then be NULL; lavt_attn_uses_table(dtype, N) tells.
  * Backward: dqkv [nwin*N][3C] (every element written); dtable accumulates the table gradient.  bf16 MFMA kernel: every (window, head)
- *   writes its fp32 dS slab into ws (lavt_window_attn_bwd_ws floats; bias_ld = N rounded up to 64 / a multiple of 32) with plain stores;
+ *   writes its fp32 dS slab into ws (lavt_window_attn_bwd_ws floats; bias_ld = 64 / 160 / 416) with plain stores;
  *   two small kernels sum the slabs over windows, bin them by relative-position index and add the result to dtable (LDS float atomics inside the attention
  *   kernel measured 37 of 57 us per window-head).  Exact-fp32 kernel: global atomics into dtable; needs the dense `bias`.
  * ------------------------------------------------------------------------------------------- */
