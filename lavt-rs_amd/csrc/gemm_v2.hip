@@ -843,9 +843,11 @@ int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st) {
     const int ktiles = cdiv(p.K, 64);
     const long tiles64 = (long)cdiv(p.I, 64) * cdiv(p.J, 64) * p.batch;
     const long tiles128 = (long)cdiv(p.I, 128) * cdiv(p.J, 128) * p.batch;
-    // conv weight gradients (long K, >= 128 tiles of 128x128): the larger tile halves the L2->LDS bytes per MFMA (measured 303 vs 357 us)
+    // conv weight gradients (long K, >= 48 tiles of 128x128 -- the Swin-T decoder's 384-channel convolutions have 102): the larger tile halves the
+    // L2->LDS bytes per MFMA (measured 303 vs 357 us on Swin-B's; 16.9 -> 16.1 ms per Swin-T step)
     static const bool tn128 = getenv("LAVT_TN_BIG") == nullptr || getenv("LAVT_TN_BIG")[0] != '0';
-    const bool big = force ? force == 128 : (tn128 && p.conv_kc > 0 && tiles128 >= 128 && ktiles >= 64);
+    static const int tn_big_min = getenv("LAVT_TN_BIG_MIN") ? atoi(getenv("LAVT_TN_BIG_MIN")) : 48;
+    const bool big = force ? force == 128 : (tn128 && p.conv_kc > 0 && tiles128 >= tn_big_min && ktiles >= 64);
     const long tiles = big ? tiles128 : tiles64;
     int split = p.split_k;
     { const char* se = getenv("LAVT_TN_SPLIT"); if (se) split = atoi(se); }
