@@ -68,7 +68,10 @@ class TrainStep:
             return
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: ProcessGroupNCCL's watchdog thread polls events of earlier (eager warm-up) collectives with hipEventQuery; under the
+            # default "global" capture mode such a call from another thread, if it lands inside the capture window, aborts the capture with
+            # hipErrorStreamCaptureUnsupported (seen as a c10::DistBackendError that takes the process down)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.loss = self._body()
             self.graph = g
             self.captured = True
