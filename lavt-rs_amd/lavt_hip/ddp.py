@@ -100,6 +100,10 @@ class GradBuckets:
         # A parameter can report twice in one backward: once from the fused-accumulation path (ops.sinks.done, right after its
         # weight-gradient kernel is enqueued) and once from autograd's post-accumulate hook, which PyTorch also runs when the
         # op returned no gradient tensor.  Count each parameter once per step, or a bucket is reduced before it is complete.
+        if self.fused:
+            from . import ops
+            if id(p) in ops.wgrads.pending:          # hook fired for a weight gradient that is still queued for a grouped launch: not ready yet
+                return
         if id(p) in self._seen:
             return
         self._seen.add(id(p))

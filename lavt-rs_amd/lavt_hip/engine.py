@@ -25,11 +25,14 @@ from .runtime import compute_dtype
 
 
 class TrainStep:
-    def __init__(self, model, image, l_feats, l_mask, target, world=1, use_graph=True, bucket_mib=64.0, fused_loss=True):
+    def __init__(self, model, image, l_feats, l_mask, target, world=1, use_graph=True, bucket_mib=32.0, fused_loss=True):
         self.model = model
         dev = image.device
         self.x, self.l, self.m, self.t = image, l_feats, l_mask, target
         self.w = torch.tensor([0.9, 1.1], device=dev)                    # losses.py:7-11
+        # 32 MiB: the bucket that holds the earliest layers is reduced after backward has ended -- its all-reduce is the exposed tail of the step
+        # (64 MiB ~ 0.4-0.8 ms over xGMI), while ~15 collectives of this size still run at full ring bandwidth.  LAVT_BUCKET_MIB overrides.
+        bucket_mib = float(os.environ.get("LAVT_BUCKET_MIB", bucket_mib))
         self.buckets = GradBuckets(model, bucket_mib=bucket_mib, fused_accumulation=True)
         self.world = world
         self.graph = None

@@ -290,6 +290,7 @@ class _WgradQueue:
     def __init__(self):
         self.enabled = False
         self.items, self.keep, self.ready = [], [], []
+        self.pending = set()         # ids of parameters whose weight gradient is still queued (their autograd hook fires before the launch)
 
     def active(self):
         return self.enabled and sinks.map and os.environ.get("LAVT_WGRAD_GROUP", "1") != "0"
@@ -301,7 +302,11 @@ class _WgradQueue:
             self.flush()
 
     def notify(self, param):
+        # The op returns None for this parameter's gradient, and PyTorch runs the parameter's post-accumulate hook all the same -- BEFORE the
+        # grouped kernel exists.  Until flush() has enqueued it the parameter is `pending`: GradBuckets ignores hook reports for pending
+        # parameters, or a bucket whose last member is a queued gradient would be all-reduced while that gradient is still being written.
         self.ready.append(param)
+        self.pending.add(id(param))
 
     def flush(self):
         if self.items:
@@ -310,6 +315,7 @@ class _WgradQueue:
         ready = self.ready
         self.items, self.keep, self.ready = [], [], []
         for prm in ready:
+            self.pending.discard(id(prm))
             if sinks.on_ready is not None:
                 sinks.on_ready(prm)
 

@@ -341,13 +341,17 @@ def test_video_bf16_close_to_fp32(golden, tag):
 
 
 # ================================================================================================ DDP plumbing on one GPU
-def test_ddp_step_graph_equals_eager_in_one_rank_group():
+@pytest.mark.parametrize("bucket_mib", [64, 32, 16])
+def test_ddp_step_graph_equals_eager_in_one_rank_group(bucket_mib):
     """The N>1 code path (SyncBN statistic all-reduces, bucketed gradient all-reduces on the communication stream) run in a 1-rank RCCL
-    group, eagerly and captured into a hipGraph: identical gradients.  (Multi-rank behaviour itself is covered by the gloo tests.)"""
+    group, eagerly and captured into a hipGraph: identical gradients.  (Multi-rank behaviour itself is covered by the gloo tests.)
+    Several bucket sizes: the boundaries then fall on different parameters -- a bucket whose last member is a weight gradient still queued
+    for a grouped launch must not be reduced when PyTorch fires that parameter's hook early (found with 32 / 16 MiB buckets)."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
         import os, sys, torch, torch.distributed as dist
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() %% 400), RANK="0", WORLD_SIZE="1", LAVT_FORCE_COLLECTIVES="1")
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() %% 400), RANK="0", WORLD_SIZE="1", LAVT_FORCE_COLLECTIVES="1",
+                          LAVT_BUCKET_MIB="%d")
         sys.path[:0] = [%r, %r]
         import lavt_hip
         from types import SimpleNamespace
@@ -374,7 +378,7 @@ def test_ddp_step_graph_equals_eager_in_one_rank_group():
         err = float((g0 - g1).abs().max()) / float(g0.abs().max())
         print("RESULT", l0, l1, err)
         assert abs(l0 - l1) < 1e-6 and err < 2e-4, (l0, l1, err)        # split-K atomics: fp32 summation order differs run to run
-    """) % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lavt-rs_amd"), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    """) % (bucket_mib, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lavt-rs_amd"), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
 

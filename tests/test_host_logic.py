@@ -221,6 +221,29 @@ def test_grad_buckets_count_each_parameter_once():
     assert gb.pending == [0] and gb.launched == [False]
 
 
+def test_grad_buckets_ignore_hooks_of_queued_weight_gradients():
+    """Fused accumulation: a Linear whose weight gradient is queued for a grouped launch returns None from backward, and PyTorch runs the
+    parameter's post-accumulate hook right away -- before the kernel exists.  Such a report must not count (the queue reports the parameter
+    itself once the launch is enqueued), or the bucket would be reduced while the gradient is still being written."""
+    from lavt_hip import ops
+    from lavt_hip.ddp import GradBuckets
+    net = torch.nn.Sequential(*[torch.nn.Linear(8, 8) for _ in range(2)])
+    gb = GradBuckets(net, bucket_mib=1.0, fused_accumulation=True)
+    try:
+        gb.zero()
+        ps = list(net.parameters())
+        queued = ps[0]
+        ops.wgrads.notify(queued)              # what _Linear.backward does after deferring the GEMM
+        for p in ps:
+            gb._on_grad(p)                     # autograd hooks of every parameter, the queued one included
+        assert gb.launched == [False] and gb.pending == [len(ps) - 1]
+        ops.wgrads.flush()                     # no queued GEMMs here; reports the parameter through sinks.on_ready
+        assert gb.launched == [True] and not ops.wgrads.pending
+    finally:
+        ops.sinks.clear()
+        ops.wgrads.ready, ops.wgrads.pending = [], set()
+
+
 def test_syncbn_rank_statistics_combination():
     """SyncBN forward: the ranks' (sum, centred M2) pairs, gathered with ONE collective, combine to the statistics of the whole batch --
     also when the channel means are large compared with the spread (no E[x^2] - E[x]^2 cancellation)"""
