@@ -147,6 +147,12 @@ def main():
     ap.add_argument("--drop-path", type=float, default=0.3)
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record.  Libraries write there too (RCCL prints a version banner through C stdio when its first
+    # communicator is built, flushed at exit, i.e. after the record): keep the real stdout aside and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -247,7 +253,7 @@ def main():
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline and not cfg.get("video"):
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out), flush=True)
+        os.write(record_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
