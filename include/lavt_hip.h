@@ -267,6 +267,14 @@ int lavt_upsample_ce_fwd(int dtype, const void* x, const int64_t* target, float 
                          int B, int Hi, int Wi, int Ho, int Wo, void* stream);
 int lavt_upsample_ce_bwd(int dtype, const void* x, const int64_t* target, float w0, float w1, const float* out4, const float* dloss,
                          void* dx, int B, int Hi, int Wi, int Ho, int Wo, void* stream);
+/* Fused bilinear upsample (align_corners) + MultiClassDiceLoss (reference losses.py:38-77, `--loss mc_dice`, train.py:703-704) on the 2-class
+ * low-resolution logits x NHWC [B,Hi,Wi,2]; target int64 [B,Ho,Wo] in {0,1}.  stats (device fp32, 2 + 6*B floats) = {loss, 0, then per sample
+ * {I0, I1, sum p0^2, sum p1^2, #[t==0], #[t==1]}}; ws: >= 6*256*B floats of scratch.  Backward: dx = dloss[0] (NULL = 1) * d loss / d x, gather form.
+ * With Hi == Ho and Wi == Wo the upsample is the identity: the same entry points serve the un-fused criterion on full-resolution logits. */
+int lavt_upsample_dice_fwd(int dtype, const void* x, const int64_t* target, float* ws, int64_t ws_floats, float* stats,
+                           int B, int Hi, int Wi, int Ho, int Wo, void* stream);
+int lavt_upsample_dice_bwd(int dtype, const void* x, const int64_t* target, const float* stats, const float* dloss, void* dx,
+                           int B, int Hi, int Wi, int Ho, int Wo, void* stream);
 /* classifier head conv1_1: 1x1 conv hidden->2 with bias (lib/mask_predictor.py:50,99) */
 int lavt_cls_head_fwd(int dtype, const void* x, const float* w, const float* b, void* y, int64_t rows, int C, void* stream);
 int lavt_cls_head_bwd(int dtype, const void* x, const void* dy, const float* w, void* dx, float* dw, float* db,

@@ -158,9 +158,15 @@ class BertModel(nn.Module):
             raise OSError(f"BertModel.from_pretrained: {path!r} is not a directory with config.json / pytorch_model.bin (no network download here)")
         model = cls(BertConfig.from_json_file(cfg))
         wfile = os.path.join(str(path), "pytorch_model.bin")
+        sfile = os.path.join(str(path), "model.safetensors")
         if os.path.isfile(wfile):
-            sd = torch.load(wfile, map_location="cpu")
-            model.load_hf_state_dict(sd)
+            sd = torch.load(wfile, map_location="cpu", weights_only=True)
+        elif os.path.isfile(sfile):
+            from safetensors.torch import load_file
+            sd = load_file(sfile)
+        else:      # a config without weights would silently give an untrained text encoder
+            raise OSError(f"BertModel.from_pretrained: {path!r} holds config.json but neither pytorch_model.bin nor model.safetensors")
+        model.load_hf_state_dict(sd)
         return model
 
     def load_hf_state_dict(self, sd):

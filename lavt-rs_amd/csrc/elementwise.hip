@@ -653,3 +653,119 @@ extern "C" int lavt_adamw_step(const int64_t* desc, const float* hyper, int coun
     LAVT_CHECK_LAUNCH("lavt_adamw_step");
     return LAVT_OK;
 }
+
+// ---- fused bilinear upsample + MultiClassDiceLoss (losses.py:38-77 of the reference: the `--loss mc_dice` criterion of the released lavt_one) ----
+// per sample b and class c:  I_bc = sum_pix p_c [t == c],  C_bc = sum_pix (p_c^2 + [t == c]),  loss = mean_{b,c} (1 - 2 I_bc / (C_bc + 1e-6)).
+// stats = {loss, 0, then per sample {I0, I1, Q0 = sum p0^2, Q1 = sum p1^2, N0 = #[t == 0], N1 = #[t == 1]}}; like the cross-entropy pair above the
+// (B, 2, H, W) logits are never written.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_dice_fwd_kernel(const T* __restrict__ x, const int64_t* __restrict__ target, float* __restrict__ partial,
+                                                                int Hi, int Wi, int Ho, int Wo, float sh, float sw) {
+    const int b = blockIdx.y;
+    const int64_t n = (int64_t)Ho * Wo;
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int xo = (int)(i % Wo), yo = (int)(i / Wo);
+        int y0, y1, x0, x1; float ly, lx;
+        bl_coord(yo, sh, Hi, y0, y1, ly);
+        bl_coord(xo, sw, Wi, x0, x1, lx);
+        const UpCe u = upce_at<T>(x + (int64_t)b * Hi * Wi * 2, Wi, y0, y1, ly, x0, x1, lx);
+        const float p0 = expf(u.up0 - u.lse), p1 = expf(u.up1 - u.lse);
+        const int64_t t = target[(int64_t)b * n + i];
+        if (t == 0) { s[0] += p0; s[4] += 1.f; }
+        if (t == 1) { s[1] += p1; s[5] += 1.f; }
+        s[2] += p0 * p0; s[3] += p1 * p1;
+    }
+    __shared__ float red[4][6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) red[threadIdx.x >> 6][k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 6) partial[((int64_t)b * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void upsample_dice_finish_kernel(const float* __restrict__ partial, int nblk, int B, float* __restrict__ stats) {
+    __shared__ float red[4][6];
+    __shared__ float loss_acc;
+    if (threadIdx.x == 0) loss_acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = threadIdx.x; k < nblk; k += 256)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) a[j] += partial[((int64_t)b * nblk + k) * 6 + j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) a[j] = wave_sum(a[j]);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) red[threadIdx.x >> 6][j] = a[j];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { v[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j]; stats[2 + b * 6 + j] = v[j]; }
+            loss_acc += (1.f - 2.f * v[0] / (v[2] + v[4] + 1e-6f)) + (1.f - 2.f * v[1] / (v[3] + v[5] + 1e-6f));
+        }
+    }
+    if (threadIdx.x == 0) { stats[0] = loss_acc / (2.f * (float)B); stats[1] = 0.f; }
+}
+// dx[b, yi, xi, c]: with a_bc = -1 / (B (C_bc + eps)) and e_bc = I_bc / (B (C_bc + eps)^2),  d loss / d p_c(pix) = a_bc [t == c] + 2 p_c e_bc,
+// through the 2-class softmax (dz1 = p0 p1 (g1 - g0) = -dz0) and the bilinear weights, gathered per low-resolution pixel (no atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_dice_bwd_kernel(const T* __restrict__ x, const int64_t* __restrict__ target, const float* __restrict__ stats,
+                                                                const float* __restrict__ dloss, T* __restrict__ dx, int B, int Hi, int Wi, int Ho, int Wo,
+                                                                float sh, float sw) {
+    const int64_t n = (int64_t)B * Hi * Wi;
+    const float g = dloss ? dloss[0] : 1.f;
+    GRID_STRIDE(i, n) {
+        const int xi = (int)(i % Wi), yi = (int)((i / Wi) % Hi), b = (int)(i / Wi / Hi);
+        const float* sb = stats + 2 + b * 6;
+        const float c0 = sb[2] + sb[4] + 1e-6f, c1 = sb[3] + sb[5] + 1e-6f, invB = 0.5f / (float)B;      // mean over (b, c): 1 / (2B)
+        const float A0 = -2.f * invB / c0, A1 = -2.f * invB / c1, E0 = 2.f * invB * sb[0] / (c0 * c0), E1 = 2.f * invB * sb[1] / (c1 * c1);
+        int ylo, yhi, xlo, xhi;
+        bl_range(yi, sh, Hi, Ho, ylo, yhi);
+        bl_range(xi, sw, Wi, Wo, xlo, xhi);
+        const T* base = x + (int64_t)b * Hi * Wi * 2;
+        float acc = 0.f;
+        for (int yo = ylo; yo <= yhi; ++yo) {
+            int y0, y1; float ly;
+            bl_coord(yo, sh, Hi, y0, y1, ly);
+            const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int xo = xlo; xo <= xhi; ++xo) {
+                int x0, x1; float lx;
+                bl_coord(xo, sw, Wi, x0, x1, lx);
+                const float wx = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
+                if (wx == 0.f) continue;
+                const int64_t t = target[((int64_t)b * Ho + yo) * Wo + xo];
+                const UpCe u = upce_at<T>(base, Wi, y0, y1, ly, x0, x1, lx);
+                const float p0 = expf(u.up0 - u.lse), p1 = expf(u.up1 - u.lse);
+                const float g0 = (t == 0 ? A0 : 0.f) + 2.f * p0 * E0, g1 = (t == 1 ? A1 : 0.f) + 2.f * p1 * E1;
+                acc += wy * wx * p0 * p1 * (g1 - g0);
+            }
+        }
+        dx[i * 2] = from_f<T>(-acc * g);
+        dx[i * 2 + 1] = from_f<T>(acc * g);
+    }
+}
+extern "C" int lavt_upsample_dice_fwd(int dtype, const void* x, const int64_t* target, float* ws, int64_t ws_floats, float* stats,
+                                      int B, int Hi, int Wi, int Ho, int Wo, void* stream) {
+    LAVT_CHECK_ARG(x && target && ws && stats && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "lavt_upsample_dice_fwd: bad arguments");
+    const int64_t n = (int64_t)Ho * Wo;
+    int blocks = (int)((n + 1023) / 1024);
+    if (blocks > 256) blocks = 256;
+    LAVT_CHECK_ARG(ws_floats >= (int64_t)blocks * 6 * B, "lavt_upsample_dice_fwd: scratch of %d floats needed", blocks * 6 * B);
+    DISPATCH_T(dtype, "lavt_upsample_dice_fwd", hipLaunchKernelGGL(upsample_dice_fwd_kernel<T>, dim3(blocks, B), dim3(256), 0, ST, (const T*)x, target, ws, Hi, Wi, Ho, Wo, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
+    hipLaunchKernelGGL(upsample_dice_finish_kernel, dim3(1), dim3(256), 0, ST, ws, blocks, B, stats);
+    LAVT_CHECK_LAUNCH("lavt_upsample_dice_fwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_upsample_dice_bwd(int dtype, const void* x, const int64_t* target, const float* stats, const float* dloss, void* dx,
+                                      int B, int Hi, int Wi, int Ho, int Wo, void* stream) {
+    LAVT_CHECK_ARG(x && target && stats && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "lavt_upsample_dice_bwd: bad arguments");
+    const int64_t n = (int64_t)B * Hi * Wi;
+    DISPATCH_T(dtype, "lavt_upsample_dice_bwd", hipLaunchKernelGGL(upsample_dice_bwd_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, ST, (const T*)x, target, stats, dloss, (T*)dx, B, Hi, Wi, Ho, Wo, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
+    LAVT_CHECK_LAUNCH("lavt_upsample_dice_bwd");
+    return LAVT_OK;
+}

@@ -15,7 +15,90 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: build it with `make -C lavt-rs_amd/csrc` (or __graft_entry__.build()). "
         "The LAVT HIP path has no CPU/eager fallback.")
-lib = C.CDLL(LIB_PATH)
+_cdll = C.CDLL(LIB_PATH)
+
+
+class _Profiler:
+    """In-process kernel timing for bench.py: when enabled, every C-ABI launch is bracketed by two HIP events recorded on the
+    stream the kernel is launched on, and tagged with the entry point, the caller's scope label ("wmsa", "pwam", ...: lavt_hip._capi.scope) and a
+    shape / algorithmic-work note left by the host wrapper.  Off by default (one attribute test per launch); never on inside a hipGraph capture."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (entry point, scope, note, start event, end event)
+        self.label = "other"
+        self.note = None
+
+    def start(self):
+        self.records, self.enabled, self.note = [], True, None
+
+    def stop(self):
+        """-> list of (entry point, scope, note, microseconds)"""
+        self.enabled = False
+        torch.cuda.synchronize()
+        out = [(n, s, d, e0.elapsed_time(e1) * 1e3) for n, s, d, e0, e1 in self.records]
+        self.records = []
+        return out
+
+
+prof = _Profiler()
+
+
+class scope:
+    """`with scope("wmsa"):` labels the launches issued inside (forward); autograd Functions decorated with @scoped carry the label of their
+    forward into their backward."""
+
+    def __init__(self, label):
+        self.label = label
+
+    def __enter__(self):
+        self.prev, prof.label = prof.label, self.label
+
+    def __exit__(self, *exc):
+        prof.label = self.prev
+        return False
+
+
+def scoped(fn_cls):
+    """class decorator for torch.autograd.Function: backward launches inherit the scope label that was current in forward"""
+    fwd, bwd = fn_cls.forward, fn_cls.backward
+
+    def forward(ctx, *a):
+        ctx._lavt_scope = prof.label
+        return fwd(ctx, *a)
+
+    def backward(ctx, *g):
+        with scope(getattr(ctx, "_lavt_scope", "other")):
+            return bwd(ctx, *g)
+
+    fn_cls.forward, fn_cls.backward = staticmethod(forward), staticmethod(backward)
+    return fn_cls
+
+
+class _Lib:
+    """The CDLL behind a thin proxy: `lib.lavt_x(...)` is the ctypes function itself unless the profiler is on."""
+
+    def __init__(self, cdll):
+        self._c = cdll
+
+    def __getattr__(self, name):
+        fn = getattr(self._c, name)
+
+        def call(*args):
+            if not prof.enabled:
+                return fn(*args)
+            note, prof.note = prof.note, None
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            prof.records.append((name, prof.label, note, e0, e1))
+            return rc
+        setattr(self, name, call)
+        return call
+
+
+lib = _Lib(_cdll)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
@@ -85,6 +168,8 @@ _PROTOTYPES = {
     "lavt_adamw_step": [vp, vp, i32, vp, f32, f32, vp],
     "lavt_upsample_ce_fwd": [i32, vp, vp, f32, f32, vp, i64, vp, i32, i32, i32, i32, i32, vp],
     "lavt_upsample_ce_bwd": [i32, vp, vp, f32, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "lavt_upsample_dice_fwd": [i32, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, vp],
+    "lavt_upsample_dice_bwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lavt_cls_head_fwd": [i32, vp, vp, vp, vp, i64, i32, vp],
     "lavt_cls_head_bwd": [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp],
     "lavt_im2col4": [i32, vp, vp, i32, i32, i32, vp],
@@ -96,12 +181,14 @@ _PROTOTYPES = {
     "lavt_cast_multi": [vp, i32, i32, vp],
 }
 for _name, _args in _PROTOTYPES.items():
-    _fn = getattr(lib, _name)          # AttributeError here = header/library mismatch: fail loudly
+    _fn = getattr(_cdll, _name)          # AttributeError here = header/library mismatch: fail loudly
     _fn.argtypes = _args
     _fn.restype = C.c_int
-lib.lavt_last_error.restype = C.c_char_p
-lib.lavt_window_attn_bwd_ws.restype = C.c_int64
-lib.lavt_last_error.argtypes = []
+_cdll.lavt_last_error.restype = C.c_char_p
+_cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
+_cdll.lavt_last_error.argtypes = []
+for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version"):      # queries, not launches: never timed
+    setattr(lib, _name, getattr(_cdll, _name))
 
 EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)
 

@@ -83,6 +83,9 @@ class GradBuckets:
         self.launched = [False] * len(self.buckets)
         self.works = []
         self._seen = set()
+        if self.fused:
+            from . import ops
+            ops.sinks.begin_step()
 
     def _is_view(self, p):
         lo = self.flat.data_ptr()

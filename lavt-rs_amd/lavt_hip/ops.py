@@ -130,18 +130,32 @@ class _GradSinks:
     def __init__(self):
         self.map = {}
         self.on_ready = None
+        self.used = set()
 
     def set(self, params, on_ready=None):
         self.map = {id(p): (weakref.ref(p), p.grad) for p in params if p.grad is not None}
         self.on_ready = on_ready
+        self.used = set()
 
     def clear(self):
-        self.map, self.on_ready = {}, None
+        self.map, self.on_ready, self.used = {}, None, set()
+
+    def begin_step(self):
+        """the flat gradient buffer has just been zeroed (GradBuckets.zero): every parameter may receive ONE weight gradient until the next call"""
+        self.used = set()
 
     def buf(self, p, shape):
         """-> (fp32 buffer of `shape` to accumulate into, is_sink)"""
         ent = self.map.get(id(p)) if p is not None else None
         if ent is not None and ent[0]() is p:
+            # Sink targets are written with plain stores when a reduction is not split (gemm_v2.hip: `atomic = nsplit > 1 || accumulate`) and
+            # each parameter is reported ready once per step: a parameter used twice in one forward, or micro-batch accumulation without
+            # GradBuckets.zero() in between, would silently lose a contribution.  Refuse instead.
+            if id(p) in self.used:
+                raise RuntimeError("fused gradient accumulation: a second weight gradient for the same parameter within one step (parameter shared "
+                                   "between two ops, or gradient accumulation over micro-batches) is not supported by the step harness; "
+                                   "call ops.sinks.clear() to use ordinary autograd accumulation")
+            self.used.add(id(p))
             return ent[1].view(shape), True
         return torch.zeros(shape, dtype=torch.float32, device=p.device), False
 
@@ -251,6 +265,9 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.C2, p.ldc2, p.c_split = K.ptr(C2), ldc2, c_split
     p.c_rowmap, p.c_f32 = K.ptr(c_rowmap), int(c_f32)
     p.zeros = _zero_page(A.device)
+    if K.prof.enabled:
+        K.prof.note = {"flops": 2.0 * M * N * Kd * batch, "shape": f"nt {M}x{N}x{Kd}" + (f" b{batch}" if batch > 1 else "") + (" conv" if conv is not None else "")
+                       + (" kmajor" if b_kmajor else "")}
     K.check(K.lib.lavt_gemm_nt(C.byref(p), K.stream()))
 
 
@@ -277,6 +294,8 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     if defer is not None:
         defer.add(p, (A, B, Cout, a_rowmap, a_rowscale, b_rowmap, colsum))
         return
+    if K.prof.enabled:
+        K.prof.note = {"flops": 2.0 * I * J * Kd * batch, "shape": f"tn {I}x{J}x{Kd}" + (f" b{batch}" if batch > 1 else "") + (" conv" if conv is not None else "")}
     K.check(K.lib.lavt_gemm_tn(C.byref(p), K.stream()))
 
 
@@ -289,7 +308,7 @@ class _WgradQueue:
 
     def __init__(self):
         self.enabled = False
-        self.items, self.keep, self.ready = [], [], []
+        self.items, self.keep, self.ready, self.scopes = [], [], [], []
         self.pending = set()         # ids of parameters whose weight gradient is still queued (their autograd hook fires before the launch)
 
     def active(self):
@@ -298,6 +317,7 @@ class _WgradQueue:
     def add(self, p, tensors):
         self.items.append(p)
         self.keep.append(tensors)
+        self.scopes.append(K.prof.label)
         if len(self.items) == 4:
             self.flush()
 
@@ -311,9 +331,13 @@ class _WgradQueue:
     def flush(self):
         if self.items:
             arr = (K.GemmTN * len(self.items))(*self.items)
+            if K.prof.enabled:       # a grouped launch mixes scopes (qkv / proj with fc1 / fc2): the note carries the per-member flops and labels
+                fl = [2.0 * q.I * q.J * q.K for q in self.items]
+                K.prof.note = {"flops": sum(fl), "shape": "tn-grouped " + "+".join(f"{q.I}x{q.J}x{q.K}" for q in self.items),
+                               "members": list(zip(self.scopes, fl))}
             K.check(K.lib.lavt_gemm_tn_grouped(arr, len(self.items), K.stream()))
         ready = self.ready
-        self.items, self.keep, self.ready = [], [], []
+        self.items, self.keep, self.ready, self.scopes = [], [], [], []
         for prm in ready:
             self.pending.discard(id(prm))
             if sinks.on_ready is not None:
@@ -345,6 +369,7 @@ class LinOpts:
     row_scale_value: float = 0.0               # if != 0: row_scale holds only 0 and this value (lets the wgrad kernel treat it as a row mask)
 
 
+@K.scoped
 class _Linear(torch.autograd.Function):
     """y[out_map[m]] = act((x[in_map[m]] @ W^T + b) * row_scale[m // div]) + residual[out_map[m]]"""
 
@@ -412,6 +437,7 @@ class _Linear(torch.autograd.Function):
         return dx, dW, db, d_res, None
 
 
+@K.scoped
 class _LinearCat(torch.autograd.Function):
     """[x W1^T + b1 | x W2^T + b2 | ...]: several Linear layers of the same input as ONE GEMM over the stacked weight (weights.get_cat) and
     ONE data-gradient GEMM; the weight / bias gradients stay per parameter (column blocks of dy)."""
@@ -475,6 +501,7 @@ def linear(x, weight, bias=None, residual=None, **kw):
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
+@K.scoped
 class _LayerNorm(torch.autograd.Function):
     """y = LN(x) (optionally over the PatchMerging 2x2 gather).  With `passthrough` the function also returns x itself: use that alias
     for the residual branch (x + f(LN(x))) and the two gradients of x meet inside the LayerNorm backward kernel (dx = LN'(dy) + dres)
@@ -531,6 +558,7 @@ FUSED_ATTN_MAX_N = 160          # exact-fp32 fused kernels: one window's K/V (an
 FUSED_ATTN_MAX_N_BF16 = 400     # bf16 MFMA kernels: Q/K/V(/dO) of a whole window in LDS up to 25 key tiles (Video-Swin 8x7x7 = 392 tokens)
 
 
+@K.scoped
 class _WindowAttn(torch.autograd.Function):
     """Fused kernels (N <= 160 tokens per window).  qkv [nwin*N, 3C] windowed rows."""
 
@@ -573,6 +601,7 @@ class _WindowAttn(torch.autograd.Function):
         return dqkv, sinks.done(table, dtable, ts), None, None, None, None
 
 
+@K.scoped
 class _WindowAttnComposed(torch.autograd.Function):
     """Windows too large for the fused kernels (Video-Swin: 8x7x7 = 392, 8x12x12 = 1152 tokens):
     S = scale q k^T (gather-GEMM batched over (window, head)) -> bias + shift mask + softmax (lavt_attn_softmax) -> P v (GEMM).
@@ -658,6 +687,7 @@ def _stats(x, groups, rows, Cc):
     return s
 
 
+@K.scoped
 class _InstanceNorm(torch.autograd.Function):
     """y = IN_over_rows(x) (* mul); x [B*T, C], statistics per (b, c) over the T rows (lib/backbone.py:1311-1327)."""
 
@@ -708,6 +738,7 @@ def combine_rank_stats(allst: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
     return torch.stack([tot, m2])
 
 
+@K.scoped
 class _BatchNormRelu(torch.autograd.Function):
     """BatchNorm2d + ReLU on NHWC rows [R, C].  training: batch statistics (all-reduced over `group` when given =
     SyncBatchNorm semantics, train.py:589), running stats updated in place; eval: running statistics."""
@@ -785,6 +816,7 @@ def batch_norm_relu(x, bn: torch.nn.modules.batchnorm._BatchNorm):
 
 
 # ------------------------------------------------------------------------------------------ language gate
+@K.scoped
 class _Gate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gpre, r):
@@ -809,6 +841,7 @@ def gate(x, gpre, r):
 
 
 # ------------------------------------------------------------------------------------------ PWAM pixel-word attention
+@K.scoped
 class _PwamAttn(torch.autograd.Function):
     """softmax_words(q k^T * C^-1/2 + maskbias) v   per sample and head group (lib/backbone.py:1349-1363).
     q [B*T, C]; k, v [B*KV_LD, C] (rows >= n_l are zero); maskbias fp32 [B, KV_LD]."""
@@ -866,6 +899,7 @@ def pwam_attention(q, k, v, maskbias, B, T, n_l, G):
 
 
 # ------------------------------------------------------------------------------------------ text side (BERT encoder of lavt_one / lavt_video)
+@K.scoped
 class _BertEmbed(torch.autograd.Function):
     """word[ids] + token_type[tt] + position[0..N-1] (BertEmbeddings.forward before its LayerNorm; HF transformers 3.0.2 modeling_bert.py)."""
 
@@ -898,6 +932,7 @@ def bert_embed(ids, token_type_ids, word, pos, typ, N, dtype):
     return _BertEmbed.apply(ids, token_type_ids, word, pos, typ, N, dtype)
 
 
+@K.scoped
 class _Dropout(torch.autograd.Function):
     """y = dropout(x) (+ residual): the keep mask is drawn with torch's generator (so torch.manual_seed governs it, as for nn.Dropout),
     the scaling / masking / residual add is one HIP kernel."""
@@ -931,6 +966,7 @@ def dropout(x, p, training, residual=None):
     return _Dropout.apply(x, residual, float(p))
 
 
+@K.scoped
 class _MaskedSelfAttn(torch.autograd.Function):
     """BertSelfAttention core: softmax(q k^T / sqrt(hd) + keybias) v per (sample, head); qkv [B*N, 3H] token-major (q | k | v), keybias fp32 [B, N]
     (= (1 - attention_mask) * -10000).  Heads are regrouped head-major ([B][heads][Np][q|k|v x hd]) so that each GEMM is ONE batched launch;
@@ -1000,6 +1036,7 @@ def masked_self_attention(qkv, keybias, B, N, heads, p_drop=0.0):
 
 
 # ------------------------------------------------------------------------------------------ layout changes
+@K.scoped
 class _Transpose(torch.autograd.Function):
     """[B, R, Cc] -> [B, Cc, R] (both contiguous) with optional dtype change; used for NCHW<->NHWC at the boundary."""
 
@@ -1026,6 +1063,7 @@ def transpose_last2(x, out_dtype=None):
     return _Transpose.apply(x, out_dtype or x.dtype)
 
 
+@K.scoped
 class _Cast(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dtype):
@@ -1042,6 +1080,7 @@ def cast_ad(x, dtype):
 
 
 # ------------------------------------------------------------------------------------------ patch embed
+@K.scoped
 class _PatchEmbed(torch.autograd.Function):
     """Conv2d(3->C0, k4, s4) on an NCHW fp32 image, zero padded to a multiple of 4 (lib/backbone.py:315-324)."""
 
@@ -1084,6 +1123,7 @@ def patch_embed(img, weight, bias, dtype):
 
 
 # ------------------------------------------------------------------------------------------ decoder pieces
+@K.scoped
 class _ConvTaps(torch.autograd.Function):
     """'same'-padded convolution over NHWC / NDHWC rows as an implicit GEMM: 3x3 (decoder, no bias) or kd x kh x kw with bias
     (Conv3d of SepTPWAM); the input may be the channel concat of x1 and x2; optional fused GELU (pre-activation saved)."""
@@ -1156,6 +1196,7 @@ def conv3d(x, weight, bias, B, D, H, W, act=K.ACT_NONE):
     return _ConvTaps.apply(x, None, weight, bias, B, D, H, W, act)
 
 
+@K.scoped
 class _Bilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, B, Hi, Wi, Ho, Wo):
@@ -1179,6 +1220,7 @@ def bilinear(x, B, Hi, Wi, Ho, Wo):
     return _Bilinear.apply(x, B, Hi, Wi, Ho, Wo)
 
 
+@K.scoped
 class _ClsHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -1206,6 +1248,7 @@ def cls_head(x, weight, bias):
     return _ClsHead.apply(x, weight, bias)
 
 
+@K.scoped
 class _LogitsUp(torch.autograd.Function):
     """NHWC [B*Hi*Wi, 2] -> NCHW fp32 [B, 2, Ho, Wo] bilinear, align_corners=True (lib/_utils.py:21)."""
 
@@ -1231,6 +1274,7 @@ def logits_upsample(x, B, Hi, Wi, Ho, Wo):
 
 
 # ------------------------------------------------------------------------------------------ fused upsample + weighted CE (+ I/U counts)
+@K.scoped
 class _UpsampleCE(torch.autograd.Function):
     """loss = F.cross_entropy(F.interpolate(y, (Ho, Wo), bilinear, align_corners=True), target, weight=(w0, w1)) on the low-resolution
     2-class logits rows x [B*Hi*Wi, 2] (lib/_utils.py:21 + losses.py:7-11) without materialising the upsampled logits.
@@ -1262,3 +1306,36 @@ class _UpsampleCE(torch.autograd.Function):
 
 def upsample_cross_entropy(x, target, B, Hi, Wi, Ho, Wo, weight=(0.9, 1.1)):
     return _UpsampleCE.apply(x, target, B, Hi, Wi, Ho, Wo, weight[0], weight[1])
+
+
+@K.scoped
+class _UpsampleDice(torch.autograd.Function):
+    """MultiClassDiceLoss()(F.interpolate(y, (Ho, Wo), bilinear, align_corners=True), target) on the low-resolution 2-class logits rows
+    x [B*Hi*Wi, 2] (reference losses.py:38-77 after lib/_utils.py:21), the upsampled logits never written.
+    Returns (loss, stats) with stats = [loss, 0, per sample {I0, I1, sum p0^2, sum p1^2, #t==0, #t==1}]."""
+
+    @staticmethod
+    def forward(ctx, x, target, B, Hi, Wi, Ho, Wo):
+        x = x.contiguous()
+        target = target.contiguous()
+        assert target.dtype == torch.int64 and target.numel() == B * Ho * Wo
+        stats = torch.empty(2 + 6 * B, dtype=torch.float32, device=x.device)
+        ws = _scratch(6 * 256 * B, x.device)
+        K.check(K.lib.lavt_upsample_dice_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(target), K.ptr(ws), ws.numel(), K.ptr(stats), B, Hi, Wi, Ho, Wo, K.stream()))
+        ctx.save_for_backward(x, target, stats)
+        ctx.dims = (B, Hi, Wi, Ho, Wo)
+        ctx.mark_non_differentiable(stats)
+        return stats[0].clone(), stats
+
+    @staticmethod
+    def backward(ctx, dloss, _dstats):
+        x, target, stats = ctx.saved_tensors
+        B, Hi, Wi, Ho, Wo = ctx.dims
+        dx = torch.empty_like(x)
+        dl = dloss.contiguous().float().reshape(1)
+        K.check(K.lib.lavt_upsample_dice_bwd(K.dt(x.dtype), K.ptr(x), K.ptr(target), K.ptr(stats), K.ptr(dl), K.ptr(dx), B, Hi, Wi, Ho, Wo, K.stream()))
+        return dx, None, None, None, None, None, None
+
+
+def upsample_dice_loss(x, target, B, Hi, Wi, Ho, Wo):
+    return _UpsampleDice.apply(x, target, B, Hi, Wi, Ho, Wo)

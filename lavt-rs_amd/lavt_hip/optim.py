@@ -90,6 +90,10 @@ class FusedAdamW(torch.optim.Optimizer):
             self._build()
         _, desc, hyper, n = self._tables
         K.check(K.lib.lavt_adamw_step(K.ptr(desc), K.ptr(hyper), n, K.ptr(self._step), self.total_steps, self.power, K.stream()))
+        # the kernel writes the parameters through raw pointers: p._version does not move, so the cached compute copies (bf16 Linear weights,
+        # packed conv weights) must be declared stale here or the next forward would run on the old weights
+        from . import ops
+        ops.weights.invalidate()
         return loss
 
     def steps_taken(self) -> int:

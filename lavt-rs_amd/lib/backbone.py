@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from lavt_hip import ops, rowmaps
-from lavt_hip._capi import ACT_GELU, ACT_NONE, ACT_RELU
+from lavt_hip._capi import ACT_GELU, ACT_NONE, ACT_RELU, scope
 from lavt_hip.runtime import compute_dtype
 
 
@@ -47,9 +47,9 @@ class _LangCtx:
 
     @classmethod
     def get(cls, l, l_mask, dtype):
-        key = (id(l), id(l_mask), l._version, dtype)
-        if cls._cache is None or cls._cache[0] != key or cls._cache[2] is not l:
-            cls._cache = (key, cls(l, l_mask, dtype), l)
+        key = (id(l), id(l_mask), l._version, l_mask._version, dtype)
+        if cls._cache is None or cls._cache[0] != key or cls._cache[2] is not l or cls._cache[3] is not l_mask:
+            cls._cache = (key, cls(l, l_mask, dtype), l, l_mask)
         return cls._cache[1]
 
 
@@ -145,15 +145,17 @@ class SwinTransformerBlock(nn.Module):
         M = wmap.numel()
         a = self.attn
         xn, x2 = ops.layer_norm_res(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps)     # x2: alias for the residual branch
-        qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, in_map=wmap, rows=M)
-        o = ops.window_attention(qkv, a.relative_position_bias_table, region, ws, self.num_heads)
         f1 = self.drop_path.factors(B, dev)
         dpv = 1.0 / (1.0 - self.drop_path.drop_prob) if self.drop_path.drop_prob < 1.0 else 0.0
-        x2 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x2, out_map=wmap, rows=M, out_rows=B * L,
-                        row_scale=f1, row_scale_div=M // B, row_scale_value=dpv)
+        with scope("wmsa"):
+            qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, in_map=wmap, rows=M)
+            o = ops.window_attention(qkv, a.relative_position_bias_table, region, ws, self.num_heads)
+            x2 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x2, out_map=wmap, rows=M, out_rows=B * L,
+                            row_scale=f1, row_scale_div=M // B, row_scale_value=dpv)
         f2 = self.drop_path.factors(B, dev)
         h, x2 = ops.layer_norm_res(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        x2 = self.mlp(h, residual=x2, row_scale=f2, row_scale_div=L, row_scale_value=dpv)
+        with scope("mlp"):
+            x2 = self.mlp(h, residual=x2, row_scale=f2, row_scale_div=L, row_scale_value=dpv)
         return x2.view(B, L, C)
 
 
@@ -299,12 +301,13 @@ class MMBasicLayer(nn.Module):
             x = blk(x)
         x2 = x.reshape(B * L, C)
         lang = _LangCtx.get(l, l_mask, x.dtype)
-        r = self.fusion.rows(x2, B, L, lang)
-        if self.version == "default":
-            g = ops.linear(ops.linear(r, self.res_gate[0].weight, None, act=ACT_RELU), self.res_gate[2].weight, None)
-            x2 = ops.gate(x2, g, r)                                   # x + tanh(g) * r
-        elif self.version == "no_gate":
-            x2 = x2 + r
+        with scope("pwam"):
+            r = self.fusion.rows(x2, B, L, lang)
+            if self.version == "default":
+                g = ops.linear(ops.linear(r, self.res_gate[0].weight, None, act=ACT_RELU), self.res_gate[2].weight, None)
+                x2 = ops.gate(x2, g, r)                                   # x + tanh(g) * r
+            elif self.version == "no_gate":
+                x2 = x2 + r
         feat = x2 if self.hs else (x.reshape(B * L, C) if self.lazy_pred else r)
         xg = x2.view(B, L, C)
         if self.downsample is not None:

@@ -61,6 +61,11 @@ class SimpleDecoding(nn.Module):
         return x, (H, W)
 
     def _run(self, x_c4, x_c3, x_c2, x_c1):
+        from lavt_hip._capi import scope
+        with scope("decoder"):
+            return self._run_scoped(x_c4, x_c3, x_c2, x_c1)
+
+    def _run_scoped(self, x_c4, x_c3, x_c2, x_c1):
         dtype = compute_dtype()
         B = x_c4.shape[0]
         feats = []

@@ -240,3 +240,14 @@ def iou_counts(logits, target):
     inter = int((pred & target).sum())
     union = int((pred | target).sum())
     return inter, union
+
+
+def multiclass_dice(logits, target, eps=1e-6):
+    """MultiClassDiceLoss.forward (reference losses.py:38-77): softmax over classes; per sample and class
+    I = sum p*onehot, C = sum (p*p + onehot) over pixels; mean over samples of (1 - 2I/(C+eps)), then the mean of the two classes."""
+    p = torch.softmax(logits, 1)
+    oh = F.one_hot(target, logits.shape[1]).permute(0, 3, 1, 2).to(logits.dtype)
+    inter = (p * oh).sum((2, 3))
+    card = (p * p + oh).sum((2, 3))
+    dl = (1.0 - 2.0 * inter / (card + eps)).mean(0)
+    return (dl[1] + dl[0]) / 2

@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--only-video", action="store_true")
     ap.add_argument("--only-checkpoint", action="store_true")
     ap.add_argument("--only-bert", action="store_true")
+    ap.add_argument("--only-dice", action="store_true")
+    ap.add_argument("--only-full", default="", help="comma list of full-size (BASELINE.json configs) cases: swin_b,swin_t,video_pwam,video_sept")
     cli = ap.parse_args()
     if cli.only_bert:
         bert_cases()
@@ -130,6 +132,12 @@ def main():
     from lib import _utils as ru
     if cli.only_video:
         video_cases(args)
+        return
+    if cli.only_full:
+        full_cases(args, cli.only_full.split(","))
+        return
+    if cli.only_dice:
+        dice_cases()
         return
     if cli.only_checkpoint:
         checkpoint_cases()
@@ -285,6 +293,22 @@ def main():
     print("   tiny: params without grad:", nograd)
     video_cases(args)
     checkpoint_cases()
+    dice_cases()
+
+
+def dice_cases():
+    """`--loss mc_dice` (train.py:703-704): the reference's losses.MultiClassDiceLoss after the final upsample of lib/_utils.py:21, on seeded
+    low-resolution logits and targets (one sample has no foreground pixel at all: its class-1 intersection and target count are 0)."""
+    import losses as rl
+    crit = rl.MultiClassDiceLoss()
+    for tag, (B, h, w, H, W) in {"a": (3, 13, 11, 52, 44), "b": (2, 30, 30, 120, 120), "same": (2, 9, 7, 9, 7)}.items():
+        y = (randn(91, B, 2, h, w) * 2.0).requires_grad_(True)
+        tgt = (randn(92, B, H, W) > 0.3).long()
+        tgt[B - 1] = 0
+        up = F.interpolate(y, size=(H, W), mode="bilinear", align_corners=True)
+        loss = crit(up, tgt)
+        loss.backward()
+        save(f"dice_{tag}", dims=np.array([B, h, w, H, W]), seeds=np.array([91, 92]), loss=float(loss), dy=y.grad)
 
 
 def video_cases(args_base):
@@ -374,6 +398,95 @@ def video_cases(args_base):
             f.write("\n".join(keys) + "\n")
 
 
+def _full_record(name, model_params, logits, lowres, feats, tgt, loss, inputs_with_grad, extra):
+    """What a full-size fixture holds (inputs are regenerated from the seed, weights from their names): the decoder output before the
+    upsample, a strided sample of the upsampled logits, the bit-packed argmax mask and the bit-packed set of decisive pixels
+    (|logit1 - logit0| > 2e-3), loss, I/U, per-feature statistics + strided samples, and a digest of every parameter gradient."""
+    pred = logits.argmax(1)
+    margin = (logits[:, 1] - logits[:, 0]).abs()
+    rec = dict(lowres=lowres, logits_s=logits[:, :, 1::4, 2::4] if logits.shape[0] <= 2 else logits[:, :, 1::8, 2::8],
+               mask=np.packbits(pred.numpy().astype(np.uint8).reshape(-1)), decisive=np.packbits((margin > 2e-3).numpy().reshape(-1)),
+               I=int((pred & tgt).sum()), U=int((pred | tgt).sum()), loss=float(loss), logit_std=float(logits.std()),
+               margin_frac=float((margin > 2e-3).float().mean()),
+               feat_sums=np.array([float(f.double().sum()) for f in feats]), feat_abs=np.array([float(f.double().abs().sum()) for f in feats]))
+    for i, f in enumerate(feats):
+        st = max(f.shape[-1] // 15, 1)
+        rec[f"c{i + 1}_s"] = f[:, ::8, ::st, ::st]
+    nograd = []
+    for k, p in model_params:
+        if p.grad is None:
+            nograd.append(k)
+        else:
+            rec["g|" + k] = grad_digest(p.grad)
+    rec["nograd"] = np.array(nograd)
+    for k, t in inputs_with_grad.items():
+        rec[k] = grad_digest(t.grad)
+    rec.update(extra)
+    save(name, **rec)
+    print(f"   {name}: loss {float(loss):.6f} logit std {float(logits.std()):.4f} decisive {rec['margin_frac']:.5f} pos {float(pred.float().mean()):.4f} nograd {nograd}")
+
+
+def full_cases(args, which):
+    """BASELINE.json configs at their real sizes (the configurations bench.py times), train mode (batch-statistics BatchNorm), drop_path 0
+    (DropPath's random draws cannot be matched across implementations), forward + weighted CE + backward through the reference's classes."""
+    import time
+    from lib import backbone as rb
+    from lib import mask_predictor as rmp
+    from lib import _utils as ru
+    w = torch.tensor([0.9, 1.1])
+    for tag, (embed, depths, heads, ws, B) in {"swin_b": (128, [2, 2, 18, 2], [4, 8, 16, 32], 12, 2), "swin_t": (96, [2, 2, 6, 2], [3, 6, 12, 24], 7, 8)}.items():
+        if tag not in which:
+            continue
+        t0 = time.time()
+        bb = rb.MultiModalSwinTransformer(embed_dim=embed, depths=depths, num_heads=heads, window_size=ws, ape=False, drop_path_rate=0.0, patch_norm=True,
+                                          out_indices=(0, 1, 2, 3), use_checkpoint=False, num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=args)
+        model = ru.LAVT(bb, rmp.SimpleDecoding(8 * embed, args))
+        fill_state_dict_(model)
+        model.train()
+        x, l, lm, tgt = det_inputs(B, 480, 20, seed=1234)
+        x.requires_grad_(True)
+        l.requires_grad_(True)
+        feats = model.backbone(x, l, lm)
+        lowres = model.classifier(feats[3], feats[2], feats[1], feats[0])
+        logits = F.interpolate(lowres, size=(480, 480), mode="bilinear", align_corners=True)          # lib/_utils.py:21
+        loss = F.cross_entropy(logits, tgt, weight=w)
+        loss.backward()
+        _full_record(f"full_{tag}_480_b{B}", list(model.named_parameters()), logits.detach(), lowres.detach(), [f.detach() for f in feats], tgt, loss.detach(),
+                     {"dx": x, "dl": l}, dict(seed=1234, B=B, ws=ws))
+        print(f"   ({time.time() - t0:.0f} s)")
+        del model, feats, logits, loss
+    import lib.video_swin_transformer as rv
+    rv.sr_ratio = [1, 1, 1, 1]
+    sept = ("--sep_t_pwam", "--conv3d_kernel_size_t", "3-3-3", "--conv3d_kernel_size_s", "1-1-1", "--w_t3x3_s1x1", "--mm_t3x3_s1x1")
+    for tag, a in (("video_pwam", ref_args("--swin_type", "base")), ("video_sept", ref_args("--swin_type", "base", *sept))):
+        if tag not in which and tag + "_fwd" not in which:
+            continue
+        fwd_only = tag + "_fwd" in which
+        t0 = time.time()
+        bb = rv.MultiModalSwinTransformer3D(patch_size=(1, 4, 4), embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=(8, 7, 7),
+                                            drop_path_rate=0.0, patch_norm=True, out_indices=(0, 1, 2, 3), use_checkpoint=False,
+                                            num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=a)
+        dec = rmp.SimpleDecoding(1024, a)
+        model = nn.ModuleDict({"backbone": bb, "classifier": dec})
+        fill_state_dict_(model)
+        model.train()
+        frames, l, lm, tgt = det_inputs(1, 384, 22, seed=1234, frames=8)
+        with torch.set_grad_enabled(not fwd_only):
+            if not fwd_only:
+                frames.requires_grad_(True)
+                l.requires_grad_(True)
+            feats = bb(frames.permute(0, 2, 1, 3, 4), l, lm)
+            lowres = dec(feats[3], feats[2], feats[1], feats[0])
+            logits = F.interpolate(lowres, size=(384, 384), mode="bilinear", align_corners=True)
+            loss = F.cross_entropy(logits, tgt, weight=w)
+            if not fwd_only:
+                loss.backward()
+        _full_record(f"full_{tag}_t8_384", [] if fwd_only else list(model.named_parameters()), logits.detach(), lowres.detach(), [f.detach() for f in feats], tgt,
+                     loss.detach(), {} if fwd_only else {"dframes": frames, "dl": l}, dict(seed=1234, B=1, T=8, fwd_only=int(fwd_only)))
+        print(f"   ({time.time() - t0:.0f} s)")
+        del model, feats, logits, loss
+
+
 def _ref_mask(rb, Hp, Wp, ws):
     """Run the reference's own mask construction (lib/backbone.py:634-652) by calling the
     stage forward with zero blocks and capturing the mask handed to a probe block."""
@@ -442,6 +555,37 @@ def checkpoint_cases():
             for k in ("layers.0.blocks.1.attn.relative_position_bias_table", "layers.2.blocks.0.attn.qkv.weight", "patch_embed.proj.weight"):
                 out[tag + "|" + k] = sd[k].clone()
     save("checkpoint_surgery", **out)
+
+    # ---- released 2-D LAVT weights into the video model: LAVTVideo.load_from_pretrained2d_lavt_weights[_into_a_3d_model]
+    # (lib/_utils.py:133-238), driven as train.py:575-578 does.  The fake 2-D checkpoint has window-5 tables (bicubic resize to 13x13, then
+    # repeated 2*8-1 times) and carries relative_position_index buffers (must be dropped).
+    from synth_ckpt import synthetic_lavt2d_checkpoint
+    import lib._utils as ru
+    from lib import mask_predictor as rmp
+    m2 = ru.LAVT(rb.MultiModalSwinTransformer(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=5, ape=False, drop_path_rate=0.0,
+                                              patch_norm=True, use_checkpoint=False, num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=a),
+                 rmp.SimpleDecoding(256, a))
+    with open(os.path.join(HERE, "state_dict_keys_lavt2d_micro_w5.txt"), "w") as f:
+        for k, v in m2.state_dict().items():
+            f.write(f"{k}|{'x'.join(str(d) for d in v.shape)}|{'i' if not v.dtype.is_floating_point else 'f'}\n")
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "lavt2d.pth")
+        torch.save({"model": synthetic_lavt2d_checkpoint()}, path)
+        for method in ("load_from_pretrained2d_lavt_weights", "load_from_pretrained2d_lavt_weights_into_a_3d_model"):
+            b3 = rv.MultiModalSwinTransformer3D(patch_size=(1, 4, 4), embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=(8, 7, 7),
+                                                drop_path_rate=0.0, patch_norm=True, out_indices=(0, 1, 2, 3), use_checkpoint=False,
+                                                num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=a)
+            vm = ru.LAVTVideo(b3, rmp.SimpleDecoding(256, a), a)
+            fill_state_dict_(vm)
+            getattr(vm, method)(path)
+            sd = vm.state_dict()
+            for k in ("backbone.layers.0.blocks.1.attn.relative_position_bias_table", "backbone.layers.3.blocks.0.attn.relative_position_bias_table",
+                      "backbone.patch_embed.proj.weight", "backbone.layers.1.blocks.0.attn.qkv.weight", "backbone.layers.1.fusion.vis_project.0.weight",
+                      "backbone.layers.2.fusion.image_lang_att.f_key.0.weight", "backbone.layers.0.res_gate.0.weight", "classifier.conv2_3.weight",
+                      "classifier.bn1_4.running_var"):
+                out[method + "|" + k] = sd[k].clone()
+    save("lavt2d_into_video", **out)
 
 
 BERT_MICRO = dict(vocab_size=64, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, max_position_embeddings=32,

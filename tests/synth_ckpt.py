@@ -23,3 +23,15 @@ def synthetic_swin_checkpoint(embed=32, depths=(2, 2, 2, 2), heads=(1, 2, 4, 8),
     if prefix:
         sd["module.decode_head.conv_seg.weight"] = torch.zeros(2, 4)                              # upper-net tensor: must be dropped
     return sd
+
+
+def synthetic_lavt2d_checkpoint():
+    """A fake 'released 2-D LAVT' state dict (micro dims, window 5; `backbone.` / `classifier.` prefixes, index buffers included): the tensors
+    of the reference's 2-D LAVT micro model (key list written by make_golden.py) with name-keyed deterministic values."""
+    import os
+    sd = {}
+    for line in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_dict_keys_lavt2d_micro_w5.txt")):
+        k, shp, kind = line.strip().split("|")
+        shape = tuple(int(s) for s in shp.split("x")) if shp else ()
+        sd[k] = torch.zeros(shape, dtype=torch.long) if kind == "i" else det_tensor("lavt2d." + k, shape, torch.float32)
+    return sd

@@ -1,0 +1,224 @@
+"""GPU parity AT THE BENCHMARKED CONFIGURATIONS (BASELINE.json configs 2-4, the shapes bench.py times), against fixtures captured from the real
+reference at those sizes (tests/golden/make_golden.py --only-full ...: full_swin_b_480_b2, full_swin_t_480_b8, full_video_{pwam,sept}_t8_384):
+
+* fp32 compute: decoder output and upsampled logits <= 1e-3, argmax mask identical on decisive pixels, I/U and loss equal, EVERY parameter
+  gradient against the reference's digest (train-mode BatchNorm, drop_path 0);
+* bf16 compute (the dtype of the timed run), same fixtures, stated gate: mask IoU >= 0.98, mask agreement on decisive pixels >= 0.99,
+  max |dlogit| <= 0.35 sigma_logit, |d loss| <= 2e-2, gradient norms within 6 %; the achieved numbers are printed (pytest -s / -rP);
+* the step harness itself (hipGraph replay, fused upsample+CE, grouped weight gradients, flat gradient buffer) at the bench shape.
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lavt_hip.detweights import det_inputs, fill_state_dict_
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+IMAGE = {"swin_b": ("full_swin_b_480_b2", 128, [2, 2, 18, 2], [4, 8, 16, 32], 12, 2),
+         "swin_t": ("full_swin_t_480_b8", 96, [2, 2, 6, 2], [3, 6, 12, 24], 7, 8)}
+SEPT = dict(sep_t_pwam=True, conv3d_kernel_size_t="3-3-3", conv3d_kernel_size_s="1-1-1", w_t3x3_s1x1=True, mm_t3x3_s1x1=True)
+# gradients the bench's hot kernels produce (the grouped stage-2 weight gradients, the 256x256-tile decoder convolutions, ...): always reported
+NAMED = ["backbone.layers.2.blocks.17.attn.qkv.weight", "backbone.layers.2.blocks.17.attn.proj.weight", "backbone.layers.2.blocks.17.mlp.fc1.weight",
+         "backbone.layers.2.blocks.17.mlp.fc2.weight", "backbone.layers.2.blocks.17.attn.relative_position_bias_table", "backbone.layers.2.blocks.17.norm1.weight",
+         "backbone.layers.2.blocks.0.attn.qkv.weight", "backbone.layers.2.blocks.9.mlp.fc1.weight", "backbone.layers.0.blocks.1.attn.qkv.weight",
+         "backbone.layers.0.blocks.1.mlp.fc2.weight", "backbone.layers.1.blocks.0.attn.proj.weight", "backbone.layers.3.blocks.1.mlp.fc1.weight",
+         "backbone.layers.0.fusion.vis_project.0.weight", "backbone.layers.2.fusion.image_lang_att.f_key.0.weight", "backbone.layers.2.fusion.image_lang_att.W.0.weight",
+         "backbone.layers.1.res_gate.0.weight", "backbone.layers.1.downsample.reduction.weight", "backbone.patch_embed.proj.weight", "backbone.norm2.weight",
+         "classifier.conv1_4.weight", "classifier.conv2_4.weight", "classifier.conv1_3.weight", "classifier.conv2_3.weight", "classifier.conv1_2.weight",
+         "classifier.conv2_2.weight", "classifier.bn2_2.weight", "classifier.conv1_1.weight"]
+
+
+def grad_digest(t, n=24):
+    f = t.detach().reshape(-1).double().cpu()
+    step = max(f.numel() // (n // 2), 1)
+    samp = torch.cat([f[: n // 2], f[::step][: n // 2]])
+    samp = F.pad(samp, (0, n - samp.numel()))
+    return torch.cat([torch.stack([f.norm(), f.sum()]), samp]).float()
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    import lavt_hip
+    from lavt_hip import ops
+    lavt_hip.set_compute_dtype(torch.float32)
+    yield
+    ops.sinks.clear()
+    ops.wgrads.enabled = False
+    lavt_hip.set_compute_dtype(torch.float32)
+    torch.cuda.empty_cache()
+
+
+def _image_model(embed, depths, heads, ws):
+    from lib._utils import LAVT
+    from lib.backbone import MultiModalSwinTransformer
+    from lib.mask_predictor import SimpleDecoding
+    a = SimpleNamespace()
+    model = LAVT(MultiModalSwinTransformer(embed_dim=embed, depths=depths, num_heads=heads, window_size=ws, drop_path_rate=0.0, args=a), SimpleDecoding(8 * embed, a))
+    fill_state_dict_(model)
+    return model.to(DEV).train()
+
+
+def _video_model(sept):
+    from lib.mask_predictor import SimpleDecoding
+    from lib.video_swin_transformer import MultiModalSwinTransformer3D
+    a = SimpleNamespace(**(SEPT if sept else {}))
+    bb = MultiModalSwinTransformer3D(patch_size=(1, 4, 4), embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=(8, 7, 7),
+                                     drop_path_rate=0.0, patch_norm=True, out_indices=(0, 1, 2, 3), use_checkpoint=False, num_heads_fusion=[1, 1, 1, 1],
+                                     fusion_drop=0.0, args=a)
+    model = torch.nn.ModuleDict({"backbone": bb, "classifier": SimpleDecoding(1024, a)})
+    fill_state_dict_(model)
+    return model.to(DEV).train()
+
+
+def _unpack(bits, shape):
+    n = int(np.prod(shape))
+    return torch.as_tensor(np.unpackbits(bits)[:n].reshape(shape)).bool()
+
+
+def _forward(model, video, x, l, m):
+    from lib._utils import _upsample_logits
+    if video:
+        feats = model["backbone"](x.permute(0, 2, 1, 3, 4), l, m)
+        lowres = model["classifier"](feats[3], feats[2], feats[1], feats[0])
+    else:
+        feats = model.backbone(x, l, m)
+        lowres = model.classifier(feats[3], feats[2], feats[1], feats[0])
+    return feats, lowres, _upsample_logits(lowres, x.shape[-2:])
+
+
+def _check_forward(g, feats, lowres, logits, tgt, loss, fp32):
+    """-> dict of achieved numbers; asserts the gate of the dtype"""
+    size = logits.shape[-1]
+    lg = logits.detach().float().cpu()
+    ref_low = torch.as_tensor(g["lowres"])
+    ref_s = torch.as_tensor(g["logits_s"])
+    stride = 4 if lg.shape[0] <= 2 else 8
+    got_s = lg[:, :, 1::stride, 2::stride]
+    sigma = float(g["logit_std"])
+    ref_mask = _unpack(g["mask"], (lg.shape[0], size, size))
+    decisive = _unpack(g["decisive"], (lg.shape[0], size, size))
+    pred = lg.argmax(1).bool()
+    r = dict(err_lowres=float((lowres.detach().float().cpu() - ref_low).abs().max()), err_logits=float((got_s - ref_s).abs().max()), sigma=sigma,
+             agree_decisive=float((pred[decisive] == ref_mask[decisive]).float().mean()),
+             mask_iou=float((pred & ref_mask).sum()) / max(float((pred | ref_mask).sum()), 1.0),
+             dloss=abs(float(loss) - float(g["loss"])), ties=int((~decisive).sum()))
+    I, U = int((pred & tgt.bool().cpu()).sum()), int((pred | tgt.bool().cpu()).sum())
+    r["dI"], r["dU"] = abs(I - int(g["I"])), abs(U - int(g["U"]))
+    for i, f in enumerate(feats):
+        st = max(f.shape[-1] // 15, 1)
+        r[f"err_c{i + 1}"] = float((f.detach().float().cpu()[:, ::8, ::st, ::st] - torch.as_tensor(g[f"c{i + 1}_s"])).abs().max())
+    if fp32:
+        assert r["err_lowres"] <= 1e-3 and r["err_logits"] <= 1e-3, r
+        assert r["agree_decisive"] == 1.0, r
+        assert r["dI"] <= r["ties"] and r["dU"] <= r["ties"], r
+        assert r["dloss"] < 1e-4, r
+        assert max(r[f"err_c{i}"] for i in range(1, 5)) <= 1e-3, r
+    else:
+        assert r["mask_iou"] >= 0.98 and r["agree_decisive"] >= 0.99, r
+        assert max(r["err_lowres"], r["err_logits"]) <= 0.35 * sigma, r
+        assert r["dloss"] <= 2e-2, r
+    return r
+
+
+def _check_grads(g, named_grads, fp32, extra=()):
+    """named_grads: iterable of (name, grad tensor or None).  fp32: every digest entry within 2e-3 of the gradient's norm (3e-3 video);
+    bf16: gradient norm within 6 % and digest samples within 8 % of the norm."""
+    nograd = set(g["nograd"].tolist())
+    worst, bad, seen = {}, [], 0
+    for k, grad in named_grads:
+        if k in nograd:
+            assert grad is None or float(grad.abs().max()) == 0.0, k
+            continue
+        ref = torch.as_tensor(g["g|" + k])
+        d = grad_digest(grad)
+        norm = max(float(ref[0]), 1e-9)
+        if fp32:
+            e = float((torch.cat([d[:1], d[2:]]) - torch.cat([ref[:1], ref[2:]])).abs().max()) / norm          # entry 1 is a plain sum: fp32 cancellation noise
+            tol = 3e-3
+        else:
+            e = max(abs(float(d[0]) - norm) / norm, float((d[2:] - ref[2:]).abs().max()) / norm / 1.5)
+            tol = 0.06
+        seen += 1
+        worst[k] = e
+        if not e <= tol + 5e-6 / norm:
+            bad.append((k, round(e, 5), norm))
+    assert seen >= 20
+    assert not bad, f"{len(bad)} of {seen} parameter gradients off: {bad[:10]}"
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    named = {k: round(worst[k], 6) for k in NAMED if k in worst}
+    return dict(n=seen, worst=top, named=named)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag", ["swin_b", "swin_t"])
+def test_full_image_config(golden, tag, dtype):
+    """BASELINE configs[2] (Swin-B w12, 2x480x480: 30->36 / 15->24 padded windows at C=512/1024, M=28 800 decoder convolutions on the
+    256x256 tile) and configs[1] (Swin-T w7, 8x480x480: 126-row padded grid)."""
+    import lavt_hip
+    name, embed, depths, heads, ws, B = IMAGE[tag]
+    g = golden(name)
+    lavt_hip.set_compute_dtype(torch.float32 if dtype == "fp32" else torch.bfloat16)
+    model = _image_model(embed, depths, heads, ws)
+    x, l, m, tgt = det_inputs(B, 480, 20, seed=int(g["seed"]))
+    x, l = x.to(DEV).requires_grad_(True), l.to(DEV).requires_grad_(True)
+    feats, lowres, logits = _forward(model, False, x, l, m.to(DEV))
+    loss = F.cross_entropy(logits, tgt.to(DEV), weight=torch.tensor([0.9, 1.1], device=DEV))
+    r = _check_forward(g, feats, lowres, logits, tgt, loss.detach(), dtype == "fp32")
+    loss.backward()
+    gr = _check_grads(g, [(k, p.grad) for k, p in model.named_parameters()] , dtype == "fp32")
+    for nm, t in (("dx", x.grad), ("dl", l.grad)):
+        ref = torch.as_tensor(g[nm])
+        e = float((grad_digest(t)[2:] - ref[2:]).abs().max()) / float(ref[0])
+        assert e <= (3e-3 if dtype == "fp32" else 0.08), (nm, e)
+    print(f"\n[full {tag} {dtype}] forward {r}\n[full {tag} {dtype}] gradients {gr}")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag", ["pwam", "sept"])
+def test_full_video_config(golden, tag, dtype):
+    """BASELINE configs[3]: Video-Swin-B, one clip of T=8 frames at 384x384, 22 tokens; PWAM and the README SepTPWAM recipe
+    (lib/video_swin_transformer.py:854-881).  392-token windows: fp32 on the composed path, bf16 on the fused 25-tile kernels."""
+    import lavt_hip
+    g = golden(f"full_video_{tag}_t8_384")
+    lavt_hip.set_compute_dtype(torch.float32 if dtype == "fp32" else torch.bfloat16)
+    model = _video_model(tag == "sept")
+    frames, l, m, tgt = det_inputs(1, 384, 22, seed=int(g["seed"]), frames=8)
+    frames, l = frames.to(DEV).requires_grad_(True), l.to(DEV).requires_grad_(True)
+    feats, lowres, logits = _forward(model, True, frames, l, m.to(DEV))
+    loss = F.cross_entropy(logits, tgt.to(DEV), weight=torch.tensor([0.9, 1.1], device=DEV))
+    r = _check_forward(g, feats, lowres, logits, tgt, loss.detach(), dtype == "fp32")
+    gr = None
+    if not int(g["fwd_only"]):
+        loss.backward()
+        gr = _check_grads(g, [(k, p.grad) for k, p in model.named_parameters()], dtype == "fp32")
+    print(f"\n[full video {tag} {dtype}] forward {r}\n[full video {tag} {dtype}] gradients {gr}")
+
+
+def test_bench_step_matches_reference(golden):
+    """What bench.py times -- TrainStep on Swin-B w12, 2x480x480, bf16: hipGraph replay, fused upsample + CE + I/U kernel, grouped weight
+    gradients into the flat buffer -- against the reference's fp32 run of the same inputs (drop_path 0): loss, I/U, every gradient."""
+    import lavt_hip
+    from lavt_hip.engine import TrainStep
+    name, embed, depths, heads, ws, B = IMAGE["swin_b"]
+    g = golden(name)
+    lavt_hip.set_compute_dtype(torch.bfloat16)
+    model = _image_model(embed, depths, heads, ws)
+    x, l, m, tgt = det_inputs(B, 480, 20, seed=int(g["seed"]))
+    step = TrainStep(model, x.to(DEV), l.to(DEV), m.to(DEV), tgt.to(DEV))
+    step.warmup_and_capture(eager_iters=2)
+    assert step.captured and step.fused_loss
+    step.step()
+    step.step()
+    torch.cuda.synchronize()
+    dloss = abs(float(step.loss) - float(g["loss"]))
+    stats = step.stats.cpu()
+    dI, dU = abs(int(stats[2]) - int(g["I"])), abs(int(stats[3]) - int(g["U"]))
+    assert dloss <= 2e-2, dloss
+    assert dI <= 0.02 * int(g["U"]) and dU <= 0.02 * int(g["U"]), (dI, dU, int(g["I"]), int(g["U"]))
+    gr = _check_grads(g, [(k, p.grad) for k, p in model.named_parameters()], False)
+    print(f"\n[bench step bf16 graph] dloss {dloss:.5f} dI {dI} dU {dU} of U {int(g['U'])}; gradients {gr}")

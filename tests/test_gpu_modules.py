@@ -504,7 +504,7 @@ def test_lavt_one_micro_matches_oracle_chain():
     from oracle import lavt_oracle as O
     args = SimpleNamespace(lazy_pred=False)
     bb = MultiModalSwinTransformer(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=7, drop_path_rate=0.0, args=args)
-    model = LAVTOne(bb, SimpleDecoding(256, args), SimpleNamespace(ck_bert="/nonexistent"))
+    model = LAVTOne(bb, SimpleDecoding(256, args), SimpleNamespace(ck_bert="/nonexistent", bert_random_init=True))
     model.text_encoder = BertModel(BertConfig(vocab_size=64, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=256,
                                               max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), add_pooling_layer=False)
     fill_state_dict_(model)

@@ -604,3 +604,45 @@ def test_attn_dbias_sum(dtype):
     K.check(K.lib.lavt_attn_dbias_sum(K.dt(dtype), K.ptr(ds), K.ptr(out), nwin, heads, N, rpw, ld, K.stream()))
     ref = ds.float()[:, :, :N].sum(0)
     assert float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------- MultiClassDiceLoss
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tag", ["a", "b", "same"])
+def test_upsample_dice_golden(golden, tag, dtype):
+    """lavt_upsample_dice_{fwd,bwd} vs the reference's MultiClassDiceLoss on the upsampled logits (losses.py:38-77): loss and d loss / d y"""
+    from lib._utils import fused_dice_loss
+    g = golden(f"dice_{tag}")
+    B, h, w, H, W = g["dims"].tolist()
+    y = (torch.randn(B, 2, h, w, generator=torch.Generator("cpu").manual_seed(int(g["seeds"][0]))) * 2.0)
+    tgt = (torch.randn(B, H, W, generator=torch.Generator("cpu").manual_seed(int(g["seeds"][1]))) > 0.3).long()
+    tgt[B - 1] = 0
+    yd = y.to(dev()).to(dtype).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).requires_grad_(True)     # NCHW-shaped view of NHWC memory, as the decoder returns it
+    loss, stats = fused_dice_loss(yd, tgt.to(dev()))
+    loss.backward()
+    tol = 1e-5 if dtype == torch.float32 else 3e-3
+    assert abs(float(loss) - float(g["loss"])) < tol
+    ref = torch.as_tensor(g["dy"])
+    assert float((yd.grad.float().cpu() - ref).abs().max()) <= (1e-6 if dtype == torch.float32 else 0.02 * float(ref.abs().max()))
+    per = stats[2:].view(B, 6).cpu()
+    assert torch.equal(per[:, 5], (tgt == 1).flatten(1).sum(1).float()) and float(per[B - 1, 1]) == 0.0
+
+
+def test_losses_module_criteria_on_full_resolution_logits(golden):
+    """`losses.cross_entropy_loss` / `losses.MultiClassDiceLoss()` called as train.py:225 does (criterion(output, target), output (B,2,H,W))"""
+    import losses
+    from oracle import lavt_oracle as O
+    g = torch.Generator("cpu").manual_seed(17)
+    out = (torch.randn(2, 2, 40, 36, generator=g) * 2).requires_grad_(True)
+    tgt = (torch.randn(2, 40, 36, generator=g) > 0).long()
+    o2 = out.detach().to(dev()).requires_grad_(True)
+    for crit, ref_fn in ((losses.cross_entropy_loss, O.weighted_ce), (losses.MultiClassDiceLoss(), O.multiclass_dice)):
+        out.grad = o2.grad = None
+        ref = ref_fn(out, tgt)
+        ref.backward()
+        got = crit(o2, tgt.to(dev()))
+        got.backward()
+        assert abs(float(got) - float(ref)) < 1e-5
+        assert float((o2.grad.cpu() - out.grad).abs().max()) < 1e-6
+    with pytest.raises(NotImplementedError):
+        losses.DiceFocalLoss()

@@ -139,7 +139,7 @@ SEPT_FLAGS = dict(sep_t_pwam=True, conv3d_kernel_size_t="3-3-3", conv3d_kernel_s
 def test_video_factory_state_dict_keys(tag, flags):
     """lavt_video builds the reference's parameter set (names + shapes) for Video-Swin-B, default PWAM and the README SepTPWAM recipe"""
     from lib import segmentation
-    model = segmentation.lavt_video("", SimpleNamespace(swin_type="base", **flags))
+    model = segmentation.lavt_video("", SimpleNamespace(swin_type="base", bert_random_init=True, **flags))
     keys = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in model.backbone.state_dict().items())
     assert keys == open(os.path.join(GOLDEN, f"state_dict_keys_video_swin_b_{tag}.txt")).read().split()      # backbone of the reference factory
     assert {k.split(".")[0] for k in model.state_dict()} == {"backbone", "classifier", "text_encoder"}
@@ -148,7 +148,7 @@ def test_video_factory_state_dict_keys(tag, flags):
 def test_video_unsupported_fusions_fail_loudly():
     from lib import segmentation
     with pytest.raises(NotImplementedError):
-        segmentation.lavt_video("", SimpleNamespace(swin_type="tiny", ts_pwam=True, conv3d_kernel_size="3-1-1"))
+        segmentation.lavt_video("", SimpleNamespace(swin_type="tiny", ts_pwam=True, conv3d_kernel_size="3-1-1", bert_random_init=True))
 
 
 # ---------------------------------------------------------------------------------------------------- checkpoint surgery
@@ -188,6 +188,43 @@ def test_checkpoint_loaders_match_reference(golden, tmp_path):
         sd = b3.state_dict()
         for k in [k for k in g.files if k.startswith(tag + "|")]:
             assert np.array_equal(sd[k.split("|")[1]].numpy(), g[k]), k
+
+
+def test_lavt_video_loads_2d_lavt_weights_as_train_py_does(golden, tmp_path):
+    """train.py:572-578 of the reference: `model = segmentation.__dict__[args.model](...)`, then
+    `model.load_from_pretrained2d_lavt_weights(path)` or `model.load_from_pretrained2d_lavt_weights_into_a_3d_model(path)`
+    (lib/_utils.py:133-182 / :184-238): tables resized bicubically and repeated 2*Wd-1 times, patch embedding unsqueezed, index buffers dropped,
+    and -- for the second form -- the 2-D `.fusion` tensors left out.  Expected tensors come from the reference's own methods (make_golden.py)."""
+    from lib import segmentation
+    from lavt_hip.detweights import fill_state_dict_
+    from lib._utils import LAVTVideo
+    from lib.mask_predictor import SimpleDecoding
+    from lib.video_swin_transformer import MultiModalSwinTransformer3D
+    from synth_ckpt import synthetic_lavt2d_checkpoint
+    g = golden("lavt2d_into_video")
+    path = str(tmp_path / "lavt2d.pth")
+    torch.save({"model": synthetic_lavt2d_checkpoint()}, path)
+    assert all(hasattr(segmentation.LAVTVideo, n) for n in ("forward_feats", "load_from_pretrained2d_lavt_weights", "load_from_pretrained2d_lavt_weights_into_a_3d_model"))
+    a = SimpleNamespace(bert_random_init=True)
+    for method in ("load_from_pretrained2d_lavt_weights", "load_from_pretrained2d_lavt_weights_into_a_3d_model"):
+        b3 = MultiModalSwinTransformer3D(patch_size=(1, 4, 4), embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=(8, 7, 7),
+                                         drop_path_rate=0.0, patch_norm=True, out_indices=(0, 1, 2, 3), use_checkpoint=False,
+                                         num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=a)
+        model = LAVTVideo(b3, SimpleDecoding(256, a), a)
+        text = {k: v.clone() for k, v in model.text_encoder.state_dict().items()}
+        fill_state_dict_(model.backbone)            # keys as in the fixture's model: 'backbone.*' / 'classifier.*'
+        with torch.no_grad():
+            from lavt_hip.detweights import det_tensor
+            for k, t in model.state_dict().items():
+                if not k.startswith("text_encoder.") and not k.endswith("relative_position_index"):
+                    t.copy_(det_tensor(k, t.shape, t.dtype))
+        getattr(model, method)(path)
+        sd = model.state_dict()
+        keys = [k for k in g.files if k.startswith(method + "|")]
+        assert len(keys) == 9
+        for k in keys:
+            assert np.array_equal(sd[k.split("|")[1]].numpy(), g[k]), k
+        assert all(torch.equal(v, model.text_encoder.state_dict()[k]) for k, v in text.items())          # the text encoder is untouched
 
 
 def test_init_weights_loads_a_checkpoint_path(tmp_path):
