@@ -137,6 +137,17 @@ def profile_step(step, cfg, device, reps=3):
                 s_ = scopes.setdefault(sc, [0.0, 0.0])
                 s_[0] += us
                 s_[1] += fl
+    dump = os.environ.get("LAVT_PROFILE_DUMP")
+    if dump:          # every (entry point, shape, scope) family of the last eager step, for tools / profiles
+        by = {}
+        for name, sc, note, us in recs:
+            k = (name, note["shape"] if note else "", sc)
+            e = by.setdefault(k, [0, 0.0])
+            e[0] += 1
+            e[1] += us
+        with open(dump, "w") as f:
+            for (name, shape, sc), (n, us) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{us:9.1f} us  {n:4d} x {us / n:7.1f}  {sc:8s} {name} {shape}\n")
     total_us = sum(f[1] for f in fams.values()) / reps
     top = sorted(fams.items(), key=lambda kv: -kv[1][1])
     table = [{"entry": k[0], "shape": k[1], "launches_per_step": round(v[0] / reps, 1), "us_per_step": round(v[1] / reps, 1),

@@ -738,64 +738,102 @@ def combine_rank_stats(allst: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
     return torch.stack([tot, m2])
 
 
+def syncbn_exchange_forward(s: torch.Tensor, rows: int, group):
+    """SyncBatchNorm forward exchange (train.py:589 semantics): `s` [2, 1, C] = this rank's (sum x, centred second moment) over its `rows` rows.
+    ONE collective gathers every rank's pair; the pairs are combined locally (Chan et al.; equal row counts per rank, as DistributedSampler with
+    drop_last gives).  -> (statistics of the global batch [2, 1, C], global row count)"""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    flat = torch.empty(world * s.numel(), dtype=torch.float32, device=s.device)          # flat in / flat out: the layout every backend accepts
+    dist.all_gather_into_tensor(flat, s.contiguous().view(-1), group=group)
+    return combine_rank_stats(flat.view((world,) + tuple(s.shape)), rows), float(rows * world)
+
+
+def syncbn_exchange_backward(s: torch.Tensor, group):
+    """SyncBatchNorm backward exchange: `s` [2, C] = this rank's (sum dy, sum dy * xhat); summed over the ranks in place (one all-reduce)"""
+    import torch.distributed as dist
+    dist.all_reduce(s, group=group)
+    return s
+
+
+class _HipBnKernels:
+    """The local passes of BatchNorm + ReLU on NHWC rows (csrc/norm.hip).  _BatchNormRelu talks to them through this small interface so that the
+    multi-rank protocol around them (what is exchanged, when, with which counts) can be driven by a CPU stand-in in the gloo tests."""
+
+    @staticmethod
+    def stats(x):
+        return _stats(x, 1, x.shape[0], x.shape[1])                      # [2, 1, C]: sum, centred second moment of the local rows
+
+    @staticmethod
+    def finalize(s, count, eps, running_mean, running_var, momentum):
+        Cc = s.shape[-1]
+        mean = torch.empty(Cc, dtype=torch.float32, device=s.device)
+        rstd = torch.empty_like(mean)
+        K.check(K.lib.lavt_stats_finalize(K.ptr(s[0]), K.ptr(s[1]), count, eps, K.ptr(mean), K.ptr(rstd), K.ptr(running_mean), K.ptr(running_var),
+                                          momentum, Cc, K.stream()))
+        return mean, rstd
+
+    @staticmethod
+    def apply(x, mean, rstd, gamma, beta):
+        y = torch.empty_like(x)
+        K.check(K.lib.lavt_norm_apply(K.dt(x.dtype), K.ptr(x), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), None, 1,
+                                      K.ptr(y), 1, x.shape[0], x.shape[1], K.stream()))
+        return y
+
+    @staticmethod
+    def bwd_stats(dy, x, y, mean, rstd, gamma, beta):
+        R, Cc = x.shape
+        s = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)
+        ws = _scratch(1025 * 2 * Cc, x.device)
+        K.check(K.lib.lavt_norm_bwd_stats(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(y), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)),
+                                          None, 1, K.ptr(s[0]), K.ptr(s[1]), K.ptr(ws), ws.numel(), 1, R, Cc, K.stream()))
+        return s
+
+    @staticmethod
+    def bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count):
+        R, Cc = x.shape
+        dx = torch.empty_like(x)
+        K.check(K.lib.lavt_norm_bwd_apply(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(y), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)),
+                                          None, 1, K.ptr(s[0]), K.ptr(s[1]), count, K.ptr(dx), None, 1, R, Cc, K.stream()))
+        return dx
+
+
 @K.scoped
 class _BatchNormRelu(torch.autograd.Function):
-    """BatchNorm2d + ReLU on NHWC rows [R, C].  training: batch statistics (all-reduced over `group` when given =
+    """BatchNorm2d + ReLU on NHWC rows [R, C].  training: batch statistics (exchanged over `group` when given =
     SyncBatchNorm semantics, train.py:589), running stats updated in place; eval: running statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, group):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, group, kern):
         x = x.contiguous()
         R, Cc = x.shape
-        dev = x.device
-        mean = torch.empty(Cc, dtype=torch.float32, device=dev)
-        rstd = torch.empty_like(mean)
         count = float(R)
         if training:
-            s = _stats(x, 1, R, Cc)                          # [sum x, centred second moment] of the local rows
+            s = kern.stats(x)                                # [sum x, centred second moment] of the local rows
             if group is not None:
-                # ONE collective: gather every rank's (sum, centred M2) and combine them locally (Chan et al.): with equal row counts
-                # per rank, sum = sum_r sum_r and M2 = sum_r M2_r + R * sum_r (mean_r - mean)^2
-                import torch.distributed as dist
-                world = dist.get_world_size(group)
-                allst = torch.empty(world, 2, 1, Cc, dtype=torch.float32, device=dev)
-                dist.all_gather_into_tensor(allst, s.contiguous(), group=group)
-                count = float(R * world)
-                s = combine_rank_stats(allst, R)
-            K.check(K.lib.lavt_stats_finalize(K.ptr(s[0]), K.ptr(s[1]), count, eps, K.ptr(mean), K.ptr(rstd), K.ptr(running_mean),
-                                              K.ptr(running_var), momentum, Cc, K.stream()))
+                s, count = syncbn_exchange_forward(s, R, group)
+            mean, rstd = kern.finalize(s.view(2, Cc), count, eps, running_mean, running_var, momentum)
         else:
             # eval: mean = running_mean, var = running_var  (sum = mean, m2 = var, count = 1)
-            s = torch.stack([running_mean, running_var])
-            K.check(K.lib.lavt_stats_finalize(K.ptr(s[0]), K.ptr(s[1]), 1.0, eps, K.ptr(mean), K.ptr(rstd), None, None, 0.0, Cc, K.stream()))
-        y = torch.empty_like(x)
-        K.check(K.lib.lavt_norm_apply(K.dt(x.dtype), K.ptr(x), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), None, 1,
-                                      K.ptr(y), 1, R, Cc, K.stream()))
+            mean, rstd = kern.finalize(torch.stack([running_mean, running_var]), 1.0, eps, None, None, 0.0)
+        y = kern.apply(x, mean, rstd, gamma, beta)
         ctx.save_for_backward(x, y, gamma, beta, mean, rstd)
-        ctx.cfg = (training, count, group)
+        ctx.cfg = (training, count, group, kern)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, gamma, beta, mean, rstd = ctx.saved_tensors
-        training, count, group = ctx.cfg
-        R, Cc = x.shape
+        training, count, group, kern = ctx.cfg
         dy = dy.contiguous()
-        d = K.dt(x.dtype)
-        s = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)
-        ws = _scratch(1025 * 2 * Cc, x.device)
-        K.check(K.lib.lavt_norm_bwd_stats(d, K.ptr(dy), K.ptr(x), K.ptr(y), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)),
-                                          None, 1, K.ptr(s[0]), K.ptr(s[1]), K.ptr(ws), ws.numel(), 1, R, Cc, K.stream()))
+        s = kern.bwd_stats(dy, x, y, mean, rstd, gamma, beta)
         dgamma, dbeta = s[1].clone(), s[0].clone()          # local sums: DDP averages parameter grads later
         if not training:
             s.zero_()                                       # running statistics are constants: no batch terms
         elif group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(s, group=group)
-        dx = torch.empty_like(x)
-        K.check(K.lib.lavt_norm_bwd_apply(d, K.ptr(dy), K.ptr(x), K.ptr(y), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)),
-                                          None, 1, K.ptr(s[0]), K.ptr(s[1]), count, K.ptr(dx), None, 1, R, Cc, K.stream()))
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+            syncbn_exchange_backward(s, group)
+        dx = kern.bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def batch_norm_relu(x, bn: torch.nn.modules.batchnorm._BatchNorm):
@@ -812,7 +850,7 @@ def batch_norm_relu(x, bn: torch.nn.modules.batchnorm._BatchNorm):
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return _BatchNormRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                                bn.momentum if bn.momentum is not None else 0.1, bn.eps, group)
+                                bn.momentum if bn.momentum is not None else 0.1, bn.eps, group, _HipBnKernels)
 
 
 # ------------------------------------------------------------------------------------------ language gate

@@ -74,3 +74,176 @@ def test_grad_buckets_world2(bucket_mib):
         out = mgr.dict()
         mp.spawn(_worker, args=(2, port, bucket_mib, out), nprocs=2, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+# ------------------------------------------------------------------------------------------------ SyncBN protocol, two real processes
+class _CpuBnKernels:
+    """CPU stand-in for the local BatchNorm + ReLU passes of csrc/norm.hip (same interface as lavt_hip.ops._HipBnKernels, same definitions:
+    sum / centred second moment, biased variance for normalisation and unbiased for the running estimate, ReLU mask from the saved output)."""
+
+    @staticmethod
+    def stats(x):
+        return torch.stack([x.sum(0), ((x - x.mean(0)) ** 2).sum(0)]).view(2, 1, -1)
+
+    @staticmethod
+    def finalize(s, count, eps, running_mean, running_var, momentum):
+        mean, var = s[0] / count, s[1] / count
+        if running_mean is not None:
+            running_mean.mul_(1 - momentum).add_(momentum * mean)
+            running_var.mul_(1 - momentum).add_(momentum * var * (count / max(count - 1.0, 1.0)))
+        return mean, torch.rsqrt(var + eps)
+
+    @staticmethod
+    def apply(x, mean, rstd, gamma, beta):
+        return torch.relu((x - mean) * rstd * gamma + beta)
+
+    @staticmethod
+    def bwd_stats(dy, x, y, mean, rstd, gamma, beta):
+        g = dy * (y > 0)
+        return torch.stack([g.sum(0), (g * (x - mean) * rstd).sum(0)])
+
+    @staticmethod
+    def bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count):
+        g = dy * (y > 0)
+        xh = (x - mean) * rstd
+        return gamma * rstd * (g - s[0] / count - xh * s[1] / count)
+
+
+def _syncbn_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lavt_hip import ops
+    R, C = 37, 6
+    g = torch.Generator().manual_seed(5)
+    x_all = torch.randn(world * R, C, generator=g, dtype=torch.float64) * 0.5 + 3.0 * torch.arange(1, C + 1)        # large means: no E[x^2]-E[x]^2
+    dy_all = torch.randn(world * R, C, generator=g, dtype=torch.float64)
+    gamma = (1.0 + 0.1 * torch.randn(C, generator=g, dtype=torch.float64))
+    beta = 0.1 * torch.randn(C, generator=g, dtype=torch.float64)
+    # this rank's shard through the product's autograd Function: real all_gather_into_tensor / all_reduce between the two processes
+    x = x_all[rank * R:(rank + 1) * R].clone().float().requires_grad_(True)
+    gm, bt = gamma.float().requires_grad_(True), beta.float().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = ops._BatchNormRelu.apply(x, gm, bt, rm, rv, True, 0.1, 1e-5, dist.group.WORLD, _CpuBnKernels)
+    y.backward(dy_all[rank * R:(rank + 1) * R].float())
+    # single-process BatchNorm over the concatenated batch (float64)
+    bn = nn.BatchNorm1d(C, eps=1e-5, momentum=0.1).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    xr = x_all.clone().requires_grad_(True)
+    yr = torch.relu(bn(xr))
+    yr.backward(dy_all)
+    sl = slice(rank * R, (rank + 1) * R)
+    assert torch.allclose(y.detach().double(), yr[sl].detach(), atol=2e-5), "forward"
+    assert torch.allclose(rm.double(), bn.running_mean, atol=1e-5) and torch.allclose(rv.double(), bn.running_var, atol=1e-5), "running statistics"
+    assert torch.allclose(x.grad.double(), xr.grad[sl], atol=2e-5), "dx"
+    # parameter gradients stay local sums (DDP averages them afterwards): their sum over the ranks is the single-process gradient
+    tot = torch.stack([gm.grad, bt.grad])
+    dist.all_reduce(tot)
+    assert torch.allclose(tot[0].double(), bn.weight.grad, atol=1e-4) and torch.allclose(tot[1].double(), bn.bias.grad, atol=1e-4), "dgamma / dbeta"
+    # eval mode never communicates and uses the running estimates
+    ye = ops._BatchNormRelu.apply(x.detach(), gm.detach(), bt.detach(), rm, rv, False, 0.1, 1e-5, None, _CpuBnKernels)
+    assert torch.allclose(ye.double(), torch.relu(bn.eval()(x_all[sl])).detach(), atol=2e-5)
+    out[rank] = True
+    dist.destroy_process_group()
+
+
+def test_syncbn_exchange_world2():
+    """lavt_hip.ops._BatchNormRelu with a process group: statistics exchanged with ONE all_gather_into_tensor forward and ONE all_reduce backward
+    between two processes == BatchNorm over the concatenated batch (output, running statistics, dx, dgamma / dbeta); local passes on CPU."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_syncbn_worker, args=(2, port, out), nprocs=2, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
+# ------------------------------------------------------------------------------------------------ fused-accumulation bucket protocol, two processes
+class _FusedLinear(torch.autograd.Function):
+    """What lavt_hip.ops._Linear does to its weight gradient under the step harness, with the GEMMs in torch: the gradient is written straight into
+    the sink (a view of GradBuckets.flat), the Function returns None for it, and -- for `defer` -- the write happens later, at the grouped launch."""
+
+    @staticmethod
+    def forward(ctx, x, w, defer, queue):
+        ctx.save_for_backward(x, w)
+        ctx.defer, ctx.queue = defer, queue
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from lavt_hip import ops
+        x, w = ctx.saved_tensors
+        wbuf, is_sink = ops.sinks.buf(w, tuple(w.shape))
+        assert is_sink
+        if ctx.defer:
+            ctx.queue.append((wbuf, dy.t() @ x))        # the grouped kernel does not exist yet: PyTorch will still fire w's hook right now
+            ops.wgrads.notify(w)
+            dw = None
+        else:
+            wbuf.copy_(dy.t() @ x)
+            dw = ops.sinks.done(w, wbuf, True)
+        return dy @ w, dw, None, None
+
+
+def _fused_worker(rank, world, port, bucket_mib, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lavt_hip import ops
+    from lavt_hip.ddp import GradBuckets
+    torch.manual_seed(0)
+    ws = nn.ParameterList([nn.Parameter(torch.randn(8, 8) * 0.3) for _ in range(6)])
+    unused = nn.Parameter(torch.randn(8, 8))
+    holder = nn.Module()
+    holder.ws, holder.unused = ws, unused
+    gb = GradBuckets(holder, bucket_mib=bucket_mib, fused_accumulation=True)
+    xs = [torch.randn(5, 8, generator=torch.Generator().manual_seed(20 + r)) for r in range(world)]
+    try:
+        for step in range(2):
+            gb.zero()
+            queue = []
+            h = xs[rank]
+            for i, w in enumerate(ws):
+                h = torch.tanh(_FusedLinear.apply(h, w, i % 2 == 1, queue))     # odd layers: weight gradient deferred to a grouped launch
+            loss = h.pow(2).mean()
+            flushed = []
+
+            def flush():                         # the grouped launch: writes the queued gradients, THEN reports their parameters ready
+                for buf, val in queue:
+                    buf.copy_(val)
+                flushed.append(len(queue))
+                queue.clear()
+                ops.wgrads.flush()
+            # backward with a flush every time two gradients are queued (the Swin block's grouped launch), and a final one
+            hooks = []
+            loss.backward()
+            flush()
+            gb.finish()
+        grads = []
+        for r in range(world):
+            ref = [w.detach().clone().requires_grad_(True) for w in ws]
+            h = xs[r]
+            for w in ref:
+                h = torch.tanh(h @ w.t())
+            h.pow(2).mean().backward()
+            grads.append([w.grad for w in ref])
+        for i, w in enumerate(ws):
+            want = sum(g[i] for g in grads) / world
+            assert torch.allclose(w.grad, want, atol=1e-6), f"weight {i} (deferred: {i % 2 == 1})"
+        assert float(unused.grad.abs().max()) == 0.0
+        out[rank] = True
+    finally:
+        ops.sinks.clear()
+        ops.wgrads.ready, ops.wgrads.pending = [], set()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_mib", [64.0, 0.0003])
+def test_fused_accumulation_buckets_world2(bucket_mib):
+    """TrainStep's gradient protocol between two processes: gradients written into the flat buffer by the ops themselves (no AccumulateGrad),
+    half of them deferred to a later 'grouped launch' while PyTorch fires their hooks early, buckets all-reduced when complete, a parameter that
+    never gets a gradient -- and after finish() every .grad is the mean over the ranks."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_fused_worker, args=(2, port, bucket_mib, out), nprocs=2, join=True)
+        assert dict(out) == {0: True, 1: True}
