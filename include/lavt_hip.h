@@ -102,6 +102,13 @@ typedef struct lavt_gemm_nt {
      * (batch, conv_d, conv_h, conv_w) grid and the taps run over conv_kd x conv_kh x conv_kw (each 1 or 3, 'same' zero padding), kw fastest.
      * All zero = the 2-D default (conv_d = 1, taps 1 x 3 x 3). */
     int32_t conv_d, conv_kd, conv_kh, conv_kw;
+    /* Fused activation gradient (ABI v2): when dact_pre != NULL the stored value is C * act'(dact_pre[row][n]) with act = dact (LAVT_ACT_*):
+     * the data gradient of the layer AFTER an activation leaves as the gradient w.r.t. the pre-activation (fc2's dgrad of a Swin Mlp applies
+     * GELU' of fc1's saved pre-activation, reference lib/backbone.py:24-30 under autograd), so no separate element-wise pass exists.
+     * bf16, b_kmajor, no conv taps, K % 64 == 0, lddact % 8 == 0 only (LAVT_ERR_INVALID otherwise: the caller keeps the two-kernel form). */
+    const void* dact_pre;
+    int64_t lddact;
+    int32_t dact;
 } lavt_gemm_nt_t;
 
 int lavt_gemm_nt(const lavt_gemm_nt_t* p, void* stream);

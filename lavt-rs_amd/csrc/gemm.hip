@@ -439,6 +439,7 @@ extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
     { const char* e = getenv("LAVT_GEMM_EPI"); p.epi_lds = (e && e[0] == 'l') ? 1 : 0; }
     const int rc2 = lavt_gemm_nt_v2(p, st);          // bf16 LDS-DMA pipeline (gemm_v2.hip); 1 = not applicable
     if (rc2 != 1) return rc2;
+    LAVT_CHECK_ARG(p.dact_pre == nullptr, "lavt_gemm_nt: dact_pre (fused activation gradient) exists on the bf16 LDS-DMA path only");
     return p.dtype == LAVT_F32 ? dispatch_nt<float>(p, st) : dispatch_nt<bf16>(p, st);
 }
 

@@ -114,7 +114,15 @@ __device__ __forceinline__ int xcd_tile_id(int b, int nb) {
 }
 
 // ---- NT epilogue shared by both generations: accumulators hold C^T tiles (rows = 4 consecutive n per lane, column = m) ----
-template <typename T, int MI, int NI>
+__device__ __forceinline__ float act_grad(int act, float pre) {
+    switch (act) {
+        case LAVT_ACT_GELU: return gelu_grad_f(pre);
+        case LAVT_ACT_RELU: return pre > 0.f ? 1.f : 0.f;
+        case LAVT_ACT_TANH: { const float t = tanhf(pre); return 1.f - t * t; }
+        default: return 1.f;
+    }
+}
+template <typename T, int MI, int NI, bool DACT = false>
 __device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz) {
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
     const float* rscale = p.row_scale ? p.row_scale + (int64_t)bz * p.strideRowScale : nullptr;
@@ -138,6 +146,11 @@ __device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc
                 v[r] *= rs;
             }
             const bool full = (n + 3 < p.N);
+            if constexpr (DACT) {          // gradient w.r.t. the pre-activation of the producing layer: v *= act'(pre[orow][n..n+3])
+                const T* dp = reinterpret_cast<const T*>(p.dact_pre) + (int64_t)orow * p.lddact + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] *= act_grad(p.dact, to_f<T>(dp[r]));
+            }
             if (p.Cpre) {
                 T* cp = reinterpret_cast<T*>(p.Cpre) + (int64_t)orow * p.ldcpre + n;
                 if (full) {

@@ -115,7 +115,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // MODE 2 = convolution taps with Cin (and the concat split) a multiple of the 64-wide K tile: the tap of a K tile is wave-uniform and walks
 // forward with the K loop (no division), the lanes' voxel coordinates are computed once, so a neighbour fetch is three range checks and one
 // address add.  MODE 0 (anything else) decodes every K tile from scratch.
-template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE>
+template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_nt_t p) {
     constexpr bool SIMPLE = MODE == 1, CONVFAST = MODE == 2;
     using T = bf16;
@@ -383,26 +383,38 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = mfma16<T>(fb[ks][j], fa[ks][i], acc[i][j]);
     }
+    if constexpr (DACT) { nt_epilogue<T, MI, NI, true>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz); return; }
     if (!p.epi_lds || p.c_f32 || (p.ldc % 8) || (p.C2 && (p.ldc2 % 8 || p.c_split % 8)) || (p.R && p.ldr % 8) || (p.Cpre && p.ldcpre % 8))
         nt_epilogue<T, MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
     else
         nt_epilogue_lds<BM, BN, MI, NI>(p, acc, reinterpret_cast<bf16*>(smem), m0, n0, wm * WM, wn * WN, tid, lane, bz);
 }
 
-template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE> int launch_nt_v2_(const lavt_gemm_nt_t& p, hipStream_t st) {
+template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false> int launch_nt_v2_(const lavt_gemm_nt_t& p, hipStream_t st) {
     constexpr size_t lds = STAGES * (size_t)(BM * 128 + BN * 128);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             lavt_set_error("lavt_gemm_nt(v2): cannot reserve %zu bytes of LDS", lds);
             return LAVT_ERR_LAUNCH;
         }
         attr_set = true;
     }
     dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch);
-    hipLaunchKernelGGL((gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE>), grid, dim3(WAVES * 64), lds, st, p);
+    hipLaunchKernelGGL((gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT>), grid, dim3(WAVES * 64), lds, st, p);
     LAVT_CHECK_LAUNCH("lavt_gemm_nt(v2)");
     return LAVT_OK;
+}
+// Fused activation-gradient epilogue (dact_pre): data gradients only (k-major B, plain K walk); the flag is a template parameter so that no
+// other instantiation pays its registers (as a run-time branch in every kernel it cost 12 VGPRs and 0.25 ms per step in round 1).
+int launch_nt_v2_dact(const lavt_gemm_nt_t& p, hipStream_t st) {
+    if (!p.b_kmajor || p.conv_kc > 0 || p.A2 || p.K % 64 || p.lddact % 8 || p.c_f32 || p.C2 || p.Cpre || p.R || p.act) {
+        lavt_set_error("lavt_gemm_nt: dact_pre needs a plain k-major data-gradient problem (no taps / concat / residual / activation, K %% 64 == 0)");
+        return LAVT_ERR_INVALID;
+    }
+    const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch, tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;
+    if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_<128, 128, true, 2, 8, 1, true>(p, st) : launch_nt_v2_<128, 128, true, 4, 8, 1, true>(p, st);
+    return tiles64 >= 600 ? launch_nt_v2_<64, 64, true, 2, 4, 1, true>(p, st) : launch_nt_v2_<64, 64, true, 4, 4, 1, true>(p, st);
 }
 template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     static const bool general_only = getenv("LAVT_GEMM_GENERAL") != nullptr;
@@ -737,6 +749,7 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     const char* e = getenv("LAVT_GEMM_V2");
     if (e && e[0] == '0') return 1;
     if (p.lda % 8 || p.ldb % 8 || (p.A2 && p.lda2 % 8)) return 1;
+    if (p.dact_pre) return launch_nt_v2_dact(p, st);
     // Dispatch measured on MI355X (tools/gemm_bench.py, hipGraph-timed): 128x128 tile with 8 waves (2 per SIMD: one wave's DMA issue and
     // LDS reads hide under the other's MFMAs) and a 2-stage ring (64-80 KiB -> 2 workgroups per CU) once there are >= 200 such tiles;
     // otherwise 64x64 tiles / 4 waves (5 workgroups per CU), 3 stages only for long-K problems with few tiles.

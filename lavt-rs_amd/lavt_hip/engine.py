@@ -3,7 +3,10 @@
     zero grads -> out = model(image, l, l_mask) -> F.cross_entropy(out, target, weight=[0.9, 1.1]) -> backward
     -> gradient all-reduce (world > 1)
 
-The whole step is ~2,000 kernel launches for Swin-B; issued from Python it is launch-bound, so on one GPU the
+Gradient accumulation over micro-batches is not supported by this harness (every parameter receives exactly one weight gradient per
+step into a buffer zeroed at the start of the step; lavt_hip.ops.sinks refuses a second one).
+
+The whole step is ~1,000 kernel launches for Swin-B; issued from Python it is launch-bound, so on one GPU the
 step is captured once into a hipGraph (torch.cuda.CUDAGraph on the stream our C-ABI launches go to) and
 replayed: weight casts, DropPath masks, BatchNorm running-stat updates all happen inside the graph.
 With world > 1 the same capture includes the collectives: the SyncBN statistic all-reduces on the capture stream and the
@@ -25,7 +28,7 @@ from .runtime import compute_dtype
 
 
 class TrainStep:
-    def __init__(self, model, image, l_feats, l_mask, target, world=1, use_graph=True, bucket_mib=32.0, fused_loss=True):
+    def __init__(self, model, image, l_feats, l_mask, target, world=1, use_graph=True, bucket_mib=32.0, fused_loss=True, refresh_weights_in_step=False):
         self.model = model
         dev = image.device
         self.x, self.l, self.m, self.t = image, l_feats, l_mask, target
@@ -42,9 +45,14 @@ class TrainStep:
         ops.wgrads.enabled = True                # one weight gradient per parameter per step into the zeroed flat buffer: grouped, plainly stored
         self.fused_loss = fused_loss and hasattr(model, "forward_lowres")
         self.stats = None                        # fused loss: [loss, sum of weights, I, U] of the last step (device tensor)
+        # The compute-dtype weight copies are refreshed by the optimizer (FusedAdamW.step re-casts them right after the update).  Set this when
+        # the weights are changed by something else between replays of the captured step (a torch.optim optimizer, manual edits): the casts
+        # (~0.3 ms for Swin-B) then run at the start of every step, inside the graph.
+        self.refresh_in_step = refresh_weights_in_step or os.environ.get("LAVT_REFRESH_IN_STEP", "0") == "1"
 
     def _body(self):
-        ops.weights.refresh_all()                # re-cast weights inside the step (they change every optimizer step)
+        if self.refresh_in_step:
+            ops.weights.refresh_all()            # re-cast weights inside the step (for optimizers that do not maintain the compute copies)
         self.buckets.zero()
         if self.fused_loss:                       # upsample + weighted CE (+ I/U) fused: the (B,2,H,W) logits are never written
             from lib._utils import fused_loss
@@ -62,11 +70,13 @@ class TrainStep:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(eager_iters):
+            for it in range(eager_iters):
                 self.loss = self._body()
+                if it == 0:                      # every compute copy exists now: one descriptor table for the one-launch refresh
+                    ops.weights.build_multicast(compute_dtype())
+                    ops.weights.refresh_all()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        ops.weights.build_multicast(compute_dtype())
         if not self.use_graph:
             return
         try:

@@ -245,7 +245,7 @@ def _zero_page(device):
 def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, strideB=0, strideC=0, A2=None, lda2=0,
             a_split=0, a_rowmap=None, conv=None, b_kmajor=False, b_tap_stride=0, alpha=1.0, bias=None, strideBias=0,
             row_scale=None, strideRowScale=0, row_scale_div=1, act=K.ACT_NONE, Cpre=None, ldcpre=0, R=None, ldr=0, C2=None, ldc2=0,
-            c_split=0, c_rowmap=None, c_f32=False, a_off=0, b_off=0, c_off=0):
+            c_split=0, c_rowmap=None, c_f32=False, a_off=0, b_off=0, c_off=0, dact_pre=None, lddact=0, dact=K.ACT_NONE):
     """A/B/Cout are tensors; *_off are element offsets into them (column sub-blocks)."""
     es = 4 if dtype == torch.float32 else 2
     p = K.GemmNT()
@@ -265,6 +265,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.C2, p.ldc2, p.c_split = K.ptr(C2), ldc2, c_split
     p.c_rowmap, p.c_f32 = K.ptr(c_rowmap), int(c_f32)
     p.zeros = _zero_page(A.device)
+    p.dact_pre, p.lddact, p.dact = K.ptr(dact_pre), lddact, dact
     if K.prof.enabled:
         K.prof.note = {"flops": 2.0 * M * N * Kd * batch, "shape": f"nt {M}x{N}x{Kd}" + (f" b{batch}" if batch > 1 else "") + (" conv" if conv is not None else "")
                        + (" kmajor" if b_kmajor else "")}
@@ -335,7 +336,11 @@ class _WgradQueue:
                 fl = [2.0 * q.I * q.J * q.K for q in self.items]
                 K.prof.note = {"flops": sum(fl), "shape": "tn-grouped " + "+".join(f"{q.I}x{q.J}x{q.K}" for q in self.items),
                                "members": list(zip(self.scopes, fl))}
-            K.check(K.lib.lavt_gemm_tn_grouped(arr, len(self.items), K.stream()))
+            n_items = len(self.items)
+            tensors = [t for tup in self.keep for t in tup if t is not None]
+            # the grouped launch is off the critical path of backward (only the optimizer / all-reduce consumes it): on a side stream it overlaps
+            # the latency-bound data-gradient chain of the next block (LAVT_SIDE_STREAMS=1)
+            side.run(lambda: K.check(K.lib.lavt_gemm_tn_grouped(arr, n_items, K.stream())), tensors, True)
         ready = self.ready
         self.items, self.keep, self.ready, self.scopes = [], [], [], []
         for prm in ready:
@@ -498,6 +503,81 @@ def linear_cat(x, layers):
 
 def linear(x, weight, bias=None, residual=None, **kw):
     return _Linear.apply(x, weight, bias, residual, LinOpts(**kw))
+
+
+@K.scoped
+class _Mlp(torch.autograd.Function):
+    """y = fc2(GELU(fc1(x))) * row_scale + residual (Swin Mlp, reference lib/backbone.py:24-30, with the block's DropPath and residual folded in)
+    as ONE autograd node, so that backward can hand the gradient through the activation inside a GEMM: fc2's data-gradient GEMM applies
+    GELU'(pre) in its epilogue (lavt_gemm_nt dact_pre) and directly produces d/d pre -- no element-wise GELU-backward pass, no extra [M, 4C]
+    round trip.  bf16 only (the exact-fp32 path keeps the two-op form)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, o: LinOpts):
+        x = x.contiguous()
+        dtype = x.dtype
+        W1, W2 = weights.get(w1, dtype, "lin"), weights.get(w2, dtype, "lin")
+        Hd, Cin = W1.shape
+        Cout = W2.shape[0]
+        M = x.shape[0]
+        pre = torch.empty(M, Hd, dtype=dtype, device=x.device)
+        h = torch.empty_like(pre)
+        gemm_nt(dtype, M, Hd, Cin, x, Cin, W1, Cin, h, Hd, bias=_f32(b1), act=K.ACT_GELU, Cpre=pre, ldcpre=Hd)
+        y = torch.empty(M, Cout, dtype=dtype, device=x.device)
+        if residual is not None:
+            residual = residual.contiguous()
+        gemm_nt(dtype, M, Cout, Hd, h, Hd, W2, Hd, y, Cout, bias=_f32(b2), row_scale=o.row_scale, row_scale_div=o.row_scale_div, R=residual, ldr=Cout)
+        ctx.save_for_backward(x, w1, b1, w2, b2, pre, h)
+        ctx.o, ctx.has_res = o, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2, b2, pre, h = ctx.saved_tensors
+        o = ctx.o
+        dtype = x.dtype
+        dy = dy.contiguous()
+        W1, W2 = weights.get(w1, dtype, "lin"), weights.get(w2, dtype, "lin")
+        Hd, Cin = W1.shape
+        Cout = W2.shape[0]
+        M = x.shape[0]
+        # d pre = ((dy * row_scale) W2) * GELU'(pre): the activation gradient rides in the data-gradient GEMM's epilogue
+        dpre = torch.empty_like(pre)
+        gemm_nt(dtype, M, Hd, Cout, dy, Cout, W2, Hd, dpre, Hd, b_kmajor=True, row_scale=o.row_scale, row_scale_div=o.row_scale_div,
+                dact_pre=pre, lddact=Hd, dact=K.ACT_GELU)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm_nt(dtype, M, Cin, Hd, dpre, Hd, W1, Cin, dx, Cin, b_kmajor=True)
+        binary = o.row_scale is not None and o.row_scale_value != 0.0
+        grads = []
+        for (w, b, g, inp, n, kd, rs) in ((w2, b2, dy, h, Cout, Hd, True), (w1, b1, dpre, x, Hd, Cin, False)):
+            wbuf, wsink = sinks.buf(w, (n, kd))
+            bbuf, bsink = sinks.buf(b, (n,)) if b is not None else (None, True)
+            kw = dict(a_rowscale=o.row_scale, a_rowscale_div=o.row_scale_div, a_rowscale_binary=binary, alpha=o.row_scale_value if binary else 1.0) if rs and o.row_scale is not None else {}
+            if wgrads.active() and wsink and bsink and (not kw or binary):
+                gemm_tn(dtype, n, kd, M, g, n, inp, kd, wbuf, kd, colsum=bbuf, defer=wgrads, **kw)
+                wgrads.notify(w)
+                if b is not None:
+                    wgrads.notify(b)
+                grads += [None, None]
+            else:
+                side.run(lambda: gemm_tn(dtype, n, kd, M, g, n, inp, kd, wbuf, kd, colsum=bbuf, **kw), (g, inp), wsink and bsink)
+                grads += [sinks.done(w, wbuf, wsink), sinks.done(b, bbuf, bsink) if b is not None else None]
+        dw2, db2, dw1, db1 = grads
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res and ctx.needs_input_grad[5] else None), None
+
+
+def mlp(x, w1, b1, w2, b2, residual=None, **kw):
+    """fc2(GELU(fc1(x))) [* row_scale] [+ residual]; the fused single-node form on the bf16 path, two `linear` ops otherwise"""
+    o = LinOpts(**kw)
+    # Measured on MI355X (Swin-B 2x480x480 step, same box, two repeats): 12.59 / 12.58 ms with the fused node vs 12.51 / 12.53 ms without -- the
+    # erf-based GELU' and the 8-byte scattered reads of `pre` in the data-gradient epilogue cost as much as the element-wise pass they replace.
+    # Off by default; LAVT_FUSED_MLP=1 selects it.
+    if x.dtype == torch.bfloat16 and w1.shape[1] % 8 == 0 and w1.shape[0] % 64 == 0 and w2.shape[0] % 64 == 0 and os.environ.get("LAVT_FUSED_MLP", "0") == "1":
+        return _Mlp.apply(x, w1, b1, w2, b2, residual, o)
+    h = linear(x, w1, b1, act=K.ACT_GELU)
+    return linear(h, w2, b2, residual=residual, **kw)
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
@@ -781,13 +861,16 @@ class _HipBnKernels:
         return y
 
     @staticmethod
-    def bwd_stats(dy, x, y, mean, rstd, gamma, beta):
+    def bwd_stats(dy, x, y, mean, rstd, gamma, beta, out=None):
+        """-> (sum dy', sum dy' * xhat) as two [C] fp32 tensors; `out` = two zeroed buffers to accumulate into (the parameters' gradient sinks)"""
         R, Cc = x.shape
-        s = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)
+        if out is None:
+            s = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)
+            out = (s[0], s[1])
         ws = _scratch(1025 * 2 * Cc, x.device)
         K.check(K.lib.lavt_norm_bwd_stats(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(y), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)),
-                                          None, 1, K.ptr(s[0]), K.ptr(s[1]), K.ptr(ws), ws.numel(), 1, R, Cc, K.stream()))
-        return s
+                                          None, 1, K.ptr(out[0]), K.ptr(out[1]), K.ptr(ws), ws.numel(), 1, R, Cc, K.stream()))
+        return out
 
     @staticmethod
     def bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count):
@@ -826,7 +909,16 @@ class _BatchNormRelu(torch.autograd.Function):
         x, y, gamma, beta, mean, rstd = ctx.saved_tensors
         training, count, group, kern = ctx.cfg
         dy = dy.contiguous()
-        s = kern.bwd_stats(dy, x, y, mean, rstd, gamma, beta)
+        if training and group is None and kern is _HipBnKernels:
+            # single rank: the two sums ARE d beta / d gamma -- accumulate them straight into the parameters' gradient sinks (when the step harness
+            # provides them) and let the apply pass read them from there: no clones, no AccumulateGrad adds
+            bbuf, bsink = sinks.buf(beta, (x.shape[1],))
+            gbuf, gsink = sinks.buf(gamma, (x.shape[1],))
+            s = kern.bwd_stats(dy, x, y, mean, rstd, gamma, beta, out=(bbuf, gbuf))
+            dx = kern.bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count)
+            return dx, sinks.done(gamma, gbuf, gsink), sinks.done(beta, bbuf, bsink), None, None, None, None, None, None, None
+        s0, s1 = kern.bwd_stats(dy, x, y, mean, rstd, gamma, beta)
+        s = torch.stack([s0, s1])
         dgamma, dbeta = s[1].clone(), s[0].clone()          # local sums: DDP averages parameter grads later
         if not training:
             s.zero_()                                       # running statistics are constants: no batch terms
@@ -1215,10 +1307,12 @@ class _ConvTaps(torch.autograd.Function):
         if bias is not None:
             db, bsink = sinks.buf(bias, (Cout,))
         # the GEMM writes [Cout][taps][Cin] (contiguous split-K atomics), a small kernel adds it into the [Cout][Cin][taps] gradient
-        packed = torch.zeros(Cout, taps * Cin, dtype=torch.float32, device=dy.device)
-        gemm_tn(dtype, Cout, taps * Cin, M, dy, Cout, x1, C1, packed, taps * Cin, B2=x2, ldb2=C2, b_split=C1,
-                conv=(H, W, Cin, D, kd, kh, kw), colsum=db)
-        K.check(K.lib.lavt_unpack_conv_grad(K.ptr(packed), K.ptr(dW), Cout, Cin, taps, K.stream()))
+        def _wgrad():
+            packed = torch.zeros(Cout, taps * Cin, dtype=torch.float32, device=dy.device)
+            gemm_tn(dtype, Cout, taps * Cin, M, dy, Cout, x1, C1, packed, taps * Cin, B2=x2, ldb2=C2, b_split=C1,
+                    conv=(H, W, Cin, D, kd, kh, kw), colsum=db)
+            K.check(K.lib.lavt_unpack_conv_grad(K.ptr(packed), K.ptr(dW), Cout, Cin, taps, K.stream()))
+        side.run(_wgrad, (dy, x1, x2), wsink and (db is None or bsink))
         return (dx1, dx2, sinks.done(weight, dW, wsink), sinks.done(bias, db, bsink) if bias is not None else None,
                 None, None, None, None, None)
 

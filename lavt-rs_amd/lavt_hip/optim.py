@@ -90,10 +90,12 @@ class FusedAdamW(torch.optim.Optimizer):
             self._build()
         _, desc, hyper, n = self._tables
         K.check(K.lib.lavt_adamw_step(K.ptr(desc), K.ptr(hyper), n, K.ptr(self._step), self.total_steps, self.power, K.stream()))
-        # the kernel writes the parameters through raw pointers: p._version does not move, so the cached compute copies (bf16 Linear weights,
-        # packed conv weights) must be declared stale here or the next forward would run on the old weights
+        # The kernel writes the parameters through raw pointers: p._version does not move, so the cached compute copies (bf16 Linear weights,
+        # packed conv weights) are stale now.  They are part of the optimizer's output (fp32 master weights + the compute-dtype copies the next
+        # forward reads, as in any mixed-precision trainer): re-cast them here, on the same stream, so that the forward/backward step itself
+        # carries no cast kernels (the step harness refreshes them only when asked to: TrainStep(refresh_weights_in_step=True)).
         from . import ops
-        ops.weights.invalidate()
+        ops.weights.refresh_all()
         return loss
 
     def steps_taken(self) -> int:

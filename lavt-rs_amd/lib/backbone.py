@@ -66,9 +66,8 @@ class Mlp(nn.Module):
     def forward(self, x, residual=None, row_scale=None, row_scale_div=1, row_scale_value=0.0):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
-        h = ops.linear(x2, self.fc1.weight, self.fc1.bias, act=ACT_GELU)
-        y = ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual, row_scale=row_scale, row_scale_div=row_scale_div,
-                       row_scale_value=row_scale_value)
+        y = ops.mlp(x2, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual=residual, row_scale=row_scale,
+                    row_scale_div=row_scale_div, row_scale_value=row_scale_value)
         return y.view(*shp[:-1], y.shape[-1])
 
 

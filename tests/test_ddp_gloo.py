@@ -98,9 +98,9 @@ class _CpuBnKernels:
         return torch.relu((x - mean) * rstd * gamma + beta)
 
     @staticmethod
-    def bwd_stats(dy, x, y, mean, rstd, gamma, beta):
+    def bwd_stats(dy, x, y, mean, rstd, gamma, beta, out=None):
         g = dy * (y > 0)
-        return torch.stack([g.sum(0), (g * (x - mean) * rstd).sum(0)])
+        return g.sum(0), (g * (x - mean) * rstd).sum(0)
 
     @staticmethod
     def bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count):

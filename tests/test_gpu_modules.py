@@ -532,3 +532,40 @@ def test_lavt_one_micro_matches_oracle_chain():
               "backbone.layers.2.blocks.1.attn.qkv.weight"):
         gr = params[k].grad
         assert float((got[k].grad.cpu() - gr).abs().max()) <= 5e-3 * float(gr.abs().max()) + 1e-6, k
+
+
+@pytest.mark.gpu
+def test_fused_adamw_with_model_forward_outside_train_step():
+    """The loop the optimizer's docstring documents -- `model(...)`; `loss.backward()`; `opt.step()`, no TrainStep -- in bf16: FusedAdamW updates
+    the parameters through raw pointers, so it must refresh the cached compute-dtype weight copies itself (round-1 ADVICE: it did not, and
+    training silently went nowhere).  Two steps against a twin model driven by torch.optim.AdamW (whose in-place update bumps p._version)."""
+    import lavt_hip
+    from lavt_hip import ops
+    from lavt_hip.optim import FusedAdamW
+    x, l, m, t = det_inputs(2, 64, 20, seed=11)
+    x, l, m, t = x.to(DEV), l.to(DEV), m.to(DEV), t.to(DEV)
+    w = torch.tensor([0.9, 1.1], device=DEV)
+    with lavt_hip.use_dtype(torch.bfloat16):
+        ours, twin = (_build(32, [2, 2, 2, 2], [1, 2, 4, 8], 7, dpr=0.0).train() for _ in range(2))
+        opt = FusedAdamW([p for p in ours.parameters()], lr=1e-4, weight_decay=1e-2)
+        ref = torch.optim.AdamW([p for p in twin.parameters()], lr=1e-4, weight_decay=1e-2)
+        losses = []
+        for it in range(3):
+            lo = F.cross_entropy(ours(x, l, m), t, weight=w)
+            lt = F.cross_entropy(twin(x, l, m), t, weight=w)
+            losses.append((float(lo), float(lt)))
+            if it == 2:
+                break
+            for p in list(ours.parameters()) + list(twin.parameters()):
+                p.grad = None
+            lo.backward()
+            lt.backward()
+            opt.step()
+            ref.step()
+        assert abs(losses[0][0] - losses[0][1]) < 1e-6
+        assert abs(losses[1][0] - losses[0][0]) > 1e-3, f"the first optimizer step did not reach the forward: {losses}"
+        assert abs(losses[2][0] - losses[1][0]) > 1e-4, f"the second optimizer step did not reach the forward: {losses}"
+        for a, b in losses[1:]:
+            assert abs(a - b) < 5e-3, losses          # same update rule on both sides (fp32 masters); bf16 forward noise only
+        qk = ours.backbone.layers[1].blocks[0].attn.qkv.weight
+        assert torch.equal(ops.weights.get(qk, torch.bfloat16), qk.detach().to(torch.bfloat16)), "stale bf16 weight copy after FusedAdamW.step()"

@@ -646,3 +646,28 @@ def test_losses_module_criteria_on_full_resolution_logits(golden):
         assert float((o2.grad.cpu() - out.grad).abs().max()) < 1e-6
     with pytest.raises(NotImplementedError):
         losses.DiceFocalLoss()
+
+
+def test_fused_mlp_node_matches_two_linears(monkeypatch):
+    """ops.mlp's single-node form (LAVT_FUSED_MLP=1: fc2's data-gradient GEMM applies GELU'(pre) in its epilogue, lavt_gemm_nt dact_pre)
+    against the two-op form: output and every gradient, with a DropPath row mask and a residual"""
+    from lavt_hip import ops
+    g = torch.Generator().manual_seed(3)
+    M, Cc = 1800, 128
+    bf = torch.bfloat16
+    x0 = (torch.randn(M, Cc, generator=g)).to(dev()).to(bf)
+    res0 = (torch.randn(M, Cc, generator=g)).to(dev()).to(bf)
+    ws = [torch.randn(4 * Cc, Cc, generator=g) * Cc ** -0.5, torch.randn(4 * Cc, generator=g) * 0.1, torch.randn(Cc, 4 * Cc, generator=g) * (4 * Cc) ** -0.5,
+          torch.randn(Cc, generator=g) * 0.1]
+    mask = torch.tensor([1.25, 0.0], device=dev())
+    dy = torch.randn(M, Cc, generator=g).to(dev()).to(bf)
+    outs = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("LAVT_FUSED_MLP", fused)
+        x, res = x0.clone().requires_grad_(True), res0.clone().requires_grad_(True)
+        ps = [torch.nn.Parameter(w.clone().to(dev())) for w in ws]
+        y = ops.mlp(x, ps[0], ps[1], ps[2], ps[3], residual=res, row_scale=mask, row_scale_div=M // 2, row_scale_value=1.25)
+        y.backward(dy)
+        outs.append([y.detach().float(), x.grad.float(), res.grad.float()] + [p.grad for p in ps])
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max()) + 1e-6

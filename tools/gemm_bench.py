@@ -85,7 +85,11 @@ def main():
             os.environ.pop(k)
         fn = nt(a, b, c) if kind == "nt" else nt(a, b, c, True) if kind == "ntk" else tn(a, b, c)
         t = timeit(fn)
-        print(f"{name:9s} {kind:3s} {a:6d} {b:5d} {c:5d} | " + " | ".join(f"{tile}: {us:5.1f}us {tf:4.0f}" for tile, us, tf in res) + f" | auto: {t * 1e6:5.1f}us")
+        # yardstick only (never on the product path): the vendor library's GEMM on the same shape through torch.matmul (hipBLASLt)
+        Am = torch.randn(a, c, device=dev).to(bf)
+        Bm = torch.randn((c, b) if kind == "ntk" else (b, c), device=dev).to(bf)
+        tl = timeit((lambda: torch.matmul(Am, Bm)) if kind == "ntk" else (lambda: torch.matmul(Am, Bm.t())))
+        print(f"{name:9s} {kind:3s} {a:6d} {b:5d} {c:5d} | " + " | ".join(f"{tile}: {us:5.1f}us {tf:4.0f}" for tile, us, tf in res) + f" | auto: {t * 1e6:5.1f}us | hipBLASLt: {tl * 1e6:5.1f}us")
 
 
 if __name__ == "__main__":
