@@ -34,6 +34,9 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0                                                 
 WORKLOADS = {
     "swin_b_w12_480_b2": dict(variant="base", window12=True, batch=2, size=480, flops="swin_b_w12_480"),
     "swin_t_w7_480_b8": dict(variant="tiny", window12=False, batch=8, size=480, flops="swin_t_w7_480"),
+    # BASELINE.json configs[4]: fp8 (e4m3) weights / activations for the forward contractions that opt in, batch 4 per GPU (run with --dtype fp8)
+    "swin_b_w12_480_b4_fp8": dict(variant="base", window12=True, batch=4, size=480, flops="swin_b_w12_480", fp8=True),
+    "swin_b_w12_480_b4": dict(variant="base", window12=True, batch=4, size=480, flops="swin_b_w12_480"),
     # the same step with the BERT-base text encoder inside the model (`lavt_one`): token ids in, BERT trained with the rest
     "lavt_one_swin_b_w12_480_b2": dict(variant="base", window12=True, batch=2, size=480, flops="swin_b_w12_480", one=True),
     # BASELINE.json configs[3]: Video-Swin-B LAVT, one clip of T=8 frames at 384x384 per GPU (metric counts frames); PWAM / README SepTPWAM recipe
@@ -103,8 +106,11 @@ def measure_conv_kernel(device, iters=20):
         traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")))["traffic_bytes_per_launch"]
     except Exception:  # noqa: BLE001
         pass
-    return {"bound": "mfma", "kernel": "implicit-GEMM conv3x3 512->512 @120x120, batch 2 (decoder conv2_2), timed alone", "achieved": round(achieved, 2),
-            "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4),
+    import lavt_hip
+    f8 = lavt_hip.fp8_enabled()          # fp8 workload: the same convolution on e4m3 operands (v_mfma_scale 16x16x128: dense peak 5 PFLOP/s), quantisation launches included
+    peak = 2.0 * BF16_DENSE_PEAK_TFLOPS if f8 else BF16_DENSE_PEAK_TFLOPS
+    return {"bound": "mfma", "kernel": "implicit-GEMM conv3x3 512->512 @120x120, batch 2 (decoder conv2_2), timed alone" + (" [fp8: incl. the activation quantiser]" if f8 else ""),
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "avg_launch_us": round(ms * 1e3, 2), "flops_per_launch": flops, "traffic": traffic, "traffic_source": "profiles/pmc_dominant_kernel.json (recorded)"}
 
 
@@ -262,7 +268,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="swin_b_w12_480_b2", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp8"], help="default: bf16 (fp8 for the *_fp8 workload)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
@@ -298,6 +304,8 @@ def main():
     from lavt_hip.detweights import det_inputs
     from lavt_hip.engine import TrainStep
     cfg = dict(WORKLOADS[a.workload], name=a.workload)
+    if a.dtype is None:
+        a.dtype = "fp8" if cfg.get("fp8") else "bf16"
     lavt_hip.set_compute_dtype(a.dtype)
     model = build_model(cfg, device, a.drop_path)
     if world > 1 or force:
@@ -380,7 +388,7 @@ def main():
         }
         if world == 1 and not force:
             try:
-                conv = measure_conv_kernel(device) if a.dtype == "bf16" else None
+                conv = measure_conv_kernel(device) if a.dtype in ("bf16", "fp8") else None
                 if a.no_profile:
                     out["roofline"] = conv
                 else:

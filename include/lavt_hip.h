@@ -26,6 +26,7 @@ extern "C" {
 
 #define LAVT_F32 0
 #define LAVT_BF16 1
+#define LAVT_FP8 2 /* lavt_gemm_nt only: A and B are OCP e4m3 (1 byte / element, k-contiguous), C / bias / residual bf16, fp32 accumulate */
 
 #define LAVT_OK 0
 #define LAVT_ERR_INVALID (-22) /* bad argument (EINVAL) */
@@ -109,6 +110,13 @@ typedef struct lavt_gemm_nt {
     const void* dact_pre;
     int64_t lddact;
     int32_t dact;
+    /* dtype == LAVT_FP8 (BASELINE.json configs[4]): per-tensor scaling.  deq_a / deq_b point at the device floats holding the |max| the A / B
+     * tensors were quantised against (lavt_fp8_quantize*: q = e4m3(x * 448 / amax); a value <= 0 means "scale 1"); the epilogue multiplies the
+     * accumulator by (amax_a / 448) * (amax_b / 448) * alpha.  The contraction runs on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block
+     * scales (twice the bf16 MFMA rate at half the operand bytes).  Requirements: !b_kmajor, no dact_pre, K % 16 == 0, lda / ldb % 16 == 0,
+     * conv_kc (and a_split) % 128 == 0 for the tap-walking fast path. */
+    const float* deq_a;
+    const float* deq_b;
 } lavt_gemm_nt_t;
 
 int lavt_gemm_nt(const lavt_gemm_nt_t* p, void* stream);
@@ -282,6 +290,15 @@ int lavt_upsample_dice_fwd(int dtype, const void* x, const int64_t* target, floa
                            int B, int Hi, int Wi, int Ho, int Wo, void* stream);
 int lavt_upsample_dice_bwd(int dtype, const void* x, const int64_t* target, const float* stats, const float* dloss, void* dx,
                            int B, int Hi, int Wi, int Ho, int Wo, void* stream);
+/* ---- fp8 (OCP e4m3) operand preparation for lavt_gemm_nt(dtype = LAVT_FP8) ----
+ * lavt_fp8_quantize: activations, delayed scaling: dst[i] = e4m3(clamp(src[i] * s, +-448)), s = *amax_prev > 0 ? 448 / *amax_prev : 1 (the |max| seen
+ *   in the PREVIOUS step; the GEMM reads the same float through deq_a); max |src| of THIS call is folded into *amax_cur (atomic max).
+ * lavt_fp8_advance: start of a step, for n slots: prev[i] = cur[i] > 0 ? cur[i] : prev[i]; cur[i] = 0.
+ * lavt_fp8_quantize_weight: fp32 parameter -> e4m3 with CURRENT scaling (*amax is computed here, over the whole tensor); taps > 1 re-packs a
+ *   [Cout][Cin][taps] convolution weight as [Cout][taps][Cin] (the implicit-GEMM layout) on the way. */
+int lavt_fp8_quantize(int src_dtype, const void* src, void* dst, int64_t n, const float* amax_prev, float* amax_cur, void* stream);
+int lavt_fp8_advance(float* amax_prev, float* amax_cur, int n, void* stream);
+int lavt_fp8_quantize_weight(const float* src, void* dst, float* amax, int cout, int cin, int taps, void* stream);
 /* classifier head conv1_1: 1x1 conv hidden->2 with bias (lib/mask_predictor.py:50,99) */
 int lavt_cls_head_fwd(int dtype, const void* x, const float* w, const float* b, void* y, int64_t rows, int C, void* stream);
 int lavt_cls_head_bwd(int dtype, const void* x, const void* dy, const float* w, void* dx, float* dw, float* db,

@@ -418,8 +418,8 @@ int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st);
 extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
     LAVT_CHECK_ARG(pp != nullptr, "lavt_gemm_nt: null params");
     lavt_gemm_nt_t p = *pp;
-    LAVT_CHECK_ARG(p.dtype == LAVT_F32 || p.dtype == LAVT_BF16, "lavt_gemm_nt: bad dtype %d", p.dtype);
-    const int epc = p.dtype == LAVT_F32 ? 4 : 8;
+    LAVT_CHECK_ARG(p.dtype == LAVT_F32 || p.dtype == LAVT_BF16 || p.dtype == LAVT_FP8, "lavt_gemm_nt: bad dtype %d", p.dtype);
+    const int epc = p.dtype == LAVT_F32 ? 4 : (p.dtype == LAVT_FP8 ? 16 : 8);
     LAVT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.batch >= 1, "lavt_gemm_nt: bad shape M=%d N=%d K=%d batch=%d", p.M, p.N, p.K, p.batch);
     LAVT_CHECK_ARG(p.K % epc == 0, "lavt_gemm_nt: K=%d must be a multiple of %d", p.K, epc);
     LAVT_CHECK_ARG(p.A && p.B && p.C, "lavt_gemm_nt: null operand");
@@ -440,6 +440,7 @@ extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
     const int rc2 = lavt_gemm_nt_v2(p, st);          // bf16 LDS-DMA pipeline (gemm_v2.hip); 1 = not applicable
     if (rc2 != 1) return rc2;
     LAVT_CHECK_ARG(p.dact_pre == nullptr, "lavt_gemm_nt: dact_pre (fused activation gradient) exists on the bf16 LDS-DMA path only");
+    LAVT_CHECK_ARG(p.dtype != LAVT_FP8, "lavt_gemm_nt: fp8 operands exist on the LDS-DMA path only");
     return p.dtype == LAVT_F32 ? dispatch_nt<float>(p, st) : dispatch_nt<bf16>(p, st);
 }
 

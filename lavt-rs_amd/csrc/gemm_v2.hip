@@ -115,19 +115,25 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // MODE 2 = convolution taps with Cin (and the concat split) a multiple of the 64-wide K tile: the tap of a K tile is wave-uniform and walks
 // forward with the K loop (no division), the lanes' voxel coordinates are computed once, so a neighbour fetch is three range checks and one
 // address add.  MODE 0 (anything else) decodes every K tile from scratch.
-template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false>
+typedef __attribute__((__vector_size__(8 * sizeof(int)))) int i32x8;
+// fp8 (F8): the operand tiles are the same BYTES as the bf16 ones (rows of 128 B = 128 e4m3 elements, 16 per 16-byte chunk), so the DMA ring,
+// the chunk swizzle and the fragment reads are unchanged; a lane feeds one v_mfma_scale_f32_16x16x128_f8f6f4 with the two chunks g and g + 4
+// (g = lane / 16) of its row -- which 32 k of the 128 a lane group holds is immaterial as long as A and B agree (unit block scales); these
+// two are the chunks the bf16 fragments of k-steps 0 and 1 read, i.e. the bank-conflict-free pattern (chunks 2g, 2g+1 conflict 2-way).
+template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_nt_t p) {
     constexpr bool SIMPLE = MODE == 1, CONVFAST = MODE == 2;
-    using T = bf16;
-    constexpr int BK = 64, EPC = 8;
+    using T = typename std::conditional<F8, unsigned char, bf16>::type;
+    constexpr int BK = F8 ? 128 : 64, EPC = F8 ? 16 : 8;
+    static_assert(!(F8 && (BKM || DACT)), "fp8: k-contiguous operands, plain epilogue");
     constexpr int WAVES_M = WAVES == 16 ? 4 : 2;             // wave grid: WAVES_M (M) x WAVES_N (N); 16 waves: 4 x 4 waves of 64 x 64
     constexpr int WAVES_N = WAVES / WAVES_M;
     constexpr int A_INSTR = BM / (8 * WAVES);                // DMA instructions per wave per K tile for A (8 rows x 8 chunks each)
     constexpr int B_CH = BN / EPC;                           // chunks per k-major B row: [BK][BN] unpadded, 32-byte slots swizzled by tn_swz
     constexpr int B_INSTR = BN / (8 * WAVES);                // (k-contiguous and k-major tiles both hold BN * BK elements)
     constexpr int L = A_INSTR + B_INSTR;
-    constexpr int A_BYTES = BM * BK * 2;
-    constexpr int B_BYTES = BN * BK * 2;
+    constexpr int A_BYTES = BM * 128;
+    constexpr int B_BYTES = BN * 128;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NI = WN / 16;
     static_assert(A_INSTR >= 1 && B_INSTR >= 1 && MI >= 1 && NI >= 1, "tile too small for this many waves");
@@ -324,6 +330,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         wait_groups<L>(min(STAGES - 2, ktiles - 1 - kt));          // tile kt landed; up to STAGES-2 younger tiles stay in flight
         __builtin_amdgcn_s_barrier();
         if (kt + STAGES - 1 < ktiles) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        if constexpr (F8) {
+            const bf16* cA = reinterpret_cast<const bf16*>(smem + (kt % STAGES) * STAGE_BYTES);          // byte image identical to a bf16 [rows][64] tile
+            const bf16* cB = reinterpret_cast<const bf16*>(smem + (kt % STAGES) * STAGE_BYTES + A_BYTES);
+            i32x8 fa8[MI], fb8[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * WM + i * 16 + (lane & 15), g = lane >> 4;      // chunks g and g + 4: the bf16 fragments' conflict-free read pattern
+                const uint4 lo = *reinterpret_cast<const uint4*>(cA + kc_off<bf16>(row, g)), hi = *reinterpret_cast<const uint4*>(cA + kc_off<bf16>(row, g + 4));
+                fa8[i] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int row = wn * WN + j * 16 + (lane & 15), g = lane >> 4;
+                const uint4 lo = *reinterpret_cast<const uint4*>(cB + kc_off<bf16>(row, g)), hi = *reinterpret_cast<const uint4*>(cB + kc_off<bf16>(row, g + 4));
+                fb8[j] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)      // (B, A) operand order as in the bf16 path: the accumulators hold C^T tiles; formats 0 = e4m3; scales 0x7F = 2^0
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[j], fa8[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            continue;
+        } else {
         const T* cA = reinterpret_cast<const T*>(smem + (kt % STAGES) * STAGE_BYTES);
         const T* cB = reinterpret_cast<const T*>(smem + (kt % STAGES) * STAGE_BYTES + A_BYTES);
         if constexpr (WAVES == 16 && BKM) {
@@ -382,28 +411,55 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = mfma16<T>(fb[ks][j], fa[ks][i], acc[i][j]);
+        }
     }
+    if constexpr (F8) {
+        // dequantisation: the tensors were quantised as q = e4m3(x * 448 / amax); amax <= 0 stands for "scale 1" (uncalibrated first step)
+        lavt_gemm_nt_t q = p;
+        const float da = p.deq_a ? *p.deq_a : 0.f, db = p.deq_b ? *p.deq_b : 0.f;
+        q.alpha = p.alpha * (da > 0.f ? da * (1.f / 448.f) : 1.f) * (db > 0.f ? db * (1.f / 448.f) : 1.f);
+        nt_epilogue<bf16, MI, NI>(q, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
+        return;
+    } else {
     if constexpr (DACT) { nt_epilogue<T, MI, NI, true>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz); return; }
     if (!p.epi_lds || p.c_f32 || (p.ldc % 8) || (p.C2 && (p.ldc2 % 8 || p.c_split % 8)) || (p.R && p.ldr % 8) || (p.Cpre && p.ldcpre % 8))
         nt_epilogue<T, MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
     else
         nt_epilogue_lds<BM, BN, MI, NI>(p, acc, reinterpret_cast<bf16*>(smem), m0, n0, wm * WM, wn * WN, tid, lane, bz);
+    }
 }
 
-template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false> int launch_nt_v2_(const lavt_gemm_nt_t& p, hipStream_t st) {
+template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false> int launch_nt_v2_(const lavt_gemm_nt_t& p, hipStream_t st) {
     constexpr size_t lds = STAGES * (size_t)(BM * 128 + BN * 128);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             lavt_set_error("lavt_gemm_nt(v2): cannot reserve %zu bytes of LDS", lds);
             return LAVT_ERR_LAUNCH;
         }
         attr_set = true;
     }
     dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch);
-    hipLaunchKernelGGL((gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT>), grid, dim3(WAVES * 64), lds, st, p);
+    hipLaunchKernelGGL((gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8>), grid, dim3(WAVES * 64), lds, st, p);
     LAVT_CHECK_LAUNCH("lavt_gemm_nt(v2)");
     return LAVT_OK;
+}
+// fp8 operands (LAVT_FP8): k-contiguous A and B, 128-element K tiles; 128x128 / 8 waves when that fills the chip, else 64x64 / 4 waves
+template <int BM, int BN, int STAGES, int WAVES> int launch_nt_v2_f8(const lavt_gemm_nt_t& p, hipStream_t st) {
+    const bool simple = p.conv_kc <= 0 && p.A2 == nullptr && p.K % 128 == 0;
+    const bool convfast = p.conv_kc > 0 && p.conv_kc % 128 == 0 && (p.A2 == nullptr || p.a_split % 128 == 0);
+    if (simple) return launch_nt_v2_<BM, BN, false, STAGES, WAVES, 1, false, true>(p, st);
+    if (convfast) return launch_nt_v2_<BM, BN, false, STAGES, WAVES, 2, false, true>(p, st);
+    return launch_nt_v2_<BM, BN, false, STAGES, WAVES, 0, false, true>(p, st);
+}
+int launch_nt_v2_fp8(const lavt_gemm_nt_t& p, hipStream_t st) {
+    if (p.b_kmajor || p.dact_pre || p.c_f32 || p.lda % 16 || p.ldb % 16 || (p.A2 && (p.lda2 % 16 || p.a_split % 16)) || p.K % 16 || (p.conv_kc > 0 && p.conv_kc % 16) || !p.zeros) {
+        lavt_set_error("lavt_gemm_nt(fp8): needs k-contiguous e4m3 operands with 16-byte aligned rows (lda, ldb, K, conv_kc, a_split %% 16 == 0), bf16 C, no dact_pre");
+        return LAVT_ERR_INVALID;
+    }
+    const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch, tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;
+    if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_f8<128, 128, 2, 8>(p, st) : launch_nt_v2_f8<128, 128, 4, 8>(p, st);
+    return tiles64 >= 600 ? launch_nt_v2_f8<64, 64, 2, 4>(p, st) : launch_nt_v2_f8<64, 64, 4, 4>(p, st);
 }
 // Fused activation-gradient epilogue (dact_pre): data gradients only (k-major B, plain K walk); the flag is a template parameter so that no
 // other instantiation pays its registers (as a run-time branch in every kernel it cost 12 VGPRs and 0.25 ms per step in round 1).
@@ -745,6 +801,7 @@ template <int BI, int BJ, int WAVES> int launch_tn_v2(const lavt_gemm_tn_t& p, i
 
 // returns 1 when the problem is not for this kernel (caller falls back to gemm.hip), else a LAVT status
 int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
+    if (p.dtype == LAVT_FP8) return launch_nt_v2_fp8(p, st);
     if (p.dtype != LAVT_BF16 || p.zeros == nullptr) return 1;
     const char* e = getenv("LAVT_GEMM_V2");
     if (e && e[0] == '0') return 1;

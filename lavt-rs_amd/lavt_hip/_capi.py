@@ -100,7 +100,7 @@ class _Lib:
 
 lib = _Lib(_cdll)
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -115,7 +115,7 @@ class GemmNT(C.Structure):
         ("Cpre", vp), ("ldcpre", i64), ("R", vp), ("ldr", i64),
         ("C", vp), ("ldc", i64), ("strideC", i64), ("C2", vp), ("ldc2", i64), ("c_split", i32), ("c_rowmap", vp),
         ("c_f32", i32), ("zeros", vp), ("epi_lds", i32), ("conv_d", i32), ("conv_kd", i32), ("conv_kh", i32), ("conv_kw", i32),
-        ("dact_pre", vp), ("lddact", i64), ("dact", i32),
+        ("dact_pre", vp), ("lddact", i64), ("dact", i32), ("deq_a", vp), ("deq_b", vp),
     ]
 
 
@@ -171,6 +171,9 @@ _PROTOTYPES = {
     "lavt_upsample_ce_bwd": [i32, vp, vp, f32, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lavt_upsample_dice_fwd": [i32, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, vp],
     "lavt_upsample_dice_bwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "lavt_fp8_quantize": [i32, vp, vp, i64, vp, vp, vp],
+    "lavt_fp8_advance": [vp, vp, i32, vp],
+    "lavt_fp8_quantize_weight": [vp, vp, vp, i32, i32, i32, vp],
     "lavt_cls_head_fwd": [i32, vp, vp, vp, vp, i64, i32, vp],
     "lavt_cls_head_bwd": [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp],
     "lavt_im2col4": [i32, vp, vp, i32, i32, i32, vp],

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .ddp import GradBuckets
-from .runtime import compute_dtype
+from .runtime import compute_dtype, fp8_enabled
 
 
 class TrainStep:
@@ -54,6 +54,8 @@ class TrainStep:
         if self.refresh_in_step:
             ops.weights.refresh_all()            # re-cast weights inside the step (for optimizers that do not maintain the compute copies)
         self.buckets.zero()
+        if fp8_enabled():
+            ops.fp8.advance()                    # delayed scaling: last step's |max| values become this step's quantisation scales
         if self.fused_loss:                       # upsample + weighted CE (+ I/U) fused: the (B,2,H,W) logits are never written
             from lib._utils import fused_loss
             loss, self.stats = fused_loss(self.model.forward_lowres(self.x, self.l, self.m), self.t, (0.9, 1.1))

@@ -6,13 +6,17 @@ import torch
 
 _DTYPES = {"fp32": torch.float32, "float32": torch.float32, "f32": torch.float32,
            "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
-_state = {"dtype": _DTYPES[os.environ.get("LAVT_DTYPE", "fp32").lower()]}
+_state = {"dtype": _DTYPES[os.environ.get("LAVT_DTYPE", "fp32").lower()], "fp8": os.environ.get("LAVT_FP8", "0") == "1"}
 
 
 def set_compute_dtype(dtype) -> None:
     """torch.float32: exact-fp32 MFMA path (parity).  torch.bfloat16: bf16 MFMA, fp32 accumulate (throughput)."""
     if isinstance(dtype, str):
+        if dtype.lower() == "fp8":          # bf16 activations / gradients, e4m3 operands for the forward contractions that opt in (set_fp8)
+            _state["dtype"], _state["fp8"] = torch.bfloat16, True
+            return
         dtype = _DTYPES[dtype.lower()]
+    _state["fp8"] = False
     if dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("compute dtype must be float32 or bfloat16")
     _state["dtype"] = dtype
@@ -25,11 +29,16 @@ def compute_dtype() -> torch.dtype:
     return _state["dtype"]
 
 
+def fp8_enabled() -> bool:
+    """BASELINE.json configs[4]: e4m3 weights / activations on the CDNA4 fp8 MFMA for the forward contractions (bf16 everywhere else)."""
+    return _state["fp8"] and _state["dtype"] == torch.bfloat16
+
+
 @contextlib.contextmanager
 def use_dtype(dtype):
-    prev = _state["dtype"]
+    prev = dict(_state)
     set_compute_dtype(dtype)
     try:
         yield
     finally:
-        _state["dtype"] = prev
+        _state.update(prev)

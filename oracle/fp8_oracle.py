@@ -1,0 +1,38 @@
+"""CPU restatement of the fp8 (OCP e4m3) operand path of BASELINE.json configs[4] -- TEST INFRASTRUCTURE ONLY (tests/, smoke, bench baseline).
+
+The reference (Yxxxb/LAVT-RS) has no fp8 arithmetic: it is a PyTorch fp32 / AMP code base.  What this file pins is therefore the build's own
+stated format, so that the HIP kernels can be checked bit-for-bit / to rounding against an independent evaluation:
+
+* quantisation: q = e4m3fn(clamp(x * 448 / amax, +-448)) with round-to-nearest-even (torch.float8_e4m3fn's cast), per-tensor amax
+  (amax <= 0 means scale 1);
+* contraction: exact products of the e4m3 values, fp32 accumulation, result multiplied by (amax_a / 448) * (amax_b / 448).
+
+The model-level gate of the fp8 configuration is taken against the REFERENCE's fp32 run (tests/golden/full_swin_b_480_b2.npz), like bf16's.
+"""
+import torch
+import torch.nn.functional as F
+
+E4M3_MAX = 448.0
+
+
+def scale_of(amax: float) -> float:
+    return E4M3_MAX / amax if amax > 0 else 1.0
+
+
+def quantize_bytes(x: torch.Tensor, amax: float) -> torch.Tensor:
+    """-> uint8 tensor holding the e4m3fn encodings"""
+    return (x.float() * scale_of(amax)).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def dequantize(x: torch.Tensor, amax: float) -> torch.Tensor:
+    """quantise-dequantise: the values the fp8 contraction effectively multiplies"""
+    return (x.float() * scale_of(amax)).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).float() / scale_of(amax)
+
+
+def linear_fp8(x, w, b, amax_x, amax_w):
+    y = dequantize(x, amax_x) @ dequantize(w, amax_w).t()
+    return y + b if b is not None else y
+
+
+def conv3x3_fp8(x_nchw, w, amax_x, amax_w):
+    return F.conv2d(dequantize(x_nchw, amax_x), dequantize(w, amax_w), padding=1)

@@ -255,3 +255,48 @@ def test_bench_step_matches_reference(golden):
     flips = (1.0 - float(g["refbf16_agree"]) + 0.005) * n_pix          # the I / U counts may move by what the reference's own bf16 run flips
     assert dI <= flips and dU <= flips, (dI, dU, flips)
     _check_grads(g, [(k, p.grad) for k, p in model.named_parameters()], False)
+
+
+def test_full_swin_b_fp8(golden):
+    """BASELINE configs[4] arithmetic (e4m3 weights / activations on the fp8 MFMA for the decoder's 3x3 convolutions -- 54 % of the FLOPs -- bf16
+    elsewhere) on the Swin-B 2x480x480 fixture, after one calibration step (delayed scaling).  The reference has no fp8 path: the gate is stated
+    against its fp32 run, next to the reference's own bf16 figures -- mask IoU on decisive pixels (|margin| > 0.25 sigma) >= 0.97,
+    pixel agreement >= the reference-bf16 agreement - 0.02, |d loss| <= 3e-2, gradient-digest error median / p90 <= 3 x the reference-bf16's."""
+    import lavt_hip
+    from lavt_hip import ops
+    name, embed, depths, heads, ws, B = IMAGE["swin_b"]
+    g = golden(name)
+    ops.fp8.__init__()
+    with lavt_hip.use_dtype("fp8"):
+        model = _image_model(embed, depths, heads, ws)
+        x, l, m, tgt = det_inputs(B, 480, 20, seed=int(g["seed"]))
+        x, l, m = x.to(DEV), l.to(DEV), m.to(DEV)
+        with torch.no_grad():                              # calibration pass: records the |max| of every quantisation site
+            ops.fp8.advance()
+            _forward(model, False, x, l, m)
+        ops.fp8.advance()
+        feats, lowres, logits = _forward(model, False, x, l, m)
+        loss = F.cross_entropy(logits, tgt.to(DEV), weight=torch.tensor([0.9, 1.1], device=DEV))
+        loss.backward()
+    size = 480
+    lg = logits.detach().float().cpu()
+    ref_mask, dq = _unpack(g["mask"], (B, size, size)), _unpack(g["decisive_q"], (B, size, size))
+    pred = lg.argmax(1).bool()
+    r = dict(agree=float((pred == ref_mask).float().mean()), mask_iou=float((pred & ref_mask).sum()) / float((pred | ref_mask).sum()),
+             iou_decisive_q=float((pred & ref_mask & dq).sum()) / max(float(((pred | ref_mask) & dq).sum()), 1.0),
+             err_lowres=float((lowres.detach().float().cpu() - torch.as_tensor(g["lowres"])).abs().max()), sigma=float(g["logit_std"]),
+             dloss=abs(float(loss) - float(g["loss"])), reference_bf16_agree=float(g["refbf16_agree"]), reference_bf16_iou=float(g["refbf16_iou"]))
+    print(f"\n[forward fp8] {r}")
+    assert r["iou_decisive_q"] >= 0.97 and r["agree"] >= float(g["refbf16_agree"]) - 0.02 and r["dloss"] <= 3e-2, r
+    worst = {}
+    for k, p in model.named_parameters():
+        if p.grad is None or ("g|" + k) not in g.files or float(g["g|" + k][0]) <= 1e-6:
+            continue
+        ref = torch.as_tensor(g["g|" + k])
+        d = grad_digest(p.grad)
+        worst[k] = max(abs(float(d[0]) - float(ref[0])) / float(ref[0]), float((d[2:] - ref[2:]).abs().max()) / float(ref[0]) / 1.5)
+    es = sorted(worst.values())
+    out = dict(n=len(es), median=round(es[len(es) // 2], 5), p90=round(es[int(len(es) * 0.9)], 5), max=round(es[-1], 5),
+               reference_bf16={k: round(float(g["refbf16_grad_" + k]), 5) for k in ("median", "p90", "max")})
+    print(f"[gradients fp8] {out}")
+    assert out["median"] <= 3.0 * float(g["refbf16_grad_median"]) and out["p90"] <= 3.0 * float(g["refbf16_grad_p90"]), out

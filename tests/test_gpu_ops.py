@@ -671,3 +671,73 @@ def test_fused_mlp_node_matches_two_linears(monkeypatch):
         outs.append([y.detach().float(), x.grad.float(), res.grad.float()] + [p.grad for p in ps])
     for a, b in zip(*outs):
         assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max()) + 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- fp8 (BASELINE.json configs[4])
+def test_fp8_quantizer_bit_exact_and_delayed_scaling():
+    """lavt_fp8_quantize vs torch's float8_e4m3fn cast (round to nearest even, saturating at +-448): identical bytes; the |max| seen by one
+    call becomes the scale of the next step after lavt_fp8_advance"""
+    from lavt_hip import ops
+    from oracle import fp8_oracle as F8
+    st = ops._Fp8State()
+    x = (rnd(512, 128, seed=3) * 3.0).to(torch.bfloat16)
+    x[0, 0], x[1, 1] = 1000.0, -777.0                                    # beyond +-448 at scale 1: must saturate, not become NaN
+    q0, _ = st.quantize(x.to(dev()), "site")                            # uncalibrated: scale 1
+    assert torch.equal(q0.cpu(), F8.quantize_bytes(x, 0.0))
+    st.advance()
+    amax = float(x.float().abs().max())
+    assert float(st.prev[0]) == amax and float(st.cur[0]) == 0.0
+    q1, _ = st.quantize(x.to(dev()), "site")
+    assert torch.equal(q1.cpu(), F8.quantize_bytes(x, amax))
+
+
+@pytest.mark.parametrize("cat", [False, True])
+def test_fp8_conv3x3_matches_quantised_oracle(cat):
+    """decoder 3x3 convolution on e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales): both concat sources against one scale,
+    weights with current scaling; against the fp32 convolution of the quantise-dequantised tensors"""
+    import lavt_hip
+    from lavt_hip import ops
+    from oracle import fp8_oracle as F8
+    B, H, W, C1, C2, Cout = 2, 20, 24, 128, (128 if cat else 0), 256
+    x1 = (rnd(B * H * W, C1, seed=1)).to(torch.bfloat16)
+    x2 = (rnd(B * H * W, C2, seed=2) * 2.0).to(torch.bfloat16) if cat else None
+    w = rnd(Cout, C1 + C2, 3, 3, seed=5) * (9 * (C1 + C2)) ** -0.5
+    wd = torch.nn.Parameter(w.clone().to(dev()))
+    ops.fp8.__init__()
+    with lavt_hip.use_dtype("fp8"):
+        assert lavt_hip.fp8_enabled()
+        for it in range(2):                                              # second call: calibrated scale (delayed scaling)
+            ops.fp8.advance()
+            with torch.no_grad():
+                y = ops.conv3x3(x1.to(dev()), x2.to(dev()) if cat else None, wd, B, H, W)
+    assert not lavt_hip.fp8_enabled()
+    xs = torch.cat([x1, x2], 1) if cat else x1
+    amax_x, amax_w = float(xs.float().abs().max()), float(w.abs().max())
+    ref = F8.conv3x3_fp8(xs.float().view(B, H, W, -1).permute(0, 3, 1, 2), w, amax_x, amax_w).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    err = float((y.float().cpu() - ref).abs().max())
+    assert err <= 1e-2 * float(ref.abs().max()), err / float(ref.abs().max())
+    exact = F.conv2d(xs.float().view(B, H, W, -1).permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    rel = float((y.float().cpu() - exact).norm() / exact.norm())
+    assert rel < 0.06, rel                                               # e4m3 has 3 mantissa bits: ~3-4 % rms on a 1000-term contraction
+
+
+def test_fp8_linear_matches_quantised_oracle(monkeypatch):
+    """the Linear form of the fp8 contraction (off by default: ops._FP8_LINEAR_MIN_ROWS) against the quantised oracle"""
+    import lavt_hip
+    from lavt_hip import ops
+    from oracle import fp8_oracle as F8
+    monkeypatch.setattr(ops, "_FP8_LINEAR_MIN_ROWS", 4096)
+    M, Kd, N = 4608, 256, 384
+    x = rnd(M, Kd, seed=7).to(torch.bfloat16)
+    w, b = rnd(N, Kd, seed=8) * Kd ** -0.5, rnd(N, seed=9) * 0.1
+    wd, bd = torch.nn.Parameter(w.clone().to(dev())), torch.nn.Parameter(b.clone().to(dev()))
+    ops.fp8.__init__()
+    with lavt_hip.use_dtype("fp8"):
+        for it in range(2):
+            ops.fp8.advance()
+            xd = x.to(dev()).requires_grad_(True)
+            y = ops.linear(xd, wd, bd)
+        y.float().sum().backward()                                       # backward runs on the bf16 tensors
+    ref = F8.linear_fp8(x, w, b, float(x.float().abs().max()), float(w.abs().max()))
+    assert float((y.detach().float().cpu() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
+    assert float((xd.grad.float().cpu() - w.sum(0).to(torch.bfloat16).float()).abs().max()) <= 3e-2 * float(w.sum(0).abs().max())
