@@ -867,6 +867,9 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     TnGroup g;
     bool maps = false;
     int tiles = 0, ntiles = 0;
+    // tile shape of the group: LAVT_TNG_TILE = 64 (4 waves, default) | 128 (8 waves of 64x32) | 1284 (128x128, 4 waves of 64x64)
+    static const int tng_tile = getenv("LAVT_TNG_TILE") ? atoi(getenv("LAVT_TNG_TILE")) : 64;
+    const int TB = tng_tile == 64 ? 64 : 128;
     for (int i = 0; i < n; ++i) {
         const lavt_gemm_tn_t& p = probs[i];
         if (!tn_v2_eligible(p) || p.batch != 1 || p.conv_kc > 0 || p.B2 || p.I % 8 || p.J % 8) return 1;
@@ -885,13 +888,33 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         const int per = cdiv(ktiles, ns);
         ns = cdiv(ktiles, per);                      // no empty pieces
         g.split[i] = ns;
-        ntiles += cdiv(p.I, 64) * cdiv(p.J, 64);
-        tiles += cdiv(p.I, 64) * cdiv(p.J, 64) * ns;
+        ntiles += cdiv(p.I, TB) * cdiv(p.J, TB);
+        tiles += cdiv(p.I, TB) * cdiv(p.J, TB) * ns;
         g.tile_end[i] = tiles;
     }
     for (int i = n; i < TN_GROUP_MAX; ++i) { g.p[i] = probs[0]; g.tile_end[i] = tiles; g.split[i] = 1; }
     g.n = n;
-    if (ntiles < 256) return 1;                      // too few tiles to fill the chip without (more) split-K
+    if (ntiles < (TB == 64 ? 256 : 96)) return 1;    // too few tiles to fill the chip without (more) split-K
+    if (TB == 128) {
+        const size_t lds128 = 2 * (size_t)(64 * (128 + 128) * 2) + (maps ? 3 * 768 + 256 : 0);
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<128, 128, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<128, 128, 8, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<128, 128, 4, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<128, 128, 4, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+            attr = true;
+        }
+        if (tng_tile == 1284) {
+            if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<128, 128, 4, 2, true>), dim3(tiles), dim3(256), lds128, st, g);
+            else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<128, 128, 4, 2, false>), dim3(tiles), dim3(256), lds128, st, g);
+        } else {
+            if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<128, 128, 8, 2, true>), dim3(tiles), dim3(512), lds128, st, g);
+            else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<128, 128, 8, 2, false>), dim3(tiles), dim3(512), lds128, st, g);
+        }
+        LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
+        return LAVT_OK;
+    }
     // (a 128x64 tile -- 3/4 of the operand bytes per flop -- measured slower on the stage-2 block: 13.34 vs 12.96 ms per step)
     const size_t lds = 2 * (size_t)(64 * (64 + 64) * 2) + (maps ? 3 * 768 + 256 : 0);
     if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true>), dim3(tiles), dim3(256), lds, st, g);

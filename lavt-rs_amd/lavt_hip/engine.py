@@ -81,6 +81,12 @@ class TrainStep:
         torch.cuda.synchronize()
         if not self.use_graph:
             return
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # ProcessGroupNCCL's watchdog thread retires the eager warm-up collectives by polling their events every ~100 ms.  Give it time to
+            # empty its list before the capture window opens: a poll that lands inside the window was seen (1 run in ~10 of the 1-rank-group
+            # test) to fail with hipErrorCapturedEvent and take the process down, also under the thread_local capture mode used below.
+            import time
+            time.sleep(float(os.environ.get("LAVT_CAPTURE_SETTLE_S", "0.5")))
         try:
             g = torch.cuda.CUDAGraph()
             # thread_local: ProcessGroupNCCL's watchdog thread polls events of earlier (eager warm-up) collectives with hipEventQuery; under the

@@ -1390,8 +1390,16 @@ class _ConvTaps(torch.autograd.Function):
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             dx1 = torch.empty_like(x1)
             dx2 = torch.empty_like(x2) if x2 is not None else None
-            gemm_nt(dtype, M, Cin, taps * Cout, dy, Cout, Wp, taps * Cin, dx1, C1, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
-                    b_tap_stride=Cin, C2=dx2, ldc2=C2, c_split=C1)
+            if x2 is not None and C1 % 256 == 0 and C2 % 64 == 0 and dtype == torch.bfloat16 and os.environ.get("LAVT_DGRAD_SPLIT", "1") != "0":
+                # concat convolution (conv1_2: 512 + 128 input channels): N = 640 is not a multiple of the 256-wide tile, so the whole data gradient
+                # fell back to 128x128 tiles (239 us at 2x120x120).  As two launches over column blocks of the packed weight the 512-channel part
+                # runs on the 256x256 tile and the skip part on its own.
+                gemm_nt(dtype, M, C1, taps * Cout, dy, Cout, Wp, taps * Cin, dx1, C1, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True, b_tap_stride=Cin)
+                gemm_nt(dtype, M, C2, taps * Cout, dy, Cout, Wp, taps * Cin, dx2, C2, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True, b_tap_stride=Cin,
+                        b_off=C1)
+            else:
+                gemm_nt(dtype, M, Cin, taps * Cout, dy, Cout, Wp, taps * Cin, dx1, C1, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
+                        b_tap_stride=Cin, C2=dx2, ldc2=C2, c_split=C1)
         dW, wsink = sinks.buf(weight, (Cout, Cin * taps))
         db = bsink = None
         if bias is not None:

@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--only-checkpoint", action="store_true")
     ap.add_argument("--only-bert", action="store_true")
     ap.add_argument("--only-dice", action="store_true")
+    ap.add_argument("--only-w12", action="store_true")
     ap.add_argument("--only-full", default="", help="comma list of full-size (BASELINE.json configs) cases: swin_b,swin_t,video_pwam,video_sept")
     cli = ap.parse_args()
     if cli.only_bert:
@@ -138,6 +139,9 @@ def main():
         return
     if cli.only_dice:
         dice_cases()
+        return
+    if cli.only_w12:
+        video_cases(args, only_w12=True)
         return
     if cli.only_checkpoint:
         checkpoint_cases()
@@ -311,11 +315,27 @@ def dice_cases():
         save(f"dice_{tag}", dims=np.array([B, h, w, H, W]), seeds=np.array([91, 92]), loss=float(loss), dy=y.grad)
 
 
-def video_cases(args_base):
+def video_cases(args_base, only_w12=False):
     """Golden vectors of the video path (lib/video_swin_transformer.py), driven through the reference's own classes."""
     import lib.video_swin_transformer as rv
     from lib import mask_predictor as rmp
     rv.sr_ratio = [1, 1, 1, 1]                    # the shipped file reads an undefined global (SURVEY.md B2); set from outside
+
+    # --- `--window12` video windows: (8, 12, 12) = 1152 tokens per window (lib/segmentation.py:173-176), un-shifted and shifted (0, 6, 6) ---------
+    for shifted in (0, 1):
+        window = (8, 12, 12)
+        B, D, H, W = 1, 8, 24, 24
+        blk = rv.SwinTransformerBlock3D(64, 2, window, shift_size=tuple(w // 2 for w in window) if shifted else (0, 0, 0)).eval()
+        fill_state_dict_(blk)
+        x = randn(73, B, D, H, W, 64)
+        win, shift = rv.get_window_size((D, H, W), window, tuple(w // 2 for w in window))
+        mask = rv.compute_mask(D, H, W, win, shift, "cpu")
+        with torch.no_grad():
+            y = blk(x, mask)
+        save(f"vblock_w12_s{shifted}", dims=np.array([B, D, H, W]), seed=73, y=y[:, :, ::2, ::2], ysum=float(y.double().sum()), yabs=float(y.double().abs().sum()))
+
+    if only_w12:
+        return
 
     # --- 3-D shift masks ---------------------------------------------------------------------------------------
     packs = {}

@@ -261,6 +261,36 @@ def test_video_block_golden(golden, tag, shifted):
     close(y, g["y"], 2e-4, "video swin block")
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shifted", [0, 1])
+def test_video_block_window12_golden(golden, shifted, dtype):
+    """`--window12` video: windows of (8, 12, 12) = 1152 tokens (lib/video_swin_transformer.py:137-168) -- beyond the fused kernels' 400-token
+    limit, on the composed GEMM -> softmax -> GEMM route with [windows x heads, 1152, 1152] scores; forward vs the reference block, and the
+    backward against the same block on the fused-kernel-free fp32 route"""
+    import lavt_hip
+    from lib.video_swin_transformer import SwinTransformerBlock3D
+    g = golden(f"vblock_w12_s{shifted}")
+    B, D, H, W = g["dims"].tolist()
+    blk = SwinTransformerBlock3D(64, 2, (8, 12, 12), (4, 6, 6) if shifted else (0, 0, 0)).eval()
+    fill_state_dict_(blk)
+    blk.to(DEV)
+    x = randn(int(g["seed"]), B, D, H, W, 64).to(DEV).requires_grad_(True)
+    with lavt_hip.use_dtype(torch.float32 if dtype == "fp32" else torch.bfloat16):
+        y = blk(x)
+        y.float().square().sum().backward()
+    ref = torch.as_tensor(g["y"])
+    err = float((y.detach().float().cpu()[:, :, ::2, ::2] - ref).abs().max())
+    assert err <= (2e-4 if dtype == "fp32" else 0.05 * float(ref.abs().max())), err
+    if dtype == "fp32":
+        assert abs(float(y.detach().double().sum()) - float(g["ysum"])) <= 1e-5 * float(g["yabs"])
+        # gradient oracle: the CPU restatement of the block under autograd
+        from oracle import lavt_video_oracle as OV
+        sd = {"b." + k: v.detach().cpu() for k, v in blk.state_dict().items()}
+        xc = x.detach().cpu().requires_grad_(True)
+        OV.swin_block_3d(sd, "b", xc, 2, (8, 12, 12), bool(shifted)).square().sum().backward()
+        assert float((x.grad.cpu() - xc.grad).abs().max()) <= 2e-3 * float(xc.grad.abs().max())
+
+
 def test_video_sep_t_pwam_golden(golden):
     from lib.video_swin_transformer import SepTPWAM
     g = golden("sep_t_pwam")

@@ -300,6 +300,18 @@ def test_video_block(golden, tag, shifted):
     close(OV.swin_block_3d(sd, "b", x, 2, (8, 7, 7), bool(shifted)), g["y"], 1e-4)
 
 
+@pytest.mark.parametrize("shifted", [0, 1])
+def test_video_block_window12(golden, shifted):
+    """`--window12` video windows, (8, 12, 12) = 1152 tokens (lib/video_swin_transformer.py:137-168, SURVEY.md 8 shape row 4'), un-shifted / shifted"""
+    g = golden(f"vblock_w12_s{shifted}")
+    B, D, H, W = g["dims"].tolist()
+    sd = {"b." + k: v for k, v in gen_sd(vblock_spec(64, 2, (8, 12, 12))).items()}
+    x = randn(int(g["seed"]), B, D, H, W, 64)
+    y = OV.swin_block_3d(sd, "b", x, 2, (8, 12, 12), bool(shifted))
+    close(y[:, :, ::2, ::2], g["y"], 1e-4)
+    assert abs(float(y.double().sum()) - float(g["ysum"])) <= 1e-5 * float(g["yabs"])
+
+
 def sept_spec(C, p=""):
     s = {}
     for k, ks in (("temporal_vis_project.0", 3), ("spatial_vis_project.0", 1), ("f_query_t.0", 3), ("f_query_s.0", 1), ("W_t.0", 3), ("W_s.0", 1),
