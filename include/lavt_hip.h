@@ -117,6 +117,7 @@ typedef struct lavt_gemm_nt {
      * conv_kc (and a_split) % 128 == 0 for the tap-walking fast path. */
     const float* deq_a;
     const float* deq_b;
+    int32_t epi_wide; /* set by the library: 16-byte stores from paired accumulator fragments (all row strides / splits 8-element aligned) */
 } lavt_gemm_nt_t;
 
 int lavt_gemm_nt(const lavt_gemm_nt_t* p, void* stream);

@@ -29,7 +29,7 @@ template <typename T> __global__ void act_bwd_kernel(int act, const T* dy, const
         chunk_to_f<T>(*reinterpret_cast<const uint4*>(pre + i * EPC), x);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            if (act == LAVT_ACT_GELU) g[e] *= gelu_grad_f(x[e]);
+            if (act == LAVT_ACT_GELU) g[e] *= std::is_same<T, bf16>::value ? gelu_grad_f_fast(x[e]) : gelu_grad_f(x[e]);
             else if (act == LAVT_ACT_RELU) g[e] = x[e] > 0.f ? g[e] : 0.f;
             else if (act == LAVT_ACT_TANH) { const float t = tanhf(x[e]); g[e] *= 1.f - t * t; }
         }

@@ -436,7 +436,11 @@ extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
     }
     LAVT_CHECK_ARG((!p.R || p.ldr % 4 == 0) && (!p.Cpre || p.ldcpre % 4 == 0), "lavt_gemm_nt: ldr/ldcpre must be multiples of 4");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    { const char* e = getenv("LAVT_GEMM_EPI"); p.epi_lds = (e && e[0] == 'l') ? 1 : 0; }
+    { const char* e = getenv("LAVT_GEMM_EPI"); p.epi_lds = (e && e[0] == 'l') ? 1 : 0;
+      static const bool wide_off = e && e[0] == 'n';          // LAVT_GEMM_EPI=narrow: the 8-byte store form
+      p.epi_wide = (!wide_off && p.dtype != LAVT_F32 && !p.c_f32 && p.ldc % 8 == 0 && (!p.C2 || (p.ldc2 % 8 == 0 && p.c_split % 8 == 0)) && (!p.R || p.ldr % 4 == 0) &&
+                    (!p.Cpre || p.ldcpre % 8 == 0) && (!p.dact_pre || p.lddact % 4 == 0) && (!p.bias || (p.strideBias % 4 == 0 && ((uintptr_t)p.bias % 16) == 0)) &&
+                    ((uintptr_t)p.C % 16) == 0 && (!p.C2 || ((uintptr_t)p.C2 % 16) == 0) && (!p.Cpre || ((uintptr_t)p.Cpre % 16) == 0) && (p.strideC % 8 == 0)) ? 1 : 0; }
     const int rc2 = lavt_gemm_nt_v2(p, st);          // bf16 LDS-DMA pipeline (gemm_v2.hip); 1 = not applicable
     if (rc2 != 1) return rc2;
     LAVT_CHECK_ARG(p.dact_pre == nullptr, "lavt_gemm_nt: dact_pre (fused activation gradient) exists on the bf16 LDS-DMA path only");

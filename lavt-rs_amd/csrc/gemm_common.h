@@ -50,9 +50,9 @@ template <typename T> __device__ __forceinline__ f32x4 mfma16(typename FragT<T>:
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ uint4 zero16() { return make_uint4(0, 0, 0, 0); }
 
-__device__ __forceinline__ float apply_act(int act, float v) {
+template <bool FAST = false> __device__ __forceinline__ float apply_act(int act, float v) {
     switch (act) {
-        case LAVT_ACT_GELU: return gelu_f(v);
+        case LAVT_ACT_GELU: return FAST ? gelu_f_fast(v) : gelu_f(v);
         case LAVT_ACT_RELU: return fmaxf(v, 0.f);
         case LAVT_ACT_TANH: return tanhf(v);
         default: return v;
@@ -116,14 +116,89 @@ __device__ __forceinline__ int xcd_tile_id(int b, int nb) {
 // ---- NT epilogue shared by both generations: accumulators hold C^T tiles (rows = 4 consecutive n per lane, column = m) ----
 __device__ __forceinline__ float act_grad(int act, float pre) {
     switch (act) {
-        case LAVT_ACT_GELU: return gelu_grad_f(pre);
+        case LAVT_ACT_GELU: return gelu_grad_f_fast(pre);          // bf16 data-gradient epilogue only
         case LAVT_ACT_RELU: return pre > 0.f ? 1.f : 0.f;
         case LAVT_ACT_TANH: { const float t = tanhf(pre); return 1.f - t * t; }
         default: return 1.f;
     }
 }
+// ---- wide bf16 stores straight from the accumulators ----------------------------------------------------------------------------------
+// In the C^T accumulator layout a lane holds 4 consecutive n of one row m, and the four lane groups g = lane / 16 hold columns 4g .. 4g+3 of
+// the same 16 rows: stored as they stand, a wave-instruction writes 16 rows x 32 B in 8-byte pieces (measured: a second [1800 x 2048] output
+// -- the pre-activation -- cost a 12 us GEMM another 6 us, i.e. ~1.2 TB/s).  Two neighbouring 16-column fragments are therefore combined:
+// lanes g and g ^ 1 swap one packed pair (ds_bpermute, no memory), after which an even group owns columns 4g .. 4g+7 of the first fragment and
+// an odd group columns 4(g-1) .. 4(g-1)+7 of the second -- one 16-byte store per lane, 64 contiguous bytes per row per wave-instruction, half
+// the store instructions.  Bias is read as float4.  Conditions are checked by the caller (whole 32-column pairs inside N, 16-byte aligned rows).
+__device__ __forceinline__ uint2 xchg16(uint2 v) { return make_uint2((unsigned)__shfl_xor((int)v.x, 16, 64), (unsigned)__shfl_xor((int)v.y, 16, 64)); }
+template <int MI, int NI, bool DACT>
+__device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz) {
+    const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
+    const float* rscale = p.row_scale ? p.row_scale + (int64_t)bz * p.strideRowScale : nullptr;
+    const int64_t c_off = (int64_t)bz * p.strideC;
+    const int g = lane >> 4;
+    const bool odd = g & 1;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m_base + i * 16 + (lane & 15);
+        int orow = -1;
+        if (m < p.M) orow = p.c_rowmap ? p.c_rowmap[m] : m;
+        const bool live = orow >= 0;                         // dead lanes still take part in the exchanges
+        const float rs = (rscale && m < p.M) ? rscale[p.row_scale_div > 1 ? m / p.row_scale_div : m] : 1.f;
+#pragma unroll
+        for (int jp = 0; jp < NI / 2; ++jp) {
+            uint2 packed[2], packed_pre[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = n_base + (2 * jp + h) * 16 + 4 * g;
+                float v[4];
+                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bias) b4 = *reinterpret_cast<const float4*>(bias + n);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (p.alpha * acc[i][2 * jp + h][r] + bb[r]) * rs;
+                if constexpr (DACT) {
+                    if (live) {
+                        const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.dact_pre) + (int64_t)orow * p.lddact + n);
+                        v[0] *= act_grad(p.dact, __uint_as_float(q.x << 16)); v[1] *= act_grad(p.dact, __uint_as_float(q.x & 0xFFFF0000u));
+                        v[2] *= act_grad(p.dact, __uint_as_float(q.y << 16)); v[3] *= act_grad(p.dact, __uint_as_float(q.y & 0xFFFF0000u));
+                    }
+                }
+                packed_pre[h] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                if (p.act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = apply_act<true>(p.act, v[r]);
+                }
+                if (p.R && live) {          // (an fp32 exchange + one 16-byte residual load measured slower than these 8-byte loads: 2.6 vs 2.0 us on the fc1 shape)
+                    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.R) + (int64_t)orow * p.ldr + n);
+                    v[0] += __uint_as_float(q.x << 16); v[1] += __uint_as_float(q.x & 0xFFFF0000u);
+                    v[2] += __uint_as_float(q.y << 16); v[3] += __uint_as_float(q.y & 0xFFFF0000u);
+                }
+                packed[h] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+            // even groups keep fragment 0 and send their fragment-1 piece; odd groups keep fragment 1 and send their fragment-0 piece
+            const uint2 got = xchg16(odd ? packed[0] : packed[1]);
+            const uint4 out = odd ? make_uint4(got.x, got.y, packed[1].x, packed[1].y) : make_uint4(packed[0].x, packed[0].y, got.x, got.y);
+            const int n_out = n_base + (2 * jp + (odd ? 1 : 0)) * 16 + 4 * (g & ~1);
+            if (p.Cpre) {
+                const uint2 gp = xchg16(odd ? packed_pre[0] : packed_pre[1]);
+                const uint4 op = odd ? make_uint4(gp.x, gp.y, packed_pre[1].x, packed_pre[1].y) : make_uint4(packed_pre[0].x, packed_pre[0].y, gp.x, gp.y);
+                if (live) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.Cpre) + (int64_t)orow * p.ldcpre + n_out) = op;
+            }
+            if (live) {
+                const bool second = p.C2 != nullptr && n_out >= p.c_split;
+                bf16* cp = reinterpret_cast<bf16*>(second ? p.C2 : p.C) + c_off + (int64_t)orow * (second ? p.ldc2 : p.ldc) + (second ? n_out - p.c_split : n_out);
+                *reinterpret_cast<uint4*>(cp) = out;
+            }
+        }
+    }
+}
+
 template <typename T, int MI, int NI, bool DACT = false>
 __device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz) {
+    if constexpr (std::is_same<T, bf16>::value && NI % 2 == 0) {
+        // wave-uniform conditions: the whole wave takes one path (the exchanges need every lane)
+        if (!p.c_f32 && p.epi_wide && n_base + NI * 16 <= p.N) { nt_epilogue_wide<MI, NI, DACT>(p, acc, m_base, n_base, lane, bz); return; }
+    }
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
     const float* rscale = p.row_scale ? p.row_scale + (int64_t)bz * p.strideRowScale : nullptr;
     const int64_t c_off = (int64_t)bz * p.strideC;
@@ -160,7 +235,7 @@ __device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc
             }
             if (p.act) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = apply_act<std::is_same<T, bf16>::value>(p.act, v[r]);
             }
             if (p.R) {
                 const T* rp = reinterpret_cast<const T*>(p.R) + (int64_t)orow * p.ldr + n;
@@ -222,13 +297,13 @@ __device__ __forceinline__ void nt_epilogue_lds(const lavt_gemm_nt_t& p, f32x4 (
                     v[r] = p.alpha * acc[i][j][r];
                     if (bias && n + r < p.N) v[r] += bias[n + r];
                     v[r] *= rs[i];
-                    if (!pre && p.act) v[r] = apply_act(p.act, v[r]);
+                    if (!pre && p.act) v[r] = apply_act<true>(p.act, v[r]);
                 }
                 *reinterpret_cast<uint2*>(sC + ml * LD + nl) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < CHUNKS; idx += 256) {
+        for (int idx = tid; idx < CHUNKS; idx += (int)blockDim.x) {
             const int row = idx / CPR, c = idx - row * CPR;
             const int m = m0 + row, n = n0 + c * 8;
             if (m >= p.M || n >= p.N) continue;
