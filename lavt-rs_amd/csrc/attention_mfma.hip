@@ -43,6 +43,16 @@ __device__ __forceinline__ bf16x8 zero8() {
     return z;
 }
 __device__ __forceinline__ bf16x8 ldg8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// A lane holds two packed quadruples of one (token, head) row: channels 4g .. 4g+3 (p0) and 16+4g .. 16+4g+3 (p1), g = lane / 16.  Lanes g and
+// g ^ 1 swap one of them (ds_bpermute, no memory) so that every lane stores 16 contiguous bytes -- 64 contiguous bytes per row and
+// wave-instruction instead of 8-byte pieces.  Every lane of the wave must call (the partner of a valid lane is valid: same row).
+__device__ __forceinline__ void store_head_row16(bf16* row_head, int g, uint2 p0, uint2 p1, bool valid) {
+    const bool odd = g & 1;
+    const uint2 send = odd ? p0 : p1;
+    const uint2 got = make_uint2((unsigned)__shfl_xor((int)send.x, 16, 64), (unsigned)__shfl_xor((int)send.y, 16, 64));
+    const uint4 out = odd ? make_uint4(got.x, got.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, got.x, got.y);
+    if (valid) *reinterpret_cast<uint4*>(row_head + (odd ? 16 + 4 * (g - 1) : 4 * g)) = out;
+}
 
 // ================================================================================================ forward
 // One workgroup (4 waves) per (window, head).  Q, K, V are staged once into LDS by all 256 threads (one round of 16-byte loads in
@@ -159,12 +169,11 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
             o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CACHE ? vf[0][CACHE ? ks : 0] : v_frag(0, ks), pf, o[0], 0, 0, 0);
             o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CACHE ? vf[1][CACHE ? ks : 0] : v_frag(1, ks), pf, o[1], 0, 0, 0);
         }
-        if (vi) {
+        {
             const float inv = 1.f / sum;
-            bf16* dst = out + ((int64_t)w * N + i) * C + h * HD + 4 * g;
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                *reinterpret_cast<uint2*>(dst + 16 * u) = make_uint2(pack_bf16x2(o[u][0] * inv, o[u][1] * inv), pack_bf16x2(o[u][2] * inv, o[u][3] * inv));
+            store_head_row16(out + ((int64_t)w * N + (vi ? i : 0)) * C + h * HD, g,
+                             make_uint2(pack_bf16x2(o[0][0] * inv, o[0][1] * inv), pack_bf16x2(o[0][2] * inv, o[0][3] * inv)),
+                             make_uint2(pack_bf16x2(o[1][0] * inv, o[1][1] * inv), pack_bf16x2(o[1][2] * inv, o[1][3] * inv)), vi);
         }
     }
 }
@@ -295,23 +304,21 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
                                             __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Os + off + 16 * R_LD)));
                     const bf16x8 qt = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Qs + off)),
                                             __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Qs + off + 16 * R_LD)));
-                    dv[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pp, ot, dv[u], 0, 0, 0);
-                    dk[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dp8, qt, dk[u], 0, 0, 0);
+                    // operands swapped (a B fragment of X is the A fragment of X^T): the accumulators hold dV^T / dK^T, i.e. a lane owns 4 consecutive
+                    // channels of ONE key row -- the layout of the dQ accumulators below -- instead of one channel of 4 keys (2-byte stores)
+                    dv[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot, pp, dv[u], 0, 0, 0);
+                    dk[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dp8, dk[u], 0, 0, 0);
                 }
             }
-            // C[m = key 4g+r][n = d = c16 (+16u)]
-            bf16* dst = dqkv + (int64_t)w * N * 3 * C + h * HD + c16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int jj = 16 * jt + 4 * g + r;
-                if (jj < N) {
-                    bf16* row = dst + (int64_t)jj * 3 * C;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        row[C + 16 * u] = (bf16)(dk[u][r] * scale);
-                        row[2 * C + 16 * u] = (bf16)dv[u][r];
-                    }
-                }
+            // C[m = d = 4g+r (+16u)][n = key c16]
+            {
+                const int jj = 16 * jt + c16;
+                const bool vj = jj < N;
+                bf16* row = dqkv + ((int64_t)w * N + (vj ? jj : 0)) * 3 * C + h * HD;
+                store_head_row16(row + C, g, make_uint2(pack_bf16x2(dk[0][0] * scale, dk[0][1] * scale), pack_bf16x2(dk[0][2] * scale, dk[0][3] * scale)),
+                                 make_uint2(pack_bf16x2(dk[1][0] * scale, dk[1][1] * scale), pack_bf16x2(dk[1][2] * scale, dk[1][3] * scale)), vj);
+                store_head_row16(row + 2 * C, g, make_uint2(pack_bf16x2(dv[0][0], dv[0][1]), pack_bf16x2(dv[0][2], dv[0][3])),
+                                 make_uint2(pack_bf16x2(dv[1][0], dv[1][1]), pack_bf16x2(dv[1][2], dv[1][3])), vj);
             }
         }
 
@@ -368,12 +375,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
                 }
             }
             // C[m = d = 4g+r (+16u)][n = query c16]: 4 consecutive channels per lane
-            if (vi) {
-                bf16* dst = dqkv + ((int64_t)w * N + i) * 3 * C + h * HD + 4 * g;
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    *reinterpret_cast<uint2*>(dst + 16 * u) = make_uint2(pack_bf16x2(dq[u][0] * scale, dq[u][1] * scale), pack_bf16x2(dq[u][2] * scale, dq[u][3] * scale));
-            }
+            store_head_row16(dqkv + ((int64_t)w * N + (vi ? i : 0)) * 3 * C + h * HD, g,
+                             make_uint2(pack_bf16x2(dq[0][0] * scale, dq[0][1] * scale), pack_bf16x2(dq[0][2] * scale, dq[0][3] * scale)),
+                             make_uint2(pack_bf16x2(dq[1][0] * scale, dq[1][1] * scale), pack_bf16x2(dq[1][2] * scale, dq[1][3] * scale)), vi);
         }
     }
 }

@@ -652,10 +652,10 @@ class _Mlp(torch.autograd.Function):
 def mlp(x, w1, b1, w2, b2, residual=None, **kw):
     """fc2(GELU(fc1(x))) [* row_scale] [+ residual]; the fused single-node form on the bf16 path, two `linear` ops otherwise"""
     o = LinOpts(**kw)
-    # Measured on MI355X (Swin-B 2x480x480 step, same box, two repeats): 12.59 / 12.58 ms with the fused node vs 12.51 / 12.53 ms without -- the
-    # erf-based GELU' and the 8-byte scattered reads of `pre` in the data-gradient epilogue cost as much as the element-wise pass they replace.
-    # Off by default; LAVT_FUSED_MLP=1 selects it.
-    if x.dtype == torch.bfloat16 and w1.shape[1] % 8 == 0 and w1.shape[0] % 64 == 0 and w2.shape[0] % 64 == 0 and os.environ.get("LAVT_FUSED_MLP", "0") == "1":
+    # Measured on MI355X (Swin-B 2x480x480 step, same box, two repeats each).  With the library erff and 8-byte epilogue stores the fused node lost
+    # (12.59 / 12.58 ms vs 12.51 / 12.53 ms); with the fast erf and the 16-byte paired-fragment stores it is level or slightly ahead
+    # (11.94 / 11.91 ms vs 11.94 / 11.97 ms) and saves the [M, 4C] round trip.  LAVT_FUSED_MLP=0 selects the two-op form.
+    if x.dtype == torch.bfloat16 and w1.shape[1] % 8 == 0 and w1.shape[0] % 64 == 0 and w2.shape[0] % 64 == 0 and os.environ.get("LAVT_FUSED_MLP", "1") != "0":
         return _Mlp.apply(x, w1, b1, w2, b2, residual, o)
     h = linear(x, w1, b1, act=K.ACT_GELU)
     return linear(h, w2, b2, residual=residual, **kw)
