@@ -497,7 +497,8 @@ __device__ __forceinline__ void dma4(const void* src, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 4, 0, 0);
 }
 
-template <int BI, int BJ, int WAVES, int STAGES, bool MAPS>
+// CS: how the bias gradient (colsum) is produced -- 0 none, 1 scalar walk of the LDS tile by the first BI threads, 2 on the matrix cores
+template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS>
 __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_linear, const int bz, const int split_idx, const int kt_per_split,
                                         const int nsplit, char* smem) {
     using T = bf16;
@@ -679,8 +680,21 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
     for (int i = 0; i < II; ++i)
 #pragma unroll
         for (int j = 0; j < JJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient colsum[i] = sum_k A[k][i] of the tile_j == 0 workgroups.  CS == 2: one more "column" of the contraction -- the A fragments
+    // times a fragment of ones, on the matrix cores, by the waves of the first wave column.  The scalar form (CS == 1: one thread per column
+    // walking the 64 K rows of the LDS tile) runs on a single wave while the others wait at the barrier, with 46 % of its LDS cycles bank
+    // conflicts: where few workgroups carry it (many column tiles: the grouped Swin-block launch, 62.8 -> 54.0 us) they were the tail of the
+    // launch; where every second workgroup carries it (J = 128: PWAM's 1x1 convolutions) the scalar walk hides better.  A template
+    // parameter: the extra accumulators cost the colsum-free 128x128 conv kernels 40 % when they were unconditional.
+    const bool cs_wave = CS == 2 && (p.colsum != nullptr) && tile_j == 0 && wj == 0;
+    f32x4 cacc[CS == 2 ? II : 1];
+#pragma unroll
+    for (int i = 0; i < (CS == 2 ? II : 1); ++i) cacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
     float csum = 0.f;
-    const bool do_colsum = (p.colsum != nullptr) && tile_j == 0 && tid < BI;
+    const bool do_colsum = CS == 1 && (p.colsum != nullptr) && tile_j == 0 && tid < BI;
 
     // prologue: side inputs of the first AHEAD tiles, then the first STAGES-1 data tiles (each followed by one map DMA: uniform groups)
     if constexpr (MAPS) {
@@ -713,10 +727,21 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
                 acc[i][jj] = mfma16<T>(frag_from(al0[i], ah0[i]), frag_from(bl0[jj], bh0[jj]), acc[i][jj]);
                 acc[i][jj] = mfma16<T>(frag_from(al1[i], ah1[i]), frag_from(bl1[jj], bh1[jj]), acc[i][jj]);
             }
-        if (do_colsum) {
-            const T* col = reinterpret_cast<const T*>(cA) + (tid & 7);
+        if constexpr (CS == 2) {
+            if (cs_wave) {
+#pragma unroll
+                for (int i = 0; i < II; ++i) {
+                    cacc[i] = mfma16<T>(frag_from(al0[i], ah0[i]), ones, cacc[i]);
+                    cacc[i] = mfma16<T>(frag_from(al1[i], ah1[i]), ones, cacc[i]);
+                }
+            }
+        }
+        if constexpr (CS == 1) {
+            if (do_colsum) {
+                const T* col = reinterpret_cast<const T*>(cA) + (tid & 7);
 #pragma unroll 8
-            for (int k = 0; k < BK; ++k) csum += to_f<T>(col[k * BI + (((tid >> 3) ^ tn_swz<A_CH>(k)) << 3)]);
+                for (int k = 0; k < BK; ++k) csum += to_f<T>(col[k * BI + (((tid >> 3) ^ tn_swz<A_CH>(k)) << 3)]);
+            }
         }
     }
 
@@ -739,16 +764,29 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
             }
         }
     }
-    if (do_colsum && i0 + tid < p.I) {
-        float* cs = p.colsum + (int64_t)bz * p.strideColsum + i0 + tid;
-        if (atomic) atomicAdd(cs, csum * p.alpha); else *cs = csum * p.alpha;      // one tile_j == 0 workgroup per I tile when the reduction is not split
+    if constexpr (CS == 1) {
+        if (do_colsum && i0 + tid < p.I) {
+            float* cs = p.colsum + (int64_t)bz * p.strideColsum + i0 + tid;
+            if (atomic) atomicAdd(cs, csum * p.alpha); else *cs = csum * p.alpha;
+        }
+    }
+    if (CS == 2 && cs_wave && (lane & 15) == 0) {          // every column of cacc holds the same sums: lanes of column 0 write rows 4 (lane / 16) + r
+#pragma unroll
+        for (int i = 0; i < (CS == 2 ? II : 1); ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ii = i0 + wi * WI + i * 16 + 4 * (lane >> 4) + r;
+                if (ii >= p.I) continue;
+                float* cs = p.colsum + (int64_t)bz * p.strideColsum + ii;
+                if (atomic) atomicAdd(cs, cacc[i][r] * p.alpha); else *cs = cacc[i][r] * p.alpha;      // one tile_j == 0 workgroup per I tile when the reduction is not split
+            }
     }
 }
 
-template <int BI, int BJ, int WAVES, int STAGES, bool MAPS>
+template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS>
 __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_tn_t p, int kt_per_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    tn_tile<BI, BJ, WAVES, STAGES, MAPS>(p, blockIdx.x, blockIdx.y, blockIdx.z, kt_per_split, gridDim.z, smem);
+    tn_tile<BI, BJ, WAVES, STAGES, MAPS, CS>(p, blockIdx.x, blockIdx.y, blockIdx.z, kt_per_split, gridDim.z, smem);
 }
 
 // Several independent weight-gradient problems in ONE launch (the four wgrads of a Swin block): together they fill the chip without
@@ -761,7 +799,7 @@ struct TnGroup {
     int split[TN_GROUP_MAX];         // K splits of problem k (1 = single writer per output element, plain stores)
     int n;
 };
-template <int BI, int BJ, int WAVES, int STAGES, bool MAPS>
+template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS>
 __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_grouped_kernel(const TnGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int k = 0;
@@ -770,14 +808,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_grouped_kernel(const Tn
     const lavt_gemm_tn_t& p = g.p[k];
     const int ns = g.split[k], ktiles = (p.K + 63) / 64;
     // the splits of a tile sit next to each other (local % ns): neighbours in time share the output tile's cache lines for their atomics
-    tn_tile<BI, BJ, WAVES, STAGES, MAPS>(p, local / ns, 0, local % ns, (ktiles + ns - 1) / ns, ns, smem);
+    tn_tile<BI, BJ, WAVES, STAGES, MAPS, CS>(p, local / ns, 0, local % ns, (ktiles + ns - 1) / ns, ns, smem);
 }
 
-template <int BI, int BJ, int WAVES, int STAGES, bool MAPS> int launch_tn_v2_(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
+template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS> int launch_tn_v2_(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
     constexpr size_t lds = STAGES * (size_t)(64 * (BI + BJ) * 2) + (MAPS ? (2 * (STAGES - 1) + 1) * 768 + 256 : 0);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             lavt_set_error("lavt_gemm_tn(v2): cannot reserve %zu bytes of LDS", lds);
             return LAVT_ERR_LAUNCH;
         }
@@ -786,15 +824,20 @@ template <int BI, int BJ, int WAVES, int STAGES, bool MAPS> int launch_tn_v2_(co
     const int ktiles = cdiv(p.K, 64);
     const int per = cdiv(ktiles, split);
     dim3 grid(cdiv(p.I, BI) * cdiv(p.J, BJ), p.batch, cdiv(ktiles, per));
-    hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS>), grid, dim3(WAVES * 64), lds, st, p, per);
+    hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS>), grid, dim3(WAVES * 64), lds, st, p, per);
     LAVT_CHECK_LAUNCH("lavt_gemm_tn(v2)");
     return LAVT_OK;
 }
-template <int BI, int BJ, int WAVES> int launch_tn_v2(const lavt_gemm_tn_t& p, int split, int stages, hipStream_t st) {
+// two-stage ring only (3 / 4 stages cost a resident workgroup per CU and lost end to end in round 1: those instantiations are gone)
+template <int BI, int BJ, int WAVES> int launch_tn_v2(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
     const bool maps = p.a_rowmap || p.a_rowscale || p.b_rowmap;
-    if (stages <= 2) return maps ? launch_tn_v2_<BI, BJ, WAVES, 2, true>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 2, false>(p, split, st);
-    if (stages == 3) return maps ? launch_tn_v2_<BI, BJ, WAVES, 3, true>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 3, false>(p, split, st);
-    return maps ? launch_tn_v2_<BI, BJ, WAVES, 4, true>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 4, false>(p, split, st);
+    // colsum on the matrix cores when the workgroups carrying it are a minority (>= 4 column tiles), the scalar walk otherwise; 128x128: scalar
+    const int cs = !p.colsum ? 0 : ((BI == 64 && cdiv(p.J, BJ) >= 4) ? 2 : 1);
+    if constexpr (BI == 64) {
+        if (cs == 2) return maps ? launch_tn_v2_<BI, BJ, WAVES, 2, true, 2>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 2, false, 2>(p, split, st);
+    }
+    if (cs) return maps ? launch_tn_v2_<BI, BJ, WAVES, 2, true, 1>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 2, false, 1>(p, split, st);
+    return maps ? launch_tn_v2_<BI, BJ, WAVES, 2, true, 0>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 2, false, 0>(p, split, st);
 }
 
 }  // namespace
@@ -867,9 +910,8 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     TnGroup g;
     bool maps = false;
     int tiles = 0, ntiles = 0;
-    // tile shape of the group: LAVT_TNG_TILE = 64 (4 waves, default) | 128 (8 waves of 64x32) | 1284 (128x128, 4 waves of 64x64)
-    static const int tng_tile = getenv("LAVT_TNG_TILE") ? atoi(getenv("LAVT_TNG_TILE")) : 64;
-    const int TB = tng_tile == 64 ? 64 : 128;
+    constexpr int TB = 64;          // (128x128 tiles, 8 or 4 waves, measured level or slower on the stage-2 block: 12.44 / 12.94 vs 12.46 ms per step)
+    bool any_colsum = false;
     for (int i = 0; i < n; ++i) {
         const lavt_gemm_tn_t& p = probs[i];
         if (!tn_v2_eligible(p) || p.batch != 1 || p.conv_kc > 0 || p.B2 || p.I % 8 || p.J % 8) return 1;
@@ -877,6 +919,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         // tiles) would run serially inside one workgroup while short-K members (BERT layers, K = 40 rows) supply the tile count
         if (cdiv(p.K, 64) > 128) return 1;
         maps = maps || p.a_rowmap || p.a_rowscale || p.b_rowmap;
+        any_colsum = any_colsum || p.colsum != nullptr;
         g.p[i] = p;
         // A member whose C holds zeros (split_k < 0: the step harness' zeroed flat gradient buffer) may split a long reduction:
         // the launch lasts as long as its longest serial chain of K tiles (~1 us each with one tile in flight), e.g. 41 for the window-ordered
@@ -894,31 +937,15 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     }
     for (int i = n; i < TN_GROUP_MAX; ++i) { g.p[i] = probs[0]; g.tile_end[i] = tiles; g.split[i] = 1; }
     g.n = n;
-    if (ntiles < (TB == 64 ? 256 : 96)) return 1;    // too few tiles to fill the chip without (more) split-K
-    if (TB == 128) {
-        const size_t lds128 = 2 * (size_t)(64 * (128 + 128) * 2) + (maps ? 3 * 768 + 256 : 0);
-        static bool attr = false;
-        if (!attr) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<128, 128, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<128, 128, 8, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<128, 128, 4, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<128, 128, 4, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-            attr = true;
-        }
-        if (tng_tile == 1284) {
-            if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<128, 128, 4, 2, true>), dim3(tiles), dim3(256), lds128, st, g);
-            else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<128, 128, 4, 2, false>), dim3(tiles), dim3(256), lds128, st, g);
-        } else {
-            if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<128, 128, 8, 2, true>), dim3(tiles), dim3(512), lds128, st, g);
-            else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<128, 128, 8, 2, false>), dim3(tiles), dim3(512), lds128, st, g);
-        }
-        LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
-        return LAVT_OK;
-    }
-    // (a 128x64 tile -- 3/4 of the operand bytes per flop -- measured slower on the stage-2 block: 13.34 vs 12.96 ms per step)
+    if (ntiles < 256) return 1;                      // too few tiles to fill the chip without (more) split-K
     const size_t lds = 2 * (size_t)(64 * (64 + 64) * 2) + (maps ? 3 * 768 + 256 : 0);
-    if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true>), dim3(tiles), dim3(256), lds, st, g);
-    else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, false>), dim3(tiles), dim3(256), lds, st, g);
+    if (any_colsum) {
+        if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true, 2>), dim3(tiles), dim3(256), lds, st, g);
+        else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, false, 2>), dim3(tiles), dim3(256), lds, st, g);
+    } else {
+        if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true, 0>), dim3(tiles), dim3(256), lds, st, g);
+        else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, false, 0>), dim3(tiles), dim3(256), lds, st, g);
+    }
     LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
     return LAVT_OK;
 }
@@ -954,8 +981,6 @@ int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st) {
         if (split < 1) split = 1;
     }
     if (split > ktiles) split = ktiles;
-    const char* sg = getenv("LAVT_TN_STAGES");
-    const int stages = sg ? atoi(sg) : 2;          // measured: 3 stages cost a resident workgroup per CU and lose end to end
-    if (big) return launch_tn_v2<128, 128, 8>(p, split, stages > 3 ? 3 : stages, st);
-    return launch_tn_v2<64, 64, 4>(p, split, stages, st);
+    if (big) return launch_tn_v2<128, 128, 8>(p, split, st);
+    return launch_tn_v2<64, 64, 4>(p, split, st);
 }
