@@ -234,14 +234,14 @@ int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, const int32_t* 
  * Per-channel statistics over rows, and the normalisations built on them:
  *   InstanceNorm1d over all H*W positions (PWAM f_query / W, lib/backbone.py:1311-1327): groups = batch;
  *   BatchNorm2d (+ReLU) of the decoder (lib/mask_predictor.py:19-37; SyncBN = all-reduce of sums between the calls).
- * lavt_colstats: x [groups][rows][C] -> sum = sum_r x and m2 = sum_r (x - mean_group)^2, fp32 [groups][C] (pass zeroed buffers).
+ * lavt_colstats: x [groups][rows][C] -> sum = sum_r x and m2 = sum_r (x - mean_group)^2, fp32 [groups][C] (with scratch the call clears them itself; without it pass zeroed buffers).
  *   The second moment is centred (accumulated about the group's first row, then re-centred), never E[x^2]-E[x]^2.
  *   Combining ranks (SyncBN): all-reduce sum -> global mean; m2_r += rows_r*(mean_r - mean)^2; all-reduce m2.
  * lavt_stats_finalize: mean = sum/count, var = m2/count (biased), rstd = 1/sqrt(var+eps); optional running-stat update (unbiased var).
  * ws / ws_floats (here, in lavt_norm_bwd_stats and lavt_layernorm_bwd): optional fp32 scratch of >= 1025*groups*2*C floats; with it the
  *   per-workgroup partial sums are written out and reduced by a second tiny kernel instead of contending atomics on the same C addresses.
  * lavt_norm_apply: y = ((x-mean)*rstd*gamma + beta) (*mul) with optional ReLU; mean/rstd [groups][C]; gamma/beta/mul optional.
- * lavt_norm_bwd_stats: s1 += sum(g), s2 += sum(g*xhat) with g = dy (*mul) masked by relu (y>0);  [groups][C].
+ * lavt_norm_bwd_stats: s1 = sum(g), s2 = sum(g*xhat) (cleared by the call when scratch is given, else added to the zeroed buffers passed in) with g = dy (*mul) masked by relu (y>0);  [groups][C].
  * lavt_norm_bwd_apply: dx = gamma*rstd*(g - s1/n - xhat*s2/n); dmul = dy*xhat_affine (optional).
  * ------------------------------------------------------------------------------------------- */
 int lavt_colstats(int dtype, const void* x, float* sum, float* m2, float* ws, int64_t ws_floats, int groups, int rows, int C, void* stream);

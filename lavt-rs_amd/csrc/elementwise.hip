@@ -63,25 +63,49 @@ template <typename T> __global__ void gate_bwd_kernel(const T* dxo, const T* gpr
 }
 
 // ---------------------------------------------------------------------------------------------- PWAM word softmax
-template <typename T> __global__ void rowsoftmax_fwd_kernel(const T* s, T* p, int64_t rows, int n_l, int ld) {
+// A thread per row, the whole row (ld <= 32 elements: 4 / 8 sixteen-byte chunks) in registers: loaded at once, stored at once.  (The first
+// version walked the row three times with 2-byte loads and stored it element by element: a ~15 us dependent chain whatever the row count.)
+template <typename T> __global__ __launch_bounds__(256) void rowsoftmax_fwd_kernel(const T* __restrict__ s, T* __restrict__ p, int64_t rows, int n_l, int ld) {
+    constexpr int EPC = Chunk<T>::N, MAXC = 32 / EPC;
+    const int nch = ld / EPC;
     GRID_STRIDE(r, rows) {
-        const T* sr = s + r * ld;
-        T* pr = p + r * ld;
+        float v[32];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < nch) chunk_to_f<T>(*reinterpret_cast<const uint4*>(s + r * ld + c * EPC), v + c * EPC);
         float mx = -INFINITY;
-        for (int j = 0; j < n_l; ++j) mx = fmaxf(mx, to_f<T>(sr[j]));
+#pragma unroll
+        for (int j = 0; j < 32; ++j) if (j < n_l) mx = fmaxf(mx, v[j]);
         float sum = 0.f;
-        for (int j = 0; j < n_l; ++j) sum += __expf(to_f<T>(sr[j]) - mx);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { v[j] = j < n_l ? __expf(v[j] - mx) : 0.f; sum += v[j]; }
         const float inv = 1.f / sum;
-        for (int j = 0; j < ld; ++j) pr[j] = from_f<T>(j < n_l ? __expf(to_f<T>(sr[j]) - mx) * inv : 0.f);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] *= inv;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < nch) *reinterpret_cast<uint4*>(p + r * ld + c * EPC) = f_to_chunk<T>(v + c * EPC);
     }
 }
-template <typename T> __global__ void rowsoftmax_bwd_kernel(const T* p, const T* dp, T* ds, int64_t rows, int n_l, int ld) {
+template <typename T> __global__ __launch_bounds__(256) void rowsoftmax_bwd_kernel(const T* __restrict__ p, const T* __restrict__ dp, T* __restrict__ ds, int64_t rows, int n_l, int ld) {
+    constexpr int EPC = Chunk<T>::N, MAXC = 32 / EPC;
+    const int nch = ld / EPC;
     GRID_STRIDE(r, rows) {
-        const T* pr = p + r * ld;
-        const T* dr = dp + r * ld;
+        float pv[32], dv[32];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < nch) {
+                chunk_to_f<T>(*reinterpret_cast<const uint4*>(p + r * ld + c * EPC), pv + c * EPC);
+                chunk_to_f<T>(*reinterpret_cast<const uint4*>(dp + r * ld + c * EPC), dv + c * EPC);
+            }
         float dot = 0.f;
-        for (int j = 0; j < n_l; ++j) dot += to_f<T>(pr[j]) * to_f<T>(dr[j]);
-        for (int j = 0; j < ld; ++j) ds[r * ld + j] = from_f<T>(j < n_l ? to_f<T>(pr[j]) * (to_f<T>(dr[j]) - dot) : 0.f);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) if (j < n_l) dot += pv[j] * dv[j];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) dv[j] = j < n_l ? pv[j] * (dv[j] - dot) : 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < nch) *reinterpret_cast<uint4*>(ds + r * ld + c * EPC) = f_to_chunk<T>(dv + c * EPC);
     }
 }
 
@@ -504,13 +528,13 @@ extern "C" int lavt_gate_bwd(int dtype, const void* dxo, const void* gpre, const
     return LAVT_OK;
 }
 extern "C" int lavt_rowsoftmax_fwd(int dtype, const void* s, void* p, int64_t rows, int n_l, int ld, void* stream) {
-    LAVT_CHECK_ARG(s && p && rows > 0 && n_l > 0 && n_l <= ld, "lavt_rowsoftmax_fwd: bad arguments");
+    LAVT_CHECK_ARG(s && p && rows > 0 && n_l > 0 && n_l <= ld && ld <= 32 && ld % EPC_OF(dtype) == 0, "lavt_rowsoftmax_fwd: bad arguments (ld <= 32, a multiple of the 16-byte chunk)");
     DISPATCH_T(dtype, "lavt_rowsoftmax_fwd", hipLaunchKernelGGL(rowsoftmax_fwd_kernel<T>, dim3(ew_grid(rows)), dim3(256), 0, ST, (const T*)s, (T*)p, rows, n_l, ld));
     LAVT_CHECK_LAUNCH("lavt_rowsoftmax_fwd");
     return LAVT_OK;
 }
 extern "C" int lavt_rowsoftmax_bwd(int dtype, const void* p, const void* dp, void* ds, int64_t rows, int n_l, int ld, void* stream) {
-    LAVT_CHECK_ARG(p && dp && ds && rows > 0 && n_l > 0 && n_l <= ld, "lavt_rowsoftmax_bwd: bad arguments");
+    LAVT_CHECK_ARG(p && dp && ds && rows > 0 && n_l > 0 && n_l <= ld && ld <= 32 && ld % EPC_OF(dtype) == 0, "lavt_rowsoftmax_bwd: bad arguments (ld <= 32, a multiple of the 16-byte chunk)");
     DISPATCH_T(dtype, "lavt_rowsoftmax_bwd", hipLaunchKernelGGL(rowsoftmax_bwd_kernel<T>, dim3(ew_grid(rows)), dim3(256), 0, ST, (const T*)p, (const T*)dp, (T*)ds, rows, n_l, ld));
     LAVT_CHECK_LAUNCH("lavt_rowsoftmax_bwd");
     return LAVT_OK;

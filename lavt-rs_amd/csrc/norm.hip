@@ -223,7 +223,7 @@ template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, const T* __restrict__ xin, const T* __restrict__ yout,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const T* __restrict__ mul, int relu, float* __restrict__ o1,
-                                                       float* __restrict__ o2, float* __restrict__ partials, int rows, int C, int rows_per_block) {
+                                                       float* __restrict__ o2, float* __restrict__ partials, int rows, int C, int rows_per_block, int zero_out) {
     // !BWD: a = x; o1 += sum (x-K), o2 += sum (x-K)^2, K = x[g][0][:].     BWD: a = dy; g = dy (*mul) (masked y>0); o1 += sum g, o2 += sum g*xhat
     constexpr int EPC = Chunk<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -234,6 +234,10 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, 
     float s1[EPC], s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    // two-stage form: the outputs are produced by the reduce kernel that FOLLOWS this launch (it adds: several row slices may meet there),
+    // so the first row block clears them here and the caller needs no zero-fill launch of its own
+    if (partials && zero_out && blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += 256) { o1[(int64_t)g * C + c] = 0.f; o2[(int64_t)g * C + c] = 0.f; }
     // chunk columns are walked in slabs of 256 when cpr > 256 is impossible here (C <= 2048 -> cpr <= 512)
     for (int cbase = 0; cbase < cpr; cbase += 256) {
         const int span = min(256, cpr - cbase);
@@ -507,7 +511,7 @@ extern "C" int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq,
     float* partials = (ws && ws_floats >= (int64_t)blocks * groups * 2 * C) ? ws : nullptr;
     DISPATCH_T(dtype, "lavt_colstats",
                hipLaunchKernelGGL((colstats_kernel<T, false>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
-                                  (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, 0, sum, sumsq, partials, rows, C, rpb));
+                                  (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, 0, sum, sumsq, partials, rows, C, rpb, 1));
     if (partials) hipLaunchKernelGGL(reduce_partials_kernel, reduce_partials_grid(blocks, groups * 2 * C), dim3(256), 0, st, partials, blocks, groups * 2 * C, C, sum, sumsq);
     DISPATCH_T(dtype, "lavt_colstats",
                hipLaunchKernelGGL(colstats_center_kernel<T>, dim3(cdiv(groups * C, 256)), dim3(256), 0, st, (const T*)x, sum, sumsq, rows, C, groups * C));
@@ -539,6 +543,7 @@ extern "C" int lavt_norm_bwd_stats(int dtype, const void* dy, const void* x, con
                                    const float* gamma, const float* beta, const void* mul, int relu, float* s1, float* s2,
                                    float* ws, int64_t ws_floats, int groups, int rows, int C, void* stream) {
     (void)gamma; (void)beta;
+    const int zero_out = 1;          // with scratch (two-stage form) s1 / s2 are cleared by this call; without it they must arrive zeroed (atomics)
     const int epc = dtype == LAVT_F32 ? 4 : 8;
     LAVT_CHECK_ARG(dy && x && mean && rstd && s1 && s2 && (!relu || y) && groups > 0 && rows > 0 && C % epc == 0, "lavt_norm_bwd_stats: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -547,7 +552,7 @@ extern "C" int lavt_norm_bwd_stats(int dtype, const void* dy, const void* x, con
     float* partials = (ws && ws_floats >= (int64_t)blocks * groups * 2 * C) ? ws : nullptr;
     DISPATCH_T(dtype, "lavt_norm_bwd_stats",
                hipLaunchKernelGGL((colstats_kernel<T, true>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
-                                  (const T*)dy, (const T*)x, (const T*)y, mean, rstd, (const T*)mul, relu, s1, s2, partials, rows, C, rpb));
+                                  (const T*)dy, (const T*)x, (const T*)y, mean, rstd, (const T*)mul, relu, s1, s2, partials, rows, C, rpb, zero_out));
     if (partials) hipLaunchKernelGGL(reduce_partials_kernel, reduce_partials_grid(blocks, groups * 2 * C), dim3(256), 0, st, partials, blocks, groups * 2 * C, C, s1, s2);
     LAVT_CHECK_LAUNCH("lavt_norm_bwd_stats");
     return LAVT_OK;

@@ -842,7 +842,7 @@ def window_attention(qkv, table, region, win, heads, N=None):
 
 # ------------------------------------------------------------------------------------------ Instance / Batch norm
 def _stats(x, groups, rows, Cc):
-    s = torch.zeros(2, groups, Cc, dtype=torch.float32, device=x.device)
+    s = torch.empty(2, groups, Cc, dtype=torch.float32, device=x.device)       # cleared by the kernel (two-stage form)
     ws = _scratch(1025 * groups * 2 * Cc, x.device)
     K.check(K.lib.lavt_colstats(K.dt(x.dtype), K.ptr(x), K.ptr(s[0]), K.ptr(s[1]), K.ptr(ws), ws.numel(), groups, rows, Cc, K.stream()))
     return s
@@ -873,7 +873,7 @@ class _InstanceNorm(torch.autograd.Function):
         x, mul, mean, rstd = ctx.saved_tensors
         B, T, Cc = ctx.dims
         dy = dy.contiguous()
-        s = torch.zeros(2, B, Cc, dtype=torch.float32, device=x.device)
+        s = torch.empty(2, B, Cc, dtype=torch.float32, device=x.device)         # cleared by lavt_norm_bwd_stats (two-stage form)
         d = K.dt(x.dtype)
         ws = _scratch(1025 * B * 2 * Cc, x.device)
         K.check(K.lib.lavt_norm_bwd_stats(d, K.ptr(dy), K.ptr(x), None, K.ptr(mean), K.ptr(rstd), None, None, K.ptr(mul), 0,
@@ -946,7 +946,7 @@ class _HipBnKernels:
         """-> (sum dy', sum dy' * xhat) as two [C] fp32 tensors; `out` = two zeroed buffers to accumulate into (the parameters' gradient sinks)"""
         R, Cc = x.shape
         if out is None:
-            s = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)
+            s = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
             out = (s[0], s[1])
         ws = _scratch(1025 * 2 * Cc, x.device)
         K.check(K.lib.lavt_norm_bwd_stats(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(y), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)),
