@@ -163,6 +163,16 @@ def profile_step(step, cfg, device, reps=3):
     roof = {"bound": "mfma", "kernel": f"{dname} [{dshape}] -- largest us/step of the step, timed per launch inside eager steps", "achieved": round(ach, 2),
             "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "avg_launch_us": round(dv[1] / dv[0], 2),
             "flops_per_launch": dv[2] / dv[0], "launches_per_step": round(dv[0] / reps, 1), "us_per_step": round(dv[1] / reps, 1), "traffic": None}
+    if dname == "lavt_gemm_tn_grouped":
+        # fabric-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE on
+        # tools/wgrad_group_one.py, the same four problems): a recorded constant, not a measurement of this run
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_conv_and_grouped_wgrad.json")))["wgrad_group_one"]["derived"]
+            roof["traffic"] = int(pm["fabric_bytes (FETCH_SIZE KB x2 gfx950 correction + WRITE_SIZE KB)"])
+            roof["traffic_source"] = "profiles/r02_pmc_conv_and_grouped_wgrad.json (recorded)"
+            roof["algorithmic_bytes"] = int(2 * (1536 * 2592 + 512 * 2592 + 512 * 2592 + 512 * 2592 + 2 * (2048 * 1800 + 512 * 1800)) + 4 * (1536 * 512 + 512 * 512 + 2 * 2048 * 512))
+        except Exception:  # noqa: BLE001
+            pass
     scope_us = {k: round(v[0] / reps, 1) for k, v in sorted(scopes.items(), key=lambda kv: -kv[1][0])}
     out = {"eager_kernel_us_per_step": round(total_us, 1), "top_families": table, "scope_us_per_step": scope_us}
     if cfg["flops"] == "swin_b_w12_480":
