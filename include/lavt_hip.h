@@ -227,6 +227,14 @@ int lavt_layernorm_fwd(int dtype, const void* x, const int32_t* gather, const fl
 int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
                        const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats,
                        const void* dres, int rows, int C, void* stream);
+/* Deferred form: the weight / bias gradients of a LayerNorm feed nothing but the gradient buffer, so their partial sums need not be reduced
+ * inside backward.  lavt_layernorm_bwd_partial writes ONLY the per-workgroup partials (ws: >= lavt_layernorm_bwd_blocks(...) * 2 * C floats,
+ * [block][dgamma | dbeta][C]) besides dx; lavt_reduce_partials_multi later adds any number of such partial sets into their gradients in ONE
+ * launch: desc = device int64 [n][5] rows {partials, blocks, C, dgamma, dbeta}.  (60 two-kernel reductions per Swin-B step -> 1 launch.) */
+int lavt_layernorm_bwd_blocks(int dtype, int rows, int C);
+int lavt_layernorm_bwd_partial(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma, const float* mean,
+                               const float* rstd, void* dx, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream);
+int lavt_reduce_partials_multi(const int64_t* desc, int n, void* stream);
 /* dres (optional, [rows][C], not with gather): gradient of the residual stream that bypassed the LayerNorm (x -> LN(x) and x -> + ...):
  * dx = LN'(dy) + dres in the same pass, instead of a separate element-wise add of the two gradients of x */
 

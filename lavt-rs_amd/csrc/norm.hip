@@ -215,6 +215,31 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
         else dst[(int64_t)(g2 >> 1) * C + c] += t;
     }
 }
+// Several partial sets in one launch (deferred LayerNorm weight / bias gradients): grid = (column blocks of 32, row slices, sets).
+// desc[s] = {partials, nblk, C, o1, o2}; partials [nblk][2][C]; the row slices of a set meet through atomics.
+__global__ __launch_bounds__(256) void reduce_partials_multi_kernel(const int64_t* __restrict__ desc) {
+    const int64_t* d = desc + (int64_t)blockIdx.z * 5;
+    const float* partials = reinterpret_cast<const float*>(d[0]);
+    const int nblk = (int)d[1], C = (int)d[2], W = 2 * C;
+    float* o1 = reinterpret_cast<float*>(d[3]);
+    float* o2 = reinterpret_cast<float*>(d[4]);
+    if ((int)blockIdx.x * 32 >= W) return;
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int w = blockIdx.x * 32 + col;
+    const int per = (nblk + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * per, k1 = min(nblk, k0 + per);
+    float a = 0.f;
+    if (w < W)
+        for (int k = k0 + slice; k < k1; k += 8) a += partials[(int64_t)k * W + w];
+    red[slice][col] = a;
+    __syncthreads();
+    if (slice == 0 && w < W && k0 < k1) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][col];
+        atomicAdd((w >= C ? o2 : o1) + (w >= C ? w - C : w), t);
+    }
+}
 static inline dim3 reduce_partials_grid(int nblk, int W) { return dim3(cdiv(W, 32), nblk >= 128 ? 4 : (nblk >= 48 ? 2 : 1)); }
 
 // ---------------------------------------------------------------------------------------------- column statistics
@@ -461,29 +486,55 @@ extern "C" int lavt_layernorm_fwd(int dtype, const void* x, const int32_t* gathe
     return LAVT_OK;
 }
 
-extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
-                                  const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats,
-                                  const void* dres, int rows, int C, void* stream) {
+static int ln_bwd_geometry(int dtype, int rows, int C, int* lpr_out, int* cpl_out) {
     const int epc = dtype == LAVT_F32 ? 4 : 8;
-    LAVT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "lavt_layernorm_bwd: bad arguments");
-    LAVT_CHECK_ARG(C > 0 && C <= 2048 && C % epc == 0 && (!gather || (C / 4) % epc == 0), "lavt_layernorm_bwd: unsupported C=%d", C);
-    LAVT_CHECK_ARG(!(gather && dres), "lavt_layernorm_bwd: dres is not supported together with gather");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nchunk = C / epc;
     const int lpr = nchunk <= 16 ? 16 : nchunk <= 32 ? 32 : 64;
     const int cpl = cdiv(nchunk, lpr);                       // 1 (C <= 512 bf16 / 256 fp32), 2, or up to 4 / 8
     int blocks = cdiv(rows, 4 * (64 / lpr) * 2);             // two rows per wave: the step's LayerNorms have 450 .. 28 800 rows
-    if (rows <= 256) blocks = cdiv(rows, 4 * (64 / lpr));    // a few dozen rows (BERT: 40-44 tokens): one row per wave (no gain at 1 800 rows: measured)    // a few dozen rows (BERT: 40-44 tokens): one row per wave, no serial second row
+    if (rows <= 256) blocks = cdiv(rows, 4 * (64 / lpr));    // a few dozen rows (BERT: 40-44 tokens): one row per wave, no serial second row
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
+    *lpr_out = lpr; *cpl_out = cpl;
+    return blocks;
+}
+extern "C" int lavt_layernorm_bwd_blocks(int dtype, int rows, int C) { int a, b; return ln_bwd_geometry(dtype, rows, C, &a, &b); }
+
+static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
+                              const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats,
+                              const void* dres, int rows, int C, void* stream, bool partial_only) {
+    const int epc = dtype == LAVT_F32 ? 4 : 8;
+    LAVT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && (partial_only || (dgamma && dbeta)) && rows > 0, "lavt_layernorm_bwd: bad arguments");
+    LAVT_CHECK_ARG(C > 0 && C <= 2048 && C % epc == 0 && (!gather || (C / 4) % epc == 0), "lavt_layernorm_bwd: unsupported C=%d", C);
+    LAVT_CHECK_ARG(!(gather && dres), "lavt_layernorm_bwd: dres is not supported together with gather");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int lpr, cpl;
+    const int blocks = ln_bwd_geometry(dtype, rows, C, &lpr, &cpl);
     float* partials = (ws && ws_floats >= (int64_t)blocks * 2 * C) ? ws : nullptr;
+    LAVT_CHECK_ARG(!partial_only || partials, "lavt_layernorm_bwd_partial: scratch of %ld floats needed", (long)blocks * 2 * C);
 #define LN_BWD(LPR_, CPL_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_, CPL_>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, (const T*)dres, rows, C)
     DISPATCH_T(dtype, "lavt_layernorm_bwd",
                if (lpr == 16) LN_BWD(16, 1); else if (lpr == 32) LN_BWD(32, 1);
                else if (cpl == 1) LN_BWD(64, 1); else if (cpl == 2) LN_BWD(64, 2); else if (cpl <= 4) LN_BWD(64, 4); else LN_BWD(64, 8));
 #undef LN_BWD
-    if (partials) hipLaunchKernelGGL(reduce_partials_kernel, reduce_partials_grid(blocks, 2 * C), dim3(256), 0, st, partials, blocks, 2 * C, C, dgamma, dbeta);
+    if (partials && !partial_only) hipLaunchKernelGGL(reduce_partials_kernel, reduce_partials_grid(blocks, 2 * C), dim3(256), 0, st, partials, blocks, 2 * C, C, dgamma, dbeta);
     LAVT_CHECK_LAUNCH("lavt_layernorm_bwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
+                                  const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats,
+                                  const void* dres, int rows, int C, void* stream) {
+    return layernorm_bwd_impl(dtype, dy, x, gather, gamma, mean, rstd, dx, dgamma, dbeta, ws, ws_floats, dres, rows, C, stream, false);
+}
+extern "C" int lavt_layernorm_bwd_partial(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma, const float* mean,
+                                          const float* rstd, void* dx, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream) {
+    return layernorm_bwd_impl(dtype, dy, x, gather, gamma, mean, rstd, dx, nullptr, nullptr, ws, ws_floats, dres, rows, C, stream, true);
+}
+extern "C" int lavt_reduce_partials_multi(const int64_t* desc, int n, void* stream) {
+    LAVT_CHECK_ARG(desc && n > 0, "lavt_reduce_partials_multi: bad arguments");
+    // widest supported set: C = 2048 -> 128 column blocks; 4 row slices per set
+    hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(128, 4, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
+    LAVT_CHECK_LAUNCH("lavt_reduce_partials_multi");
     return LAVT_OK;
 }
 

@@ -148,6 +148,9 @@ _PROTOTYPES = {
     "lavt_attn_dbias_sum": [i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "lavt_layernorm_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "lavt_layernorm_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
+    "lavt_layernorm_bwd_blocks": [i32, i32, i32],
+    "lavt_layernorm_bwd_partial": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
+    "lavt_reduce_partials_multi": [vp, i32, vp],
     "lavt_colstats": [i32, vp, vp, vp, vp, i64, i32, i32, i32, vp],
     "lavt_stats_finalize": [vp, vp, f32, f32, vp, vp, vp, vp, f32, i32, vp],
     "lavt_norm_apply": [i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp],
@@ -191,7 +194,7 @@ for _name, _args in _PROTOTYPES.items():
 _cdll.lavt_last_error.restype = C.c_char_p
 _cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
 _cdll.lavt_last_error.argtypes = []
-for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version"):      # queries, not launches: never timed
+for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks"):      # queries, not launches: never timed
     setattr(lib, _name, getattr(_cdll, _name))
 
 EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)

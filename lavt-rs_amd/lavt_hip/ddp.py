@@ -142,6 +142,10 @@ class GradBuckets:
 
     def finish(self):
         """Call after backward: reduces buckets that never filled (unused parameters) and joins the side stream."""
+        if self.fused:                                   # gradients still parked by the ops (grouped weight gradients, deferred LayerNorm sums)
+            from . import ops
+            ops.wgrads.flush()
+            ops.ln_deferred.flush()
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)

@@ -64,6 +64,7 @@ class TrainStep:
             loss = F.cross_entropy(out, self.t, weight=self.w)
         loss.backward()
         ops.wgrads.flush()                       # weight-gradient GEMMs still queued for a grouped launch
+        ops.ln_deferred.flush()                  # all LayerNorm weight / bias partial sums of this backward: one reduction launch
         ops.side.join()                          # wgrad GEMMs ran on side streams: join before the step (or the graph capture) ends
         self.buckets.finish()                    # stragglers (never-used parameters) + join of the communication stream
         return loss.detach()
