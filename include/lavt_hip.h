@@ -190,10 +190,16 @@ int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, int bias
                          void* stream);
 int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img,
                          const void* out, const void* dout, const float* lse, void* dqkv, const float* table, float* dtable,
-                         float* ws, int64_t ws_floats, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim, float scale,
+                         float* ws, int64_t ws_floats, float* parts, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim, float scale,
                          void* stream);
 /* 1 when lavt_window_attn_fwd/bwd take the bias from the table for this (dtype, N) -- no dense bias / lavt_relpos_expand needed */
 int lavt_attn_uses_table(int dtype, int N);
+/* Deferred table gradient (bf16 MFMA path): with `parts` != NULL (a caller-owned buffer of lavt_window_attn_bwd_pieces(...) * heads * (2wd-1)(2wh-1)(2ww-1)
+ * floats that outlives the call) lavt_window_attn_bwd leaves its per-workgroup table histograms there and does not touch dtable; one
+ * lavt_attn_dtable_finish_multi launch later adds the histograms of any number of layers into their table gradients:
+ * desc = device int64 [n][5] rows {parts, pieces, heads, R, dtable}; max_R / max_heads size the grid. */
+int lavt_window_attn_bwd_pieces(int dtype, int nwin, int N, int heads, int bias_ld);
+int lavt_attn_dtable_finish_multi(const int64_t* desc, int n, int max_R, int max_heads, void* stream);
 /* floats of scratch (`ws`) lavt_window_attn_bwd wants for these shapes: dS slabs + per-workgroup table histograms (0 for the exact-fp32 kernel) */
 int64_t lavt_window_attn_bwd_ws(int dtype, int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww);
 

@@ -390,8 +390,10 @@ int launch_bwd(const void* qkv, const float* bias, int bias_ld, const int8_t* re
 int lavt_window_attn_fwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, void* out, float* lse,
                               int wd, int wh, int ww, int nwin, int N, int heads, float scale, hipStream_t st);
 int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, const void* out, const void* dout,
-                              const float* lse, void* dqkv, float* dtable, int bias_ld, float* ws, int wd, int wh, int ww, int nwin, int N,
+                              const float* lse, void* dqkv, float* dtable, int bias_ld, float* ws, float* parts, int wd, int wh, int ww, int nwin, int N,
                               int heads, float scale, hipStream_t st);
+int lavt_attn_dtable_finish_multi_impl(const int64_t* desc, int n, int max_R, int max_heads, hipStream_t st);
+int lavt_window_attn_bwd_pieces_mfma(int nwin, int N, int heads);
 int64_t lavt_window_attn_bwd_ws_mfma(int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww);
 // LAVT_ATTN_SIMPLE=1 forces the VALU formulation for bf16 too (A/B tests of the MFMA kernels)
 static bool use_mfma(int dtype, int N, int bias_ld) {
@@ -417,15 +419,16 @@ extern "C" int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bia
 
 extern "C" int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img,
                                     const void* out, const void* dout, const float* lse, void* dqkv, const float* table, float* dtable,
-                                    float* ws, int64_t ws_floats, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim,
+                                    float* ws, int64_t ws_floats, float* parts, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim,
                                     float scale, void* stream) {
     LAVT_CHECK_ARG(head_dim == HD, "lavt_window_attn_bwd: head_dim %d != 32", head_dim);
-    LAVT_CHECK_ARG(qkv && out && dout && lse && dqkv && table && dtable && nwin > 0 && N > 0 && heads > 0, "lavt_window_attn_bwd: bad arguments");
+    LAVT_CHECK_ARG(qkv && out && dout && lse && dqkv && table && (dtable || parts) && nwin > 0 && N > 0 && heads > 0, "lavt_window_attn_bwd: bad arguments");
     LAVT_CHECK_ARG(wd > 0 && wh > 0 && ww > 0 && N <= wd * wh * ww, "lavt_window_attn_bwd: window shape (wd, wh, ww) must cover N tokens");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // the bf16 MFMA kernel takes the bias values from an LDS copy of the table and needs one fp32 [N][bias_ld] slab per (window, head)
     const bool fast = use_mfma(dtype, N, bias_ld) && ws && ws_floats >= lavt_window_attn_bwd_ws_mfma(nwin, N, heads, bias_ld, wd, wh, ww);
-    if (fast) return lavt_window_attn_bwd_mfma(qkv, table, region, nw_img, out, dout, lse, dqkv, dtable, bias_ld, ws, wd, wh, ww, nwin, N, heads, scale, st);
+    if (fast) return lavt_window_attn_bwd_mfma(qkv, table, region, nw_img, out, dout, lse, dqkv, dtable, bias_ld, ws, parts, wd, wh, ww, nwin, N, heads, scale, st);
+    LAVT_CHECK_ARG(parts == nullptr && dtable, "lavt_window_attn_bwd: the deferred table-gradient form exists on the bf16 MFMA path only");
     LAVT_CHECK_ARG(bias && bias_ld >= N, "lavt_window_attn_bwd: the exact-fp32 kernel needs the dense bias (lavt_relpos_expand)");
     if (dtype == LAVT_F32) return launch_bwd<float>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, nullptr, dtable, wd, wh, ww, nwin, N, heads, scale, st);
     if (dtype == LAVT_BF16) return launch_bwd<bf16>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, nullptr, dtable, wd, wh, ww, nwin, N, heads, scale, st);
@@ -435,6 +438,14 @@ extern "C" int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bia
 
 extern "C" int64_t lavt_window_attn_bwd_ws(int dtype, int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww) {
     return use_mfma(dtype, N, bias_ld) ? lavt_window_attn_bwd_ws_mfma(nwin, N, heads, bias_ld, wd, wh, ww) : 0;
+}
+// deferred table gradient: number of per-workgroup histograms ([pieces][heads][R] floats in `parts`); 0 when this (dtype, N) has no deferred form
+extern "C" int lavt_window_attn_bwd_pieces(int dtype, int nwin, int N, int heads, int bias_ld) {
+    return use_mfma(dtype, N, bias_ld) ? lavt_window_attn_bwd_pieces_mfma(nwin, N, heads) : 0;
+}
+extern "C" int lavt_attn_dtable_finish_multi(const int64_t* desc, int n, int max_R, int max_heads, void* stream) {
+    LAVT_CHECK_ARG(desc && n > 0 && max_R > 0 && max_heads > 0, "lavt_attn_dtable_finish_multi: bad arguments");
+    return lavt_attn_dtable_finish_multi_impl(desc, n, max_R, max_heads, reinterpret_cast<hipStream_t>(stream));
 }
 extern "C" int lavt_attn_uses_table(int dtype, int N) { return use_mfma(dtype, N, N <= 64 ? 64 : N <= 160 ? 160 : 416) ? 1 : 0; }
 

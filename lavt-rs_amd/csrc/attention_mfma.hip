@@ -496,10 +496,39 @@ int64_t lavt_window_attn_bwd_ws_mfma(int nwin, int N, int heads, int bias_ld, in
     return (int64_t)nwin * heads * N * bias_ld + (int64_t)wgroups * cdiv(N, rpb) * heads * R;
 }
 
+// several layers' per-workgroup table histograms -> their table gradients in ONE launch (deferred form): desc[s] = {part, pieces, heads, R, dtable}
+__global__ void wattn_dtable_finish_multi(const int64_t* __restrict__ desc) {
+    const int64_t* d = desc + (int64_t)blockIdx.z * 5;
+    const float* part = reinterpret_cast<const float*>(d[0]);
+    const int pieces = (int)d[1], heads = (int)d[2], R = (int)d[3];
+    float* dtable = reinterpret_cast<float*>(d[4]);
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y;
+    if (e >= R || h >= heads) return;
+    const float* q = part + (int64_t)h * R + e;
+    const int64_t st = (int64_t)heads * R;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 3 < pieces; k += 4, q += 4 * st)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += q[u * st];
+    for (; k < pieces; ++k, q += st) acc[0] += *q;
+    dtable[(int64_t)e * heads + h] += (acc[0] + acc[1]) + (acc[2] + acc[3]);          // one writer per entry: the zeroed gradient buffer
+}
+int lavt_attn_dtable_finish_multi_impl(const int64_t* desc, int n, int max_R, int max_heads, hipStream_t st) {
+    hipLaunchKernelGGL(wattn_dtable_finish_multi, dim3(cdiv(max_R, 256), max_heads, n), dim3(256), 0, st, desc);
+    LAVT_CHECK_LAUNCH("lavt_attn_dtable_finish_multi");
+    return LAVT_OK;
+}
+int lavt_window_attn_bwd_pieces_mfma(int nwin, int N, int heads) {
+    int rpb, wgroups, wpg;
+    dtable_geometry(nwin, N, heads, &rpb, &wgroups, &wpg);
+    return wgroups * cdiv(N, rpb);
+}
+
 int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, const void* out, const void* dout,
-                              const float* lse, void* dqkv, float* dtable, int bias_ld, float* ws, int wd, int wh, int ww, int nwin, int N,
+                              const float* lse, void* dqkv, float* dtable, int bias_ld, float* ws, float* parts, int wd, int wh, int ww, int nwin, int N,
                               int heads, float scale, hipStream_t st) {
-    if (N > 400 || !table || !dtable || !ws || bias_ld % 4) { lavt_set_error("lavt_window_attn_bwd(mfma): N=%d (<= 400), table, dtable and scratch required", N); return LAVT_ERR_INVALID; }
+    if (N > 400 || !table || !(dtable || parts) || !ws || bias_ld % 4) { lavt_set_error("lavt_window_attn_bwd(mfma): N=%d (<= 400), table, dtable and scratch required", N); return LAVT_ERR_INVALID; }
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
     // >= 2 workgroups per CU when there is that much work
     int wpb = (int)(((long)nwin * heads + 767) / 768);
@@ -532,11 +561,13 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     LAVT_CHECK_LAUNCH("lavt_window_attn_bwd(mfma)");
     int rpb, wgroups, wpg;
     dtable_geometry(nwin, N, heads, &rpb, &wgroups, &wpg);
-    float* part = ws + (int64_t)nwin * heads * N * bias_ld;   // after the slabs: [wgroups * chunks][heads][R]
+    // per-workgroup histograms [wgroups * chunks][heads][R]: after the slabs, or -- deferred form -- in the caller's persistent buffer, to be
+    // summed into the table gradients of all layers by one lavt_attn_dtable_finish_multi launch at the end of backward
+    float* part = parts ? parts : ws + (int64_t)nwin * heads * N * bias_ld;
     hipLaunchKernelGGL(wattn_dtable_kernel, dim3(cdiv(N, rpb), heads, wgroups), dim3(256), (size_t)(R + N) * 4, st, ws, part, bias_ld, wd, wh, ww, nwin,
                        N, heads, rpb, wpg);
     const int pieces = wgroups * cdiv(N, rpb), per_z = 16;
-    hipLaunchKernelGGL(wattn_dtable_finish, dim3(cdiv(R, 256), heads, cdiv(pieces, per_z)), dim3(256), 0, st, part, dtable, pieces, per_z, heads, R);
+    if (!parts) hipLaunchKernelGGL(wattn_dtable_finish, dim3(cdiv(R, 256), heads, cdiv(pieces, per_z)), dim3(256), 0, st, part, dtable, pieces, per_z, heads, R);
     LAVT_CHECK_LAUNCH("lavt_window_attn_bwd(table gradient)");
     return LAVT_OK;
 }

@@ -138,7 +138,9 @@ _PROTOTYPES = {
     "lavt_gemm_tn": [C.POINTER(GemmTN), vp],
     "lavt_gemm_tn_grouped": [C.POINTER(GemmTN), i32, vp],
     "lavt_window_attn_fwd": [i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
-    "lavt_window_attn_bwd": [i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "lavt_window_attn_bwd": [i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "lavt_window_attn_bwd_pieces": [i32, i32, i32, i32, i32],
+    "lavt_attn_dtable_finish_multi": [vp, i32, i32, i32, vp],
     "lavt_attn_uses_table": [i32, i32],
     "lavt_window_attn_bwd_ws": [i32, i32, i32, i32, i32, i32, i32, i32],
     "lavt_relpos_expand": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
@@ -194,7 +196,7 @@ for _name, _args in _PROTOTYPES.items():
 _cdll.lavt_last_error.restype = C.c_char_p
 _cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
 _cdll.lavt_last_error.argtypes = []
-for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks"):      # queries, not launches: never timed
+for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces"):      # queries, not launches: never timed
     setattr(lib, _name, getattr(_cdll, _name))
 
 EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)

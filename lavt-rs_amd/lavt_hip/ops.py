@@ -434,8 +434,8 @@ class _LnDeferred:
     ARENA_FLOATS = 32 << 20          # 128 MiB: Swin-B needs 56 x 225 x 1024 floats = 12.9 M
 
     def __init__(self):
-        self.arena, self.off, self.items, self.params = None, 0, [], []
-        self.desc, self.desc_key = None, None
+        self.arena, self.off, self.items, self.params, self.tables = None, 0, [], [], []
+        self.desc, self.desc_key, self.tdesc, self.tdesc_key = None, None, None, None
 
     def active(self):
         return wgrads.active() and os.environ.get("LAVT_LN_DEFER", "1") != "0"
@@ -455,7 +455,22 @@ class _LnDeferred:
             self.params.append(p)
             wgrads.pending.add(id(p))          # its autograd hook fires now, before the reduction exists: GradBuckets ignores pending parameters
 
+    def add_table(self, parts, pieces, heads, R, dtable, param):
+        """attention bias-table gradient: per-workgroup histograms parked in the arena (lavt_attn_dtable_finish_multi at flush)"""
+        self.tables.append((parts.data_ptr(), pieces, heads, R, dtable.data_ptr()))
+        self.params.append(param)
+        wgrads.pending.add(id(param))
+
     def flush(self):
+        if self.tables:
+            key = tuple(self.tables)
+            if key != self.tdesc_key:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("deferred table gradients: the step being captured differs from the warm-up steps")
+                self.tdesc = torch.tensor(self.tables, dtype=torch.int64).to(self.arena.device)
+                self.tdesc_key = key
+            K.check(K.lib.lavt_attn_dtable_finish_multi(K.ptr(self.tdesc), len(self.tables), max(t[3] for t in self.tables), max(t[2] for t in self.tables), K.stream()))
+            self.tables = []
         if self.items:
             key = tuple(self.items)
             if key != self.desc_key:
@@ -813,10 +828,16 @@ class _WindowAttn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         nws = int(K.lib.lavt_window_attn_bwd_ws(K.dt(qkv.dtype), nwin, N, heads, ld, wd, wh, ww))
         ws = torch.empty(nws, dtype=torch.float32, device=qkv.device) if nws > 0 else None                      # dS slabs + table histograms
-        dtable, ts = sinks.buf(table, ((2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1), heads))
+        R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1)
+        dtable, ts = sinks.buf(table, (R, heads))
+        pieces = int(K.lib.lavt_window_attn_bwd_pieces(K.dt(qkv.dtype), nwin, N, heads, ld)) if (ts and ln_deferred.active()) else 0
+        parts = ln_deferred.alloc(pieces * heads * R, qkv.device) if pieces > 0 else None
         K.check(K.lib.lavt_window_attn_bwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout),
-                                           K.ptr(lse), K.ptr(dqkv), K.ptr(_f32(table)), K.ptr(dtable), K.ptr(ws), ws.numel() if ws is not None else 0,
-                                           wd, wh, ww, nwin, N, heads, Cc // heads, scale, K.stream()))
+                                           K.ptr(lse), K.ptr(dqkv), K.ptr(_f32(table)), None if parts is not None else K.ptr(dtable), K.ptr(ws),
+                                           ws.numel() if ws is not None else 0, K.ptr(parts), wd, wh, ww, nwin, N, heads, Cc // heads, scale, K.stream()))
+        if parts is not None:          # table gradient finished with the other layers' in one launch at the end of backward
+            ln_deferred.add_table(parts, pieces, heads, R, dtable, table)
+            return dqkv, None, None, None, None, None
         return dqkv, sinks.done(table, dtable, ts), None, None, None, None
 
 

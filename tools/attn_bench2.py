@@ -17,7 +17,7 @@ def run(nwin, heads, ws, iters=20):
     dtable = torch.zeros((2 * ws - 1) ** 2, heads, device=dev); wsb = torch.empty(int(K.lib.lavt_window_attn_bwd_ws(K.dt(bf), nwin, N, heads, ld, 1, ws, ws)), device=dev); table = torch.randn((2 * ws - 1) ** 2, heads, device=dev) * 0.1
     st = K.stream()
     fwd = lambda: K.check(K.lib.lavt_window_attn_fwd(K.dt(bf), K.ptr(qkv), K.ptr(dense), ld, None, 0, K.ptr(out), K.ptr(lse), K.ptr(table), 1, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
-    bwd = lambda: K.check(K.lib.lavt_window_attn_bwd(K.dt(bf), K.ptr(qkv), K.ptr(dense), ld, None, 0, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(table), K.ptr(dtable), K.ptr(wsb), wsb.numel(), 1, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
+    bwd = lambda: K.check(K.lib.lavt_window_attn_bwd(K.dt(bf), K.ptr(qkv), K.ptr(dense), ld, None, 0, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(table), K.ptr(dtable), K.ptr(wsb), wsb.numel(), None, 1, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
     res = []
     for fn in (fwd, bwd):
         for _ in range(3): fn()
