@@ -348,6 +348,40 @@ __global__ void colstats_center_kernel(const T* __restrict__ x, float* __restric
     o2[i] = fmaxf(s2 - s1 * s1 / (float)rows, 0.f);
 }
 
+// Second stage of the forward statistics when nothing sits between the sums and their use (InstanceNorm; BatchNorm on one rank): the partial
+// rows are summed, re-centred about the pivot row and turned into mean / rstd (and the running estimates) in ONE kernel instead of
+// reduce_partials + colstats_center + stats_finalize.  Workgroup = 16 columns x {shifted sum, shifted square sum} x 8 row slices.
+template <typename T>
+__global__ __launch_bounds__(256) void colstats_finish_kernel(const float* __restrict__ partials, int nblk, int groups, int C, const T* __restrict__ x,
+                                                              int rows, float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                                              float* __restrict__ sum_out, float* __restrict__ m2_out,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
+    __shared__ float red[8][32];
+    const int c16 = threadIdx.x & 15, which = (threadIdx.x >> 4) & 1, slice = threadIdx.x >> 5;
+    const int c = blockIdx.x * 16 + c16, g = blockIdx.y;
+    const int64_t W = (int64_t)groups * 2 * C;
+    float a = 0.f;
+    if (c < C)
+        for (int k = slice; k < nblk; k += 8) a += partials[(int64_t)k * W + ((int64_t)g * 2 + which) * C + c];
+    red[slice][threadIdx.x & 31] = a;
+    __syncthreads();
+    if (slice == 0 && which == 0 && c < C) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1 += red[k][c16]; s2 += red[k][16 + c16]; }
+        const float kpiv = to_f<T>(x[(int64_t)g * rows * C + c]);
+        const float n = (float)rows;
+        const float sum = s1 + n * kpiv, m2 = fmaxf(s2 - s1 * s1 / n, 0.f);
+        const float mu = sum / n, var = m2 / n;
+        const int64_t i = (int64_t)g * C + c;
+        mean[i] = mu;
+        rstd[i] = rsqrtf(var + eps);
+        if (sum_out) { sum_out[i] = sum; m2_out[i] = m2; }
+        if (running_mean) running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * mu;
+        if (running_var) running_var[i] = (1.f - momentum) * running_var[i] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+    }
+}
+
 __global__ void stats_finalize_kernel(const float* sum, const float* m2, float count, float eps, float* mean, float* rstd,
                                       float* running_mean, float* running_var, float momentum, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -567,6 +601,23 @@ extern "C" int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq,
     DISPATCH_T(dtype, "lavt_colstats",
                hipLaunchKernelGGL(colstats_center_kernel<T>, dim3(cdiv(groups * C, 256)), dim3(256), 0, st, (const T*)x, sum, sumsq, rows, C, groups * C));
     LAVT_CHECK_LAUNCH("lavt_colstats");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_colstats_meanrstd(int dtype, const void* x, float* mean, float* rstd, float* ws, int64_t ws_floats, int groups, int rows, int C,
+                                      float eps, float* running_mean, float* running_var, float momentum, void* stream) {
+    const int epc = dtype == LAVT_F32 ? 4 : 8;
+    LAVT_CHECK_ARG(x && mean && rstd && ws && groups > 0 && rows > 0 && C > 0 && C % epc == 0, "lavt_colstats_meanrstd: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rpb;
+    const int blocks = stats_launch_geometry(rows, groups, C, epc, &rpb);
+    LAVT_CHECK_ARG(ws_floats >= (int64_t)blocks * groups * 2 * C, "lavt_colstats_meanrstd: scratch of %ld floats needed", (long)blocks * groups * 2 * C);
+    DISPATCH_T(dtype, "lavt_colstats_meanrstd",
+               hipLaunchKernelGGL((colstats_kernel<T, false>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
+                                  (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, 0, mean, rstd, ws, rows, C, rpb, 0);
+               hipLaunchKernelGGL(colstats_finish_kernel<T>, dim3(cdiv(C, 16), groups), dim3(256), 0, st, ws, blocks, groups, C, (const T*)x, rows, eps, mean, rstd,
+                                  (float*)nullptr, (float*)nullptr, running_mean, running_var, momentum));
+    LAVT_CHECK_LAUNCH("lavt_colstats_meanrstd");
     return LAVT_OK;
 }
 

@@ -935,10 +935,10 @@ class _InstanceNorm(torch.autograd.Function):
     def forward(ctx, x, mul, B, T):
         x = x.contiguous()
         Cc = x.shape[1]
-        s = _stats(x, B, T, Cc)
         mean = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        K.check(K.lib.lavt_stats_finalize(K.ptr(s[0]), K.ptr(s[1]), float(T), 1e-5, K.ptr(mean), K.ptr(rstd), None, None, 0.0, B * Cc, K.stream()))
+        ws = _scratch(1025 * B * 2 * Cc, x.device)
+        K.check(K.lib.lavt_colstats_meanrstd(K.dt(x.dtype), K.ptr(x), K.ptr(mean), K.ptr(rstd), K.ptr(ws), ws.numel(), B, T, Cc, 1e-5, None, None, 0.0, K.stream()))
         if mul is not None:
             mul = mul.contiguous()
         y = torch.empty_like(x)
@@ -1005,6 +1005,17 @@ class _HipBnKernels:
         return _stats(x, 1, x.shape[0], x.shape[1])                      # [2, 1, C]: sum, centred second moment of the local rows
 
     @staticmethod
+    def stats_fused(x, eps, running_mean, running_var, momentum):
+        """single-rank training statistics: sums -> mean / rstd (+ running estimates) in two launches (lavt_colstats_meanrstd)"""
+        R, Cc = x.shape
+        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = _scratch(1025 * 2 * Cc, x.device)
+        K.check(K.lib.lavt_colstats_meanrstd(K.dt(x.dtype), K.ptr(x), K.ptr(mean), K.ptr(rstd), K.ptr(ws), ws.numel(), 1, R, Cc, eps, K.ptr(running_mean),
+                                             K.ptr(running_var), momentum, K.stream()))
+        return mean, rstd
+
+    @staticmethod
     def finalize(s, count, eps, running_mean, running_var, momentum):
         Cc = s.shape[-1]
         mean = torch.empty(Cc, dtype=torch.float32, device=s.device)
@@ -1051,7 +1062,9 @@ class _BatchNormRelu(torch.autograd.Function):
         x = x.contiguous()
         R, Cc = x.shape
         count = float(R)
-        if training:
+        if training and group is None and hasattr(kern, "stats_fused"):
+            mean, rstd = kern.stats_fused(x, eps, running_mean, running_var, momentum)
+        elif training:
             s = kern.stats(x)                                # [sum x, centred second moment] of the local rows
             if group is not None:
                 s, count = syncbn_exchange_forward(s, R, group)
