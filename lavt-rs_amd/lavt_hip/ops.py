@@ -11,6 +11,7 @@ gradients are produced in fp32.
 """
 import ctypes as C
 import os
+import types
 import weakref
 from dataclasses import dataclass
 from typing import Optional
@@ -1147,34 +1148,39 @@ def gate(x, gpre, r):
 @K.scoped
 class _PwamAttn(torch.autograd.Function):
     """softmax_words(q k^T * C^-1/2 + maskbias) v   per sample and head group (lib/backbone.py:1349-1363).
-    q [B*T, C]; k, v [B*KV_LD, C] (rows >= n_l are zero); maskbias fp32 [B, KV_LD]."""
+    q [B*T, C]; k, v [B*KV_LD, C] (rows >= n_l are zero; may be column blocks of a wider matrix: row stride kv_ld); maskbias fp32 [B, KV_LD].
+    `sinks_kv` = (dk view, dv view) of a caller-owned gradient buffer: the key / value gradients are written there (the hoisted
+    all-stages K / V projection reads them as ONE matrix) and the same views are returned as the gradients."""
 
     @staticmethod
-    def forward(ctx, q, k, v, maskbias, B, T, n_l, G):
-        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    def forward(ctx, q, k, v, maskbias, B, T, n_l, G, sinks_kv):
+        q = q.contiguous()
+        assert k.stride(1) == 1 and v.stride(1) == 1 and k.stride(0) == v.stride(0)
         dtype, dev = q.dtype, q.device
         Cc = q.shape[1]
+        kld = k.stride(0)
         c = Cc // G
         alpha = float(Cc ** -0.5)
         o = torch.empty_like(q)
         Ps = []
         for g in range(G):
             S = torch.empty(B * T, KV_LD, dtype=dtype, device=dev)
-            gemm_nt(dtype, T, KV_LD, c, q, Cc, k, Cc, S, KV_LD, batch=B, strideA=T * Cc, strideB=KV_LD * Cc, strideC=T * KV_LD,
+            gemm_nt(dtype, T, KV_LD, c, q, Cc, k, kld, S, KV_LD, batch=B, strideA=T * Cc, strideB=KV_LD * kld, strideC=T * KV_LD,
                     alpha=alpha, bias=maskbias, strideBias=KV_LD, a_off=g * c, b_off=g * c)
             P = torch.empty_like(S)
             K.check(K.lib.lavt_rowsoftmax_fwd(K.dt(dtype), K.ptr(S), K.ptr(P), B * T, n_l, KV_LD, K.stream()))
-            gemm_nt(dtype, T, c, KV_LD, P, KV_LD, v, Cc, o, Cc, batch=B, strideA=T * KV_LD, strideB=KV_LD * Cc, strideC=T * Cc,
+            gemm_nt(dtype, T, c, KV_LD, P, KV_LD, v, kld, o, Cc, batch=B, strideA=T * KV_LD, strideB=KV_LD * kld, strideC=T * Cc,
                     b_kmajor=True, b_off=g * c, c_off=g * c)
             Ps.append(P)
         ctx.save_for_backward(q, k, v, *Ps)
-        ctx.dims = (B, T, n_l, G, Cc, alpha)
+        ctx.dims = (B, T, n_l, G, Cc, alpha, kld)
+        ctx.sinks_kv = sinks_kv
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, *Ps = ctx.saved_tensors
-        B, T, n_l, G, Cc, alpha = ctx.dims
+        B, T, n_l, G, Cc, alpha, kld = ctx.dims
         dtype, dev = q.dtype, q.device
         c = Cc // G
         do = do.contiguous()
@@ -1184,21 +1190,112 @@ class _PwamAttn(torch.autograd.Function):
         for g in range(G):
             P = Ps[g]
             dP = torch.empty_like(P)
-            gemm_nt(dtype, T, KV_LD, c, do, Cc, v, Cc, dP, KV_LD, batch=B, strideA=T * Cc, strideB=KV_LD * Cc, strideC=T * KV_LD,
+            gemm_nt(dtype, T, KV_LD, c, do, Cc, v, kld, dP, KV_LD, batch=B, strideA=T * Cc, strideB=KV_LD * kld, strideC=T * KV_LD,
                     a_off=g * c, b_off=g * c)
             dS = torch.empty_like(P)
             K.check(K.lib.lavt_rowsoftmax_bwd(K.dt(dtype), K.ptr(P), K.ptr(dP), K.ptr(dS), B * T, n_l, KV_LD, K.stream()))
-            gemm_nt(dtype, T, c, KV_LD, dS, KV_LD, k, Cc, dq, Cc, batch=B, strideA=T * KV_LD, strideB=KV_LD * Cc, strideC=T * Cc,
+            gemm_nt(dtype, T, c, KV_LD, dS, KV_LD, k, kld, dq, Cc, batch=B, strideA=T * KV_LD, strideB=KV_LD * kld, strideC=T * Cc,
                     b_kmajor=True, alpha=alpha, b_off=g * c, c_off=g * c)
             gemm_tn(dtype, KV_LD, c, T, dS, KV_LD, q, Cc, dk, Cc, batch=B, strideA=T * KV_LD, strideB=T * Cc, strideC=KV_LD * Cc,
                     alpha=alpha, b_off=g * c, c_off=g * c)
             gemm_tn(dtype, KV_LD, c, T, P, KV_LD, do, Cc, dv, Cc, batch=B, strideA=T * KV_LD, strideB=T * Cc, strideC=KV_LD * Cc,
                     b_off=g * c, c_off=g * c)
-        return dq, cast(dk, dtype), cast(dv, dtype), None, None, None, None, None
+        if ctx.sinks_kv is not None:          # fp32 -> compute dtype straight into the column blocks of the shared key / value gradient matrix
+            sk, sv = ctx.sinks_kv
+            sk.copy_(dk)
+            sv.copy_(dv)
+            return dq, sk, sv, None, None, None, None, None, None
+        return dq, cast(dk, dtype), cast(dv, dtype), None, None, None, None, None, None
 
 
-def pwam_attention(q, k, v, maskbias, B, T, n_l, G):
-    return _PwamAttn.apply(q, k, v, maskbias, B, T, n_l, G)
+def pwam_attention(q, k, v, maskbias, B, T, n_l, G, sinks_kv=None):
+    return _PwamAttn.apply(q, k, v, maskbias, B, T, n_l, G, sinks_kv)
+
+
+@K.scoped
+class _KvAll(torch.autograd.Function):
+    """The language key / value projections of ALL stages (f_key / f_value of the four PWAMs: Conv1d(768 -> C_i, 1) on the same <= 22 word
+    features, masked; lib/backbone.py:1345-1348 per stage) as ONE GEMM over the stacked weight [sum 2 C_i, 768], once per forward, and one
+    data-gradient GEMM in backward (was 8 + 8 launches plus 7 gradient adds).  Outputs: per layer a column block [B*KV_LD, C_i] of one
+    matrix (row stride = total width; rows >= n_l zero).  The consumers (_PwamAttn) write their key / value gradients into the matching
+    column blocks of `ctx_kv.grad` and return those views."""
+
+    @staticmethod
+    def forward(ctx, lt, ctx_kv, *wb):
+        lt = lt.contiguous()
+        dtype = lt.dtype
+        ws, bs = wb[0::2], wb[1::2]
+        Wc = weights.get_cat(ws, dtype)
+        Nt, Kd = Wc.shape
+        M = lt.shape[0]
+        rows = ctx_kv.B * KV_LD
+        big = torch.zeros(rows, Nt, dtype=dtype, device=lt.device)
+        bias = torch.cat([_f32(b) for b in bs])
+        gemm_nt(dtype, M, Nt, Kd, lt, Kd, Wc, Kd, big, Nt, bias=bias, row_scale=ctx_kv.mask_rows, c_rowmap=ctx_kv.kv_map)
+        ctx.save_for_backward(lt, *wb)
+        ctx.ctx_kv = ctx_kv
+        ctx_kv.grad = torch.empty_like(big) if any(ctx.needs_input_grad) else None       # every column block is written by its consumer's backward
+        outs, off = [], 0
+        for w in ws:
+            outs.append(big[:, off:off + w.shape[0]])
+            off += w.shape[0]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lt, *wb = ctx.saved_tensors
+        ws, bs = wb[0::2], wb[1::2]
+        kv = ctx.ctx_kv
+        dtype = lt.dtype
+        G = kv.grad
+        Nt, Kd, M = G.shape[1], lt.shape[1], lt.shape[0]
+        off = 0
+        for w, g in zip(ws, grads):               # consumers return the views of G they filled; anything else is copied in (or zero)
+            n = w.shape[0]
+            if g is None:
+                G[:, off:off + n].zero_()
+            elif g.data_ptr() != G.data_ptr() + off * G.element_size() or g.stride(0) != Nt:
+                G[:, off:off + n].copy_(g)
+            off += n
+        Wc = weights.get_cat(ws, dtype)
+        dlt = None
+        if ctx.needs_input_grad[0]:
+            dlt = torch.empty_like(lt)
+            gemm_nt(dtype, M, Kd, Nt, G, Nt, Wc, Kd, dlt, Kd, a_rowmap=kv.kv_map, b_kmajor=True, row_scale=kv.mask_rows)
+        out, off = [], 0
+        for w, b in zip(ws, bs):
+            n = w.shape[0]
+            wbuf, wsink = sinks.buf(w, (n, Kd))
+            bbuf, bsink = sinks.buf(b, (n,))
+            kw = dict(a_rowmap=kv.kv_map, a_rowscale=kv.mask_rows, a_rowscale_binary=True, alpha=1.0, colsum=bbuf, a_off=off)
+            if wgrads.active() and wsink and bsink and dtype == torch.bfloat16:
+                gemm_tn(dtype, n, Kd, M, G, Nt, lt, Kd, wbuf, Kd, defer=wgrads, **kw)
+                wgrads.notify(w)
+                wgrads.notify(b)
+                out += [None, None]
+            else:
+                gemm_tn(dtype, n, Kd, M, G, Nt, lt, Kd, wbuf, Kd, **kw)
+                out += [sinks.done(w, wbuf, wsink), sinks.done(b, bbuf, bsink)]
+            off += n
+        return (dlt, None, *out)
+
+
+def kv_all(lt, ctx_kv, layers):
+    """layers: [(f_key conv, f_value conv), ...] -> list of (k, v, (dk sink, dv sink) or None) per entry"""
+    wb = []
+    for fk, fv in layers:
+        wb += [fk.weight, fk.bias, fv.weight, fv.bias]
+    # per-call holder: the gradient matrix belongs to THIS forward (a second forward before the backward must not replace it)
+    ctx_kv = types.SimpleNamespace(B=ctx_kv.B, mask_rows=ctx_kv.mask_rows, kv_map=ctx_kv.kv_map, grad=None)
+    outs = _KvAll.apply(lt, ctx_kv, *wb)
+    res, off = [], 0
+    for i, (fk, fv) in enumerate(layers):
+        k, v = outs[2 * i], outs[2 * i + 1]
+        nk, nv = fk.weight.shape[0], fv.weight.shape[0]
+        sink = (ctx_kv.grad[:, off:off + nk], ctx_kv.grad[:, off + nk:off + nk + nv]) if ctx_kv.grad is not None else None
+        res.append((k, v, sink))
+        off += nk + nv
+    return res
 
 
 # ------------------------------------------------------------------------------------------ text side (BERT encoder of lavt_one / lavt_video)

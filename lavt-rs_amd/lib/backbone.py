@@ -14,6 +14,7 @@ GEMM's loads and the proj GEMM's stores.  Out of scope here: BCAM/
 LangProject (`--fuse simple`), the 2-D-Swin-on-video ablation layers, the language-free Swin.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -44,6 +45,24 @@ class _LangCtx:
         bias[:, :n_l] = 1e4 * m - 1e4                                                # lib/backbone.py:1360
         self.maskbias = bias
         self.kv_map = rowmaps.kv_pad_map(B, n_l, ops.KV_LD, l.device)
+        self.plan, self.kv_done = None, None
+
+    def set_plan(self, layers):
+        """layers: the (f_key, f_value) 1x1 convolutions of every stage's fusion module, in stage order.  With a plan the key / value projections
+        of all stages are computed by ONE GEMM at the first request of a forward (ops.kv_all); without one (a fusion module called on its own)
+        each module projects its own."""
+        self.plan, self.kv_done = (list(layers) if layers is not None else None), None
+
+    def kv(self, f_key, f_value):
+        """-> (k, v, gradient sinks or None) for this module's projections"""
+        if self.plan is not None and os.environ.get("LAVT_KV_HOIST", "1") != "0":
+            if self.kv_done is None:
+                self.kv_done = ops.kv_all(self.lt, self, self.plan)
+            for (fk, fv), res in zip(self.plan, self.kv_done):
+                if fk is f_key and fv is f_value:
+                    return res
+        kw = dict(out_map=self.kv_map, out_rows=self.B * ops.KV_LD, zero_init=True, row_scale=self.mask_rows, row_scale_value=1.0)
+        return (ops.linear(self.lt, f_key.weight, f_key.bias, **kw), ops.linear(self.lt, f_value.weight, f_value.bias, **kw), None)
 
     @classmethod
     def get(cls, l, l_mask, dtype):
@@ -222,10 +241,8 @@ class SpatialImageLanguageAttention(nn.Module):
         """x2 [B*T, C] -> IN(W(attn)) (* mul) as [B*T, C]."""
         G = self.num_heads
         q = ops.instance_norm(ops.linear(x2, self.f_query[0].weight, self.f_query[0].bias), B, T)
-        kw = dict(out_map=lang.kv_map, out_rows=B * ops.KV_LD, zero_init=True, row_scale=lang.mask_rows, row_scale_value=1.0)
-        k = ops.linear(lang.lt, self.f_key[0].weight, self.f_key[0].bias, **kw)
-        v = ops.linear(lang.lt, self.f_value[0].weight, self.f_value[0].bias, **kw)
-        o = ops.pwam_attention(q, k, v, lang.maskbias, B, T, lang.n_l, G)
+        k, v, kv_sinks = lang.kv(self.f_key[0], self.f_value[0])
+        o = ops.pwam_attention(q, k, v, lang.maskbias, B, T, lang.n_l, G, kv_sinks)
         return ops.instance_norm(ops.linear(o, self.W[0].weight, self.W[0].bias), B, T, mul=mul)
 
     def forward(self, x, l, l_mask):
@@ -392,6 +409,8 @@ class MultiModalSwinTransformer(nn.Module):
         dtype = compute_dtype()
         B = x.shape[0]
         self._draw_drop_path(B, x.device)
+        lang = _LangCtx.get(l, l_mask, dtype)
+        lang.set_plan([(layer.fusion.image_lang_att.f_key[0], layer.fusion.image_lang_att.f_value[0]) for layer in self.layers])
         t, Wh, Ww = self.patch_embed.tokens(x, dtype)
         t = t.view(B, Wh * Ww, self.embed_dim)
         outs = []
@@ -402,6 +421,7 @@ class MultiModalSwinTransformer(nn.Module):
                 C = self.num_features[i]
                 fn = ops.layer_norm(f.reshape(B * H * W, C), nl.weight, nl.bias, nl.eps)
                 outs.append(fn.view(B, H, W, C).permute(0, 3, 1, 2))          # NCHW-shaped view of NHWC memory
+        lang.set_plan(None)
         return tuple(outs)
 
     def train(self, mode=True):

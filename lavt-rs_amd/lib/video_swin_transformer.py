@@ -196,10 +196,8 @@ class SepTPWAM(nn.Module):
             return y if residual is None else y + residual
         vis = c3(x2, self.spatial_vis_project, ACT_GELU, residual=c3(x2, self.temporal_vis_project, ACT_GELU))
         q = ops.instance_norm(c3(x2, self.f_query_t), B, T) + ops.instance_norm(c3(x2, self.f_query_s), B, T)
-        kw = dict(out_map=lang.kv_map, out_rows=B * ops.KV_LD, zero_init=True, row_scale=lang.mask_rows, row_scale_value=1.0)
-        k = ops.linear(lang.lt, self.f_key[0].weight, self.f_key[0].bias, **kw)
-        v = ops.linear(lang.lt, self.f_value[0].weight, self.f_value[0].bias, **kw)
-        o = ops.pwam_attention(q, k, v, lang.maskbias, B, T, lang.n_l, self.num_heads)
+        k, v, kv_sinks = lang.kv(self.f_key[0], self.f_value[0])
+        o = ops.pwam_attention(q, k, v, lang.maskbias, B, T, lang.n_l, self.num_heads, kv_sinks)
         mm = ops.instance_norm(c3(o, self.W_t), B, T, mul=vis) + ops.instance_norm(c3(o, self.W_s), B, T, mul=vis)      # vis * (W_t + W_s)
         return c3(mm, self.project_mm_s, ACT_GELU, residual=c3(mm, self.project_mm_t, ACT_GELU))
 
@@ -361,6 +359,9 @@ class MultiModalSwinTransformer3D(nn.Module):
         dtype = compute_dtype()
         B = x.shape[0]
         self._draw_drop_path(B, x.device)
+        lang = _LangCtx.get(l, l_mask, dtype)
+        fusions = [layer.fusion if layer.sep_t_pwam else layer.fusion.image_lang_att for layer in self.layers]
+        lang.set_plan([(f.f_key[0], f.f_value[0]) for f in fusions])
         t, T, Wh, Ww = self.patch_embed.tokens(x, dtype)
         t = t.view(B, T, Wh, Ww, self.embed_dim)
         outs = []
@@ -371,6 +372,7 @@ class MultiModalSwinTransformer3D(nn.Module):
                 _, D, H, W, C = f.shape
                 fn = ops.layer_norm(f.reshape(B * D * H * W, C), nl.weight, nl.bias, nl.eps)
                 outs.append(fn.view(B * D, H, W, C).permute(0, 3, 1, 2))
+        lang.set_plan(None)
         return tuple(outs)
 
     def train(self, mode=True):
