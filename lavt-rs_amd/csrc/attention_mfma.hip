@@ -64,7 +64,13 @@ __device__ __forceinline__ void store_head_row16(bf16* row_head, int g, uint2 p0
 // key tiles are directly the B operand of the second MFMA (no LDS round trip for P).
 constexpr int F_LD = 40;        // bf16 elements per LDS row of Q / K / V (80 B)
 
-template <int NT>
+// Arithmetic diet (the kernels are VALU-issue bound: rocprofv3 counters, profiles/r02_pmc_attention.json): scores live in the log2 domain
+// (table column and scale pre-multiplied by log2 e when staged, so the exponential is the bare v_exp_f32), the shift-mask compare is compiled
+// out for unshifted blocks (REGION), and with FULL (N == 16 NT: no padded key / query inside a real tile) the bounds selects and the whole
+// padding tile of an odd tile count disappear.
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+template <int NT, bool REGION, bool FULL>
 __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                       const int8_t* __restrict__ region, int nw_img, bf16* __restrict__ out,
                                                       float* __restrict__ lse, int wd, int wh, int ww, int nwin, int N, int heads, float scale) {
@@ -101,11 +107,12 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
         bs[e] = (dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx;
         Rs[e] = (region && e < N) ? (uint8_t)region[(int64_t)(w % nw_img) * N + e] : 0;
     }
-    for (int e = tid; e < R; e += 256) tab[e] = table[(int64_t)e * heads + h];
+    for (int e = tid; e < R; e += 256) tab[e] = table[(int64_t)e * heads + h] * LOG2E;
     __syncthreads();
 
     const int QT = (N + 15) / 16;
     if (wave >= QT) return;
+    const float sc2 = scale * LOG2E;
     // Up to 10 key tiles (12x12 windows) the K and V^T fragments stay in registers for all query tiles of the wave; the 25-tile windows of
     // Video-Swin (8x7x7 = 392 tokens) re-read them from LDS per query tile (their score block alone is 104 registers).
     constexpr bool CACHE = NT <= 10;
@@ -134,32 +141,38 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
         f32x4 s[2 * KS];
         float mx = -1e30f;
 #pragma unroll
-        for (int t = 0; t < 2 * KS; ++t) {
-            if (t < NT) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CACHE ? kf[CACHE ? t : 0] : k_frag(t), qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            else s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CACHE ? kf[CACHE ? t : 0] : k_frag(t), qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             const int j0 = 16 * t + 4 * g;
             const int4 bj = *reinterpret_cast<const int4*>(bs + j0);
-            const uint32_t rj = *reinterpret_cast<const uint32_t*>(Rs + j0);
-            const float bb[4] = {tab[bi - bj.x], tab[bi - bj.y], tab[bi - bj.z], tab[bi - bj.w]};
+            const f32x4 bb = {tab[bi - bj.x], tab[bi - bj.y], tab[bi - bj.z], tab[bi - bj.w]};
+            f32x4 v = acc * sc2 + bb;
+            if constexpr (REGION) {
+                const uint32_t rj = *reinterpret_cast<const uint32_t*>(Rs + j0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = s[t][r] * scale + bb[r];
-                v += ((int)((rj >> (8 * r)) & 0xFF) != rid_i) ? -100.0f : 0.f;
-                v = (j0 + r < N) ? v : -1e30f;
-                s[t][r] = v;
-                mx = fmaxf(mx, v);
+                for (int r = 0; r < 4; ++r) v[r] += ((int)((rj >> (8 * r)) & 0xFF) != rid_i) ? -100.0f * LOG2E : 0.f;
             }
+            if constexpr (!FULL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (j0 + r < N) ? v[r] : -1e30f;
+            }
+            s[t] = v;
+            mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2 * KS; ++t)
+        for (int t = 0; t < 2 * KS; ++t) {
+            if (t < NT) {
+                const f32x4 d = s[t] - mx;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float p = __expf(s[t][r] - mx); s[t][r] = p; sum += p; }
+                for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(d[r]); s[t][r] = p; sum += p; }
+            } else s[t] = f32x4{0.f, 0.f, 0.f, 0.f};          // padding tile of an odd tile count: zero probabilities, no arithmetic
+        }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        if (vi && g == 0) lse[((int64_t)w * heads + h) * N + i] = mx + __logf(sum);
+        if (vi && g == 0) lse[((int64_t)w * heads + h) * N + i] = (mx + __log2f(sum)) * LN2;
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -192,14 +205,13 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
 // gradient (dbias) is only written when no table pointer is given.
 constexpr int R_LD = 40;        // bf16 elements per LDS row of Q / K / V / dO (80 B rows, 16-byte aligned chunks)
 
-template <int NT, int WAVES>
+template <int NT, int WAVES, bool REGION, bool FULL>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void wattn_bwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                       const int8_t* __restrict__ region, int nw_img, const bf16* __restrict__ out,
                                                       const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                       bf16* __restrict__ dqkv, float* __restrict__ slab, int slab_ld,
                                                       int wd, int wh, int ww, int nwin, int N, int heads, float scale, int win_per_block) {
     constexpr int KS = (NT + 1) / 2, NP = KS * 32;         // tiles are consumed in pairs (k = 32)
-    constexpr int TPW = (NT + WAVES - 1) / WAVES;          // tiles owned by a wave
     constexpr int NTHR = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16* Qs = reinterpret_cast<bf16*>(smem_raw);
@@ -207,10 +219,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
     bf16* Vs = Ks + NP * R_LD;
     bf16* Os = Vs + NP * R_LD;                             // dO
     float* dl = reinterpret_cast<float*>(Os + NP * R_LD);  // delta_i = sum_d dO*O
-    float* ls = dl + NP;                                   // lse_i
+    float* ls = dl + NP;                                   // lse_i * log2 e
     int* bs = reinterpret_cast<int*>(ls + NP);             // table-index base of token i
     uint8_t* Rs = reinterpret_cast<uint8_t*>(bs + NP);
-    float* tab = reinterpret_cast<float*>(Rs + NP);        // this head's column of the bias table, [(2wd-1)(2wh-1)(2ww-1)]
+    float* tab = reinterpret_cast<float*>(Rs + NP);        // this head's column of the bias table * log2 e, [(2wd-1)(2wh-1)(2ww-1)]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int h = blockIdx.x % heads, chunk = blockIdx.x / heads;
@@ -218,11 +230,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
     const int QT = (N + 15) / 16;
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
     const int centre = ((wd - 1) * (2 * wh - 1) + (wh - 1)) * (2 * ww - 1) + (ww - 1);
-    for (int e = tid; e < R; e += NTHR) tab[e] = table[(int64_t)e * heads + h];
+    const float sc2 = scale * LOG2E;
+    for (int e = tid; e < R; e += NTHR) tab[e] = table[(int64_t)e * heads + h] * LOG2E;
     for (int e = tid; e < NP; e += NTHR) {
         const int dz = e / (wh * ww), hy = (e / ww) % wh, wx = e % ww;
         bs[e] = (dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx;
     }
+    // Task list of a window: t < QT -> pass 1 of key tile t; QT <= t < 2 QT -> pass 2 of query tile t - QT.  A wave takes t = slot, slot + WAVES, ...
+    // (9 tiles on 8 waves: 3, 3, 2, ... tasks instead of one wave running 2 + 2).  The kernel is VALU-issue bound and waves w, w + 4 share a SIMD,
+    // so workgroups that are likely to share a CU (the grid's second round of 256) start the list two slots later: the heavy SIMDs differ.
+    const int slot = (wave + 2 * ((blockIdx.x >> 8) & 1)) % WAVES;
 
     const int w_end = min(nwin, (chunk + 1) * win_per_block);
     for (int w = chunk * win_per_block; w < w_end; ++w) {
@@ -252,20 +269,21 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
             for (int x = 0; x < 8; ++x) part += fd[x] * fo[x];
             part += __shfl_xor(part, 1, 64);
             part += __shfl_xor(part, 2, 64);
-            if (c == 0) { dl[row] = part; ls[row] = row < N ? lse[((int64_t)w * heads + h) * N + row] : 0.f; }
+            if (c == 0) { dl[row] = part; ls[row] = row < N ? lse[((int64_t)w * heads + h) * N + row] * LOG2E : 0.f; }
         }
-        for (int e = tid; e < NP; e += NTHR) Rs[e] = (region && e < N) ? (uint8_t)region[(int64_t)(w % nw_img) * N + e] : 0;
+        if constexpr (REGION)
+            for (int e = tid; e < NP; e += NTHR) Rs[e] = e < N ? (uint8_t)region[(int64_t)(w % nw_img) * N + e] : 0;
         __syncthreads();
 
-        // ---- pass 1: dV, dK of the key tiles this wave owns -----------------------------------------------------------
 #pragma unroll 1
-        for (int m = 0; m < TPW; ++m) {
-            const int jt = wave + WAVES * m;
-            if (jt >= NT || 16 * jt >= N) break;
+        for (int t = slot; t < 2 * QT; t += WAVES) {
+          if (t < QT) {
+            // ---- pass 1: dV, dK of key tile jt ----------------------------------------------------------------------------
+            const int jt = t;
             const int j = 16 * jt + c16;
             const bf16x8 kfr = lds_row8(Ks, R_LD, j, 8 * g);
             const bf16x8 vfr = lds_row8(Vs, R_LD, j, 8 * g);
-            const int rj = Rs[j];
+            const int rj = REGION ? Rs[j] : 0;
             f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dk[2] = {dv[0], dv[0]};
             const int bj = bs[j] - centre;                 // bias[i][j] = tab[bs[i] - bs[j] + centre]
 #pragma unroll
@@ -274,27 +292,35 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int it = 2 * ks + half;
+                    if (FULL && it >= NT) {                // the padding tile of an odd tile count: zero fragments, no arithmetic
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { pp[half * 4 + r] = (bf16)0.f; dp8[half * 4 + r] = (bf16)0.f; }
+                        continue;
+                    }
                     const bf16x8 qf = lds_row8(Qs, R_LD, 16 * it + c16, 8 * g);
                     const bf16x8 of = lds_row8(Os, R_LD, 16 * it + c16, 8 * g);
                     const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kfr, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, vfr, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    // per-query constants of the 4 rows this lane holds: three vector LDS reads (rows >= N hold lse = delta = 0)
+                    // per-query constants of the 4 rows this lane holds: vector LDS reads (rows >= N hold lse = delta = 0)
                     const int i0 = 16 * it + 4 * g;
-                    const float4 l4 = *reinterpret_cast<const float4*>(ls + i0), d4 = *reinterpret_cast<const float4*>(dl + i0);
-                    const uint32_t ri4 = *reinterpret_cast<const uint32_t*>(Rs + i0);
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + i0), d4 = *reinterpret_cast<const f32x4*>(dl + i0);
                     const int4 bi4 = *reinterpret_cast<const int4*>(bs + i0);
-                    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
-                    const float bb[4] = {tab[bi4.x - bj], tab[bi4.y - bj], tab[bi4.z - bj], tab[bi4.w - bj]};
+                    const f32x4 bb = {tab[bi4.x - bj], tab[bi4.y - bj], tab[bi4.z - bj], tab[bi4.w - bj]};
+                    f32x4 a = s * sc2 + (bb - l4);
+                    if constexpr (REGION) {
+                        const uint32_t ri4 = *reinterpret_cast<const uint32_t*>(Rs + i0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a[r] += ((int)((ri4 >> (8 * r)) & 0xFF) != rj) ? -100.0f * LOG2E : 0.f;
+                    }
+                    f32x4 p;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float a = s[r] * scale + bb[r];
-                        a += ((int)((ri4 >> (8 * r)) & 0xFF) != rj) ? -100.0f : 0.f;
-                        float p = __expf(a - lv[r]);
-                        p = (i0 + r < N && j < N) ? p : 0.f;              // branch-free: padded rows / columns contribute exactly zero
-                        const float ds = p * (dp[r] - dvv[r]);
-                        pp[half * 4 + r] = (bf16)p;
-                        dp8[half * 4 + r] = (bf16)ds;
+                        p[r] = __builtin_amdgcn_exp2f(a[r]);
+                        if constexpr (!FULL) p[r] = (i0 + r < N && j < N) ? p[r] : 0.f;      // branch-free: padded rows / columns contribute exactly zero
                     }
+                    const f32x4 ds = p * (dp - d4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pp[half * 4 + r] = (bf16)p[r]; dp8[half * 4 + r] = (bf16)ds[r]; }
                 }
                 // B operands [k = query i][n = d]: transposing reads of dO / Q, k-slot (g, jj) <-> i = 32 ks + 16 (jj >> 2) + 4 g + (jj & 3)
 #pragma unroll
@@ -312,27 +338,23 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
             }
             // C[m = d = 4g+r (+16u)][n = key c16]
             {
-                const int jj = 16 * jt + c16;
-                const bool vj = jj < N;
-                bf16* row = dqkv + ((int64_t)w * N + (vj ? jj : 0)) * 3 * C + h * HD;
+                const bool vj = j < N;
+                bf16* row = dqkv + ((int64_t)w * N + (vj ? j : 0)) * 3 * C + h * HD;
                 store_head_row16(row + C, g, make_uint2(pack_bf16x2(dk[0][0] * scale, dk[0][1] * scale), pack_bf16x2(dk[0][2] * scale, dk[0][3] * scale)),
                                  make_uint2(pack_bf16x2(dk[1][0] * scale, dk[1][1] * scale), pack_bf16x2(dk[1][2] * scale, dk[1][3] * scale)), vj);
                 store_head_row16(row + 2 * C, g, make_uint2(pack_bf16x2(dv[0][0], dv[0][1]), pack_bf16x2(dv[0][2], dv[0][3])),
                                  make_uint2(pack_bf16x2(dv[1][0], dv[1][1]), pack_bf16x2(dv[1][2], dv[1][3])), vj);
             }
-        }
-
-        // ---- pass 2: dQ of the query tiles this wave owns; bias gradient -------------------------------------------------
-#pragma unroll 1
-        for (int m = 0; m < TPW; ++m) {
-            const int it = wave + WAVES * m;
-            if (it >= QT) break;
+          } else {
+            // ---- pass 2: dQ of query tile it; dS slab for the bias gradient -------------------------------------------------
+            const int it = t - QT;
             const int i = 16 * it + c16;
             const bool vi = i < N;
             const bf16x8 qfb = lds_row8(Qs, R_LD, i, 8 * g);
             const bf16x8 ofb = lds_row8(Os, R_LD, i, 8 * g);
             const float li = ls[i], di = dl[i];
-            const int ri = Rs[i], bi = bs[i] + centre;
+            const int ri = REGION ? Rs[i] : 0, bi = bs[i] + centre;
+            float* srow = slab + (((int64_t)w * heads + h) * N + (vi ? i : 0)) * slab_ld;
             f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -340,30 +362,35 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int jt = 2 * ks + half, j0 = 16 * jt + 4 * g;
+                    if (FULL && jt >= NT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ds8[half * 4 + r] = (bf16)0.f;          // (slab columns >= N are never read)
+                        continue;
+                    }
                     const bf16x8 ka = lds_row8(Ks, R_LD, 16 * jt + c16, 8 * g);
                     const bf16x8 va = lds_row8(Vs, R_LD, 16 * jt + c16, 8 * g);
                     const f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qfb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     const f32x4 dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, ofb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    const uint32_t rj4 = *reinterpret_cast<const uint32_t*>(Rs + j0);
                     const int4 bj4 = *reinterpret_cast<const int4*>(bs + j0);
-                    const int bj[4] = {bj4.x, bj4.y, bj4.z, bj4.w};
-                    const float bb[4] = {tab[bi - bj[0]], tab[bi - bj[1]], tab[bi - bj[2]], tab[bi - bj[3]]};
-                    float dsr[4];
+                    const f32x4 bb = {tab[bi - bj4.x], tab[bi - bj4.y], tab[bi - bj4.z], tab[bi - bj4.w]};
+                    f32x4 a = st * sc2 + (bb - li);
+                    if constexpr (REGION) {
+                        const uint32_t rj4 = *reinterpret_cast<const uint32_t*>(Rs + j0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a[r] += ((int)((rj4 >> (8 * r)) & 0xFF) != ri) ? -100.0f * LOG2E : 0.f;
+                    }
+                    f32x4 p;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float a = st[r] * scale + bb[r];
-                        a += ((int)((rj4 >> (8 * r)) & 0xFF) != ri) ? -100.0f : 0.f;
-                        float p = __expf(a - li);
-                        const bool ok = vi && j0 + r < N;
-                        p = ok ? p : 0.f;
-                        const float ds = p * (dpt[r] - di);
-                        dsr[r] = ds;
-                        ds8[half * 4 + r] = (bf16)ds;
+                        p[r] = __builtin_amdgcn_exp2f(a[r]);
+                        if constexpr (!FULL) p[r] = (vi && j0 + r < N) ? p[r] : 0.f;
                     }
-                    // dS of this (window, head) goes to its own fp32 slab (plain 16-byte stores); wattn_dbias_sum adds the slabs up.
+                    const f32x4 ds = p * (dpt - di);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds8[half * 4 + r] = (bf16)ds[r];
+                    // dS of this (window, head) goes to its own fp32 slab (plain 16-byte stores); wattn_dtable_kernel bins the slabs.
                     // (LDS float atomics for an in-kernel histogram cost 37 of 57 us per window-head; global atomics were as bad.)
-                    if (vi && j0 + 3 < slab_ld)
-                        *reinterpret_cast<float4*>(slab + (((int64_t)w * heads + h) * N + i) * slab_ld + j0) = make_float4(dsr[0], dsr[1], dsr[2], dsr[3]);
+                    if (vi && j0 + 3 < slab_ld) *reinterpret_cast<f32x4*>(srow + j0) = ds;
                 }
                 // A operand [m = d][k = key j]: transposing read of K, k-slot (g, jj) <-> j = 32 ks + 16 (jj >> 2) + 4 g + (jj & 3)
 #pragma unroll
@@ -378,6 +405,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
             store_head_row16(dqkv + ((int64_t)w * N + (vi ? i : 0)) * 3 * C + h * HD, g,
                              make_uint2(pack_bf16x2(dq[0][0] * scale, dq[0][1] * scale), pack_bf16x2(dq[0][2] * scale, dq[0][3] * scale)),
                              make_uint2(pack_bf16x2(dq[1][0] * scale, dq[1][1] * scale), pack_bf16x2(dq[1][2] * scale, dq[1][3] * scale)), vi);
+          }
         }
     }
 }
@@ -458,25 +486,29 @@ int lavt_window_attn_fwd_mfma(const void* qkv, const float* table, const int8_t*
     if (N > 400 || !table) { lavt_set_error("lavt_window_attn_fwd(mfma): N=%d (<= 400) with the bias table required", N); return LAVT_ERR_INVALID; }
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
     dim3 grid(nwin * heads);
-#define LAVT_FWD(NT_)                                                                                                                        \
+#define LAVT_FWD(NT_, FULL_)                                                                                                                        \
     do {                                                                                                                                     \
         constexpr int NP = ((NT_ + 1) / 2) * 32;                                                                                             \
         const size_t lds = (size_t)3 * NP * F_LD * 2 + (size_t)NP * 4 + NP + (size_t)R * 4 + 16;                                             \
         static size_t reserved = 0;                                                                                                          \
         if (lds > 65536 && lds > reserved) {                                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_fwd_mfma<NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_fwd_mfma<NT_, true, FULL_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || \
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_fwd_mfma<NT_, false, FULL_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
                 lavt_set_error("lavt_window_attn_fwd(mfma): cannot reserve %zu bytes of LDS", lds);                                          \
                 return LAVT_ERR_LAUNCH;                                                                                                      \
             }                                                                                                                                \
             reserved = lds;                                                                                                                  \
         }                                                                                                                                    \
-        hipLaunchKernelGGL(wattn_fwd_mfma<NT_>, grid, dim3(256), lds, st, (const bf16*)qkv, table, region, nw_img, (bf16*)out, lse, wd, wh,  \
-                           ww, nwin, N, heads, scale);                                                                                       \
+        if (region) hipLaunchKernelGGL((wattn_fwd_mfma<NT_, true, FULL_>), grid, dim3(256), lds, st, (const bf16*)qkv, table, region, nw_img, (bf16*)out, lse, wd, wh, \
+                                       ww, nwin, N, heads, scale);                                                                           \
+        else hipLaunchKernelGGL((wattn_fwd_mfma<NT_, false, FULL_>), grid, dim3(256), lds, st, (const bf16*)qkv, table, region, nw_img, (bf16*)out, lse, wd, wh, \
+                                ww, nwin, N, heads, scale);                                                                                  \
     } while (0)
-    if (N <= 64) LAVT_FWD(4);
-    else if (N <= 144) LAVT_FWD(9);
-    else if (N <= 160) LAVT_FWD(10);
-    else LAVT_FWD(25);
+    if (N <= 64) LAVT_FWD(4, false);
+    else if (N == 144) LAVT_FWD(9, true);
+    else if (N <= 144) LAVT_FWD(9, false);
+    else if (N <= 160) LAVT_FWD(10, false);
+    else LAVT_FWD(25, false);
 #undef LAVT_FWD
     LAVT_CHECK_LAUNCH("lavt_window_attn_fwd(mfma)");
     return LAVT_OK;
@@ -535,29 +567,36 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     if (wpb < 1) wpb = 1;
     const int chunks = cdiv(nwin, wpb);
     dim3 grid(chunks * heads);
-#define LAVT_BWD(NT_, WV_)                                                                                                                   \
+#define LAVT_BWD_K(NT_, WV_, RG_, FULL_)                                                                                                    \
     do {                                                                                                                                     \
         const size_t lds = bwd_lds_bytes<NT_>(R);                                                                                            \
         static size_t reserved = 0;                                                                                                          \
         if (lds > 65536 && lds > reserved) {                                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_bwd_mfma<NT_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_bwd_mfma<NT_, WV_, RG_, FULL_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
                 lavt_set_error("lavt_window_attn_bwd(mfma): cannot reserve %zu bytes of LDS", lds);                                          \
                 return LAVT_ERR_LAUNCH;                                                                                                      \
             }                                                                                                                                \
             reserved = lds;                                                                                                                  \
         }                                                                                                                                    \
-        hipLaunchKernelGGL((wattn_bwd_mfma<NT_, WV_>), grid, dim3(WV_ * 64), lds, st, (const bf16*)qkv, table, region, nw_img,              \
+        hipLaunchKernelGGL((wattn_bwd_mfma<NT_, WV_, RG_, FULL_>), grid, dim3(WV_ * 64), lds, st, (const bf16*)qkv, table, region, nw_img,   \
                            (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, ws, bias_ld, wd, wh, ww, nwin, N, heads, scale, wpb);     \
+    } while (0)
+#define LAVT_BWD(NT_, WV_, FULL_)                                                                                                            \
+    do {                                                                                                                                     \
+        if (region) LAVT_BWD_K(NT_, WV_, true, FULL_);                                                                                       \
+        else LAVT_BWD_K(NT_, WV_, false, FULL_);                                                                                             \
     } while (0)
     // 8 waves share one window-head, capped at 128 VGPRs so two workgroups (16 waves) sit on a CU: 5-9% faster than 4 waves x 2 at every
     // stage shape of Swin-B w12 @480 (measured, tools/attn_bench2.py).  LAVT_ATTN_BWD_WAVES=4 keeps the 4-wave variant reachable.
     static const int force_waves = getenv("LAVT_ATTN_BWD_WAVES") ? atoi(getenv("LAVT_ATTN_BWD_WAVES")) : 0;
     const int waves = force_waves ? force_waves : 8;
-    if (N <= 64) LAVT_BWD(4, 4);
-    else if (N <= 144) { if (waves == 8) LAVT_BWD(9, 8); else LAVT_BWD(9, 4); }
-    else if (N <= 160) { if (waves == 8) LAVT_BWD(10, 8); else LAVT_BWD(10, 4); }
-    else LAVT_BWD(25, 8);                  // Video-Swin 8x7x7 windows: 149 KB of LDS, one workgroup per CU
+    if (N <= 64) LAVT_BWD(4, 4, false);
+    else if (N == 144) { if (waves == 8) LAVT_BWD(9, 8, true); else LAVT_BWD(9, 4, true); }
+    else if (N <= 144) LAVT_BWD(9, 8, false);
+    else if (N <= 160) LAVT_BWD(10, 8, false);
+    else LAVT_BWD(25, 8, false);           // Video-Swin 8x7x7 windows: 149 KB of LDS, one workgroup per CU
 #undef LAVT_BWD
+#undef LAVT_BWD_K
     LAVT_CHECK_LAUNCH("lavt_window_attn_bwd(mfma)");
     int rpb, wgroups, wpg;
     dtable_geometry(nwin, N, heads, &rpb, &wgroups, &wpg);

@@ -596,6 +596,9 @@ def test_fused_adamw_with_model_forward_outside_train_step():
         assert abs(losses[1][0] - losses[0][0]) > 1e-3, f"the first optimizer step did not reach the forward: {losses}"
         assert abs(losses[2][0] - losses[1][0]) > 1e-4, f"the second optimizer step did not reach the forward: {losses}"
         for a, b in losses[1:]:
-            assert abs(a - b) < 5e-3, losses          # same update rule on both sides (fp32 masters); bf16 forward noise only
+            # same update rule on both sides (fp32 masters).  Adam's first steps are sign-like (g / |g|), so rounding-level differences between the
+            # two optimizers' arithmetic become lr-sized weight differences for near-zero gradients: measured 2e-3 .. 1e-2 here, moving with every
+            # change of kernel rounding; one step changes the loss by 0.18, which is what a stale compute copy would show
+            assert abs(a - b) < 3e-2, losses
         qk = ours.backbone.layers[1].blocks[0].attn.qkv.weight
         assert torch.equal(ops.weights.get(qk, torch.bfloat16), qk.detach().to(torch.bfloat16)), "stale bf16 weight copy after FusedAdamW.step()"

@@ -33,6 +33,10 @@ def run(nwin, heads, ws, iters=20):
         res.append(e0.elapsed_time(e1) / (5 * iters) * 1e3)
     fl = 4.0 * nwin * heads * N * N * 32
     print(f"nwin={nwin:4d} heads={heads:2d} ws={ws:2d}: fwd {res[0]:7.1f} us ({fl / res[0] / 1e6:6.1f} TF/s)   bwd {res[1]:7.1f} us ({2.5 * fl / res[1] / 1e6:6.1f} TF/s)")
-for nwin, heads in ((200, 4), (50, 8), (18, 16), (8, 32)):
-    run(nwin, heads, 12)
-run(648, 3, 7); run(72, 12, 7)
+if len(sys.argv) > 1 and sys.argv[1] == "scan":          # time against the number of (window, head) pairs: one workgroup per CU vs several
+    for nwin in (4, 8, 16, 18, 24, 32, 48, 64):
+        run(nwin, 16, 12)
+else:
+    for nwin, heads in ((200, 4), (50, 8), (18, 16), (8, 32)):
+        run(nwin, heads, 12)
+    run(648, 3, 7); run(72, 12, 7)

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Runs the fused window-attention forward / backward of a stage-2 Swin-B w12 block at batch 2 (18 windows x 16 heads, 144 tokens) a few times:
+target of the rocprofv3 --pmc passes (tools/pmc_passes.sh attn_one)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "lavt-rs_amd"))
+import torch
+from lavt_hip import _capi as K
+dev, bf = "cuda:0", torch.bfloat16
+nwin, heads, ws = int(os.environ.get("ATTN_NWIN", 18)), int(os.environ.get("ATTN_HEADS", 16)), 12
+N, C = ws * ws, heads * 32
+ld = -(-N // 32) * 32
+qkv = torch.randn(nwin * N, 3 * C, device=dev).to(bf)
+out = torch.empty(nwin * N, C, device=dev, dtype=bf); lse = torch.empty(nwin, heads, N, device=dev)
+dout = torch.randn_like(out); dqkv = torch.empty_like(qkv)
+dtable = torch.zeros((2 * ws - 1) ** 2, heads, device=dev)
+wsb = torch.empty(int(K.lib.lavt_window_attn_bwd_ws(K.dt(bf), nwin, N, heads, ld, 1, ws, ws)), device=dev)
+table = torch.randn((2 * ws - 1) ** 2, heads, device=dev) * 0.1
+for _ in range(6):
+    K.check(K.lib.lavt_window_attn_fwd(K.dt(bf), K.ptr(qkv), None, ld, None, 0, K.ptr(out), K.ptr(lse), K.ptr(table), 1, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
+    K.check(K.lib.lavt_window_attn_bwd(K.dt(bf), K.ptr(qkv), None, ld, None, 0, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(table), K.ptr(dtable), K.ptr(wsb), wsb.numel(), None, 1, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
+torch.cuda.synchronize()

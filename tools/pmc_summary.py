@@ -3,9 +3,12 @@
 usage: pmc_summary.py <gpurun_out/r02_pmc> <out.json>"""
 import csv, glob, json, os, sys
 root, out = sys.argv[1], sys.argv[2]
-TARGET = {"conv_one": "gemm_nt_v2_kernel<256, 256, false, 2, 16, 2", "wgrad_group_one": "gemm_tn_v2_grouped_kernel"}
+TARGET = {"conv_one": ["gemm_nt_v2_kernel<256, 256, false, 2, 16, 2"], "wgrad_group_one": ["gemm_tn_v2_grouped_kernel"],
+          "attn_one": ["wattn_bwd_mfma", "wattn_fwd_mfma"]}
 res = {}
-for tgt, pat in TARGET.items():
+for tgt, pat in [(t, p) for t, ps in TARGET.items() for p in ps]:
+    if not os.path.isdir(os.path.join(root, tgt)):
+        continue
     ent = {"kernel_match": pat, "counters_per_launch": {}}
     for d in sorted(glob.glob(os.path.join(root, tgt, "*"))):
         name = os.path.basename(d)
@@ -23,6 +26,6 @@ for tgt, pat in TARGET.items():
             ent["counters_per_launch"][name] = sum(vals) / len(vals)
             ent.setdefault("launch_us_under_profiler", {})[name] = round(sum(durs) / len(durs), 1)
             ent["vgpr_agpr_sgpr_scratch_lds_grid_wg"] = regs
-    res[tgt] = ent
+    res[tgt if len(TARGET[tgt]) == 1 else tgt + ":" + pat] = ent
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
