@@ -389,7 +389,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ds8[half * 4 + r] = (bf16)ds[r];
                     // dS of this (window, head) goes to its own fp32 slab (plain 16-byte stores); wattn_dtable_kernel bins the slabs.
-                    // (LDS float atomics for an in-kernel histogram cost 37 of 57 us per window-head; global atomics were as bad.)
+                    // (LDS float atomics for an in-kernel histogram -- ds_add_f32 per element, up to 4 lanes of a wave on one table entry -- were
+                    // measured twice: 37 of 57 us per window-head in round 1, 72 vs 34 us for the stage-2 launch in round 2; global atomics as bad.)
                     if (vi && j0 + 3 < slab_ld) *reinterpret_cast<f32x4*>(srow + j0) = ds;
                 }
                 // A operand [m = d][k = key j]: transposing read of K, k-slot (g, jj) <-> j = 32 ks + 16 (jj >> 2) + 4 g + (jj & 3)
@@ -529,25 +530,37 @@ int64_t lavt_window_attn_bwd_ws_mfma(int nwin, int N, int heads, int bias_ld, in
 }
 
 // several layers' per-workgroup table histograms -> their table gradients in ONE launch (deferred form): desc[s] = {part, pieces, heads, R, dtable}
-__global__ void wattn_dtable_finish_multi(const int64_t* __restrict__ desc) {
+__global__ __launch_bounds__(256) void wattn_dtable_finish_multi(const int64_t* __restrict__ desc) {
+    // 32 table entries x 8 piece lanes per workgroup (one thread per entry walking all pieces -- 252 for a stage-0 layer -- was a 38 us launch)
+    __shared__ float red[8][32];
     const int64_t* d = desc + (int64_t)blockIdx.z * 5;
     const float* part = reinterpret_cast<const float*>(d[0]);
     const int pieces = (int)d[1], heads = (int)d[2], R = (int)d[3];
     float* dtable = reinterpret_cast<float*>(d[4]);
-    const int e = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y;
-    if (e >= R || h >= heads) return;
-    const float* q = part + (int64_t)h * R + e;
+    const int el = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el, h = blockIdx.y;
+    if (h >= heads || blockIdx.x * 32 >= R) return;          // uniform per workgroup
     const int64_t st = (int64_t)heads * R;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 3 < pieces; k += 4, q += 4 * st)
+    if (e < R) {
+        const float* q = part + (int64_t)h * R + e;
+        int k = pl;
+        for (; k + 24 < pieces; k += 32)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] += q[u * st];
-    for (; k < pieces; ++k, q += st) acc[0] += *q;
-    dtable[(int64_t)e * heads + h] += (acc[0] + acc[1]) + (acc[2] + acc[3]);          // one writer per entry: the zeroed gradient buffer
+            for (int u = 0; u < 4; ++u) acc[u] += q[(int64_t)(k + 8 * u) * st];
+        for (; k < pieces; k += 8) acc[0] += q[(int64_t)k * st];
+    }
+    red[pl][el] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (pl == 0 && e < R) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += red[k][el];
+        dtable[(int64_t)e * heads + h] += a;                 // one writer per entry: the zeroed gradient buffer
+    }
 }
 int lavt_attn_dtable_finish_multi_impl(const int64_t* desc, int n, int max_R, int max_heads, hipStream_t st) {
-    hipLaunchKernelGGL(wattn_dtable_finish_multi, dim3(cdiv(max_R, 256), max_heads, n), dim3(256), 0, st, desc);
+    hipLaunchKernelGGL(wattn_dtable_finish_multi, dim3(cdiv(max_R, 32), max_heads, n), dim3(256), 0, st, desc);
     LAVT_CHECK_LAUNCH("lavt_attn_dtable_finish_multi");
     return LAVT_OK;
 }

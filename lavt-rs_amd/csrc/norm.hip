@@ -228,10 +228,13 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(const int64_
     const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int w = blockIdx.x * 32 + col;
     const int per = (nblk + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * per, k1 = min(nblk, k0 + per);
-    float a = 0.f;
-    if (w < W)
-        for (int k = k0 + slice; k < k1; k += 8) a += partials[(int64_t)k * W + w];
-    red[slice][col] = a;
+    float a = 0.f, b = 0.f;
+    if (w < W) {
+        int k = k0 + slice;
+        for (; k + 8 < k1; k += 16) { a += partials[(int64_t)k * W + w]; b += partials[(int64_t)(k + 8) * W + w]; }
+        for (; k < k1; k += 8) a += partials[(int64_t)k * W + w];
+    }
+    red[slice][col] = a + b;
     __syncthreads();
     if (slice == 0 && w < W && k0 < k1) {
         float t = 0.f;
@@ -352,23 +355,28 @@ __global__ void colstats_center_kernel(const T* __restrict__ x, float* __restric
 // rows are summed, re-centred about the pivot row and turned into mean / rstd (and the running estimates) in ONE kernel instead of
 // reduce_partials + colstats_center + stats_finalize.  Workgroup = 16 columns x {shifted sum, shifted square sum} x 8 row slices.
 template <typename T>
-__global__ __launch_bounds__(256) void colstats_finish_kernel(const float* __restrict__ partials, int nblk, int groups, int C, const T* __restrict__ x,
-                                                              int rows, float eps, float* __restrict__ mean, float* __restrict__ rstd,
-                                                              float* __restrict__ sum_out, float* __restrict__ m2_out,
-                                                              float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
-    __shared__ float red[8][32];
+__global__ __launch_bounds__(1024) void colstats_finish_kernel(const float* __restrict__ partials, int nblk, int groups, int C, const T* __restrict__ x,
+                                                               int rows, float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                                               float* __restrict__ sum_out, float* __restrict__ m2_out,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
+    // 32 row slices (was 8: 112 dependent-latency loads per thread on the 900 row blocks of the decoder maps, 22 us per launch)
+    __shared__ float red[32][32];
     const int c16 = threadIdx.x & 15, which = (threadIdx.x >> 4) & 1, slice = threadIdx.x >> 5;
     const int c = blockIdx.x * 16 + c16, g = blockIdx.y;
     const int64_t W = (int64_t)groups * 2 * C;
-    float a = 0.f;
-    if (c < C)
-        for (int k = slice; k < nblk; k += 8) a += partials[(int64_t)k * W + ((int64_t)g * 2 + which) * C + c];
-    red[slice][threadIdx.x & 31] = a;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < C) {
+        const float* q = partials + ((int64_t)g * 2 + which) * C + c;
+        int k = slice;
+        for (; k + 96 < nblk; k += 128) { a0 += q[(int64_t)k * W]; a1 += q[(int64_t)(k + 32) * W]; a2 += q[(int64_t)(k + 64) * W]; a3 += q[(int64_t)(k + 96) * W]; }
+        for (; k < nblk; k += 32) a0 += q[(int64_t)k * W];
+    }
+    red[slice][threadIdx.x & 31] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (slice == 0 && which == 0 && c < C) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { s1 += red[k][c16]; s2 += red[k][16 + c16]; }
+        for (int k = 0; k < 32; ++k) { s1 += red[k][c16]; s2 += red[k][16 + c16]; }
         const float kpiv = to_f<T>(x[(int64_t)g * rows * C + c]);
         const float n = (float)rows;
         const float sum = s1 + n * kpiv, m2 = fmaxf(s2 - s1 * s1 / n, 0.f);
@@ -566,8 +574,8 @@ extern "C" int lavt_layernorm_bwd_partial(int dtype, const void* dy, const void*
 }
 extern "C" int lavt_reduce_partials_multi(const int64_t* desc, int n, void* stream) {
     LAVT_CHECK_ARG(desc && n > 0, "lavt_reduce_partials_multi: bad arguments");
-    // widest supported set: C = 2048 -> 128 column blocks; 4 row slices per set
-    hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(128, 4, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
+    // widest supported set: C = 2048 -> 128 column blocks; 8 row slices per set
+    hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(128, 8, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
     LAVT_CHECK_LAUNCH("lavt_reduce_partials_multi");
     return LAVT_OK;
 }
@@ -615,7 +623,7 @@ extern "C" int lavt_colstats_meanrstd(int dtype, const void* x, float* mean, flo
     DISPATCH_T(dtype, "lavt_colstats_meanrstd",
                hipLaunchKernelGGL((colstats_kernel<T, false>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
                                   (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, 0, mean, rstd, ws, rows, C, rpb, 0);
-               hipLaunchKernelGGL(colstats_finish_kernel<T>, dim3(cdiv(C, 16), groups), dim3(256), 0, st, ws, blocks, groups, C, (const T*)x, rows, eps, mean, rstd,
+               hipLaunchKernelGGL(colstats_finish_kernel<T>, dim3(cdiv(C, 16), groups), dim3(1024), 0, st, ws, blocks, groups, C, (const T*)x, rows, eps, mean, rstd,
                                   (float*)nullptr, (float*)nullptr, running_mean, running_var, momentum));
     LAVT_CHECK_LAUNCH("lavt_colstats_meanrstd");
     return LAVT_OK;
