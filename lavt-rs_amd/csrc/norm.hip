@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     }
 }
 
-template <typename T, int LPR, int CPL>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T, int LPR, int CPL, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const int32_t* __restrict__ gather, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     float dg[MAXC * EPC], db[MAXC * EPC];
 #pragma unroll
     for (int e = 0; e < MAXC * EPC; ++e) { dg[e] = 0.f; db[e] = 0.f; }
-    const int64_t rstride = (int64_t)gridDim.x * 4 * RPW;
-    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += rstride) {
+    const int64_t rstride = (int64_t)gridDim.x * WAVES * RPW;
+    for (int64_t row0 = ((int64_t)blockIdx.x * WAVES + wave) * RPW; row0 < rows; row0 += rstride) {
         const int64_t row = row0 + lane / LPR;
         const bool live = row < rows;
         const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
@@ -150,13 +150,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
         }
     }
-    // sum the RPW row groups of the wave, then the four waves through LDS, then ONE atomic per channel per workgroup
+    // sum the RPW row groups of the wave, then the waves through LDS, then ONE partial (or atomic) per channel per workgroup
 #pragma unroll
     for (int e = 0; e < MAXC * EPC; ++e) {
 #pragma unroll
         for (int o = LPR; o < 64; o <<= 1) { dg[e] += __shfl_xor(dg[e], o, 64); db[e] += __shfl_xor(db[e], o, 64); }
     }
-    __shared__ float red[3 * 2048];
+    __shared__ float red[(WAVES - 1) * (LPR * CPL * EPC)];
+    constexpr int RW = LPR * CPL * EPC;                    // >= C
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         float* part = pass == 0 ? dg : db;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 const int ch = lir + LPR * c;
                 if (c < cpl && ch < nchunk)
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) red[(wave - 1) * 2048 + ch * EPC + e] = part[c * EPC + e];
+                    for (int e = 0; e < EPC; ++e) red[(wave - 1) * RW + ch * EPC + e] = part[c * EPC + e];
             }
         }
         __syncthreads();
@@ -180,7 +181,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
                         const int col = ch * EPC + e;
-                        const float tot = part[c * EPC + e] + red[col] + red[2048 + col] + red[4096 + col];
+                        float tot = part[c * EPC + e];
+#pragma unroll
+                        for (int w = 0; w < WAVES - 1; ++w) tot += red[w * RW + col];
                         // hundreds of workgroups adding to the SAME C addresses serialise in L2: write per-workgroup partials instead
                         if (partials) partials[((int64_t)blockIdx.x * 2 + pass) * C + col] = tot;
                         else atomicAdd(dst + col, tot);
@@ -528,19 +531,23 @@ extern "C" int lavt_layernorm_fwd(int dtype, const void* x, const int32_t* gathe
     return LAVT_OK;
 }
 
-static int ln_bwd_geometry(int dtype, int rows, int C, int* lpr_out, int* cpl_out) {
+static int ln_bwd_geometry(int dtype, int rows, int C, int* lpr_out, int* cpl_out, int* waves_out) {
     const int epc = dtype == LAVT_F32 ? 4 : 8;
     const int nchunk = C / epc;
     const int lpr = nchunk <= 16 ? 16 : nchunk <= 32 ? 32 : 64;
     const int cpl = cdiv(nchunk, lpr);                       // 1 (C <= 512 bf16 / 256 fp32), 2, or up to 4 / 8
-    int blocks = cdiv(rows, 4 * (64 / lpr) * 2);             // two rows per wave: the step's LayerNorms have 450 .. 28 800 rows
-    if (rows <= 256) blocks = cdiv(rows, 4 * (64 / lpr));    // a few dozen rows (BERT: 40-44 tokens): one row per wave, no serial second row
+    // 8 waves of one row pass each where that keeps the partial count of the old "4 waves x 2 serial rows" form (the second row's loads
+    // started only after the first row's reductions: 9.5 us for the 1800 x 512 maps of a stage-2 block); wide rows (cpl > 2) stay at 4 waves
+    const int waves = (cpl <= 2 && rows > 256) ? 8 : 4;
+    int blocks = cdiv(rows, 8 * (64 / lpr));
+    if (rows <= 256) blocks = cdiv(rows, 4 * (64 / lpr));    // a few dozen rows (BERT: 40-44 tokens): one row per wave
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     *lpr_out = lpr; *cpl_out = cpl;
+    if (waves_out) *waves_out = waves;
     return blocks;
 }
-extern "C" int lavt_layernorm_bwd_blocks(int dtype, int rows, int C) { int a, b; return ln_bwd_geometry(dtype, rows, C, &a, &b); }
+extern "C" int lavt_layernorm_bwd_blocks(int dtype, int rows, int C) { int a, b; return ln_bwd_geometry(dtype, rows, C, &a, &b, nullptr); }
 
 static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
                               const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats,
@@ -550,14 +557,15 @@ static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const in
     LAVT_CHECK_ARG(C > 0 && C <= 2048 && C % epc == 0 && (!gather || (C / 4) % epc == 0), "lavt_layernorm_bwd: unsupported C=%d", C);
     LAVT_CHECK_ARG(!(gather && dres), "lavt_layernorm_bwd: dres is not supported together with gather");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int lpr, cpl;
-    const int blocks = ln_bwd_geometry(dtype, rows, C, &lpr, &cpl);
+    int lpr, cpl, waves;
+    const int blocks = ln_bwd_geometry(dtype, rows, C, &lpr, &cpl, &waves);
     float* partials = (ws && ws_floats >= (int64_t)blocks * 2 * C) ? ws : nullptr;
     LAVT_CHECK_ARG(!partial_only || partials, "lavt_layernorm_bwd_partial: scratch of %ld floats needed", (long)blocks * 2 * C);
-#define LN_BWD(LPR_, CPL_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_, CPL_>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, (const T*)dres, rows, C)
+#define LN_BWD(LPR_, CPL_, WV_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_, CPL_, WV_>), dim3(blocks), dim3(WV_ * 64), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, (const T*)dres, rows, C)
     DISPATCH_T(dtype, "lavt_layernorm_bwd",
-               if (lpr == 16) LN_BWD(16, 1); else if (lpr == 32) LN_BWD(32, 1);
-               else if (cpl == 1) LN_BWD(64, 1); else if (cpl == 2) LN_BWD(64, 2); else if (cpl <= 4) LN_BWD(64, 4); else LN_BWD(64, 8));
+               if (waves == 8) { if (lpr == 16) LN_BWD(16, 1, 8); else if (lpr == 32) LN_BWD(32, 1, 8); else if (cpl == 1) LN_BWD(64, 1, 8); else LN_BWD(64, 2, 8); }
+               else if (lpr == 16) LN_BWD(16, 1, 4); else if (lpr == 32) LN_BWD(32, 1, 4);
+               else if (cpl == 1) LN_BWD(64, 1, 4); else if (cpl == 2) LN_BWD(64, 2, 4); else if (cpl <= 4) LN_BWD(64, 4, 4); else LN_BWD(64, 8, 4));
 #undef LN_BWD
     if (partials && !partial_only) hipLaunchKernelGGL(reduce_partials_kernel, reduce_partials_grid(blocks, 2 * C), dim3(256), 0, st, partials, blocks, 2 * C, C, dgamma, dbeta);
     LAVT_CHECK_LAUNCH("lavt_layernorm_bwd");
