@@ -563,6 +563,9 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
 
     // ---- side inputs of tile t (relative to kt_begin) -> map ring slot t % NSLOT: wave 0 a_rowmap, 1 a_rowscale, 2 b_rowmap, others spare
     const float inv_rsdiv = 1.0f / (float)(p.a_rowscale_div > 1 ? p.a_rowscale_div : 1);
+    const int amask = p.a_rowmap ? -1 : 0, bmask = p.b_rowmap ? -1 : 0;
+    const unsigned nors = p.a_rowscale ? 0u : 1u, lda_u = (unsigned)p.lda;
+    const int Kdim = p.K;
     auto map_dma = [&](int t) {
         if constexpr (MAPS) {
             int k = (kt_begin + t) * BK + lane;
@@ -631,38 +634,40 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
             }
             return;
         }
+        // mapped rows: branch-free -- the per-problem switches (which maps exist) are lane-uniform masks hoisted out of the loop; the first
+        // version tested them per DMA inside the K loop: ~30 scalar branches per K tile, 14 vector instructions per MFMA (PMC)
         const int kbase = (kt_begin + t) * BK;
         const int* m_a = reinterpret_cast<const int*>(maps + (t % NSLOT) * SLOT_BYTES);
-        const float* m_rs = reinterpret_cast<const float*>(maps + (t % NSLOT) * SLOT_BYTES + 256);
+        const unsigned* m_rs = reinterpret_cast<const unsigned*>(maps + (t % NSLOT) * SLOT_BYTES + 256);
         const int* m_b = reinterpret_cast<const int*>(maps + (t % NSLOT) * SLOT_BYTES + 512);
-        int a_src[A_INSTR], b_src[B_INSTR];
+        const T* a_ptr[A_INSTR];
+        const T* b_ptr[B_INSTR];
+        int ma[A_INSTR], mb[B_INSTR];
+        unsigned mr[A_INSTR];
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) { ma[i] = m_a[a_kr[i] & 63]; mr[i] = m_rs[a_kr[i] & 63]; }      // all LDS reads first (dead lanes, a_kr = -1,
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) mb[i] = m_b[b_kr[i] & 63];                                      //  read slot 63 and are masked below)
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
-            const int kr = a_kr[i] >= 0 ? a_kr[i] : 0, k = kbase + kr;
-            int src = k;
-            bool ok = a_kr[i] >= 0 && k < p.K;
-            if constexpr (MAPS) {
-                if (p.a_rowmap) src = m_a[kr];
-                if (p.a_rowscale) ok = ok && m_rs[kr] != 0.f;
-            }
-            a_src[i] = (ok && src >= 0) ? src : -1;
+            const int k = kbase + (a_kr[i] & 63);
+            const int src = (ma[i] & amask) | (k & ~amask);
+            const bool ok = ((a_kr[i] | src) >= 0) & (k < Kdim) & (((mr[i] << 1) | nors) != 0u);
+            const unsigned off = ok ? (unsigned)src * lda_u + (unsigned)a_col[i] : 0u;
+            a_ptr[i] = (ok ? A : Z) + off;
         }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            const int kr = b_kr[i] >= 0 ? b_kr[i] : 0, k = kbase + kr;
-            int src = k;
-            if constexpr (MAPS) { if (p.b_rowmap) src = m_b[kr]; }
-            b_src[i] = (b_kr[i] >= 0 && k < p.K) ? src : -1;
+            const int k = kbase + (b_kr[i] & 63);
+            const int src = (mb[i] & bmask) | (k & ~bmask);
+            const bool ok = ((b_kr[i] | src) >= 0) & (k < Kdim);
+            const unsigned off = ok ? (unsigned)src * (unsigned)b_ld[i] : 0u;
+            b_ptr[i] = (ok ? b_base[i] : Z) + off;
         }
 #pragma unroll
-        for (int i = 0; i < A_INSTR; ++i)
-            dma16(a_src[i] >= 0 ? A + (int64_t)a_src[i] * p.lda + a_col[i] : Z, sa + (wave * A_INSTR + i) * 1024);
+        for (int i = 0; i < A_INSTR; ++i) dma16(a_ptr[i], sa + (wave * A_INSTR + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            int src = b_src[i];
-            if (conv) src = conv_nbr(cg, src, b_dz[i], b_dy[i], b_dx[i]);
-            dma16(src >= 0 ? b_base[i] + (int64_t)src * b_ld[i] : Z, sb + (wave * B_INSTR + i) * 1024);
-        }
+        for (int i = 0; i < B_INSTR; ++i) dma16(b_ptr[i], sb + (wave * B_INSTR + i) * 1024);
     };
 
     // fragment read addresses relative to a stage's operand tile: K row of the lane, swizzled 32-byte slot of fragment i, 8-byte half
@@ -908,6 +913,8 @@ static bool tn_v2_eligible(const lavt_gemm_tn_t& p) {
     if (p.dtype != LAVT_BF16 || p.zeros == nullptr) return false;
     if (p.lda % 8 || p.ldb % 8 || (p.B2 && p.ldb2 % 8)) return false;
     if (p.a_rowscale && !p.a_rowscale_binary) return false;
+    if ((p.a_rowmap || p.a_rowscale || p.b_rowmap) && (p.conv_kc > 0 || p.B2)) return false;      // the mapped K loop has no taps / second source
+    if ((int64_t)p.K * (p.lda > p.ldb ? p.lda : p.ldb) >= (1LL << 31)) return false;                // 32-bit element offsets
     return true;
 }
 
@@ -964,8 +971,7 @@ int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st) {
     if (p.dtype != LAVT_BF16 || p.zeros == nullptr) return 1;
     const char* e = getenv("LAVT_GEMM_V2");
     if (e && e[0] == '0') return 1;
-    if (p.lda % 8 || p.ldb % 8 || (p.B2 && p.ldb2 % 8)) return 1;
-    if (p.a_rowscale && !p.a_rowscale_binary) return 1;          // only 0 / constant masks can be folded into the row fetch
+    if (!tn_v2_eligible(p)) return 1;                            // (only 0 / constant row masks can be folded into the row fetch)
     // Measured (tools/gemm_bench.py tn): the 64x64 / 4-wave tile wins on every weight-gradient shape of the step, the conv wgrads included
     // (369 vs 230 TF/s for 128x128); the split-K factor trades workgroup count (latency hiding) against fp32 atomic traffic.
     const char* t = getenv("LAVT_GEMM_TILE");
