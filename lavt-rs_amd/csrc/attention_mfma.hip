@@ -239,6 +239,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
     // Task list of a window: t < QT -> pass 1 of key tile t; QT <= t < 2 QT -> pass 2 of query tile t - QT.  A wave takes t = slot, slot + WAVES, ...
     // (9 tiles on 8 waves: 3, 3, 2, ... tasks instead of one wave running 2 + 2).  The kernel is VALU-issue bound and waves w, w + 4 share a SIMD,
     // so workgroups that are likely to share a CU (the grid's second round of 256) start the list two slots later: the heavy SIMDs differ.
+    // (9 waves of exactly one pass-1 and one pass-2 task -- 96 VGPRs for two workgroups per CU, 34 spills in the shifted variant -- measured
+    // slower: 36.7 vs 34.1 us with the table kernels for the stage-2 launch, 10.77 vs 10.50 ms per step.)
     const int slot = (wave + 2 * ((blockIdx.x >> 8) & 1)) % WAVES;
 
     const int w_end = min(nwin, (chunk + 1) * win_per_block);

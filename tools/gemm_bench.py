@@ -52,6 +52,7 @@ SHAPES = [
     ("qkv s2", "nt", 2592, 1536, 512), ("proj s2", "nt", 2592, 512, 512), ("fc1 s2", "nt", 1800, 2048, 512), ("fc2 s2", "nt", 1800, 512, 2048),
     ("qkv s0", "nt", 28800, 384, 128), ("fc1 s0", "nt", 28800, 512, 128), ("fc2 s0", "nt", 28800, 128, 512), ("fc1 s1", "nt", 7200, 1024, 256),
     ("fc1 s3", "nt", 450, 4096, 1024), ("fc2 s3", "nt", 450, 1024, 4096),
+    ("pwam s0", "nt", 28800, 128, 128), ("pwam s1", "nt", 7200, 256, 256), ("pwam s2", "nt", 1800, 512, 512), ("d-pwam s0", "ntk", 28800, 128, 128),
     ("d-qkv s2", "ntk", 2592, 512, 1536), ("d-fc1 s2", "ntk", 1800, 512, 2048), ("d-fc2 s2", "ntk", 1800, 2048, 512), ("d-fc2 s0", "ntk", 28800, 512, 128),
     ("w-conv2_2", "tn", 512, 4608, 28800), ("w-qkv s2", "tn", 1536, 512, 2592), ("w-fc1 s2", "tn", 2048, 512, 1800), ("w-fc2 s2", "tn", 512, 2048, 1800), ("w-fc1 s0", "tn", 512, 128, 28800),
     ("w-qkv s0", "tn", 384, 128, 28800), ("w-fc1 s3", "tn", 4096, 1024, 450), ("w-pwam s0", "tn", 128, 128, 28800),
@@ -59,7 +60,7 @@ SHAPES = [
 
 def main():
     for name, kind, a, b, c in SHAPES:
-        if len(sys.argv) > 1 and kind != sys.argv[1]:
+        if len(sys.argv) > 1 and kind != sys.argv[1] and sys.argv[1] not in name:
             continue
         res = []
         if kind == "tn":
