@@ -209,7 +209,7 @@ template <int NT, int WAVES, bool REGION, bool FULL>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void wattn_bwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                       const int8_t* __restrict__ region, int nw_img, const bf16* __restrict__ out,
                                                       const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                      bf16* __restrict__ dqkv, float* __restrict__ slab, int slab_ld,
+                                                      bf16* __restrict__ dqkv, bf16* __restrict__ slab, int slab_ld,
                                                       int wd, int wh, int ww, int nwin, int N, int heads, float scale, int win_per_block) {
     constexpr int KS = (NT + 1) / 2, NP = KS * 32;         // tiles are consumed in pairs (k = 32)
     constexpr int NTHR = WAVES * 64;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
             const bf16x8 ofb = lds_row8(Os, R_LD, i, 8 * g);
             const float li = ls[i], di = dl[i];
             const int ri = REGION ? Rs[i] : 0, bi = bs[i] + centre;
-            float* srow = slab + (((int64_t)w * heads + h) * N + (vi ? i : 0)) * slab_ld;
+            bf16* srow = slab + (((int64_t)w * heads + h) * N + (vi ? i : 0)) * slab_ld;
             f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -390,10 +390,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
                     const f32x4 ds = p * (dpt - di);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ds8[half * 4 + r] = (bf16)ds[r];
-                    // dS of this (window, head) goes to its own fp32 slab (plain 16-byte stores); wattn_dtable_kernel bins the slabs.
+                    // dS of this (window, head) goes to its own slab, in bf16 -- the values dQ / dK are computed from -- as plain 8-byte stores;
+                    // wattn_dtable_kernel sums the slabs over windows in fp32 and bins them (fp32 slabs: twice the bytes written here and read
+                    // there, 9.1 vs ~6 us for the binning kernel of a stage-2 block).
                     // (LDS float atomics for an in-kernel histogram -- ds_add_f32 per element, up to 4 lanes of a wave on one table entry -- were
                     // measured twice: 37 of 57 us per window-head in round 1, 72 vs 34 us for the stage-2 launch in round 2; global atomics as bad.)
-                    if (vi && j0 + 3 < slab_ld) *reinterpret_cast<f32x4*>(srow + j0) = ds;
+                    if (vi && j0 + 3 < slab_ld)
+                        *reinterpret_cast<uint2*>(srow + j0) = make_uint2(pack_bf16x2(ds[0], ds[1]), pack_bf16x2(ds[2], ds[3]));
                 }
                 // A operand [m = d][k = key j]: transposing read of K, k-slot (g, jj) <-> j = 32 ks + 16 (jj >> 2) + 4 g + (jj & 3)
 #pragma unroll
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
 // grid = (row chunks, heads, window groups).  A wave walks rows i of its chunk, lanes cover the keys j (coalesced row reads), the sum over
 // the group's windows stays in registers; the (i, j) -> table-index binning then costs one LDS atomic per (i, j) per workgroup (not per
 // window), and one global atomic per touched table entry per workgroup.
-__global__ __launch_bounds__(256) void wattn_dtable_kernel(const float* __restrict__ slab, float* __restrict__ part, int slab_ld, int wd, int wh,
+__global__ __launch_bounds__(256) void wattn_dtable_kernel(const bf16* __restrict__ slab, float* __restrict__ part, int slab_ld, int wd, int wh,
                                                            int ww, int nwin, int N, int heads, int rows_per_block, int win_per_group) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(256) void wattn_dtable_kernel(const float* __restri
     int* bs = reinterpret_cast<int*>(hist + R);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y;
     for (int e = tid; e < R; e += 256) hist[e] = 0.f;
-    for (int e = tid; e < N; e += 256) {
+    for (int e = tid; e < N + 1; e += 256) {
         const int dz = e / (wh * ww), hy = (e / ww) % wh, wx = e % ww;
         bs[e] = (dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx;
     }
@@ -435,20 +438,29 @@ __global__ __launch_bounds__(256) void wattn_dtable_kernel(const float* __restri
     const int w0 = blockIdx.z * win_per_group, w1 = min(nwin, w0 + win_per_group);
     const int64_t wstride = (int64_t)heads * N * slab_ld;
     for (int i = r0 + wave; i < r1; i += 4) {
-        const float* row = slab + ((int64_t)w0 * heads + h) * N * slab_ld + (int64_t)i * slab_ld;
+        const bf16* row = slab + ((int64_t)w0 * heads + h) * N * slab_ld + (int64_t)i * slab_ld;
         const int bi = bs[i] + centre;
-        // eight windows at a time: eight independent loads in flight per lane and key
-        for (int j = lane; j < N; j += 64) {
-            const float* q = row + j;
-            float acc[8];
+        // a lane owns a PAIR of keys (one 4-byte load); eight windows at a time: eight independent loads in flight per lane
+        for (int j = 2 * lane; j < N; j += 128) {
+            const bf16* q = row + j;
+            float a0[8], a1[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+            for (int u = 0; u < 8; ++u) { a0[u] = 0.f; a1[u] = 0.f; }
             int w = w0;
             for (; w + 7 < w1; w += 8, q += 8 * wstride)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u] += q[u * wstride];
-            for (; w < w1; ++w, q += wstride) acc[0] += *q;
-            atomicAdd(hist + (bi - bs[j]), ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])));
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned v = *reinterpret_cast<const unsigned*>(q + u * wstride);
+                    a0[u] += __uint_as_float(v << 16);
+                    a1[u] += __uint_as_float(v & 0xFFFF0000u);
+                }
+            for (; w < w1; ++w, q += wstride) {
+                const unsigned v = *reinterpret_cast<const unsigned*>(q);
+                a0[0] += __uint_as_float(v << 16);
+                a1[0] += __uint_as_float(v & 0xFFFF0000u);
+            }
+            atomicAdd(hist + (bi - bs[j]), ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7])));
+            if (j + 1 < N) atomicAdd(hist + (bi - bs[j + 1]), ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7])));
         }
     }
     __syncthreads();
@@ -594,7 +606,7 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
             reserved = lds;                                                                                                                  \
         }                                                                                                                                    \
         hipLaunchKernelGGL((wattn_bwd_mfma<NT_, WV_, RG_, FULL_>), grid, dim3(WV_ * 64), lds, st, (const bf16*)qkv, table, region, nw_img,   \
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, ws, bias_ld, wd, wh, ww, nwin, N, heads, scale, wpb);     \
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, reinterpret_cast<bf16*>(ws), bias_ld, wd, wh, ww, nwin, N, heads, scale, wpb); \
     } while (0)
 #define LAVT_BWD(NT_, WV_, FULL_)                                                                                                            \
     do {                                                                                                                                     \
@@ -618,7 +630,7 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     // per-workgroup histograms [wgroups * chunks][heads][R]: after the slabs, or -- deferred form -- in the caller's persistent buffer, to be
     // summed into the table gradients of all layers by one lavt_attn_dtable_finish_multi launch at the end of backward
     float* part = parts ? parts : ws + (int64_t)nwin * heads * N * bias_ld;
-    hipLaunchKernelGGL(wattn_dtable_kernel, dim3(cdiv(N, rpb), heads, wgroups), dim3(256), (size_t)(R + N) * 4, st, ws, part, bias_ld, wd, wh, ww, nwin,
+    hipLaunchKernelGGL(wattn_dtable_kernel, dim3(cdiv(N, rpb), heads, wgroups), dim3(256), (size_t)(R + N + 1) * 4, st, reinterpret_cast<const bf16*>(ws), part, bias_ld, wd, wh, ww, nwin,
                        N, heads, rpb, wpg);
     const int pieces = wgroups * cdiv(N, rpb), per_z = 16;
     if (!parts) hipLaunchKernelGGL(wattn_dtable_finish, dim3(cdiv(R, 256), heads, cdiv(pieces, per_z)), dim3(256), 0, st, part, dtable, pieces, per_z, heads, R);
