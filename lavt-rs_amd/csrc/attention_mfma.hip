@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void wattn_dtable_kernel(const bf16* __restric
     int* bs = reinterpret_cast<int*>(hist + R);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y;
     for (int e = tid; e < R; e += 256) hist[e] = 0.f;
-    for (int e = tid; e < N + 1; e += 256) {
+    for (int e = tid; e < N; e += 256) {
         const int dz = e / (wh * ww), hy = (e / ww) % wh, wx = e % ww;
         bs[e] = (dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx;
     }
@@ -440,27 +440,33 @@ __global__ __launch_bounds__(256) void wattn_dtable_kernel(const bf16* __restric
     for (int i = r0 + wave; i < r1; i += 4) {
         const bf16* row = slab + ((int64_t)w0 * heads + h) * N * slab_ld + (int64_t)i * slab_ld;
         const int bi = bs[i] + centre;
-        // a lane owns a PAIR of keys (one 4-byte load); eight windows at a time: eight independent loads in flight per lane
-        for (int j = 2 * lane; j < N; j += 128) {
+        // a lane owns a QUAD of keys (one 8-byte load: 36 lanes cover a 144-token row in one pass); sixteen windows at a time, then ONE predicated
+        // round for the rest: the kernel is a chain of dependent-latency rounds (18 windows were 2 passes x 3 rounds with key pairs and 8-window steps)
+        for (int j = 4 * lane; j < N; j += 256) {
             const bf16* q = row + j;
-            float a0[8], a1[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { a0[u] = 0.f; a1[u] = 0.f; }
+            float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+            auto add = [&](float (&t)[4], uint2 v) {
+                t[0] += __uint_as_float(v.x << 16); t[1] += __uint_as_float(v.x & 0xFFFF0000u);
+                t[2] += __uint_as_float(v.y << 16); t[3] += __uint_as_float(v.y & 0xFFFF0000u);
+            };
             int w = w0;
-            for (; w + 7 < w1; w += 8, q += 8 * wstride)
+            for (; w + 15 < w1; w += 16, q += 16 * wstride) {
+                uint2 v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const unsigned v = *reinterpret_cast<const unsigned*>(q + u * wstride);
-                    a0[u] += __uint_as_float(v << 16);
-                    a1[u] += __uint_as_float(v & 0xFFFF0000u);
-                }
-            for (; w < w1; ++w, q += wstride) {
-                const unsigned v = *reinterpret_cast<const unsigned*>(q);
-                a0[0] += __uint_as_float(v << 16);
-                a1[0] += __uint_as_float(v & 0xFFFF0000u);
+                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const uint2*>(q + u * wstride);
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) { add(a, v[u]); add(b, v[u + 1]); }
             }
-            atomicAdd(hist + (bi - bs[j]), ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7])));
-            if (j + 1 < N) atomicAdd(hist + (bi - bs[j + 1]), ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7])));
+            if (w < w1) {
+                uint2 v[15];
+#pragma unroll
+                for (int u = 0; u < 15; ++u) v[u] = (w + u < w1) ? *reinterpret_cast<const uint2*>(q + u * wstride) : make_uint2(0u, 0u);
+#pragma unroll
+                for (int u = 0; u < 15; ++u) add((u & 1) ? b : a, v[u]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (j + r < N) atomicAdd(hist + (bi - bs[j + r]), a[r] + b[r]);
         }
     }
     __syncthreads();
@@ -630,7 +636,7 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     // per-workgroup histograms [wgroups * chunks][heads][R]: after the slabs, or -- deferred form -- in the caller's persistent buffer, to be
     // summed into the table gradients of all layers by one lavt_attn_dtable_finish_multi launch at the end of backward
     float* part = parts ? parts : ws + (int64_t)nwin * heads * N * bias_ld;
-    hipLaunchKernelGGL(wattn_dtable_kernel, dim3(cdiv(N, rpb), heads, wgroups), dim3(256), (size_t)(R + N + 1) * 4, st, reinterpret_cast<const bf16*>(ws), part, bias_ld, wd, wh, ww, nwin,
+    hipLaunchKernelGGL(wattn_dtable_kernel, dim3(cdiv(N, rpb), heads, wgroups), dim3(256), (size_t)(R + N) * 4, st, reinterpret_cast<const bf16*>(ws), part, bias_ld, wd, wh, ww, nwin,
                        N, heads, rpb, wpg);
     const int pieces = wgroups * cdiv(N, rpb), per_z = 16;
     if (!parts) hipLaunchKernelGGL(wattn_dtable_finish, dim3(cdiv(R, 256), heads, cdiv(pieces, per_z)), dim3(256), 0, st, part, dtable, pieces, per_z, heads, R);
