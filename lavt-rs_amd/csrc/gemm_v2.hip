@@ -939,7 +939,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         // A member whose C holds zeros (split_k < 0: the step harness' zeroed flat gradient buffer) may split a long reduction:
         // the launch lasts as long as its longest serial chain of K tiles (~1 us each with one tile in flight), e.g. 41 for the window-ordered
         // qkv / proj gradients of a stage-2 block against 29 for its fc1 / fc2.  Chains above `chain` K tiles are cut; the pieces meet through atomics.
-        static const int chain = getenv("LAVT_TNG_CHAIN") ? atoi(getenv("LAVT_TNG_CHAIN")) : 32;
+        static const int chain = getenv("LAVT_TNG_CHAIN") ? atoi(getenv("LAVT_TNG_CHAIN")) : 48;     // 32 / 48 / 64 / 128: video step 23.16 / 22.93 / 22.82 / 22.87 ms, image step level
         const int ktiles = cdiv(p.K, 64);
         int ns = (p.split_k < 0 && chain > 0) ? cdiv(ktiles, chain) : 1;
         if (ns > 4) ns = 4;

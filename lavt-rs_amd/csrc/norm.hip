@@ -536,13 +536,18 @@ static int ln_bwd_geometry(int dtype, int rows, int C, int* lpr_out, int* cpl_ou
     const int nchunk = C / epc;
     const int lpr = nchunk <= 16 ? 16 : nchunk <= 32 ? 32 : 64;
     const int cpl = cdiv(nchunk, lpr);                       // 1 (C <= 512 bf16 / 256 fp32), 2, or up to 4 / 8
-    // 8 waves of one row pass each where that keeps the partial count of the old "4 waves x 2 serial rows" form (the second row's loads
-    // started only after the first row's reductions: 9.5 us for the 1800 x 512 maps of a stage-2 block); wide rows (cpl > 2) stay at 4 waves
-    const int waves = (cpl <= 2 && rows > 256) ? 8 : 4;
-    int blocks = cdiv(rows, 8 * (64 / lpr));
-    if (rows <= 256) blocks = cdiv(rows, 4 * (64 / lpr));    // a few dozen rows (BERT: 40-44 tokens): one row per wave
-    if (blocks > 1024) blocks = 1024;
+    // One row pass per wave, 4-wave workgroups: the kernel needs 95-99 VGPRs, i.e. 5 waves per SIMD = five such workgroups per CU (1280 on the
+    // chip), so up to 1280 blocks run as ONE round.  (8-wave workgroups: two per CU -- 576 blocks (Video-Swin stage 2, 4608 rows) or 900 (stage 0)
+    // were two rounds, 16.9 us for 19 MB; 4 waves x 2 serial rows: the second row's loads started after the first row's reductions.)
+    // More rows than one round holds: two (or more, grid-stride) serial rows per wave.
+    int waves = 4;
+    const int rpb = 4 * (64 / lpr);
+    int blocks = cdiv(rows, rpb);
+    if (blocks > 1280) blocks = cdiv(rows, 2 * rpb);
+    if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
+    static const int old_geom = getenv("LAVT_LN_BWD_WAVES") ? atoi(getenv("LAVT_LN_BWD_WAVES")) : 0;
+    if (old_geom == 8 && cpl <= 2 && rows > 256) { waves = 8; blocks = cdiv(rows, 8 * (64 / lpr)); if (blocks > 1024) blocks = 1024; }
     *lpr_out = lpr; *cpl_out = cpl;
     if (waves_out) *waves_out = waves;
     return blocks;

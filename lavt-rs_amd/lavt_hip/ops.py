@@ -432,7 +432,7 @@ class _LnDeferred:
     reduction per LayerNorm (56 per Swin-B step, ~4.9 us each).  The arena offsets and the sink addresses repeat from step to step, so the
     device descriptor table is built once (outside a capture) and reused; a step whose sequence differs rebuilds it (not possible while
     capturing: that raises)."""
-    ARENA_FLOATS = 32 << 20          # 128 MiB: Swin-B needs 56 x 225 x 1024 floats = 12.9 M
+    ARENA_FLOATS = int(os.environ.get("LAVT_LN_ARENA_M", "96")) << 20          # 384 MiB of the 288 GB: Swin-B needs 37 x 450 x 1024 + ... = 24 M floats, Video-Swin-B (4608 rows) 50 M; beyond it a LayerNorm reduces at once
 
     def __init__(self):
         self.arena, self.off, self.items, self.params, self.tables = None, 0, [], [], []
@@ -765,7 +765,7 @@ class _LayerNorm(torch.autograd.Function):
                                                          K.ptr(dx), K.ptr(wsd), wsd.numel(), K.ptr(dres), ctx.rows, ctx.C, K.stream()))
                 ln_deferred.add(wsd, nblk, ctx.C, dg, db, (gamma, beta))
                 return dx, None, None, None, None, None, None, None
-        ws = _scratch(1025 * 2 * ctx.C, x.device)
+        ws = _scratch(int(K.lib.lavt_layernorm_bwd_blocks(K.dt(x.dtype), ctx.rows, ctx.C)) * 2 * ctx.C, x.device)     # (without it the kernel falls back to same-address atomics)
         K.check(K.lib.lavt_layernorm_bwd(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(gather), K.ptr(_f32(gamma)), K.ptr(mean), K.ptr(rstd),
                                          K.ptr(dx), K.ptr(dg), K.ptr(db), K.ptr(ws), ws.numel(), K.ptr(dres), ctx.rows, ctx.C, K.stream()))
         return dx, sinks.done(gamma, dg, gs), sinks.done(beta, db, bs), None, None, None, None, None
