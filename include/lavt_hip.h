@@ -252,8 +252,10 @@ int lavt_reduce_partials_multi(const int64_t* desc, int n, void* stream);
  *   The second moment is centred (accumulated about the group's first row, then re-centred), never E[x^2]-E[x]^2.
  *   Combining ranks (SyncBN): all-reduce sum -> global mean; m2_r += rows_r*(mean_r - mean)^2; all-reduce m2.
  * lavt_stats_finalize: mean = sum/count, var = m2/count (biased), rstd = 1/sqrt(var+eps); optional running-stat update (unbiased var).
- * ws / ws_floats (here, in lavt_norm_bwd_stats and lavt_layernorm_bwd): optional fp32 scratch of >= 1025*groups*2*C floats; with it the
- *   per-workgroup partial sums are written out and reduced by a second tiny kernel instead of contending atomics on the same C addresses.
+ * ws / ws_floats (here and in lavt_norm_bwd_stats): optional fp32 scratch of >= 1025*groups*2*C floats; with it the per-workgroup partial
+ *   sums are written out and reduced by a second tiny kernel instead of contending atomics on the same C addresses.  lavt_layernorm_bwd's
+ *   scratch is lavt_layernorm_bwd_blocks(dtype, rows, C) * 2 * C floats (up to 2048 blocks); a smaller one selects the atomic form (slow:
+ *   hundreds of workgroups adding to the same C addresses).
  * lavt_norm_apply: y = ((x-mean)*rstd*gamma + beta) (*mul) with optional ReLU; mean/rstd [groups][C]; gamma/beta/mul optional.
  * lavt_norm_bwd_stats: s1 = sum(g), s2 = sum(g*xhat) (cleared by the call when scratch is given, else added to the zeroed buffers passed in) with g = dy (*mul) masked by relu (y>0);  [groups][C].
  * lavt_norm_bwd_apply: dx = gamma*rstd*(g - s1/n - xhat*s2/n); dmul = dy*xhat_affine (optional).
