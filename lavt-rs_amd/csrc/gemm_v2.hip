@@ -97,6 +97,12 @@ __device__ __forceinline__ void tr_read_frags_step(const unsigned (&a)[NF], u64 
 // 32-byte slot swizzle of a k-major [64][CH x 16 B] tile: the 16 K rows one transposing read touches (rows r, r+1, r+2, r+3 of four 8-row
 // blocks) land in different slots.  Uses row bits 0, 1, 3, 4 only, so rows r + 4 and r + 32 share the swizzle of row r.
 template <int CH> __device__ __forceinline__ int tn_swz(int kr) {
+    if constexpr (CH == 8) {
+        // 128-byte rows: two rows span the 64 banks, so row bit 0 already alternates the bank half; the two swizzle bits a 4-slot row has
+        // go to row bits 1 and 3.  (With bits 0 and 1 -- the general formula -- rows r, r+8, r+16, r+24 of a transposing read met in the
+        // same banks: 46 % of the LDS cycles of the 64x64-tile weight-gradient kernels were bank conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT.)
+        return (((kr >> 1) & 1) | ((kr >> 2) & 2)) << 1;
+    }
     constexpr int FM = (CH / 2 - 1) < 15 ? (CH / 2 - 1) : 15;
     return (((kr & 3) | ((kr >> 1) & 12)) & FM) << 1;
 }
