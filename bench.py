@@ -101,17 +101,22 @@ def measure_conv_kernel(device, iters=20):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * B * H * W * Cout * 9 * Cin
     achieved = flops / (ms * 1e-3) / 1e12
-    traffic = None          # fabric-side bytes per launch from the committed rocprofv3 --pmc passes of this kernel (profiles/pmc_dominant_kernel.json): a recorded constant, not measured by this run
+    traffic, tsrc = None, None          # fabric-side bytes per launch from the committed rocprofv3 --pmc passes of this kernel: a recorded constant, not measured by this run
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")))["traffic_bytes_per_launch"]
+        traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_conv_and_grouped_wgrad.json")))["conv_one"]["derived"]["fabric_bytes (FETCH_SIZE KB x2 gfx950 correction + WRITE_SIZE KB)"])
+        tsrc = "profiles/r02_pmc_conv_and_grouped_wgrad.json (recorded)"
     except Exception:  # noqa: BLE001
-        pass
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")))["traffic_bytes_per_launch"]
+            tsrc = "profiles/pmc_dominant_kernel.json (recorded)"
+        except Exception:  # noqa: BLE001
+            pass
     import lavt_hip
     f8 = lavt_hip.fp8_enabled()          # fp8 workload: the same convolution on e4m3 operands (v_mfma_scale 16x16x128: dense peak 5 PFLOP/s), quantisation launches included
     peak = 2.0 * BF16_DENSE_PEAK_TFLOPS if f8 else BF16_DENSE_PEAK_TFLOPS
     return {"bound": "mfma", "kernel": "implicit-GEMM conv3x3 512->512 @120x120, batch 2 (decoder conv2_2), timed alone" + (" [fp8: incl. the activation quantiser]" if f8 else ""),
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "avg_launch_us": round(ms * 1e3, 2), "flops_per_launch": flops, "traffic": traffic, "traffic_source": "profiles/pmc_dominant_kernel.json (recorded)"}
+            "avg_launch_us": round(ms * 1e3, 2), "flops_per_launch": flops, "traffic": traffic, "traffic_source": tsrc}
 
 
 def profile_step(step, cfg, device, reps=3):
