@@ -159,9 +159,16 @@ typedef struct lavt_gemm_tn {
     int32_t a_rowscale_binary; /* 1: a_rowscale holds only 0 and ONE non-zero value which the caller folded into alpha (row masks) */
     int32_t accumulate;        /* 1: C += (atomics) even without split-K; 0: C may be overwritten when the reduction is not split */
     int32_t conv_d, conv_kd, conv_kh, conv_kw; /* 3-D taps, as in lavt_gemm_nt_t; c_conv_permute then stores column (tap,c) at c*taps+tap */
+    float* partials;           /* optional scratch (ABI v3): with it a split reduction (many K pieces on few output tiles: the long-K weight gradients */
+    int64_t partials_floats;   /* of PWAM's 1x1 convolutions, K = 28 800 rows) stores one plain partial tile per piece ([piece][I][J], then [piece][I] */
+                               /* for colsum) and a second small kernel adds the pieces into C -- instead of up to ~60 workgroups adding into the same */
+                               /* 64x64 tile through fp32 atomics.  Needs pieces*(I*J + I) floats (lavt_gemm_tn_pieces gives an upper bound); too small */
+                               /* or NULL selects the atomic form.  The scratch may be shared by consecutive calls on one stream. */
 } lavt_gemm_tn_t;
 
 int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);
+/* upper bound of the K pieces lavt_gemm_tn may cut this problem into (for sizing `partials`) */
+int lavt_gemm_tn_pieces(const lavt_gemm_tn_t* p);
 /* n (<= 4) independent problems of the family in one call, e.g. the four weight gradients of a Swin block: when they qualify (bf16, no
  * conv taps / concat, batch 1, together >= 256 64x64 output tiles) they run as ONE launch without split-K -- every output element then has
  * a single writer, and with accumulate == 0 it is stored plainly instead of added through fp32 atomics; otherwise they are issued one by

@@ -467,6 +467,17 @@ extern "C" int lavt_gemm_tn(const lavt_gemm_tn_t* pp, void* stream) {
     return p.dtype == LAVT_F32 ? dispatch_tn<float>(p, st) : dispatch_tn<bf16>(p, st);
 }
 
+// upper bound of the K pieces of lavt_gemm_tn (>= 8 K tiles of 64 rows per piece, unless LAVT_TN_SPLIT forces a count)
+extern "C" int lavt_gemm_tn_pieces(const lavt_gemm_tn_t* p) {
+    if (!p || p->K <= 0) return 1;
+    const int ktiles = cdiv(p->K, 64);
+    const char* se = getenv("LAVT_TN_SPLIT");
+    int n = cdiv(ktiles, 8);
+    if (se && atoi(se) > n) n = atoi(se);
+    if (n > ktiles) n = ktiles;
+    return n < 1 ? 1 : n;
+}
+
 int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st);
 // n independent weight-gradient problems issued together: one grouped launch without split-K when they qualify (bf16, plain / row-mapped
 // operands, >= 256 output tiles in total), else one lavt_gemm_tn call each.  Results are identical either way up to fp32 summation order.

@@ -781,8 +781,13 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
         }
     }
 
-    float* C = p.C + (int64_t)bz * p.strideC;
-    const bool atomic = nsplit > 1 || p.accumulate;
+    // split reduction with a partials buffer: this piece's tile goes to partials[piece][I][J] as plain stores (tn_reduce_pieces adds the pieces
+    // into C afterwards); otherwise pieces meet in C through atomics
+    const bool to_parts = p.partials != nullptr && nsplit > 1;
+    float* C = to_parts ? p.partials + (int64_t)split_idx * p.I * p.J : p.C + (int64_t)bz * p.strideC;
+    const int64_t ldc_out = to_parts ? p.J : p.ldc;
+    float* colsum_out = to_parts ? p.partials + (int64_t)nsplit * p.I * p.J + (int64_t)split_idx * p.I : (p.colsum ? p.colsum + (int64_t)bz * p.strideColsum : nullptr);
+    const bool atomic = !to_parts && (nsplit > 1 || p.accumulate);
 #pragma unroll
     for (int i = 0; i < II; ++i) {
 #pragma unroll
@@ -795,14 +800,14 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
                 if (jj >= p.J) continue;
                 int64_t col = jj;
                 if (p.c_conv_permute) { const int t2 = jj / p.conv_kc; col = (int64_t)(jj - t2 * p.conv_kc) * cg.taps + t2; }
-                float* dst = C + (int64_t)ii * p.ldc + col;
+                float* dst = C + (int64_t)ii * ldc_out + col;
                 if (atomic) atomicAdd(dst, p.alpha * acc[i][j][r]); else *dst = p.alpha * acc[i][j][r];
             }
         }
     }
     if constexpr (CS == 1) {
         if (do_colsum && i0 + tid < p.I) {
-            float* cs = p.colsum + (int64_t)bz * p.strideColsum + i0 + tid;
+            float* cs = colsum_out + i0 + tid;
             if (atomic) atomicAdd(cs, csum * p.alpha); else *cs = csum * p.alpha;
         }
     }
@@ -813,7 +818,7 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
             for (int r = 0; r < 4; ++r) {
                 const int ii = i0 + wi * WI + i * 16 + 4 * (lane >> 4) + r;
                 if (ii >= p.I) continue;
-                float* cs = p.colsum + (int64_t)bz * p.strideColsum + ii;
+                float* cs = colsum_out + ii;
                 if (atomic) atomicAdd(cs, cacc[i][r] * p.alpha); else *cs = cacc[i][r] * p.alpha;      // one tile_j == 0 workgroup per I tile when the reduction is not split
             }
     }
@@ -855,6 +860,32 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_grouped_kernel(const Tn
     tn_tile<BI, BJ, WAVES, STAGES, MAPS, CS>(p, local / ns, 0, local % ns, (ktiles + ns - 1) / ns, ns, smem);
 }
 
+// second stage of a split reduction through partial tiles: C[i][j] += sum_s parts[s][i][J + j], colsum[i] += sum_s parts[nsplit*I*J + s*I + i].
+// 64 outputs x 4 piece lanes per workgroup (coalesced 256-byte reads, four independent loads in flight per thread), one writer per output.
+__global__ __launch_bounds__(256) void tn_reduce_pieces(const float* __restrict__ parts, int nsplit, int I, int J, float* __restrict__ C, int64_t ldc,
+                                                        float* __restrict__ colsum) {
+    __shared__ float red[4][64];
+    const int64_t W = (int64_t)I * J, total = W + (colsum ? I : 0);
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + col;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < total) {
+        // element e of piece s: the C part is [s][W], the colsum part [nsplit*W + s*I]
+        const float* q = e < W ? parts + e : parts + (int64_t)nsplit * W + (e - W);
+        const int64_t st = e < W ? W : I;
+        int s = sl;
+        for (; s + 12 < nsplit; s += 16) { a0 += q[(int64_t)s * st]; a1 += q[(int64_t)(s + 4) * st]; a2 += q[(int64_t)(s + 8) * st]; a3 += q[(int64_t)(s + 12) * st]; }
+        for (; s < nsplit; s += 4) a0 += q[(int64_t)s * st];
+    }
+    red[sl][col] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && e < total) {
+        const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        if (e < W) { const int64_t i = e / J; C[i * ldc + (e - i * J)] += t; }
+        else colsum[e - W] += t;
+    }
+}
+
 template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS> int launch_tn_v2_(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
     constexpr size_t lds = STAGES * (size_t)(64 * (BI + BJ) * 2) + (MAPS ? (2 * (STAGES - 1) + 1) * 768 + 256 : 0);
     static bool attr_set = false;
@@ -868,7 +899,18 @@ template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS> int launch_t
     const int ktiles = cdiv(p.K, 64);
     const int per = cdiv(ktiles, split);
     dim3 grid(cdiv(p.I, BI) * cdiv(p.J, BJ), p.batch, cdiv(ktiles, per));
-    hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS>), grid, dim3(WAVES * 64), lds, st, p, per);
+    const int pieces = (int)grid.z;
+    // partial tiles instead of atomics when the caller lent scratch for them (plain problems only: no conv column permutation, batch 1)
+    const bool parts = pieces > 1 && p.partials && p.batch == 1 && !p.c_conv_permute && p.partials_floats >= (int64_t)pieces * ((int64_t)p.I * p.J + p.I);
+    if (!parts) {
+        lavt_gemm_tn_t q = p;
+        q.partials = nullptr;
+        hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS>), grid, dim3(WAVES * 64), lds, st, q, per);
+    } else {
+        hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS>), grid, dim3(WAVES * 64), lds, st, p, per);
+        const int64_t total = (int64_t)p.I * p.J + (p.colsum ? p.I : 0);
+        hipLaunchKernelGGL(tn_reduce_pieces, dim3((unsigned)cdiv(total, 64)), dim3(256), 0, st, p.partials, pieces, p.I, p.J, p.C, p.ldc, p.colsum);
+    }
     LAVT_CHECK_LAUNCH("lavt_gemm_tn(v2)");
     return LAVT_OK;
 }
@@ -967,6 +1009,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         maps = maps || p.a_rowmap || p.a_rowscale || p.b_rowmap;
         any_colsum = any_colsum || p.colsum != nullptr;
         g.p[i] = p;
+        g.p[i].partials = nullptr;                   // (pieces of a grouped member meet through atomics: at most 4 per output element)
         // A member whose C holds zeros (split_k < 0: the step harness' zeroed flat gradient buffer) may split a long reduction:
         // the launch lasts as long as its longest serial chain of K tiles (~1 us each with one tile in flight), e.g. 41 for the window-ordered
         // qkv / proj gradients of a stage-2 block against 29 for its fc1 / fc2.  Chains above `chain` K tiles are cut; the pieces meet through atomics.

@@ -128,6 +128,7 @@ class GemmTN(C.Structure):
         ("alpha", f32), ("C", vp), ("ldc", i64), ("strideC", i64), ("c_conv_permute", i32), ("split_k", i32),
         ("colsum", vp), ("strideColsum", i64), ("zeros", vp), ("a_rowscale_binary", i32), ("accumulate", i32),
         ("conv_d", i32), ("conv_kd", i32), ("conv_kh", i32), ("conv_kw", i32),
+        ("partials", vp), ("partials_floats", i64),
     ]
 
 
@@ -136,6 +137,7 @@ _PROTOTYPES = {
     "lavt_abi_version": [],
     "lavt_gemm_nt": [C.POINTER(GemmNT), vp],
     "lavt_gemm_tn": [C.POINTER(GemmTN), vp],
+    "lavt_gemm_tn_pieces": [C.POINTER(GemmTN)],
     "lavt_gemm_tn_grouped": [C.POINTER(GemmTN), i32, vp],
     "lavt_window_attn_fwd": [i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "lavt_window_attn_bwd": [i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
@@ -197,7 +199,7 @@ for _name, _args in _PROTOTYPES.items():
 _cdll.lavt_last_error.restype = C.c_char_p
 _cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
 _cdll.lavt_last_error.argtypes = []
-for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces"):      # queries, not launches: never timed
+for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces"):      # queries, not launches: never timed
     setattr(lib, _name, getattr(_cdll, _name))
 
 EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)

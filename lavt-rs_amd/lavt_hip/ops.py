@@ -303,6 +303,18 @@ def _scratch(n_floats, device):
     return torch.empty(int(n_floats), dtype=torch.float32, device=device)
 
 
+_TN_PARTS = {}
+
+
+def _tn_parts(n_floats, device):
+    """One persistent fp32 buffer per device for the partial tiles of split weight-gradient reductions: a launch's pieces are consumed by its own
+    reduction kernel before the next launch of the stream writes them again (stream order), so consecutive launches share it."""
+    t = _TN_PARTS.get(device)
+    if t is None or t.numel() < n_floats:
+        t = _TN_PARTS[device] = torch.empty(max(int(n_floats), 4 << 20), dtype=torch.float32, device=device)
+    return t
+
+
 def _zero_page(device):
     """256 zero bytes per device: source of every chunk that must read 0 in the LDS-DMA GEMM (padding rows, conv halo, tails)."""
     z = _ZERO_PAGES.get(device)
@@ -366,6 +378,12 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.c_conv_permute, p.split_k = int(c_conv_permute), (-1 if defer is not None else 0)     # deferred = into the zeroed flat gradient buffer: a grouped launch may split K
     p.colsum, p.strideColsum = K.ptr(colsum), strideColsum
     p.zeros = _zero_page(A.device)
+    if dtype == torch.bfloat16 and conv is None and batch == 1 and Kd >= 2048 and os.environ.get("LAVT_TN_PARTIALS", "1") != "0":
+        # scratch for split reductions through partial tiles (long-K weight gradients on few output tiles: PWAM's 1x1 convolutions over 28 800 rows)
+        need = int(K.lib.lavt_gemm_tn_pieces(C.byref(p))) * (I * J + I)
+        if need <= (16 << 20):
+            scr = _tn_parts(need, A.device)
+            p.partials, p.partials_floats = K.ptr(scr), scr.numel()
     if defer is not None:
         defer.add(p, (A, B, Cout, a_rowmap, a_rowscale, b_rowmap, colsum))
         return
