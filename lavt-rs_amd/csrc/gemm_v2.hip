@@ -926,6 +926,33 @@ template <int BI, int BJ, int WAVES> int launch_tn_v2(const lavt_gemm_tn_t& p, i
     return maps ? launch_tn_v2_<BI, BJ, WAVES, 2, true, 0>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 2, false, 0>(p, split, st);
 }
 
+// the same for the members of a grouped launch that were cut into pieces through partial tiles: blockIdx.y = member
+__global__ __launch_bounds__(256) void tn_reduce_pieces_group(const TnGroup g) {
+    const lavt_gemm_tn_t& p = g.p[blockIdx.y];
+    const int nsplit = g.split[blockIdx.y];
+    if (nsplit <= 1 || p.partials == nullptr) return;
+    __shared__ float red[4][64];
+    const int64_t W = (int64_t)p.I * p.J, total = W + (p.colsum ? p.I : 0);
+    if ((int64_t)blockIdx.x * 64 >= total) return;
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + col;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < total) {
+        const float* q = e < W ? p.partials + e : p.partials + (int64_t)nsplit * W + (e - W);
+        const int64_t st = e < W ? W : p.I;
+        int s = sl;
+        for (; s + 12 < nsplit; s += 16) { a0 += q[(int64_t)s * st]; a1 += q[(int64_t)(s + 4) * st]; a2 += q[(int64_t)(s + 8) * st]; a3 += q[(int64_t)(s + 12) * st]; }
+        for (; s < nsplit; s += 4) a0 += q[(int64_t)s * st];
+    }
+    red[sl][col] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && e < total) {
+        const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        if (e < W) { const int64_t i = e / p.J; p.C[i * p.ldc + (e - i * p.J)] += t; }
+        else p.colsum[e - W] += t;
+    }
+}
+
 }  // namespace
 
 // returns 1 when the problem is not for this kernel (caller falls back to gemm.hip), else a LAVT status
@@ -997,36 +1024,51 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     if ((e && e[0] == '0') || n < 2 || n > TN_GROUP_MAX) return 1;
     TnGroup g;
     bool maps = false;
-    int tiles = 0, ntiles = 0;
+    int tiles = 0;
     constexpr int TB = 64;          // (128x128 tiles, 8 or 4 waves, measured level or slower on the stage-2 block: 12.44 / 12.94 vs 12.46 ms per step)
     bool any_colsum = false;
-    for (int i = 0; i < n; ++i) {
-        const lavt_gemm_tn_t& p = probs[i];
-        if (!tn_v2_eligible(p) || p.batch != 1 || p.conv_kc > 0 || p.B2 || p.I % 8 || p.J % 8) return 1;
-        // no split-K in here: a member with a long reduction (e.g. a stage-0 PWAM projection, K = 28 800 rows = 450 K tiles on a handful of
-        // tiles) would run serially inside one workgroup while short-K members (BERT layers, K = 40 rows) supply the tile count
-        if (cdiv(p.K, 64) > 128) return 1;
-        maps = maps || p.a_rowmap || p.a_rowscale || p.b_rowmap;
-        any_colsum = any_colsum || p.colsum != nullptr;
-        g.p[i] = p;
-        g.p[i].partials = nullptr;                   // (pieces of a grouped member meet through atomics: at most 4 per output element)
-        // A member whose C holds zeros (split_k < 0: the step harness' zeroed flat gradient buffer) may split a long reduction:
-        // the launch lasts as long as its longest serial chain of K tiles (~1 us each with one tile in flight), e.g. 41 for the window-ordered
-        // qkv / proj gradients of a stage-2 block against 29 for its fc1 / fc2.  Chains above `chain` K tiles are cut; the pieces meet through atomics.
-        static const int chain = getenv("LAVT_TNG_CHAIN") ? atoi(getenv("LAVT_TNG_CHAIN")) : 48;     // 32 / 48 / 64 / 128: video step 23.16 / 22.93 / 22.82 / 22.87 ms, image step level
-        const int ktiles = cdiv(p.K, 64);
-        int ns = (p.split_k < 0 && chain > 0) ? cdiv(ktiles, chain) : 1;
-        if (ns > 4) ns = 4;
-        const int per = cdiv(ktiles, ns);
-        ns = cdiv(ktiles, per);                      // no empty pieces
-        g.split[i] = ns;
-        ntiles += cdiv(p.I, TB) * cdiv(p.J, TB);
-        tiles += cdiv(p.I, TB) * cdiv(p.J, TB) * ns;
-        g.tile_end[i] = tiles;
+    // Pieces per member.  A member with a partials scratch (lavt_gemm_tn_t.partials: its pieces are stored as plain tiles and added into C by one
+    // small second kernel) may be cut as finely as its K allows -- the long-K weight gradients of PWAM (K = 28 800 rows = 450 K tiles on 4
+    // output tiles each) then run as ONE launch of ~1000 workgroups instead of four launches of ~230 at one workgroup per CU; a member
+    // without one is cut into at most 4 pieces that meet through atomics (only if its C holds zeros: split_k < 0), and a chain of more than
+    // 128 K tiles without a scratch keeps the group from forming (it would run serially while the short members supply the tile count).
+    static const int chain = getenv("LAVT_TNG_CHAIN") ? atoi(getenv("LAVT_TNG_CHAIN")) : 48;     // 32 / 48 / 64 / 128: video step 23.16 / 22.93 / 22.82 / 22.87 ms, image step level
+    static const int piece_tiles = getenv("LAVT_TNG_PIECE") ? atoi(getenv("LAVT_TNG_PIECE")) : 8;
+    bool any_parts = false;
+    int64_t max_total = 0;
+    for (int per_piece = piece_tiles; ; per_piece *= 2) {
+        tiles = 0; maps = false; any_colsum = false; any_parts = false; max_total = 0;
+        for (int i = 0; i < n; ++i) {
+            const lavt_gemm_tn_t& p = probs[i];
+            if (!tn_v2_eligible(p) || p.batch != 1 || p.conv_kc > 0 || p.B2 || p.I % 8 || p.J % 8) return 1;
+            const int ktiles = cdiv(p.K, 64);
+            maps = maps || p.a_rowmap || p.a_rowscale || p.b_rowmap;
+            any_colsum = any_colsum || p.colsum != nullptr;
+            g.p[i] = p;
+            int ns = 1;
+            const int want = cdiv(ktiles, per_piece);
+            const bool parts = p.partials != nullptr && !p.c_conv_permute && ktiles > chain && want > 1 &&
+                               p.partials_floats >= (int64_t)want * ((int64_t)p.I * p.J + p.I);
+            if (parts) ns = want;
+            else {
+                g.p[i].partials = nullptr;
+                if (ktiles > 128) return 1;
+                ns = (p.split_k < 0 && chain > 0) ? cdiv(ktiles, chain) : 1;
+                if (ns > 4) ns = 4;
+            }
+            const int per = cdiv(ktiles, ns);
+            ns = cdiv(ktiles, per);                      // no empty pieces
+            if (parts && ns > 1) { any_parts = true; max_total = max_total > (int64_t)p.I * p.J + p.I ? max_total : (int64_t)p.I * p.J + p.I; }
+            if (ns <= 1) g.p[i].partials = nullptr;
+            g.split[i] = ns;
+            tiles += cdiv(p.I, TB) * cdiv(p.J, TB) * ns;
+            g.tile_end[i] = tiles;
+        }
+        if (tiles <= 2048 || !any_parts || per_piece >= 64) break;      // too many workgroups: longer pieces
     }
-    for (int i = n; i < TN_GROUP_MAX; ++i) { g.p[i] = probs[0]; g.tile_end[i] = tiles; g.split[i] = 1; }
+    for (int i = n; i < TN_GROUP_MAX; ++i) { g.p[i] = probs[0]; g.p[i].partials = nullptr; g.tile_end[i] = tiles; g.split[i] = 1; }
     g.n = n;
-    if (ntiles < 256) return 1;                      // too few tiles to fill the chip without (more) split-K
+    if (tiles < 256) return 1;                       // too few workgroups to fill the chip
     // (round 2: an XCD-contiguous tile order inside each member -- it cuts the 152 MB of fabric traffic -- and a 3-stage ring were both measured
     // on the step: 10.63 vs 10.64 ms and 10.81 vs 10.62 ms; neither is kept)
     const size_t lds = 2 * (size_t)(64 * (64 + 64) * 2) + (maps ? 3 * 768 + 256 : 0);
@@ -1037,6 +1079,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true, 0>), dim3(tiles), dim3(256), lds, st, g);
         else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, false, 0>), dim3(tiles), dim3(256), lds, st, g);
     }
+    if (any_parts) hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
     LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
     return LAVT_OK;
 }

@@ -383,7 +383,7 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
         need = int(K.lib.lavt_gemm_tn_pieces(C.byref(p))) * (I * J + I)
         if need <= (16 << 20):
             scr = _tn_parts(need, A.device)
-            p.partials, p.partials_floats = K.ptr(scr), scr.numel()
+            p.partials, p.partials_floats = K.ptr(scr), (need if defer is not None else scr.numel())     # queued: flush() hands every member its own region
     if defer is not None:
         defer.add(p, (A, B, Cout, a_rowmap, a_rowscale, b_rowmap, colsum))
         return
@@ -423,6 +423,14 @@ class _WgradQueue:
 
     def flush(self):
         if self.items:
+            need = [int(q.partials_floats) if q.partials else 0 for q in self.items]
+            if sum(need):                        # the members of one launch write their partial tiles at the same time: disjoint regions of the scratch
+                dev = next(t for t in self.keep[0] if t is not None).device
+                base, off = _tn_parts(sum(need), dev).data_ptr(), 0
+                for q, nf in zip(self.items, need):
+                    if nf:
+                        q.partials = base + 4 * off
+                        off += nf
             arr = (K.GemmTN * len(self.items))(*self.items)
             if K.prof.enabled:       # a grouped launch mixes scopes (qkv / proj with fc1 / fc2): the note carries the per-member flops and labels
                 fl = [2.0 * q.I * q.J * q.K for q in self.items]
