@@ -630,8 +630,8 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
             if (conv) conv_coords(cg, k0, b_z[i], b_y[i], b_x[i]);
         }
     }
-    auto issue = [&](int t) {
-        char* sa = smem + (t % STAGES) * STAGE_BYTES;
+    auto issue = [&](int t, int stage) {
+        char* sa = smem + stage * STAGE_BYTES;
         char* sb = sa + A_BYTES;
         if constexpr (!MAPS) {
 #pragma unroll
@@ -739,20 +739,43 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
         __builtin_amdgcn_s_barrier();
     }
     for (int t = 0; t < STAGES - 1; ++t)
-        if (t < n) { issue(t); map_dma(t + AHEAD); }
+        if (t < n) { issue(t, t % STAGES); map_dma(t + AHEAD); }
 
-    for (int j = 0; j < n; ++j) {
+    // One K tile.  `stage` is a compile-time constant in the two-stage ring (the loop below is unrolled by hand over the two stages), so the
+    // fragment read addresses of a stage are loop-invariant registers instead of 2 (II + JJ) vector adds per K tile: the 64x64-tile kernels are
+    // instruction-issue bound (three workgroups' waves share a SIMD: ~150 instructions per wave per K tile against 8 MFMAs).
+    constexpr bool UNROLL2 = STAGES == 2 && BI == 64 && BJ == 64;       // (the 128x128 / 8-wave tiles sit at their 128-register cap: 16 more would spill)
+    unsigned fragA[UNROLL2 ? 2 : 1][II], fragB[UNROLL2 ? 2 : 1][JJ];
+    if constexpr (UNROLL2) {
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+            const unsigned baseA = lds_addr(smem + sg * STAGE_BYTES), baseB = baseA + A_BYTES;
+#pragma unroll
+            for (int i = 0; i < II; ++i) fragA[sg][i] = baseA + relA[i];
+#pragma unroll
+            for (int i = 0; i < JJ; ++i) fragB[sg][i] = baseB + relB[i];
+        }
+    }
+    auto k_tile = [&](int j, auto stage_tag) {
+        constexpr int SG = decltype(stage_tag)::value;             // >= 0: the stage of tile j (two-stage ring); -1: j % STAGES
+        const int stage = SG >= 0 ? SG : j % STAGES;
         wait_groups<G>(min(STAGES - 2, n - 1 - j));
         __builtin_amdgcn_s_barrier();
-        if (j + STAGES - 1 < n) { issue(j + STAGES - 1); map_dma(j + STAGES - 1 + AHEAD); }
-        const char* cA = smem + (j % STAGES) * STAGE_BYTES;
-        const char* cB = cA + A_BYTES;
-        const unsigned baseA = lds_addr(cA), baseB = lds_addr(cB);
+        if (j + STAGES - 1 < n) { issue(j + STAGES - 1, SG >= 0 ? (SG ^ 1) : (j + STAGES - 1) % STAGES); map_dma(j + STAGES - 1 + AHEAD); }
+        const char* cA = smem + stage * STAGE_BYTES;
         unsigned aA[II], aB[JJ];
+        if constexpr (SG >= 0) {
 #pragma unroll
-        for (int i = 0; i < II; ++i) aA[i] = baseA + relA[i];
+            for (int i = 0; i < II; ++i) aA[i] = fragA[SG][i];
 #pragma unroll
-        for (int i = 0; i < JJ; ++i) aB[i] = baseB + relB[i];
+            for (int i = 0; i < JJ; ++i) aB[i] = fragB[SG][i];
+        } else {
+            const unsigned baseA = lds_addr(cA), baseB = baseA + A_BYTES;
+#pragma unroll
+            for (int i = 0; i < II; ++i) aA[i] = baseA + relA[i];
+#pragma unroll
+            for (int i = 0; i < JJ; ++i) aB[i] = baseB + relB[i];
+        }
         u64 al0[II], ah0[II], al1[II], ah1[II], bl0[JJ], bh0[JJ], bl1[JJ], bh1[JJ];
         tr_read_frags<II, 4 * BI * 2, 32 * BI * 2>(aA, al0, ah0, al1, ah1);
         tr_read_frags<JJ, 4 * BJ * 2, 32 * BJ * 2>(aB, bl0, bh0, bl1, bh1);
@@ -779,6 +802,13 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
                 for (int k = 0; k < BK; ++k) csum += to_f<T>(col[k * BI + (((tid >> 3) ^ tn_swz<A_CH>(k)) << 3)]);
             }
         }
+    };
+    if constexpr (UNROLL2) {
+        int j = 0;
+        for (; j + 1 < n; j += 2) { k_tile(j, std::integral_constant<int, 0>{}); k_tile(j + 1, std::integral_constant<int, 1>{}); }
+        if (j < n) k_tile(j, std::integral_constant<int, 0>{});
+    } else {
+        for (int j = 0; j < n; ++j) k_tile(j, std::integral_constant<int, -1>{});
     }
 
     // split reduction with a partials buffer: this piece's tile goes to partials[piece][I][J] as plain stores (tn_reduce_pieces adds the pieces
