@@ -552,6 +552,65 @@ def test_gemm_tn_grouped_matches_individual():
         assert float((cr - co).abs().max()) <= 2e-3 * float(cr.abs().max())
 
 
+def test_gemm_tn_split_through_partial_tiles(monkeypatch):
+    """Long-K weight gradients on few output tiles (PWAM's 1x1 convolutions: K = 28 800 rows on 4 tiles): the K pieces store plain partial tiles
+    into the lent scratch and a second kernel adds them into C (lavt_gemm_tn_t.partials, ABI v3) -- against the atomic form of the same launch
+    and against fp32 torch; C accumulates (it holds a previous value), colsum and a gathered operand with masked rows included.  Then four such
+    problems through lavt_gemm_tn_grouped (every member cut into pieces of 8 K tiles, one reduction kernel)."""
+    from lavt_hip import _capi as K, ops
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(33)
+    Kd = 28800
+    def mk(rows, cols):
+        return (torch.randn(rows, cols, generator=g) * 0.25).to(dev()).to(bf)
+    rmap = torch.randint(-1, 7200, (Kd,), generator=g, dtype=torch.int32).to(dev())         # gathered B rows, some masked (-1)
+    cases = [(128, 128, mk(Kd, 128), mk(Kd, 128), {}), (128, 256, mk(Kd, 128), mk(7200, 256), dict(b_rowmap=rmap)), (512, 128, mk(Kd, 512), mk(Kd, 128), {})]
+    def run(I, J, A, B, kw, parts):
+        monkeypatch.setenv("LAVT_TN_PARTIALS", "1" if parts else "0")
+        out = torch.full((I, J), 0.5, device=dev()); cs = torch.full((I,), -2.0, device=dev())
+        ops.gemm_tn(bf, I, J, Kd, A, I, B, J, out, J, colsum=cs, accumulate=True, **kw)
+        torch.cuda.synchronize()
+        return out, cs
+    for I, J, A, B, kw in cases:
+        Bf = B.float()
+        if "b_rowmap" in kw:
+            Bf = torch.where(rmap[:, None] >= 0, B.float()[rmap.clamp(min=0).long()], torch.zeros(1, device=dev()))
+        ref, cref = A.float().t() @ Bf + 0.5, A.float().sum(0) - 2.0
+        (o1, c1), (o0, c0) = run(I, J, A, B, kw, True), run(I, J, A, B, kw, False)
+        scale = float(ref.abs().max())
+        for o, c in ((o1, c1), (o0, c0)):
+            assert float((o - ref).abs().max()) <= 2e-3 * scale, float((o - ref).abs().max()) / scale
+            assert float((c - cref).abs().max()) <= 2e-3 * float(cref.abs().max())
+        assert float((o1 - o0).abs().max()) <= 1e-4 * scale                                  # fp32 summation order only
+    # grouped: four long-K members in one launch
+    monkeypatch.setenv("LAVT_TN_PARTIALS", "1")
+    structs, keep, outs = [], [], []
+    class _Q:
+        def add(self, p, t): structs.append(p); keep.append(t)
+    members = [cases[0], cases[1], cases[2], (128, 128, mk(Kd, 128), mk(Kd, 128), {})]
+    for I, J, A, B, kw in members:
+        out = torch.zeros(I, J, device=dev()); cs = torch.zeros(I, device=dev())
+        ops.gemm_tn(bf, I, J, Kd, A, I, B, J, out, J, colsum=cs, defer=_Q(), **kw)
+        outs.append((out, cs))
+    need = [int(q.partials_floats) for q in structs]
+    assert all(n > 0 for n in need)
+    scr = torch.empty(sum(need), device=dev())
+    off = 0
+    for q, n in zip(structs, need):                 # what ops._WgradQueue.flush does: disjoint regions of one scratch
+        q.partials = scr.data_ptr() + 4 * off
+        off += n
+    arr = (K.GemmTN * len(structs))(*structs)
+    K.check(K.lib.lavt_gemm_tn_grouped(arr, len(structs), K.stream()))
+    torch.cuda.synchronize()
+    for (I, J, A, B, kw), (o, c) in zip(members, outs):
+        Bf = B.float()
+        if "b_rowmap" in kw:
+            Bf = torch.where(rmap[:, None] >= 0, B.float()[rmap.clamp(min=0).long()], torch.zeros(1, device=dev()))
+        ref, cref = A.float().t() @ Bf, A.float().sum(0)
+        assert float((o - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+        assert float((c - cref).abs().max()) <= 2e-3 * float(cref.abs().max())
+
+
 # ------------------------------------------------------------------------------------------------ text side + composed-attention helpers
 @pytest.mark.parametrize("dtype", DT)
 def test_bert_embed(dtype):
