@@ -48,6 +48,10 @@ for (M, N, Kd, tag) in ((1800, 2048, 512, "fc1"), (2592, 1536, 512, "qkv"), (180
     tc = graph_time([f for i in range(12) for f in (fl, rotA(i % NW))]) / 12 - tf
     td = graph_time([epi(0)] * n) / n
     te = graph_time([epi(i % NW) for i in range(n)]) / n
+    ea = lambda: ops.gemm_nt(bf, M, N, Kd, A[0], Kd, W[0], Kd, C, N, bias=bias, act=K.ACT_GELU)                      # GELU, one output
+    ep = lambda: ops.gemm_nt(bf, M, N, Kd, A[0], Kd, W[0], Kd, C, N, bias=bias, Cpre=P, ldcpre=N)                    # two outputs, no activation
+    t2 = [graph_time([f] * n) / n for f in (ea, ep)]
+    print(f"{tag:5s}   bias+GELU (one output) {t2[0]:5.1f} | bias + second output (no activation) {t2[1]:5.1f}")
     tv = [graph_time([f] * n) / n for f in (eb, er, es, eg)]
     print(f"{tag:5s}   epilogues: bias {tv[0]:5.1f} | bias+residual {tv[1]:5.1f} | bias+residual+scatter+rowscale {tv[2]:5.1f} | gathered A + bias {tv[3]:5.1f}")
     print(f"{tag:5s} {M}x{N}x{Kd}: same operands {ta:5.1f} us | 24 weights in rotation {tb:5.1f} | weights+inputs in rotation {tb2:5.1f} | after a 1.2 GB cache flush {tc:5.1f} (flush {tf:.0f}) | bias+GELU+pre epilogue {td:5.1f} | epilogue + rotation {te:5.1f}")
