@@ -378,7 +378,7 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.c_conv_permute, p.split_k = int(c_conv_permute), (-1 if defer is not None else 0)     # deferred = into the zeroed flat gradient buffer: a grouped launch may split K
     p.colsum, p.strideColsum = K.ptr(colsum), strideColsum
     p.zeros = _zero_page(A.device)
-    if dtype == torch.bfloat16 and conv is None and batch == 1 and Kd >= 2048 and os.environ.get("LAVT_TN_PARTIALS", "1") != "0":
+    if dtype == torch.bfloat16 and conv is None and batch == 1 and Kd >= 2048 and not side.enabled and os.environ.get("LAVT_TN_PARTIALS", "1") != "0":      # (one scratch per device: single-stream order only)
         # scratch for split reductions through partial tiles (long-K weight gradients on few output tiles: PWAM's 1x1 convolutions over 28 800 rows)
         need = int(K.lib.lavt_gemm_tn_pieces(C.byref(p))) * (I * J + I)
         if need <= (16 << 20):
