@@ -268,6 +268,10 @@ int lavt_reduce_partials_multi(const int64_t* desc, int n, void* stream);
  * lavt_norm_bwd_apply: dx = gamma*rstd*(g - s1/n - xhat*s2/n); dmul = dy*xhat_affine (optional).
  * ------------------------------------------------------------------------------------------- */
 int lavt_colstats(int dtype, const void* x, float* sum, float* m2, float* ws, int64_t ws_floats, int groups, int rows, int C, void* stream);
+/* SyncBatchNorm forward after the all-gather of every rank's (sum, m2) pair (allst: [world][2][C], `rows_per_rank` rows each): parallel-variance
+ * combination + lavt_stats_finalize in one launch (mean / rstd of the global batch, running estimates with the unbiased variance) */
+int lavt_syncbn_combine(const float* allst, int world, float rows_per_rank, float eps, float* mean, float* rstd, float* running_mean,
+                        float* running_var, float momentum, int C, void* stream);
 /* lavt_colstats + lavt_stats_finalize in two launches instead of four, for the cases where nothing sits between the sums and their use
  * (InstanceNorm; BatchNorm without a cross-rank exchange): mean / rstd [groups][C] directly, optional running-statistics update (groups == 1). */
 int lavt_colstats_meanrstd(int dtype, const void* x, float* mean, float* rstd, float* ws, int64_t ws_floats, int groups, int rows, int C, float eps,

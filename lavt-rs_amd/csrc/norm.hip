@@ -385,8 +385,7 @@ __global__ __launch_bounds__(1024) void colstats_finish_kernel(const float* __re
         const float sum = s1 + n * kpiv, m2 = fmaxf(s2 - s1 * s1 / n, 0.f);
         const float mu = sum / n, var = m2 / n;
         const int64_t i = (int64_t)g * C + c;
-        mean[i] = mu;
-        rstd[i] = rsqrtf(var + eps);
+        if (mean) { mean[i] = mu; rstd[i] = rsqrtf(var + eps); }
         if (sum_out) { sum_out[i] = sum; m2_out[i] = m2; }
         if (running_mean) running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * mu;
         if (running_var) running_var[i] = (1.f - momentum) * running_var[i] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
@@ -618,9 +617,15 @@ extern "C" int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq,
     DISPATCH_T(dtype, "lavt_colstats",
                hipLaunchKernelGGL((colstats_kernel<T, false>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
                                   (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, 0, sum, sumsq, partials, rows, C, rpb, 1));
-    if (partials) hipLaunchKernelGGL(reduce_partials_kernel, reduce_partials_grid(blocks, groups * 2 * C), dim3(256), 0, st, partials, blocks, groups * 2 * C, C, sum, sumsq);
-    DISPATCH_T(dtype, "lavt_colstats",
-               hipLaunchKernelGGL(colstats_center_kernel<T>, dim3(cdiv(groups * C, 256)), dim3(256), 0, st, (const T*)x, sum, sumsq, rows, C, groups * C));
+    if (partials) {
+        // reduce + re-centre fused (the finish kernel of lavt_colstats_meanrstd with the sum / M2 outputs instead of mean / rstd): 2 launches, not 3
+        DISPATCH_T(dtype, "lavt_colstats",
+                   hipLaunchKernelGGL(colstats_finish_kernel<T>, dim3(cdiv(C, 16), groups), dim3(1024), 0, st, partials, blocks, groups, C, (const T*)x, rows, 0.f,
+                                      (float*)nullptr, (float*)nullptr, sum, sumsq, (float*)nullptr, (float*)nullptr, 0.f));
+    } else {
+        DISPATCH_T(dtype, "lavt_colstats",
+                   hipLaunchKernelGGL(colstats_center_kernel<T>, dim3(cdiv(groups * C, 256)), dim3(256), 0, st, (const T*)x, sum, sumsq, rows, C, groups * C));
+    }
     LAVT_CHECK_LAUNCH("lavt_colstats");
     return LAVT_OK;
 }
@@ -639,6 +644,35 @@ extern "C" int lavt_colstats_meanrstd(int dtype, const void* x, float* mean, flo
                hipLaunchKernelGGL(colstats_finish_kernel<T>, dim3(cdiv(C, 16), groups), dim3(1024), 0, st, ws, blocks, groups, C, (const T*)x, rows, eps, mean, rstd,
                                   (float*)nullptr, (float*)nullptr, running_mean, running_var, momentum));
     LAVT_CHECK_LAUNCH("lavt_colstats_meanrstd");
+    return LAVT_OK;
+}
+
+// SyncBatchNorm forward, after the all-gather: every rank's (sum, centred M2) over `rows` rows each -> statistics of the global batch (parallel
+// variance combination, Chan et al.) -> mean / rstd (+ running estimates), ONE launch instead of ~9 element-wise torch kernels + lavt_stats_finalize
+__global__ void syncbn_combine_kernel(const float* __restrict__ allst, int world, float rows, float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                      float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float tot = 0.f;
+    for (int r = 0; r < world; ++r) tot += allst[((int64_t)r * 2) * C + c];
+    const float n = rows * (float)world, gmean = tot / n;
+    float m2 = 0.f;
+    for (int r = 0; r < world; ++r) {
+        const float d = allst[((int64_t)r * 2) * C + c] / rows - gmean;
+        m2 += allst[((int64_t)r * 2 + 1) * C + c] + rows * d * d;
+    }
+    const float var = m2 / n;
+    mean[c] = gmean;
+    rstd[c] = rsqrtf(var + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * gmean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+}
+extern "C" int lavt_syncbn_combine(const float* allst, int world, float rows_per_rank, float eps, float* mean, float* rstd, float* running_mean,
+                                   float* running_var, float momentum, int C, void* stream) {
+    LAVT_CHECK_ARG(allst && mean && rstd && world > 0 && rows_per_rank > 0 && C > 0, "lavt_syncbn_combine: bad arguments");
+    hipLaunchKernelGGL(syncbn_combine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), allst, world, rows_per_rank, eps, mean, rstd,
+                       running_mean, running_var, momentum, C);
+    LAVT_CHECK_LAUNCH("lavt_syncbn_combine");
     return LAVT_OK;
 }
 

@@ -156,6 +156,7 @@ _PROTOTYPES = {
     "lavt_layernorm_bwd_partial": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
     "lavt_reduce_partials_multi": [vp, i32, vp],
     "lavt_colstats": [i32, vp, vp, vp, vp, i64, i32, i32, i32, vp],
+    "lavt_syncbn_combine": [vp, i32, f32, f32, vp, vp, vp, vp, f32, i32, vp],
     "lavt_colstats_meanrstd": [i32, vp, vp, vp, vp, i64, i32, i32, i32, f32, vp, vp, f32, vp],
     "lavt_stats_finalize": [vp, vp, f32, f32, vp, vp, vp, vp, f32, i32, vp],
     "lavt_norm_apply": [i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp],

@@ -1005,6 +1005,15 @@ def combine_rank_stats(allst: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
     return torch.stack([tot, m2])
 
 
+def syncbn_gather(s: torch.Tensor, group) -> torch.Tensor:
+    """ONE collective: every rank's (sum x, centred second moment) pair -> [world, 2, 1, C]"""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    flat = torch.empty(world * s.numel(), dtype=torch.float32, device=s.device)          # flat in / flat out: the layout every backend accepts
+    dist.all_gather_into_tensor(flat, s.contiguous().view(-1), group=group)
+    return flat.view((world,) + tuple(s.shape))
+
+
 def syncbn_exchange_forward(s: torch.Tensor, rows: int, group):
     """SyncBatchNorm forward exchange (train.py:589 semantics): `s` [2, 1, C] = this rank's (sum x, centred second moment) over its `rows` rows.
     ONE collective gathers every rank's pair; the pairs are combined locally (Chan et al.; equal row counts per rank, as DistributedSampler with
@@ -1040,6 +1049,16 @@ class _HipBnKernels:
         ws = _scratch(1025 * 2 * Cc, x.device)
         K.check(K.lib.lavt_colstats_meanrstd(K.dt(x.dtype), K.ptr(x), K.ptr(mean), K.ptr(rstd), K.ptr(ws), ws.numel(), 1, R, Cc, eps, K.ptr(running_mean),
                                              K.ptr(running_var), momentum, K.stream()))
+        return mean, rstd
+
+    @staticmethod
+    def combine_finalize(allst, rows, eps, running_mean, running_var, momentum):
+        """allst [world, 2, 1, C] (every rank's sum / centred M2 over `rows` rows) -> mean, rstd of the global batch; running estimates updated"""
+        world, Cc = allst.shape[0], allst.shape[-1]
+        mean = torch.empty(Cc, dtype=torch.float32, device=allst.device)
+        rstd = torch.empty_like(mean)
+        K.check(K.lib.lavt_syncbn_combine(K.ptr(allst), world, float(rows), eps, K.ptr(mean), K.ptr(rstd), K.ptr(running_mean), K.ptr(running_var),
+                                          momentum, Cc, K.stream()))
         return mean, rstd
 
     @staticmethod
@@ -1093,9 +1112,15 @@ class _BatchNormRelu(torch.autograd.Function):
             mean, rstd = kern.stats_fused(x, eps, running_mean, running_var, momentum)
         elif training:
             s = kern.stats(x)                                # [sum x, centred second moment] of the local rows
-            if group is not None:
-                s, count = syncbn_exchange_forward(s, R, group)
-            mean, rstd = kern.finalize(s.view(2, Cc), count, eps, running_mean, running_var, momentum)
+            if group is not None and hasattr(kern, "combine_finalize"):
+                # gather, then ONE kernel: parallel-variance combination of the ranks' pairs + mean / rstd / running estimates
+                allst = syncbn_gather(s, group)
+                count = float(R * allst.shape[0])
+                mean, rstd = kern.combine_finalize(allst, R, eps, running_mean, running_var, momentum)
+            else:
+                if group is not None:
+                    s, count = syncbn_exchange_forward(s, R, group)
+                mean, rstd = kern.finalize(s.view(2, Cc), count, eps, running_mean, running_var, momentum)
         else:
             # eval: mean = running_mean, var = running_var  (sum = mean, m2 = var, count = 1)
             mean, rstd = kern.finalize(torch.stack([running_mean, running_var]), 1.0, eps, None, None, 0.0)
@@ -1109,12 +1134,16 @@ class _BatchNormRelu(torch.autograd.Function):
         x, y, gamma, beta, mean, rstd = ctx.saved_tensors
         training, count, group, kern = ctx.cfg
         dy = dy.contiguous()
-        if training and group is None and kern is _HipBnKernels:
-            # single rank: the two sums ARE d beta / d gamma -- accumulate them straight into the parameters' gradient sinks (when the step harness
-            # provides them) and let the apply pass read them from there: no clones, no AccumulateGrad adds
+        if training and kern is _HipBnKernels:
+            # the two LOCAL sums are d beta / d gamma -- accumulate them straight into the parameters' gradient sinks (when the step harness
+            # provides them): no clones, no AccumulateGrad adds.  Single rank: the apply pass reads them from there; SyncBatchNorm: the apply
+            # pass needs the sums over all ranks -- a stacked copy goes through ONE all-reduce (the parameters keep the local sums: DDP averages
+            # parameter gradients later)
             bbuf, bsink = sinks.buf(beta, (x.shape[1],))
             gbuf, gsink = sinks.buf(gamma, (x.shape[1],))
             s = kern.bwd_stats(dy, x, y, mean, rstd, gamma, beta, out=(bbuf, gbuf))
+            if group is not None:
+                s = syncbn_exchange_backward(torch.stack([bbuf, gbuf]), group)
             dx = kern.bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count)
             return dx, sinks.done(gamma, gbuf, gsink), sinks.done(beta, bbuf, bsink), None, None, None, None, None, None, None
         s0, s1 = kern.bwd_stats(dy, x, y, mean, rstd, gamma, beta)

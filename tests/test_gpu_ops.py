@@ -611,6 +611,26 @@ def test_gemm_tn_split_through_partial_tiles(monkeypatch):
         assert float((c - cref).abs().max()) <= 2e-3 * float(cref.abs().max())
 
 
+def test_syncbn_combine_kernel():
+    """lavt_syncbn_combine (gathered per-rank (sum, centred M2) pairs -> mean / rstd of the global batch + running estimates, one launch) against
+    statistics computed directly over the concatenated batch, and against ops.combine_rank_stats (the torch form the gloo tests drive)"""
+    from lavt_hip import _capi as K, ops
+    g = torch.Generator().manual_seed(7)
+    world, rows, Cc, eps, mom = 4, 300, 96, 1e-5, 0.1
+    x = (torch.randn(world, rows, Cc, generator=g) * 2.0 + 5.0).to(dev())                 # large mean: E[x^2] - E[x]^2 would lose digits
+    allst = torch.stack([torch.stack([xr.sum(0), ((xr - xr.mean(0)) ** 2).sum(0)]) for xr in x]).view(world, 2, 1, Cc).contiguous()
+    rm, rv = torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())
+    mean, rstd = ops._HipBnKernels.combine_finalize(allst, rows, eps, rm, rv, mom)
+    torch.cuda.synchronize()
+    flat = x.reshape(-1, Cc)
+    n = flat.shape[0]
+    mu, var = flat.mean(0), flat.var(0, unbiased=False)
+    assert float((mean - mu).abs().max()) < 1e-5 and float((rstd - (var + eps).rsqrt()).abs().max()) < 1e-5
+    assert float((rm - mom * mu).abs().max()) < 1e-5 and float((rv - (0.9 + mom * var * n / (n - 1))).abs().max()) < 1e-4
+    comb = ops.combine_rank_stats(allst, rows).view(2, Cc)
+    assert float((comb[0] / n - mean).abs().max()) < 1e-5 and float((comb[1] / n - var).abs().max()) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ text side + composed-attention helpers
 @pytest.mark.parametrize("dtype", DT)
 def test_bert_embed(dtype):
