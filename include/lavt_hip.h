@@ -57,7 +57,7 @@ const char* lavt_last_error(void);
  *   (fused torch.cat of [top-down, skip], lib/mask_predictor.py:60,70,81).
  * B_op: b_kmajor = 0: B[N][K] (nn.Linear weight layout);  1: B[K][N] (used for x @ W, i.e. data gradients).
  *   With conv and b_kmajor = 1, k = tap*conv_kc + c addresses B + c*ldb + tap*b_tap_stride + n.
- * Epilogue, in order: *alpha, +bias[n], *row_scale[m], (Cpre = value), act, +R[out_row][n], store.
+ * Epilogue, in order: *alpha, +bias[n], *row_scale[m], (Cpre = value), act, *mul[out_row][n], +R[out_row][n], store.
  *   Output row = c_rowmap[m] (or m); -1 drops the row.  Columns >= c_split go to C2 (fused split of the
  *   gradient of a concatenation).  c_f32 stores fp32 whatever dtype is.
  * Requirements: K % (16/sizeof(dtype)) == 0; if b_kmajor, N % (16/sizeof(dtype)) == 0; lda/ldb/ldc multiples of
@@ -118,6 +118,14 @@ typedef struct lavt_gemm_nt {
     const float* deq_a;
     const float* deq_b;
     int32_t epi_wide; /* set by the library: 16-byte stores from paired accumulator fragments (all row strides / splits 8-element aligned) */
+    /* ABI v4, fused PWAM path (reference lib/backbone.py:604-611, 669 and its autograd mirror):
+     * mul: element-wise multiplier [out_row][n] applied after the activation and before the residual -- with act = LAVT_ACT_TANH, Cpre, R = x
+     *   and mul = r the second gate GEMM writes x + tanh(g) * r directly (the language gate is no separate kernel).
+     * res_first (with dact_pre and R): the stored value is (C + R) * act'(dact_pre) instead of C * act'(dact_pre) + R -- a gradient that arrives
+     *   beside the GEMM's own contribution joins before the activation gradient. */
+    const void* mul;
+    int64_t ldmul;
+    int32_t res_first;
 } lavt_gemm_nt_t;
 
 int lavt_gemm_nt(const lavt_gemm_nt_t* p, void* stream);
@@ -294,7 +302,37 @@ int lavt_norm_bwd_apply(int dtype, const void* dy, const void* x, const void* y,
 int lavt_act_bwd(int dtype, int act, const void* dy, const void* pre, void* dx, int64_t n, void* stream);
 /* language gate, lib/backbone.py:669:  xo = x + tanh(gpre) * r ;  backward gives dgpre, dr (+= into dr_acc semantics: written) */
 int lavt_gate_fwd(int dtype, const void* x, const void* gpre, const void* r, void* xo, int64_t n, void* stream);
-int lavt_gate_bwd(int dtype, const void* dxo, const void* gpre, const void* r, void* dgpre, void* dr, int64_t n, void* stream);
+int lavt_gate_bwd(int dtype, const void* dxo, const void* gpre, const void* r, const void* dr_add, void* dgpre, void* dr, int64_t n, void* stream); /* dr = dxo * tanh(gpre) (+ dr_add) */
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused PWAM (ABI v4, bf16).  Replaces, with the GEMMs above, PWAM.forward (lib/backbone.py:1265-1278),
+ * SpatialImageLanguageAttention.forward (:1329-1372) and the language gate (:604-611, :669) and their autograd backward.
+ * The instance norm of the query folds into the keys and the W projection collapses onto the <= 32 word probabilities
+ * (w = P (V Wo^T) + bo, so IN(w) = (P - Pbar) VW' from the word statistics alone): see csrc/pwam.hip and tools/pwam_algebra_check.py.
+ * Word axes are padded to 32 slots; B samples of T pixels each, rows [B*T]; C % 32 == 0.
+ *   lavt_pwam_words_fwd: P[row][32] = softmax_{j < n_l}(alpha * IN_T(q) K^T + maskbias)   (q raw, mean / rstd [B][C] of q over the T pixels)
+ *   lavt_pwam_lang_fwd:  from V [B][32][ldv], Wo [C][C] (bf16 compute copy), PP = P^T P [B][32][32], sumP [B][32]:
+ *                        VW' channel-major VWc [B][C][32] and word-major VWw [B][32][C] (bf16), beta = -Pbar VW' [B][C], rw = rstd of w [B][C],
+ *                        Pbar [B][32], Cov [B][32][32]
+ *   lavt_pwam_mix mode 0: out0 = GELU(X + xbias) * (Wd Wc^T + v0)      (mm = vis * IN(w);  Wd = P, Wc = VWc, v0 = beta, X = x Wv^T, xbias = bv)
+ *                 mode 1: out0 = D * what * GELU'(X), out1 = D * GELU(X)  (d vpre, d what;  D = d mm)
+ *                 mode 2: out0 = Wd Wc^T + v0 - X * v1                  (dq;  Wd = dS, Wc = K''^T, X = q)
+ *   lavt_pwam_lang_bwd1: HT = dwhat^T P [B][C][32], s = colsum(dwhat) [B][C] -> dVW [B*32][C] (bf16), Q [B][32][32] and u [B][32] ADDED into zeroed buffers
+ *   lavt_pwam_words_bwd: dS[row][32] = P * (dP - sum_j P_j dP_j),  dP = dwhat VW'^T - P Q + (Pbar Q - u)
+ *   lavt_pwam_lang_bwd2: G = dS^T q [B][32][C], sdS = colsum(dS) [B][32] -> dK [B*32][lddk] (bf16), K''^T [B][C][32] (bf16), c0, c1 [B][C]
+ * ------------------------------------------------------------------------------------------- */
+int lavt_pwam_words_fwd(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
+                        void* P, int B, int T, int C, int n_l, float alpha, void* stream);
+int lavt_pwam_words_bwd(const void* dwhat, int64_t ldx, const void* VWw, const float* Qf, const float* u, const float* pbar, const void* P,
+                        void* dS, int B, int T, int C, void* stream);
+int lavt_pwam_mix(int mode, const void* Wd, const void* Wc, const float* v0, const float* v1, const float* xbias, const void* X, int64_t ldx, const void* D, int64_t ldd,
+                  void* out0, int64_t ld0, void* out1, int64_t ld1, int B, int T, int C, void* stream);
+int lavt_pwam_lang_fwd(const void* V, int64_t ldv, const void* Wo, const float* PP, const float* sumP, void* VWc, void* VWw, float* beta, float* rw,
+                       float* pbar, float* cov, int B, int T, int C, float eps, void* stream);
+int lavt_pwam_lang_bwd1(const float* HT, const float* s, const void* VWc, const float* rw, const float* pbar, const float* cov, void* dVW, float* Qf, float* u,
+                        int B, int T, int C, void* stream);
+int lavt_pwam_lang_bwd2(const float* G, const float* sdS, const void* K, int64_t ldk, const float* mean, const float* rstd, void* dK, int64_t lddk, void* K2c,
+                        float* c0, float* c1, int B, int T, int C, float alpha, void* stream);
 /* masked softmax over the (padded) word axis of PWAM scores, lib/backbone.py:1358-1361.
  * s,p: [rows][ld] (only the first n_l columns are real; p's padding columns are written as 0). */
 int lavt_rowsoftmax_fwd(int dtype, const void* s, void* p, int64_t rows, int n_l, int ld, void* stream);

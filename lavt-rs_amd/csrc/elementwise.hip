@@ -13,7 +13,7 @@ void lavt_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* lavt_last_error(void) { return g_err; }
-extern "C" int lavt_abi_version(void) { return 3; }
+extern "C" int lavt_abi_version(void) { return 4; }
 
 namespace {
 
@@ -48,15 +48,16 @@ template <typename T> __global__ void gate_fwd_kernel(const T* x, const T* gpre,
         *reinterpret_cast<uint4*>(xo + i * EPC) = f_to_chunk<T>(a);
     }
 }
-template <typename T> __global__ void gate_bwd_kernel(const T* dxo, const T* gpre, const T* r, T* dgpre, T* dr, int64_t nchunks) {
+template <typename T> __global__ void gate_bwd_kernel(const T* dxo, const T* gpre, const T* r, const T* dr_add, T* dgpre, T* dr, int64_t nchunks) {
     constexpr int EPC = Chunk<T>::N;
     GRID_STRIDE(i, nchunks) {
-        float d[EPC], g[EPC], b[EPC], o1[EPC], o2[EPC];
+        float d[EPC], g[EPC], b[EPC], o1[EPC], o2[EPC], ad[EPC];
         chunk_to_f<T>(*reinterpret_cast<const uint4*>(dxo + i * EPC), d);
         chunk_to_f<T>(*reinterpret_cast<const uint4*>(gpre + i * EPC), g);
         chunk_to_f<T>(*reinterpret_cast<const uint4*>(r + i * EPC), b);
+        if (dr_add) chunk_to_f<T>(*reinterpret_cast<const uint4*>(dr_add + i * EPC), ad);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { const float t = tanhf(g[e]); o1[e] = d[e] * b[e] * (1.f - t * t); o2[e] = d[e] * t; }
+        for (int e = 0; e < EPC; ++e) { const float t = tanhf(g[e]); o1[e] = d[e] * b[e] * (1.f - t * t); o2[e] = d[e] * t + (dr_add ? ad[e] : 0.f); }
         *reinterpret_cast<uint4*>(dgpre + i * EPC) = f_to_chunk<T>(o1);
         *reinterpret_cast<uint4*>(dr + i * EPC) = f_to_chunk<T>(o2);
     }
@@ -520,10 +521,10 @@ extern "C" int lavt_gate_fwd(int dtype, const void* x, const void* gpre, const v
     LAVT_CHECK_LAUNCH("lavt_gate_fwd");
     return LAVT_OK;
 }
-extern "C" int lavt_gate_bwd(int dtype, const void* dxo, const void* gpre, const void* r, void* dgpre, void* dr, int64_t n, void* stream) {
+extern "C" int lavt_gate_bwd(int dtype, const void* dxo, const void* gpre, const void* r, const void* dr_add, void* dgpre, void* dr, int64_t n, void* stream) {
     LAVT_CHECK_ARG(dxo && gpre && r && dgpre && dr && n > 0 && n % EPC_OF(dtype) == 0, "lavt_gate_bwd: bad arguments");
     const int64_t nc = n / EPC_OF(dtype);
-    DISPATCH_T(dtype, "lavt_gate_bwd", hipLaunchKernelGGL(gate_bwd_kernel<T>, dim3(ew_grid(nc)), dim3(256), 0, ST, (const T*)dxo, (const T*)gpre, (const T*)r, (T*)dgpre, (T*)dr, nc));
+    DISPATCH_T(dtype, "lavt_gate_bwd", hipLaunchKernelGGL(gate_bwd_kernel<T>, dim3(ew_grid(nc)), dim3(256), 0, ST, (const T*)dxo, (const T*)gpre, (const T*)r, (const T*)dr_add, (T*)dgpre, (T*)dr, nc));
     LAVT_CHECK_LAUNCH("lavt_gate_bwd");
     return LAVT_OK;
 }

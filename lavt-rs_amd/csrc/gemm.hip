@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const lavt_gemm_nt_t p) {
     }
 
     if constexpr (std::is_same<T, bf16>::value) {
-        if (p.epi_lds && !(p.c_f32 || (p.ldc % 8) || (p.C2 && (p.ldc2 % 8 || p.c_split % 8)) || (p.R && p.ldr % 8) || (p.Cpre && p.ldcpre % 8))) {
+        if (p.epi_lds && !(p.mul || p.c_f32 || (p.ldc % 8) || (p.C2 && (p.ldc2 % 8 || p.c_split % 8)) || (p.R && p.ldr % 8) || (p.Cpre && p.ldcpre % 8))) {
             nt_epilogue_lds<BM, BN, MI, NI>(p, acc, reinterpret_cast<bf16*>(smem), m0, n0, wm * WM, wn * WN, tid, lane, bz);
             return;
         }
@@ -434,7 +434,8 @@ extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
         LAVT_CHECK_ARG(p.K == taps * p.conv_kc && p.conv_kc % epc == 0 && p.conv_h > 0 && p.conv_w > 0, "lavt_gemm_nt: bad conv geometry");
         LAVT_CHECK_ARG(p.M % vox == 0, "lavt_gemm_nt: conv rows %d not a multiple of D*H*W", p.M);
     }
-    LAVT_CHECK_ARG((!p.R || p.ldr % 4 == 0) && (!p.Cpre || p.ldcpre % 4 == 0), "lavt_gemm_nt: ldr/ldcpre must be multiples of 4");
+    LAVT_CHECK_ARG((!p.R || p.ldr % 4 == 0) && (!p.Cpre || p.ldcpre % 4 == 0) && (!p.mul || p.ldmul % 4 == 0), "lavt_gemm_nt: ldr/ldcpre/ldmul must be multiples of 4");
+    LAVT_CHECK_ARG(!p.res_first || (p.dact_pre && p.R), "lavt_gemm_nt: res_first orders the residual before the fused activation gradient (needs dact_pre and R)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     { const char* e = getenv("LAVT_GEMM_EPI"); p.epi_lds = (e && e[0] == 'l') ? 1 : 0;
       static const bool wide_off = e && e[0] == 'n';          // LAVT_GEMM_EPI=narrow: the 8-byte store form

@@ -158,6 +158,11 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p, f32x4 
                 for (int r = 0; r < 4; ++r) v[r] = (p.alpha * acc[i][2 * jp + h][r] + bb[r]) * rs;
                 if constexpr (DACT) {
                     if (live) {
+                        if (p.res_first && p.R) {          // gradient arriving beside the GEMM's own (a residual branch) joins BEFORE the activation gradient
+                            const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.R) + (int64_t)orow * p.ldr + n);
+                            v[0] += __uint_as_float(q.x << 16); v[1] += __uint_as_float(q.x & 0xFFFF0000u);
+                            v[2] += __uint_as_float(q.y << 16); v[3] += __uint_as_float(q.y & 0xFFFF0000u);
+                        }
                         const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.dact_pre) + (int64_t)orow * p.lddact + n);
                         v[0] *= act_grad(p.dact, __uint_as_float(q.x << 16)); v[1] *= act_grad(p.dact, __uint_as_float(q.x & 0xFFFF0000u));
                         v[2] *= act_grad(p.dact, __uint_as_float(q.y << 16)); v[3] *= act_grad(p.dact, __uint_as_float(q.y & 0xFFFF0000u));
@@ -168,7 +173,12 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p, f32x4 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = apply_act<true>(p.act, v[r]);
                 }
-                if (p.R && live) {          // (an fp32 exchange + one 16-byte residual load measured slower than these 8-byte loads: 2.6 vs 2.0 us on the fc1 shape)
+                if (p.mul && live) {        // language gate: x + tanh(g) * r -- the multiplier r rides between the activation and the residual
+                    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.mul) + (int64_t)orow * p.ldmul + n);
+                    v[0] *= __uint_as_float(q.x << 16); v[1] *= __uint_as_float(q.x & 0xFFFF0000u);
+                    v[2] *= __uint_as_float(q.y << 16); v[3] *= __uint_as_float(q.y & 0xFFFF0000u);
+                }
+                if (p.R && live && !(DACT && p.res_first)) {          // (an fp32 exchange + one 16-byte residual load measured slower than these 8-byte loads: 2.6 vs 2.0 us on the fc1 shape)
                     const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.R) + (int64_t)orow * p.ldr + n);
                     v[0] += __uint_as_float(q.x << 16); v[1] += __uint_as_float(q.x & 0xFFFF0000u);
                     v[2] += __uint_as_float(q.y << 16); v[3] += __uint_as_float(q.y & 0xFFFF0000u);
@@ -222,6 +232,11 @@ __device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc
             }
             const bool full = (n + 3 < p.N);
             if constexpr (DACT) {          // gradient w.r.t. the pre-activation of the producing layer: v *= act'(pre[orow][n..n+3])
+                if (p.res_first && p.R) {
+                    const T* rp = reinterpret_cast<const T*>(p.R) + (int64_t)orow * p.ldr + n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += to_f<T>(rp[r]);
+                }
                 const T* dp = reinterpret_cast<const T*>(p.dact_pre) + (int64_t)orow * p.lddact + n;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] *= act_grad(p.dact, to_f<T>(dp[r]));
@@ -237,7 +252,12 @@ __device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = apply_act<std::is_same<T, bf16>::value>(p.act, v[r]);
             }
-            if (p.R) {
+            if (p.mul) {
+                const T* mp = reinterpret_cast<const T*>(p.mul) + (int64_t)orow * p.ldmul + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] *= to_f<T>(mp[r]);
+            }
+            if (p.R && !(DACT && p.res_first)) {
                 const T* rp = reinterpret_cast<const T*>(p.R) + (int64_t)orow * p.ldr + n;
                 if (full) {
                     if constexpr (std::is_same<T, float>::value) { const float4 q = *reinterpret_cast<const float4*>(rp); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         return;
     } else {
     if constexpr (DACT) { nt_epilogue<T, MI, NI, true>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz); return; }
-    if (!p.epi_lds || p.c_f32 || (p.ldc % 8) || (p.C2 && (p.ldc2 % 8 || p.c_split % 8)) || (p.R && p.ldr % 8) || (p.Cpre && p.ldcpre % 8))
+    if (!p.epi_lds || p.mul || p.c_f32 || (p.ldc % 8) || (p.C2 && (p.ldc2 % 8 || p.c_split % 8)) || (p.R && p.ldr % 8) || (p.Cpre && p.ldcpre % 8))
         nt_epilogue<T, MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
     else
         nt_epilogue_lds<BM, BN, MI, NI>(p, acc, reinterpret_cast<bf16*>(smem), m0, n0, wm * WM, wn * WN, tid, lane, bz);
@@ -495,7 +495,7 @@ int launch_nt_v2_fp8(const lavt_gemm_nt_t& p, hipStream_t st) {
 // Fused activation-gradient epilogue (dact_pre): data gradients only (k-major B, plain K walk); the flag is a template parameter so that no
 // other instantiation pays its registers (as a run-time branch in every kernel it cost 12 VGPRs and 0.25 ms per step in round 1).
 int launch_nt_v2_dact(const lavt_gemm_nt_t& p, hipStream_t st) {
-    if (!p.b_kmajor || p.conv_kc > 0 || p.A2 || p.K % 64 || p.lddact % 8 || p.c_f32 || p.C2 || p.Cpre || p.R || p.act) {
+    if (!p.b_kmajor || p.conv_kc > 0 || p.A2 || p.K % 64 || p.lddact % 8 || p.c_f32 || p.C2 || p.Cpre || (p.R && !p.res_first) || p.act || p.mul) {
         lavt_set_error("lavt_gemm_nt: dact_pre needs a plain k-major data-gradient problem (no taps / concat / residual / activation, K %% 64 == 0)");
         return LAVT_ERR_INVALID;
     }

@@ -1,0 +1,504 @@
+// Fused PWAM (pixel-word attention module + language gate) for gfx950, bf16.
+// Reference arithmetic: PWAM.forward lib/backbone.py:1265-1278, SpatialImageLanguageAttention.forward :1329-1372, gate :604-611 / :669.
+//
+// The reference evaluates, per sample, on T pixels x C channels with <= 32 word slots J:
+//     vis = GELU(x Wv^T + bv);   q = IN_T(x Wq^T + bq);   P = softmax_words(q K^T C^-1/2 + mask);   w = (P V) Wo^T + bo;
+//     r = GELU((vis * IN_T(w)) Wm^T + bm);   x' = x + tanh(ReLU(r W1^T) W2^T) * r
+// as ~15 kernels forward and ~35 backward when composed from GEMMs and normalisation passes.  Two identities collapse the middle part:
+//   (1) the instance norm of q folds into the keys:  S = q K''^T + s0,  K'' = C^-1/2 rstd_q K,  s0 = mask - mu_q K''^T        (no normalised q tensor)
+//   (2) w = P (V Wo^T) + bo is a [T x 32] x [32 x C] product of the word probabilities, so its instance-norm statistics follow from the word
+//       statistics alone: mean_T w = Pbar VW + bo, var_T w[c] = VW[:,c]^T Cov_T(P) VW[:,c], and IN_T(w) = (P - Pbar) VW' with VW' = VW rstd_w
+//       -- the [T x C] tensor w, its two statistics passes and its [C x C] GEMM over T rows do not exist.
+// What remains besides plain GEMMs are two row-streaming kernel families (HBM-bound; the 32-wide contractions ride on v_mfma_f32_16x16x32_bf16):
+//   pwam_words_kernel: [T x C] x [C x 32] -> per-row word vectors (forward: S -> softmax -> P; backward: dP -> softmax' -> dS)
+//   pwam_mix_kernel:   [T x 32] x [32 x C] -> per-row channel vectors fused with the element-wise neighbours
+//                      (forward: mm = GELU(vpre) * what; backward A: d vpre, d what; backward C: dq = dS K'' + c0 - q c1)
+// and three tiny language-side kernels on [32 x C] / [32 x 32] matrices.  tools/pwam_algebra_check.py proves the algebra against autograd.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ bf16x8 ldg8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 lds8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+__device__ __forceinline__ float bf16_round(float v) { return (float)(bf16)v; }
+
+// A lane of a C^T accumulator pair holds, for ONE row, elements 4g .. 4g+3 of a 16-wide tile (p0) and the same of the next tile (p1), g = lane / 16.
+// Lanes g and g ^ 1 swap one packed quadruple so that every lane moves 16 contiguous bytes (64 contiguous bytes per row and wave-instruction).
+__device__ __forceinline__ void store_pair16(bf16* row32, int g, uint2 p0, uint2 p1, bool valid) {
+    const bool odd = g & 1;
+    const uint2 send = odd ? p0 : p1;
+    const uint2 got = make_uint2((unsigned)__shfl_xor((int)send.x, 16, 64), (unsigned)__shfl_xor((int)send.y, 16, 64));
+    const uint4 out = odd ? make_uint4(got.x, got.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, got.x, got.y);
+    if (valid) *reinterpret_cast<uint4*>(row32 + (odd ? 16 + 4 * (g - 1) : 4 * g)) = out;
+}
+// the mirror image: one 16-byte load per lane, then the exchange -> this lane's quadruples of both tiles
+__device__ __forceinline__ void load_pair16(const bf16* row32, int g, uint2& p0, uint2& p1) {
+    const bool odd = g & 1;
+    const uint4 L = *reinterpret_cast<const uint4*>(row32 + (odd ? 16 + 4 * (g - 1) : 4 * g));
+    const uint2 send = odd ? make_uint2(L.x, L.y) : make_uint2(L.z, L.w);
+    const uint2 got = make_uint2((unsigned)__shfl_xor((int)send.x, 16, 64), (unsigned)__shfl_xor((int)send.y, 16, 64));
+    p0 = odd ? got : make_uint2(L.x, L.y);
+    p1 = odd ? make_uint2(L.z, L.w) : got;
+}
+__device__ __forceinline__ void unpack4(uint2 p, float (&f)[4]) { f[0] = bf_lo(p.x); f[1] = bf_hi(p.x); f[2] = bf_lo(p.y); f[3] = bf_hi(p.y); }
+__device__ __forceinline__ uint2 pack4(const float (&f)[4]) { return make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3])); }
+
+// ================================================================================================ words kernel
+// grid (row blocks, B), 256 threads; a wave owns 16-row tiles.  LDS: the [32][C] word matrix (rows padded by 8 elements) + 32 floats.
+//   BWD = false: Wm = K'' * log2 e (built here from K, rstd_q), vec = (maskbias - mu_q K''^T) log2 e;  out = P = softmax over words < n_l
+//   BWD = true:  Wm = VW' (word-major, from lavt_pwam_lang_fwd), second contraction with -Q over the words of P, vec = Pbar Q - u;
+//                out = dS = P (dP - sum_j P_j dP_j)
+struct WordsArgs {
+    const bf16* X;        // [B*T][ldx]: q (forward) / d what (backward)
+    int64_t ldx;
+    const bf16* Wsrc;     // forward: K [B][32][ldw];  backward: VW' [B][32][C] (ldw = C)
+    int64_t ldw;
+    const float* mean;    // forward: mu_q, rstd_q [B][C]
+    const float* rstd;
+    const float* vec;     // forward: maskbias [B][32];  backward: u [B][32]
+    const float* Qf;      // backward: Q [B][32][32] fp32
+    const float* pbar;    // backward: Pbar [B][32]
+    const bf16* P;        // backward: P [B*T][32]
+    bf16* out;            // [B*T][32]
+    int T, C, n_l;
+    float alpha;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int C = a.C, LDW = C + 8;
+    bf16* Wm = reinterpret_cast<bf16*>(smem_raw);                   // [32][LDW]
+    float* vec = reinterpret_cast<float*>(Wm + 32 * LDW);           // [32]
+    bf16* Qn = reinterpret_cast<bf16*>(vec + 32);                   // backward: -Q as bf16 [32][40]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.y;
+
+    // ---- prologue: the word matrix and the per-word constants of this sample ----
+    const int nch = C >> 3;
+    for (int e = tid; e < 32 * nch; e += 256) {
+        const int j = e / nch, cc = e - j * nch;
+        float f[8];
+        chunk_to_f<bf16>(*reinterpret_cast<const uint4*>(a.Wsrc + ((int64_t)b * 32 + j) * a.ldw + cc * 8), f);
+        if constexpr (!BWD) {
+            const float4 r0 = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + cc * 8), r1 = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + cc * 8 + 4);
+            const float s = a.alpha * LOG2E;
+            f[0] *= r0.x * s; f[1] *= r0.y * s; f[2] *= r0.z * s; f[3] *= r0.w * s; f[4] *= r1.x * s; f[5] *= r1.y * s; f[6] *= r1.z * s; f[7] *= r1.w * s;
+        }
+        *reinterpret_cast<uint4*>(Wm + j * LDW + cc * 8) = f_to_chunk<bf16>(f);
+    }
+    if constexpr (BWD) {
+        for (int e = tid; e < 1024; e += 256) Qn[(e >> 5) * 40 + (e & 31)] = (bf16)(-a.Qf[(int64_t)b * 1024 + e]);
+    }
+    __syncthreads();
+    {
+        const int j = tid >> 3, part = tid & 7;
+        float s = 0.f;
+        if constexpr (!BWD) {
+            for (int cc = part; cc < nch; cc += 8) {
+                float f[8];
+                chunk_to_f<bf16>(*reinterpret_cast<const uint4*>(Wm + j * LDW + cc * 8), f);
+                const float* mu = a.mean + (int64_t)b * C + cc * 8;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) s += f[x] * mu[x];
+            }
+        } else {
+            for (int k = part; k < 32; k += 8) s += a.pbar[b * 32 + k] * (-(float)Qn[k * 40 + j]);       // Pbar Q with the bf16 Q the MFMA sees
+        }
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if (part == 0) vec[j] = BWD ? s - a.vec[b * 32 + j] : a.vec[b * 32 + j] * LOG2E - s;
+    }
+    __syncthreads();
+
+    const int ntiles = (a.T + 15) >> 4;
+    const int ksteps = C >> 5;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int t = tile * 16 + c16;
+        const bool vr = t < a.T;
+        const int64_t row = (int64_t)b * a.T + (vr ? t : a.T - 1);
+        const bf16* xp = a.X + row * a.ldx + 8 * g;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const bf16* w0 = Wm + c16 * LDW + 8 * g;
+        const bf16* w1 = w0 + 16 * LDW;
+        int ks = 0;
+        for (; ks + 4 <= ksteps; ks += 4) {
+            bf16x8 xf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xf[u] = ldg8(xp + 32 * (ks + u));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(w0 + 32 * (ks + u)), xf[u], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(w1 + 32 * (ks + u)), xf[u], acc[1], 0, 0, 0);
+            }
+        }
+        for (; ks < ksteps; ++ks) {
+            const bf16x8 xf = ldg8(xp + 32 * ks);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(w0 + 32 * ks), xf, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(w1 + 32 * ks), xf, acc[1], 0, 0, 0);
+        }
+        // lane: row c16, words 4g + r (tile 0) and 16 + 4g + r (tile 1)
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(vec + 4 * g), v1 = *reinterpret_cast<const f32x4*>(vec + 16 + 4 * g);
+        float o0[4], o1[4];
+        if constexpr (!BWD) {
+            float s0[4], s1[4], mx = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r] = (4 * g + r < a.n_l) ? acc[0][r] + v0[r] : -3.0e38f;
+                s1[r] = (16 + 4 * g + r < a.n_l) ? acc[1][r] + v1[r] : -3.0e38f;
+                mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o0[r] = (4 * g + r < a.n_l) ? __builtin_amdgcn_exp2f(s0[r] - mx) : 0.f;
+                o1[r] = (16 + 4 * g + r < a.n_l) ? __builtin_amdgcn_exp2f(s1[r] - mx) : 0.f;
+                sum += o0[r] + o1[r];
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o0[r] *= inv; o1[r] *= inv; }
+        } else {
+            // second contraction: - P Q (k = words of P): A = -Q rows (word 16wt + c16, k-words 8g..), B = P row fragment
+            const bf16x8 pf = ldg8(a.P + row * 32 + 8 * g);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(Qn + c16 * 40 + 8 * g), pf, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(Qn + (16 + c16) * 40 + 8 * g), pf, acc[1], 0, 0, 0);
+            float p0[4], p1[4], dot = 0.f;
+            unpack4(*reinterpret_cast<const uint2*>(a.P + row * 32 + 4 * g), p0);
+            unpack4(*reinterpret_cast<const uint2*>(a.P + row * 32 + 16 + 4 * g), p1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o0[r] = acc[0][r] + v0[r];
+                o1[r] = acc[1][r] + v1[r];
+                dot += p0[r] * o0[r] + p1[r] * o1[r];
+            }
+            dot += __shfl_xor(dot, 16, 64);
+            dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o0[r] = p0[r] * (o0[r] - dot); o1[r] = p1[r] * (o1[r] - dot); }
+        }
+        store_pair16(a.out + row * 32, g, pack4(o0), pack4(o1), vr);
+    }
+}
+
+// ================================================================================================ mix kernel
+// grid (row blocks, B), 256 threads; a wave owns 32-row tile pairs.  acc[channel 4g + r of a 16-channel tile][row c16] = sum_j Wc[channel][j] Wd[row][j].
+//   MODE 0 (forward):    what = acc + beta;  mm = GELU(vpre) * what                               out0 = mm
+//   MODE 1 (backward A): dmm given;  d what = dmm * GELU(vpre);  d vpre = dmm * what * GELU'(vpre)  out0 = d vpre, out1 = d what
+//   MODE 2 (backward C): Wd = dS, Wc = K''^T;  dq = acc + c0 - q * c1                              out0 = dq
+struct MixArgs {
+    const bf16* Wd;       // [B*T][32] row-major word vectors (P / dS)
+    const bf16* Wc;       // [B][C][32] channel-major (VW'^T / K''^T)
+    const float* v0;      // [B][C]: beta (modes 0, 1) / c0 (mode 2)
+    const float* v1;      // [B][C]: c1 (mode 2)
+    const float* xb;      // [C] or null: bias added to X (modes 0, 1: the vis_project bias, so that the producing GEMM needs none)
+    const bf16* X;        // [B*T][ldx]: vpre (modes 0, 1) / q (mode 2)
+    int64_t ldx;
+    const bf16* D;        // [B*T][ldd]: dmm (mode 1)
+    int64_t ldd;
+    bf16* out0;
+    int64_t ld0;
+    bf16* out1;
+    int64_t ld1;
+    int T, C;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void pwam_mix_kernel(const MixArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.y, C = a.C;
+    const int ntiles = (a.T + 31) >> 5;
+    const bf16* Wc = a.Wc + (int64_t)b * C * 32;
+    const float* v0 = a.v0 + (int64_t)b * C;
+    const float* v1 = MODE == 2 ? a.v1 + (int64_t)b * C : nullptr;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        int64_t row[2];
+        bool vr[2];
+        bf16x8 wd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = tile * 32 + 16 * h + c16;
+            vr[h] = t < a.T;
+            row[h] = (int64_t)b * a.T + (vr[h] ? t : a.T - 1);
+            wd[h] = ldg8(a.Wd + row[h] * 32 + 8 * g);
+        }
+        for (int cp = 0; cp < (C >> 5); ++cp) {
+            const int ch0 = 32 * cp;
+            const bf16x8 wa0 = ldg8(Wc + (int64_t)(ch0 + c16) * 32 + 8 * g), wa1 = ldg8(Wc + (int64_t)(ch0 + 16 + c16) * 32 + 8 * g);
+            const float4 va0 = *reinterpret_cast<const float4*>(v0 + ch0 + 4 * g), va1 = *reinterpret_cast<const float4*>(v0 + ch0 + 16 + 4 * g);
+            const float c0a[4] = {va0.x, va0.y, va0.z, va0.w}, c0b[4] = {va1.x, va1.y, va1.z, va1.w};
+            float c1a[4] = {0.f, 0.f, 0.f, 0.f}, c1b[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (MODE == 2) {
+                const float4 q0 = *reinterpret_cast<const float4*>(v1 + ch0 + 4 * g), q1 = *reinterpret_cast<const float4*>(v1 + ch0 + 16 + 4 * g);
+                c1a[0] = q0.x; c1a[1] = q0.y; c1a[2] = q0.z; c1a[3] = q0.w; c1b[0] = q1.x; c1b[1] = q1.y; c1b[2] = q1.z; c1b[3] = q1.w;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa0, wd[h], z, 0, 0, 0);
+                const f32x4 e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa1, wd[h], z, 0, 0, 0);
+                uint2 xp0, xp1;
+                load_pair16(a.X + row[h] * a.ldx + ch0, g, xp0, xp1);
+                float x0[4], x1[4], r0[4], r1[4];
+                unpack4(xp0, x0); unpack4(xp1, x1);
+                if (MODE != 2 && a.xb) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(a.xb + ch0 + 4 * g), b1 = *reinterpret_cast<const float4*>(a.xb + ch0 + 16 + 4 * g);
+                    x0[0] += b0.x; x0[1] += b0.y; x0[2] += b0.z; x0[3] += b0.w; x1[0] += b1.x; x1[1] += b1.y; x1[2] += b1.z; x1[3] += b1.w;
+                }
+                if constexpr (MODE == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { r0[r] = gelu_f_fast(x0[r]) * (e0[r] + c0a[r]); r1[r] = gelu_f_fast(x1[r]) * (e1[r] + c0b[r]); }
+                    store_pair16(a.out0 + row[h] * a.ld0 + ch0, g, pack4(r0), pack4(r1), vr[h]);
+                } else if constexpr (MODE == 1) {
+                    uint2 dp0, dp1;
+                    load_pair16(a.D + row[h] * a.ldd + ch0, g, dp0, dp1);
+                    float d0[4], d1[4], w0[4], w1[4];
+                    unpack4(dp0, d0); unpack4(dp1, d1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float wh0 = e0[r] + c0a[r], wh1 = e1[r] + c0b[r];
+                        r0[r] = d0[r] * wh0 * gelu_grad_f_fast(x0[r]); r1[r] = d1[r] * wh1 * gelu_grad_f_fast(x1[r]);
+                        w0[r] = d0[r] * gelu_f_fast(x0[r]); w1[r] = d1[r] * gelu_f_fast(x1[r]);
+                    }
+                    store_pair16(a.out0 + row[h] * a.ld0 + ch0, g, pack4(r0), pack4(r1), vr[h]);
+                    store_pair16(a.out1 + row[h] * a.ld1 + ch0, g, pack4(w0), pack4(w1), vr[h]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { r0[r] = e0[r] + c0a[r] - x0[r] * c1a[r]; r1[r] = e1[r] + c0b[r] - x1[r] * c1b[r]; }
+                    store_pair16(a.out0 + row[h] * a.ld0 + ch0, g, pack4(r0), pack4(r1), vr[h]);
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================ language side
+// forward: VW = V Wo^T on the matrix cores, Cov_T(P) from the second-moment matrix, var_w -> VW' in both layouts, beta = -Pbar VW'.
+// grid (C / 64, B), 256 threads: wave w owns channels 16 w .. 16 w + 15 of the block's 64.
+__global__ __launch_bounds__(256) void pwam_lang_fwd_kernel(const bf16* __restrict__ V, int64_t ldv, const bf16* __restrict__ Wo, const float* __restrict__ PP,
+                                                            const float* __restrict__ sumP, bf16* __restrict__ VWc, bf16* __restrict__ VWw, float* __restrict__ beta,
+                                                            float* __restrict__ rw, float* __restrict__ pbar_out, float* __restrict__ cov_out, int T, int C, float eps) {
+    __shared__ float vw[64][33];
+    __shared__ float cov[32][33];
+    __shared__ float pb[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.y, c0 = blockIdx.x * 64;
+    const float invT = 1.0f / (float)T;
+    if (tid < 32) pb[tid] = sumP[b * 32 + tid] * invT;
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+        const int j = e >> 5, k = e & 31;
+        const float cv = PP[(int64_t)b * 1024 + e] * invT - pb[j] * pb[k];
+        cov[j][k] = cv;
+        if (blockIdx.x == 0) cov_out[(int64_t)b * 1024 + e] = cv;
+    }
+    if (blockIdx.x == 0 && tid < 32) pbar_out[b * 32 + tid] = pb[tid];
+    // VW[word][channel] for this wave's 16 channels
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int ch = c0 + wave * 16 + c16;
+    const bool vc = ch < C;
+    const bf16* wp = Wo + (int64_t)(vc ? ch : C - 1) * C + 8 * g;
+    const bf16* vp0 = V + ((int64_t)b * 32 + c16) * ldv + 8 * g;
+    const bf16* vp1 = vp0 + 16 * ldv;
+    for (int ks = 0; ks < (C >> 5); ++ks) {
+        const bf16x8 wf = ldg8(wp + 32 * ks);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(vp0 + 32 * ks), wf, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(vp1 + 32 * ks), wf, acc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { vw[wave * 16 + c16][4 * g + r] = acc[0][r]; vw[wave * 16 + c16][16 + 4 * g + r] = acc[1][r]; }
+    __syncthreads();
+    const int c = tid >> 2, part = tid & 3;
+    float var = 0.f;
+    for (int j = part * 8; j < part * 8 + 8; ++j) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) t += cov[j][k] * vw[c][k];
+        var += vw[c][j] * t;
+    }
+    var += __shfl_xor(var, 1, 64); var += __shfl_xor(var, 2, 64);
+    const float rs = rsqrtf(fmaxf(var, 0.f) + eps);
+    float f[8], bsum = 0.f;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) { f[x] = bf16_round(vw[c][part * 8 + x] * rs); bsum -= pb[part * 8 + x] * f[x]; }
+    bsum += __shfl_xor(bsum, 1, 64); bsum += __shfl_xor(bsum, 2, 64);
+    if (c0 + c < C) {
+        *reinterpret_cast<uint4*>(VWc + ((int64_t)b * C + c0 + c) * 32 + part * 8) = f_to_chunk<bf16>(f);
+#pragma unroll
+        for (int x = 0; x < 8; ++x) VWw[((int64_t)b * 32 + part * 8 + x) * C + c0 + c] = (bf16)f[x];
+        if (part == 0) { beta[(int64_t)b * C + c0 + c] = bsum; rw[(int64_t)b * C + c0 + c] = rs; }
+    }
+}
+
+// backward 1: from H^T = dwhat^T P [C][32] and s = colsum(dwhat) [C]: the IN-backward constants a, b per channel, dVW [32][C] (bf16, word-major),
+// and the sums over channels Q = VW' diag(b) VW'^T [32][32], u = VW' a [32] (atomics into zeroed buffers: <= C / 64 adders per address).
+__global__ __launch_bounds__(256) void pwam_lang_bwd1_kernel(const float* __restrict__ HT, const float* __restrict__ s, const bf16* __restrict__ VWc,
+                                                             const float* __restrict__ rw, const float* __restrict__ pbar, const float* __restrict__ cov_in,
+                                                             bf16* __restrict__ dVW, float* __restrict__ Qf, float* __restrict__ u, int T, int C) {
+    __shared__ float vw[64][33];
+    __shared__ float h[64][33];
+    __shared__ float cov[32][33];
+    __shared__ float pb[32];
+    __shared__ float av[64], bv[64];
+    const int tid = threadIdx.x, b = blockIdx.y, c0 = blockIdx.x * 64;
+    const float Tf = (float)T, invT = 1.0f / Tf;
+    if (tid < 32) pb[tid] = pbar[b * 32 + tid];
+    for (int e = tid; e < 1024; e += 256) cov[e >> 5][e & 31] = cov_in[(int64_t)b * 1024 + e];
+    for (int e = tid; e < 64 * 32; e += 256) {
+        const int c = e >> 5, j = e & 31;
+        const bool ok = c0 + c < C;
+        vw[c][j] = ok ? (float)VWc[((int64_t)b * C + c0 + c) * 32 + j] : 0.f;
+        h[c][j] = ok ? HT[((int64_t)b * C + c0 + c) * 32 + j] : 0.f;
+    }
+    __syncthreads();
+    const int c = tid >> 2, part = tid & 3;
+    const bool ok = c0 + c < C;
+    const float sc = ok ? s[(int64_t)b * C + c0 + c] : 0.f;
+    float bs = 0.f;
+    for (int j = part * 8; j < part * 8 + 8; ++j) bs += vw[c][j] * (h[c][j] - pb[j] * sc);
+    bs += __shfl_xor(bs, 1, 64); bs += __shfl_xor(bs, 2, 64);
+    const float bc = bs * invT, ac = sc * invT;
+    if (part == 0) { av[c] = ac; bv[c] = bc; }
+    const float rs = ok ? rw[(int64_t)b * C + c0 + c] : 0.f;
+    for (int j = part * 8; j < part * 8 + 8; ++j) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) t += cov[j][k] * vw[c][k];
+        const float d = rs * (h[c][j] - Tf * pb[j] * ac - Tf * bc * t);
+        if (ok) dVW[((int64_t)b * 32 + j) * C + c0 + c] = (bf16)d;
+    }
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+        const int k = e >> 5, j = e & 31;
+        float q = 0.f;
+#pragma unroll 8
+        for (int cc = 0; cc < 64; ++cc) q += vw[cc][k] * bv[cc] * vw[cc][j];
+        atomicAdd(Qf + (int64_t)b * 1024 + e, q);
+    }
+    if (tid < 32) {
+        float q = 0.f;
+        for (int cc = 0; cc < 64; ++cc) q += vw[cc][tid] * av[cc];
+        atomicAdd(u + b * 32 + tid, q);
+    }
+}
+
+// backward 2: from G = dS^T q [32][C] (raw q) and colsum(dS) [32]: dK, the dq constants c0, c1 and K'' in channel-major layout.
+__global__ __launch_bounds__(256) void pwam_lang_bwd2_kernel(const float* __restrict__ G, const float* __restrict__ sdS, const bf16* __restrict__ K, int64_t ldk,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd, bf16* __restrict__ dK, int64_t lddk,
+                                                             bf16* __restrict__ K2c, float* __restrict__ c0o, float* __restrict__ c1o, int T, int C, float alpha) {
+    __shared__ float sd[32];
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < 32) sd[threadIdx.x] = sdS[b * 32 + threadIdx.x];
+    __syncthreads();
+    if (c >= C) return;
+    const float mu = mean[(int64_t)b * C + c], rq = rstd[(int64_t)b * C + c], invT = 1.0f / (float)T;
+    float a2 = 0.f, b2 = 0.f, k2[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const float kv = (float)K[((int64_t)b * 32 + j) * ldk + c];
+        const float gh = (G[((int64_t)b * 32 + j) * C + c] - sd[j] * mu) * rq;
+        dK[((int64_t)b * 32 + j) * lddk + c] = (bf16)(alpha * gh);
+        a2 += sd[j] * kv;
+        b2 += kv * gh;
+        k2[j] = alpha * rq * kv;
+    }
+    a2 *= alpha * invT; b2 *= alpha * invT;
+    const float c1 = rq * rq * b2;
+    c1o[(int64_t)b * C + c] = c1;
+    c0o[(int64_t)b * C + c] = -rq * a2 + mu * c1;
+    bf16* dst = K2c + ((int64_t)b * C + c) * 32;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) *reinterpret_cast<uint4*>(dst + j) = f_to_chunk<bf16>(k2 + j);
+}
+
+int rows_grid(int tiles_per_sample, int B) {
+    int gx = (tiles_per_sample + 3) / 4;            // 4 waves, one tile each per pass
+    const int cap = 1024 / (B > 0 ? B : 1);
+    if (gx > cap) gx = cap;
+    return gx < 1 ? 1 : gx;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int lavt_pwam_words_fwd(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
+                                   void* P, int B, int T, int C, int n_l, float alpha, void* stream) {
+    LAVT_CHECK_ARG(q && K && mean && rstd && maskbias && P && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && C <= 2048 && n_l > 0 && n_l <= 32 && ldq % 8 == 0 && ldk % 8 == 0,
+                   "lavt_pwam_words_fwd: bad arguments (C %% 32 == 0, C <= 2048, 1 <= n_l <= 32, 16-byte aligned rows)");
+    WordsArgs a{};
+    a.X = (const bf16*)q; a.ldx = ldq; a.Wsrc = (const bf16*)K; a.ldw = ldk; a.mean = mean; a.rstd = rstd; a.vec = maskbias; a.out = (bf16*)P;
+    a.T = T; a.C = C; a.n_l = n_l; a.alpha = alpha;
+    const size_t lds = (size_t)32 * (C + 8) * 2 + 128 + 32 * 40 * 2;
+    static size_t reserved = 0;
+    if (lds > 65536 && lds > reserved) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pwam_words_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { lavt_set_error("lavt_pwam_words_fwd: cannot reserve LDS"); return LAVT_ERR_LAUNCH; }
+        reserved = lds;
+    }
+    hipLaunchKernelGGL(pwam_words_kernel<false>, dim3(rows_grid((T + 15) / 16, B), B), dim3(256), lds, ST, a);
+    LAVT_CHECK_LAUNCH("lavt_pwam_words_fwd");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_pwam_words_bwd(const void* dwhat, int64_t ldx, const void* VWw, const float* Qf, const float* u, const float* pbar, const void* P,
+                                   void* dS, int B, int T, int C, void* stream) {
+    LAVT_CHECK_ARG(dwhat && VWw && Qf && u && pbar && P && dS && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && C <= 2048 && ldx % 8 == 0, "lavt_pwam_words_bwd: bad arguments");
+    WordsArgs a{};
+    a.X = (const bf16*)dwhat; a.ldx = ldx; a.Wsrc = (const bf16*)VWw; a.ldw = C; a.vec = u; a.Qf = Qf; a.pbar = pbar; a.P = (const bf16*)P; a.out = (bf16*)dS;
+    a.T = T; a.C = C; a.n_l = 32; a.alpha = 1.f;
+    const size_t lds = (size_t)32 * (C + 8) * 2 + 128 + 32 * 40 * 2;
+    static size_t reserved = 0;
+    if (lds > 65536 && lds > reserved) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pwam_words_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { lavt_set_error("lavt_pwam_words_bwd: cannot reserve LDS"); return LAVT_ERR_LAUNCH; }
+        reserved = lds;
+    }
+    hipLaunchKernelGGL(pwam_words_kernel<true>, dim3(rows_grid((T + 15) / 16, B), B), dim3(256), lds, ST, a);
+    LAVT_CHECK_LAUNCH("lavt_pwam_words_bwd");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_pwam_mix(int mode, const void* Wd, const void* Wc, const float* v0, const float* v1, const float* xbias, const void* X, int64_t ldx, const void* D, int64_t ldd,
+                             void* out0, int64_t ld0, void* out1, int64_t ld1, int B, int T, int C, void* stream) {
+    LAVT_CHECK_ARG(Wd && Wc && v0 && X && out0 && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && ldx % 8 == 0 && ld0 % 8 == 0 && mode >= 0 && mode <= 2 &&
+                   (mode != 1 || (D && out1 && ldd % 8 == 0 && ld1 % 8 == 0)) && (mode != 2 || v1), "lavt_pwam_mix: bad arguments");
+    MixArgs a{};
+    a.Wd = (const bf16*)Wd; a.Wc = (const bf16*)Wc; a.v0 = v0; a.v1 = v1; a.xb = xbias; a.X = (const bf16*)X; a.ldx = ldx; a.D = (const bf16*)D; a.ldd = ldd;
+    a.out0 = (bf16*)out0; a.ld0 = ld0; a.out1 = (bf16*)out1; a.ld1 = ld1; a.T = T; a.C = C;
+    const dim3 grid(rows_grid((T + 31) / 32, B), B);
+    if (mode == 0) hipLaunchKernelGGL(pwam_mix_kernel<0>, grid, dim3(256), 0, ST, a);
+    else if (mode == 1) hipLaunchKernelGGL(pwam_mix_kernel<1>, grid, dim3(256), 0, ST, a);
+    else hipLaunchKernelGGL(pwam_mix_kernel<2>, grid, dim3(256), 0, ST, a);
+    LAVT_CHECK_LAUNCH("lavt_pwam_mix");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_pwam_lang_fwd(const void* V, int64_t ldv, const void* Wo, const float* PP, const float* sumP, void* VWc, void* VWw, float* beta, float* rw,
+                                  float* pbar, float* cov, int B, int T, int C, float eps, void* stream) {
+    LAVT_CHECK_ARG(V && Wo && PP && sumP && VWc && VWw && beta && rw && pbar && cov && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && ldv % 8 == 0, "lavt_pwam_lang_fwd: bad arguments");
+    hipLaunchKernelGGL(pwam_lang_fwd_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, ST, (const bf16*)V, ldv, (const bf16*)Wo, PP, sumP, (bf16*)VWc, (bf16*)VWw, beta, rw, pbar, cov, T, C, eps);
+    LAVT_CHECK_LAUNCH("lavt_pwam_lang_fwd");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_pwam_lang_bwd1(const float* HT, const float* s, const void* VWc, const float* rw, const float* pbar, const float* cov, void* dVW, float* Qf, float* u,
+                                   int B, int T, int C, void* stream) {
+    LAVT_CHECK_ARG(HT && s && VWc && rw && pbar && cov && dVW && Qf && u && B > 0 && T > 0 && C >= 32, "lavt_pwam_lang_bwd1: bad arguments");
+    hipLaunchKernelGGL(pwam_lang_bwd1_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, ST, HT, s, (const bf16*)VWc, rw, pbar, cov, (bf16*)dVW, Qf, u, T, C);
+    LAVT_CHECK_LAUNCH("lavt_pwam_lang_bwd1");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_pwam_lang_bwd2(const float* G, const float* sdS, const void* K, int64_t ldk, const float* mean, const float* rstd, void* dK, int64_t lddk, void* K2c,
+                                   float* c0, float* c1, int B, int T, int C, float alpha, void* stream) {
+    LAVT_CHECK_ARG(G && sdS && K && mean && rstd && dK && K2c && c0 && c1 && B > 0 && T > 0 && C >= 32, "lavt_pwam_lang_bwd2: bad arguments");
+    hipLaunchKernelGGL(pwam_lang_bwd2_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, ST, G, sdS, (const bf16*)K, ldk, mean, rstd, (bf16*)dK, lddk, (bf16*)K2c, c0, c1, T, C, alpha);
+    LAVT_CHECK_LAUNCH("lavt_pwam_lang_bwd2");
+    return LAVT_OK;
+}

@@ -116,6 +116,7 @@ class GemmNT(C.Structure):
         ("C", vp), ("ldc", i64), ("strideC", i64), ("C2", vp), ("ldc2", i64), ("c_split", i32), ("c_rowmap", vp),
         ("c_f32", i32), ("zeros", vp), ("epi_lds", i32), ("conv_d", i32), ("conv_kd", i32), ("conv_kh", i32), ("conv_kw", i32),
         ("dact_pre", vp), ("lddact", i64), ("dact", i32), ("deq_a", vp), ("deq_b", vp), ("epi_wide", i32),
+        ("mul", vp), ("ldmul", i64), ("res_first", i32),
     ]
 
 
@@ -167,7 +168,13 @@ _PROTOTYPES = {
     "lavt_bert_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "lavt_dropout": [i32, vp, vp, f32, vp, vp, i64, vp],
     "lavt_gate_fwd": [i32, vp, vp, vp, vp, i64, vp],
-    "lavt_gate_bwd": [i32, vp, vp, vp, vp, vp, i64, vp],
+    "lavt_gate_bwd": [i32, vp, vp, vp, vp, vp, vp, i64, vp],
+    "lavt_pwam_words_fwd": [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "lavt_pwam_words_bwd": [vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "lavt_pwam_mix": [i32, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
+    "lavt_pwam_lang_fwd": [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "lavt_pwam_lang_bwd1": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "lavt_pwam_lang_bwd2": [vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, vp],
     "lavt_rowsoftmax_fwd": [i32, vp, vp, i64, i32, i32, vp],
     "lavt_rowsoftmax_bwd": [i32, vp, vp, vp, i64, i32, i32, vp],
     "lavt_bilinear_fwd": [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp],
@@ -197,6 +204,10 @@ for _name, _args in _PROTOTYPES.items():
     _fn = getattr(_cdll, _name)          # AttributeError here = header/library mismatch: fail loudly
     _fn.argtypes = _args
     _fn.restype = C.c_int
+EXPECTED_ABI = 4          # the ctypes struct layouts and prototypes in this file were written for this lavt_abi_version()
+if _cdll.lavt_abi_version() != EXPECTED_ABI:
+    raise ImportError(f"{LIB_PATH} reports ABI v{_cdll.lavt_abi_version()} but lavt_hip/_capi.py binds ABI v{EXPECTED_ABI}: rebuild the library "
+                      "(`make -C lavt-rs_amd/csrc`) -- a mismatch would make the kernels read past the caller's parameter structs")
 _cdll.lavt_last_error.restype = C.c_char_p
 _cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
 _cdll.lavt_last_error.argtypes = []

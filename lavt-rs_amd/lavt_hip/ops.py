@@ -327,7 +327,8 @@ def _zero_page(device):
 def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, strideB=0, strideC=0, A2=None, lda2=0,
             a_split=0, a_rowmap=None, conv=None, b_kmajor=False, b_tap_stride=0, alpha=1.0, bias=None, strideBias=0,
             row_scale=None, strideRowScale=0, row_scale_div=1, act=K.ACT_NONE, Cpre=None, ldcpre=0, R=None, ldr=0, C2=None, ldc2=0,
-            c_split=0, c_rowmap=None, c_f32=False, a_off=0, b_off=0, c_off=0, dact_pre=None, lddact=0, dact=K.ACT_NONE, deq=None):
+            c_split=0, c_rowmap=None, c_f32=False, a_off=0, b_off=0, c_off=0, dact_pre=None, lddact=0, dact=K.ACT_NONE, deq=None,
+            mul=None, ldmul=0, res_first=False):
     """A/B/Cout are tensors; *_off are element offsets into them (column sub-blocks).  dtype torch.uint8 = e4m3 operands (A, B 1 byte per
     element; C / residual bf16) with the two dequantisation |max| pointers in `deq`."""
     f8 = dtype == torch.uint8
@@ -350,6 +351,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.c_rowmap, p.c_f32 = K.ptr(c_rowmap), int(c_f32)
     p.zeros = _zero_page(A.device)
     p.dact_pre, p.lddact, p.dact = K.ptr(dact_pre), lddact, dact
+    p.mul, p.ldmul, p.res_first = K.ptr(mul), ldmul, int(res_first)
     if deq is not None:
         p.deq_a, p.deq_b = deq
     if K.prof.enabled:
@@ -1190,7 +1192,7 @@ class _Gate(torch.autograd.Function):
         gpre, r = ctx.saved_tensors
         d = d.contiguous()
         dg, dr = torch.empty_like(gpre), torch.empty_like(r)
-        K.check(K.lib.lavt_gate_bwd(K.dt(d.dtype), K.ptr(d), K.ptr(gpre), K.ptr(r), K.ptr(dg), K.ptr(dr), d.numel(), K.stream()))
+        K.check(K.lib.lavt_gate_bwd(K.dt(d.dtype), K.ptr(d), K.ptr(gpre), K.ptr(r), None, K.ptr(dg), K.ptr(dr), d.numel(), K.stream()))
         return d, dg, dr
 
 
@@ -1265,6 +1267,174 @@ class _PwamAttn(torch.autograd.Function):
 
 def pwam_attention(q, k, v, maskbias, B, T, n_l, G, sinks_kv=None):
     return _PwamAttn.apply(q, k, v, maskbias, B, T, n_l, G, sinks_kv)
+
+
+@K.scoped
+class _PwamGate(torch.autograd.Function):
+    """PWAM + language gate as ONE autograd node on the fused bf16 kernels (csrc/pwam.hip; reference lib/backbone.py:1265-1278, 1329-1372, 604-611, 669):
+
+        vis = GELU(x Wv^T + bv);  P = softmax_words(IN_T(x Wq^T + bq) K^T C^-1/2 + mask);  what = IN_T((P V) Wo^T + bo) = (P - Pbar) VW'
+        r = GELU((vis * what) Wm^T + bm);  xg = x + tanh(ReLU(r W1^T) W2^T) * r                                   -> (r, xg)
+
+    Forward, 10 launches: [vis | q] GEMM over the stacked weight, q statistics (2), word kernel (P), word second moments (TN GEMM), language
+    kernel (VW', beta), mix kernel (mm), project_mm GEMM, two gate GEMMs (the second writes xg in its epilogue).  bq and bo sit in front of an
+    instance norm: they change nothing and their gradients are exactly zero.  Backward: gate_bwd, three data-gradient GEMMs (ReLU' / GELU' in
+    the epilogues), mix A (d vpre, d what), H = dwhat^T P (TN), language kernel 1, word kernel (dS), G = dS^T q (TN), language kernel 2, mix C
+    (dq), one data-gradient GEMM over [d vpre | dq], dV GEMM + the weight gradients (grouped)."""
+
+    @staticmethod
+    def forward(ctx, x, k, v, maskbias, kv_sinks, dims, Wv, bv, Wq, bq, Wo, bo, Wm, bm, W1, W2):
+        B, T, n_l = dims
+        x = x.contiguous()
+        dtype, dev = x.dtype, x.device
+        assert dtype == torch.bfloat16
+        M, Cc = x.shape
+        assert k.stride(1) == 1 and v.stride(1) == 1 and k.stride(0) == v.stride(0)
+        kld = k.stride(0)
+        alpha = float(Cc ** -0.5)
+        Wst = weights.get_cat((Wv, Wq), dtype)                      # [2C, C]
+        vpre = torch.empty(M, Cc, dtype=dtype, device=dev)          # x Wv^T (the bias joins in the mix kernel)
+        q = torch.empty_like(vpre)
+        gemm_nt(dtype, M, 2 * Cc, Cc, x, Cc, Wst, Cc, vpre, Cc, C2=q, ldc2=Cc, c_split=Cc)
+        mean = torch.empty(B, Cc, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        ws = _scratch(1025 * B * 2 * Cc, dev)
+        K.check(K.lib.lavt_colstats_meanrstd(K.dt(dtype), K.ptr(q), K.ptr(mean), K.ptr(rstd), K.ptr(ws), ws.numel(), B, T, Cc, 1e-5, None, None, 0.0, K.stream()))
+        P = torch.empty(M, KV_LD, dtype=dtype, device=dev)
+        K.check(K.lib.lavt_pwam_words_fwd(K.ptr(q), Cc, K.ptr(k), kld, K.ptr(mean), K.ptr(rstd), K.ptr(maskbias), K.ptr(P), B, T, Cc, n_l, alpha, K.stream()))
+        st = torch.zeros(B * (KV_LD * KV_LD + KV_LD), dtype=torch.float32, device=dev)
+        PP, sumP = st[:B * KV_LD * KV_LD], st[B * KV_LD * KV_LD:]
+        gemm_tn(dtype, KV_LD, KV_LD, T, P, KV_LD, P, KV_LD, PP, KV_LD, batch=B, strideA=T * KV_LD, strideB=T * KV_LD, strideC=KV_LD * KV_LD, colsum=sumP, strideColsum=KV_LD)
+        VWc = torch.empty(B, Cc, KV_LD, dtype=dtype, device=dev)
+        VWw = torch.empty(B, KV_LD, Cc, dtype=dtype, device=dev)
+        lf = torch.empty(B * (2 * Cc + KV_LD + KV_LD * KV_LD), dtype=torch.float32, device=dev)
+        beta, rw, pbar, cov = lf[:B * Cc], lf[B * Cc:2 * B * Cc], lf[2 * B * Cc:2 * B * Cc + B * KV_LD], lf[2 * B * Cc + B * KV_LD:]
+        K.check(K.lib.lavt_pwam_lang_fwd(K.ptr(v), kld, K.ptr(weights.get(Wo, dtype, "lin")), K.ptr(PP), K.ptr(sumP), K.ptr(VWc), K.ptr(VWw), K.ptr(beta), K.ptr(rw),
+                                         K.ptr(pbar), K.ptr(cov), B, T, Cc, 1e-5, K.stream()))
+        mm = torch.empty_like(vpre)
+        K.check(K.lib.lavt_pwam_mix(0, K.ptr(P), K.ptr(VWc), K.ptr(beta), None, K.ptr(_f32(bv)), K.ptr(vpre), Cc, None, 0, K.ptr(mm), Cc, None, 0, B, T, Cc, K.stream()))
+        rpre = torch.empty_like(vpre)
+        r = torch.empty_like(vpre)
+        gemm_nt(dtype, M, Cc, Cc, mm, Cc, weights.get(Wm, dtype, "lin"), Cc, r, Cc, bias=_f32(bm), act=K.ACT_GELU, Cpre=rpre, ldcpre=Cc)
+        g1 = torch.empty_like(vpre)
+        gemm_nt(dtype, M, Cc, Cc, r, Cc, weights.get(W1, dtype, "lin"), Cc, g1, Cc, act=K.ACT_RELU)
+        g2 = torch.empty_like(vpre)
+        xg = torch.empty_like(vpre)
+        gemm_nt(dtype, M, Cc, Cc, g1, Cc, weights.get(W2, dtype, "lin"), Cc, xg, Cc, act=K.ACT_TANH, Cpre=g2, ldcpre=Cc, R=x, ldr=Cc, mul=r, ldmul=Cc)
+        ctx.save_for_backward(x, k, v, vpre, q, mean, rstd, P, VWc, VWw, beta, rw, pbar, cov, mm, rpre, r, g1, g2, Wv, bv, Wq, bq, Wo, bo, Wm, bm, W1, W2)
+        ctx.dims, ctx.kv_sinks, ctx.alpha = dims, kv_sinks, alpha
+        ctx.set_materialize_grads(False)          # an unused output arrives as None in backward (the last stage's gated x)
+        return r, xg
+
+    @staticmethod
+    def backward(ctx, dr_out, dxg):
+        (x, k, v, vpre, q, mean, rstd, P, VWc, VWw, beta, rw, pbar, cov, mm, rpre, r, g1, g2, Wv, bv, Wq, bq, Wo, bo, Wm, bm, W1, W2) = ctx.saved_tensors
+        B, T, n_l = ctx.dims
+        alpha = ctx.alpha
+        dtype, dev = x.dtype, x.device
+        M, Cc = x.shape
+        kld = k.stride(0)
+        gate_live = dxg is not None              # the last stage's gated x feeds nothing (reference lib/backbone.py:669-686): its gate gets no gradient
+        dxg = dxg.contiguous() if gate_live else None
+        dr_out = dr_out.contiguous() if dr_out is not None else None
+        W2c, W1c, Wmc, Woc = (weights.get(w, dtype, "lin") for w in (W2, W1, Wm, Wo))
+        Wst = weights.get_cat((Wv, Wq), dtype)
+        drpre = torch.empty_like(x)
+        if gate_live:
+            dg2 = torch.empty_like(x)
+            dr = torch.empty_like(x)
+            K.check(K.lib.lavt_gate_bwd(K.dt(dtype), K.ptr(dxg), K.ptr(g2), K.ptr(r), K.ptr(dr_out), K.ptr(dg2), K.ptr(dr), x.numel(), K.stream()))
+            dpre1 = torch.empty_like(x)
+            gemm_nt(dtype, M, Cc, Cc, dg2, Cc, W2c, Cc, dpre1, Cc, b_kmajor=True, dact_pre=g1, lddact=Cc, dact=K.ACT_RELU)
+            gemm_nt(dtype, M, Cc, Cc, dpre1, Cc, W1c, Cc, drpre, Cc, b_kmajor=True, dact_pre=rpre, lddact=Cc, dact=K.ACT_GELU, R=dr, ldr=Cc, res_first=True)
+        else:
+            if dr_out is None:
+                dr_out = torch.zeros_like(x)
+            K.check(K.lib.lavt_act_bwd(K.dt(dtype), K.ACT_GELU, K.ptr(dr_out), K.ptr(rpre), K.ptr(drpre), x.numel(), K.stream()))
+        dmm = torch.empty_like(x)
+        gemm_nt(dtype, M, Cc, Cc, drpre, Cc, Wmc, Cc, dmm, Cc, b_kmajor=True)
+        g = torch.empty(M, 2 * Cc, dtype=dtype, device=dev)                 # [d vpre | dq]: the A operand of the stacked data / weight gradient
+        dwh = torch.empty_like(x)
+        K.check(K.lib.lavt_pwam_mix(1, K.ptr(P), K.ptr(VWc), K.ptr(beta), None, K.ptr(_f32(bv)), K.ptr(vpre), Cc, K.ptr(dmm), Cc, K.ptr(g), 2 * Cc, K.ptr(dwh), Cc,
+                                    B, T, Cc, K.stream()))
+        # one zeroed side buffer for everything that is accumulated with atomics: H^T, s, Q, u, G, colsum(dS)
+        nz = B * (Cc * KV_LD + Cc + KV_LD * KV_LD + KV_LD + KV_LD * Cc + KV_LD)
+        z = torch.zeros(nz, dtype=torch.float32, device=dev)
+        o = 0
+        HT = z[o:o + B * Cc * KV_LD]; o += B * Cc * KV_LD
+        s = z[o:o + B * Cc]; o += B * Cc
+        Qf = z[o:o + B * KV_LD * KV_LD]; o += B * KV_LD * KV_LD
+        u = z[o:o + B * KV_LD]; o += B * KV_LD
+        G = z[o:o + B * KV_LD * Cc]; o += B * KV_LD * Cc
+        sdS = z[o:o + B * KV_LD]
+        gemm_tn(dtype, Cc, KV_LD, T, dwh, Cc, P, KV_LD, HT, KV_LD, batch=B, strideA=T * Cc, strideB=T * KV_LD, strideC=Cc * KV_LD, colsum=s, strideColsum=Cc)
+        dVW = torch.empty(B * KV_LD, Cc, dtype=dtype, device=dev)
+        K.check(K.lib.lavt_pwam_lang_bwd1(K.ptr(HT), K.ptr(s), K.ptr(VWc), K.ptr(rw), K.ptr(pbar), K.ptr(cov), K.ptr(dVW), K.ptr(Qf), K.ptr(u), B, T, Cc, K.stream()))
+        dS = torch.empty_like(P)
+        K.check(K.lib.lavt_pwam_words_bwd(K.ptr(dwh), Cc, K.ptr(VWw), K.ptr(Qf), K.ptr(u), K.ptr(pbar), K.ptr(P), K.ptr(dS), B, T, Cc, K.stream()))
+        gemm_tn(dtype, KV_LD, Cc, T, dS, KV_LD, q, Cc, G, Cc, batch=B, strideA=T * KV_LD, strideB=T * Cc, strideC=KV_LD * Cc, colsum=sdS, strideColsum=KV_LD)
+        if ctx.kv_sinks is not None:
+            dk, dv = ctx.kv_sinks                                            # column blocks of the shared key / value gradient matrix
+        else:
+            dk = torch.empty(B * KV_LD, Cc, dtype=dtype, device=dev)
+            dv = torch.empty_like(dk)
+        K2c = torch.empty(B, Cc, KV_LD, dtype=dtype, device=dev)
+        cc = torch.empty(2, B, Cc, dtype=torch.float32, device=dev)
+        K.check(K.lib.lavt_pwam_lang_bwd2(K.ptr(G), K.ptr(sdS), K.ptr(k), kld, K.ptr(mean), K.ptr(rstd), K.ptr(dk), dk.stride(0), K.ptr(K2c), K.ptr(cc[0]), K.ptr(cc[1]),
+                                          B, T, Cc, alpha, K.stream()))
+        K.check(K.lib.lavt_pwam_mix(2, K.ptr(dS), K.ptr(K2c), K.ptr(cc[0]), K.ptr(cc[1]), None, K.ptr(q), Cc, None, 0, g.data_ptr() + 2 * Cc, 2 * Cc, None, 0,
+                                    B, T, Cc, K.stream()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm_nt(dtype, M, Cc, 2 * Cc, g, 2 * Cc, Wst, Cc, dx, Cc, b_kmajor=True, R=dxg, ldr=Cc)
+        gemm_nt(dtype, B * KV_LD, Cc, Cc, dVW, Cc, Woc, Cc, dv, dv.stride(0), b_kmajor=True)          # dV = dVW Wo
+        # ---- weight gradients (joined into grouped launches under the step harness) ----
+        grads = {}
+
+        def wgrad(w, b, A, lda, a_off, Bm, ldb, n, kd, rows):
+            wbuf, wsink = sinks.buf(w, (n, kd))
+            bbuf, bsink = sinks.buf(b, (n,)) if b is not None else (None, True)
+            if wgrads.active() and wsink and bsink:
+                gemm_tn(dtype, n, kd, rows, A, lda, Bm, ldb, wbuf, kd, colsum=bbuf, a_off=a_off, defer=wgrads)
+                wgrads.notify(w)
+                if b is not None:
+                    wgrads.notify(b)
+                grads[id(w)] = None
+                if b is not None:
+                    grads[id(b)] = None
+            else:
+                gemm_tn(dtype, n, kd, rows, A, lda, Bm, ldb, wbuf, kd, colsum=bbuf, a_off=a_off)
+                grads[id(w)] = sinks.done(w, wbuf, wsink)
+                if b is not None:
+                    grads[id(b)] = sinks.done(b, bbuf, bsink)
+
+        grads[id(W1)] = grads[id(W2)] = None
+        if gate_live:
+            wgrad(W2, None, dg2, Cc, 0, g1, Cc, Cc, Cc, M)
+            wgrad(W1, None, dpre1, Cc, 0, r, Cc, Cc, Cc, M)
+        wgrad(Wm, bm, drpre, Cc, 0, mm, Cc, Cc, Cc, M)
+        wgrad(Wv, bv, g, 2 * Cc, 0, x, Cc, Cc, Cc, M)
+        wgrad(Wq, None, g, 2 * Cc, Cc, x, Cc, Cc, Cc, M)
+        wgrad(Wo, None, dVW, Cc, 0, v, kld, Cc, Cc, B * KV_LD)
+        for b0 in (bq, bo):                                                 # in front of an instance norm: exactly zero
+            zb, zs = sinks.buf(b0, tuple(b0.shape))
+            grads[id(b0)] = sinks.done(b0, zb, zs)
+        gp = [grads[id(p)] for p in (Wv, bv, Wq, bq, Wo, bo, Wm, bm, W1, W2)]
+        return (dx, dk, dv, None, None, None, *gp)
+
+
+def pwam_gate(x, k, v, maskbias, kv_sinks, B, T, n_l, fusion, res_gate):
+    """fusion: the PWAM module (parameter container), res_gate: nn.Sequential(Linear, ReLU, Linear, Tanh) -> (r, x + tanh(gate(r)) * r)"""
+    sila = fusion.image_lang_att
+    return _PwamGate.apply(x, k, v, maskbias, kv_sinks, (B, T, n_l), fusion.vis_project[0].weight, fusion.vis_project[0].bias, sila.f_query[0].weight,
+                           sila.f_query[0].bias, sila.W[0].weight, sila.W[0].bias, fusion.project_mm[0].weight, fusion.project_mm[0].bias,
+                           res_gate[0].weight, res_gate[2].weight)
+
+
+def pwam_fused_ok(x, G):
+    """the fused node covers the default configuration: bf16, one fusion head, channels a multiple of 32"""
+    return x.dtype == torch.bfloat16 and G == 1 and x.shape[1] % 32 == 0 and os.environ.get("LAVT_PWAM_FUSED", "1") != "0"
 
 
 @K.scoped

@@ -315,16 +315,22 @@ class MMBasicLayer(nn.Module):
         for blk in self.blocks:
             blk.H, blk.W = H, W
             x = blk(x)
-        x2 = x.reshape(B * L, C)
+        x2 = xin = x.reshape(B * L, C)
         lang = _LangCtx.get(l, l_mask, x.dtype)
         with scope("pwam"):
-            r = self.fusion.rows(x2, B, L, lang)
-            if self.version == "default":
-                g = ops.linear(ops.linear(r, self.res_gate[0].weight, None, act=ACT_RELU), self.res_gate[2].weight, None)
-                x2 = ops.gate(x2, g, r)                                   # x + tanh(g) * r
-            elif self.version == "no_gate":
-                x2 = x2 + r
-        feat = x2 if self.hs else (x.reshape(B * L, C) if self.lazy_pred else r)
+            sila = self.fusion.image_lang_att
+            if self.version == "default" and ops.pwam_fused_ok(x2, sila.num_heads):
+                # PWAM + gate as one autograd node on the fused kernels (csrc/pwam.hip): 10 launches forward instead of ~15, ~17 backward instead of ~35
+                k, v, kv_sinks = lang.kv(sila.f_key[0], sila.f_value[0])
+                r, x2 = ops.pwam_gate(x2, k, v, lang.maskbias, kv_sinks, B, L, lang.n_l, self.fusion, self.res_gate)
+            else:
+                r = self.fusion.rows(x2, B, L, lang)
+                if self.version == "default":
+                    g = ops.linear(ops.linear(r, self.res_gate[0].weight, None, act=ACT_RELU), self.res_gate[2].weight, None)
+                    x2 = ops.gate(x2, g, r)                               # x + tanh(g) * r
+                elif self.version == "no_gate":
+                    x2 = x2 + r
+        feat = x2 if self.hs else (xin if self.lazy_pred else r)
         xg = x2.view(B, L, C)
         if self.downsample is not None:
             return feat.view(B, L, C), H, W, self.downsample(xg, H, W), (H + 1) // 2, (W + 1) // 2

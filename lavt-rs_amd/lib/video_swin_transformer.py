@@ -265,12 +265,19 @@ class MMBasicLayer(nn.Module):
         L = D * H * W
         x2 = x.reshape(B * L, C)
         lang = _LangCtx.get(l, l_mask, x.dtype)
-        r = self.fusion.rows(x2, B, D, H, W, lang) if self.sep_t_pwam else self.fusion.rows(x2, B, L, lang)
-        xg = x2
-        if self.version == "default" and (not self.use_checkpoint or not self.is_last_layer):
+        gated = self.version == "default" and (not self.use_checkpoint or not self.is_last_layer)
+        fused = gated and not self.sep_t_pwam and ops.pwam_fused_ok(x2, self.fusion.image_lang_att.num_heads)
+        if fused:                                                     # PWAM + gate as one autograd node (csrc/pwam.hip)
+            sila = self.fusion.image_lang_att
+            k, v, kv_sinks = lang.kv(sila.f_key[0], sila.f_value[0])
+            r, xg = ops.pwam_gate(x2, k, v, lang.maskbias, kv_sinks, B, L, lang.n_l, self.fusion, self.res_gate)
+        else:
+            r = self.fusion.rows(x2, B, D, H, W, lang) if self.sep_t_pwam else self.fusion.rows(x2, B, L, lang)
+            xg = x2
+        if not fused and gated:
             g = ops.linear(ops.linear(r, self.res_gate[0].weight, None, act=ACT_RELU), self.res_gate[2].weight, None)
             xg = ops.gate(x2, g, r)                                   # x + tanh(g) * r
-        elif self.version == "no_gate":
+        elif not fused and self.version == "no_gate":
             xg = x2 + r
         feat = xg if self.hs else (x2 if self.lazy_pred else r)
         xg = xg.view(B, D, H, W, C)

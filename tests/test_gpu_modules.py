@@ -602,3 +602,73 @@ def test_fused_adamw_with_model_forward_outside_train_step():
             assert abs(a - b) < 3e-2, losses
         qk = ours.backbone.layers[1].blocks[0].attn.qkv.weight
         assert torch.equal(ops.weights.get(qk, torch.bfloat16), qk.detach().to(torch.bfloat16)), "stale bf16 weight copy after FusedAdamW.step()"
+
+
+@pytest.mark.parametrize("C,T,gate_live", [(64, 90, True), (128, 1000, True), (256, 77, False), (512, 130, True)])
+def test_pwam_gate_fused_node(C, T, gate_live):
+    """The fused PWAM + language-gate node (csrc/pwam.hip: instance norm of q folded into the keys, W projection collapsed onto the word
+    probabilities) against the fp32 CPU oracle of the reference (lib/backbone.py:1265-1278, 1329-1372, 604-611, 669), forward and every gradient;
+    the composed bf16 path (one kernel per reference op) is the yardstick: the fused node may not be further from the oracle than 1.5 x that + 1 %."""
+    import lavt_hip
+    from lavt_hip import ops
+    from lib.backbone import MMBasicLayer
+    from oracle import lavt_oracle as O
+    B, n_l = 2, 20
+    st = MMBasicLayer(dim=C, depth=0, num_heads=C // 32, window_size=7, drop_path=0.0, downsample=None, num_heads_fusion=1, fusion_drop=0.0, args=ARGS).eval()
+    fill_state_dict_(st)
+    sd = {k: v.clone() for k, v in st.state_dict().items()}
+    st.to(DEV)
+    x0, l0 = randn(11, B, T, C), randn(12, B, 768, n_l)
+    m = torch.zeros(B, n_l, 1)
+    m[0, :13] = 1
+    m[1, :7] = 1
+    wr, wx = randn(13, B, T, C), randn(14, B, T, C)
+
+    # oracle (fp32, CPU)
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
+    xo, lo = x0.clone().requires_grad_(True), l0.clone().requires_grad_(True)
+    r_ref = O.pwam(ps, "fusion", xo, lo, m, 1)
+    g_ref = torch.tanh(F.linear(F.relu(F.linear(r_ref, ps["res_gate.0.weight"])), ps["res_gate.2.weight"]))
+    xg_ref = xo + g_ref * r_ref
+    ((r_ref * wr).sum() + ((xg_ref * wx).sum() if gate_live else 0.0)).backward()
+    ref = {"r": r_ref.detach(), "xg": xg_ref.detach(), "dx": xo.grad, "dl": lo.grad}
+    ref.update({k: p.grad for k, p in ps.items() if p.grad is not None})
+
+    def run(fused):
+        os.environ["LAVT_PWAM_FUSED"] = "1" if fused else "0"
+        try:
+            lavt_hip.set_compute_dtype(torch.bfloat16)
+            st.zero_grad(set_to_none=True)
+            x = x0.to(DEV).to(torch.bfloat16).requires_grad_(True)
+            l = l0.to(DEV).requires_grad_(True)
+            r, H, W, xg, _, _ = st(x, T, 1, l, m.to(DEV))
+            assert ops.pwam_fused_ok(x.reshape(B * T, C), 1) == fused
+            loss = (r.float() * wr.to(DEV)).sum()
+            if gate_live:
+                loss = loss + (xg.float() * wx.to(DEV)).sum()
+            loss.backward()
+            out = {"r": r, "xg": xg, "dx": x.grad, "dl": l.grad}
+            out.update({k: p.grad for k, p in st.named_parameters() if p.grad is not None})
+            return {k: v.detach().float().cpu() for k, v in out.items()}
+        finally:
+            os.environ.pop("LAVT_PWAM_FUSED", None)
+            lavt_hip.set_compute_dtype(torch.float32)
+
+    comp, fus = run(False), run(True)
+    assert set(fus) >= set(k for k in comp), sorted(set(comp) - set(fus))
+    report = {}
+    for k, rv in ref.items():
+        if k not in comp:
+            continue
+        scale = float(rv.abs().max())
+        if scale < 1e-6:                         # biases in front of an instance norm: analytically zero
+            assert float(fus[k].abs().max()) <= 1e-3, k
+            continue
+        ec = float((comp[k] - rv).abs().max()) / scale
+        ef = float((fus[k] - rv).abs().max()) / scale
+        report[k] = (round(ec, 4), round(ef, 4))
+        assert ef <= 1.5 * ec + 1e-2, (k, ec, ef, report)
+    if not gate_live:
+        for k in ("res_gate.0.weight", "res_gate.2.weight"):
+            assert k not in fus or float(fus[k].abs().max()) == 0.0
+    assert len(report) >= 12, report
