@@ -212,68 +212,91 @@ struct MixArgs {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void pwam_mix_kernel(const MixArgs a) {
+    // A wave owns items (16-row tile, 64-channel group): every global load of an item is issued before the first use (the kernel is a stream of
+    // 16-byte loads and stores with 4 MFMAs in between; as a loop over channel pairs with the loads inside it ran as a chain of exposed latencies:
+    // 35 us per launch at 28 800 x 128 where the bytes take ~5).
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int b = blockIdx.y, C = a.C;
-    const int ntiles = (a.T + 31) >> 5;
+    const int ntiles = (a.T + 15) >> 4, ngrp = (C + 63) >> 6;
     const bf16* Wc = a.Wc + (int64_t)b * C * 32;
     const float* v0 = a.v0 + (int64_t)b * C;
     const float* v1 = MODE == 2 ? a.v1 + (int64_t)b * C : nullptr;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        int64_t row[2];
-        bool vr[2];
-        bf16x8 wd[2];
+    const bool odd = g & 1;
+    const int poff = odd ? 16 + 4 * (g - 1) : 4 * g;          // this lane's 16-byte piece of a 32-channel span (load_pair16 / store_pair16)
+    for (int item = blockIdx.x * 4 + wave; item < ntiles * ngrp; item += gridDim.x * 4) {
+        const int tile = item / ngrp, grp = item - tile * ngrp;
+        const int t = tile * 16 + c16;
+        const bool vr = t < a.T;
+        const int64_t row = (int64_t)b * a.T + (vr ? t : a.T - 1);
+        const int chg = 64 * grp;
+        const bool two = chg + 64 <= C;                        // C % 32 == 0: the last group may hold one 32-channel span only (wave-uniform)
+        const bf16x8 wd = ldg8(a.Wd + row * 32 + 8 * g);
+        bf16x8 wa[2][2];
+        uint4 xr[2], dr[2];
+        float4 va[2][2], vb[2][2], xb4[2][2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int t = tile * 32 + 16 * h + c16;
-            vr[h] = t < a.T;
-            row[h] = (int64_t)b * a.T + (vr[h] ? t : a.T - 1);
-            wd[h] = ldg8(a.Wd + row[h] * 32 + 8 * g);
-        }
-        for (int cp = 0; cp < (C >> 5); ++cp) {
-            const int ch0 = 32 * cp;
-            const bf16x8 wa0 = ldg8(Wc + (int64_t)(ch0 + c16) * 32 + 8 * g), wa1 = ldg8(Wc + (int64_t)(ch0 + 16 + c16) * 32 + 8 * g);
-            const float4 va0 = *reinterpret_cast<const float4*>(v0 + ch0 + 4 * g), va1 = *reinterpret_cast<const float4*>(v0 + ch0 + 16 + 4 * g);
-            const float c0a[4] = {va0.x, va0.y, va0.z, va0.w}, c0b[4] = {va1.x, va1.y, va1.z, va1.w};
-            float c1a[4] = {0.f, 0.f, 0.f, 0.f}, c1b[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int cp = 0; cp < 2; ++cp) {
+            const int ch0 = (cp == 1 && !two) ? chg : chg + 32 * cp;      // (a dead second span re-reads the first: no out-of-range access, result unused)
+            wa[cp][0] = ldg8(Wc + (int64_t)(ch0 + c16) * 32 + 8 * g);
+            wa[cp][1] = ldg8(Wc + (int64_t)(ch0 + 16 + c16) * 32 + 8 * g);
+            xr[cp] = *reinterpret_cast<const uint4*>(a.X + row * a.ldx + ch0 + poff);
+            if constexpr (MODE == 1) dr[cp] = *reinterpret_cast<const uint4*>(a.D + row * a.ldd + ch0 + poff);
+            va[cp][0] = *reinterpret_cast<const float4*>(v0 + ch0 + 4 * g);
+            va[cp][1] = *reinterpret_cast<const float4*>(v0 + ch0 + 16 + 4 * g);
             if constexpr (MODE == 2) {
-                const float4 q0 = *reinterpret_cast<const float4*>(v1 + ch0 + 4 * g), q1 = *reinterpret_cast<const float4*>(v1 + ch0 + 16 + 4 * g);
-                c1a[0] = q0.x; c1a[1] = q0.y; c1a[2] = q0.z; c1a[3] = q0.w; c1b[0] = q1.x; c1b[1] = q1.y; c1b[2] = q1.z; c1b[3] = q1.w;
+                vb[cp][0] = *reinterpret_cast<const float4*>(v1 + ch0 + 4 * g);
+                vb[cp][1] = *reinterpret_cast<const float4*>(v1 + ch0 + 16 + 4 * g);
+            } else if (a.xb) {
+                xb4[cp][0] = *reinterpret_cast<const float4*>(a.xb + ch0 + 4 * g);
+                xb4[cp][1] = *reinterpret_cast<const float4*>(a.xb + ch0 + 16 + 4 * g);
+            } else {
+                xb4[cp][0] = xb4[cp][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+        auto xchg = [&](uint4 L, uint2& p0, uint2& p1) {
+            const uint2 send = odd ? make_uint2(L.x, L.y) : make_uint2(L.z, L.w);
+            const uint2 got = make_uint2((unsigned)__shfl_xor((int)send.x, 16, 64), (unsigned)__shfl_xor((int)send.y, 16, 64));
+            p0 = odd ? got : make_uint2(L.x, L.y);
+            p1 = odd ? make_uint2(L.z, L.w) : got;
+        };
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa0, wd[h], z, 0, 0, 0);
-                const f32x4 e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa1, wd[h], z, 0, 0, 0);
-                uint2 xp0, xp1;
-                load_pair16(a.X + row[h] * a.ldx + ch0, g, xp0, xp1);
-                float x0[4], x1[4], r0[4], r1[4];
-                unpack4(xp0, x0); unpack4(xp1, x1);
-                if (MODE != 2 && a.xb) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(a.xb + ch0 + 4 * g), b1 = *reinterpret_cast<const float4*>(a.xb + ch0 + 16 + 4 * g);
-                    x0[0] += b0.x; x0[1] += b0.y; x0[2] += b0.z; x0[3] += b0.w; x1[0] += b1.x; x1[1] += b1.y; x1[2] += b1.z; x1[3] += b1.w;
+        for (int cp = 0; cp < 2; ++cp) {
+            const int ch0 = chg + 32 * cp;
+            const bool live = vr && (cp == 0 || two);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cp][0], wd, z, 0, 0, 0);
+            const f32x4 e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cp][1], wd, z, 0, 0, 0);
+            uint2 xp0, xp1;
+            xchg(xr[cp], xp0, xp1);
+            float x0[4], x1[4], r0[4], r1[4];
+            unpack4(xp0, x0); unpack4(xp1, x1);
+            const float c0a[4] = {va[cp][0].x, va[cp][0].y, va[cp][0].z, va[cp][0].w}, c0b[4] = {va[cp][1].x, va[cp][1].y, va[cp][1].z, va[cp][1].w};
+            if constexpr (MODE != 2) {
+                x0[0] += xb4[cp][0].x; x0[1] += xb4[cp][0].y; x0[2] += xb4[cp][0].z; x0[3] += xb4[cp][0].w;
+                x1[0] += xb4[cp][1].x; x1[1] += xb4[cp][1].y; x1[2] += xb4[cp][1].z; x1[3] += xb4[cp][1].w;
+            }
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { r0[r] = gelu_f_fast(x0[r]) * (e0[r] + c0a[r]); r1[r] = gelu_f_fast(x1[r]) * (e1[r] + c0b[r]); }
+                store_pair16(a.out0 + row * a.ld0 + ch0, g, pack4(r0), pack4(r1), live);
+            } else if constexpr (MODE == 1) {
+                uint2 dp0, dp1;
+                xchg(dr[cp], dp0, dp1);
+                float d0[4], d1[4], w0[4], w1[4];
+                unpack4(dp0, d0); unpack4(dp1, d1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float wh0 = e0[r] + c0a[r], wh1 = e1[r] + c0b[r];
+                    r0[r] = d0[r] * wh0 * gelu_grad_f_fast(x0[r]); r1[r] = d1[r] * wh1 * gelu_grad_f_fast(x1[r]);
+                    w0[r] = d0[r] * gelu_f_fast(x0[r]); w1[r] = d1[r] * gelu_f_fast(x1[r]);
                 }
-                if constexpr (MODE == 0) {
+                store_pair16(a.out0 + row * a.ld0 + ch0, g, pack4(r0), pack4(r1), live);
+                store_pair16(a.out1 + row * a.ld1 + ch0, g, pack4(w0), pack4(w1), live);
+            } else {
+                const float c1a[4] = {vb[cp][0].x, vb[cp][0].y, vb[cp][0].z, vb[cp][0].w}, c1b[4] = {vb[cp][1].x, vb[cp][1].y, vb[cp][1].z, vb[cp][1].w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { r0[r] = gelu_f_fast(x0[r]) * (e0[r] + c0a[r]); r1[r] = gelu_f_fast(x1[r]) * (e1[r] + c0b[r]); }
-                    store_pair16(a.out0 + row[h] * a.ld0 + ch0, g, pack4(r0), pack4(r1), vr[h]);
-                } else if constexpr (MODE == 1) {
-                    uint2 dp0, dp1;
-                    load_pair16(a.D + row[h] * a.ldd + ch0, g, dp0, dp1);
-                    float d0[4], d1[4], w0[4], w1[4];
-                    unpack4(dp0, d0); unpack4(dp1, d1);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float wh0 = e0[r] + c0a[r], wh1 = e1[r] + c0b[r];
-                        r0[r] = d0[r] * wh0 * gelu_grad_f_fast(x0[r]); r1[r] = d1[r] * wh1 * gelu_grad_f_fast(x1[r]);
-                        w0[r] = d0[r] * gelu_f_fast(x0[r]); w1[r] = d1[r] * gelu_f_fast(x1[r]);
-                    }
-                    store_pair16(a.out0 + row[h] * a.ld0 + ch0, g, pack4(r0), pack4(r1), vr[h]);
-                    store_pair16(a.out1 + row[h] * a.ld1 + ch0, g, pack4(w0), pack4(w1), vr[h]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { r0[r] = e0[r] + c0a[r] - x0[r] * c1a[r]; r1[r] = e1[r] + c0b[r] - x1[r] * c1b[r]; }
-                    store_pair16(a.out0 + row[h] * a.ld0 + ch0, g, pack4(r0), pack4(r1), vr[h]);
-                }
+                for (int r = 0; r < 4; ++r) { r0[r] = e0[r] + c0a[r] - x0[r] * c1a[r]; r1[r] = e1[r] + c0b[r] - x1[r] * c1b[r]; }
+                store_pair16(a.out0 + row * a.ld0 + ch0, g, pack4(r0), pack4(r1), live);
             }
         }
     }
@@ -471,7 +494,8 @@ extern "C" int lavt_pwam_mix(int mode, const void* Wd, const void* Wc, const flo
     MixArgs a{};
     a.Wd = (const bf16*)Wd; a.Wc = (const bf16*)Wc; a.v0 = v0; a.v1 = v1; a.xb = xbias; a.X = (const bf16*)X; a.ldx = ldx; a.D = (const bf16*)D; a.ldd = ldd;
     a.out0 = (bf16*)out0; a.ld0 = ld0; a.out1 = (bf16*)out1; a.ld1 = ld1; a.T = T; a.C = C;
-    const dim3 grid(rows_grid((T + 31) / 32, B), B);
+    const long items = (long)((T + 15) / 16) * ((C + 63) / 64);
+    const dim3 grid((unsigned)(items / 4 + 1 > 8192 ? 8192 : items / 4 + 1), B);
     if (mode == 0) hipLaunchKernelGGL(pwam_mix_kernel<0>, grid, dim3(256), 0, ST, a);
     else if (mode == 1) hipLaunchKernelGGL(pwam_mix_kernel<1>, grid, dim3(256), 0, ST, a);
     else hipLaunchKernelGGL(pwam_mix_kernel<2>, grid, dim3(256), 0, ST, a);

@@ -1269,6 +1269,11 @@ def pwam_attention(q, k, v, maskbias, B, T, n_l, G, sinks_kv=None):
     return _PwamAttn.apply(q, k, v, maskbias, B, T, n_l, G, sinks_kv)
 
 
+def _note(shape, flops=0.0):
+    if K.prof.enabled:
+        K.prof.note = {"flops": flops, "shape": shape}
+
+
 @K.scoped
 class _PwamGate(torch.autograd.Function):
     """PWAM + language gate as ONE autograd node on the fused bf16 kernels (csrc/pwam.hip; reference lib/backbone.py:1265-1278, 1329-1372, 604-611, 669):
@@ -1299,8 +1304,10 @@ class _PwamGate(torch.autograd.Function):
         mean = torch.empty(B, Cc, dtype=torch.float32, device=dev)
         rstd = torch.empty_like(mean)
         ws = _scratch(1025 * B * 2 * Cc, dev)
+        _note(f"in-stats {M}x{Cc}")
         K.check(K.lib.lavt_colstats_meanrstd(K.dt(dtype), K.ptr(q), K.ptr(mean), K.ptr(rstd), K.ptr(ws), ws.numel(), B, T, Cc, 1e-5, None, None, 0.0, K.stream()))
         P = torch.empty(M, KV_LD, dtype=dtype, device=dev)
+        _note(f"words {M}x{Cc}", 2.0 * M * Cc * KV_LD)
         K.check(K.lib.lavt_pwam_words_fwd(K.ptr(q), Cc, K.ptr(k), kld, K.ptr(mean), K.ptr(rstd), K.ptr(maskbias), K.ptr(P), B, T, Cc, n_l, alpha, K.stream()))
         st = torch.zeros(B * (KV_LD * KV_LD + KV_LD), dtype=torch.float32, device=dev)
         PP, sumP = st[:B * KV_LD * KV_LD], st[B * KV_LD * KV_LD:]
@@ -1309,9 +1316,11 @@ class _PwamGate(torch.autograd.Function):
         VWw = torch.empty(B, KV_LD, Cc, dtype=dtype, device=dev)
         lf = torch.empty(B * (2 * Cc + KV_LD + KV_LD * KV_LD), dtype=torch.float32, device=dev)
         beta, rw, pbar, cov = lf[:B * Cc], lf[B * Cc:2 * B * Cc], lf[2 * B * Cc:2 * B * Cc + B * KV_LD], lf[2 * B * Cc + B * KV_LD:]
+        _note(f"lang {B}x{Cc}")
         K.check(K.lib.lavt_pwam_lang_fwd(K.ptr(v), kld, K.ptr(weights.get(Wo, dtype, "lin")), K.ptr(PP), K.ptr(sumP), K.ptr(VWc), K.ptr(VWw), K.ptr(beta), K.ptr(rw),
                                          K.ptr(pbar), K.ptr(cov), B, T, Cc, 1e-5, K.stream()))
         mm = torch.empty_like(vpre)
+        _note(f"mix0 {M}x{Cc}", 2.0 * M * Cc * KV_LD)
         K.check(K.lib.lavt_pwam_mix(0, K.ptr(P), K.ptr(VWc), K.ptr(beta), None, K.ptr(_f32(bv)), K.ptr(vpre), Cc, None, 0, K.ptr(mm), Cc, None, 0, B, T, Cc, K.stream()))
         rpre = torch.empty_like(vpre)
         r = torch.empty_like(vpre)
@@ -1345,8 +1354,15 @@ class _PwamGate(torch.autograd.Function):
             dr = torch.empty_like(x)
             K.check(K.lib.lavt_gate_bwd(K.dt(dtype), K.ptr(dxg), K.ptr(g2), K.ptr(r), K.ptr(dr_out), K.ptr(dg2), K.ptr(dr), x.numel(), K.stream()))
             dpre1 = torch.empty_like(x)
-            gemm_nt(dtype, M, Cc, Cc, dg2, Cc, W2c, Cc, dpre1, Cc, b_kmajor=True, dact_pre=g1, lddact=Cc, dact=K.ACT_RELU)
-            gemm_nt(dtype, M, Cc, Cc, dpre1, Cc, W1c, Cc, drpre, Cc, b_kmajor=True, dact_pre=rpre, lddact=Cc, dact=K.ACT_GELU, R=dr, ldr=Cc, res_first=True)
+            if Cc % 64 == 0:                      # activation gradients in the data-gradient GEMMs' epilogues
+                gemm_nt(dtype, M, Cc, Cc, dg2, Cc, W2c, Cc, dpre1, Cc, b_kmajor=True, dact_pre=g1, lddact=Cc, dact=K.ACT_RELU)
+                gemm_nt(dtype, M, Cc, Cc, dpre1, Cc, W1c, Cc, drpre, Cc, b_kmajor=True, dact_pre=rpre, lddact=Cc, dact=K.ACT_GELU, R=dr, ldr=Cc, res_first=True)
+            else:                                 # (Swin-T's 96-channel stage: the fused-epilogue kernel needs K % 64 == 0)
+                tmp = torch.empty_like(x)
+                gemm_nt(dtype, M, Cc, Cc, dg2, Cc, W2c, Cc, tmp, Cc, b_kmajor=True)
+                K.check(K.lib.lavt_act_bwd(K.dt(dtype), K.ACT_RELU, K.ptr(tmp), K.ptr(g1), K.ptr(dpre1), x.numel(), K.stream()))
+                gemm_nt(dtype, M, Cc, Cc, dpre1, Cc, W1c, Cc, tmp, Cc, b_kmajor=True, R=dr, ldr=Cc)
+                K.check(K.lib.lavt_act_bwd(K.dt(dtype), K.ACT_GELU, K.ptr(tmp), K.ptr(rpre), K.ptr(drpre), x.numel(), K.stream()))
         else:
             if dr_out is None:
                 dr_out = torch.zeros_like(x)
@@ -1355,6 +1371,7 @@ class _PwamGate(torch.autograd.Function):
         gemm_nt(dtype, M, Cc, Cc, drpre, Cc, Wmc, Cc, dmm, Cc, b_kmajor=True)
         g = torch.empty(M, 2 * Cc, dtype=dtype, device=dev)                 # [d vpre | dq]: the A operand of the stacked data / weight gradient
         dwh = torch.empty_like(x)
+        _note(f"mix1 {M}x{Cc}", 2.0 * M * Cc * KV_LD)
         K.check(K.lib.lavt_pwam_mix(1, K.ptr(P), K.ptr(VWc), K.ptr(beta), None, K.ptr(_f32(bv)), K.ptr(vpre), Cc, K.ptr(dmm), Cc, K.ptr(g), 2 * Cc, K.ptr(dwh), Cc,
                                     B, T, Cc, K.stream()))
         # one zeroed side buffer for everything that is accumulated with atomics: H^T, s, Q, u, G, colsum(dS)
@@ -1369,8 +1386,10 @@ class _PwamGate(torch.autograd.Function):
         sdS = z[o:o + B * KV_LD]
         gemm_tn(dtype, Cc, KV_LD, T, dwh, Cc, P, KV_LD, HT, KV_LD, batch=B, strideA=T * Cc, strideB=T * KV_LD, strideC=Cc * KV_LD, colsum=s, strideColsum=Cc)
         dVW = torch.empty(B * KV_LD, Cc, dtype=dtype, device=dev)
+        _note(f"lang {B}x{Cc}")
         K.check(K.lib.lavt_pwam_lang_bwd1(K.ptr(HT), K.ptr(s), K.ptr(VWc), K.ptr(rw), K.ptr(pbar), K.ptr(cov), K.ptr(dVW), K.ptr(Qf), K.ptr(u), B, T, Cc, K.stream()))
         dS = torch.empty_like(P)
+        _note(f"words {M}x{Cc}", 2.0 * M * (Cc + KV_LD) * KV_LD)
         K.check(K.lib.lavt_pwam_words_bwd(K.ptr(dwh), Cc, K.ptr(VWw), K.ptr(Qf), K.ptr(u), K.ptr(pbar), K.ptr(P), K.ptr(dS), B, T, Cc, K.stream()))
         gemm_tn(dtype, KV_LD, Cc, T, dS, KV_LD, q, Cc, G, Cc, batch=B, strideA=T * KV_LD, strideB=T * Cc, strideC=KV_LD * Cc, colsum=sdS, strideColsum=KV_LD)
         if ctx.kv_sinks is not None:
@@ -1380,8 +1399,10 @@ class _PwamGate(torch.autograd.Function):
             dv = torch.empty_like(dk)
         K2c = torch.empty(B, Cc, KV_LD, dtype=dtype, device=dev)
         cc = torch.empty(2, B, Cc, dtype=torch.float32, device=dev)
+        _note(f"lang {B}x{Cc}")
         K.check(K.lib.lavt_pwam_lang_bwd2(K.ptr(G), K.ptr(sdS), K.ptr(k), kld, K.ptr(mean), K.ptr(rstd), K.ptr(dk), dk.stride(0), K.ptr(K2c), K.ptr(cc[0]), K.ptr(cc[1]),
                                           B, T, Cc, alpha, K.stream()))
+        _note(f"mix2 {M}x{Cc}", 2.0 * M * Cc * KV_LD)
         K.check(K.lib.lavt_pwam_mix(2, K.ptr(dS), K.ptr(K2c), K.ptr(cc[0]), K.ptr(cc[1]), None, K.ptr(q), Cc, None, 0, g.data_ptr() + 2 * Cc, 2 * Cc, None, 0,
                                     B, T, Cc, K.stream()))
         dx = None

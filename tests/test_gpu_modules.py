@@ -604,7 +604,7 @@ def test_fused_adamw_with_model_forward_outside_train_step():
         assert torch.equal(ops.weights.get(qk, torch.bfloat16), qk.detach().to(torch.bfloat16)), "stale bf16 weight copy after FusedAdamW.step()"
 
 
-@pytest.mark.parametrize("C,T,gate_live", [(64, 90, True), (128, 1000, True), (256, 77, False), (512, 130, True)])
+@pytest.mark.parametrize("C,T,gate_live", [(64, 90, True), (96, 200, True), (128, 1000, True), (256, 77, False), (512, 130, True)])
 def test_pwam_gate_fused_node(C, T, gate_live):
     """The fused PWAM + language-gate node (csrc/pwam.hip: instance norm of q folded into the keys, W projection collapsed onto the word
     probabilities) against the fp32 CPU oracle of the reference (lib/backbone.py:1265-1278, 1329-1372, 604-611, 669), forward and every gradient;
@@ -660,15 +660,16 @@ def test_pwam_gate_fused_node(C, T, gate_live):
     for k, rv in ref.items():
         if k not in comp:
             continue
-        scale = float(rv.abs().max())
-        if scale < 1e-6:                         # biases in front of an instance norm: analytically zero
+        scale = float(rv.norm())
+        if float(rv.abs().max()) < 1e-6:         # biases in front of an instance norm: analytically zero
             assert float(fus[k].abs().max()) <= 1e-3, k
             continue
-        ec = float((comp[k] - rv).abs().max()) / scale
-        ef = float((fus[k] - rv).abs().max()) / scale
+        ec = float((comp[k] - rv).norm()) / scale          # relative l2 error (a maximum over ~10^4 bf16-noisy values is a coin toss)
+        ef = float((fus[k] - rv).norm()) / scale
         report[k] = (round(ec, 4), round(ef, 4))
         assert ef <= 1.5 * ec + 1e-2, (k, ec, ef, report)
     if not gate_live:
         for k in ("res_gate.0.weight", "res_gate.2.weight"):
             assert k not in fus or float(fus[k].abs().max()) == 0.0
     assert len(report) >= 12, report
+    print("\n[fused PWAM node, relative l2 error vs the fp32 oracle: (composed bf16, fused bf16)]", report)
