@@ -80,16 +80,39 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
 
     // ---- prologue: the word matrix and the per-word constants of this sample ----
     const int nch = C >> 3;
-    for (int e = tid; e < 32 * nch; e += 256) {
-        const int j = e / nch, cc = e - j * nch;
-        float f[8];
-        chunk_to_f<bf16>(*reinterpret_cast<const uint4*>(a.Wsrc + ((int64_t)b * 32 + j) * a.ldw + cc * 8), f);
-        if constexpr (!BWD) {
-            const float4 r0 = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + cc * 8), r1 = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + cc * 8 + 4);
-            const float s = a.alpha * LOG2E;
-            f[0] *= r0.x * s; f[1] *= r0.y * s; f[2] *= r0.z * s; f[3] *= r0.w * s; f[4] *= r1.x * s; f[5] *= r1.y * s; f[6] *= r1.z * s; f[7] *= r1.w * s;
+    // (four chunks per thread per pass, every load issued before the first use: as a one-chunk loop the 32 x 1024 matrix of the last stage was a
+    // chain of 16 exposed round trips per thread -- 22 us for a launch whose rows take 2)
+    for (int e0 = tid; e0 < 32 * nch; e0 += 1024) {
+        uint4 raw[4];
+        float4 r0[4], r1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            if (e < 32 * nch) {
+                const int j = e / nch, cc = e - j * nch;
+                raw[u] = *reinterpret_cast<const uint4*>(a.Wsrc + ((int64_t)b * 32 + j) * a.ldw + cc * 8);
+                if constexpr (!BWD) {
+                    r0[u] = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + cc * 8);
+                    r1[u] = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + cc * 8 + 4);
+                }
+            }
         }
-        *reinterpret_cast<uint4*>(Wm + j * LDW + cc * 8) = f_to_chunk<bf16>(f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            if (e < 32 * nch) {
+                const int j = e / nch, cc = e - j * nch;
+                if constexpr (!BWD) {
+                    float f[8];
+                    chunk_to_f<bf16>(raw[u], f);
+                    const float s = a.alpha * LOG2E;
+                    f[0] *= r0[u].x * s; f[1] *= r0[u].y * s; f[2] *= r0[u].z * s; f[3] *= r0[u].w * s;
+                    f[4] *= r1[u].x * s; f[5] *= r1[u].y * s; f[6] *= r1[u].z * s; f[7] *= r1[u].w * s;
+                    raw[u] = f_to_chunk<bf16>(f);
+                }
+                *reinterpret_cast<uint4*>(Wm + j * LDW + cc * 8) = raw[u];
+            }
+        }
     }
     if constexpr (BWD) {
         for (int e = tid; e < 1024; e += 256) Qn[(e >> 5) * 40 + (e & 31)] = (bf16)(-a.Qf[(int64_t)b * 1024 + e]);
@@ -99,12 +122,12 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
         const int j = tid >> 3, part = tid & 7;
         float s = 0.f;
         if constexpr (!BWD) {
+#pragma unroll 4
             for (int cc = part; cc < nch; cc += 8) {
                 float f[8];
                 chunk_to_f<bf16>(*reinterpret_cast<const uint4*>(Wm + j * LDW + cc * 8), f);
-                const float* mu = a.mean + (int64_t)b * C + cc * 8;
-#pragma unroll
-                for (int x = 0; x < 8; ++x) s += f[x] * mu[x];
+                const float4 m0 = *reinterpret_cast<const float4*>(a.mean + (int64_t)b * C + cc * 8), m1 = *reinterpret_cast<const float4*>(a.mean + (int64_t)b * C + cc * 8 + 4);
+                s += f[0] * m0.x + f[1] * m0.y + f[2] * m0.z + f[3] * m0.w + f[4] * m1.x + f[5] * m1.y + f[6] * m1.z + f[7] * m1.w;
             }
         } else {
             for (int k = part; k < 32; k += 8) s += a.pbar[b * 32 + k] * (-(float)Qn[k * 40 + j]);       // Pbar Q with the bf16 Q the MFMA sees
@@ -330,7 +353,19 @@ __global__ __launch_bounds__(256) void pwam_lang_fwd_kernel(const bf16* __restri
     const bf16* wp = Wo + (int64_t)(vc ? ch : C - 1) * C + 8 * g;
     const bf16* vp0 = V + ((int64_t)b * 32 + c16) * ldv + 8 * g;
     const bf16* vp1 = vp0 + 16 * ldv;
-    for (int ks = 0; ks < (C >> 5); ++ks) {
+    const int ksteps = C >> 5;
+    int ks = 0;
+    for (; ks + 4 <= ksteps; ks += 4) {          // four k-steps of loads in flight (one per step was a chain of C / 32 exposed round trips)
+        bf16x8 wf[4], a0[4], a1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { wf[u] = ldg8(wp + 32 * (ks + u)); a0[u] = ldg8(vp0 + 32 * (ks + u)); a1[u] = ldg8(vp1 + 32 * (ks + u)); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[u], wf[u], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u], wf[u], acc[1], 0, 0, 0);
+        }
+    }
+    for (; ks < ksteps; ++ks) {
         const bf16x8 wf = ldg8(wp + 32 * ks);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(vp0 + 32 * ks), wf, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(vp1 + 32 * ks), wf, acc[1], 0, 0, 0);
@@ -365,49 +400,50 @@ __global__ __launch_bounds__(256) void pwam_lang_fwd_kernel(const bf16* __restri
 __global__ __launch_bounds__(256) void pwam_lang_bwd1_kernel(const float* __restrict__ HT, const float* __restrict__ s, const bf16* __restrict__ VWc,
                                                              const float* __restrict__ rw, const float* __restrict__ pbar, const float* __restrict__ cov_in,
                                                              bf16* __restrict__ dVW, float* __restrict__ Qf, float* __restrict__ u, int T, int C) {
-    __shared__ float vw[64][33];
-    __shared__ float h[64][33];
+    // grid (C / 16, B): 16 channels per workgroup, thread (channel tid / 16, word pair tid % 16).  (64 channels per workgroup with 8 words per
+    // thread ran 13 us at every size: ~1 300 dependent LDS operations per thread.)
+    __shared__ float vw[16][33];
+    __shared__ float h[16][33];
     __shared__ float cov[32][33];
     __shared__ float pb[32];
-    __shared__ float av[64], bv[64];
-    const int tid = threadIdx.x, b = blockIdx.y, c0 = blockIdx.x * 64;
+    __shared__ float av[16], bv[16];
+    const int tid = threadIdx.x, b = blockIdx.y, c0 = blockIdx.x * 16;
     const float Tf = (float)T, invT = 1.0f / Tf;
     if (tid < 32) pb[tid] = pbar[b * 32 + tid];
+#pragma unroll
     for (int e = tid; e < 1024; e += 256) cov[e >> 5][e & 31] = cov_in[(int64_t)b * 1024 + e];
-    for (int e = tid; e < 64 * 32; e += 256) {
+#pragma unroll
+    for (int e = tid; e < 16 * 32; e += 256) {
         const int c = e >> 5, j = e & 31;
-        const bool ok = c0 + c < C;
-        vw[c][j] = ok ? (float)VWc[((int64_t)b * C + c0 + c) * 32 + j] : 0.f;
-        h[c][j] = ok ? HT[((int64_t)b * C + c0 + c) * 32 + j] : 0.f;
+        vw[c][j] = (float)VWc[((int64_t)b * C + c0 + c) * 32 + j];
+        h[c][j] = HT[((int64_t)b * C + c0 + c) * 32 + j];
     }
     __syncthreads();
-    const int c = tid >> 2, part = tid & 3;
-    const bool ok = c0 + c < C;
-    const float sc = ok ? s[(int64_t)b * C + c0 + c] : 0.f;
-    float bs = 0.f;
-    for (int j = part * 8; j < part * 8 + 8; ++j) bs += vw[c][j] * (h[c][j] - pb[j] * sc);
-    bs += __shfl_xor(bs, 1, 64); bs += __shfl_xor(bs, 2, 64);
+    const int c = tid >> 4, j0 = 2 * (tid & 15);
+    const float sc = s[(int64_t)b * C + c0 + c];
+    float bs = vw[c][j0] * (h[c][j0] - pb[j0] * sc) + vw[c][j0 + 1] * (h[c][j0 + 1] - pb[j0 + 1] * sc);
+    bs += __shfl_xor(bs, 1, 64); bs += __shfl_xor(bs, 2, 64); bs += __shfl_xor(bs, 4, 64); bs += __shfl_xor(bs, 8, 64);
     const float bc = bs * invT, ac = sc * invT;
-    if (part == 0) { av[c] = ac; bv[c] = bc; }
-    const float rs = ok ? rw[(int64_t)b * C + c0 + c] : 0.f;
-    for (int j = part * 8; j < part * 8 + 8; ++j) {
-        float t = 0.f;
+    if ((tid & 15) == 0) { av[c] = ac; bv[c] = bc; }
+    const float rs = rw[(int64_t)b * C + c0 + c];
+    float t0 = 0.f, t1 = 0.f;
 #pragma unroll 8
-        for (int k = 0; k < 32; ++k) t += cov[j][k] * vw[c][k];
-        const float d = rs * (h[c][j] - Tf * pb[j] * ac - Tf * bc * t);
-        if (ok) dVW[((int64_t)b * 32 + j) * C + c0 + c] = (bf16)d;
-    }
+    for (int k = 0; k < 32; ++k) { const float v = vw[c][k]; t0 += cov[j0][k] * v; t1 += cov[j0 + 1][k] * v; }
+    dVW[((int64_t)b * 32 + j0) * C + c0 + c] = (bf16)(rs * (h[c][j0] - Tf * pb[j0] * ac - Tf * bc * t0));
+    dVW[((int64_t)b * 32 + j0 + 1) * C + c0 + c] = (bf16)(rs * (h[c][j0 + 1] - Tf * pb[j0 + 1] * ac - Tf * bc * t1));
     __syncthreads();
+#pragma unroll
     for (int e = tid; e < 1024; e += 256) {
         const int k = e >> 5, j = e & 31;
         float q = 0.f;
-#pragma unroll 8
-        for (int cc = 0; cc < 64; ++cc) q += vw[cc][k] * bv[cc] * vw[cc][j];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) q += vw[cc][k] * bv[cc] * vw[cc][j];
         atomicAdd(Qf + (int64_t)b * 1024 + e, q);
     }
     if (tid < 32) {
         float q = 0.f;
-        for (int cc = 0; cc < 64; ++cc) q += vw[cc][tid] * av[cc];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) q += vw[cc][tid] * av[cc];
         atomicAdd(u + b * 32 + tid, q);
     }
 }
@@ -514,7 +550,7 @@ extern "C" int lavt_pwam_lang_fwd(const void* V, int64_t ldv, const void* Wo, co
 extern "C" int lavt_pwam_lang_bwd1(const float* HT, const float* s, const void* VWc, const float* rw, const float* pbar, const float* cov, void* dVW, float* Qf, float* u,
                                    int B, int T, int C, void* stream) {
     LAVT_CHECK_ARG(HT && s && VWc && rw && pbar && cov && dVW && Qf && u && B > 0 && T > 0 && C >= 32, "lavt_pwam_lang_bwd1: bad arguments");
-    hipLaunchKernelGGL(pwam_lang_bwd1_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, ST, HT, s, (const bf16*)VWc, rw, pbar, cov, (bf16*)dVW, Qf, u, T, C);
+    hipLaunchKernelGGL(pwam_lang_bwd1_kernel, dim3(C / 16, B), dim3(256), 0, ST, HT, s, (const bf16*)VWc, rw, pbar, cov, (bf16*)dVW, Qf, u, T, C);
     LAVT_CHECK_LAUNCH("lavt_pwam_lang_bwd1");
     return LAVT_OK;
 }
