@@ -305,6 +305,20 @@ int lavt_gate_fwd(int dtype, const void* x, const void* gpre, const void* r, voi
 int lavt_gate_bwd(int dtype, const void* dxo, const void* gpre, const void* r, const void* dr_add, void* dgpre, void* dr, int64_t n, void* stream); /* dr = dxo * tanh(gpre) (+ dr_add) */
 
 /* ---------------------------------------------------------------------------------------------
+ * One-kernel W-MSA / SW-MSA forward (ABI v4, bf16): norm1 + pad / roll / window_partition + qkv + relative-position-bias attention
+ * (SwinTransformerBlock.forward lib/backbone.py:201-217, WindowAttention.forward :113-140).  One workgroup per (window, head): the window's
+ * token rows (row map, -1 = padded token) and the head's 96 weight rows stream through an LDS-DMA ring, LayerNorm is applied algebraically
+ * (raw rows x gamma-folded weights, row statistics from the resident tiles, epilogue rstd (acc - mu wsum) + biasp; padded tokens get the plain
+ * bias: the reference pads after norm1), q / k / v stay in LDS for the attention core.  Side outputs for backward: qkv [nwin*N][3C], the
+ * LayerNorm output xn [tokens][C] and its row statistics.  Needs C = 32 * heads, C % 64 == 0, ws * ws <= 160.
+ *   lavt_ln_fold: Wg[n][k] = bf16(gamma_k W[n][k]), wsum[n] = sum_k Wg[n][k], biasp[n] = bias_n + sum_k beta_k W[n][k]   (per weight update)
+ * ------------------------------------------------------------------------------------------- */
+int lavt_ln_fold(const float* W, const float* gamma, const float* beta, const float* bias, void* Wg, float* wsum, float* biasp, int N, int K, void* stream);
+int lavt_wmsa_fwd(const void* x, const int32_t* wmap, const void* Wg, const float* wsum, const float* biasp, const float* bias, const float* gamma,
+                  const float* beta, const float* table, const int8_t* region, int nw_img, void* out, float* lse, void* qkv, void* xn, float* mean,
+                  float* rstd, const void* zeros, int ws, int nwin, int N, int heads, int C, float eps, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused PWAM (ABI v4, bf16).  Replaces, with the GEMMs above, PWAM.forward (lib/backbone.py:1265-1278),
  * SpatialImageLanguageAttention.forward (:1329-1372) and the language gate (:604-611, :669) and their autograd backward.
  * The instance norm of the query folds into the keys and the W projection collapses onto the <= 32 word probabilities

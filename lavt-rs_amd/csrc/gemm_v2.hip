@@ -1055,7 +1055,20 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     TnGroup g;
     bool maps = false;
     int tiles = 0;
-    constexpr int TB = 64;          // (128x128 tiles, 8 or 4 waves, measured level or slower on the stage-2 block: 12.44 / 12.94 vs 12.46 ms per step)
+    // Tile configuration of the grouped launch: LAVT_TNG_CFG = "tile,waves,stages" (64,4,2 = the round-1/2 form).
+    static int cfg_tile = 64, cfg_waves = 4, cfg_stages = 2;
+    static bool cfg_read = false;
+    if (!cfg_read) {
+        cfg_read = true;
+        const char* c = getenv("LAVT_TNG_CFG");
+        if (c) sscanf(c, "%d,%d,%d", &cfg_tile, &cfg_waves, &cfg_stages);
+    }
+    int TB = cfg_tile;
+    {   // the large tile only where its tiles still occupy most of the chip
+        long t128 = 0;
+        for (int i = 0; i < n; ++i) t128 += (long)cdiv(probs[i].I, 128) * cdiv(probs[i].J, 128);
+        if (TB == 128 && t128 < 128) TB = 64;
+    }
     bool any_colsum = false;
     // Pieces per member.  A member with a partials scratch (lavt_gemm_tn_t.partials: its pieces are stored as plain tiles and added into C by one
     // small second kernel) may be cut as finely as its K allows -- the long-K weight gradients of PWAM (K = 28 800 rows = 450 K tiles on 4
@@ -1098,9 +1111,38 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     }
     for (int i = n; i < TN_GROUP_MAX; ++i) { g.p[i] = probs[0]; g.p[i].partials = nullptr; g.tile_end[i] = tiles; g.split[i] = 1; }
     g.n = n;
-    if (tiles < 256) return 1;                       // too few workgroups to fill the chip
+    if (tiles < (TB == 128 ? 128 : 256)) return 1;   // too few workgroups to fill the chip
     // (round 2: an XCD-contiguous tile order inside each member -- it cuts the 152 MB of fabric traffic -- and a 3-stage ring were both measured
     // on the step: 10.63 vs 10.64 ms and 10.81 vs 10.62 ms; neither is kept)
+    if (TB == 128 || cfg_waves != 4 || cfg_stages != 2) {
+#define TNG_GO(BT_, WV_, SG_)                                                                                                                          \
+    do {                                                                                                                                               \
+        const size_t l = SG_ * (size_t)(64 * (BT_ + BT_) * 2) + (maps ? (2 * (SG_ - 1) + 1) * 768 + 256 : 0);                                          \
+        static bool attr = false;                                                                                                                      \
+        if (!attr && l > 65536) {                                                                                                                      \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);  \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
+            attr = true;                                                                                                                               \
+        }                                                                                                                                              \
+        if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, true, 2>), dim3(tiles), dim3(WV_ * 64), l, st, g);                 \
+        else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, false, 2>), dim3(tiles), dim3(WV_ * 64), l, st, g);                     \
+    } while (0)
+        bool done = true;
+        if (TB == 128 && cfg_waves == 8 && cfg_stages == 2) TNG_GO(128, 8, 2);
+        else if (TB == 128 && cfg_waves == 8 && cfg_stages == 3) TNG_GO(128, 8, 3);
+        else if (TB == 128 && cfg_waves == 8 && cfg_stages == 4) TNG_GO(128, 8, 4);
+        else if (TB == 128 && cfg_waves == 4 && cfg_stages == 2) TNG_GO(128, 4, 2);
+        else if (TB == 128 && cfg_waves == 4 && cfg_stages == 3) TNG_GO(128, 4, 3);
+        else if (TB == 128 && cfg_waves == 4 && cfg_stages == 4) TNG_GO(128, 4, 4);
+        else if (TB == 64 && cfg_waves == 4 && cfg_stages == 4) TNG_GO(64, 4, 4);
+        else done = false;
+#undef TNG_GO
+        if (done) {
+            if (any_parts) hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
+            LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
+            return LAVT_OK;
+        }
+    }
     const size_t lds = 2 * (size_t)(64 * (64 + 64) * 2) + (maps ? 3 * 768 + 256 : 0);
     if (any_colsum) {
         if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true, 2>), dim3(tiles), dim3(256), lds, st, g);

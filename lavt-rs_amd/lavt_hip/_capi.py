@@ -169,6 +169,8 @@ _PROTOTYPES = {
     "lavt_dropout": [i32, vp, vp, f32, vp, vp, i64, vp],
     "lavt_gate_fwd": [i32, vp, vp, vp, vp, i64, vp],
     "lavt_gate_bwd": [i32, vp, vp, vp, vp, vp, vp, i64, vp],
+    "lavt_ln_fold": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "lavt_wmsa_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp],
     "lavt_pwam_words_fwd": [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "lavt_pwam_words_bwd": [vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "lavt_pwam_mix": [i32, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],

@@ -49,6 +49,15 @@ class TrainStep:
         # the weights are changed by something else between replays of the captured step (a torch.optim optimizer, manual edits): the casts
         # (~0.3 ms for Swin-B) then run at the start of every step, inside the graph.
         self.refresh_in_step = refresh_weights_in_step or os.environ.get("LAVT_REFRESH_IN_STEP", "0") == "1"
+        # A captured step runs no Python, so the per-parameter version check of the weight cache never fires on replay.  step() therefore compares
+        # the parameters' version counters / storage addresses with what the compute copies were made from and re-casts them (eagerly, in front of
+        # the replay) when anything but FusedAdamW has touched them: torch.optim optimizers, load_state_dict, manual edits all bump p._version.
+        # FusedAdamW writes through raw pointers (versions do not move) and refreshes the copies itself.
+        self._params = [p for p in model.parameters()]
+        self._seen = None
+
+    def _param_stamp(self):
+        return sum(p._version for p in self._params), sum(p.data_ptr() for p in self._params)
 
     def _body(self):
         if self.refresh_in_step:
@@ -80,6 +89,7 @@ class TrainStep:
                     ops.weights.refresh_all()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        self._seen = self._param_stamp()
         if not self.use_graph:
             return
         if torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -103,6 +113,12 @@ class TrainStep:
             torch.cuda.synchronize()
 
     def step(self):
+        if not self.refresh_in_step:
+            stamp = self._param_stamp()
+            if stamp != self._seen:                 # weights changed behind the compute copies' back (see __init__): refresh before the step
+                if self._seen is not None:
+                    ops.weights.refresh_all()
+                self._seen = stamp
         if self.graph is not None:
             self.graph.replay()
         else:

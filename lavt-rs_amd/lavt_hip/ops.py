@@ -82,6 +82,29 @@ class _WeightCache:
         self.store[key] = (stamp, (q, amax), weakref.ref(p))
         return q, amax
 
+    def get_lnfold(self, w, b, gamma, beta):
+        """(Wg bf16 [N, K] = gamma-folded weight, wsum fp32 [N], biasp fp32 [N]) of a Linear that directly follows a LayerNorm (lavt_ln_fold): the
+        fused W-MSA kernel contracts RAW rows with Wg and applies the normalisation in its epilogue.  Refreshed like every compute copy (by
+        refresh_all / on a version change of any of the four parameters)."""
+        key = (id(w), "lnfold", "lin")
+        ent = self.store.get(key)
+        ps = (w, b, gamma, beta)
+        if ent is not None and ent[2]() is not w:
+            ent = None
+        stamp = (tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps), self.epoch)
+        if ent is not None and ent[0] == stamp:
+            return ent[1][:3]
+        N, Kd = w.shape[0], w.numel() // w.shape[0]
+        if ent is not None:
+            Wg, wsum, biasp = ent[1][:3]
+        else:
+            Wg = torch.empty(N, Kd, dtype=torch.bfloat16, device=w.device)
+            wsum = torch.empty(N, dtype=torch.float32, device=w.device)
+            biasp = torch.empty(N, dtype=torch.float32, device=w.device)
+        K.check(K.lib.lavt_ln_fold(K.ptr(w.detach()), K.ptr(gamma.detach()), K.ptr(beta.detach()), K.ptr(b.detach()), K.ptr(Wg), K.ptr(wsum), K.ptr(biasp), N, Kd, K.stream()))
+        self.store[key] = (stamp, (Wg, wsum, biasp, [weakref.ref(p) for p in ps]), weakref.ref(w))
+        return Wg, wsum, biasp
+
     def get_cat(self, ps, dtype: torch.dtype) -> torch.Tensor:
         """[sum N_i, K] compute copy of several Linear weights stacked along N (BERT's query / key / value): the per-parameter 'lin' entries
         become row slices of ONE buffer, so the usual refresh (get / refresh_all's multi-cast) keeps the stacked matrix current for free."""
@@ -137,6 +160,12 @@ class _WeightCache:
                 del self.store[k]
             elif k[1] == "fp8":
                 self.get_fp8(p, k[2])
+            elif k[1] == "lnfold":
+                others = [r() for r in out[3]]
+                if all(o is not None for o in others):
+                    self.get_lnfold(*others)
+                else:
+                    del self.store[k]
             elif k not in done:
                 self.get(p, k[1], k[2])
 
@@ -286,6 +315,12 @@ class _SideStreams:
 
 
 side = _SideStreams()
+
+
+def _note(shape, flops=0.0):
+    """profiler annotation of the next C-ABI launch (bench.py's in-process family timing)"""
+    if K.prof.enabled:
+        K.prof.note = {"flops": flops, "shape": shape}
 
 
 def _f32(p: Optional[torch.Tensor]):
@@ -937,6 +972,111 @@ class _WindowAttnComposed(torch.autograd.Function):
         return dqkv, sinks.done(table, dtable, ts), None, None, None, None
 
 
+@K.scoped
+class _WmsaFused(torch.autograd.Function):
+    """norm1 -> window partition / shift / pad -> qkv -> attention core of a Swin block as ONE forward kernel (csrc/wmsa_fused.hip; reference
+    lib/backbone.py:201-217 + 113-140).  x [tokens, C] is the residual stream; returns (o [nwin * N, C] in window order -- the proj GEMM scatters it
+    back and adds the residual --, x' aliasing x for the residual branch).  The kernel also leaves qkv, the LayerNorm output and its row statistics
+    for the backward pass, which is the unfused sequence: attention backward -> qkv data / weight gradients -> LayerNorm backward (+ residual gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, wq, bq, table, region, wmap, ws, heads, eps):
+        x = x.contiguous()
+        dtype, dev = x.dtype, x.device
+        M, Cc = x.shape
+        N = ws * ws
+        Mw = wmap.numel()
+        nwin = Mw // N
+        Wg, wsum, biasp = weights.get_lnfold(wq, bq, gamma, beta)
+        out = torch.empty(Mw, Cc, dtype=dtype, device=dev)
+        qkv = torch.empty(Mw, 3 * Cc, dtype=dtype, device=dev)
+        xn = torch.empty_like(x)
+        lse = torch.empty(nwin, heads, N, dtype=torch.float32, device=dev)
+        st = torch.empty(2, M, dtype=torch.float32, device=dev)
+        nw_img = region.shape[0] if region is not None else 0
+        scale = float((Cc // heads) ** -0.5)
+        _note(f"wmsa {Mw}x{Cc} N{N}", 2.0 * Mw * Cc * 3 * Cc + 4.0 * nwin * heads * N * N * 32)
+        K.check(K.lib.lavt_wmsa_fwd(K.ptr(x), K.ptr(wmap), K.ptr(Wg), K.ptr(wsum), K.ptr(biasp), K.ptr(_f32(bq)), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), K.ptr(_f32(table)),
+                                    K.ptr(region), nw_img, K.ptr(out), K.ptr(lse), K.ptr(qkv), K.ptr(xn), K.ptr(st[0]), K.ptr(st[1]), _zero_page(dev), ws, nwin, N,
+                                    heads, Cc, eps, scale, K.stream()))
+        ctx.save_for_backward(x, gamma, beta, wq, bq, table, region, wmap, out, qkv, xn, lse, st)
+        ctx.dims = (ws, heads, nwin, N, Cc, nw_img, scale, Mw)
+        return out, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dout, dres):
+        x, gamma, beta, wq, bq, table, region, wmap, out, qkv, xn, lse, st = ctx.saved_tensors
+        ws_, heads, nwin, N, Cc, nw_img, scale, Mw = ctx.dims
+        dtype, dev = x.dtype, x.device
+        M = x.shape[0]
+        ld = 64 if N <= 64 else 160
+        # ---- attention core (as _WindowAttn.backward) ----
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        nws = int(K.lib.lavt_window_attn_bwd_ws(K.dt(dtype), nwin, N, heads, ld, 1, ws_, ws_))
+        wsb = torch.empty(nws, dtype=torch.float32, device=dev) if nws > 0 else None
+        R = (2 * ws_ - 1) * (2 * ws_ - 1)
+        dtable, ts = sinks.buf(table, (R, heads))
+        pieces = int(K.lib.lavt_window_attn_bwd_pieces(K.dt(dtype), nwin, N, heads, ld)) if (ts and ln_deferred.active()) else 0
+        parts = ln_deferred.alloc(pieces * heads * R, dev) if pieces > 0 else None
+        _note(f"wattn-bwd {Mw}x{Cc} N{N}", 10.0 * nwin * heads * N * N * 32)
+        K.check(K.lib.lavt_window_attn_bwd(K.dt(dtype), K.ptr(qkv), None, ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(_f32(table)),
+                                           None if parts is not None else K.ptr(dtable), K.ptr(wsb), wsb.numel() if wsb is not None else 0, K.ptr(parts), 1, ws_, ws_,
+                                           nwin, N, heads, Cc // heads, scale, K.stream()))
+        if parts is not None:
+            ln_deferred.add_table(parts, pieces, heads, R, dtable, table)
+            g_table = None
+        else:
+            g_table = sinks.done(table, dtable, ts)
+        # ---- qkv projection: data gradient scattered back to token order, weight / bias gradient over the windowed rows ----
+        Wc = weights.get(wq, dtype, "lin")
+        dxn = torch.empty_like(x)
+        gemm_nt(dtype, Mw, Cc, 3 * Cc, dqkv, 3 * Cc, Wc, Cc, dxn, Cc, b_kmajor=True, c_rowmap=wmap)
+        wbuf, wsink = sinks.buf(wq, (3 * Cc, Cc))
+        bbuf, bsink = sinks.buf(bq, (3 * Cc,))
+        if wgrads.active() and wsink and bsink:
+            gemm_tn(dtype, 3 * Cc, Cc, Mw, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, b_rowmap=wmap, colsum=bbuf, defer=wgrads)
+            wgrads.notify(wq)
+            wgrads.notify(bq)
+            g_w = g_b = None
+        else:
+            gemm_tn(dtype, 3 * Cc, Cc, Mw, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, b_rowmap=wmap, colsum=bbuf)
+            g_w, g_b = sinks.done(wq, wbuf, wsink), sinks.done(bq, bbuf, bsink)
+        # ---- LayerNorm backward, the residual branch's gradient joining inside the kernel (as _LayerNorm.backward) ----
+        if dres is not None:
+            dres = dres.contiguous()
+        dx = torch.empty_like(x)
+        dg, gs = sinks.buf(gamma, (Cc,))
+        db, bs_ = sinks.buf(beta, (Cc,))
+        done = False
+        if gs and bs_ and ln_deferred.active():
+            nblk = int(K.lib.lavt_layernorm_bwd_blocks(K.dt(dtype), M, Cc))
+            wsd = ln_deferred.alloc(nblk * 2 * Cc, dev)
+            if wsd is not None:
+                K.check(K.lib.lavt_layernorm_bwd_partial(K.dt(dtype), K.ptr(dxn), K.ptr(x), None, K.ptr(_f32(gamma)), K.ptr(st[0]), K.ptr(st[1]), K.ptr(dx), K.ptr(wsd),
+                                                         wsd.numel(), K.ptr(dres), M, Cc, K.stream()))
+                ln_deferred.add(wsd, nblk, Cc, dg, db, (gamma, beta))
+                g_g = g_be = None
+                done = True
+        if not done:
+            wsl = _scratch(int(K.lib.lavt_layernorm_bwd_blocks(K.dt(dtype), M, Cc)) * 2 * Cc, dev)
+            K.check(K.lib.lavt_layernorm_bwd(K.dt(dtype), K.ptr(dxn), K.ptr(x), None, K.ptr(_f32(gamma)), K.ptr(st[0]), K.ptr(st[1]), K.ptr(dx), K.ptr(dg), K.ptr(db),
+                                             K.ptr(wsl), wsl.numel(), K.ptr(dres), M, Cc, K.stream()))
+            g_g, g_be = sinks.done(gamma, dg, gs), sinks.done(beta, db, bs_)
+        return dx, g_g, g_be, g_w, g_b, g_table, None, None, None, None, None
+
+
+def wmsa_fused_ok(x, ws, heads, has_bias):
+    """the one-kernel W-MSA forward covers bf16 2-D windows of <= 160 tokens with C = 32 heads a multiple of 64 and a qkv bias"""
+    return (x.dtype == torch.bfloat16 and has_bias and x.shape[1] == 32 * heads and x.shape[1] % 64 == 0 and ws * ws <= 160
+            and os.environ.get("LAVT_WMSA_FUSED", "1") != "0")
+
+
+def wmsa_fused(x, norm, attn, region, wmap, ws, heads):
+    """x [tokens, C], norm = the block's norm1, attn = its WindowAttention (parameter containers) -> (attention output in window order, x')"""
+    return _WmsaFused.apply(x, norm.weight, norm.bias, attn.qkv.weight, attn.qkv.bias, attn.relative_position_bias_table, region, wmap, ws, heads, norm.eps)
+
+
 def window_attention(qkv, table, region, win, heads, N=None):
     """win: int ws (2-D) or (wd, wh, ww); N: tokens per window (default: the full window; smaller for clipped video windows)."""
     win = _win3(win)
@@ -1267,11 +1407,6 @@ class _PwamAttn(torch.autograd.Function):
 
 def pwam_attention(q, k, v, maskbias, B, T, n_l, G, sinks_kv=None):
     return _PwamAttn.apply(q, k, v, maskbias, B, T, n_l, G, sinks_kv)
-
-
-def _note(shape, flops=0.0):
-    if K.prof.enabled:
-        K.prof.note = {"flops": flops, "shape": shape}
 
 
 @K.scoped

@@ -673,3 +673,82 @@ def test_pwam_gate_fused_node(C, T, gate_live):
             assert k not in fus or float(fus[k].abs().max()) == 0.0
     assert len(report) >= 12, report
     print("\n[fused PWAM node, relative l2 error vs the fp32 oracle: (composed bf16, fused bf16)]", report)
+
+
+def test_train_step_graph_sees_foreign_optimizer_updates():
+    """round-2 ADVICE: a captured step runs no Python, so the version check of the weight cache cannot fire on replay.  TrainStep.step() compares the
+    parameters' version counters with what the bf16 compute copies were made from and re-casts them when a torch.optim optimizer (as in the
+    reference's train.py:615-700) has updated the fp32 masters: the replayed loss must follow the updates."""
+    import lavt_hip
+    from lavt_hip import ops
+    from lavt_hip.engine import TrainStep
+    x, l, m, t = det_inputs(2, 64, 20, seed=13)
+    x, l, m, t = x.to(DEV), l.to(DEV), m.to(DEV), t.to(DEV)
+    with lavt_hip.use_dtype(torch.bfloat16):
+        model = _build(32, [2, 2, 2, 2], [1, 2, 4, 8], 7, dpr=0.0).train()
+        step = TrainStep(model, x, l, m, t, world=1, use_graph=True)
+        step.warmup_and_capture()
+        assert step.captured
+        opt = torch.optim.AdamW([p for p in model.parameters()], lr=2e-3, weight_decay=0.0)
+        losses = []
+        for _ in range(4):
+            losses.append(float(step.step()))
+            opt.step()                       # gradients live in the step's flat buffer (p.grad views)
+        torch.cuda.synchronize()
+        assert losses[1] < losses[0] - 1e-3 and losses[3] < losses[1] - 1e-3, f"replayed steps do not see the optimizer's updates: {losses}"
+        qk = model.backbone.layers[1].blocks[0].attn.qkv.weight
+        step.step()
+        torch.cuda.synchronize()
+        assert torch.equal(ops.weights.get(qk, torch.bfloat16), qk.detach().to(torch.bfloat16))
+    ops.wgrads.enabled = False
+    ops.sinks.clear()
+
+
+@pytest.mark.parametrize("C,ws,H,W,shifted", [(128, 12, 15, 15, 0), (128, 12, 15, 15, 1), (64, 7, 10, 9, 1), (512, 12, 30, 30, 1), (192, 7, 14, 14, 0)])
+def test_wmsa_fused_forward_kernel(C, ws, H, W, shifted):
+    """The one-kernel W-MSA forward (csrc/wmsa_fused.hip: norm1 folded into the qkv contraction, padded / shifted windows through the row map,
+    attention core on the LDS copies) inside a Swin block, against the fp32 CPU oracle of the reference block (lib/backbone.py:188-245), forward and
+    every gradient; yardstick = the unfused bf16 path (LayerNorm kernel -> qkv GEMM -> attention kernel): fused error <= 1.5 x unfused + 1 %."""
+    import lavt_hip
+    from lavt_hip import ops
+    from lib.backbone import SwinTransformerBlock
+    from oracle import lavt_oracle as O
+    B, nH = 2, C // 32
+    blk = SwinTransformerBlock(C, nH, ws, shift_size=(ws // 2 if shifted else 0)).eval()
+    fill_state_dict_(blk)
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    blk.to(DEV)
+    blk.H, blk.W = H, W
+    x0, wy = randn(21, B, H * W, C), randn(22, B, H * W, C)
+    ps = {"blk." + k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
+    xo = x0.clone().requires_grad_(True)
+    y_ref = O.swin_block(ps, "blk", xo, H, W, nH, ws, shifted=bool(shifted))
+    (y_ref * wy).sum().backward()
+    ref = {"y": y_ref.detach(), "dx": xo.grad}
+    ref.update({k[4:]: p.grad for k, p in ps.items() if p.grad is not None})
+
+    def run(fused):
+        os.environ["LAVT_WMSA_FUSED"] = "1" if fused else "0"
+        try:
+            lavt_hip.set_compute_dtype(torch.bfloat16)
+            blk.zero_grad(set_to_none=True)
+            x = x0.to(DEV).to(torch.bfloat16).requires_grad_(True)
+            assert ops.wmsa_fused_ok(x.reshape(B * H * W, C), ws, nH, True) == fused
+            y = blk(x)
+            (y.float() * wy.to(DEV)).sum().backward()
+            out = {"y": y, "dx": x.grad}
+            out.update({k: p.grad for k, p in blk.named_parameters() if p.grad is not None})
+            return {k: v.detach().float().cpu() for k, v in out.items()}
+        finally:
+            os.environ.pop("LAVT_WMSA_FUSED", None)
+            lavt_hip.set_compute_dtype(torch.float32)
+
+    comp, fus = run(False), run(True)
+    report = {}
+    for k, rv in ref.items():
+        scale = float(rv.norm())
+        ec, ef = float((comp[k] - rv).norm()) / scale, float((fus[k] - rv).norm()) / scale
+        report[k] = (round(ec, 4), round(ef, 4))
+        assert ef <= 1.5 * ec + 1e-2, (k, ec, ef, report)
+    assert len(report) >= 14, report
+    print("\n[fused W-MSA forward, relative l2 error vs the fp32 oracle: (unfused bf16, fused bf16)]", report)
