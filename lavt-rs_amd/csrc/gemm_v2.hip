@@ -1120,8 +1120,8 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         const size_t l = SG_ * (size_t)(64 * (BT_ + BT_) * 2) + (maps ? (2 * (SG_ - 1) + 1) * 768 + 256 : 0);                                          \
         static bool attr = false;                                                                                                                      \
         if (!attr && l > 65536) {                                                                                                                      \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);  \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
             attr = true;                                                                                                                               \
         }                                                                                                                                              \
         if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, true, 2>), dim3(tiles), dim3(WV_ * 64), l, st, g);                 \

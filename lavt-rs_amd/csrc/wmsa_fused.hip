@@ -7,7 +7,7 @@
 //   phase 1  [q | k | v]_head = LN(x_window) W_head^T + b_head as a 144 x 96 x C GEMM: the window's token rows are gathered through the row map by
 //            LDS-DMA (global_load_lds_dwordx4, -1 = padded token = zero page) into a 2-stage ring of 64-wide K tiles, the head's 96 weight rows likewise.
 //            LayerNorm is applied algebraically: the MFMA contracts the RAW rows with gamma-folded weights, the row statistics are accumulated from
-//            the same LDS tiles while they are resident (shifted sums: no E[x^2] - E[x]^2 cancellation), and the epilogue forms
+//            the same LDS tiles while they are resident (v_dot2c_f32_bf16: exact products, fp32 sums over C <= 1024 values), and the epilogue forms
 //                rstd_r (acc - mu_r wsum_n) + (b_n + sum_k beta_k W_nk)        [padded tokens: b_n only -- the reference pads AFTER norm1]
 //            q, k, v go to LDS (and to HBM once, for the backward pass); the normalised rows xn -- the qkv weight gradient's operand -- are written
 //            by column slices, one slice per head.
@@ -65,6 +65,7 @@ struct WmsaArgs {
     const void* zeros;
     int nw_img, wh, ww, nwin, N, heads, C;
     float eps, scale;
+    int debug;
 };
 
 template <int NT, bool REGION, bool FULL>
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
     int* srcs = reinterpret_cast<int*>(rsd + MR);
     uint8_t* Rs = reinterpret_cast<uint8_t*>(srcs + MR);
     float* tab = reinterpret_cast<float*>(Rs + NP);
+    float* evec = tab + ((2 * a.wh - 1) * (2 * a.ww - 1) + 3) / 4 * 4;      // [3][96]: wsum | biasp | bias of this head's q, k, v columns
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int w = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
@@ -94,12 +96,6 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
     const bf16* Z = reinterpret_cast<const bf16*>(a.zeros);
 
     for (int e = tid; e < MR; e += 256) srcs[e] = e < N ? a.wmap[(int64_t)w * N + e] : -1;
-    for (int e = tid; e < NP; e += 256) {
-        const int hy = (e / ww) % wh, wx = e % ww;
-        bs[e] = hy * (2 * ww - 1) + wx;
-        Rs[e] = (REGION && e < N) ? (uint8_t)a.region[(int64_t)(w % a.nw_img) * N + e] : 0;
-    }
-    for (int e = tid; e < R; e += 256) tab[e] = a.table[(int64_t)e * a.heads + h] * LOG2E;
     __syncthreads();
 
     // ---- phase 1: [q | k | v]_head = LN(x_window) W_head^T ----------------------------------------------------------------------------
@@ -130,12 +126,25 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float sh[A_INSTR], s1[A_INSTR], s2[A_INSTR];
+    float s1[A_INSTR], s2[A_INSTR];
 #pragma unroll
-    for (int u = 0; u < A_INSTR; ++u) { sh[u] = 0.f; s1[u] = 0.f; s2[u] = 0.f; }
+    for (int u = 0; u < A_INSTR; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
+    typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2;
+    const bf16x2 ones2 = {(bf16)1.0f, (bf16)1.0f};
     const int QT = (N + 15) / 16;
-    const int ktiles = C >> 6;
-    issue(0);
+    const int ktiles = (a.debug & 2) ? 0 : (C >> 6);
+    if (ktiles) issue(0);
+    // the small tables are staged while the first K tile is in flight (they are first read after the loop's barriers)
+    for (int e = tid; e < NP; e += 256) {
+        const int hy = (e / ww) % wh, wx = e % ww;
+        bs[e] = hy * (2 * ww - 1) + wx;
+        Rs[e] = (REGION && e < N) ? (uint8_t)a.region[(int64_t)(w % a.nw_img) * N + e] : 0;
+    }
+    for (int e = tid; e < R; e += 256) tab[e] = a.table[(int64_t)e * a.heads + h] * LOG2E;
+    for (int e = tid; e < 3 * 96; e += 256) {
+        const int which = e / 96, n = e - which * 96, col = (n >> 5) * C + h * HD + (n & 31);
+        evec[e] = (which == 0 ? a.wsum : (which == 1 ? a.biasp : a.bias))[col];
+    }
     for (int kt = 0; kt < ktiles; ++kt) {
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -143,14 +152,19 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
         const bf16* cA = reinterpret_cast<const bf16*>(smem + (kt & 1) * STAGE);
         const bf16* cB = reinterpret_cast<const bf16*>(smem + (kt & 1) * STAGE + A_BYTES);
         // row statistics from the resident tile: thread t owns the 16-byte chunk t % 8 of rows t / 8 + 32 u (any physical chunk order: sums only)
+        // (v_dot2c_f32_bf16: one instruction per PAIR and sum -- exact bf16 products, fp32 accumulation; the first version unpacked every value and
+        // accumulated shifted sums on the VALU: ~200 instructions per thread per K tile, 16 x redundantly over the heads of a window)
 #pragma unroll
         for (int u = 0; u < A_INSTR; ++u) {
             const int row = (tid >> 3) + 32 * u;
-            if (kt == 0) sh[u] = (float)cA[row * 64 + ((row & 7) << 3)];              // x[row][0]: logical chunk 0 sits at physical chunk row % 8
-            float f[8];
-            chunk_to_f<bf16>(*reinterpret_cast<const uint4*>(cA + row * 64 + (tid & 7) * 8), f);
+            const uint4 c4 = *reinterpret_cast<const uint4*>(cA + row * 64 + (tid & 7) * 8);
+            const unsigned wv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = f[e] - sh[u]; s1[u] += d; s2[u] += d * d; }
+            for (int e = 0; e < 4; ++e) {
+                const bf16x2 v2 = __builtin_bit_cast(bf16x2, wv[e]);
+                s1[u] = __builtin_amdgcn_fdot2_f32_bf16(v2, ones2, s1[u], false);
+                s2[u] = __builtin_amdgcn_fdot2_f32_bf16(v2, v2, s2[u], false);
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
             if ((tid & 7) == 0) {
                 const int row = (tid >> 3) + 32 * u;
                 const float m1 = t1 * invC;
-                mu[row] = sh[u] + m1;
+                mu[row] = m1;
                 rsd[row] = rsqrtf(fmaxf(t2 * invC - m1 * m1, 0.f) + a.eps);
             }
         }
@@ -197,8 +211,8 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
             uint2 p[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const int col = jp * C + h * HD + hf * 16 + 4 * g;
-                const float4 ws4 = *reinterpret_cast<const float4*>(a.wsum + col), bp4 = *reinterpret_cast<const float4*>(a.biasp + col), b4 = *reinterpret_cast<const float4*>(a.bias + col);
+                const int col = jp * 32 + hf * 16 + 4 * g;
+                const float4 ws4 = *reinterpret_cast<const float4*>(evec + col), bp4 = *reinterpret_cast<const float4*>(evec + 96 + col), b4 = *reinterpret_cast<const float4*>(evec + 192 + col);
                 const float wsv[4] = {ws4.x, ws4.y, ws4.z, ws4.w}, bpv[4] = {bp4.x, bp4.y, bp4.z, bp4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
                 float v[4];
 #pragma unroll
@@ -217,26 +231,9 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
         *reinterpret_cast<uint4*>(Ks + row * F_LD + c * 8) = z;
         *reinterpret_cast<uint4*>(Vs + row * F_LD + c * 8) = z;
     }
-    // this head's 32-column slice of the LayerNorm output (operand of the qkv weight gradient) + the row statistics (LayerNorm backward)
-    for (int e = tid; e < N * 4; e += 256) {
-        const int row = e >> 2, c = e & 3;
-        const int src = srcs[row];
-        if (src < 0) continue;
-        float f[8];
-        chunk_to_f<bf16>(*reinterpret_cast<const uint4*>(a.x + (int64_t)src * C + h * HD + c * 8), f);
-        const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + h * HD + c * 8), g1 = *reinterpret_cast<const float4*>(a.gamma + h * HD + c * 8 + 4);
-        const float4 e0 = *reinterpret_cast<const float4*>(a.beta + h * HD + c * 8), e1 = *reinterpret_cast<const float4*>(a.beta + h * HD + c * 8 + 4);
-        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-        const float mr = mu[row], rr = rsd[row];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) f[k] = (f[k] - mr) * rr * gm[k] + bt[k];
-        *reinterpret_cast<uint4*>(a.xn + (int64_t)src * C + h * HD + c * 8) = f_to_chunk<bf16>(f);
-        if (h == 0 && c == 0) { a.mean[src] = mr; a.rstd[src] = rr; }
-    }
     __syncthreads();
 
     // ---- phase 2: attention core on the LDS copies (wattn_fwd_mfma, attention_mfma.hip) ----------------------------------------------------
-    if (wave >= QT) return;
     const float sc2 = a.scale * LOG2E;
     bf16x8 kf[NT], vf[2][KS];
 #pragma unroll
@@ -249,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
             vf[u][ks] = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p), __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * F_LD)));
         }
     const int heads = a.heads;
-    for (int it = wave; it < QT; it += 4) {
+    for (int it = ((a.debug & 1) ? QT : wave); it < QT; it += 4) {
         const int i = 16 * it + c16;
         const bool vi = i < N;
         const bf16x8 qf = lds_row8(Qs, F_LD, i, 8 * g);
@@ -303,6 +300,22 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
                          make_uint2(pack_bf16x2(o[0][0] * inv, o[0][1] * inv), pack_bf16x2(o[0][2] * inv, o[0][3] * inv)),
                          make_uint2(pack_bf16x2(o[1][0] * inv, o[1][1] * inv), pack_bf16x2(o[1][2] * inv, o[1][3] * inv)), vi);
     }
+    // this head's 32-column slice of the LayerNorm output (operand of the qkv weight gradient) + the row statistics (LayerNorm backward)
+    for (int e = tid; e < N * 4; e += 256) {          // (last: off the critical path of the attention phase; mu / rsd / srcs live outside the aliased ring)
+        const int row = e >> 2, c = e & 3;
+        const int src = srcs[row];
+        if (src < 0) continue;
+        float f[8];
+        chunk_to_f<bf16>(*reinterpret_cast<const uint4*>(a.x + (int64_t)src * C + h * HD + c * 8), f);
+        const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + h * HD + c * 8), g1 = *reinterpret_cast<const float4*>(a.gamma + h * HD + c * 8 + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(a.beta + h * HD + c * 8), e1 = *reinterpret_cast<const float4*>(a.beta + h * HD + c * 8 + 4);
+        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        const float mr = mu[row], rr = rsd[row];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = (f[k] - mr) * rr * gm[k] + bt[k];
+        *reinterpret_cast<uint4*>(a.xn + (int64_t)src * C + h * HD + c * 8) = f_to_chunk<bf16>(f);
+        if (h == 0 && c == 0) { a.mean[src] = mr; a.rstd[src] = rr; }
+    }
 }
 
 // gamma-folded weight of a Linear that follows a LayerNorm: Wg[n][k] = bf16(gamma_k W[n][k]), wsum[n] = sum_k Wg[n][k] (of the ROUNDED values: the
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ 
 template <int NT, bool FULL> int launch_wmsa(const WmsaArgs& a, hipStream_t st) {
     constexpr int KS = (NT + 1) / 2, NP = KS * 32, MR = ((NT * 16 + 31) / 32) * 32, STAGE = MR * 128 + 96 * 128;
     const int R = (2 * a.wh - 1) * (2 * a.ww - 1);
-    const size_t lds = (size_t)2 * STAGE + (size_t)NP * 4 + (size_t)MR * 12 + NP + (size_t)R * 4 + 32;
+    const size_t lds = (size_t)2 * STAGE + (size_t)NP * 4 + (size_t)MR * 12 + NP + (size_t)R * 4 + 32 + 3 * 96 * 4;
     static size_t reserved = 0;
     if (lds > 65536 && lds > reserved) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wmsa_fwd_fused_kernel<NT, true, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
@@ -364,6 +377,7 @@ extern "C" int lavt_wmsa_fwd(const void* x, const int32_t* wmap, const void* Wg,
     a.x = (const bf16*)x; a.wmap = wmap; a.Wg = (const bf16*)Wg; a.wsum = wsum; a.biasp = biasp; a.bias = bias; a.gamma = gamma; a.beta = beta;
     a.table = table; a.region = region; a.out = (bf16*)out; a.lse = lse; a.qkv = (bf16*)qkv; a.xn = (bf16*)xn; a.mean = mean; a.rstd = rstd; a.zeros = zeros;
     a.nw_img = nw_img; a.wh = ws; a.ww = ws; a.nwin = nwin; a.N = N; a.heads = heads; a.C = C; a.eps = eps; a.scale = scale;
+    { const char* d = getenv("LAVT_WMSA_DEBUG"); a.debug = d ? atoi(d) : 0; }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (N <= 64) return launch_wmsa<4, false>(a, st);
     if (N == 144) return launch_wmsa<9, true>(a, st);

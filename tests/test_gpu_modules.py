@@ -721,7 +721,7 @@ def test_train_step_graph_sees_foreign_optimizer_updates():
         ops.sinks.clear()
 
 
-@pytest.mark.parametrize("C,ws,H,W,shifted", [(128, 12, 15, 15, 0), (128, 12, 15, 15, 1), (64, 7, 10, 9, 1), (512, 12, 30, 30, 1), (192, 7, 14, 14, 0)])
+@pytest.mark.parametrize("C,ws,H,W,shifted", [(128, 12, 15, 15, 0), (128, 12, 15, 15, 1), (64, 7, 10, 9, 1), (512, 12, 30, 30, 1), (192, 7, 14, 14, 0), (384, 7, 7, 7, 1)])
 def test_wmsa_fused_forward_kernel(C, ws, H, W, shifted):
     """The one-kernel W-MSA forward (csrc/wmsa_fused.hip: norm1 folded into the qkv contraction, padded / shifted windows through the row map,
     attention core on the LDS copies) inside a Swin block, against the fp32 CPU oracle of the reference block (lib/backbone.py:188-245), forward and
