@@ -126,9 +126,17 @@ typedef struct lavt_gemm_nt {
     const void* mul;
     int64_t ldmul;
     int32_t res_first;
+    /* conv_tap_split > 0 (ABI v4): the reduction of a convolution is cut at tap boundaries over the batch index -- entry bz contracts taps
+     * [bz * conv_tap_split, (bz + 1) * conv_tap_split) only (K = conv_tap_split * conv_kc, batch * conv_tap_split = taps; with !b_kmajor strideB
+     * advances the packed weight by conv_tap_split * conv_kc elements, with b_kmajor strideB = 0).  Used with c_f32 + strideC as split-K through
+     * fp32 partial outputs for the decoder's small-pixel-count convolutions (1 800 rows x K = 13 824: 60-232 tiles with serial chains of 72-216
+     * K tiles otherwise); lavt_splitk_reduce adds the partials.  Tap-walking fast path only (conv_kc % 64 == 0). */
+    int32_t conv_tap_split;
 } lavt_gemm_nt_t;
 
 int lavt_gemm_nt(const lavt_gemm_nt_t* p, void* stream);
+/* out[m][n] (dtype) = sum_s parts[s][m][n] (fp32): second stage of a split reduction of lavt_gemm_nt (c_f32 partial outputs, one per batch entry) */
+int lavt_splitk_reduce(int dtype, const float* parts, int splits, int64_t M, int N, void* out, int64_t ldc, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Gather-GEMM, "TN" family (weight gradients):   C[I,J] += alpha * sum_k A[k][i] * B[k][j]      (fp32 C)
@@ -331,19 +339,20 @@ int lavt_wmsa_fwd(const void* x, const int32_t* wmap, const void* Wg, const floa
  *   lavt_pwam_mix mode 0: out0 = GELU(X + xbias) * (Wd Wc^T + v0)      (mm = vis * IN(w);  Wd = P, Wc = VWc, v0 = beta, X = x Wv^T, xbias = bv)
  *                 mode 1: out0 = D * what * GELU'(X), out1 = D * GELU(X)  (d vpre, d what;  D = d mm)
  *                 mode 2: out0 = Wd Wc^T + v0 - X * v1                  (dq;  Wd = dS, Wc = K''^T, X = q)
- *   lavt_pwam_lang_bwd1: HT = dwhat^T P [B][C][32], s = colsum(dwhat) [B][C] -> dVW [B*32][C] (bf16), Q [B][32][32] and u [B][32] ADDED into zeroed buffers
+ *   lavt_pwam_lang_bwd1: HT = dwhat^T P [B][C][32], s = colsum(dwhat) [B][C] -> dVW [B*32][C] (bf16), partial records of Q [32][32] and u [32] in Qp
  *   lavt_pwam_words_bwd: dS[row][32] = P * (dP - sum_j P_j dP_j),  dP = dwhat VW'^T - P Q + (Pbar Q - u)
  *   lavt_pwam_lang_bwd2: G = dS^T q [B][32][C], sdS = colsum(dS) [B][32] -> dK [B*32][lddk] (bf16), K''^T [B][C][32] (bf16), c0, c1 [B][C]
  * ------------------------------------------------------------------------------------------- */
 int lavt_pwam_words_fwd(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
                         void* P, int B, int T, int C, int n_l, float alpha, void* stream);
-int lavt_pwam_words_bwd(const void* dwhat, int64_t ldx, const void* VWw, const float* Qf, const float* u, const float* pbar, const void* P,
+int lavt_pwam_words_bwd(const void* dwhat, int64_t ldx, const void* VWw, const float* Qp, const float* pbar, const void* P,
                         void* dS, int B, int T, int C, void* stream);
+int lavt_pwam_q_parts(int C); /* records per sample in Qp: [B][records][1024 Q | 32 u] floats, written by lavt_pwam_lang_bwd1, summed in fixed order by lavt_pwam_words_bwd */
 int lavt_pwam_mix(int mode, const void* Wd, const void* Wc, const float* v0, const float* v1, const float* xbias, const void* X, int64_t ldx, const void* D, int64_t ldd,
                   void* out0, int64_t ld0, void* out1, int64_t ld1, int B, int T, int C, void* stream);
 int lavt_pwam_lang_fwd(const void* V, int64_t ldv, const void* Wo, const float* PP, const float* sumP, void* VWc, void* VWw, float* beta, float* rw,
                        float* pbar, float* cov, int B, int T, int C, float eps, void* stream);
-int lavt_pwam_lang_bwd1(const float* HT, const float* s, const void* VWc, const float* rw, const float* pbar, const float* cov, void* dVW, float* Qf, float* u,
+int lavt_pwam_lang_bwd1(const float* HT, const float* s, const void* VWc, const float* rw, const float* pbar, const float* cov, void* dVW, float* Qp,
                         int B, int T, int C, void* stream);
 int lavt_pwam_lang_bwd2(const float* G, const float* sdS, const void* K, int64_t ldk, const float* mean, const float* rstd, void* dK, int64_t lddk, void* K2c,
                         float* c0, float* c1, int B, int T, int C, float alpha, void* stream);

@@ -668,6 +668,32 @@ extern "C" int lavt_unpack_conv_grad(const float* packed, float* dw, int Cout, i
     LAVT_CHECK_LAUNCH("lavt_unpack_conv_grad");
     return LAVT_OK;
 }
+// second stage of a split-K lavt_gemm_nt (fp32 partial outputs [splits][M][N]): 8 columns per thread, 16-byte loads, bf16 / fp32 out
+template <typename T> __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ parts, int splits, int64_t MN, int64_t chunks, int N, T* __restrict__ out, int64_t ldc) {
+    GRID_STRIDE(i, chunks) {
+        const int64_t e = i * 8;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < splits; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(parts + (int64_t)s * MN + e), v1 = *reinterpret_cast<const float4*>(parts + (int64_t)s * MN + e + 4);
+            a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w;
+        }
+        const int64_t m = e / N;
+        const int n = (int)(e - m * N);
+        if constexpr (std::is_same<T, float>::value) {
+            *reinterpret_cast<float4*>(out + m * ldc + n) = make_float4(a[0], a[1], a[2], a[3]);
+            *reinterpret_cast<float4*>(out + m * ldc + n + 4) = make_float4(a[4], a[5], a[6], a[7]);
+        } else *reinterpret_cast<uint4*>(out + m * ldc + n) = f_to_chunk<bf16>(a);
+    }
+}
+extern "C" int lavt_splitk_reduce(int dtype, const float* parts, int splits, int64_t M, int N, void* out, int64_t ldc, void* stream) {
+    LAVT_CHECK_ARG(parts && out && splits > 0 && M > 0 && N > 0 && N % 8 == 0 && ldc % 8 == 0, "lavt_splitk_reduce: bad arguments (N, ldc multiples of 8)");
+    const int64_t chunks = M * N / 8;
+    if (dtype == LAVT_BF16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(ew_grid(chunks)), dim3(256), 0, ST, parts, splits, M * N, chunks, N, (bf16*)out, ldc);
+    else if (dtype == LAVT_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(ew_grid(chunks)), dim3(256), 0, ST, parts, splits, M * N, chunks, N, (float*)out, ldc);
+    else { lavt_set_error("lavt_splitk_reduce: bad dtype %d", dtype); return LAVT_ERR_INVALID; }
+    LAVT_CHECK_LAUNCH("lavt_splitk_reduce");
+    return LAVT_OK;
+}
 extern "C" int lavt_cast_multi(const int64_t* desc, int count, int dst_dtype, void* stream) {
     LAVT_CHECK_ARG(desc && count > 0 && (dst_dtype | 1) == 1, "lavt_cast_multi: bad arguments");
     dim3 grid(64, count);

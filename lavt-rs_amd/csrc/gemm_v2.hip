@@ -254,7 +254,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
             a_p1[i] = A + row * p.lda + cl * EPC;
             a_p2[i] = A2 ? A2 + row * p.lda2 + cl * EPC : a_p1[i];
         }
-        conv_tap(cg, 0, c_dz, c_dy, c_dx);
+        if (p.conv_tap_split > 0) c_tap = bz * p.conv_tap_split;          // split reduction over the batch index: this entry's first tap
+        conv_tap(cg, c_tap, c_dz, c_dy, c_dx);
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
             if constexpr (!BKM) {
@@ -814,9 +815,10 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
     // split reduction with a partials buffer: this piece's tile goes to partials[piece][I][J] as plain stores (tn_reduce_pieces adds the pieces
     // into C afterwards); otherwise pieces meet in C through atomics
     const bool to_parts = p.partials != nullptr && nsplit > 1;
-    float* C = to_parts ? p.partials + (int64_t)split_idx * p.I * p.J : p.C + (int64_t)bz * p.strideC;
+    float* const pbase = to_parts ? p.partials + (int64_t)bz * nsplit * ((int64_t)p.I * p.J + p.I) : nullptr;      // one [pieces][I][J] + [pieces][I] block per batch entry
+    float* C = to_parts ? pbase + (int64_t)split_idx * p.I * p.J : p.C + (int64_t)bz * p.strideC;
     const int64_t ldc_out = to_parts ? p.J : p.ldc;
-    float* colsum_out = to_parts ? p.partials + (int64_t)nsplit * p.I * p.J + (int64_t)split_idx * p.I : (p.colsum ? p.colsum + (int64_t)bz * p.strideColsum : nullptr);
+    float* colsum_out = to_parts ? pbase + (int64_t)nsplit * p.I * p.J + (int64_t)split_idx * p.I : (p.colsum ? p.colsum + (int64_t)bz * p.strideColsum : nullptr);
     const bool atomic = !to_parts && (nsplit > 1 || p.accumulate);
 #pragma unroll
     for (int i = 0; i < II; ++i) {
@@ -893,9 +895,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_grouped_kernel(const Tn
 // second stage of a split reduction through partial tiles: C[i][j] += sum_s parts[s][i][J + j], colsum[i] += sum_s parts[nsplit*I*J + s*I + i].
 // 64 outputs x 4 piece lanes per workgroup (coalesced 256-byte reads, four independent loads in flight per thread), one writer per output.
 __global__ __launch_bounds__(256) void tn_reduce_pieces(const float* __restrict__ parts, int nsplit, int I, int J, float* __restrict__ C, int64_t ldc,
-                                                        float* __restrict__ colsum) {
+                                                        float* __restrict__ colsum, int64_t strideC, int64_t strideColsum) {
     __shared__ float red[4][64];
     const int64_t W = (int64_t)I * J, total = W + (colsum ? I : 0);
+    parts += (int64_t)blockIdx.y * nsplit * (W + I);          // batch entry
+    C += (int64_t)blockIdx.y * strideC;
+    if (colsum) colsum += (int64_t)blockIdx.y * strideColsum;
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 64 + col;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -931,7 +936,7 @@ template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS> int launch_t
     dim3 grid(cdiv(p.I, BI) * cdiv(p.J, BJ), p.batch, cdiv(ktiles, per));
     const int pieces = (int)grid.z;
     // partial tiles instead of atomics when the caller lent scratch for them (plain problems only: no conv column permutation, batch 1)
-    const bool parts = pieces > 1 && p.partials && p.batch == 1 && !p.c_conv_permute && p.partials_floats >= (int64_t)pieces * ((int64_t)p.I * p.J + p.I);
+    const bool parts = pieces > 1 && p.partials && !p.c_conv_permute && p.partials_floats >= (int64_t)p.batch * pieces * ((int64_t)p.I * p.J + p.I);
     if (!parts) {
         lavt_gemm_tn_t q = p;
         q.partials = nullptr;
@@ -939,7 +944,7 @@ template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS> int launch_t
     } else {
         hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS>), grid, dim3(WAVES * 64), lds, st, p, per);
         const int64_t total = (int64_t)p.I * p.J + (p.colsum ? p.I : 0);
-        hipLaunchKernelGGL(tn_reduce_pieces, dim3((unsigned)cdiv(total, 64)), dim3(256), 0, st, p.partials, pieces, p.I, p.J, p.C, p.ldc, p.colsum);
+        hipLaunchKernelGGL(tn_reduce_pieces, dim3((unsigned)cdiv(total, 64), p.batch), dim3(256), 0, st, p.partials, pieces, p.I, p.J, p.C, p.ldc, p.colsum, p.strideC, p.strideColsum);
     }
     LAVT_CHECK_LAUNCH("lavt_gemm_tn(v2)");
     return LAVT_OK;

@@ -14,6 +14,8 @@
 //   pwam_mix_kernel:   [T x 32] x [32 x C] -> per-row channel vectors fused with the element-wise neighbours
 //                      (forward: mm = GELU(vpre) * what; backward A: d vpre, d what; backward C: dq = dS K'' + c0 - q c1)
 // and three tiny language-side kernels on [32 x C] / [32 x 32] matrices.  tools/pwam_algebra_check.py proves the algebra against autograd.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -59,8 +61,8 @@ struct WordsArgs {
     int64_t ldw;
     const float* mean;    // forward: mu_q, rstd_q [B][C]
     const float* rstd;
-    const float* vec;     // forward: maskbias [B][32];  backward: u [B][32]
-    const float* Qf;      // backward: Q [B][32][32] fp32
+    const float* vec;     // forward: maskbias [B][32]
+    const float* Qf;      // backward: [B][records][1024 Q | 32 u] fp32 partial records of lavt_pwam_lang_bwd1
     const float* pbar;    // backward: Pbar [B][32]
     const bf16* P;        // backward: P [B*T][32]
     bf16* out;            // [B*T][32]
@@ -115,7 +117,11 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
         }
     }
     if constexpr (BWD) {
-        for (int e = tid; e < 1024; e += 256) Qn[(e >> 5) * 40 + (e & 31)] = (bf16)(-a.Qf[(int64_t)b * 1024 + e]);
+        for (int e = tid; e < 1024; e += 256) {
+            float q = 0.f;
+            for (int wq = 0; wq < a.n_l; ++wq) q += a.Qf[((int64_t)b * a.n_l + wq) * 1056 + e];          // (n_l carries the record count in this mode)
+            Qn[(e >> 5) * 40 + (e & 31)] = (bf16)(-q);
+        }
     }
     __syncthreads();
     {
@@ -133,7 +139,13 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
             for (int k = part; k < 32; k += 8) s += a.pbar[b * 32 + k] * (-(float)Qn[k * 40 + j]);       // Pbar Q with the bf16 Q the MFMA sees
         }
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-        if (part == 0) vec[j] = BWD ? s - a.vec[b * 32 + j] : a.vec[b * 32 + j] * LOG2E - s;
+        if (part == 0) {
+            if constexpr (BWD) {
+                float uj = 0.f;
+                for (int wq = 0; wq < a.n_l; ++wq) uj += a.Qf[((int64_t)b * a.n_l + wq) * 1056 + 1024 + j];
+                vec[j] = s - uj;
+            } else vec[j] = a.vec[b * 32 + j] * LOG2E - s;
+        }
     }
     __syncthreads();
 
@@ -396,22 +408,25 @@ __global__ __launch_bounds__(256) void pwam_lang_fwd_kernel(const bf16* __restri
 }
 
 // backward 1: from H^T = dwhat^T P [C][32] and s = colsum(dwhat) [C]: the IN-backward constants a, b per channel, dVW [32][C] (bf16, word-major),
-// and the sums over channels Q = VW' diag(b) VW'^T [32][32], u = VW' a [32] (atomics into zeroed buffers: <= C / 64 adders per address).
+// and this workgroup's share of the sums over channels Q = VW' diag(b) VW'^T [32][32], u = VW' a [32] (one record per workgroup, no atomics).
 __global__ __launch_bounds__(256) void pwam_lang_bwd1_kernel(const float* __restrict__ HT, const float* __restrict__ s, const bf16* __restrict__ VWc,
                                                              const float* __restrict__ rw, const float* __restrict__ pbar, const float* __restrict__ cov_in,
-                                                             bf16* __restrict__ dVW, float* __restrict__ Qf, float* __restrict__ u, int T, int C) {
-    // grid (C / 16, B): 16 channels per workgroup, thread (channel tid / 16, word pair tid % 16).  (64 channels per workgroup with 8 words per
+                                                             bf16* __restrict__ dVW, float* __restrict__ Qf, int T, int C) {
+    // grid (min(C / 16, 8), B): 16 channels per workgroup, thread (channel tid / 16, word pair tid % 16).  (64 channels per workgroup with 8 words per
     // thread ran 13 us at every size: ~1 300 dependent LDS operations per thread.)
     __shared__ float vw[16][33];
     __shared__ float h[16][33];
     __shared__ float cov[32][33];
     __shared__ float pb[32];
     __shared__ float av[16], bv[16];
-    const int tid = threadIdx.x, b = blockIdx.y, c0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, b = blockIdx.y;
     const float Tf = (float)T, invT = 1.0f / Tf;
     if (tid < 32) pb[tid] = pbar[b * 32 + tid];
 #pragma unroll
     for (int e = tid; e < 1024; e += 256) cov[e >> 5][e & 31] = cov_in[(int64_t)b * 1024 + e];
+    float qacc[4] = {0.f, 0.f, 0.f, 0.f}, uacc = 0.f;
+    for (int c0 = blockIdx.x * 16; c0 < C; c0 += gridDim.x * 16) {
+    __syncthreads();
 #pragma unroll
     for (int e = tid; e < 16 * 32; e += 256) {
         const int c = e >> 5, j = e & 31;
@@ -433,19 +448,22 @@ __global__ __launch_bounds__(256) void pwam_lang_bwd1_kernel(const float* __rest
     dVW[((int64_t)b * 32 + j0 + 1) * C + c0 + c] = (bf16)(rs * (h[c][j0 + 1] - Tf * pb[j0 + 1] * ac - Tf * bc * t1));
     __syncthreads();
 #pragma unroll
-    for (int e = tid; e < 1024; e += 256) {
-        const int k = e >> 5, j = e & 31;
-        float q = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, k = e >> 5, j = e & 31;
 #pragma unroll
-        for (int cc = 0; cc < 16; ++cc) q += vw[cc][k] * bv[cc] * vw[cc][j];
-        atomicAdd(Qf + (int64_t)b * 1024 + e, q);
+        for (int cc = 0; cc < 16; ++cc) qacc[i] += vw[cc][k] * bv[cc] * vw[cc][j];
     }
     if (tid < 32) {
-        float q = 0.f;
 #pragma unroll
-        for (int cc = 0; cc < 16; ++cc) q += vw[cc][tid] * av[cc];
-        atomicAdd(u + b * 32 + tid, q);
+        for (int cc = 0; cc < 16; ++cc) uacc += vw[cc][tid] * av[cc];
     }
+    }
+    // this workgroup's share of Q and u: plain stores, summed in a fixed order by the consumer (lavt_pwam_words_bwd) -- fp32 atomics here made the
+    // bf16 copy of Q, and through it the gradients, differ between runs by a rounding flip (1.5e-3 of the largest gradient, seen eager vs hipGraph)
+    float* dst = Qf + ((int64_t)b * gridDim.x + blockIdx.x) * 1056;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[tid + 256 * i] = qacc[i];
+    if (tid < 32) dst[1024 + tid] = uacc;
 }
 
 // backward 2: from G = dS^T q [32][C] (raw q) and colsum(dS) [32]: dK, the dq constants c0, c1 and K'' in channel-major layout.
@@ -488,6 +506,9 @@ int rows_grid(int tiles_per_sample, int B) {
 
 #define ST ((hipStream_t)stream)
 
+// workgroups per sample of lavt_pwam_lang_bwd1 = partial [1024 Q | 32 u] records per sample that lavt_pwam_words_bwd sums
+extern "C" int lavt_pwam_q_parts(int C) { const int n = C / 16; return n < 8 ? (n < 1 ? 1 : n) : 8; }
+
 extern "C" int lavt_pwam_words_fwd(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
                                    void* P, int B, int T, int C, int n_l, float alpha, void* stream) {
     LAVT_CHECK_ARG(q && K && mean && rstd && maskbias && P && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && C <= 2048 && n_l > 0 && n_l <= 32 && ldq % 8 == 0 && ldk % 8 == 0,
@@ -506,12 +527,12 @@ extern "C" int lavt_pwam_words_fwd(const void* q, int64_t ldq, const void* K, in
     return LAVT_OK;
 }
 
-extern "C" int lavt_pwam_words_bwd(const void* dwhat, int64_t ldx, const void* VWw, const float* Qf, const float* u, const float* pbar, const void* P,
+extern "C" int lavt_pwam_words_bwd(const void* dwhat, int64_t ldx, const void* VWw, const float* Qp, const float* pbar, const void* P,
                                    void* dS, int B, int T, int C, void* stream) {
-    LAVT_CHECK_ARG(dwhat && VWw && Qf && u && pbar && P && dS && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && C <= 2048 && ldx % 8 == 0, "lavt_pwam_words_bwd: bad arguments");
+    LAVT_CHECK_ARG(dwhat && VWw && Qp && pbar && P && dS && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && C <= 2048 && ldx % 8 == 0, "lavt_pwam_words_bwd: bad arguments");
     WordsArgs a{};
-    a.X = (const bf16*)dwhat; a.ldx = ldx; a.Wsrc = (const bf16*)VWw; a.ldw = C; a.vec = u; a.Qf = Qf; a.pbar = pbar; a.P = (const bf16*)P; a.out = (bf16*)dS;
-    a.T = T; a.C = C; a.n_l = 32; a.alpha = 1.f;
+    a.X = (const bf16*)dwhat; a.ldx = ldx; a.Wsrc = (const bf16*)VWw; a.ldw = C; a.Qf = Qp; a.pbar = pbar; a.P = (const bf16*)P; a.out = (bf16*)dS;
+    a.T = T; a.C = C; a.n_l = lavt_pwam_q_parts(C); a.alpha = 1.f;
     const size_t lds = (size_t)32 * (C + 8) * 2 + 128 + 32 * 40 * 2;
     static size_t reserved = 0;
     if (lds > 65536 && lds > reserved) {
@@ -547,10 +568,10 @@ extern "C" int lavt_pwam_lang_fwd(const void* V, int64_t ldv, const void* Wo, co
     return LAVT_OK;
 }
 
-extern "C" int lavt_pwam_lang_bwd1(const float* HT, const float* s, const void* VWc, const float* rw, const float* pbar, const float* cov, void* dVW, float* Qf, float* u,
+extern "C" int lavt_pwam_lang_bwd1(const float* HT, const float* s, const void* VWc, const float* rw, const float* pbar, const float* cov, void* dVW, float* Qp,
                                    int B, int T, int C, void* stream) {
-    LAVT_CHECK_ARG(HT && s && VWc && rw && pbar && cov && dVW && Qf && u && B > 0 && T > 0 && C >= 32, "lavt_pwam_lang_bwd1: bad arguments");
-    hipLaunchKernelGGL(pwam_lang_bwd1_kernel, dim3(C / 16, B), dim3(256), 0, ST, HT, s, (const bf16*)VWc, rw, pbar, cov, (bf16*)dVW, Qf, u, T, C);
+    LAVT_CHECK_ARG(HT && s && VWc && rw && pbar && cov && dVW && Qp && B > 0 && T > 0 && C >= 32 && C % 16 == 0, "lavt_pwam_lang_bwd1: bad arguments");
+    hipLaunchKernelGGL(pwam_lang_bwd1_kernel, dim3(lavt_pwam_q_parts(C), B), dim3(256), 0, ST, HT, s, (const bf16*)VWc, rw, pbar, cov, (bf16*)dVW, Qp, T, C);
     LAVT_CHECK_LAUNCH("lavt_pwam_lang_bwd1");
     return LAVT_OK;
 }

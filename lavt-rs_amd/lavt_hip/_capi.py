@@ -116,7 +116,7 @@ class GemmNT(C.Structure):
         ("C", vp), ("ldc", i64), ("strideC", i64), ("C2", vp), ("ldc2", i64), ("c_split", i32), ("c_rowmap", vp),
         ("c_f32", i32), ("zeros", vp), ("epi_lds", i32), ("conv_d", i32), ("conv_kd", i32), ("conv_kh", i32), ("conv_kw", i32),
         ("dact_pre", vp), ("lddact", i64), ("dact", i32), ("deq_a", vp), ("deq_b", vp), ("epi_wide", i32),
-        ("mul", vp), ("ldmul", i64), ("res_first", i32),
+        ("mul", vp), ("ldmul", i64), ("res_first", i32), ("conv_tap_split", i32),
     ]
 
 
@@ -138,6 +138,7 @@ _PROTOTYPES = {
     "lavt_abi_version": [],
     "lavt_gemm_nt": [C.POINTER(GemmNT), vp],
     "lavt_gemm_tn": [C.POINTER(GemmTN), vp],
+    "lavt_splitk_reduce": [i32, vp, i32, i64, i32, vp, i64, vp],
     "lavt_gemm_tn_pieces": [C.POINTER(GemmTN)],
     "lavt_gemm_tn_grouped": [C.POINTER(GemmTN), i32, vp],
     "lavt_window_attn_fwd": [i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
@@ -172,10 +173,11 @@ _PROTOTYPES = {
     "lavt_ln_fold": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "lavt_wmsa_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp],
     "lavt_pwam_words_fwd": [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
-    "lavt_pwam_words_bwd": [vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "lavt_pwam_words_bwd": [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "lavt_pwam_q_parts": [i32],
     "lavt_pwam_mix": [i32, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
     "lavt_pwam_lang_fwd": [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
-    "lavt_pwam_lang_bwd1": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "lavt_pwam_lang_bwd1": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "lavt_pwam_lang_bwd2": [vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, vp],
     "lavt_rowsoftmax_fwd": [i32, vp, vp, i64, i32, i32, vp],
     "lavt_rowsoftmax_bwd": [i32, vp, vp, vp, i64, i32, i32, vp],
@@ -213,7 +215,7 @@ if _cdll.lavt_abi_version() != EXPECTED_ABI:
 _cdll.lavt_last_error.restype = C.c_char_p
 _cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
 _cdll.lavt_last_error.argtypes = []
-for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces"):      # queries, not launches: never timed
+for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts"):      # queries, not launches: never timed
     setattr(lib, _name, getattr(_cdll, _name))
 
 EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)

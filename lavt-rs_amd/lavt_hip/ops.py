@@ -363,7 +363,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
             a_split=0, a_rowmap=None, conv=None, b_kmajor=False, b_tap_stride=0, alpha=1.0, bias=None, strideBias=0,
             row_scale=None, strideRowScale=0, row_scale_div=1, act=K.ACT_NONE, Cpre=None, ldcpre=0, R=None, ldr=0, C2=None, ldc2=0,
             c_split=0, c_rowmap=None, c_f32=False, a_off=0, b_off=0, c_off=0, dact_pre=None, lddact=0, dact=K.ACT_NONE, deq=None,
-            mul=None, ldmul=0, res_first=False):
+            mul=None, ldmul=0, res_first=False, conv_tap_split=0):
     """A/B/Cout are tensors; *_off are element offsets into them (column sub-blocks).  dtype torch.uint8 = e4m3 operands (A, B 1 byte per
     element; C / residual bf16) with the two dequantisation |max| pointers in `deq`."""
     f8 = dtype == torch.uint8
@@ -386,7 +386,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.c_rowmap, p.c_f32 = K.ptr(c_rowmap), int(c_f32)
     p.zeros = _zero_page(A.device)
     p.dact_pre, p.lddact, p.dact = K.ptr(dact_pre), lddact, dact
-    p.mul, p.ldmul, p.res_first = K.ptr(mul), ldmul, int(res_first)
+    p.mul, p.ldmul, p.res_first, p.conv_tap_split = K.ptr(mul), ldmul, int(res_first), conv_tap_split
     if deq is not None:
         p.deq_a, p.deq_b = deq
     if K.prof.enabled:
@@ -415,9 +415,10 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.c_conv_permute, p.split_k = int(c_conv_permute), (-1 if defer is not None else 0)     # deferred = into the zeroed flat gradient buffer: a grouped launch may split K
     p.colsum, p.strideColsum = K.ptr(colsum), strideColsum
     p.zeros = _zero_page(A.device)
-    if dtype == torch.bfloat16 and conv is None and batch == 1 and Kd >= 2048 and not side.enabled and os.environ.get("LAVT_TN_PARTIALS", "1") != "0":      # (one scratch per device: single-stream order only)
-        # scratch for split reductions through partial tiles (long-K weight gradients on few output tiles: PWAM's 1x1 convolutions over 28 800 rows)
-        need = int(K.lib.lavt_gemm_tn_pieces(C.byref(p))) * (I * J + I)
+    if dtype == torch.bfloat16 and conv is None and (batch == 1 or defer is None) and Kd >= (2048 if batch == 1 else 128) and not side.enabled and os.environ.get("LAVT_TN_PARTIALS", "1") != "0":      # (one scratch per device: single-stream order only)
+        # scratch for split reductions through partial tiles (long-K weight gradients on few output tiles: PWAM's 1x1 convolutions over 28 800 rows;
+        # batched: the per-sample word-side matrices of the fused PWAM node -- plain stores + a fixed-order sum, so the result is run-to-run identical)
+        need = batch * int(K.lib.lavt_gemm_tn_pieces(C.byref(p))) * (I * J + I)
         if need <= (16 << 20):
             scr = _tn_parts(need, A.device)
             p.partials, p.partials_floats = K.ptr(scr), (need if defer is not None else scr.numel())     # queued: flush() hands every member its own region
@@ -1515,23 +1516,22 @@ class _PwamGate(torch.autograd.Function):
         _note(f"mix1 {M}x{Cc}", 2.0 * M * Cc * KV_LD)
         K.check(K.lib.lavt_pwam_mix(1, K.ptr(P), K.ptr(VWc), K.ptr(beta), None, K.ptr(_f32(bv)), K.ptr(vpre), Cc, K.ptr(dmm), Cc, K.ptr(g), 2 * Cc, K.ptr(dwh), Cc,
                                     B, T, Cc, K.stream()))
-        # one zeroed side buffer for everything that is accumulated with atomics: H^T, s, Q, u, G, colsum(dS)
-        nz = B * (Cc * KV_LD + Cc + KV_LD * KV_LD + KV_LD + KV_LD * Cc + KV_LD)
+        # one zeroed side buffer for the targets of the split reductions (partial tiles, then += the fixed-order sum): H^T, s, G, colsum(dS)
+        nz = B * (Cc * KV_LD + Cc + KV_LD * Cc + KV_LD)
         z = torch.zeros(nz, dtype=torch.float32, device=dev)
         o = 0
         HT = z[o:o + B * Cc * KV_LD]; o += B * Cc * KV_LD
         s = z[o:o + B * Cc]; o += B * Cc
-        Qf = z[o:o + B * KV_LD * KV_LD]; o += B * KV_LD * KV_LD
-        u = z[o:o + B * KV_LD]; o += B * KV_LD
         G = z[o:o + B * KV_LD * Cc]; o += B * KV_LD * Cc
         sdS = z[o:o + B * KV_LD]
+        Qp = torch.empty(B * int(K.lib.lavt_pwam_q_parts(Cc)) * (KV_LD * KV_LD + KV_LD), dtype=torch.float32, device=dev)      # partial records, written plainly
         gemm_tn(dtype, Cc, KV_LD, T, dwh, Cc, P, KV_LD, HT, KV_LD, batch=B, strideA=T * Cc, strideB=T * KV_LD, strideC=Cc * KV_LD, colsum=s, strideColsum=Cc)
         dVW = torch.empty(B * KV_LD, Cc, dtype=dtype, device=dev)
         _note(f"lang {B}x{Cc}")
-        K.check(K.lib.lavt_pwam_lang_bwd1(K.ptr(HT), K.ptr(s), K.ptr(VWc), K.ptr(rw), K.ptr(pbar), K.ptr(cov), K.ptr(dVW), K.ptr(Qf), K.ptr(u), B, T, Cc, K.stream()))
+        K.check(K.lib.lavt_pwam_lang_bwd1(K.ptr(HT), K.ptr(s), K.ptr(VWc), K.ptr(rw), K.ptr(pbar), K.ptr(cov), K.ptr(dVW), K.ptr(Qp), B, T, Cc, K.stream()))
         dS = torch.empty_like(P)
         _note(f"words {M}x{Cc}", 2.0 * M * (Cc + KV_LD) * KV_LD)
-        K.check(K.lib.lavt_pwam_words_bwd(K.ptr(dwh), Cc, K.ptr(VWw), K.ptr(Qf), K.ptr(u), K.ptr(pbar), K.ptr(P), K.ptr(dS), B, T, Cc, K.stream()))
+        K.check(K.lib.lavt_pwam_words_bwd(K.ptr(dwh), Cc, K.ptr(VWw), K.ptr(Qp), K.ptr(pbar), K.ptr(P), K.ptr(dS), B, T, Cc, K.stream()))
         gemm_tn(dtype, KV_LD, Cc, T, dS, KV_LD, q, Cc, G, Cc, batch=B, strideA=T * KV_LD, strideB=T * Cc, strideC=KV_LD * Cc, colsum=sdS, strideColsum=KV_LD)
         if ctx.kv_sinks is not None:
             dk, dv = ctx.kv_sinks                                            # column blocks of the shared key / value gradient matrix
@@ -1941,6 +1941,14 @@ class _ConvTaps(torch.autograd.Function):
             x2q = fp8.quantize(x2, id(weight))[0] if x2 is not None else None
             gemm_nt(torch.uint8, M, Cout, taps * Cin, x1q, C1, Wq, taps * Cin, y, Cout, A2=x2q, lda2=C2, a_split=C1,
                     conv=(H, W, Cin, 0, D, kd, kh, kw), bias=_f32(bias), act=act, Cpre=pre, ldcpre=Cout, deq=(a_ptr, w_amax.data_ptr()))
+        elif _conv_split(dtype, M, Cout, Cin, C1, C2, taps, bias, act):
+            # few pixels, long reduction (decoder level 4: 1 800 rows x K = 13 824 = 60-232 tiles walking 72-216 K tiles each): the reduction is cut
+            # at tap boundaries over the batch index into fp32 partial outputs, a second small kernel adds them
+            sp = _conv_split(dtype, M, Cout, Cin, C1, C2, taps, bias, act)
+            parts = torch.empty(sp, M, Cout, dtype=torch.float32, device=x1.device)
+            gemm_nt(dtype, M, Cout, (taps // sp) * Cin, x1, C1, Wp, taps * Cin, parts, Cout, A2=x2, lda2=C2, a_split=C1, conv=(H, W, Cin, 0, D, kd, kh, kw),
+                    batch=sp, strideB=(taps // sp) * Cin, strideC=M * Cout, c_f32=True, conv_tap_split=taps // sp)
+            K.check(K.lib.lavt_splitk_reduce(K.dt(dtype), K.ptr(parts), sp, M, Cout, K.ptr(y), Cout, K.stream()))
         else:
             gemm_nt(dtype, M, Cout, taps * Cin, x1, C1, Wp, taps * Cin, y, Cout, A2=x2, lda2=C2, a_split=C1,
                     conv=(H, W, Cin, 0, D, kd, kh, kw), bias=_f32(bias), act=act, Cpre=pre, ldcpre=Cout)
@@ -1970,9 +1978,22 @@ class _ConvTaps(torch.autograd.Function):
                 # concat convolution (conv1_2: 512 + 128 input channels): N = 640 is not a multiple of the 256-wide tile, so the whole data gradient
                 # fell back to 128x128 tiles (239 us at 2x120x120).  As two launches over column blocks of the packed weight the 512-channel part
                 # runs on the 256x256 tile and the skip part on its own.
-                gemm_nt(dtype, M, C1, taps * Cout, dy, Cout, Wp, taps * Cin, dx1, C1, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True, b_tap_stride=Cin)
-                gemm_nt(dtype, M, C2, taps * Cout, dy, Cout, Wp, taps * Cin, dx2, C2, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True, b_tap_stride=Cin,
-                        b_off=C1)
+                for dxo, Cn, boff in ((dx1, C1, 0), (dx2, C2, C1)):
+                    sp = _conv_split(dtype, M, Cn, Cout, Cout, 0, taps, None, K.ACT_NONE)
+                    if sp:
+                        parts = torch.empty(sp, M, Cn, dtype=torch.float32, device=dy.device)
+                        gemm_nt(dtype, M, Cn, (taps // sp) * Cout, dy, Cout, Wp, taps * Cin, parts, Cn, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
+                                b_tap_stride=Cin, b_off=boff, batch=sp, strideC=M * Cn, c_f32=True, conv_tap_split=taps // sp)
+                        K.check(K.lib.lavt_splitk_reduce(K.dt(dtype), K.ptr(parts), sp, M, Cn, K.ptr(dxo), Cn, K.stream()))
+                    else:
+                        gemm_nt(dtype, M, Cn, taps * Cout, dy, Cout, Wp, taps * Cin, dxo, Cn, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True, b_tap_stride=Cin,
+                                b_off=boff)
+            elif x2 is None and _conv_split(dtype, M, Cin, Cout, Cout, 0, taps, None, K.ACT_NONE):
+                sp = _conv_split(dtype, M, Cin, Cout, Cout, 0, taps, None, K.ACT_NONE)
+                parts = torch.empty(sp, M, Cin, dtype=torch.float32, device=dy.device)
+                gemm_nt(dtype, M, Cin, (taps // sp) * Cout, dy, Cout, Wp, taps * Cin, parts, Cin, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
+                        b_tap_stride=Cin, batch=sp, strideC=M * Cin, c_f32=True, conv_tap_split=taps // sp)
+                K.check(K.lib.lavt_splitk_reduce(K.dt(dtype), K.ptr(parts), sp, M, Cin, K.ptr(dx1), Cin, K.stream()))
             else:
                 gemm_nt(dtype, M, Cin, taps * Cout, dy, Cout, Wp, taps * Cin, dx1, C1, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
                         b_tap_stride=Cin, C2=dx2, ldc2=C2, c_split=C1)
@@ -1989,6 +2010,19 @@ class _ConvTaps(torch.autograd.Function):
         side.run(_wgrad, (dy, x1, x2), wsink and (db is None or bsink))
         return (dx1, dx2, sinks.done(weight, dW, wsink), sinks.done(bias, db, bsink) if bias is not None else None,
                 None, None, None, None, None)
+
+
+_CONV_SPLIT_MAX_ROWS = int(os.environ.get("LAVT_CONV_SPLIT_ROWS", "2048"))
+
+
+def _conv_split(dtype, M, N, Kc, C1, C2, taps, bias, act):
+    """number of tap groups a convolution's reduction is cut into (0 = not split): bf16 tap-walking problems (channels % 64 == 0) without a fused
+    epilogue, few rows (<= 2048: the fp32 partials are M x N x splits x 4 bytes written and re-read) and a long reduction"""
+    if dtype != torch.bfloat16 or bias is not None or act != K.ACT_NONE or fp8_enabled() or M > _CONV_SPLIT_MAX_ROWS or taps % 3 or taps > 27:
+        return 0
+    if Kc % 64 or C1 % 64 or C2 % 64 or N % 8 or taps * Kc < 4096:
+        return 0
+    return int(os.environ.get("LAVT_CONV_SPLIT_N", "3")) if taps == 9 else taps // 3
 
 
 def conv3x3(x1, x2, weight, B, H, W):
