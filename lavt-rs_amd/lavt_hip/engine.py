@@ -96,8 +96,14 @@ class TrainStep:
             # ProcessGroupNCCL's watchdog thread retires the eager warm-up collectives by polling their events every ~100 ms.  Give it time to
             # empty its list before the capture window opens: a poll that lands inside the window was seen (1 run in ~10 of the 1-rank-group
             # test) to fail with hipErrorCapturedEvent and take the process down, also under the thread_local capture mode used below.
+            # Explicit drain first: every warm-up collective has been waited for (GradBuckets.finish), the device is idle (synchronize above), and a
+            # barrier puts all ranks at the same point -- after it no rank has an incomplete collective.  What remains is the watchdog's own
+            # bookkeeping: it drops completed work objects from its list on its next poll, and PyTorch exposes no call to wait for that, so the
+            # harness waits a few poll periods (TORCH_NCCL watchdog sleep: 100 ms) before opening the capture window.
             import time
-            time.sleep(float(os.environ.get("LAVT_CAPTURE_SETTLE_S", "0.5")))
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+            time.sleep(float(os.environ.get("LAVT_CAPTURE_SETTLE_S", "0.35")))
         try:
             g = torch.cuda.CUDAGraph()
             # thread_local: ProcessGroupNCCL's watchdog thread polls events of earlier (eager warm-up) collectives with hipEventQuery; under the

@@ -317,10 +317,11 @@ class _SideStreams:
 side = _SideStreams()
 
 
-def _note(shape, flops=0.0):
-    """profiler annotation of the next C-ABI launch (bench.py's in-process family timing)"""
+def _note(shape, flops=0.0, nbytes=0.0):
+    """profiler annotation of the next C-ABI launch (bench.py's in-process family timing): problem shape + algorithmic work -- flops for the
+    contractions, bytes (one read / write of every operand) for the HBM-bound kernels"""
     if K.prof.enabled:
-        K.prof.note = {"flops": flops, "shape": shape}
+        K.prof.note = {"flops": flops, "bytes": nbytes, "shape": shape}
 
 
 def _f32(p: Optional[torch.Tensor]):
@@ -804,6 +805,7 @@ class _LayerNorm(torch.autograd.Function):
         y = torch.empty(rows, C, dtype=x.dtype, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
+        _note(f"ln {rows}x{C}", nbytes=2.0 * rows * C * x.element_size())
         K.check(K.lib.lavt_layernorm_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(gather), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), K.ptr(y),
                                          K.ptr(mean), K.ptr(rstd), rows, C, eps, K.stream()))
         ctx.save_for_backward(x, gamma, mean, rstd, gather, beta)
@@ -825,6 +827,7 @@ class _LayerNorm(torch.autograd.Function):
             nblk = int(K.lib.lavt_layernorm_bwd_blocks(K.dt(x.dtype), ctx.rows, ctx.C))
             wsd = ln_deferred.alloc(nblk * 2 * ctx.C, x.device)
             if wsd is not None:
+                _note(f"ln-bwd {ctx.rows}x{ctx.C}", nbytes=(4.0 if dres is not None else 3.0) * ctx.rows * ctx.C * x.element_size())
                 K.check(K.lib.lavt_layernorm_bwd_partial(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(gather), K.ptr(_f32(gamma)), K.ptr(mean), K.ptr(rstd),
                                                          K.ptr(dx), K.ptr(wsd), wsd.numel(), K.ptr(dres), ctx.rows, ctx.C, K.stream()))
                 ln_deferred.add(wsd, nblk, ctx.C, dg, db, (gamma, beta))
@@ -878,6 +881,7 @@ class _WindowAttn(torch.autograd.Function):
         lse = torch.empty(nwin, heads, N, dtype=torch.float32, device=dev)
         nw_img = region.shape[0] if region is not None else 0
         scale = float((Cc // heads) ** -0.5)
+        _note(f"wattn {nwin * N}x{Cc} N{N}", 4.0 * nwin * heads * N * N * 32)
         K.check(K.lib.lavt_window_attn_fwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(lse),
                                            K.ptr(_f32(table)), wd, wh, ww, nwin, N, heads, Cc // heads, scale, K.stream()))
         ctx.save_for_backward(qkv, dense, region, out, lse, table)
@@ -897,6 +901,7 @@ class _WindowAttn(torch.autograd.Function):
         dtable, ts = sinks.buf(table, (R, heads))
         pieces = int(K.lib.lavt_window_attn_bwd_pieces(K.dt(qkv.dtype), nwin, N, heads, ld)) if (ts and ln_deferred.active()) else 0
         parts = ln_deferred.alloc(pieces * heads * R, qkv.device) if pieces > 0 else None
+        _note(f"wattn-bwd {nwin * N}x{Cc} N{N}", 10.0 * nwin * heads * N * N * 32)
         K.check(K.lib.lavt_window_attn_bwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout),
                                            K.ptr(lse), K.ptr(dqkv), K.ptr(_f32(table)), None if parts is not None else K.ptr(dtable), K.ptr(ws),
                                            ws.numel() if ws is not None else 0, K.ptr(parts), wd, wh, ww, nwin, N, heads, Cc // heads, scale, K.stream()))
@@ -1054,6 +1059,7 @@ class _WmsaFused(torch.autograd.Function):
             nblk = int(K.lib.lavt_layernorm_bwd_blocks(K.dt(dtype), M, Cc))
             wsd = ln_deferred.alloc(nblk * 2 * Cc, dev)
             if wsd is not None:
+                _note(f"ln-bwd {M}x{Cc}", nbytes=(4.0 if dres is not None else 3.0) * M * Cc * x.element_size())
                 K.check(K.lib.lavt_layernorm_bwd_partial(K.dt(dtype), K.ptr(dxn), K.ptr(x), None, K.ptr(_f32(gamma)), K.ptr(st[0]), K.ptr(st[1]), K.ptr(dx), K.ptr(wsd),
                                                          wsd.numel(), K.ptr(dres), M, Cc, K.stream()))
                 ln_deferred.add(wsd, nblk, Cc, dg, db, (gamma, beta))
@@ -1184,6 +1190,7 @@ def syncbn_exchange_backward(s: torch.Tensor, group):
 class _HipBnKernels:
     """The local passes of BatchNorm + ReLU on NHWC rows (csrc/norm.hip).  _BatchNormRelu talks to them through this small interface so that the
     multi-rank protocol around them (what is exchanged, when, with which counts) can be driven by a CPU stand-in in the gloo tests."""
+    fused_sinks = True          # bwd_stats can accumulate the local sums straight into the parameters' gradient sinks (the shipping backward branch)
 
     @staticmethod
     def stats(x):
@@ -1283,7 +1290,7 @@ class _BatchNormRelu(torch.autograd.Function):
         x, y, gamma, beta, mean, rstd = ctx.saved_tensors
         training, count, group, kern = ctx.cfg
         dy = dy.contiguous()
-        if training and kern is _HipBnKernels:
+        if training and getattr(kern, "fused_sinks", False):
             # the two LOCAL sums are d beta / d gamma -- accumulate them straight into the parameters' gradient sinks (when the step harness
             # provides them): no clones, no AccumulateGrad adds.  Single rank: the apply pass reads them from there; SyncBatchNorm: the apply
             # pass needs the sums over all ranks -- a stacked copy goes through ONE all-reduce (the parameters keep the local sums: DDP averages

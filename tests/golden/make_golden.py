@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--only-bert", action="store_true")
     ap.add_argument("--only-dice", action="store_true")
     ap.add_argument("--only-w12", action="store_true")
+    ap.add_argument("--only-feats", action="store_true", help="LAVTVideo.forward_feats (lib/_utils.py:110-131) on the micro video model")
     ap.add_argument("--only-full", default="", help="comma list of full-size (BASELINE.json configs) cases: swin_b,swin_t,video_pwam,video_sept")
     cli = ap.parse_args()
     if cli.only_bert:
@@ -139,6 +140,9 @@ def main():
         return
     if cli.only_dice:
         dice_cases()
+        return
+    if cli.only_feats:
+        forward_feats_case()
         return
     if cli.only_w12:
         video_cases(args, only_w12=True)
@@ -416,6 +420,38 @@ def video_cases(args_base, only_w12=False):
         keys = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in bb.state_dict().items())
         with open(os.path.join(HERE, f"state_dict_keys_video_swin_b_{tag}.txt"), "w") as f:
             f.write("\n".join(keys) + "\n")
+
+
+def forward_feats_case():
+    """_LAVTVideoSimpleDecode.forward_feats (reference lib/_utils.py:110-131) through the reference's own class: the text encoder is the shim's stub
+    (the reference ships no ./bert) returning fixed language features, everything after it -- permute, Video-Swin backbone, SimpleDecoding.forward_feats
+    (lib/mask_predictor.py:102-146), bilinear upsample -- is the reference's code.  Eval mode (running BatchNorm statistics), micro model."""
+    import lib.video_swin_transformer as rv
+    from lib import _utils as ru
+    from lib import mask_predictor as rmp
+    rv.sr_ratio = [1, 1, 1, 1]
+    a = ref_args()
+    bb = rv.MultiModalSwinTransformer3D(patch_size=(1, 4, 4), embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=(8, 7, 7),
+                                        drop_path_rate=0.0, patch_norm=True, out_indices=(0, 1, 2, 3), use_checkpoint=False,
+                                        num_heads_fusion=[1, 1, 1, 1], fusion_drop=0.0, args=a)
+    dec = rmp.SimpleDecoding(256, a)
+    frames, l, lm, _ = det_inputs(2, 64, 22, seed=321, frames=4)
+
+    class _Text(nn.Module):                      # stands where BertModel stands: (ids, attention_mask) -> ((B, N_l, 768),)
+        def forward(self, ids, attention_mask=None):
+            return (l.permute(0, 2, 1),)
+
+    model = ru._LAVTVideoSimpleDecode.__new__(ru._LAVTVideoSimpleDecode)
+    nn.Module.__init__(model)
+    model.backbone, model.classifier, model.text_encoder = bb, dec, _Text()
+    model.lazy_pred, model.seg_last = False, False
+    fill_state_dict_(nn.ModuleDict({"backbone": bb, "classifier": dec}))
+    model.eval()
+    ids = torch.zeros(2, 22, dtype=torch.long)
+    with torch.no_grad():
+        y, feats = model.forward_feats(frames, ids, lm.squeeze(-1))
+    save("video_forward_feats", seed=321, logits=y, **{f"feat{i}": f for i, f in enumerate(feats)}, nfeats=len(feats))
+    print("   forward_feats:", tuple(y.shape), [tuple(f.shape) for f in feats])
 
 
 def _full_record(name, model_params, logits, lowres, feats, tgt, loss, inputs_with_grad, extra):

@@ -67,6 +67,45 @@ def _worker(rank, world, port, bucket_mib, out):
     dist.destroy_process_group()
 
 
+def _bf16_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LAVT_BF16_BUCKETS="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lavt_hip.ddp import GradBuckets
+    torch.manual_seed(0)
+    model = Toy()
+    gb = GradBuckets(model, bucket_mib=0.0005)
+    assert gb.bf16
+    xs = [torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+    gb.zero()
+    model(xs[rank]).pow(2).mean().backward()
+    gb.finish()
+    ref = Toy()
+    torch.manual_seed(0)
+    ref = Toy()
+    grads = []
+    for r in range(world):
+        ref.zero_grad()
+        ref(xs[r]).pow(2).mean().backward()
+        grads.append({n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in ref.named_parameters()})
+    for n, p in model.named_parameters():
+        want = sum(g[n].to(torch.bfloat16).float() for g in grads) / world          # each rank's contribution rounded to bf16 before the sum
+        assert p.grad.dtype == torch.float32 and torch.allclose(p.grad, want, rtol=2e-2, atol=1e-6), n
+        exact = sum(g[n] for g in grads) / world
+        assert float((p.grad - exact).abs().max()) <= 1e-2 * float(exact.abs().max()) + 1e-7, n
+    out[rank] = True
+    dist.destroy_process_group()
+
+
+def test_bf16_grad_buckets_world2():
+    """LAVT_BF16_BUCKETS=1: buckets are reduced as bf16 copies and written back into the fp32 flat buffer: gradients = the mean of the ranks' bf16-rounded
+    gradients (within 1 % of the exact mean), .grad stays fp32"""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_bf16_worker, args=(2, port, out), nprocs=2, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
 @pytest.mark.parametrize("bucket_mib", [64.0, 0.0005])
 def test_grad_buckets_world2(bucket_mib):
     port = _free_port()
@@ -100,7 +139,12 @@ class _CpuBnKernels:
     @staticmethod
     def bwd_stats(dy, x, y, mean, rstd, gamma, beta, out=None):
         g = dy * (y > 0)
-        return g.sum(0), (g * (x - mean) * rstd).sum(0)
+        s0, s1 = g.sum(0), (g * (x - mean) * rstd).sum(0)
+        if out is not None:                     # the product's form: accumulate into the (zeroed) gradient sinks of beta / gamma
+            out[0].add_(s0)
+            out[1].add_(s1)
+            return out
+        return s0, s1
 
     @staticmethod
     def bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count):
@@ -109,10 +153,32 @@ class _CpuBnKernels:
         return gamma * rstd * (g - s[0] / count - xh * s[1] / count)
 
 
-def _syncbn_worker(rank, world, port, out):
+class _CpuBnKernelsShipping(_CpuBnKernels):
+    """the same local passes + the two entry points that select the SHIPPING multi-rank branches of _BatchNormRelu (ops.py: syncbn_gather +
+    combine_finalize forward; local sums into the gradient sinks + one stacked all-reduce backward).  combine_finalize restates
+    csrc/norm.hip:syncbn_combine_kernel: allst [world, 2, 1, C] = every rank's (sum, centred M2) over `rows` rows."""
+    fused_sinks = True
+
+    @staticmethod
+    def combine_finalize(allst, rows, eps, running_mean, running_var, momentum):
+        world = allst.shape[0]
+        a = allst.reshape(world, 2, -1)
+        n = float(rows * world)
+        gmean = a[:, 0].sum(0) / n
+        m2 = (a[:, 1] + rows * (a[:, 0] / rows - gmean) ** 2).sum(0)
+        var = m2 / n
+        if running_mean is not None:
+            running_mean.mul_(1 - momentum).add_(momentum * gmean)
+            running_var.mul_(1 - momentum).add_(momentum * var * (n / max(n - 1.0, 1.0)))
+        return gmean, torch.rsqrt(var + eps)
+
+
+
+def _syncbn_worker(rank, world, port, out, shipping=False, use_sinks=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from lavt_hip import ops
+    kern = _CpuBnKernelsShipping if shipping else _CpuBnKernels
     R, C = 37, 6
     g = torch.Generator().manual_seed(5)
     x_all = torch.randn(world * R, C, generator=g, dtype=torch.float64) * 0.5 + 3.0 * torch.arange(1, C + 1)        # large means: no E[x^2]-E[x]^2
@@ -123,8 +189,14 @@ def _syncbn_worker(rank, world, port, out):
     x = x_all[rank * R:(rank + 1) * R].clone().float().requires_grad_(True)
     gm, bt = gamma.float().requires_grad_(True), beta.float().requires_grad_(True)
     rm, rv = torch.zeros(C), torch.ones(C)
-    y = ops._BatchNormRelu.apply(x, gm, bt, rm, rv, True, 0.1, 1e-5, dist.group.WORLD, _CpuBnKernels)
-    y.backward(dy_all[rank * R:(rank + 1) * R].float())
+    if use_sinks:                               # the step harness' fused accumulation: .grad = zeroed views the op accumulates into, no gradient tensors returned
+        gm.grad, bt.grad = torch.zeros(C), torch.zeros(C)
+        ops.sinks.set([gm, bt])
+    try:
+        y = ops._BatchNormRelu.apply(x, gm, bt, rm, rv, True, 0.1, 1e-5, dist.group.WORLD, kern)
+        y.backward(dy_all[rank * R:(rank + 1) * R].float())
+    finally:
+        ops.sinks.clear()
     # single-process BatchNorm over the concatenated batch (float64)
     bn = nn.BatchNorm1d(C, eps=1e-5, momentum=0.1).double().train()
     with torch.no_grad():
@@ -142,7 +214,7 @@ def _syncbn_worker(rank, world, port, out):
     dist.all_reduce(tot)
     assert torch.allclose(tot[0].double(), bn.weight.grad, atol=1e-4) and torch.allclose(tot[1].double(), bn.bias.grad, atol=1e-4), "dgamma / dbeta"
     # eval mode never communicates and uses the running estimates
-    ye = ops._BatchNormRelu.apply(x.detach(), gm.detach(), bt.detach(), rm, rv, False, 0.1, 1e-5, None, _CpuBnKernels)
+    ye = ops._BatchNormRelu.apply(x.detach(), gm.detach(), bt.detach(), rm, rv, False, 0.1, 1e-5, None, kern)
     assert torch.allclose(ye.double(), torch.relu(bn.eval()(x_all[sl])).detach(), atol=2e-5)
     out[rank] = True
     dist.destroy_process_group()
@@ -155,6 +227,19 @@ def test_syncbn_exchange_world2():
     with mp.Manager() as mgr:
         out = mgr.dict()
         mp.spawn(_syncbn_worker, args=(2, port, out), nprocs=2, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("use_sinks", [False, True])
+def test_syncbn_shipping_branch_world2(use_sinks):
+    """The branch the GPU product takes when world > 1 (ops._BatchNormRelu with a kernel set that has combine_finalize + fused_sinks): forward =
+    syncbn_gather of every rank's (sum, centred M2) pair + ONE combination of the pairs (the stand-in restates lavt_syncbn_combine: counts
+    rows * world, layout [world, 2, 1, C]); backward = local sums into the parameters' gradient sinks (or fresh buffers without sinks) + one
+    all-reduce of a stacked copy.  Same reference as above: BatchNorm over the concatenated batch."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_syncbn_worker, args=(2, port, out, True, use_sinks), nprocs=2, join=True)
         assert dict(out) == {0: True, 1: True}
 
 

@@ -769,3 +769,30 @@ def test_wmsa_fused_forward_kernel(C, ws, H, W, shifted):
         assert ef <= 1.5 * ec + 1e-2, (k, ec, ef, report)
     assert len(report) >= 14, report
     print("\n[fused W-MSA forward, relative l2 error vs the fp32 oracle: (unfused bf16, fused bf16)]", report)
+
+
+def test_lavt_video_forward_feats_golden(golden):
+    """LAVTVideo.forward_feats (reference lib/_utils.py:110-131 + lib/mask_predictor.py:102-146) numerically: logits and the four returned
+    feature maps against vectors of the reference's own method (tests/golden/make_golden.py --only-feats; the text encoder is a stub on both
+    sides returning the same language features: the reference ships no ./bert)."""
+    from lib._utils import LAVTVideo
+    g = golden("video_forward_feats")
+    parts = _build_video("pwam")
+    frames, l, m, _ = det_inputs(2, 64, 22, seed=int(g["seed"]), frames=4)
+    frames, l, m = frames.to(DEV), l.to(DEV), m.to(DEV)
+
+    class _Text(torch.nn.Module):
+        def forward(self, ids, attention_mask=None):
+            return (l.permute(0, 2, 1),)
+
+    model = LAVTVideo.__new__(LAVTVideo)
+    torch.nn.Module.__init__(model)
+    model.backbone, model.classifier, model.text_encoder = parts["backbone"], parts["classifier"], _Text()
+    model.lazy_pred, model.seg_last = False, False
+    model.eval()
+    with torch.no_grad():
+        y, feats = model.forward_feats(frames, torch.zeros(2, 22, dtype=torch.long, device=DEV), m.squeeze(-1))
+    assert len(feats) == int(g["nfeats"])
+    close(y, g["logits"], 1e-3, "forward_feats logits")
+    for i, f in enumerate(feats):
+        close(f, g[f"feat{i}"], 1e-3, f"forward_feats feature {i}")
