@@ -23,9 +23,18 @@ def set_compute_dtype(dtype) -> None:
 
 
 def compute_dtype() -> torch.dtype:
-    """bf16 inside torch.autocast('cuda', dtype=bfloat16) (the caller's AMP hook, train.py:452), else the configured dtype."""
-    if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
-        return torch.bfloat16
+    """bf16 inside torch.autocast('cuda', dtype=bfloat16), else the configured dtype.  The reference's own AMP hook is
+    `torch.cuda.amp.autocast()` (train.py:452), i.e. float16: this path has no fp16 kernels (its low-precision type is bf16: same exponent range
+    as fp32, no loss scaling), so an fp16 autocast region is REFUSED rather than silently run in another precision -- use
+    torch.autocast('cuda', dtype=torch.bfloat16) or lavt_hip.set_compute_dtype (contract narrowings)."""
+    if torch.is_autocast_enabled():
+        adt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
+        if adt == torch.bfloat16:
+            return torch.bfloat16
+        if adt == torch.float16 and os.environ.get("LAVT_ALLOW_FP16_AUTOCAST", "0") != "1":
+            raise RuntimeError("liblavt_hip: called inside torch.autocast(dtype=float16) (the reference's torch.cuda.amp.autocast(), train.py:452); this path "
+                               "computes in fp32 or bf16 only -- use torch.autocast('cuda', dtype=torch.bfloat16) or lavt_hip.set_compute_dtype('bf16') "
+                               "(LAVT_ALLOW_FP16_AUTOCAST=1 ignores the region and uses the configured dtype)")
     return _state["dtype"]
 
 

@@ -132,8 +132,14 @@ def _check_forward(g, feats, lowres, logits, tgt, loss, fp32):
     else:
         agree = float((pred == ref_mask).float().mean())
         r["agree"] = agree
-        # (SepTPWAM's 27-tap convolutions: the reference's own bf16 run moves logits by up to 1.1 sigma there, so a 0.25-sigma margin is not decisive)
-        assert r["iou_decisive_q"] >= 0.98 or float(g["refbf16_maxerr"]) > 0.5 * sigma, r
+        # Gate on the decisive pixels (|margin| > 0.25 sigma): IoU >= 0.98 -- for the configurations whose reference-bf16 run itself keeps logits
+        # within 0.5 sigma.  Video-SepTPWAM does not (27-tap convolutions: the reference's own autocast run moves logits by up to 1.1 sigma, its
+        # mask IoU is 0.757), so a 0.25-sigma margin is not decisive there and that configuration is gated as "no worse than the reference's own
+        # bf16 run" by the agreement / IoU / max-error asserts below (this build: IoU on decisive pixels 0.924, mask IoU 0.770).
+        if float(g["refbf16_maxerr"]) <= 0.5 * sigma:
+            assert r["iou_decisive_q"] >= 0.98, r
+        else:
+            r["decisive_gate"] = "not applied: reference-bf16 max error %.2f sigma > 0.5 sigma" % (float(g["refbf16_maxerr"]) / sigma)
         assert r["dloss"] <= 2e-2, r
         assert agree >= float(g["refbf16_agree"]) - 0.005, r
         assert r["mask_iou"] >= float(g["refbf16_iou"]) - 0.02, r

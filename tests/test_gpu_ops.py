@@ -820,3 +820,14 @@ def test_fp8_linear_matches_quantised_oracle(monkeypatch):
     ref = F8.linear_fp8(x, w, b, float(x.float().abs().max()), float(w.abs().max()))
     assert float((y.detach().float().cpu() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
     assert float((xd.grad.float().cpu() - w.sum(0).to(torch.bfloat16).float()).abs().max()) <= 3e-2 * float(w.sum(0).abs().max())
+
+
+def test_fp16_autocast_is_refused():
+    """The reference's AMP hook is torch.cuda.amp.autocast() = float16 (train.py:452).  This path computes in fp32 / bf16 only: an fp16 autocast region
+    raises instead of silently running the configured dtype (contract narrowings); a bf16 region selects bf16."""
+    from lavt_hip.runtime import compute_dtype
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert compute_dtype() == torch.bfloat16
+    with torch.autocast("cuda", dtype=torch.float16):
+        with pytest.raises(RuntimeError, match="float16"):
+            compute_dtype()

@@ -8,7 +8,7 @@ import torch
 from lavt_hip import _capi as K, ops
 dev, bf = "cuda:0", torch.bfloat16
 g = torch.Generator().manual_seed(21)
-M, Mw, Cc = 1800, 2592, 512
+M, Mw, Cc = 1800, int(os.environ.get("MW", "2592")), 512
 wmap = torch.randint(0, M, (Mw,), generator=g, dtype=torch.int32).to(dev)
 mk = lambda r, c: (torch.randn(r, c, generator=g) * 0.5).to(dev).to(bf)
 probs = [(4 * Cc, Cc, M, mk(M, 4 * Cc), mk(M, Cc), {}), (Cc, 4 * Cc, M, mk(M, Cc), mk(M, 4 * Cc), {}),
