@@ -132,6 +132,15 @@ typedef struct lavt_gemm_nt {
      * fp32 partial outputs for the decoder's small-pixel-count convolutions (1 800 rows x K = 13 824: 60-232 tiles with serial chains of 72-216
      * K tiles otherwise); lavt_splitk_reduce adds the partials.  Tap-walking fast path only (conv_kc % 64 == 0). */
     int32_t conv_tap_split;
+    /* LayerNorm-folded A operand (ABI v4): ln_wsum != NULL makes this GEMM compute LN(A) B^T + b without a LayerNorm launch: A = the RAW rows of the
+     * norm's input, B = the gamma-folded weight and bias = the folded bias of lavt_ln_fold, ln_wsum [N] its row sums; the kernel accumulates the
+     * row statistics from the A tiles it streams (K = the normalised width: every tile walks all of it) and applies rstd (acc - mu wsum_n) before the
+     * epilogue.  ln_mean / ln_rstd (optional, [M]) receive the statistics for the LayerNorm backward.  bf16, plain k-contiguous problems only
+     * (norm2 -> fc1 of a Swin block, lib/backbone.py:243 + :24-30). */
+    const float* ln_wsum;
+    float* ln_mean;
+    float* ln_rstd;
+    float ln_eps;
 } lavt_gemm_nt_t;
 
 int lavt_gemm_nt(const lavt_gemm_nt_t* p, void* stream);
@@ -263,6 +272,12 @@ int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, const int32_t* 
 int lavt_layernorm_bwd_blocks(int dtype, int rows, int C);
 int lavt_layernorm_bwd_partial(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma, const float* mean,
                                const float* rstd, void* dx, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream);
+/* LayerNorm backward that also writes the LayerNorm OUTPUT xn = xhat * gamma + beta (ABI v4): for a forward that folded the norm into the consumer's GEMM
+ * (lavt_gemm_nt.ln_wsum) and never materialised it; the consumer's weight gradient reads xn.  _partial_xn = the deferred-reduction form. */
+int lavt_layernorm_bwd_partial_xn(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                  void* dx, void* xn, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream);
+int lavt_layernorm_bwd_xn(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                          void* dx, void* xn, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream);
 int lavt_reduce_partials_multi(const int64_t* desc, int n, void* stream);
 /* dres (optional, [rows][C], not with gather): gradient of the residual stream that bypassed the LayerNorm (x -> LN(x) and x -> + ...):
  * dx = LN'(dy) + dres in the same pass, instead of a separate element-wise add of the two gradients of x */

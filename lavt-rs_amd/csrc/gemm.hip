@@ -448,6 +448,7 @@ extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
                     ((uintptr_t)p.C % 16) == 0 && (!p.C2 || ((uintptr_t)p.C2 % 16) == 0) && (!p.Cpre || ((uintptr_t)p.Cpre % 16) == 0) && (p.strideC % 8 == 0)) ? 1 : 0; }
     const int rc2 = lavt_gemm_nt_v2(p, st);          // bf16 LDS-DMA pipeline (gemm_v2.hip); 1 = not applicable
     if (rc2 != 1) return rc2;
+    LAVT_CHECK_ARG(p.ln_wsum == nullptr, "lavt_gemm_nt: ln_wsum (LayerNorm-folded A operand) exists on the bf16 LDS-DMA path only");
     LAVT_CHECK_ARG(p.dact_pre == nullptr, "lavt_gemm_nt: dact_pre (fused activation gradient) exists on the bf16 LDS-DMA path only");
     LAVT_CHECK_ARG(p.dtype != LAVT_FP8, "lavt_gemm_nt: fp8 operands exist on the LDS-DMA path only");
     return p.dtype == LAVT_F32 ? dispatch_nt<float>(p, st) : dispatch_nt<bf16>(p, st);

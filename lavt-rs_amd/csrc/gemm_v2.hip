@@ -126,9 +126,14 @@ typedef __attribute__((__vector_size__(8 * sizeof(int)))) int i32x8;
 // the chunk swizzle and the fragment reads are unchanged; a lane feeds one v_mfma_scale_f32_16x16x128_f8f6f4 with the two chunks g and g + 4
 // (g = lane / 16) of its row -- which 32 k of the 128 a lane group holds is immaterial as long as A and B agree (unit block scales); these
 // two are the chunks the bf16 fragments of k-steps 0 and 1 read, i.e. the bank-conflict-free pattern (chunks 2g, 2g+1 conflict 2-way).
-template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false>
+// LNA (LayerNorm-folded A operand, round 3): A holds the RAW rows of a LayerNorm input, B the gamma-folded weight (lavt_ln_fold).  Every workgroup
+// streams the whole K = C of its rows, so the row sums / sums of squares are accumulated from the resident A tiles (v_dot2c_f32_bf16) and the
+// accumulators become rstd_m (acc - mu_m wsum_n) before the ordinary epilogue, whose `bias` is then biasp = b + W beta: the LayerNorm launch and its
+// [M, C] output disappear (norm2 -> fc1 of a Swin block, reference lib/backbone.py:243 + :24-30).
+template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false, bool LNA = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_nt_t p) {
     constexpr bool SIMPLE = MODE == 1, CONVFAST = MODE == 2;
+    static_assert(!LNA || (MODE == 1 && !BKM && !DACT && !F8), "LNA: plain k-contiguous problems");
     using T = typename std::conditional<F8, unsigned char, bf16>::type;
     constexpr int BK = F8 ? 128 : 64, EPC = F8 ? 16 : 8;
     static_assert(!(F8 && (BKM || DACT)), "fp8: k-contiguous operands, plain epilogue");
@@ -352,6 +357,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ktiles = (p.K + BK - 1) / BK;
+    constexpr int LN_SU = LNA ? (BM * 8) / (WAVES * 64) : 1;           // 16-byte chunks of an A tile per thread
+    static_assert(!LNA || LN_SU * WAVES * 64 == BM * 8, "LNA: whole chunks per thread");
+    float ln_s1[LN_SU], ln_s2[LN_SU];
+#pragma unroll
+    for (int u = 0; u < LN_SU; ++u) { ln_s1[u] = 0.f; ln_s2[u] = 0.f; }
+    typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2_t;
 #pragma unroll
     for (int t = 0; t < STAGES - 1; ++t)
         if (t < ktiles) issue(t, t);
@@ -359,6 +370,22 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         wait_groups<L>(min(STAGES - 2, ktiles - 1 - kt));          // tile kt landed; up to STAGES-2 younger tiles stay in flight
         __builtin_amdgcn_s_barrier();
         if (kt + STAGES - 1 < ktiles) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        if constexpr (LNA) {
+            const bf16* tA = reinterpret_cast<const bf16*>(smem + (kt % STAGES) * STAGE_BYTES);
+            const bf16x2_t ones2 = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+            for (int u = 0; u < LN_SU; ++u) {
+                const int row = (tid >> 3) + (WAVES * 8) * u;
+                const uint4 c4 = *reinterpret_cast<const uint4*>(tA + row * 64 + (tid & 7) * 8);      // any physical chunk order: sums only
+                const unsigned wv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bf16x2_t v2 = __builtin_bit_cast(bf16x2_t, wv[e]);
+                    ln_s1[u] = __builtin_amdgcn_fdot2_f32_bf16(v2, ones2, ln_s1[u], false);
+                    ln_s2[u] = __builtin_amdgcn_fdot2_f32_bf16(v2, v2, ln_s2[u], false);
+                }
+            }
+        }
         if constexpr (F8) {
             const bf16* cA = reinterpret_cast<const bf16*>(smem + (kt % STAGES) * STAGE_BYTES);          // byte image identical to a bf16 [rows][64] tile
             const bf16* cB = reinterpret_cast<const bf16*>(smem + (kt % STAGES) * STAGE_BYTES + A_BYTES);
@@ -450,6 +477,40 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         nt_epilogue<bf16, MI, NI>(q, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
         return;
     } else {
+    if constexpr (LNA) {
+        __syncthreads();                                   // every wave is done with the ring: the row statistics take its first bytes
+        float* ln_mu = reinterpret_cast<float*>(smem);
+        float* ln_rs = ln_mu + BM;
+        const float invK = 1.0f / (float)p.K;
+#pragma unroll
+        for (int u = 0; u < LN_SU; ++u) {
+            float t1 = ln_s1[u], t2 = ln_s2[u];
+            t1 += __shfl_xor(t1, 1, 64); t1 += __shfl_xor(t1, 2, 64); t1 += __shfl_xor(t1, 4, 64);
+            t2 += __shfl_xor(t2, 1, 64); t2 += __shfl_xor(t2, 2, 64); t2 += __shfl_xor(t2, 4, 64);
+            if ((tid & 7) == 0) {
+                const int row = (tid >> 3) + (WAVES * 8) * u;
+                const float m1 = t1 * invK, rs = rsqrtf(fmaxf(t2 * invK - m1 * m1, 0.f) + p.ln_eps);
+                ln_mu[row] = m1;
+                ln_rs[row] = rs;
+                if (tile_n == 0 && m0 + row < p.M && p.ln_mean) { p.ln_mean[m0 + row] = m1; p.ln_rstd[m0 + row] = rs; }      // for the LayerNorm backward
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int ml = wm * WM + i * 16 + (lane & 15);
+            const float mu = ln_mu[ml], rs = ln_rs[ml];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * WN + j * 16 + 4 * (lane >> 4);
+                float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n + 3 < p.N) w4 = *reinterpret_cast<const float4*>(p.ln_wsum + n);
+                else { float t[4] = {0.f, 0.f, 0.f, 0.f}; for (int r = 0; r < 4; ++r) if (n + r < p.N) t[r] = p.ln_wsum[n + r]; w4 = make_float4(t[0], t[1], t[2], t[3]); }
+                acc[i][j][0] = rs * (acc[i][j][0] - mu * w4.x); acc[i][j][1] = rs * (acc[i][j][1] - mu * w4.y);
+                acc[i][j][2] = rs * (acc[i][j][2] - mu * w4.z); acc[i][j][3] = rs * (acc[i][j][3] - mu * w4.w);
+            }
+        }
+    }
     if constexpr (DACT) { nt_epilogue<T, MI, NI, true>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz); return; }
     if (!p.epi_lds || p.mul || p.c_f32 || (p.ldc % 8) || (p.C2 && (p.ldc2 % 8 || p.c_split % 8)) || (p.R && p.ldr % 8) || (p.Cpre && p.ldcpre % 8))
         nt_epilogue<T, MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
@@ -461,20 +522,30 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
 static inline int conv_taps_of(const lavt_gemm_nt_t& p) {
     return (p.conv_kd > 0 ? p.conv_kd : 1) * (p.conv_kh > 0 ? p.conv_kh : 3) * (p.conv_kw > 0 ? p.conv_kw : 3);
 }
-template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false> int launch_nt_v2_(const lavt_gemm_nt_t& p, hipStream_t st) {
+template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false, bool LNA = false> int launch_nt_v2_(const lavt_gemm_nt_t& p, hipStream_t st) {
     constexpr size_t lds = STAGES * (size_t)(BM * 128 + BN * 128);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8, LNA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             lavt_set_error("lavt_gemm_nt(v2): cannot reserve %zu bytes of LDS", lds);
             return LAVT_ERR_LAUNCH;
         }
         attr_set = true;
     }
     dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch);
-    hipLaunchKernelGGL((gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8>), grid, dim3(WAVES * 64), lds, st, p);
+    hipLaunchKernelGGL((gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8, LNA>), grid, dim3(WAVES * 64), lds, st, p);
     LAVT_CHECK_LAUNCH("lavt_gemm_nt(v2)");
     return LAVT_OK;
+}
+// LayerNorm-folded A operand (ln_wsum != NULL): plain k-contiguous problems whose workgroups see whole rows (every tile walks all of K)
+int launch_nt_v2_lna(const lavt_gemm_nt_t& p, hipStream_t st) {
+    if (p.b_kmajor || p.conv_kc > 0 || p.A2 || p.a_rowmap || p.K % 64 || p.batch != 1 || p.dact_pre || !p.bias || p.alpha != 1.0f) {
+        lavt_set_error("lavt_gemm_nt: ln_wsum (LayerNorm-folded A) needs a plain k-contiguous problem: no taps / concat / row gather / batch, K %% 64 == 0, bias = folded bias, alpha = 1");
+        return LAVT_ERR_INVALID;
+    }
+    const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128), tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
+    if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_<128, 128, false, 2, 8, 1, false, false, true>(p, st) : launch_nt_v2_<128, 128, false, 4, 8, 1, false, false, true>(p, st);
+    return tiles64 >= 600 ? launch_nt_v2_<64, 64, false, 2, 4, 1, false, false, true>(p, st) : launch_nt_v2_<64, 64, false, 4, 4, 1, false, false, true>(p, st);
 }
 // fp8 operands (LAVT_FP8): k-contiguous A and B, 128-element K tiles; 128x128 / 8 waves when that fills the chip, else 64x64 / 4 waves
 template <int BM, int BN, int STAGES, int WAVES> int launch_nt_v2_f8(const lavt_gemm_nt_t& p, hipStream_t st) {
@@ -997,6 +1068,7 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     const char* e = getenv("LAVT_GEMM_V2");
     if (e && e[0] == '0') return 1;
     if (p.lda % 8 || p.ldb % 8 || (p.A2 && p.lda2 % 8)) return 1;
+    if (p.ln_wsum) return launch_nt_v2_lna(p, st);
     if (p.dact_pre) return launch_nt_v2_dact(p, st);
     // Dispatch measured on MI355X (tools/gemm_bench.py, hipGraph-timed): 128x128 tile with 8 waves (2 per SIMD: one wave's DMA issue and
     // LDS reads hide under the other's MFMAs) and a 2-stage ring (64-80 KiB -> 2 workgroups per CU) once there are >= 200 such tiles;

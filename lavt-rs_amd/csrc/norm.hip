@@ -87,7 +87,8 @@ __global__ __launch_bounds__(WAVES * 64) void layernorm_bwd_kernel(const T* __re
                                                             const int32_t* __restrict__ gather, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float* __restrict__ partials, const T* __restrict__ dres, int rows, int C) {
+                                                            float* __restrict__ partials, const T* __restrict__ dres, int rows, int C,
+                                                            T* __restrict__ xn_out, const float* __restrict__ beta) {
     // CPL = chunks per lane (compile time: the row arrays are exactly as large as needed; LPR < 64 only with CPL == 1)
     constexpr int EPC = Chunk<T>::N, MAXC = CPL, RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, lir = lane % LPR, wave = threadIdx.x >> 6;
@@ -125,6 +126,12 @@ __global__ __launch_bounds__(WAVES * 64) void layernorm_bwd_kernel(const T* __re
                 s1 += gg; s2 += gg * xh[k];
                 dg[k] += fg[e] * xh[k];
                 db[k] += fg[e];
+            }
+            if (xn_out && on) {          // the LayerNorm OUTPUT, for a consumer whose forward folded the norm into its GEMM (the weight gradient's operand)
+                float fy[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) fy[e] = xh[c * EPC + e] * gamma[ch * EPC + e] + beta[ch * EPC + e];
+                *reinterpret_cast<uint4*>(xn_out + row * C + ch * EPC) = f_to_chunk<T>(fy);
             }
         }
         s1 = group_sum<LPR>(s1) / C; s2 = group_sum<LPR>(s2) / C;
@@ -555,7 +562,7 @@ extern "C" int lavt_layernorm_bwd_blocks(int dtype, int rows, int C) { int a, b;
 
 static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
                               const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats,
-                              const void* dres, int rows, int C, void* stream, bool partial_only) {
+                              const void* dres, int rows, int C, void* stream, bool partial_only, void* xn_out = nullptr, const float* beta = nullptr) {
     const int epc = dtype == LAVT_F32 ? 4 : 8;
     LAVT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && (partial_only || (dgamma && dbeta)) && rows > 0, "lavt_layernorm_bwd: bad arguments");
     LAVT_CHECK_ARG(C > 0 && C <= 2048 && C % epc == 0 && (!gather || (C / 4) % epc == 0), "lavt_layernorm_bwd: unsupported C=%d", C);
@@ -565,7 +572,7 @@ static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const in
     const int blocks = ln_bwd_geometry(dtype, rows, C, &lpr, &cpl, &waves);
     float* partials = (ws && ws_floats >= (int64_t)blocks * 2 * C) ? ws : nullptr;
     LAVT_CHECK_ARG(!partial_only || partials, "lavt_layernorm_bwd_partial: scratch of %ld floats needed", (long)blocks * 2 * C);
-#define LN_BWD(LPR_, CPL_, WV_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_, CPL_, WV_>), dim3(blocks), dim3(WV_ * 64), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, (const T*)dres, rows, C)
+#define LN_BWD(LPR_, CPL_, WV_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_, CPL_, WV_>), dim3(blocks), dim3(WV_ * 64), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, (const T*)dres, rows, C, (T*)xn_out, beta)
     DISPATCH_T(dtype, "lavt_layernorm_bwd",
                if (waves == 8) { if (lpr == 16) LN_BWD(16, 1, 8); else if (lpr == 32) LN_BWD(32, 1, 8); else if (cpl == 1) LN_BWD(64, 1, 8); else LN_BWD(64, 2, 8); }
                else if (lpr == 16) LN_BWD(16, 1, 4); else if (lpr == 32) LN_BWD(32, 1, 4);
@@ -583,6 +590,18 @@ extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, cons
 extern "C" int lavt_layernorm_bwd_partial(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma, const float* mean,
                                           const float* rstd, void* dx, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream) {
     return layernorm_bwd_impl(dtype, dy, x, gather, gamma, mean, rstd, dx, nullptr, nullptr, ws, ws_floats, dres, rows, C, stream, true);
+}
+// the same + the LayerNorm output xn = xhat * gamma + beta written on the way (no gather form): for a forward that folded the norm into the consumer's
+// GEMM (lavt_gemm_nt.ln_wsum) and therefore never materialised it -- the consumer's weight gradient reads it
+extern "C" int lavt_layernorm_bwd_partial_xn(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                             void* dx, void* xn, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream) {
+    LAVT_CHECK_ARG(xn && beta, "lavt_layernorm_bwd_partial_xn: xn and beta required");
+    return layernorm_bwd_impl(dtype, dy, x, nullptr, gamma, mean, rstd, dx, nullptr, nullptr, ws, ws_floats, dres, rows, C, stream, true, xn, beta);
+}
+extern "C" int lavt_layernorm_bwd_xn(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                     void* dx, void* xn, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream) {
+    LAVT_CHECK_ARG(xn && beta, "lavt_layernorm_bwd_xn: xn and beta required");
+    return layernorm_bwd_impl(dtype, dy, x, nullptr, gamma, mean, rstd, dx, dgamma, dbeta, ws, ws_floats, dres, rows, C, stream, false, xn, beta);
 }
 extern "C" int lavt_reduce_partials_multi(const int64_t* desc, int n, void* stream) {
     LAVT_CHECK_ARG(desc && n > 0, "lavt_reduce_partials_multi: bad arguments");

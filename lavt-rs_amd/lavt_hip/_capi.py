@@ -117,6 +117,7 @@ class GemmNT(C.Structure):
         ("c_f32", i32), ("zeros", vp), ("epi_lds", i32), ("conv_d", i32), ("conv_kd", i32), ("conv_kh", i32), ("conv_kw", i32),
         ("dact_pre", vp), ("lddact", i64), ("dact", i32), ("deq_a", vp), ("deq_b", vp), ("epi_wide", i32),
         ("mul", vp), ("ldmul", i64), ("res_first", i32), ("conv_tap_split", i32),
+        ("ln_wsum", vp), ("ln_mean", vp), ("ln_rstd", vp), ("ln_eps", f32),
     ]
 
 
@@ -156,6 +157,8 @@ _PROTOTYPES = {
     "lavt_layernorm_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
     "lavt_layernorm_bwd_blocks": [i32, i32, i32],
     "lavt_layernorm_bwd_partial": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
+    "lavt_layernorm_bwd_partial_xn": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
+    "lavt_layernorm_bwd_xn": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
     "lavt_reduce_partials_multi": [vp, i32, vp],
     "lavt_colstats": [i32, vp, vp, vp, vp, i64, i32, i32, i32, vp],
     "lavt_syncbn_combine": [vp, i32, f32, f32, vp, vp, vp, vp, f32, i32, vp],

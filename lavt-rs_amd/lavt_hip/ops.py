@@ -364,7 +364,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
             a_split=0, a_rowmap=None, conv=None, b_kmajor=False, b_tap_stride=0, alpha=1.0, bias=None, strideBias=0,
             row_scale=None, strideRowScale=0, row_scale_div=1, act=K.ACT_NONE, Cpre=None, ldcpre=0, R=None, ldr=0, C2=None, ldc2=0,
             c_split=0, c_rowmap=None, c_f32=False, a_off=0, b_off=0, c_off=0, dact_pre=None, lddact=0, dact=K.ACT_NONE, deq=None,
-            mul=None, ldmul=0, res_first=False, conv_tap_split=0):
+            mul=None, ldmul=0, res_first=False, conv_tap_split=0, ln=None):
     """A/B/Cout are tensors; *_off are element offsets into them (column sub-blocks).  dtype torch.uint8 = e4m3 operands (A, B 1 byte per
     element; C / residual bf16) with the two dequantisation |max| pointers in `deq`."""
     f8 = dtype == torch.uint8
@@ -388,6 +388,8 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.zeros = _zero_page(A.device)
     p.dact_pre, p.lddact, p.dact = K.ptr(dact_pre), lddact, dact
     p.mul, p.ldmul, p.res_first, p.conv_tap_split = K.ptr(mul), ldmul, int(res_first), conv_tap_split
+    if ln is not None:          # (wsum, mean out, rstd out, eps): LayerNorm-folded A operand
+        p.ln_wsum, p.ln_mean, p.ln_rstd, p.ln_eps = K.ptr(ln[0]), K.ptr(ln[1]), K.ptr(ln[2]), ln[3]
     if deq is not None:
         p.deq_a, p.deq_b = deq
     if K.prof.enabled:
@@ -778,6 +780,98 @@ class _Mlp(torch.autograd.Function):
                 grads += [sinks.done(w, wbuf, wsink), sinks.done(b, bbuf, bsink) if b is not None else None]
         dw2, db2, dw1, db1 = grads
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res and ctx.needs_input_grad[5] else None), None
+
+
+@K.scoped
+class _LnMlp(torch.autograd.Function):
+    """x + DropPath(fc2(GELU(fc1(LN(x))))) -- norm2 + Mlp + residual of a Swin block (reference lib/backbone.py:243-245, 24-30) as ONE autograd node
+    whose forward has no LayerNorm launch: fc1 contracts the RAW rows with the gamma-folded weight and applies the normalisation in its epilogue
+    (lavt_gemm_nt.ln_wsum: row statistics from the A tiles the GEMM streams anyway).  Backward: fc2 data gradient with GELU' in the epilogue ->
+    fc1 data gradient -> LayerNorm backward, which also writes the LayerNorm output the forward never materialised (the fc1 weight gradient's
+    operand) and adds the residual branch's gradient -> the two weight gradients (grouped)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w1, b1, w2, b2, eps, o: LinOpts):
+        x = x.contiguous()
+        dtype, dev = x.dtype, x.device
+        M, Cin = x.shape
+        Wg, wsum, biasp = weights.get_lnfold(w1, b1, gamma, beta)
+        W2 = weights.get(w2, dtype, "lin")
+        Hd, Cout = Wg.shape[0], W2.shape[0]
+        pre = torch.empty(M, Hd, dtype=dtype, device=dev)
+        h = torch.empty_like(pre)
+        st = torch.empty(2, M, dtype=torch.float32, device=dev)
+        gemm_nt(dtype, M, Hd, Cin, x, Cin, Wg, Cin, h, Hd, bias=biasp, act=K.ACT_GELU, Cpre=pre, ldcpre=Hd, ln=(wsum, st[0], st[1], eps))
+        y = torch.empty(M, Cout, dtype=dtype, device=dev)
+        gemm_nt(dtype, M, Cout, Hd, h, Hd, W2, Hd, y, Cout, bias=_f32(b2), row_scale=o.row_scale, row_scale_div=o.row_scale_div, R=x, ldr=Cout)
+        ctx.save_for_backward(x, gamma, beta, w1, b1, w2, b2, pre, h, st)
+        ctx.o = o
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, w1, b1, w2, b2, pre, h, st = ctx.saved_tensors
+        o = ctx.o
+        dtype, dev = x.dtype, x.device
+        dy = dy.contiguous()
+        W1, W2 = weights.get(w1, dtype, "lin"), weights.get(w2, dtype, "lin")
+        Hd, Cin = W1.shape
+        Cout = W2.shape[0]
+        M = x.shape[0]
+        dpre = torch.empty_like(pre)
+        gemm_nt(dtype, M, Hd, Cout, dy, Cout, W2, Hd, dpre, Hd, b_kmajor=True, row_scale=o.row_scale, row_scale_div=o.row_scale_div,
+                dact_pre=pre, lddact=Hd, dact=K.ACT_GELU)
+        dxn = torch.empty_like(x)
+        gemm_nt(dtype, M, Cin, Hd, dpre, Hd, W1, Cin, dxn, Cin, b_kmajor=True)
+        # LayerNorm backward: dx = LN'(dxn) + dy (the residual branch), xn written on the way
+        dx = torch.empty_like(x)
+        xn = torch.empty_like(x)
+        dg, gs = sinks.buf(gamma, (Cin,))
+        db, bs_ = sinks.buf(beta, (Cin,))
+        done = False
+        _note(f"ln-bwd {M}x{Cin}", nbytes=5.0 * M * Cin * x.element_size())
+        if gs and bs_ and ln_deferred.active():
+            nblk = int(K.lib.lavt_layernorm_bwd_blocks(K.dt(dtype), M, Cin))
+            wsd = ln_deferred.alloc(nblk * 2 * Cin, dev)
+            if wsd is not None:
+                K.check(K.lib.lavt_layernorm_bwd_partial_xn(K.dt(dtype), K.ptr(dxn), K.ptr(x), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), K.ptr(st[0]), K.ptr(st[1]), K.ptr(dx),
+                                                            K.ptr(xn), K.ptr(wsd), wsd.numel(), K.ptr(dy), M, Cin, K.stream()))
+                ln_deferred.add(wsd, nblk, Cin, dg, db, (gamma, beta))
+                g_g = g_be = None
+                done = True
+        if not done:
+            wsl = _scratch(int(K.lib.lavt_layernorm_bwd_blocks(K.dt(dtype), M, Cin)) * 2 * Cin, dev)
+            K.check(K.lib.lavt_layernorm_bwd_xn(K.dt(dtype), K.ptr(dxn), K.ptr(x), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), K.ptr(st[0]), K.ptr(st[1]), K.ptr(dx), K.ptr(xn),
+                                                K.ptr(dg), K.ptr(db), K.ptr(wsl), wsl.numel(), K.ptr(dy), M, Cin, K.stream()))
+            g_g, g_be = sinks.done(gamma, dg, gs), sinks.done(beta, db, bs_)
+        binary = o.row_scale is not None and o.row_scale_value != 0.0
+        grads = []
+        for (w, b, g, inp, n, kd, rs) in ((w2, b2, dy, h, Cout, Hd, True), (w1, b1, dpre, xn, Hd, Cin, False)):
+            wbuf, wsink = sinks.buf(w, (n, kd))
+            bbuf, bsink = sinks.buf(b, (n,)) if b is not None else (None, True)
+            kw = dict(a_rowscale=o.row_scale, a_rowscale_div=o.row_scale_div, a_rowscale_binary=binary, alpha=o.row_scale_value if binary else 1.0) if rs and o.row_scale is not None else {}
+            if wgrads.active() and wsink and bsink and (not kw or binary):
+                gemm_tn(dtype, n, kd, M, g, n, inp, kd, wbuf, kd, colsum=bbuf, defer=wgrads, **kw)
+                wgrads.notify(w)
+                if b is not None:
+                    wgrads.notify(b)
+                grads += [None, None]
+            else:
+                gemm_tn(dtype, n, kd, M, g, n, inp, kd, wbuf, kd, colsum=bbuf, **kw)
+                grads += [sinks.done(w, wbuf, wsink), sinks.done(b, bbuf, bsink) if b is not None else None]
+        dw2, db2, dw1, db1 = grads
+        return dx, g_g, g_be, dw1, db1, dw2, db2, None, None
+
+
+def ln_mlp_ok(x, w1, b1, w2):
+    """norm2 folded into fc1: bf16, biases present, widths multiples of 64 (the LDS-DMA GEMM's K tile) and the normalised width <= 1024"""
+    return (x.dtype == torch.bfloat16 and b1 is not None and x.shape[1] % 64 == 0 and x.shape[1] <= 1024 and w1.shape[0] % 64 == 0 and w2.shape[0] % 64 == 0
+            and os.environ.get("LAVT_LN_FOLD", "1") != "0" and os.environ.get("LAVT_FUSED_MLP", "1") != "0")
+
+
+def ln_mlp(x, norm, w1, b1, w2, b2, **kw):
+    """x + fc2(GELU(fc1(LN(x)))) * row_scale with the LayerNorm folded into fc1 (x is both the norm's input and the residual)"""
+    return _LnMlp.apply(x, norm.weight, norm.bias, w1, b1, w2, b2, norm.eps, LinOpts(**kw))
 
 
 def mlp(x, w1, b1, w2, b2, residual=None, **kw):

@@ -175,9 +175,14 @@ class SwinTransformerBlock(nn.Module):
             x2 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x2, out_map=wmap, rows=M, out_rows=B * L,
                             row_scale=f1, row_scale_div=M // B, row_scale_value=dpv)
         f2 = self.drop_path.factors(B, dev)
-        h, x2 = ops.layer_norm_res(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        m = self.mlp
         with scope("mlp"):
-            x2 = self.mlp(h, residual=x2, row_scale=f2, row_scale_div=L, row_scale_value=dpv)
+            if ops.ln_mlp_ok(x2, m.fc1.weight, m.fc1.bias, m.fc2.weight):
+                # norm2 folded into fc1's contraction (lavt_gemm_nt.ln_wsum): no LayerNorm launch, no [M, C] LayerNorm output in the forward
+                x2 = ops.ln_mlp(x2, self.norm2, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, row_scale=f2, row_scale_div=L, row_scale_value=dpv)
+            else:
+                h, x2 = ops.layer_norm_res(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+                x2 = self.mlp(h, residual=x2, row_scale=f2, row_scale_div=L, row_scale_value=dpv)
         return x2.view(B, L, C)
 
 

@@ -721,11 +721,13 @@ def test_train_step_graph_sees_foreign_optimizer_updates():
         ops.sinks.clear()
 
 
+@pytest.mark.parametrize("feature", ["LAVT_WMSA_FUSED", "LAVT_LN_FOLD"])
 @pytest.mark.parametrize("C,ws,H,W,shifted", [(128, 12, 15, 15, 0), (128, 12, 15, 15, 1), (64, 7, 10, 9, 1), (512, 12, 30, 30, 1), (192, 7, 14, 14, 0), (384, 7, 7, 7, 1)])
-def test_wmsa_fused_forward_kernel(C, ws, H, W, shifted):
+def test_wmsa_fused_forward_kernel(C, ws, H, W, shifted, feature):
     """The one-kernel W-MSA forward (csrc/wmsa_fused.hip: norm1 folded into the qkv contraction, padded / shifted windows through the row map,
     attention core on the LDS copies) inside a Swin block, against the fp32 CPU oracle of the reference block (lib/backbone.py:188-245), forward and
-    every gradient; yardstick = the unfused bf16 path (LayerNorm kernel -> qkv GEMM -> attention kernel): fused error <= 1.5 x unfused + 1 %."""
+    every gradient; yardstick = the unfused bf16 path (LayerNorm kernel -> qkv GEMM -> attention kernel): fused error <= 1.5 x unfused + 1 %.
+    feature = LAVT_LN_FOLD: the same for norm2 folded into fc1's contraction (lavt_gemm_nt.ln_wsum, ops._LnMlp) against the LayerNorm-kernel form."""
     import lavt_hip
     from lavt_hip import ops
     from lib.backbone import SwinTransformerBlock
@@ -745,19 +747,22 @@ def test_wmsa_fused_forward_kernel(C, ws, H, W, shifted):
     ref.update({k[4:]: p.grad for k, p in ps.items() if p.grad is not None})
 
     def run(fused):
-        os.environ["LAVT_WMSA_FUSED"] = "1" if fused else "0"
+        os.environ[feature] = "1" if fused else "0"
         try:
             lavt_hip.set_compute_dtype(torch.bfloat16)
             blk.zero_grad(set_to_none=True)
             x = x0.to(DEV).to(torch.bfloat16).requires_grad_(True)
-            assert ops.wmsa_fused_ok(x.reshape(B * H * W, C), ws, nH, True) == fused
+            if feature == "LAVT_WMSA_FUSED":
+                assert ops.wmsa_fused_ok(x.reshape(B * H * W, C), ws, nH, True) == fused
+            else:
+                assert ops.ln_mlp_ok(x.reshape(B * H * W, C), blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight) == fused
             y = blk(x)
             (y.float() * wy.to(DEV)).sum().backward()
             out = {"y": y, "dx": x.grad}
             out.update({k: p.grad for k, p in blk.named_parameters() if p.grad is not None})
             return {k: v.detach().float().cpu() for k, v in out.items()}
         finally:
-            os.environ.pop("LAVT_WMSA_FUSED", None)
+            os.environ.pop(feature, None)
             lavt_hip.set_compute_dtype(torch.float32)
 
     comp, fus = run(False), run(True)
@@ -768,7 +773,7 @@ def test_wmsa_fused_forward_kernel(C, ws, H, W, shifted):
         report[k] = (round(ec, 4), round(ef, 4))
         assert ef <= 1.5 * ec + 1e-2, (k, ec, ef, report)
     assert len(report) >= 14, report
-    print("\n[fused W-MSA forward, relative l2 error vs the fp32 oracle: (unfused bf16, fused bf16)]", report)
+    print(f"\n[{feature}=1, relative l2 error vs the fp32 oracle: (feature off, feature on)]", report)
 
 
 def test_lavt_video_forward_feats_golden(golden):
