@@ -48,6 +48,24 @@ template <typename T> __device__ __forceinline__ f32x4 mfma16(typename FragT<T>:
 }
 
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// N 16-byte LDS reads at addr + i * STRIDE bytes issued from ONE inline-asm statement that also waits for them (early-clobber outputs: no consumer
+// can be scheduled above the wait).  For reads of an LDS-DMA ring inside the K loop that are not MFMA fragments: hipcc (ROCm 7.2) puts
+// `s_waitcnt vmcnt(0)` in front of such a plain C++ LDS load when a global_load_lds is in flight -- seen in front of the row-statistics reads of the
+// fused W-MSA kernel and of the LayerNorm-folded GEMM, where it serialised the ring (the tile just issued had to land before the current one was
+// read: 10 us instead of ~5 for 8 K tiles) -- asm reads are invisible to that pass (cdna_hip_programming.md 5.4 trap (a), 5.7).
+template <int N, int STRIDE> __device__ __forceinline__ void lds_read16_n(unsigned addr, uint4 (&v)[N]) {
+    static_assert(N == 1 || N == 2 || N == 5, "instantiated counts");
+    if constexpr (N == 1) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]) : "v"(addr) : "memory");
+    else if constexpr (N == 2)
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%c3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]), "=&v"(v[1]) : "v"(addr), "n"(STRIDE) : "memory");
+    else
+        asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:%c6\n\tds_read_b128 %2, %5 offset:%c6*2\n\tds_read_b128 %3, %5 offset:%c6*3\n\t"
+                     "ds_read_b128 %4, %5 offset:%c6*4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]) : "v"(addr), "n"(STRIDE) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ unsigned lds_byte_addr(const void* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p; }
 __device__ __forceinline__ uint4 zero16() { return make_uint4(0, 0, 0, 0); }
 
 template <bool FAST = false> __device__ __forceinline__ float apply_act(int act, float v) {

@@ -373,10 +373,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         if constexpr (LNA) {
             const bf16* tA = reinterpret_cast<const bf16*>(smem + (kt % STAGES) * STAGE_BYTES);
             const bf16x2_t ones2 = {(bf16)1.0f, (bf16)1.0f};
+            uint4 sc[LN_SU];
+            lds_read16_n<LN_SU, WAVES * 8 * 128>(lds_byte_addr(tA) + (unsigned)tid * 16u, sc);      // chunk tid of rows tid / 8 + 8 WAVES u (any chunk order: sums only)
 #pragma unroll
             for (int u = 0; u < LN_SU; ++u) {
-                const int row = (tid >> 3) + (WAVES * 8) * u;
-                const uint4 c4 = *reinterpret_cast<const uint4*>(tA + row * 64 + (tid & 7) * 8);      // any physical chunk order: sums only
+                const uint4 c4 = sc[u];
                 const unsigned wv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {

@@ -154,10 +154,11 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
         // row statistics from the resident tile: thread t owns the 16-byte chunk t % 8 of rows t / 8 + 32 u (any physical chunk order: sums only)
         // (v_dot2c_f32_bf16: one instruction per PAIR and sum -- exact bf16 products, fp32 accumulation; the first version unpacked every value and
         // accumulated shifted sums on the VALU: ~200 instructions per thread per K tile, 16 x redundantly over the heads of a window)
+        uint4 sc[A_INSTR];
+        lds_read16_n<A_INSTR, 32 * 128>(lds_byte_addr(cA) + (unsigned)tid * 16u, sc);          // chunk tid of rows tid / 8 + 32 u: 16 tid + 4096 u bytes
 #pragma unroll
         for (int u = 0; u < A_INSTR; ++u) {
-            const int row = (tid >> 3) + 32 * u;
-            const uint4 c4 = *reinterpret_cast<const uint4*>(cA + row * 64 + (tid & 7) * 8);
+            const uint4 c4 = sc[u];
             const unsigned wv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

@@ -1167,14 +1167,14 @@ class _WmsaFused(torch.autograd.Function):
         return dx, g_g, g_be, g_w, g_b, g_table, None, None, None, None, None
 
 
-_WMSA_FUSED_MAX_C = int(os.environ.get("LAVT_WMSA_FUSED_MAX_C", "512"))
+_WMSA_FUSED_MAX_C = int(os.environ.get("LAVT_WMSA_FUSED_MAX_C", "1024"))
 
 
 def wmsa_fused_ok(x, ws, heads, has_bias):
     """the one-kernel W-MSA forward covers bf16 2-D windows of <= 160 tokens with C = 32 heads a multiple of 64 and a qkv bias.  Measured on MI355X
-    (tools/wmsa_time.py, Swin-B w12 stage shapes at batch 2, norm1 + qkv + attention, graph-replayed): C = 128: 39.0 vs 45.1 us unfused, 256: 24.3 vs
-    38.2, 512: 26.3-27.5 vs 30.4-31.5, 1024: 33.6 vs 31.1 -- a (window, head) workgroup streams 16 K tiles there with one tile in flight, so the
-    last stage keeps the three-kernel form."""
+    (tools/wmsa_time.py, Swin-B w12 stage shapes at batch 2, norm1 + qkv + attention, graph-replayed): C = 128: 38.5 vs 45.2 us unfused, 256: 23.4 vs
+    38.0, 512: 25.6-26.8 vs 30.5-31.7, 1024: 29.7 vs 31.6 (33.6 before the row-statistics reads of the K loop went through inline asm: hipcc put a
+    vmcnt(0) in front of the plain LDS load, which serialised the ring)."""
     return (x.dtype == torch.bfloat16 and has_bias and x.shape[1] == 32 * heads and x.shape[1] % 64 == 0 and x.shape[1] <= _WMSA_FUSED_MAX_C
             and ws * ws <= 160 and os.environ.get("LAVT_WMSA_FUSED", "1") != "0")
 
