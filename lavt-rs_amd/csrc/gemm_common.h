@@ -55,7 +55,13 @@ __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast
 // fused W-MSA kernel and of the LayerNorm-folded GEMM, where it serialised the ring (the tile just issued had to land before the current one was
 // read: 10 us instead of ~5 for 8 K tiles) -- asm reads are invisible to that pass (cdna_hip_programming.md 5.4 trap (a), 5.7).
 template <int N, int STRIDE> __device__ __forceinline__ void lds_read16_n(unsigned addr, uint4 (&v)[N]) {
-    static_assert(N == 1 || N == 2 || N == 5, "instantiated counts");
+    static_assert(N == 1 || N == 2 || N == 3 || N == 5, "instantiated counts");
+    if constexpr (N == 3) {
+        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:%c4\n\tds_read_b128 %2, %3 offset:%c4*2\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(addr), "n"(STRIDE) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
     if constexpr (N == 1) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]) : "v"(addr) : "memory");
     else if constexpr (N == 2)
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%c3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]), "=&v"(v[1]) : "v"(addr), "n"(STRIDE) : "memory");

@@ -3,7 +3,7 @@
 // window_partition), WindowAttention.forward :113-140 (qkv, scale, bias, mask, softmax, attn @ v).  The proj GEMM that follows scatters the rows back
 // (window_reverse / roll / crop) and adds the residual, as before.
 //
-// One workgroup (4 waves) per (window, head):
+// One workgroup (8 waves) per (window, head):
 //   phase 1  [q | k | v]_head = LN(x_window) W_head^T + b_head as a 144 x 96 x C GEMM: the window's token rows are gathered through the row map by
 //            LDS-DMA (global_load_lds_dwordx4, -1 = padded token = zero page) into a 2-stage ring of 64-wide K tiles, the head's 96 weight rows likewise.
 //            LayerNorm is applied algebraically: the MFMA contracts the RAW rows with gamma-folded weights, the row statistics are accumulated from
@@ -69,13 +69,18 @@ struct WmsaArgs {
 };
 
 template <int NT, bool REGION, bool FULL>
-__global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a) {
+__global__ __launch_bounds__(512, 4) void wmsa_fwd_fused_kernel(const WmsaArgs a) {
+    // 8 waves (two workgroups per CU at <= 128 registers).  With 4 waves the K loop of phase 1 was bound by the ISSUE cost of the LDS-DMA instructions
+    // (8 per wave per K tile at ~130 cycles each against 36 MFMAs: 10.4 of the kernel's 26 us at C = 512); here a wave issues 4 and owns a
+    // (m-tile group, n half) block of the 144 x 96 product.
+    constexpr int NW = 8, NTHR = NW * 64;
     constexpr int KS = (NT + 1) / 2, NP = KS * 32;
-    constexpr int MR = ((NT * 16 + 31) / 32) * 32;           // row count of the A tile: whole DMA instructions (8 rows) per wave
-    constexpr int A_INSTR = MR / 32, B_INSTR = 3, L = A_INSTR + B_INSTR;
-    constexpr int A_BYTES = MR * 128, B_BYTES = 96 * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int MI = (NT + 3) / 4;                          // m-tiles (16 window positions) per wave
-    static_assert(3 * NP * F_LD * 2 <= 2 * STAGE, "Q / K / V alias the ring");
+    constexpr int TR = ((NT * 16 + 96 + 63) / 64) * 64;     // rows of the combined [window rows | 96 weight rows] K tile: whole DMA instructions per wave
+    constexpr int MR = TR - 96, DI = TR / 64;                // window-row slots, DMA instructions per wave per K tile
+    constexpr int STAGE = TR * 128;
+    constexpr int MI = (NT + 3) / 4;                         // m-tiles (16 window positions) per wave, at most
+    constexpr int SU = (MR * 8 + NTHR - 1) / NTHR;           // 16-byte chunks of the window rows per thread (row statistics)
+    static_assert(3 * NP * F_LD * 2 <= 2 * STAGE && SU * 64 <= TR, "Q / K / V alias the ring; statistics reads stay inside a stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Qs = reinterpret_cast<bf16*>(smem);                // (after phase 1) [NP][F_LD] each
     bf16* Ks = Qs + NP * F_LD;
@@ -95,53 +100,54 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
     const int centre = (wh - 1) * (2 * ww - 1) + (ww - 1);
     const bf16* Z = reinterpret_cast<const bf16*>(a.zeros);
 
-    for (int e = tid; e < MR; e += 256) srcs[e] = e < N ? a.wmap[(int64_t)w * N + e] : -1;
+    for (int e = tid; e < MR; e += NTHR) srcs[e] = e < N ? a.wmap[(int64_t)w * N + e] : -1;
     __syncthreads();
 
     // ---- phase 1: [q | k | v]_head = LN(x_window) W_head^T ----------------------------------------------------------------------------
     const int cl = (lane & 7) ^ (lane >> 3);
-    const bf16* a_ptr[A_INSTR];
-    int a_step[A_INSTR];
-    const bf16* b_ptr[B_INSTR];
+    const bf16* d_ptr[DI];
+    int d_step[DI];
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-        const int src = srcs[(wave * A_INSTR + i) * 8 + (lane >> 3)];
-        a_ptr[i] = src >= 0 ? a.x + (int64_t)src * C + cl * 8 : Z;
-        a_step[i] = src >= 0 ? 64 : 0;
-    }
-#pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
-        const int n = (wave * B_INSTR + i) * 8 + (lane >> 3);                        // 0 .. 95: q | k | v rows of this head
-        b_ptr[i] = a.Wg + ((int64_t)(n >> 5) * C + h * HD + (n & 31)) * C + cl * 8;
+    for (int i = 0; i < DI; ++i) {
+        const int r = (wave * DI + i) * 8 + (lane >> 3);          // row of the combined tile: [0, MR) window positions, [MR, TR) weight rows
+        if (r < MR) {
+            const int src = srcs[r];
+            d_ptr[i] = src >= 0 ? a.x + (int64_t)src * C + cl * 8 : Z;
+            d_step[i] = src >= 0 ? 64 : 0;
+        } else {
+            const int n = r - MR;                                    // 0 .. 95: q | k | v rows of this head
+            d_ptr[i] = a.Wg + ((int64_t)(n >> 5) * C + h * HD + (n & 31)) * C + cl * 8;
+            d_step[i] = 64;
+        }
     }
     auto issue = [&](int stage) {
         char* sb = smem + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) { dma16(a_ptr[i], sb + (wave * A_INSTR + i) * 1024); a_ptr[i] += a_step[i]; }
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) { dma16(b_ptr[i], sb + A_BYTES + (wave * B_INSTR + i) * 1024); b_ptr[i] += 64; }
+        for (int i = 0; i < DI; ++i) { dma16(d_ptr[i], sb + (wave * DI + i) * 1024); d_ptr[i] += d_step[i]; }
     };
-    f32x4 acc[MI][6];
+    const int QT = (N + 15) / 16;
+    const int mg = wave >> 1, nh = wave & 1;
+    const int m_cnt = QT / 4 + (mg < (QT & 3) ? 1 : 0), m_beg = mg * (QT / 4) + min(mg, QT & 3);      // this wave's m-tiles; n-tiles 3 nh .. 3 nh + 2
+    f32x4 acc[MI][3];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float s1[A_INSTR], s2[A_INSTR];
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s1[SU], s2[SU];
 #pragma unroll
-    for (int u = 0; u < A_INSTR; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
+    for (int u = 0; u < SU; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
     typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2;
     const bf16x2 ones2 = {(bf16)1.0f, (bf16)1.0f};
-    const int QT = (N + 15) / 16;
     const int ktiles = (a.debug & 2) ? 0 : (C >> 6);
     if (ktiles) issue(0);
     // the small tables are staged while the first K tile is in flight (they are first read after the loop's barriers)
-    for (int e = tid; e < NP; e += 256) {
+    for (int e = tid; e < NP; e += NTHR) {
         const int hy = (e / ww) % wh, wx = e % ww;
         bs[e] = hy * (2 * ww - 1) + wx;
         Rs[e] = (REGION && e < N) ? (uint8_t)a.region[(int64_t)(w % a.nw_img) * N + e] : 0;
     }
-    for (int e = tid; e < R; e += 256) tab[e] = a.table[(int64_t)e * a.heads + h] * LOG2E;
-    for (int e = tid; e < 3 * 96; e += 256) {
+    for (int e = tid; e < R; e += NTHR) tab[e] = a.table[(int64_t)e * a.heads + h] * LOG2E;
+    for (int e = tid; e < 3 * 96; e += NTHR) {
         const int which = e / 96, n = e - which * 96, col = (n >> 5) * C + h * HD + (n & 31);
         evec[e] = (which == 0 ? a.wsum : (which == 1 ? a.biasp : a.bias))[col];
     }
@@ -150,16 +156,15 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
         __builtin_amdgcn_s_barrier();
         if (kt + 1 < ktiles) issue((kt + 1) & 1);
         const bf16* cA = reinterpret_cast<const bf16*>(smem + (kt & 1) * STAGE);
-        const bf16* cB = reinterpret_cast<const bf16*>(smem + (kt & 1) * STAGE + A_BYTES);
-        // row statistics from the resident tile: thread t owns the 16-byte chunk t % 8 of rows t / 8 + 32 u (any physical chunk order: sums only)
-        // (v_dot2c_f32_bf16: one instruction per PAIR and sum -- exact bf16 products, fp32 accumulation; the first version unpacked every value and
-        // accumulated shifted sums on the VALU: ~200 instructions per thread per K tile, 16 x redundantly over the heads of a window)
-        uint4 sc[A_INSTR];
-        lds_read16_n<A_INSTR, 32 * 128>(lds_byte_addr(cA) + (unsigned)tid * 16u, sc);          // chunk tid of rows tid / 8 + 32 u: 16 tid + 4096 u bytes
+        const bf16* cB = cA + MR * 64;
+        // row statistics from the resident tile: thread t owns the 16-byte chunk t % 8 of rows t / 8 + 64 u (any physical chunk order: sums only).
+        // (v_dot2c_f32_bf16: one instruction per PAIR and sum -- exact bf16 products, fp32 accumulation.  The reads go through inline asm: in
+        // front of a plain C++ LDS load hipcc put s_waitcnt vmcnt(0) here, serialising the ring.)
+        uint4 sc[SU];
+        lds_read16_n<SU, 64 * 128>(lds_byte_addr(cA) + (unsigned)tid * 16u, sc);
 #pragma unroll
-        for (int u = 0; u < A_INSTR; ++u) {
-            const uint4 c4 = sc[u];
-            const unsigned wv[4] = {c4.x, c4.y, c4.z, c4.w};
+        for (int u = 0; u < SU; ++u) {
+            const unsigned wv[4] = {sc[u].x, sc[u].y, sc[u].z, sc[u].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bf16x2 v2 = __builtin_bit_cast(bf16x2, wv[e]);
@@ -169,15 +174,15 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fb[6];
+            bf16x8 fb[3];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) fb[j] = frag_kc<bf16>(cB, j * 16, ks, lane);
+            for (int j = 0; j < 3; ++j) fb[j] = frag_kc<bf16>(cB, (nh * 3 + j) * 16, ks, lane);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                if (wave * MI + i < QT) {
-                    const bf16x8 fa = frag_kc<bf16>(cA, (wave * MI + i) * 16, ks, lane);
+                if (i < m_cnt) {
+                    const bf16x8 fa = frag_kc<bf16>(cA, (m_beg + i) * 16, ks, lane);
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
                 }
             }
         }
@@ -185,12 +190,12 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
     {
         const float invC = 1.0f / (float)C;
 #pragma unroll
-        for (int u = 0; u < A_INSTR; ++u) {
+        for (int u = 0; u < SU; ++u) {
             float t1 = s1[u], t2 = s2[u];
             t1 += __shfl_xor(t1, 1, 64); t1 += __shfl_xor(t1, 2, 64); t1 += __shfl_xor(t1, 4, 64);
             t2 += __shfl_xor(t2, 1, 64); t2 += __shfl_xor(t2, 2, 64); t2 += __shfl_xor(t2, 4, 64);
-            if ((tid & 7) == 0) {
-                const int row = (tid >> 3) + 32 * u;
+            const int row = (tid >> 3) + 64 * u;
+            if ((tid & 7) == 0 && row < MR) {
                 const float m1 = t1 * invC;
                 mu[row] = m1;
                 rsd[row] = rsqrtf(fmaxf(t2 * invC - m1 * m1, 0.f) + a.eps);
@@ -202,30 +207,26 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
     // epilogue of phase 1: LayerNorm algebra + bias -> LDS (attention operands) and HBM (saved for backward)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int tile = wave * MI + i;
-        if (tile >= QT) continue;
-        const int m = tile * 16 + c16;
+        if (i >= m_cnt) continue;
+        const int m = (m_beg + i) * 16 + c16;
         const bool inwin = m < N, tok = inwin && srcs[m] >= 0;
         const float mr = mu[m], rr = rsd[m];
 #pragma unroll
-        for (int jp = 0; jp < 3; ++jp) {
-            uint2 p[2];
+        for (int jj = 0; jj < 3; ++jj) {
+            const int j = nh * 3 + jj, jp = j >> 1, hf = j & 1;
+            const int col = jp * 32 + hf * 16 + 4 * g;
+            const float4 ws4 = *reinterpret_cast<const float4*>(evec + col), bp4 = *reinterpret_cast<const float4*>(evec + 96 + col), b4 = *reinterpret_cast<const float4*>(evec + 192 + col);
+            const float wsv[4] = {ws4.x, ws4.y, ws4.z, ws4.w}, bpv[4] = {bp4.x, bp4.y, bp4.z, bp4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+            float v[4];
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int col = jp * 32 + hf * 16 + 4 * g;
-                const float4 ws4 = *reinterpret_cast<const float4*>(evec + col), bp4 = *reinterpret_cast<const float4*>(evec + 96 + col), b4 = *reinterpret_cast<const float4*>(evec + 192 + col);
-                const float wsv[4] = {ws4.x, ws4.y, ws4.z, ws4.w}, bpv[4] = {bp4.x, bp4.y, bp4.z, bp4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = tok ? rr * (acc[i][2 * jp + hf][r] - mr * wsv[r]) + bpv[r] : (inwin ? bv[r] : 0.f);
-                p[hf] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                bf16* Xs = jp == 0 ? Qs : (jp == 1 ? Ks : Vs);
-                *reinterpret_cast<uint2*>(Xs + m * F_LD + hf * 16 + 4 * g) = p[hf];
-            }
-            store_head_row16(a.qkv + ((int64_t)w * N + (inwin ? m : 0)) * 3 * C + jp * C + h * HD, g, p[0], p[1], inwin);
+            for (int r = 0; r < 4; ++r) v[r] = tok ? rr * (acc[i][jj][r] - mr * wsv[r]) + bpv[r] : (inwin ? bv[r] : 0.f);
+            const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            bf16* Xs = jp == 0 ? Qs : (jp == 1 ? Ks : Vs);
+            *reinterpret_cast<uint2*>(Xs + m * F_LD + hf * 16 + 4 * g) = pk;
+            if (inwin) *reinterpret_cast<uint2*>(a.qkv + ((int64_t)w * N + m) * 3 * C + jp * C + h * HD + hf * 16 + 4 * g) = pk;
         }
     }
-    for (int e = tid; e < (NP - QT * 16) * 4; e += 256) {      // rows beyond the last computed tile read zero in the attention phase
+    for (int e = tid; e < (NP - QT * 16) * 4; e += NTHR) {      // rows beyond the last computed tile read zero in the attention phase
         const int row = QT * 16 + (e >> 2), c = e & 3;
         const uint4 z = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(Qs + row * F_LD + c * 8) = z;
@@ -234,20 +235,11 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
     }
     __syncthreads();
 
-    // ---- phase 2: attention core on the LDS copies (wattn_fwd_mfma, attention_mfma.hip) ----------------------------------------------------
+    // ---- phase 2: attention core on the LDS copies (as wattn_fwd_mfma, attention_mfma.hip; a wave owns at most two query tiles, so the K / V^T
+    // fragments are read per tile instead of being kept in registers) ---------------------------------------------------------------------------
     const float sc2 = a.scale * LOG2E;
-    bf16x8 kf[NT], vf[2][KS];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) kf[t] = lds_row8(Ks, F_LD, 16 * t + c16, 8 * g);
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16* p = Vs + (32 * ks + 4 * g + (c16 >> 2)) * F_LD + 16 * u + 4 * (c16 & 3);
-            vf[u][ks] = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p), __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * F_LD)));
-        }
     const int heads = a.heads;
-    for (int it = ((a.debug & 1) ? QT : wave); it < QT; it += 4) {
+    for (int it = ((a.debug & 1) ? QT : wave); it < QT; it += NW) {
         const int i = 16 * it + c16;
         const bool vi = i < N;
         const bf16x8 qf = lds_row8(Qs, F_LD, i, 8 * g);
@@ -256,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
         float mx = -1e30f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row8(Ks, F_LD, 16 * t + c16, 8 * g), qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             const int j0 = 16 * t + 4 * g;
             const int4 bj = *reinterpret_cast<const int4*>(bs + j0);
             const f32x4 bb = {tab[bi - bj.x], tab[bi - bj.y], tab[bi - bj.z], tab[bi - bj.w]};
@@ -272,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
             }
             s[t] = v;
             mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+            if (t % 3 == 2) __builtin_amdgcn_sched_barrier(0);          // bound the hoisting of K fragments / table gathers: 128-register budget (two workgroups per CU)
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -293,8 +286,12 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
             bf16x8 pf;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16)s[2 * ks + (jj >> 2)][jj & 3];
-            o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0][ks], pf, o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[1][ks], pf, o[1], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16* p = Vs + (32 * ks + 4 * g + (c16 >> 2)) * F_LD + 16 * u + 4 * (c16 & 3);
+                const bf16x8 vf = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p), __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * F_LD)));
+                o[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[u], 0, 0, 0);
+            }
         }
         const float inv = 1.f / sum;
         store_head_row16(a.out + ((int64_t)w * N + (vi ? i : 0)) * C + h * HD, g,
@@ -302,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void wmsa_fwd_fused_kernel(const WmsaArgs a
                          make_uint2(pack_bf16x2(o[1][0] * inv, o[1][1] * inv), pack_bf16x2(o[1][2] * inv, o[1][3] * inv)), vi);
     }
     // this head's 32-column slice of the LayerNorm output (operand of the qkv weight gradient) + the row statistics (LayerNorm backward)
-    for (int e = tid; e < N * 4; e += 256) {          // (last: off the critical path of the attention phase; mu / rsd / srcs live outside the aliased ring)
+    for (int e = tid; e < N * 4; e += NTHR) {          // (last: off the critical path of the attention phase; mu / rsd / srcs live outside the aliased ring)
         const int row = e >> 2, c = e & 3;
         const int src = srcs[row];
         if (src < 0) continue;
@@ -340,7 +337,7 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ 
 }
 
 template <int NT, bool FULL> int launch_wmsa(const WmsaArgs& a, hipStream_t st) {
-    constexpr int KS = (NT + 1) / 2, NP = KS * 32, MR = ((NT * 16 + 31) / 32) * 32, STAGE = MR * 128 + 96 * 128;
+    constexpr int KS = (NT + 1) / 2, NP = KS * 32, TR = ((NT * 16 + 96 + 63) / 64) * 64, MR = TR - 96, STAGE = TR * 128;
     const int R = (2 * a.wh - 1) * (2 * a.ww - 1);
     const size_t lds = (size_t)2 * STAGE + (size_t)NP * 4 + (size_t)MR * 12 + NP + (size_t)R * 4 + 32 + 3 * 96 * 4;
     static size_t reserved = 0;
@@ -353,8 +350,8 @@ template <int NT, bool FULL> int launch_wmsa(const WmsaArgs& a, hipStream_t st) 
         reserved = lds;
     }
     const dim3 grid(a.nwin * a.heads);
-    if (a.region) hipLaunchKernelGGL((wmsa_fwd_fused_kernel<NT, true, FULL>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((wmsa_fwd_fused_kernel<NT, false, FULL>), grid, dim3(256), lds, st, a);
+    if (a.region) hipLaunchKernelGGL((wmsa_fwd_fused_kernel<NT, true, FULL>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((wmsa_fwd_fused_kernel<NT, false, FULL>), grid, dim3(512), lds, st, a);
     LAVT_CHECK_LAUNCH("lavt_wmsa_fwd");
     return LAVT_OK;
 }
