@@ -1213,6 +1213,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         else if (TB == 128 && cfg_waves == 4 && cfg_stages == 3) TNG_GO(128, 4, 3);
         else if (TB == 128 && cfg_waves == 4 && cfg_stages == 4) TNG_GO(128, 4, 4);
         else if (TB == 64 && cfg_waves == 4 && cfg_stages == 4) TNG_GO(64, 4, 4);
+        else if (TB == 64 && cfg_waves == 4 && cfg_stages == 3) TNG_GO(64, 4, 3);
         else done = false;
 #undef TNG_GO
         if (done) {
