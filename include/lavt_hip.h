@@ -189,12 +189,16 @@ typedef struct lavt_gemm_tn {
                                /* for colsum) and a second small kernel adds the pieces into C -- instead of up to ~60 workgroups adding into the same */
                                /* 64x64 tile through fp32 atomics.  Needs pieces*(I*J + I) floats (lavt_gemm_tn_pieces gives an upper bound); too small */
                                /* or NULL selects the atomic form.  The scratch may be shared by consecutive calls on one stream. */
+    int32_t colsum_atomic;     /* ABI v4: colsum is ADDED with fp32 atomics even where C is stored plainly -- two problems then share one bias gradient:
+                                * a windowed qkv weight gradient taken over the REAL tokens only (token order: the zero rows of padded window
+                                * positions are skipped, K = tokens instead of window rows) + a side problem over the padded rows alone, whose
+                                * dq / dk / dv still belong to the bias gradient (the reference pads after norm1: lib/backbone.py:205-209) */
 } lavt_gemm_tn_t;
 
 int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);
 /* upper bound of the K pieces lavt_gemm_tn may cut this problem into (for sizing `partials`) */
 int lavt_gemm_tn_pieces(const lavt_gemm_tn_t* p);
-/* n (<= 4) independent problems of the family in one call, e.g. the four weight gradients of a Swin block: when they qualify (bf16, no
+/* n (<= 6) independent problems of the family in one call, e.g. the four weight gradients of a Swin block: when they qualify (bf16, no
  * conv taps / concat, batch 1, together >= 256 64x64 output tiles) they run as ONE launch without split-K -- every output element then has
  * a single writer, and with accumulate == 0 it is stored plainly instead of added through fp32 atomics; otherwise they are issued one by
  * one exactly as lavt_gemm_tn would.  A member with split_k < 0 declares that its C (and colsum) hold ZEROS, so that storing and adding

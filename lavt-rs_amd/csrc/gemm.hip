@@ -470,6 +470,7 @@ extern "C" int lavt_gemm_tn(const lavt_gemm_tn_t* pp, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rc2 = lavt_gemm_tn_v2(p, st);          // bf16 LDS-DMA kernel (gemm_v2.hip); 1 = not applicable
     if (rc2 != 1) return rc2;
+    LAVT_CHECK_ARG(!p.colsum_atomic, "lavt_gemm_tn: colsum_atomic needs the bf16 LDS-DMA kernel (bf16 operands, 16-byte aligned rows, zeros page)");
     return p.dtype == LAVT_F32 ? dispatch_tn<float>(p, st) : dispatch_tn<bf16>(p, st);
 }
 

@@ -916,7 +916,7 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
     if constexpr (CS == 1) {
         if (do_colsum && i0 + tid < p.I) {
             float* cs = colsum_out + i0 + tid;
-            if (atomic) atomicAdd(cs, csum * p.alpha); else *cs = csum * p.alpha;
+            if (atomic || (p.colsum_atomic && !to_parts)) atomicAdd(cs, csum * p.alpha); else *cs = csum * p.alpha;
         }
     }
     if (CS == 2 && cs_wave && (lane & 15) == 0) {          // every column of cacc holds the same sums: lanes of column 0 write rows 4 (lane / 16) + r
@@ -927,7 +927,7 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
                 const int ii = i0 + wi * WI + i * 16 + 4 * (lane >> 4) + r;
                 if (ii >= p.I) continue;
                 float* cs = colsum_out + ii;
-                if (atomic) atomicAdd(cs, cacc[i][r] * p.alpha); else *cs = cacc[i][r] * p.alpha;      // one tile_j == 0 workgroup per I tile when the reduction is not split
+                if (atomic || (p.colsum_atomic && !to_parts)) atomicAdd(cs, cacc[i][r] * p.alpha); else *cs = cacc[i][r] * p.alpha;      // one tile_j == 0 workgroup per I tile when the reduction is not split
             }
     }
 }
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_
 // Several independent weight-gradient problems in ONE launch (the four wgrads of a Swin block): together they fill the chip without
 // split-K, so each output element has a single writer and is stored plainly instead of through fp32 atomics, which execute at the memory
 // side at ~1.3 TB/s chip-wide (MI355X_MICROARCH.md) -- 44 MB of atomic traffic per stage-2 block with the per-problem split-K launches.
-constexpr int TN_GROUP_MAX = 4;
+constexpr int TN_GROUP_MAX = 6;          // four weight gradients of a block + side members (the padded-row column sums of the windowed qkv bias gradient)
 struct TnGroup {
     lavt_gemm_tn_t p[TN_GROUP_MAX];
     int tile_end[TN_GROUP_MAX];      // running count of workgroups (tiles x K splits) up to and including problem k

@@ -351,6 +351,22 @@ def _tn_parts(n_floats, device):
     return t
 
 
+_SINK_OUT = {}
+
+
+def _discard_out(n_floats, device):
+    """an output nobody reads (the C of a column-sum-only weight-gradient member); its own buffer: the shared scratch may hold partial sums"""
+    b = _SINK_OUT.get(device)
+    if b is None or b.numel() < n_floats:
+        b = _SINK_OUT[device] = torch.empty(n_floats, dtype=torch.float32, device=device)
+    return b
+
+
+def _zero_page_tensor(device):
+    _zero_page(device)
+    return _ZERO_PAGES[device]
+
+
 def _zero_page(device):
     """256 zero bytes per device: source of every chunk that must read 0 in the LDS-DMA GEMM (padding rows, conv halo, tails)."""
     z = _ZERO_PAGES.get(device)
@@ -400,7 +416,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
 
 def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, strideB=0, strideC=0, a_rowmap=None,
             a_rowscale=None, a_rowscale_div=1, a_rowscale_binary=False, accumulate=False, B2=None, ldb2=0, b_split=0, b_rowmap=None, conv=None, alpha=1.0, c_conv_permute=False, colsum=None,
-            strideColsum=0, a_off=0, b_off=0, c_off=0, defer=None):
+            strideColsum=0, a_off=0, b_off=0, c_off=0, defer=None, colsum_atomic=False, extra=False):
     es = 4 if dtype == torch.float32 else 2
     assert Cout.dtype == torch.float32
     p = K.GemmTN()
@@ -416,7 +432,7 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
             p.conv_d, p.conv_kd, p.conv_kh, p.conv_kw = conv[3:7]
     p.alpha, p.C, p.ldc, p.strideC = alpha, K.ptr(Cout) + c_off * 4, ldc, strideC
     p.c_conv_permute, p.split_k = int(c_conv_permute), (-1 if defer is not None else 0)     # deferred = into the zeroed flat gradient buffer: a grouped launch may split K
-    p.colsum, p.strideColsum = K.ptr(colsum), strideColsum
+    p.colsum, p.strideColsum, p.colsum_atomic = K.ptr(colsum), strideColsum, int(colsum_atomic)
     p.zeros = _zero_page(A.device)
     if dtype == torch.bfloat16 and conv is None and (batch == 1 or defer is None) and Kd >= (2048 if batch == 1 else 128) and not side.enabled and os.environ.get("LAVT_TN_PARTIALS", "1") != "0":      # (one scratch per device: single-stream order only)
         # scratch for split reductions through partial tiles (long-K weight gradients on few output tiles: PWAM's 1x1 convolutions over 28 800 rows;
@@ -426,7 +442,7 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
             scr = _tn_parts(need, A.device)
             p.partials, p.partials_floats = K.ptr(scr), (need if defer is not None else scr.numel())     # queued: flush() hands every member its own region
     if defer is not None:
-        defer.add(p, (A, B, Cout, a_rowmap, a_rowscale, b_rowmap, colsum))
+        defer.add(p, (A, B, Cout, a_rowmap, a_rowscale, b_rowmap, colsum), extra=extra)
         return
     if K.prof.enabled:
         K.prof.note = {"flops": 2.0 * I * J * Kd * batch, "shape": f"tn {I}x{J}x{Kd}" + (f" b{batch}" if batch > 1 else "") + (" conv" if conv is not None else "")}
@@ -442,17 +458,19 @@ class _WgradQueue:
 
     def __init__(self):
         self.enabled = False
-        self.items, self.keep, self.ready, self.scopes = [], [], [], []
+        self.items, self.keep, self.ready, self.scopes, self.primary = [], [], [], [], 0
         self.pending = set()         # ids of parameters whose weight gradient is still queued (their autograd hook fires before the launch)
 
     def active(self):
         return self.enabled and sinks.map and os.environ.get("LAVT_WGRAD_GROUP", "1") != "0"
 
-    def add(self, p, tensors):
+    def add(self, p, tensors, extra=False):
+        """extra: a side member (at most two per group: lavt_gemm_tn_grouped takes six problems) that does not count towards the four-member flush"""
         self.items.append(p)
         self.keep.append(tensors)
         self.scopes.append(K.prof.label)
-        if len(self.items) == 4:
+        self.primary += 0 if extra else 1
+        if self.primary == 4 or len(self.items) == 6:
             self.flush()
 
     def notify(self, param):
@@ -483,7 +501,7 @@ class _WgradQueue:
             # the latency-bound data-gradient chain of the next block (LAVT_SIDE_STREAMS=1)
             side.run(lambda: K.check(K.lib.lavt_gemm_tn_grouped(arr, n_items, K.stream())), tensors, True)
         ready = self.ready
-        self.items, self.keep, self.ready, self.scopes = [], [], [], []
+        self.items, self.keep, self.ready, self.scopes, self.primary = [], [], [], [], 0
         for prm in ready:
             self.pending.discard(id(prm))
             if sinks.on_ready is not None:
@@ -578,6 +596,8 @@ class LinOpts:
     row_scale: Optional[torch.Tensor] = None   # fp32 factor of GEMM row m: row_scale[m // row_scale_div] (language mask, DropPath)
     row_scale_div: int = 1
     row_scale_value: float = 0.0               # if != 0: row_scale holds only 0 and this value (lets the wgrad kernel treat it as a row mask)
+    out_inv: Optional[torch.Tensor] = None     # inverse of out_map on the output rows (out_inv[row of y] = GEMM row): the weight gradient then contracts
+                                               # over the out_rows real rows instead of the GEMM rows (padded window positions drop out)
 
 
 @K.scoped
@@ -637,7 +657,19 @@ class _Linear(torch.autograd.Function):
                 bbuf, bsink = sinks.buf(bias, (N,))
             binary = o.row_scale is not None and o.row_scale_value != 0.0
             grouped = wgrads.active() and wsink and (bbuf is None or bsink) and dtype == torch.bfloat16 and (o.row_scale is None or binary)
-            if grouped:                         # joins the block's grouped launch; the parameters report ready when it is enqueued
+            token_order = (o.out_inv is not None and o.out_map is not None and o.in_map is None and g.shape[0] < M and dtype == torch.bfloat16
+                           and os.environ.get("LAVT_TOKEN_ORDER_WGRAD", "1") != "0")
+            if token_order and grouped:
+                # windowed rows scattered back to tokens (proj): dW = sum over the TOKENS of dy[t]^T x[inv[t]] -- the padded window positions (dy = 0
+                # there) drop out of the reduction: K = tokens instead of window rows (1800 instead of 2592 at stage 2, 450 instead of 1152 at stage 3)
+                T_ = g.shape[0]
+                gemm_tn(dtype, N, Kd, T_, g, N, x, Kd, wbuf, Kd, a_rowscale=o.row_scale, a_rowscale_div=max(o.row_scale_div * T_ // M, 1) if o.row_scale is not None else 1,
+                        a_rowscale_binary=binary, alpha=o.row_scale_value if binary else 1.0, b_rowmap=o.out_inv, colsum=bbuf, defer=wgrads)
+                wgrads.notify(weight)
+                if bbuf is not None:
+                    wgrads.notify(bias)
+                dW = db = None
+            elif grouped:                         # joins the block's grouped launch; the parameters report ready when it is enqueued
                 gemm_tn(dtype, N, Kd, M, g, N, x, Kd, wbuf, Kd, a_rowmap=o.out_map, a_rowscale=o.row_scale, a_rowscale_div=o.row_scale_div,
                         a_rowscale_binary=binary, alpha=o.row_scale_value if binary else 1.0, b_rowmap=o.in_map, colsum=bbuf, defer=wgrads)
                 wgrads.notify(weight)
@@ -1080,7 +1112,7 @@ class _WmsaFused(torch.autograd.Function):
     for the backward pass, which is the unfused sequence: attention backward -> qkv data / weight gradients -> LayerNorm backward (+ residual gradient)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, wq, bq, table, region, wmap, ws, heads, eps):
+    def forward(ctx, x, gamma, beta, wq, bq, table, region, wmap, ws, heads, eps, tok=None):
         x = x.contiguous()
         dtype, dev = x.dtype, x.device
         M, Cc = x.shape
@@ -1101,6 +1133,7 @@ class _WmsaFused(torch.autograd.Function):
                                     heads, Cc, eps, scale, K.stream()))
         ctx.save_for_backward(x, gamma, beta, wq, bq, table, region, wmap, out, qkv, xn, lse, st)
         ctx.dims = (ws, heads, nwin, N, Cc, nw_img, scale, Mw)
+        ctx.tok = tok if tok is not None else (None, None)
         return out, x.view_as(x)
 
     @staticmethod
@@ -1134,7 +1167,19 @@ class _WmsaFused(torch.autograd.Function):
         gemm_nt(dtype, Mw, Cc, 3 * Cc, dqkv, 3 * Cc, Wc, Cc, dxn, Cc, b_kmajor=True, c_rowmap=wmap)
         wbuf, wsink = sinks.buf(wq, (3 * Cc, Cc))
         bbuf, bsink = sinks.buf(bq, (3 * Cc,))
-        if wgrads.active() and wsink and bsink:
+        inv, padrows = ctx.tok
+        if wgrads.active() and wsink and bsink and inv is not None and padrows.numel() > 0 and os.environ.get("LAVT_TOKEN_ORDER_WGRAD", "1") != "0":
+            # token order: dW = sum over the REAL tokens of dqkv[inv[t]]^T xn[t] (padded window positions have xn = 0: K = tokens instead of window
+            # rows); their dq / dk / dv still belong to the bias gradient (the reference pads after norm1): a side member of the grouped launch sums
+            # those rows alone (B = the zero page, 8 dummy columns), both column sums added atomically into the zeroed bias gradient
+            dummy = _discard_out(3 * Cc * 8, dev)
+            zp = _zero_page_tensor(dev)
+            gemm_tn(dtype, 3 * Cc, 8, padrows.numel(), dqkv, 3 * Cc, zp, 0, dummy, 8, a_rowmap=padrows, colsum=bbuf, colsum_atomic=True, defer=wgrads, extra=True)
+            gemm_tn(dtype, 3 * Cc, Cc, M, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, a_rowmap=inv, colsum=bbuf, colsum_atomic=True, defer=wgrads)
+            wgrads.notify(wq)
+            wgrads.notify(bq)
+            g_w = g_b = None
+        elif wgrads.active() and wsink and bsink:
             gemm_tn(dtype, 3 * Cc, Cc, Mw, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, b_rowmap=wmap, colsum=bbuf, defer=wgrads)
             wgrads.notify(wq)
             wgrads.notify(bq)
@@ -1164,7 +1209,7 @@ class _WmsaFused(torch.autograd.Function):
             K.check(K.lib.lavt_layernorm_bwd(K.dt(dtype), K.ptr(dxn), K.ptr(x), None, K.ptr(_f32(gamma)), K.ptr(st[0]), K.ptr(st[1]), K.ptr(dx), K.ptr(dg), K.ptr(db),
                                              K.ptr(wsl), wsl.numel(), K.ptr(dres), M, Cc, K.stream()))
             g_g, g_be = sinks.done(gamma, dg, gs), sinks.done(beta, db, bs_)
-        return dx, g_g, g_be, g_w, g_b, g_table, None, None, None, None, None
+        return dx, g_g, g_be, g_w, g_b, g_table, None, None, None, None, None, None
 
 
 _WMSA_FUSED_MAX_C = int(os.environ.get("LAVT_WMSA_FUSED_MAX_C", "1024"))
@@ -1179,9 +1224,10 @@ def wmsa_fused_ok(x, ws, heads, has_bias):
             and ws * ws <= 160 and os.environ.get("LAVT_WMSA_FUSED", "1") != "0")
 
 
-def wmsa_fused(x, norm, attn, region, wmap, ws, heads):
-    """x [tokens, C], norm = the block's norm1, attn = its WindowAttention (parameter containers) -> (attention output in window order, x')"""
-    return _WmsaFused.apply(x, norm.weight, norm.bias, attn.qkv.weight, attn.qkv.bias, attn.relative_position_bias_table, region, wmap, ws, heads, norm.eps)
+def wmsa_fused(x, norm, attn, region, wmap, ws, heads, tok=None):
+    """x [tokens, C], norm = the block's norm1, attn = its WindowAttention (parameter containers) -> (attention output in window order, x');
+    tok = (inverse row map, padded-row list) of rowmaps for the token-order weight gradient"""
+    return _WmsaFused.apply(x, norm.weight, norm.bias, attn.qkv.weight, attn.qkv.bias, attn.relative_position_bias_table, region, wmap, ws, heads, norm.eps, tok)
 
 
 def window_attention(qkv, table, region, win, heads, N=None):

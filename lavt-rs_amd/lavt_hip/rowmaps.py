@@ -33,6 +33,22 @@ def window_map_np(B: int, H: int, W: int, ws: int, shift: int) -> np.ndarray:
     return out.reshape(-1).astype(np.int32)
 
 
+def window_inverse_np(B: int, H: int, W: int, ws: int, shift: int) -> np.ndarray:
+    """inverse of window_map_np on the real tokens: inv[token] = its windowed row (every token sits in exactly one window).  Lets a contraction over
+    the windowed rows run over the tokens instead: the zero rows of padded window positions drop out of the reduction."""
+    wm = window_map_np(B, H, W, ws, shift)
+    inv = np.full(B * H * W, -1, np.int32)
+    rows = np.nonzero(wm >= 0)[0]
+    inv[wm[rows]] = rows
+    assert (inv >= 0).all()
+    return inv
+
+
+def window_pad_rows_np(B: int, H: int, W: int, ws: int, shift: int) -> np.ndarray:
+    """the windowed rows that hold padding (window_map_np == -1), ascending"""
+    return np.nonzero(window_map_np(B, H, W, ws, shift) < 0)[0].astype(np.int32)
+
+
 def region_ids_np(H: int, W: int, ws: int, shift: int) -> np.ndarray:
     """int8 [nW][N]: 3*g(row)+g(col) on the padded grid, g = 0 | 1 | 2 for [0,Hp-ws) | [Hp-ws,Hp-shift) | rest
     (lib/backbone.py:636-647).  Two tokens of a window attend to each other iff their ids are equal."""
@@ -102,13 +118,21 @@ def region_ids3d_np(D: int, H: int, W: int, win, shift) -> np.ndarray:
 
 @functools.lru_cache(maxsize=256)
 def _cached(kind, args, device):
-    fn = {"window": window_map_np, "region": region_ids_np, "merge": merge_map_np, "kvpad": kv_pad_map_np,
+    fn = {"window": window_map_np, "winv": window_inverse_np, "wpad": window_pad_rows_np, "region": region_ids_np, "merge": merge_map_np, "kvpad": kv_pad_map_np,
           "window3d": window_map3d_np, "region3d": region_ids3d_np}[kind]
     return torch.from_numpy(fn(*args)).to(device)
 
 
 def window_map(B, H, W, ws, shift, device):
     return _cached("window", (B, H, W, ws, shift), str(device))
+
+
+def window_inverse(B, H, W, ws, shift, device):
+    return _cached("winv", (B, H, W, ws, shift), str(device))
+
+
+def window_pad_rows(B, H, W, ws, shift, device):
+    return _cached("wpad", (B, H, W, ws, shift), str(device))
 
 
 def region_ids(H, W, ws, shift, device):

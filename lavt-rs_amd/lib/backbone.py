@@ -165,15 +165,18 @@ class SwinTransformerBlock(nn.Module):
         f1 = self.drop_path.factors(B, dev)
         dpv = 1.0 / (1.0 - self.drop_path.drop_prob) if self.drop_path.drop_prob < 1.0 else 0.0
         with scope("wmsa"):
+            padded_win = M > B * L                       # padded window positions exist: weight gradients contract over the tokens instead of the window rows
+            winv = rowmaps.window_inverse(B, H, W, ws, s, dev) if padded_win else None
             if ops.wmsa_fused_ok(x2, ws, self.num_heads, a.qkv.bias is not None):
                 # norm1 + partition + qkv + attention as one kernel (csrc/wmsa_fused.hip): the LayerNorm and qkv GEMM launches are gone from the forward
-                o, x2 = ops.wmsa_fused(x2, self.norm1, a, region, wmap, ws, self.num_heads)
+                o, x2 = ops.wmsa_fused(x2, self.norm1, a, region, wmap, ws, self.num_heads,
+                                       tok=(winv, rowmaps.window_pad_rows(B, H, W, ws, s, dev)) if padded_win else None)
             else:
                 xn, x2 = ops.layer_norm_res(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps)     # x2: alias for the residual branch
                 qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, in_map=wmap, rows=M)
                 o = ops.window_attention(qkv, a.relative_position_bias_table, region, ws, self.num_heads)
             x2 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x2, out_map=wmap, rows=M, out_rows=B * L,
-                            row_scale=f1, row_scale_div=M // B, row_scale_value=dpv)
+                            row_scale=f1, row_scale_div=M // B, row_scale_value=dpv, out_inv=winv)
         f2 = self.drop_path.factors(B, dev)
         m = self.mlp
         with scope("mlp"):

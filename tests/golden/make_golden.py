@@ -525,7 +525,8 @@ def full_cases(args, which):
     from lib import mask_predictor as rmp
     from lib import _utils as ru
     w = torch.tensor([0.9, 1.1])
-    for tag, (embed, depths, heads, ws, B) in {"swin_b": (128, [2, 2, 18, 2], [4, 8, 16, 32], 12, 2), "swin_t": (96, [2, 2, 6, 2], [3, 6, 12, 24], 7, 8)}.items():
+    for tag, (embed, depths, heads, ws, B) in {"swin_b": (128, [2, 2, 18, 2], [4, 8, 16, 32], 12, 2), "swin_t": (96, [2, 2, 6, 2], [3, 6, 12, 24], 7, 8),
+                                               "swin_b_b4": (128, [2, 2, 18, 2], [4, 8, 16, 32], 12, 4)}.items():          # b4: the per-GPU batch of BASELINE configs[4] (fp8)
         if tag not in which:
             continue
         t0 = time.time()
@@ -555,7 +556,7 @@ def full_cases(args, which):
         named = [(k, p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()]
         dxg, dlg = x.grad.clone(), l.grad.clone()
         noise = _ref_bf16_noise(run, logits.detach(), loss.detach(), fp32_grads)
-        _full_record(f"full_{tag}_480_b{B}", named, logits.detach(), lowres.detach(), [f.detach() for f in feats], tgt, loss.detach(),
+        _full_record(f"full_{tag.replace('_b4', '')}_480_b{B}", named, logits.detach(), lowres.detach(), [f.detach() for f in feats], tgt, loss.detach(),
                      {"dx": dxg, "dl": dlg}, dict(seed=1234, B=B, ws=ws, **noise))
         print(f"   ({time.time() - t0:.0f} s)")
         del model, feats, logits, loss

@@ -26,6 +26,7 @@ from lavt_hip.detweights import det_inputs, fill_state_dict_
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 IMAGE = {"swin_b": ("full_swin_b_480_b2", 128, [2, 2, 18, 2], [4, 8, 16, 32], 12, 2),
+         "swin_b_b4": ("full_swin_b_480_b4", 128, [2, 2, 18, 2], [4, 8, 16, 32], 12, 4),          # BASELINE configs[4]'s batch (4 per GPU)
          "swin_t": ("full_swin_t_480_b8", 96, [2, 2, 6, 2], [3, 6, 12, 24], 7, 8)}
 SEPT = dict(sep_t_pwam=True, conv3d_kernel_size_t="3-3-3", conv3d_kernel_size_s="1-1-1", w_t3x3_s1x1=True, mm_t3x3_s1x1=True)
 # gradients the bench's hot kernels produce (the grouped stage-2 weight gradients, the 256x256-tile decoder convolutions, ...): always reported
@@ -192,7 +193,7 @@ def _check_grads(g, named_grads, fp32, tol32=3e-3):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("tag", ["swin_b", "swin_t"])
+@pytest.mark.parametrize("tag", ["swin_b", "swin_t", "swin_b_b4"])
 def test_full_image_config(golden, tag, dtype):
     """BASELINE configs[2] (Swin-B w12, 2x480x480: 30->36 / 15->24 padded windows at C=512/1024, M=28 800 decoder convolutions on the
     256x256 tile) and configs[1] (Swin-T w7, 8x480x480: 126-row padded grid)."""
@@ -263,14 +264,15 @@ def test_bench_step_matches_reference(golden):
     _check_grads(g, [(k, p.grad) for k, p in model.named_parameters()], False)
 
 
-def test_full_swin_b_fp8(golden):
+@pytest.mark.parametrize("tag", ["swin_b", "swin_b_b4"])
+def test_full_swin_b_fp8(golden, tag):
     """BASELINE configs[4] arithmetic (e4m3 weights / activations on the fp8 MFMA for the decoder's 3x3 convolutions -- 54 % of the FLOPs -- bf16
-    elsewhere) on the Swin-B 2x480x480 fixture, after one calibration step (delayed scaling).  The reference has no fp8 path: the gate is stated
+    elsewhere) on the Swin-B 2x480x480 fixture and at configs[4]'s own batch (4x480x480), after one calibration step (delayed scaling).  The reference has no fp8 path: the gate is stated
     against its fp32 run, next to the reference's own bf16 figures -- mask IoU on decisive pixels (|margin| > 0.25 sigma) >= 0.97,
     pixel agreement >= the reference-bf16 agreement - 0.02, |d loss| <= 3e-2, gradient-digest error median / p90 <= 3 x the reference-bf16's."""
     import lavt_hip
     from lavt_hip import ops
-    name, embed, depths, heads, ws, B = IMAGE["swin_b"]
+    name, embed, depths, heads, ws, B = IMAGE[tag]
     g = golden(name)
     ops.fp8.__init__()
     with lavt_hip.use_dtype("fp8"):

@@ -536,7 +536,7 @@ def test_gemm_tn_grouped_matches_individual():
     probs.append((Cc, Cc, Mw, mk(M, Cc), mk(Mw, Cc), dict(a_rowmap=wmap)))                                       # proj (gathered gradient)
     outs_ref, outs_grp, structs, keep = [], [], [], []
     class _Q:
-        def add(self, p, t): structs.append(p); keep.append(t)
+        def add(self, p, t, extra=False): structs.append(p); keep.append(t)
     for I, J, Kd, A, B, kw in probs:
         ref = torch.zeros(I, J, device=dev()); cs_ref = torch.zeros(I, device=dev())
         ops.gemm_tn(bf, I, J, Kd, A, I, B, J, ref, J, colsum=cs_ref, **kw)
@@ -550,6 +550,56 @@ def test_gemm_tn_grouped_matches_individual():
         scale = float(r.abs().max())
         assert float((r - o).abs().max()) <= 2e-3 * scale, float((r - o).abs().max()) / scale        # fp32 summation order only
         assert float((cr - co).abs().max()) <= 2e-3 * float(cr.abs().max())
+
+
+@pytest.mark.parametrize("B,H,ws,shift,Cc", [(2, 30, 12, 6, 512), (2, 15, 12, 0, 1024), (3, 10, 7, 3, 256)])
+def test_gemm_tn_token_order_matches_window_order(B, H, ws, shift, Cc):
+    """The windowed members of a Swin block's grouped weight-gradient launch in TOKEN order (contraction over the real tokens through the inverse
+    window map; the padded window rows -- zero input rows whose dq / dk / dv still count for the qkv bias gradient -- summed by a column-sum-only
+    side member, both added atomically: lavt_gemm_tn_t.colsum_atomic) against the same gradients in window order."""
+    import ctypes as C
+    from lavt_hip import _capi as K, ops, rowmaps
+    g = torch.Generator().manual_seed(5)
+    bf = torch.bfloat16
+    wmap = rowmaps.window_map(B, H, H, ws, shift, dev())
+    inv, pad = rowmaps.window_inverse(B, H, H, ws, shift, dev()), rowmaps.window_pad_rows(B, H, H, ws, shift, dev())
+    T, Mw = B * H * H, wmap.numel()
+    assert pad.numel() == Mw - T and bool((wmap[inv.long()] == torch.arange(T, device=dev())).all())
+    def mk(rows, cols):
+        return (torch.randn(rows, cols, generator=g) * 0.5).to(dev()).to(bf)
+    dqkv, xn, dy, o = mk(Mw, 3 * Cc), mk(T, Cc), mk(T, Cc), mk(Mw, Cc)
+    fc = [(4 * Cc, Cc, T, mk(T, 4 * Cc), mk(T, Cc)), (Cc, 4 * Cc, T, mk(T, Cc), mk(T, 4 * Cc))]          # the block's MLP members fill the launch
+    structs, keep = [], []
+    class _Q:
+        def add(self, p, t, extra=False): structs.append(p); keep.append(t)
+    # window order (reference form)
+    w_qkv, b_qkv, w_proj, b_proj = (torch.zeros(3 * Cc, Cc, device=dev()), torch.zeros(3 * Cc, device=dev()), torch.zeros(Cc, Cc, device=dev()), torch.zeros(Cc, device=dev()))
+    ops.gemm_tn(bf, 3 * Cc, Cc, Mw, dqkv, 3 * Cc, xn, Cc, w_qkv, Cc, b_rowmap=wmap, colsum=b_qkv)
+    ops.gemm_tn(bf, Cc, Cc, Mw, dy, Cc, o, Cc, w_proj, Cc, a_rowmap=wmap, colsum=b_proj)
+    # token order, one grouped launch
+    t_qkv, tb_qkv, t_proj, tb_proj = (torch.zeros_like(w_qkv), torch.zeros_like(b_qkv), torch.zeros_like(w_proj), torch.zeros_like(b_proj))
+    outs = []
+    for I, J, Kd, A, Bm in fc:
+        out = torch.zeros(I, J, device=dev()); outs.append((out, A, Bm))
+        ops.gemm_tn(bf, I, J, Kd, A, I, Bm, J, out, J, defer=_Q())
+    ops.gemm_tn(bf, Cc, Cc, T, dy, Cc, o, Cc, t_proj, Cc, b_rowmap=inv, colsum=tb_proj, defer=_Q())
+    dummy = torch.empty(3 * Cc, 8, device=dev())
+    ops.gemm_tn(bf, 3 * Cc, 8, pad.numel(), dqkv, 3 * Cc, ops._zero_page_tensor(dev()), 0, dummy, 8, a_rowmap=pad, colsum=tb_qkv, colsum_atomic=True, defer=_Q(), extra=True)
+    ops.gemm_tn(bf, 3 * Cc, Cc, T, dqkv, 3 * Cc, xn, Cc, t_qkv, Cc, a_rowmap=inv, colsum=tb_qkv, colsum_atomic=True, defer=_Q())
+    assert len(structs) == 5
+    arr = (K.GemmTN * len(structs))(*structs)
+    K.check(K.lib.lavt_gemm_tn_grouped(arr, len(structs), K.stream()))
+    torch.cuda.synchronize()
+    for nm, r, t in (("qkv.weight", w_qkv, t_qkv), ("qkv.bias", b_qkv, tb_qkv), ("proj.weight", w_proj, t_proj), ("proj.bias", b_proj, tb_proj)):
+        scale = float(r.abs().max())
+        assert float((r - t).abs().max()) <= 2e-3 * scale, (nm, float((r - t).abs().max()) / scale)      # fp32 summation order only
+    assert float(dummy.abs().max()) == 0.0
+    for out, A, Bm in outs:
+        ref = A.float().t() @ Bm.float()
+        assert float((out - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+    # the qkv bias gradient really contains the padded rows' share
+    share = dqkv[pad.long()].float().sum(0)
+    assert float(share.abs().max()) > 0 and float((tb_qkv - b_qkv).abs().max()) < 0.05 * float(share.abs().max())
 
 
 def test_gemm_tn_split_through_partial_tiles(monkeypatch):
@@ -586,7 +636,7 @@ def test_gemm_tn_split_through_partial_tiles(monkeypatch):
     monkeypatch.setenv("LAVT_TN_PARTIALS", "1")
     structs, keep, outs = [], [], []
     class _Q:
-        def add(self, p, t): structs.append(p); keep.append(t)
+        def add(self, p, t, extra=False): structs.append(p); keep.append(t)
     members = [cases[0], cases[1], cases[2], (128, 128, mk(Kd, 128), mk(Kd, 128), {})]
     for I, J, A, B, kw in members:
         out = torch.zeros(I, J, device=dev()); cs = torch.zeros(I, device=dev())
