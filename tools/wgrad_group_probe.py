@@ -18,7 +18,7 @@ def build(maps=True, colsum=True, win_rows=Mw):
              (Cc, Cc, win_rows, mk(M if maps else win_rows, Cc), mk(win_rows, Cc), dict(a_rowmap=wmap[:win_rows]) if maps else {})]
     structs, keep = [], []
     class Q:
-        def add(self, p, t): structs.append(p); keep.append(t)
+        def add(self, p, t, extra=False): structs.append(p); keep.append(t)
     for I, J, Kd, A, B, kw in probs:
         out = torch.zeros(I, J, device=dev); cs = torch.zeros(I, device=dev) if colsum else None
         ops.gemm_tn(bf, I, J, Kd, A, I, B, J, out, J, colsum=cs, defer=Q(), **kw)

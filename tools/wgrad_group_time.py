@@ -15,7 +15,7 @@ probs = [(4 * Cc, Cc, M, mk(M, 4 * Cc), mk(M, Cc), {}), (Cc, 4 * Cc, M, mk(M, Cc
          (3 * Cc, Cc, Mw, mk(Mw, 3 * Cc), mk(M, Cc), dict(b_rowmap=wmap)), (Cc, Cc, Mw, mk(M, Cc), mk(Mw, Cc), dict(a_rowmap=wmap))]
 structs, keep = [], []
 class Q:
-    def add(self, p, t): structs.append(p); keep.append(t)
+    def add(self, p, t, extra=False): structs.append(p); keep.append(t)
 outs = []
 for I, J, Kd, A, B, kw in probs:
     out = torch.zeros(I, J, device=dev); cs = torch.zeros(I, device=dev)
