@@ -183,12 +183,13 @@ def profile_step(step, cfg, device, reps=3):
         roof["unannotated_top"] = {"entry": top[0][0][0], "us_per_step": round(top[0][1][1] / reps, 1)}
     if dname == "lavt_gemm_tn_grouped":
         # fabric-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE on
-        # tools/wgrad_group_one.py, the same four problems): a recorded constant, not a measurement of this run
+        # tools/wgrad_group_one.py, the same five problems in token order): a recorded constant, not a measurement of this run
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_conv_and_grouped_wgrad.json")))["wgrad_group_one"]["derived"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_grouped_wgrad_and_wmsa.json")))["wgrad_group_one"]["derived"]
             roof["traffic"] = int(pm["fabric_bytes (FETCH_SIZE KB x2 gfx950 correction + WRITE_SIZE KB)"])
-            roof["traffic_source"] = "profiles/r02_pmc_conv_and_grouped_wgrad.json (recorded)"
-            roof["algorithmic_bytes"] = int(2 * (1536 * 2592 + 512 * 2592 + 512 * 2592 + 512 * 2592 + 2 * (2048 * 1800 + 512 * 1800)) + 4 * (1536 * 512 + 512 * 512 + 2 * 2048 * 512))
+            roof["traffic_source"] = "profiles/r03_pmc_grouped_wgrad_and_wmsa.json (recorded)"
+            # bf16 operands read once (fc2, fc1, proj, the 792 padded rows of dqkv, qkv) + fp32 gradients written once
+            roof["algorithmic_bytes"] = int(2 * (2 * 1800 * (512 + 2048) + 1800 * (512 + 512) + 792 * 1536 + 1800 * (1536 + 512)) + 4 * (2 * 2048 * 512 + 512 * 512 + 1536 * 512))
         except Exception:  # noqa: BLE001
             pass
     scope_us = {k: round(v[0] / reps, 1) for k, v in sorted(scopes.items(), key=lambda kv: -kv[1][0])}

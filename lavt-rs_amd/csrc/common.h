@@ -84,12 +84,13 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- activations ------------------------------------------------------------------------------
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): 1 reciprocal, 1 exponential, 7 fma -- the library erff is ~40 instructions, and inside a
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): 1 reciprocal (v_rcp_f32, 1 ulp: __frcp_rn / a division expand to the 11-instruction
+// IEEE sequence, more than the rest of the function), 1 exponential, 7 fma -- the library erff is ~40 instructions, and inside a
 // GEMM epilogue (two waves per SIMD, nothing to overlap with) the exact form cost 4-5 us on a 1800 x 2048 tile set (tools/gemm_cold_probe.py).
 // Used on the bf16 path only (bf16 keeps 8 significant bits); the fp32 parity path keeps erff.
 __device__ __forceinline__ float erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
     const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     const float y = 1.0f - poly * __expf(-ax * ax);
     return copysignf(y, x);

@@ -161,6 +161,43 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p, f32x4 
     const int64_t c_off = (int64_t)bz * p.strideC;
     const int g = lane >> 4;
     const bool odd = g & 1;
+    // Side inputs of the whole wave tile first (pre-activation of the activation gradient, residual, multiplier), unconditionally -- dead lanes
+    // read row 0: loaded where they are used, each sits behind a per-lane `live` test, and the compiler then waits for every one of them on
+    // its own (vmcnt(0) per fragment: 8 round trips to L2 per wave on the fc2 data gradient, +6 us on a 10 us GEMM; tools/mlp_gemm_probe.py).
+    // Up to 8 fragments per wave (the 128x128 / 8-wave and 64x64 / 4-wave tiles); the 16-fragment tiles keep the loads at the use.
+    constexpr bool PF = MI * NI <= 8;
+    uint2 q_d[PF ? MI : 1][NI], q_r[PF ? MI : 1][NI], q_m[PF ? MI : 1][NI];
+    if constexpr (PF) {
+        int64_t srow[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m_base + i * 16 + (lane & 15);
+            int orow = -1;
+            if (m < p.M) orow = p.c_rowmap ? p.c_rowmap[m] : m;
+            srow[i] = orow >= 0 ? orow : 0;
+        }
+        if constexpr (DACT) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    q_d[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.dact_pre) + srow[i] * p.lddact + n_base + j * 16 + 4 * g);
+        }
+        if (p.R) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    q_r[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.R) + srow[i] * p.ldr + n_base + j * 16 + 4 * g);
+        }
+        if (p.mul) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    q_m[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.mul) + srow[i] * p.ldmul + n_base + j * 16 + 4 * g);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m_base + i * 16 + (lane & 15);
@@ -181,13 +218,15 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p, f32x4 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = (p.alpha * acc[i][2 * jp + h][r] + bb[r]) * rs;
                 if constexpr (DACT) {
-                    if (live) {
+                    if (PF || live) {
                         if (p.res_first && p.R) {          // gradient arriving beside the GEMM's own (a residual branch) joins BEFORE the activation gradient
-                            const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.R) + (int64_t)orow * p.ldr + n);
+                            uint2 q;
+                            if constexpr (PF) q = q_r[i][2 * jp + h]; else q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.R) + (int64_t)orow * p.ldr + n);
                             v[0] += __uint_as_float(q.x << 16); v[1] += __uint_as_float(q.x & 0xFFFF0000u);
                             v[2] += __uint_as_float(q.y << 16); v[3] += __uint_as_float(q.y & 0xFFFF0000u);
                         }
-                        const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.dact_pre) + (int64_t)orow * p.lddact + n);
+                        uint2 q;
+                        if constexpr (PF) q = q_d[i][2 * jp + h]; else q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.dact_pre) + (int64_t)orow * p.lddact + n);
                         v[0] *= act_grad(p.dact, __uint_as_float(q.x << 16)); v[1] *= act_grad(p.dact, __uint_as_float(q.x & 0xFFFF0000u));
                         v[2] *= act_grad(p.dact, __uint_as_float(q.y << 16)); v[3] *= act_grad(p.dact, __uint_as_float(q.y & 0xFFFF0000u));
                     }
@@ -197,13 +236,15 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p, f32x4 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = apply_act<true>(p.act, v[r]);
                 }
-                if (p.mul && live) {        // language gate: x + tanh(g) * r -- the multiplier r rides between the activation and the residual
-                    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.mul) + (int64_t)orow * p.ldmul + n);
+                if (p.mul && (PF || live)) {        // language gate: x + tanh(g) * r -- the multiplier r rides between the activation and the residual
+                    uint2 q;
+                    if constexpr (PF) q = q_m[i][2 * jp + h]; else q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.mul) + (int64_t)orow * p.ldmul + n);
                     v[0] *= __uint_as_float(q.x << 16); v[1] *= __uint_as_float(q.x & 0xFFFF0000u);
                     v[2] *= __uint_as_float(q.y << 16); v[3] *= __uint_as_float(q.y & 0xFFFF0000u);
                 }
-                if (p.R && live && !(DACT && p.res_first)) {          // (an fp32 exchange + one 16-byte residual load measured slower than these 8-byte loads: 2.6 vs 2.0 us on the fc1 shape)
-                    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.R) + (int64_t)orow * p.ldr + n);
+                if (p.R && (PF || live) && !(DACT && p.res_first)) {          // (an fp32 exchange + one 16-byte residual load measured slower than these 8-byte loads: 2.6 vs 2.0 us on the fc1 shape)
+                    uint2 q;
+                    if constexpr (PF) q = q_r[i][2 * jp + h]; else q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.R) + (int64_t)orow * p.ldr + n);
                     v[0] += __uint_as_float(q.x << 16); v[1] += __uint_as_float(q.x & 0xFFFF0000u);
                     v[2] += __uint_as_float(q.y << 16); v[3] += __uint_as_float(q.y & 0xFFFF0000u);
                 }
