@@ -13,9 +13,9 @@ for w in swin_t_w7_480_b8 video_swin_b_t8_384 video_swin_b_t8_384_sept swin_b_w1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/eager -- python3 bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-profile --no-optimizer > $O/eager.log 2>&1
 f=$(ls $O/eager/*/*kernel_stats.csv | head -1); cp $f $O/r03_z_kernel_stats_bf16_swinb_b2.csv
-f=$(ls $O/eager/*/*kernel_trace.csv | head -1); python3 tools/trace_by_shape.py $f 10 80 > $O/r03_z_by_shape.txt
+f=$(ls $O/eager/*/*kernel_trace.csv | head -1); python3 tools/trace_by_shape.py $f auto 80 > $O/r03_z_by_shape.txt
 rm -rf $O/eager
 rocprofv3 --kernel-trace --output-format csv -d $O/graph -- python3 bench.py --steps 40 --warmup 2 --no-cpu-baseline --no-profile --no-optimizer > $O/graph.log 2>&1
-f=$(ls $O/graph/*/*kernel_trace.csv | head -1); python3 tools/trace_by_shape.py $f 45 400 > $O/r03_z_by_shape_graph_replay.txt
+f=$(ls $O/graph/*/*kernel_trace.csv | head -1); python3 tools/trace_by_shape.py $f auto 400 > $O/r03_z_by_shape_graph_replay.txt
 rm -rf $O/graph
 ls -la $O

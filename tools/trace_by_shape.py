@@ -1,7 +1,10 @@
 """Group a rocprofv3 kernel trace by (kernel, grid) over the last N steps: which launches carry the step time."""
 import csv, sys, collections, re
-f, steps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10
+f = sys.argv[1]
 rows = list(csv.DictReader(open(f)))
+# "auto": the number of steps in the trace = launches of a kernel that runs exactly once per step (the fused loss's finish kernel)
+steps = sum("upsample_ce_finish_kernel" in r["Kernel_Name"] for r in rows) if len(sys.argv) > 2 and sys.argv[2] == "auto" else (int(sys.argv[2]) if len(sys.argv) > 2 else 10)
+steps = max(steps, 1)
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
