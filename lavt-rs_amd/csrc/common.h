@@ -101,6 +101,16 @@ __device__ __forceinline__ float gelu_grad_f_fast(float x) {
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+// GELU and its derivative together: Phi(x) from the fast erf, phi(x) from the SAME exponential (exp(-z^2) with z = x / sqrt 2 is exp(-x^2 / 2))
+__device__ __forceinline__ float gelu_pair_fast(float x, float& d) {
+    const float z = x * 0.70710678118654752440f, az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float e = __expf(-az * az);
+    const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, z));
+    d = cdf + x * (0.39894228040143267794f * e);
+    return x * cdf;
+}
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

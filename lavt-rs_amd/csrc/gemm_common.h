@@ -76,7 +76,7 @@ __device__ __forceinline__ uint4 zero16() { return make_uint4(0, 0, 0, 0); }
 
 template <bool FAST = false> __device__ __forceinline__ float apply_act(int act, float v) {
     switch (act) {
-        case LAVT_ACT_GELU: return FAST ? gelu_f_fast(v) : gelu_f(v);
+        case LAVT_ACT_GELU: case LAVT_ACT_GELU_D: return FAST ? gelu_f_fast(v) : gelu_f(v);
         case LAVT_ACT_RELU: return fmaxf(v, 0.f);
         case LAVT_ACT_TANH: return tanhf(v);
         default: return v;
@@ -141,6 +141,7 @@ __device__ __forceinline__ int xcd_tile_id(int b, int nb) {
 __device__ __forceinline__ float act_grad(int act, float pre) {
     switch (act) {
         case LAVT_ACT_GELU: return gelu_grad_f_fast(pre);          // bf16 data-gradient epilogue only
+        case LAVT_ACT_STORED: return pre;                           // the producing launch (LAVT_ACT_GELU_D) stored the derivative itself
         case LAVT_ACT_RELU: return pre > 0.f ? 1.f : 0.f;
         case LAVT_ACT_TANH: { const float t = tanhf(pre); return 1.f - t * t; }
         default: return 1.f;
@@ -231,10 +232,17 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p, f32x4 
                         v[2] *= act_grad(p.dact, __uint_as_float(q.y << 16)); v[3] *= act_grad(p.dact, __uint_as_float(q.y & 0xFFFF0000u));
                     }
                 }
-                packed_pre[h] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                if (p.act) {
+                if (p.act == LAVT_ACT_GELU_D) {           // the second output carries GELU'(pre), computed beside the activation
+                    float d[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = apply_act<true>(p.act, v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_pair_fast(v[r], d[r]);
+                    packed_pre[h] = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
+                } else {
+                    packed_pre[h] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    if (p.act) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act<true>(p.act, v[r]);
+                    }
                 }
                 if (p.mul && (PF || live)) {        // language gate: x + tanh(g) * r -- the multiplier r rides between the activation and the residual
                     uint2 q;
@@ -308,10 +316,15 @@ __device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc
             }
             if (p.Cpre) {
                 T* cp = reinterpret_cast<T*>(p.Cpre) + (int64_t)orow * p.ldcpre + n;
+                float w[4] = {v[0], v[1], v[2], v[3]};
+                if (p.act == LAVT_ACT_GELU_D) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[r] = std::is_same<T, bf16>::value ? gelu_grad_f_fast(v[r]) : gelu_grad_f(v[r]);
+                }
                 if (full) {
-                    if constexpr (std::is_same<T, float>::value) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-                    else *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                } else for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = from_f<T>(v[r]);
+                    if constexpr (std::is_same<T, float>::value) *reinterpret_cast<float4*>(cp) = make_float4(w[0], w[1], w[2], w[3]);
+                    else *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]));
+                } else for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = from_f<T>(w[r]);
             }
             if (p.act) {
 #pragma unroll
@@ -383,6 +396,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const lavt_gemm_nt_t& p, f32x4 (
                     if (bias && n + r < p.N) v[r] += bias[n + r];
                     v[r] *= rs[i];
                     if (!pre && p.act) v[r] = apply_act<true>(p.act, v[r]);
+                    if (pre && p.act == LAVT_ACT_GELU_D) v[r] = gelu_grad_f_fast(v[r]);
                 }
                 *reinterpret_cast<uint2*>(sC + ml * LD + nl) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             }

@@ -101,7 +101,7 @@ class _Lib:
 lib = _Lib(_cdll)
 
 F32, BF16, FP8 = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_GELU_D, ACT_STORED = 0, 1, 2, 3, 4, 5
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 
