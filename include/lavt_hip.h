@@ -344,6 +344,8 @@ int lavt_gate_bwd(int dtype, const void* dxo, const void* gpre, const void* r, c
  *   lavt_ln_fold: Wg[n][k] = bf16(gamma_k W[n][k]), wsum[n] = sum_k Wg[n][k], biasp[n] = bias_n + sum_k beta_k W[n][k]   (per weight update)
  * ------------------------------------------------------------------------------------------- */
 int lavt_ln_fold(const float* W, const float* gamma, const float* beta, const float* bias, void* Wg, float* wsum, float* biasp, int N, int K, void* stream);
+/* every fold of a model in one launch: desc int64 [count][9] = {W, gamma, beta, bias, Wg, wsum, biasp, N, K} in device memory */
+int lavt_ln_fold_multi(const int64_t* desc, int count, void* stream);
 int lavt_wmsa_fwd(const void* x, const int32_t* wmap, const void* Wg, const float* wsum, const float* biasp, const float* bias, const float* gamma,
                   const float* beta, const float* table, const int8_t* region, int nw_img, void* out, float* lse, void* qkv, void* xn, float* mean,
                   float* rstd, const void* zeros, int ws, int nwin, int N, int heads, int C, float eps, float scale, void* stream);
@@ -438,6 +440,12 @@ int lavt_cast_multi(const int64_t* desc, int count, int dst_dtype, void* stream)
  * incremented by the call (so a captured hipGraph keeps advancing its schedule); lr = base lr * (1 - step/total_steps)^power, or the
  * base lr when total_steps <= 0.  Update rule identical to torch.optim.AdamW (decoupled decay, bias-corrected moments). */
 int lavt_adamw_step(const int64_t* desc, const float* hyper, int count, float* step, float total_steps, float power, void* stream);
+/* The same update driven by a chunk table (ABI v4): desc int64 [count][6] = {param, grad, exp_avg, exp_avg_sq, numel, copy} -- a non-zero `copy` is the
+ * parameter's bf16 compute copy in the same layout, written by the same kernel (the mixed-precision trainer's re-cast of the weights the next
+ * forward reads, without a second pass over the parameters); chunks int32 [nchunks][2] = {tensor index, chunk index}: workgroup c updates elements
+ * [chunk * lavt_adamw_chunk_elems(), ...) of its tensor, so every workgroup has work.  hyper, step, schedule as above. */
+int lavt_adamw_chunk_elems(void);
+int lavt_adamw_step_chunks(const int64_t* desc, const float* hyper, const int32_t* chunks, int nchunks, float* step, float total_steps, float power, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Text side (lavt_one / lavt_video carry BERT inside the model: lib/_utils.py:38-52; train.py:595-602; the encoder is HF transformers

@@ -507,6 +507,64 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const int64_t* __restr
 }
 __global__ void adamw_tick_kernel(float* step) { step[0] += 1.f; }
 
+// The same update over a CHUNK table: workgroup c updates elements [chunk * CE, (chunk + 1) * CE) of tensor chunks[c].x -- every workgroup has work
+// (the per-tensor grid above launches 256 workgroups per tensor: ~100 000 of them find nothing to do for the ~400 small tensors of a Swin-B LAVT)
+// and all of a thread's loads are issued before the first use.  desc: int64 [count][6] = {param, grad, exp_avg, exp_avg_sq, numel, copy}: a
+// non-zero `copy` is the parameter's bf16 compute copy in the same layout (Linear / 1x1 weights), written from the registers that hold the
+// updated value -- the separate re-cast pass (a second read of every parameter) disappears.
+constexpr int ADAMW_CE = 8192;            // elements per chunk: 256 threads x 2 rounds x 4 float4
+__global__ __launch_bounds__(256) void adamw_chunks_kernel(const int64_t* __restrict__ desc, const float* __restrict__ hyper, const int2* __restrict__ chunks,
+                                                           const float* __restrict__ step, float total_steps, float power) {
+    const int2 ch = chunks[blockIdx.x];
+    const int t = ch.x;
+    float* p = reinterpret_cast<float*>(desc[6 * t]);
+    const float* g = reinterpret_cast<const float*>(desc[6 * t + 1]);
+    float* m = reinterpret_cast<float*>(desc[6 * t + 2]);
+    float* v = reinterpret_cast<float*>(desc[6 * t + 3]);
+    const int64_t n = desc[6 * t + 4];
+    bf16* cp = reinterpret_cast<bf16*>(desc[6 * t + 5]);
+    const float b1 = hyper[5 * t + 2], b2 = hyper[5 * t + 3], eps = hyper[5 * t + 4], wd = hyper[5 * t + 1];
+    const float k = step[0];
+    const float sched = total_steps > 0.f ? powf(fmaxf(1.f - k / total_steps, 0.f), power) : 1.f;
+    const float lr = hyper[5 * t] * sched;
+    const float bc1 = 1.f - powf(b1, k + 1.f), bc2 = 1.f - powf(b2, k + 1.f);
+    const float step_size = lr / bc1, rbc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        pp *= decay;
+        mm = b1 * mm + (1.f - b1) * gg;
+        vv = b2 * vv + (1.f - b2) * gg * gg;
+        pp -= step_size * mm / (sqrtf(vv) * rbc2 + eps);
+    };
+    const int64_t e0 = (int64_t)ch.y * ADAMW_CE, e1 = min(n, e0 + ADAMW_CE);
+    const bool vec = ((desc[6 * t] | desc[6 * t + 1] | desc[6 * t + 2] | desc[6 * t + 3]) & 15) == 0 && (desc[6 * t + 5] & 7) == 0;
+    if (vec && e1 - e0 == ADAMW_CE) {          // a whole chunk: no per-element conditions (a conditional load costs a branch and a full wait each)
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            float4 pp[4], gg[4], mm[4], vv[4];
+            const int64_t base = e0 + (int64_t)round * 4096 + threadIdx.x * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = base + u * 1024;
+                pp[u] = *reinterpret_cast<const float4*>(p + i); gg[u] = *reinterpret_cast<const float4*>(g + i);
+                mm[u] = *reinterpret_cast<const float4*>(m + i); vv[u] = *reinterpret_cast<const float4*>(v + i);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = base + u * 1024;
+                upd(pp[u].x, gg[u].x, mm[u].x, vv[u].x); upd(pp[u].y, gg[u].y, mm[u].y, vv[u].y);
+                upd(pp[u].z, gg[u].z, mm[u].z, vv[u].z); upd(pp[u].w, gg[u].w, mm[u].w, vv[u].w);
+                *reinterpret_cast<float4*>(p + i) = pp[u]; *reinterpret_cast<float4*>(m + i) = mm[u]; *reinterpret_cast<float4*>(v + i) = vv[u];
+                if (cp) *reinterpret_cast<uint2*>(cp + i) = make_uint2(pack_bf16x2(pp[u].x, pp[u].y), pack_bf16x2(pp[u].z, pp[u].w));
+            }
+        }
+    } else {                                   // a tensor's last chunk / unaligned tensors
+        for (int64_t i = e0 + threadIdx.x; i < e1; i += 256) {
+            upd(p[i], g[i], m[i], v[i]);
+            if (cp) cp[i] = from_f<bf16>(p[i]);
+        }
+    }
+}
+
 template <typename D> __global__ void cast_multi_kernel(const int64_t* desc, int count) {
     // blockIdx.y = tensor; grid-stride over its elements
     const int t = blockIdx.y;
@@ -729,6 +787,15 @@ extern "C" int lavt_adamw_step(const int64_t* desc, const float* hyper, int coun
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(256, count), dim3(256), 0, ST, desc, hyper, count, step, total_steps, power);      // small tensors: surplus workgroups exit at once
     hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, ST, step);
     LAVT_CHECK_LAUNCH("lavt_adamw_step");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_adamw_chunk_elems(void) { return ADAMW_CE; }
+extern "C" int lavt_adamw_step_chunks(const int64_t* desc, const float* hyper, const int32_t* chunks, int nchunks, float* step, float total_steps, float power, void* stream) {
+    LAVT_CHECK_ARG(desc && hyper && chunks && step && nchunks > 0, "lavt_adamw_step_chunks: bad arguments");
+    hipLaunchKernelGGL(adamw_chunks_kernel, dim3(nchunks), dim3(256), 0, ST, desc, hyper, reinterpret_cast<const int2*>(chunks), step, total_steps, power);
+    hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, ST, step);
+    LAVT_CHECK_LAUNCH("lavt_adamw_step_chunks");
     return LAVT_OK;
 }
 

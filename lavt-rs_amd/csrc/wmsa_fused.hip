@@ -336,6 +336,34 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ 
     if (lane == 0) { wsum[n] = s; biasp[n] = bp + (bias ? bias[n] : 0.f); }
 }
 
+// every fold of a model in one launch: desc int64 [count][9] = {W, gamma, beta, bias, Wg, wsum, biasp, N, K} (device table), blockIdx.y = fold
+__global__ __launch_bounds__(256) void ln_fold_multi_kernel(const int64_t* __restrict__ desc) {
+    const int64_t* d = desc + 9 * (int64_t)blockIdx.y;
+    const float* W = reinterpret_cast<const float*>(d[0]);
+    const float* gamma = reinterpret_cast<const float*>(d[1]);
+    const float* beta = reinterpret_cast<const float*>(d[2]);
+    const float* bias = reinterpret_cast<const float*>(d[3]);
+    bf16* Wg = reinterpret_cast<bf16*>(d[4]);
+    float* wsum = reinterpret_cast<float*>(d[5]);
+    float* biasp = reinterpret_cast<float*>(d[6]);
+    const int N = (int)d[7], Kd = (int)d[8];
+    const int lane = threadIdx.x & 63;
+    for (int n = blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += gridDim.x * 4) {
+        float s = 0.f, bp = 0.f;
+        for (int k = lane * 4; k < Kd; k += 256) {
+            const float4 w4 = *reinterpret_cast<const float4*>(W + (int64_t)n * Kd + k), g4 = *reinterpret_cast<const float4*>(gamma + k), b4 = *reinterpret_cast<const float4*>(beta + k);
+            const float v[4] = {w4.x * g4.x, w4.y * g4.y, w4.z * g4.z, w4.w * g4.w};
+            const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            *reinterpret_cast<uint2*>(Wg + (int64_t)n * Kd + k) = pk;
+            s += __uint_as_float(pk.x << 16) + __uint_as_float(pk.x & 0xFFFF0000u) + __uint_as_float(pk.y << 16) + __uint_as_float(pk.y & 0xFFFF0000u);
+            bp += w4.x * b4.x + w4.y * b4.y + w4.z * b4.z + w4.w * b4.w;
+        }
+        s = wave_sum(s);
+        bp = wave_sum(bp);
+        if (lane == 0) { wsum[n] = s; biasp[n] = bp + (bias ? bias[n] : 0.f); }
+    }
+}
+
 template <int NT, bool FULL> int launch_wmsa(const WmsaArgs& a, hipStream_t st) {
     constexpr int KS = (NT + 1) / 2, NP = KS * 32, TR = ((NT * 16 + 96 + 63) / 64) * 64, MR = TR - 96, STAGE = TR * 128;
     const int R = (2 * a.wh - 1) * (2 * a.ww - 1);
@@ -362,6 +390,13 @@ extern "C" int lavt_ln_fold(const float* W, const float* gamma, const float* bet
     LAVT_CHECK_ARG(W && gamma && beta && Wg && wsum && biasp && N > 0 && K > 0 && K % 4 == 0, "lavt_ln_fold: bad arguments");
     hipLaunchKernelGGL(ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, gamma, beta, bias, (bf16*)Wg, wsum, biasp, N, K);
     LAVT_CHECK_LAUNCH("lavt_ln_fold");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_ln_fold_multi(const int64_t* desc, int count, void* stream) {
+    LAVT_CHECK_ARG(desc && count > 0, "lavt_ln_fold_multi: bad arguments");
+    hipLaunchKernelGGL(ln_fold_multi_kernel, dim3(128, count), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
+    LAVT_CHECK_LAUNCH("lavt_ln_fold_multi");
     return LAVT_OK;
 }
 

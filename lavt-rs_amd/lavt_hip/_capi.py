@@ -190,6 +190,9 @@ _PROTOTYPES = {
     "lavt_logits_up_bwd": [i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "lavt_unpack_conv_grad": [vp, vp, i32, i32, i32, vp],
     "lavt_adamw_step": [vp, vp, i32, vp, f32, f32, vp],
+    "lavt_adamw_step_chunks": [vp, vp, vp, i32, vp, f32, f32, vp],
+    "lavt_adamw_chunk_elems": [],
+    "lavt_ln_fold_multi": [vp, i32, vp],
     "lavt_upsample_ce_fwd": [i32, vp, vp, f32, f32, vp, i64, vp, i32, i32, i32, i32, i32, vp],
     "lavt_upsample_ce_bwd": [i32, vp, vp, f32, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "lavt_upsample_dice_fwd": [i32, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, vp],
@@ -218,7 +221,7 @@ if _cdll.lavt_abi_version() != EXPECTED_ABI:
 _cdll.lavt_last_error.restype = C.c_char_p
 _cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
 _cdll.lavt_last_error.argtypes = []
-for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts"):      # queries, not launches: never timed
+for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts", "lavt_adamw_chunk_elems"):      # queries, not launches: never timed
     setattr(lib, _name, getattr(_cdll, _name))
 
 EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)

@@ -138,22 +138,31 @@ class _WeightCache:
         desc = torch.tensor([[e[2]().data_ptr(), e[1].data_ptr(), e[1].numel()] for _, e in ents], dtype=torch.int64)
         self.multi = (dtype, desc.to(dev), [k for k, _ in ents])
 
-    def refresh_all(self):
-        """Start of a step: make every compute copy current (1 launch for all Linear weights + 1 per 3x3 conv)."""
+    def refresh_all(self, done=frozenset()):
+        """Start of a step / end of an optimizer step: make every compute copy current (1 launch for all Linear weights + 1 per 3x3 conv + 1 for all
+        LayerNorm folds).  `done`: keys of 'lin' copies the caller has just written itself (FusedAdamW's update kernel): only their stamps move."""
         self.epoch += 1
         multi = getattr(self, "multi", None)
-        done = set()
+        fresh = set()
+        for k in done:
+            ent = self.store.get(k)
+            if ent is not None and ent[2]() is not None:
+                p = ent[2]()
+                self.store[k] = ((p._version, p.data_ptr(), self.epoch), ent[1], ent[2])
+                fresh.add(k)
         if multi is not None:
             dtype, desc, keys = multi
             if all(k in self.store and self.store[k][2]() is not None for k in keys):      # parameters still alive and cached
-                K.check(K.lib.lavt_cast_multi(K.ptr(desc), desc.shape[0], K.dt(dtype), K.stream()))
+                if not all(k in fresh for k in keys):
+                    K.check(K.lib.lavt_cast_multi(K.ptr(desc), desc.shape[0], K.dt(dtype), K.stream()))
                 for k in keys:
                     st, out, ref = self.store[k]
                     p = ref()
                     self.store[k] = ((p._version, p.data_ptr(), self.epoch), out, ref)
-                    done.add(k)
+                    fresh.add(k)
             else:
                 self.multi = None
+        folds = []
         for k, (st, out, ref) in list(self.store.items()):
             p = ref()
             if p is None:
@@ -163,11 +172,27 @@ class _WeightCache:
             elif k[1] == "lnfold":
                 others = [r() for r in out[3]]
                 if all(o is not None for o in others):
-                    self.get_lnfold(*others)
+                    folds.append((k, others, out))
                 else:
                     del self.store[k]
-            elif k not in done:
+            elif k not in fresh:
                 self.get(p, k[1], k[2])
+        if folds:
+            self._refresh_folds(folds)
+
+    def _refresh_folds(self, folds):
+        """all LayerNorm folds in ONE launch (48 per Swin-B step otherwise); the device descriptor table is rebuilt only when the set changes"""
+        key = tuple((k, tuple(p.data_ptr() for p in ps)) for k, ps, _ in folds)
+        tab = getattr(self, "fold_table", None)
+        if tab is None or tab[0] != key:
+            rows = [[w.data_ptr(), g.data_ptr(), be.data_ptr(), b.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), w.shape[0], w.numel() // w.shape[0]]
+                    for _, (w, b, g, be), out in folds]
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("LayerNorm folds: the set of folded weights changed inside a graph capture")
+            tab = self.fold_table = (key, torch.tensor(rows, dtype=torch.int64).to(folds[0][1][0].device))
+        K.check(K.lib.lavt_ln_fold_multi(K.ptr(tab[1]), len(folds), K.stream()))
+        for k, ps, out in folds:
+            self.store[k] = ((tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps), self.epoch), out, self.store[k][2])
 
 
 weights = _WeightCache()

@@ -9,6 +9,7 @@ checkpoint code (train.py:749-763) keeps working.  The step counter and the sche
 captured into the same hipGraph as forward/backward and still follows (1 - it/T)^0.9 on every replay (a LambdaLR on the host would be
 frozen at capture time).  amsgrad (off by default in the reference) is not implemented.
 """
+import os
 from typing import Iterable
 
 import torch
@@ -37,6 +38,7 @@ class FusedAdamW(torch.optim.Optimizer):
             raise NotImplementedError("FusedAdamW: amsgrad is not implemented (the reference's default is off)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
         self.total_steps, self.power = float(total_steps), float(power)
+        self.fuse_copies = os.environ.get("LAVT_ADAMW_FUSE_COPIES", "1") != "0"
         self._tables = None
         self._step = None
 
@@ -59,17 +61,30 @@ class FusedAdamW(torch.optim.Optimizer):
                 st.setdefault("step", self._step)
                 st["exp_avg"], st["exp_avg_sq"] = flat_m[off:off + n].view_as(p), flat_v[off:off + n].view_as(p)
                 off += n
-        desc, hyper, missing = [], [], []
+        from . import ops
+        desc, hyper, missing, chunks, fused = [], [], [], [], []
+        ce = int(K.lib.lavt_adamw_chunk_elems())
         for g, p in ps:
             if p.grad is None:
                 missing.append(p)
                 continue
             assert p.dtype == torch.float32 and p.grad.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
             st = self.state[p]
-            desc.append([p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()])
+            # the parameter's bf16 compute copy in the parameter's own layout (Linear / 1x1 weights: lavt_hip.ops.weights, kind 'lin') is written by
+            # the update kernel itself; packed conv weights, e4m3 copies and LayerNorm folds are refreshed after it (ops.weights.refresh_all)
+            ck = (id(p), torch.bfloat16, "lin")
+            ent = ops.weights.store.get(ck) if self.fuse_copies else None
+            copy = 0
+            if ent is not None and ent[2]() is p and ent[1].numel() == p.numel() and ent[1].is_contiguous():
+                copy = ent[1].data_ptr()
+                fused.append(ck)
+            for c in range(-(-p.numel() // ce)):
+                chunks.append([len(desc), c])
+            desc.append([p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), copy])
             hyper.append([g["lr"], g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"]])
-        key = tuple(d[1] for d in desc) + tuple(tuple(h) for h in hyper)
-        self._tables = (key, torch.tensor(desc, dtype=torch.int64).to(dev), torch.tensor(hyper, dtype=torch.float32).to(dev), len(desc))
+        key = tuple(d[1] for d in desc) + tuple(tuple(h) for h in hyper) + (len(ops.weights.store),)
+        self._tables = (key, torch.tensor(desc, dtype=torch.int64).to(dev), torch.tensor(hyper, dtype=torch.float32).to(dev), len(desc),
+                        torch.tensor(chunks, dtype=torch.int32).to(dev), len(chunks), frozenset(fused))
 
     def _current_key(self):
         out = []
@@ -79,7 +94,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 if p.requires_grad and p.grad is not None:
                     out.append(p.grad.data_ptr())
                     hy.append((g["lr"], g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"]))
-        return tuple(out) + tuple(hy)
+        from . import ops
+        return tuple(out) + tuple(hy) + (len(ops.weights.store),)
 
     @torch.no_grad()
     def step(self, closure=None, check_tables=True):
@@ -88,14 +104,14 @@ class FusedAdamW(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         if self._tables is None or (check_tables and self._tables[0] != self._current_key()):
             self._build()
-        _, desc, hyper, n = self._tables
-        K.check(K.lib.lavt_adamw_step(K.ptr(desc), K.ptr(hyper), n, K.ptr(self._step), self.total_steps, self.power, K.stream()))
+        _, desc, hyper, n, chunks, nchunks, fused = self._tables
+        K.check(K.lib.lavt_adamw_step_chunks(K.ptr(desc), K.ptr(hyper), K.ptr(chunks), nchunks, K.ptr(self._step), self.total_steps, self.power, K.stream()))
         # The kernel writes the parameters through raw pointers: p._version does not move, so the cached compute copies (bf16 Linear weights,
         # packed conv weights) are stale now.  They are part of the optimizer's output (fp32 master weights + the compute-dtype copies the next
         # forward reads, as in any mixed-precision trainer): re-cast them here, on the same stream, so that the forward/backward step itself
         # carries no cast kernels (the step harness refreshes them only when asked to: TrainStep(refresh_weights_in_step=True)).
         from . import ops
-        ops.weights.refresh_all()
+        ops.weights.refresh_all(done=fused)          # the copies in `fused` were written by the update kernel: only their stamps move
         return loss
 
     def steps_taken(self) -> int:

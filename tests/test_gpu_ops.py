@@ -489,6 +489,36 @@ def test_fused_adamw_matches_torch():
     assert again.steps_taken() == 6 and again.total_steps == T
 
 
+def test_fused_adamw_keeps_the_compute_copies_current():
+    """FusedAdamW's update kernel writes the bf16 compute copies of the Linear weights itself (lavt_adamw_step_chunks, `copy` column) and refreshes the
+    LayerNorm folds in one launch (lavt_ln_fold_multi): after a step every cached copy equals what a fresh cast / fold of the updated parameters gives"""
+    from lavt_hip import ops
+    from lavt_hip.optim import FusedAdamW
+    g = torch.Generator().manual_seed(11)
+    mk = lambda *sh: torch.nn.Parameter((torch.randn(*sh, generator=g) * 0.3).to(dev()))
+    W, b, gamma, beta, W2 = mk(192, 128), mk(192), mk(128), mk(128), mk(20000, 64)          # W2: several chunks + a partial last one
+    c1, c2 = ops.weights.get(W, torch.bfloat16, "lin"), ops.weights.get(W2, torch.bfloat16, "lin")
+    Wg, wsum, biasp = ops.weights.get_lnfold(W, b, gamma, beta)
+    ptrs = (c1.data_ptr(), c2.data_ptr(), Wg.data_ptr())
+    opt = FusedAdamW([W, b, gamma, beta, W2], lr=3e-2, weight_decay=1e-2)
+    for it in range(2):
+        for p in (W, b, gamma, beta, W2):
+            p.grad = torch.randn(p.shape, generator=g).to(dev())
+        before = W.detach().clone()
+        opt.step()
+    torch.cuda.synchronize()
+    assert len(opt._tables[6]) == 2 and float((W - before).abs().max()) > 1e-3
+    c1n, c2n = ops.weights.get(W, torch.bfloat16, "lin"), ops.weights.get(W2, torch.bfloat16, "lin")
+    Wgn, wsumn, biaspn = ops.weights.get_lnfold(W, b, gamma, beta)
+    assert (c1n.data_ptr(), c2n.data_ptr(), Wgn.data_ptr()) == ptrs                           # static addresses (hipGraph replays)
+    assert torch.equal(c1n, W.detach().to(torch.bfloat16)) and torch.equal(c2n.view(-1), W2.detach().to(torch.bfloat16).view(-1))
+    ref_g = (W.detach() * gamma.detach()[None, :]).to(torch.bfloat16)
+    assert torch.equal(Wgn, ref_g)
+    assert float((wsumn - ref_g.float().sum(1)).abs().max()) <= 1e-4 * float(ref_g.float().abs().sum(1).max())
+    ref_b = b.detach() + W.detach() @ beta.detach()
+    assert float((biaspn - ref_b).abs().max()) <= 1e-4 * max(float(ref_b.abs().max()), 1.0)
+
+
 def test_fused_adamw_in_hip_graph():
     """the device-side step counter keeps the schedule moving when the optimizer step is replayed from a captured hipGraph"""
     from lavt_hip.optim import FusedAdamW
