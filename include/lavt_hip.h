@@ -37,7 +37,8 @@ extern "C" {
 #define LAVT_ACT_RELU 2
 #define LAVT_ACT_TANH 3
 #define LAVT_ACT_GELU_D 4 /* lavt_gemm_nt.act: GELU whose Cpre output holds GELU'(pre) instead of pre (bf16 operands; the derivative shares the
-                           * exponential of the activation: +2 fma per element), for a consumer that only needs the derivative (ABI v4) */
+                           * exponential of the activation: +2 fma per element), for a consumer that only needs the derivative (ABI v4).
+                           * LayerNorm-folded launches only (ln_wsum): the branch is compiled into that kernel alone */
 #define LAVT_ACT_STORED 5 /* lavt_gemm_nt.dact: dact_pre already holds act'(pre) (written by a LAVT_ACT_GELU_D launch): C * dact_pre (ABI v4) */
 
 int lavt_abi_version(void);

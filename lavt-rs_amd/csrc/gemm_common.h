@@ -141,7 +141,6 @@ __device__ __forceinline__ int xcd_tile_id(int b, int nb) {
 __device__ __forceinline__ float act_grad(int act, float pre) {
     switch (act) {
         case LAVT_ACT_GELU: return gelu_grad_f_fast(pre);          // bf16 data-gradient epilogue only
-        case LAVT_ACT_STORED: return pre;                           // the producing launch (LAVT_ACT_GELU_D) stored the derivative itself
         case LAVT_ACT_RELU: return pre > 0.f ? 1.f : 0.f;
         case LAVT_ACT_TANH: { const float t = tanhf(pre); return 1.f - t * t; }
         default: return 1.f;
@@ -155,8 +154,13 @@ __device__ __forceinline__ float act_grad(int act, float pre) {
 // an odd group columns 4(g-1) .. 4(g-1)+7 of the second -- one 16-byte store per lane, 64 contiguous bytes per row per wave-instruction, half
 // the store instructions.  Bias is read as float4.  Conditions are checked by the caller (whole 32-column pairs inside N, 16-byte aligned rows).
 __device__ __forceinline__ uint2 xchg16(uint2 v) { return make_uint2((unsigned)__shfl_xor((int)v.x, 16, 64), (unsigned)__shfl_xor((int)v.y, 16, 64)); }
-template <int MI, int NI, bool DACT>
-__device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz) {
+// LEAN: the launch uses none of {activation, multiplier, second (pre-activation) output, split output}: those branches are compiled out.  Carrying
+// them as not-taken uniform branches costs every plain GEMM of the step (tools/ab_lib.sh: -0.2 ms per step with all of them compiled out, of which
+// about half is the launches that do use them).
+template <int MI, int NI, bool DACT, bool GD = false, bool LEAN = false>
+__device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz) {
+    lavt_gemm_nt_t p = p_in;
+    if constexpr (LEAN) { p.act = 0; p.mul = nullptr; p.Cpre = nullptr; p.C2 = nullptr; }
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
     const float* rscale = p.row_scale ? p.row_scale + (int64_t)bz * p.strideRowScale : nullptr;
     const int64_t c_off = (int64_t)bz * p.strideC;
@@ -228,11 +232,17 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p, f32x4 
                         }
                         uint2 q;
                         if constexpr (PF) q = q_d[i][2 * jp + h]; else q = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.dact_pre) + (int64_t)orow * p.lddact + n);
-                        v[0] *= act_grad(p.dact, __uint_as_float(q.x << 16)); v[1] *= act_grad(p.dact, __uint_as_float(q.x & 0xFFFF0000u));
-                        v[2] *= act_grad(p.dact, __uint_as_float(q.y << 16)); v[3] *= act_grad(p.dact, __uint_as_float(q.y & 0xFFFF0000u));
+                        if (p.dact == LAVT_ACT_STORED) {       // the producing launch (LAVT_ACT_GELU_D) stored the derivative itself: a uniform branch around
+                            v[0] *= __uint_as_float(q.x << 16); v[1] *= __uint_as_float(q.x & 0xFFFF0000u);      // the transcendental forms, not a case of
+                            v[2] *= __uint_as_float(q.y << 16); v[3] *= __uint_as_float(q.y & 0xFFFF0000u);      // act_grad's switch
+                        } else {                                                                                 // (as a case of it, both forms ran slower)
+                            v[0] *= act_grad(p.dact, __uint_as_float(q.x << 16)); v[1] *= act_grad(p.dact, __uint_as_float(q.x & 0xFFFF0000u));
+                            v[2] *= act_grad(p.dact, __uint_as_float(q.y << 16)); v[3] *= act_grad(p.dact, __uint_as_float(q.y & 0xFFFF0000u));
+                        }
                     }
                 }
-                if (p.act == LAVT_ACT_GELU_D) {           // the second output carries GELU'(pre), computed beside the activation
+                if constexpr (GD) {                        // the second output carries GELU'(pre), computed beside the activation (GD: only the
+                                                          // LayerNorm-folded launch is built with this branch -- in every NT kernel it cost 0.16 ms per step)
                     float d[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = gelu_pair_fast(v[r], d[r]);
@@ -276,11 +286,11 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p, f32x4 
     }
 }
 
-template <typename T, int MI, int NI, bool DACT = false>
+template <typename T, int MI, int NI, bool DACT = false, bool GD = false, bool LEAN = false>
 __device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz) {
     if constexpr (std::is_same<T, bf16>::value && NI % 2 == 0) {
         // wave-uniform conditions: the whole wave takes one path (the exchanges need every lane)
-        if (!p.c_f32 && p.epi_wide && n_base + NI * 16 <= p.N) { nt_epilogue_wide<MI, NI, DACT>(p, acc, m_base, n_base, lane, bz); return; }
+        if (!p.c_f32 && p.epi_wide && n_base + NI * 16 <= p.N) { nt_epilogue_wide<MI, NI, DACT, GD, LEAN>(p, acc, m_base, n_base, lane, bz); return; }
     }
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
     const float* rscale = p.row_scale ? p.row_scale + (int64_t)bz * p.strideRowScale : nullptr;
@@ -312,12 +322,12 @@ __device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc
                 }
                 const T* dp = reinterpret_cast<const T*>(p.dact_pre) + (int64_t)orow * p.lddact + n;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] *= act_grad(p.dact, to_f<T>(dp[r]));
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] *= p.dact == LAVT_ACT_STORED ? to_f<T>(dp[r]) : act_grad(p.dact, to_f<T>(dp[r]));
             }
             if (p.Cpre) {
                 T* cp = reinterpret_cast<T*>(p.Cpre) + (int64_t)orow * p.ldcpre + n;
                 float w[4] = {v[0], v[1], v[2], v[3]};
-                if (p.act == LAVT_ACT_GELU_D) {
+                if constexpr (GD) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) w[r] = std::is_same<T, bf16>::value ? gelu_grad_f_fast(v[r]) : gelu_grad_f(v[r]);
                 }
@@ -365,7 +375,7 @@ __device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc
 // The direct epilogue above issues 8-byte stores that touch 16 different rows per wave-instruction (32-B segments): the
 // store tail is issue-bound (cdna_hip_programming.md T21).  Here the C tile goes registers -> LDS ([BM][BN+8] bf16) -> global
 // as 16 B per lane, 4 full 256-B rows per wave-instruction; the residual is read with the same coalesced pattern.
-template <int BM, int BN, int MI, int NI>
+template <int BM, int BN, int MI, int NI, bool GD = false>
 __device__ __forceinline__ void nt_epilogue_lds(const lavt_gemm_nt_t& p, f32x4 (&acc)[MI][NI], bf16* sC, int m0, int n0, int wm_off, int wn_off,
                                                 int tid, int lane, int bz) {
     constexpr int LD = BN + 8, CPR = BN / 8, CHUNKS = BM * CPR;
@@ -396,7 +406,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const lavt_gemm_nt_t& p, f32x4 (
                     if (bias && n + r < p.N) v[r] += bias[n + r];
                     v[r] *= rs[i];
                     if (!pre && p.act) v[r] = apply_act<true>(p.act, v[r]);
-                    if (pre && p.act == LAVT_ACT_GELU_D) v[r] = gelu_grad_f_fast(v[r]);
+                    if (GD && pre) v[r] = gelu_grad_f_fast(v[r]);
                 }
                 *reinterpret_cast<uint2*>(sC + ml * LD + nl) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             }

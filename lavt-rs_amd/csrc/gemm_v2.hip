@@ -130,7 +130,7 @@ typedef __attribute__((__vector_size__(8 * sizeof(int)))) int i32x8;
 // streams the whole K = C of its rows, so the row sums / sums of squares are accumulated from the resident A tiles (v_dot2c_f32_bf16) and the
 // accumulators become rstd_m (acc - mu_m wsum_n) before the ordinary epilogue, whose `bias` is then biasp = b + W beta: the LayerNorm launch and its
 // [M, C] output disappear (norm2 -> fc1 of a Swin block, reference lib/backbone.py:243 + :24-30).
-template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false, bool LNA = false>
+template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false, bool LNA = false, bool GD = false, bool LEAN = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_nt_t p) {
     constexpr bool SIMPLE = MODE == 1, CONVFAST = MODE == 2;
     static_assert(!LNA || (MODE == 1 && !BKM && !DACT && !F8), "LNA: plain k-contiguous problems");
@@ -518,27 +518,30 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
     }
     if constexpr (DACT) { nt_epilogue<T, MI, NI, true>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz); return; }
     if (!p.epi_lds || p.mul || p.c_f32 || (p.ldc % 8) || (p.C2 && (p.ldc2 % 8 || p.c_split % 8)) || (p.R && p.ldr % 8) || (p.Cpre && p.ldcpre % 8))
-        nt_epilogue<T, MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
+        nt_epilogue<T, MI, NI, false, GD, LEAN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);           // (GD = LAVT_ACT_GELU_D: its own instantiation of the LayerNorm-folded launch)
     else
-        nt_epilogue_lds<BM, BN, MI, NI>(p, acc, reinterpret_cast<bf16*>(smem), m0, n0, wm * WM, wn * WN, tid, lane, bz);
+        nt_epilogue_lds<BM, BN, MI, NI, GD>(p, acc, reinterpret_cast<bf16*>(smem), m0, n0, wm * WM, wn * WN, tid, lane, bz);
     }
 }
 
 static inline int conv_taps_of(const lavt_gemm_nt_t& p) {
     return (p.conv_kd > 0 ? p.conv_kd : 1) * (p.conv_kh > 0 ? p.conv_kh : 3) * (p.conv_kw > 0 ? p.conv_kw : 3);
 }
-template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false, bool LNA = false> int launch_nt_v2_(const lavt_gemm_nt_t& p, hipStream_t st) {
+template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false, bool LNA = false, bool GD = false, bool LEAN = false> int launch_nt_v2_(const lavt_gemm_nt_t& p, hipStream_t st) {
+    if constexpr (!LEAN && !DACT && !LNA && !F8 && MODE != 0) {          // plain epilogue (bias / residual / row scale / row map only): the lean instantiation
+        if (p.act == 0 && !p.mul && !p.Cpre && !p.C2) return launch_nt_v2_<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8, LNA, GD, true>(p, st);
+    }
     constexpr size_t lds = STAGES * (size_t)(BM * 128 + BN * 128);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8, LNA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8, LNA, GD, LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             lavt_set_error("lavt_gemm_nt(v2): cannot reserve %zu bytes of LDS", lds);
             return LAVT_ERR_LAUNCH;
         }
         attr_set = true;
     }
     dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch);
-    hipLaunchKernelGGL((gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8, LNA>), grid, dim3(WAVES * 64), lds, st, p);
+    hipLaunchKernelGGL((gemm_nt_v2_kernel<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8, LNA, GD, LEAN>), grid, dim3(WAVES * 64), lds, st, p);
     LAVT_CHECK_LAUNCH("lavt_gemm_nt(v2)");
     return LAVT_OK;
 }
@@ -549,6 +552,11 @@ int launch_nt_v2_lna(const lavt_gemm_nt_t& p, hipStream_t st) {
         return LAVT_ERR_INVALID;
     }
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128), tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
+    // (LAVT_ACT_GELU_D is its own instantiation: with the branch on p.act inside one kernel, the classic form ran 3 us per launch slower)
+    if (p.act == LAVT_ACT_GELU_D) {
+        if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_<128, 128, false, 2, 8, 1, false, false, true, true>(p, st) : launch_nt_v2_<128, 128, false, 4, 8, 1, false, false, true, true>(p, st);
+        return tiles64 >= 600 ? launch_nt_v2_<64, 64, false, 2, 4, 1, false, false, true, true>(p, st) : launch_nt_v2_<64, 64, false, 4, 4, 1, false, false, true, true>(p, st);
+    }
     if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_<128, 128, false, 2, 8, 1, false, false, true>(p, st) : launch_nt_v2_<128, 128, false, 4, 8, 1, false, false, true>(p, st);
     return tiles64 >= 600 ? launch_nt_v2_<64, 64, false, 2, 4, 1, false, false, true>(p, st) : launch_nt_v2_<64, 64, false, 4, 4, 1, false, false, true>(p, st);
 }

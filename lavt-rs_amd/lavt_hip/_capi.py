@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "liblavt_hip.so")
+LIB_PATH = os.environ.get("LAVT_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "liblavt_hip.so")          # (override: A/B of two builds on one box)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

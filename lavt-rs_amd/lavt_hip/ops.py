@@ -782,9 +782,10 @@ def linear(x, weight, bias=None, residual=None, **kw):
     return _Linear.apply(x, weight, bias, residual, LinOpts(**kw))
 
 
-# The fused MLP nodes keep GELU'(pre) instead of pre for backward (LAVT_ACT_GELU_D / LAVT_ACT_STORED): the derivative shares the activation's
-# exponential in the fc1 epilogue (+2 fma per element), and the fc2 data gradient's epilogue becomes one multiply instead of an erf + two
-# exponentials per element (5 us of vector math on a 10 us GEMM at stage 2, tools/mlp_gemm_probe.py).  LAVT_GELU_D=0: the pre-activation form.
+# The LayerNorm-folded MLP node keeps GELU'(pre) instead of pre for backward (LAVT_ACT_GELU_D / LAVT_ACT_STORED): the derivative shares the
+# activation's exponential in the fc1 epilogue (+2 fma per element), and the fc2 data gradient's epilogue becomes one multiply instead of an erf +
+# two exponentials per element (5 us of vector math on a 10 us GEMM at stage 2, tools/mlp_gemm_probe.py).  Only that launch is built with the
+# branch: compiled into every NT kernel's epilogue it made the whole step 0.16 ms slower (tools/ab_lib.sh).  LAVT_GELU_D=0: the pre-activation form.
 _GELU_FWD, _GELU_BWD = (K.ACT_GELU_D, K.ACT_STORED) if os.environ.get("LAVT_GELU_D", "1") != "0" else (K.ACT_GELU, K.ACT_GELU)
 
 
@@ -805,7 +806,7 @@ class _Mlp(torch.autograd.Function):
         M = x.shape[0]
         pre = torch.empty(M, Hd, dtype=dtype, device=x.device)
         h = torch.empty_like(pre)
-        gemm_nt(dtype, M, Hd, Cin, x, Cin, W1, Cin, h, Hd, bias=_f32(b1), act=_GELU_FWD, Cpre=pre, ldcpre=Hd)
+        gemm_nt(dtype, M, Hd, Cin, x, Cin, W1, Cin, h, Hd, bias=_f32(b1), act=K.ACT_GELU, Cpre=pre, ldcpre=Hd)
         y = torch.empty(M, Cout, dtype=dtype, device=x.device)
         if residual is not None:
             residual = residual.contiguous()
@@ -827,7 +828,7 @@ class _Mlp(torch.autograd.Function):
         # d pre = ((dy * row_scale) W2) * GELU'(pre): the activation gradient rides in the data-gradient GEMM's epilogue
         dpre = torch.empty_like(pre)
         gemm_nt(dtype, M, Hd, Cout, dy, Cout, W2, Hd, dpre, Hd, b_kmajor=True, row_scale=o.row_scale, row_scale_div=o.row_scale_div,
-                dact_pre=pre, lddact=Hd, dact=_GELU_BWD)
+                dact_pre=pre, lddact=Hd, dact=K.ACT_GELU)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
