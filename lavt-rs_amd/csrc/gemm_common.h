@@ -157,10 +157,12 @@ __device__ __forceinline__ uint2 xchg16(uint2 v) { return make_uint2((unsigned)_
 // LEAN: the launch uses none of {activation, multiplier, second (pre-activation) output, split output}: those branches are compiled out.  Carrying
 // them as not-taken uniform branches costs every plain GEMM of the step (tools/ab_lib.sh: -0.2 ms per step with all of them compiled out, of which
 // about half is the launches that do use them).
-template <int MI, int NI, bool DACT, bool GD = false, bool LEAN = false>
+// LEAN = 2 (data gradients, convolutions without bias): additionally no bias / residual / row scale / output row map -- a plain store.
+template <int MI, int NI, bool DACT, bool GD = false, int LEAN = 0>
 __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz) {
     lavt_gemm_nt_t p = p_in;
-    if constexpr (LEAN) { p.act = 0; p.mul = nullptr; p.Cpre = nullptr; p.C2 = nullptr; }
+    if constexpr (LEAN >= 1) { p.act = 0; p.mul = nullptr; p.Cpre = nullptr; p.C2 = nullptr; }
+    if constexpr (LEAN >= 2) { p.bias = nullptr; p.R = nullptr; p.row_scale = nullptr; p.c_rowmap = nullptr; }
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
     const float* rscale = p.row_scale ? p.row_scale + (int64_t)bz * p.strideRowScale : nullptr;
     const int64_t c_off = (int64_t)bz * p.strideC;
@@ -286,7 +288,7 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32
     }
 }
 
-template <typename T, int MI, int NI, bool DACT = false, bool GD = false, bool LEAN = false>
+template <typename T, int MI, int NI, bool DACT = false, bool GD = false, int LEAN = 0>
 __device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz) {
     if constexpr (std::is_same<T, bf16>::value && NI % 2 == 0) {
         // wave-uniform conditions: the whole wave takes one path (the exchanges need every lane)

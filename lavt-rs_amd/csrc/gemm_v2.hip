@@ -130,7 +130,7 @@ typedef __attribute__((__vector_size__(8 * sizeof(int)))) int i32x8;
 // streams the whole K = C of its rows, so the row sums / sums of squares are accumulated from the resident A tiles (v_dot2c_f32_bf16) and the
 // accumulators become rstd_m (acc - mu_m wsum_n) before the ordinary epilogue, whose `bias` is then biasp = b + W beta: the LayerNorm launch and its
 // [M, C] output disappear (norm2 -> fc1 of a Swin block, reference lib/backbone.py:243 + :24-30).
-template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false, bool LNA = false, bool GD = false, bool LEAN = false>
+template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false, bool LNA = false, bool GD = false, int LEAN = 0>
 __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_nt_t p) {
     constexpr bool SIMPLE = MODE == 1, CONVFAST = MODE == 2;
     static_assert(!LNA || (MODE == 1 && !BKM && !DACT && !F8), "LNA: plain k-contiguous problems");
@@ -527,9 +527,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
 static inline int conv_taps_of(const lavt_gemm_nt_t& p) {
     return (p.conv_kd > 0 ? p.conv_kd : 1) * (p.conv_kh > 0 ? p.conv_kh : 3) * (p.conv_kw > 0 ? p.conv_kw : 3);
 }
-template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false, bool LNA = false, bool GD = false, bool LEAN = false> int launch_nt_v2_(const lavt_gemm_nt_t& p, hipStream_t st) {
-    if constexpr (!LEAN && !DACT && !LNA && !F8 && MODE != 0) {          // plain epilogue (bias / residual / row scale / row map only): the lean instantiation
-        if (p.act == 0 && !p.mul && !p.Cpre && !p.C2) return launch_nt_v2_<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8, LNA, GD, true>(p, st);
+template <int BM, int BN, bool BKM, int STAGES, int WAVES, int MODE, bool DACT = false, bool F8 = false, bool LNA = false, bool GD = false, int LEAN = 0> int launch_nt_v2_(const lavt_gemm_nt_t& p, hipStream_t st) {
+    if constexpr (LEAN == 0 && !DACT && !LNA && !F8 && MODE != 0) {      // epilogue instantiations without the features a launch does not use (gemm_common.h)
+        if (p.act == 0 && !p.mul && !p.Cpre && !p.C2) {
+            if (!p.bias && !p.R && !p.row_scale && !p.c_rowmap) return launch_nt_v2_<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8, LNA, GD, 2>(p, st);
+            return launch_nt_v2_<BM, BN, BKM, STAGES, WAVES, MODE, DACT, F8, LNA, GD, 1>(p, st);
+        }
     }
     constexpr size_t lds = STAGES * (size_t)(BM * 128 + BN * 128);
     static bool attr_set = false;
