@@ -617,7 +617,9 @@ __device__ __forceinline__ void dma4(const void* src, void* lds_dst) {
 }
 
 // CS: how the bias gradient (colsum) is produced -- 0 none, 1 scalar walk of the LDS tile by the first BI threads, 2 on the matrix cores
-template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS>
+// CONVP: the problem may be a convolution weight gradient (tap-shifted B rows); the grouped launch never is, and without the tap state (per-DMA
+// coordinates, wrap tests behind uniform branches) its map-free K loop is shorter
+template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS, bool CONVP = true>
 __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_linear, const int bz, const int split_idx, const int kt_per_split,
                                         const int nsplit, char* smem) {
     using T = bf16;
@@ -652,7 +654,7 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
     const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.strideB;
     const T* B2 = reinterpret_cast<const T*>(p.B2);
     const T* Z = reinterpret_cast<const T*>(p.zeros);
-    const bool conv = p.conv_kc > 0;
+    const bool conv = CONVP && p.conv_kc > 0;
     const ConvGeom cg = conv_geom(p);
 
     // per-lane DMA geometry (constant over K tiles): LDS chunk q = (wave*INSTR + i)*64 + lane -> (k row, column chunk)
@@ -918,7 +920,7 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
                 const int jj = j0 + wj * WJ + j * 16 + (lane & 15);
                 if (jj >= p.J) continue;
                 int64_t col = jj;
-                if (p.c_conv_permute) { const int t2 = jj / p.conv_kc; col = (int64_t)(jj - t2 * p.conv_kc) * cg.taps + t2; }
+                if (CONVP && p.c_conv_permute) { const int t2 = jj / p.conv_kc; col = (int64_t)(jj - t2 * p.conv_kc) * cg.taps + t2; }
                 float* dst = C + (int64_t)ii * ldc_out + col;
                 if (atomic) atomicAdd(dst, p.alpha * acc[i][j][r]); else *dst = p.alpha * acc[i][j][r];
             }
@@ -972,11 +974,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_grouped_kernel(const Tn
     // vector instructions per MFMA: tools/wgrad_group_probe.py -- 42.5 us with maps on two of the four members vs 33.4 us without any)
     if constexpr (MAPS) {
         if (!(p.a_rowmap || p.a_rowscale || p.b_rowmap)) {
-            tn_tile<BI, BJ, WAVES, STAGES, false, CS>(p, local / ns, 0, local % ns, (ktiles + ns - 1) / ns, ns, smem);
+            tn_tile<BI, BJ, WAVES, STAGES, false, CS, false>(p, local / ns, 0, local % ns, (ktiles + ns - 1) / ns, ns, smem);
             return;
         }
     }
-    tn_tile<BI, BJ, WAVES, STAGES, MAPS, CS>(p, local / ns, 0, local % ns, (ktiles + ns - 1) / ns, ns, smem);
+    tn_tile<BI, BJ, WAVES, STAGES, MAPS, CS, false>(p, local / ns, 0, local % ns, (ktiles + ns - 1) / ns, ns, smem);
 }
 
 // second stage of a split reduction through partial tiles: C[i][j] += sum_s parts[s][i][J + j], colsum[i] += sum_s parts[nsplit*I*J + s*I + i].
