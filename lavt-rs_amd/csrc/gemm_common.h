@@ -161,6 +161,9 @@ __device__ __forceinline__ uint2 xchg16(uint2 v) { return make_uint2((unsigned)_
 template <int MI, int NI, bool DACT, bool GD = false, int LEAN = 0>
 __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz) {
     lavt_gemm_nt_t p = p_in;
+    if constexpr (DACT && GD) {          // stored-derivative data gradient (launch_nt_v2_dact): C = acc * alpha * row_scale * dact_pre, nothing else
+        p.dact = LAVT_ACT_STORED; p.R = nullptr; p.bias = nullptr; p.c_rowmap = nullptr; p.act = 0; p.mul = nullptr; p.Cpre = nullptr; p.C2 = nullptr;
+    }
     if constexpr (LEAN >= 1) { p.act = 0; p.mul = nullptr; p.Cpre = nullptr; p.C2 = nullptr; }
     if constexpr (LEAN >= 2) { p.bias = nullptr; p.R = nullptr; p.row_scale = nullptr; p.c_rowmap = nullptr; }
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
@@ -243,7 +246,7 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32
                         }
                     }
                 }
-                if constexpr (GD) {                        // the second output carries GELU'(pre), computed beside the activation (GD: only the
+                if constexpr (GD && !DACT) {               // the second output carries GELU'(pre), computed beside the activation (GD: only the
                                                           // LayerNorm-folded launch is built with this branch -- in every NT kernel it cost 0.16 ms per step)
                     float d[4];
 #pragma unroll

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
             }
         }
     }
-    if constexpr (DACT) { nt_epilogue<T, MI, NI, true>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz); return; }
+    if constexpr (DACT) { nt_epilogue<T, MI, NI, true, GD>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz); return; }
     if (!p.epi_lds || p.mul || p.c_f32 || (p.ldc % 8) || (p.C2 && (p.ldc2 % 8 || p.c_split % 8)) || (p.R && p.ldr % 8) || (p.Cpre && p.ldcpre % 8))
         nt_epilogue<T, MI, NI, false, GD, LEAN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);           // (GD = LAVT_ACT_GELU_D: its own instantiation of the LayerNorm-folded launch)
     else
@@ -588,6 +588,11 @@ int launch_nt_v2_dact(const lavt_gemm_nt_t& p, hipStream_t st) {
         return LAVT_ERR_INVALID;
     }
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch, tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;
+    // the stored-derivative form (dact = LAVT_ACT_STORED, no residual) is its own instantiation (GD): a multiply, none of the transcendental forms
+    if (p.dact == LAVT_ACT_STORED && !p.R && !p.bias && !p.c_rowmap) {
+        if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_<128, 128, true, 2, 8, 1, true, false, false, true>(p, st) : launch_nt_v2_<128, 128, true, 4, 8, 1, true, false, false, true>(p, st);
+        return tiles64 >= 600 ? launch_nt_v2_<64, 64, true, 2, 4, 1, true, false, false, true>(p, st) : launch_nt_v2_<64, 64, true, 4, 4, 1, true, false, false, true>(p, st);
+    }
     if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_<128, 128, true, 2, 8, 1, true>(p, st) : launch_nt_v2_<128, 128, true, 4, 8, 1, true>(p, st);
     return tiles64 >= 600 ? launch_nt_v2_<64, 64, true, 2, 4, 1, true>(p, st) : launch_nt_v2_<64, 64, true, 4, 4, 1, true>(p, st);
 }
