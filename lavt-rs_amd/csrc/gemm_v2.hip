@@ -950,10 +950,10 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
     }
 }
 
-template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS>
+template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS, bool CONVP = true>
 __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_tn_t p, int kt_per_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    tn_tile<BI, BJ, WAVES, STAGES, MAPS, CS>(p, blockIdx.x, blockIdx.y, blockIdx.z, kt_per_split, gridDim.z, smem);
+    tn_tile<BI, BJ, WAVES, STAGES, MAPS, CS, CONVP>(p, blockIdx.x, blockIdx.y, blockIdx.z, kt_per_split, gridDim.z, smem);
 }
 
 // Several independent weight-gradient problems in ONE launch (the four wgrads of a Swin block): together they fill the chip without
@@ -1015,11 +1015,14 @@ __global__ __launch_bounds__(256) void tn_reduce_pieces(const float* __restrict_
     }
 }
 
-template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS> int launch_tn_v2_(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
+template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS, bool CONVP = !MAPS> int launch_tn_v2_(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
+    if constexpr (CONVP && !MAPS) {          // (mapped problems are never convolutions: tn_v2_eligible) the map-free kernel without the tap state for plain problems
+        if (p.conv_kc <= 0 && !p.c_conv_permute) return launch_tn_v2_<BI, BJ, WAVES, STAGES, MAPS, CS, false>(p, split, st);
+    }
     constexpr size_t lds = STAGES * (size_t)(64 * (BI + BJ) * 2) + (MAPS ? (2 * (STAGES - 1) + 1) * 768 + 256 : 0);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS, CONVP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             lavt_set_error("lavt_gemm_tn(v2): cannot reserve %zu bytes of LDS", lds);
             return LAVT_ERR_LAUNCH;
         }
@@ -1034,9 +1037,9 @@ template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS> int launch_t
     if (!parts) {
         lavt_gemm_tn_t q = p;
         q.partials = nullptr;
-        hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS>), grid, dim3(WAVES * 64), lds, st, q, per);
+        hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS, CONVP>), grid, dim3(WAVES * 64), lds, st, q, per);
     } else {
-        hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS>), grid, dim3(WAVES * 64), lds, st, p, per);
+        hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS, CONVP>), grid, dim3(WAVES * 64), lds, st, p, per);
         const int64_t total = (int64_t)p.I * p.J + (p.colsum ? p.I : 0);
         hipLaunchKernelGGL(tn_reduce_pieces, dim3((unsigned)cdiv(total, 64), p.batch), dim3(256), 0, st, p.partials, pieces, p.I, p.J, p.C, p.ldc, p.colsum, p.strideC, p.strideColsum);
     }
