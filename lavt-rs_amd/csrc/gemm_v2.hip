@@ -17,103 +17,9 @@
 // fragment reads conflict-free is applied to the per-lane SOURCE address (each lane fetches the logical chunk that
 // belongs at its physical position); row gathers (window maps, 3x3 taps, concat) are per-lane source addresses too.
 // Rows / chunks that must read zero (padding, halo, tails) fetch from a caller-provided zero page (`p.zeros`).
-#include <stdlib.h>
-
-#include "gemm_common.h"
-
-using namespace lavt_gemm;
+#include "gemm_v2_helpers.h"
 
 namespace {
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void gbl_void;
-
-__device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
-    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
-}
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <int G> __device__ __forceinline__ void wait_groups(int g) {      // leave g groups of G vector-memory ops in flight
-    if (g <= 0) wait_vmcnt<0>();
-    else if (g == 1) wait_vmcnt<G>();
-    else if (g == 2) wait_vmcnt<2 * G>();
-    else wait_vmcnt<3 * G>();
-}
-// ---- transposing LDS reads issued from inline asm --------------------------------------------------------------------
-// hipcc puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr builtin while LDS-DMA is in flight (it cannot tell the stages
-// apart), which would serialise the pipeline.  Asm reads are invisible to that pass; we wait for them ourselves:
-// (cdna_hip_programming.md rule 18).
-typedef unsigned long long u64;
-// One statement = all transposing reads of a K tile (both k-steps) + the wait, early-clobber outputs: the compiler can neither copy a
-// destination before its data has landed nor schedule a consumer above the wait (5.7 form i).  One address VGPR per fragment (the slot
-// swizzle of the k-major tiles permutes the fragments' 32-byte slots differently in every lane, so they are not a compile-time stride
-// apart); the second 4-row block (HO) and the second k-step (KO) are immediates because the swizzle ignores those row bits.
-template <int NF, int HO, int KO>
-__device__ __forceinline__ void tr_read_frags(const unsigned (&a)[NF], u64 (&l0)[NF], u64 (&h0)[NF], u64 (&l1)[NF], u64 (&h1)[NF]) {
-    static_assert(NF == 2 || NF == 4, "NF");
-    if constexpr (NF == 4) {
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:%c20\n\t"
-            "ds_read_b64_tr_b16 %2, %17\n\tds_read_b64_tr_b16 %3, %17 offset:%c20\n\t"
-            "ds_read_b64_tr_b16 %4, %18\n\tds_read_b64_tr_b16 %5, %18 offset:%c20\n\t"
-            "ds_read_b64_tr_b16 %6, %19\n\tds_read_b64_tr_b16 %7, %19 offset:%c20\n\t"
-            "ds_read_b64_tr_b16 %8, %16 offset:%c21\n\tds_read_b64_tr_b16 %9, %16 offset:%c21+%c20\n\t"
-            "ds_read_b64_tr_b16 %10, %17 offset:%c21\n\tds_read_b64_tr_b16 %11, %17 offset:%c21+%c20\n\t"
-            "ds_read_b64_tr_b16 %12, %18 offset:%c21\n\tds_read_b64_tr_b16 %13, %18 offset:%c21+%c20\n\t"
-            "ds_read_b64_tr_b16 %14, %19 offset:%c21\n\tds_read_b64_tr_b16 %15, %19 offset:%c21+%c20\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(l0[0]), "=&v"(h0[0]), "=&v"(l0[1]), "=&v"(h0[1]), "=&v"(l0[2]), "=&v"(h0[2]), "=&v"(l0[3]), "=&v"(h0[3]),
-              "=&v"(l1[0]), "=&v"(h1[0]), "=&v"(l1[1]), "=&v"(h1[1]), "=&v"(l1[2]), "=&v"(h1[2]), "=&v"(l1[3]), "=&v"(h1[3])
-            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(HO), "n"(KO)
-            : "memory");
-    } else {
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%c10\n\t"
-            "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:%c10\n\t"
-            "ds_read_b64_tr_b16 %4, %8 offset:%c11\n\tds_read_b64_tr_b16 %5, %8 offset:%c11+%c10\n\t"
-            "ds_read_b64_tr_b16 %6, %9 offset:%c11\n\tds_read_b64_tr_b16 %7, %9 offset:%c11+%c10\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(l0[0]), "=&v"(h0[0]), "=&v"(l0[1]), "=&v"(h0[1]), "=&v"(l1[0]), "=&v"(h1[0]), "=&v"(l1[1]), "=&v"(h1[1])
-            : "v"(a[0]), "v"(a[1]), "n"(HO), "n"(KO)
-            : "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-// One k-step (32 K rows) only: the 16-wave 256x256 tiles have 128 registers per lane and hold one k-step of operands at a time.
-template <int NF, int HO, int KOFF>
-__device__ __forceinline__ void tr_read_frags_step(const unsigned (&a)[NF], u64 (&l)[NF], u64 (&h)[NF]) {
-    static_assert(NF == 4, "NF");
-    asm volatile(
-        "ds_read_b64_tr_b16 %0, %8 offset:%c13\n\tds_read_b64_tr_b16 %1, %8 offset:%c13+%c12\n\t"
-        "ds_read_b64_tr_b16 %2, %9 offset:%c13\n\tds_read_b64_tr_b16 %3, %9 offset:%c13+%c12\n\t"
-        "ds_read_b64_tr_b16 %4, %10 offset:%c13\n\tds_read_b64_tr_b16 %5, %10 offset:%c13+%c12\n\t"
-        "ds_read_b64_tr_b16 %6, %11 offset:%c13\n\tds_read_b64_tr_b16 %7, %11 offset:%c13+%c12\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]), "=&v"(l[2]), "=&v"(h[2]), "=&v"(l[3]), "=&v"(h[3])
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(HO), "n"(KOFF)
-        : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-// 32-byte slot swizzle of a k-major [64][CH x 16 B] tile: the 16 K rows one transposing read touches (rows r, r+1, r+2, r+3 of four 8-row
-// blocks) land in different slots.  Uses row bits 0, 1, 3, 4 only, so rows r + 4 and r + 32 share the swizzle of row r.
-template <int CH> __device__ __forceinline__ int tn_swz(int kr) {
-    if constexpr (CH == 8) {
-        // 128-byte rows: two rows span the 64 banks, so row bit 0 already alternates the bank half; the two swizzle bits a 4-slot row has
-        // go to row bits 1 and 3.  (With bits 0 and 1 -- the general formula -- rows r, r+8, r+16, r+24 of a transposing read met in the
-        // same banks: 46 % of the LDS cycles of the 64x64-tile weight-gradient kernels were bank conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT.)
-        return (((kr >> 1) & 1) | ((kr >> 2) & 2)) << 1;
-    }
-    constexpr int FM = (CH / 2 - 1) < 15 ? (CH / 2 - 1) : 15;
-    return (((kr & 3) | ((kr >> 1) & 12)) & FM) << 1;
-}
-__device__ __forceinline__ bf16x8 frag_from(u64 lo, u64 hi) {
-    typedef __attribute__((__vector_size__(2 * sizeof(u64)))) u64 u64x2;
-    u64x2 v = {lo, hi};
-    return __builtin_bit_cast(bf16x8, v);
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
-}
 
 // SIMPLE = no conv taps, no concat source, K % 64 == 0: every lane's DMA source is a fixed pointer that advances by a constant per K tile,
 // so the K loop carries ~3 instructions per DMA instead of the general path's address arithmetic (which made small GEMMs issue-bound:
@@ -606,485 +512,6 @@ template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(cons
 }
 
 
-// ================================================================================================ TN (weight gradients)
-// C[I,J] (+)= alpha * sum_k A[k][i] B[k][j]; both operands k-major: LDS tiles [64 k][cols+16] filled by LDS-DMA through a STAGES-deep
-// ring, every fragment read with the transposing LDS read (asm, one statement per operand per K tile).  The operands stream from HBM
-// (every K tile is new data), so one tile in flight leaves the full HBM latency exposed per K tile (measured 0.9 us with the 2-stage
-// ring); with S stages S-2 further tiles stay in flight across the loop-top wait.
-//
-// Row maps (window order <-> token order) and the DropPath / language row mask are per-K-row side inputs.  A register load of them
-// would have to be the YOUNGEST outstanding vector-memory op when it is needed, and vmcnt retires in order -- waiting for it drains the
-// whole ring.  So (MAPS = true) they travel through LDS as well: a 4-byte-per-lane DMA per wave per K tile, issued 2(S-1) tiles ahead
-// into an 8-slot ring, read back with ds_read when the tile's row addresses are formed.  Every wave issues the same number of
-// vector-memory ops per tile (ND tile DMAs + 1 map DMA), which is what makes the counted waits valid.
-__device__ __forceinline__ void dma4(const void* src, void* lds_dst) {
-    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 4, 0, 0);
-}
-
-// CS: how the bias gradient (colsum) is produced -- 0 none, 1 scalar walk of the LDS tile by the first BI threads, 2 on the matrix cores
-// CONVP: the problem may be a convolution weight gradient (tap-shifted B rows); the grouped launch never is, and without the tap state (per-DMA
-// coordinates, wrap tests behind uniform branches) its map-free K loop is shorter
-template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS, bool CONVP = true>
-__device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_linear, const int bz, const int split_idx, const int kt_per_split,
-                                        const int nsplit, char* smem) {
-    using T = bf16;
-    constexpr int BK = 64, EPC = 8;
-    constexpr int WAVES_I = 2, WAVES_J = WAVES / WAVES_I;
-    // LDS tiles are k-major [BK][BI] / [BK][BJ] without padding; bank conflicts of the transposing reads are avoided by the tn_swz slot
-    // swizzle, applied on the DMA side through the source address each lane fetches (the LDS image of a DMA instruction is lane-linear).
-    // (A padded row -- 16 extra elements -- cost a third DMA instruction per operand per K tile whose lanes mostly fetched the zero page.)
-    constexpr int A_CH = BI / EPC, B_CH = BJ / EPC;
-    constexpr int A_INSTR = BK * A_CH / (64 * WAVES), B_INSTR = BK * B_CH / (64 * WAVES);
-    static_assert(A_INSTR * 64 * WAVES == BK * A_CH && B_INSTR * 64 * WAVES == BK * B_CH, "whole DMA instructions per operand tile");
-    constexpr int A_BYTES = A_INSTR * WAVES * 1024, B_BYTES = B_INSTR * WAVES * 1024, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int WI = BI / WAVES_I, WJ = BJ / WAVES_J, II = WI / 16, JJ = WJ / 16;
-    constexpr int G = A_INSTR + B_INSTR + (MAPS ? 1 : 0);              // vector-memory ops per wave per K tile
-    constexpr int AHEAD = 2 * (STAGES - 1);                              // map DMA runs this many tiles ahead of the compute
-    constexpr int NSLOT = AHEAD + 1, SLOT_BYTES = 768;                   // map ring: [slot][a_map | a_rowscale | b_map][64] (+ one 256 B spare for waves >= 3)
-    static_assert((II == 2 || II == 4) && (JJ == 2 || JJ == 4), "fragment counts");
-    static_assert(STAGES >= 2 && STAGES <= 4 && 3 * G <= 63, "pipeline depth");
-
-    char* const maps = smem + STAGES * STAGE_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave / WAVES_J, wj = wave % WAVES_J;
-    const int tiles_j = (p.J + BJ - 1) / BJ;
-    const int tile_i = tile_linear / tiles_j, tile_j = tile_linear % tiles_j;
-    const int i0 = tile_i * BI, j0 = tile_j * BJ;
-    const int ktiles = (p.K + BK - 1) / BK;
-    const int kt_begin = split_idx * kt_per_split, kt_end = min(ktiles, kt_begin + kt_per_split);
-    if (kt_begin >= kt_end) return;
-    const int n = kt_end - kt_begin;
-
-    const T* A = reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.strideA;
-    const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.strideB;
-    const T* B2 = reinterpret_cast<const T*>(p.B2);
-    const T* Z = reinterpret_cast<const T*>(p.zeros);
-    const bool conv = CONVP && p.conv_kc > 0;
-    const ConvGeom cg = conv_geom(p);
-
-    // per-lane DMA geometry (constant over K tiles): LDS chunk q = (wave*INSTR + i)*64 + lane -> (k row, column chunk)
-    int a_kr[A_INSTR], a_col[A_INSTR], b_kr[B_INSTR], b_dz[B_INSTR], b_dy[B_INSTR], b_dx[B_INSTR];
-    const T* b_base[B_INSTR];
-    int64_t b_ld[B_INSTR];
-#pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-        const int q = (wave * A_INSTR + i) * 64 + lane, kr = q / A_CH, cc = (q - kr * A_CH) ^ tn_swz<A_CH>(kr);
-        const bool ok = i0 + cc * EPC < p.I;
-        a_kr[i] = ok ? kr : -1;
-        a_col[i] = i0 + cc * EPC;
-    }
-#pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
-        const int q = (wave * B_INSTR + i) * 64 + lane, kr = q / B_CH, cc = (q - kr * B_CH) ^ tn_swz<B_CH>(kr);
-        const int jb = j0 + cc * EPC;
-        const bool ok = jb < p.J;
-        b_kr[i] = ok ? kr : -1;
-        int jc = jb, dz = 0, dy = 0, dx = 0;
-        if (conv) { const int tap = jb / p.conv_kc; jc = jb - tap * p.conv_kc; conv_tap(cg, tap, dz, dy, dx); }
-        const bool second = (p.B2 != nullptr) && jc >= p.b_split;
-        b_base[i] = (second ? B2 : B) + (second ? jc - p.b_split : jc);
-        b_ld[i] = second ? p.ldb2 : p.ldb;
-        b_dz[i] = dz; b_dy[i] = dy; b_dx[i] = dx;
-    }
-
-    // ---- side inputs of tile t (relative to kt_begin) -> map ring slot t % NSLOT: wave 0 a_rowmap, 1 a_rowscale, 2 b_rowmap, others spare
-    const float inv_rsdiv = 1.0f / (float)(p.a_rowscale_div > 1 ? p.a_rowscale_div : 1);
-    const int amask = p.a_rowmap ? -1 : 0, bmask = p.b_rowmap ? -1 : 0;
-    const unsigned nors = p.a_rowscale ? 0u : 1u, lda_u = (unsigned)p.lda;
-    const int Kdim = p.K;
-    auto map_dma = [&](int t) {
-        if constexpr (MAPS) {
-            int k = (kt_begin + t) * BK + lane;
-            k = k < p.K ? k : p.K - 1;
-            const void* src = Z;
-            if (wave == 0 && p.a_rowmap) src = p.a_rowmap + k;
-            if (wave == 1 && p.a_rowscale) src = p.a_rowscale + (p.a_rowscale_div > 1 ? fdiv(k, p.a_rowscale_div, inv_rsdiv) : k);
-            if (wave == 2 && p.b_rowmap) src = p.b_rowmap + k;
-            dma4(src, wave < 3 ? maps + (t % NSLOT) * SLOT_BYTES + wave * 256 : maps + NSLOT * SLOT_BYTES);
-        }
-    };
-    // !MAPS: the K rows are consecutive, so every lane keeps running source pointers (A, and B without taps) and, for conv taps, the
-    // running (z, y, x) of its K row -- advanced by 64 rows per tile with a wrap test instead of three divisions per DMA per tile
-    // (the conv weight-gradient K loop was instruction-bound: ~200 VALU instructions per K tile per wave against 8 MFMAs).
-    const T* a_run[A_INSTR];
-    const T* b_run[B_INSTR];
-    int a_k[A_INSTR], b_k[B_INSTR], b_z[B_INSTR], b_y[B_INSTR], b_x[B_INSTR], b_delta[B_INSTR];
-    if constexpr (!MAPS) {
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) {
-            a_k[i] = a_kr[i] >= 0 ? kt_begin * BK + a_kr[i] : (1 << 30);               // dead lanes sit beyond K for good
-            a_run[i] = A + (int64_t)(a_kr[i] >= 0 ? a_k[i] : 0) * p.lda + a_col[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            b_k[i] = b_kr[i] >= 0 ? kt_begin * BK + b_kr[i] : (1 << 30);
-            const int k0 = b_kr[i] >= 0 ? b_k[i] : 0;
-            b_delta[i] = conv ? (b_dz[i] * cg.h + b_dy[i]) * cg.w + b_dx[i] : 0;
-            b_run[i] = b_base[i] + (int64_t)(k0 + b_delta[i]) * b_ld[i];
-            b_z[i] = b_y[i] = b_x[i] = 0;
-            if (conv) conv_coords(cg, k0, b_z[i], b_y[i], b_x[i]);
-        }
-    }
-    auto issue = [&](int t, int stage) {
-        char* sa = smem + stage * STAGE_BYTES;
-        char* sb = sa + A_BYTES;
-        if constexpr (!MAPS) {
-#pragma unroll
-            for (int i = 0; i < A_INSTR; ++i) {
-                dma16(a_k[i] < p.K ? a_run[i] : Z, sa + (wave * A_INSTR + i) * 1024);
-                a_run[i] += (int64_t)BK * p.lda;
-                a_k[i] += BK;
-            }
-#pragma unroll
-            for (int i = 0; i < B_INSTR; ++i) {
-                bool ok = b_k[i] < p.K;
-                if (conv) {
-                    const int z = b_z[i] + b_dz[i], y = b_y[i] + b_dy[i], x = b_x[i] + b_dx[i];
-                    ok = ok && (unsigned)z < (unsigned)cg.d && (unsigned)y < (unsigned)cg.h && (unsigned)x < (unsigned)cg.w;
-                    // next tile: 64 rows further along x, carrying into y and z (and on into the next sample, whose z restarts at 0)
-                    b_x[i] += BK;
-                    if (b_x[i] >= cg.w) {
-                        const int q = fdiv(b_x[i], cg.w, cg.inv_w);
-                        b_x[i] -= q * cg.w;
-                        b_y[i] += q;
-                        if (b_y[i] >= cg.h) {
-                            const int q2 = b_y[i] / cg.h;
-                            b_y[i] -= q2 * cg.h;
-                            b_z[i] = (b_z[i] + q2) % cg.d;
-                        }
-                    }
-                }
-                dma16(ok ? b_run[i] : Z, sb + (wave * B_INSTR + i) * 1024);
-                b_run[i] += (int64_t)BK * b_ld[i];
-                b_k[i] += BK;
-            }
-            return;
-        }
-        // mapped rows: branch-free -- the per-problem switches (which maps exist) are lane-uniform masks hoisted out of the loop; the first
-        // version tested them per DMA inside the K loop: ~30 scalar branches per K tile, 14 vector instructions per MFMA (PMC)
-        const int kbase = (kt_begin + t) * BK;
-        const int* m_a = reinterpret_cast<const int*>(maps + (t % NSLOT) * SLOT_BYTES);
-        const unsigned* m_rs = reinterpret_cast<const unsigned*>(maps + (t % NSLOT) * SLOT_BYTES + 256);
-        const int* m_b = reinterpret_cast<const int*>(maps + (t % NSLOT) * SLOT_BYTES + 512);
-        const T* a_ptr[A_INSTR];
-        const T* b_ptr[B_INSTR];
-        int ma[A_INSTR], mb[B_INSTR];
-        unsigned mr[A_INSTR];
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) { ma[i] = m_a[a_kr[i] & 63]; mr[i] = m_rs[a_kr[i] & 63]; }      // all LDS reads first (dead lanes, a_kr = -1,
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) mb[i] = m_b[b_kr[i] & 63];                                      //  read slot 63 and are masked below)
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) {
-            const int k = kbase + (a_kr[i] & 63);
-            const int src = (ma[i] & amask) | (k & ~amask);
-            const bool ok = ((a_kr[i] | src) >= 0) & (k < Kdim) & (((mr[i] << 1) | nors) != 0u);
-            const unsigned off = ok ? (unsigned)src * lda_u + (unsigned)a_col[i] : 0u;
-            a_ptr[i] = (ok ? A : Z) + off;
-        }
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            const int k = kbase + (b_kr[i] & 63);
-            const int src = (mb[i] & bmask) | (k & ~bmask);
-            const bool ok = ((b_kr[i] | src) >= 0) & (k < Kdim);
-            const unsigned off = ok ? (unsigned)src * (unsigned)b_ld[i] : 0u;
-            b_ptr[i] = (ok ? b_base[i] : Z) + off;
-        }
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) dma16(a_ptr[i], sa + (wave * A_INSTR + i) * 1024);
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) dma16(b_ptr[i], sb + (wave * B_INSTR + i) * 1024);
-    };
-
-    // fragment read addresses relative to a stage's operand tile: K row of the lane, swizzled 32-byte slot of fragment i, 8-byte half
-    unsigned relA[II], relB[JJ];
-    {
-        const int row_off = 8 * (lane >> 4) + ((lane & 15) >> 2);
-        const int sA = tn_swz<A_CH>(row_off), sB = tn_swz<B_CH>(row_off);
-#pragma unroll
-        for (int i = 0; i < II; ++i) relA[i] = (unsigned)(row_off * BI + ((((wi * WI) / 8 + 2 * i) ^ sA) + ((lane & 3) >> 1)) * 8 + (lane & 1) * 4) * 2;
-#pragma unroll
-        for (int i = 0; i < JJ; ++i) relB[i] = (unsigned)(row_off * BJ + ((((wj * WJ) / 8 + 2 * i) ^ sB) + ((lane & 3) >> 1)) * 8 + (lane & 1) * 4) * 2;
-    }
-    f32x4 acc[II][JJ];
-#pragma unroll
-    for (int i = 0; i < II; ++i)
-#pragma unroll
-        for (int j = 0; j < JJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // bias gradient colsum[i] = sum_k A[k][i] of the tile_j == 0 workgroups.  CS == 2: one more "column" of the contraction -- the A fragments
-    // times a fragment of ones, on the matrix cores, by the waves of the first wave column.  The scalar form (CS == 1: one thread per column
-    // walking the 64 K rows of the LDS tile) runs on a single wave while the others wait at the barrier, with 46 % of its LDS cycles bank
-    // conflicts: where few workgroups carry it (many column tiles: the grouped Swin-block launch, 62.8 -> 54.0 us) they were the tail of the
-    // launch; where every second workgroup carries it (J = 128: PWAM's 1x1 convolutions) the scalar walk hides better.  A template
-    // parameter: the extra accumulators cost the colsum-free 128x128 conv kernels 40 % when they were unconditional.
-    const bool cs_wave = CS == 2 && (p.colsum != nullptr) && tile_j == 0 && wj == 0;
-    f32x4 cacc[CS == 2 ? II : 1];
-#pragma unroll
-    for (int i = 0; i < (CS == 2 ? II : 1); ++i) cacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
-    float csum = 0.f;
-    const bool do_colsum = CS == 1 && (p.colsum != nullptr) && tile_j == 0 && tid < BI;
-
-    // prologue: side inputs of the first AHEAD tiles, then the first STAGES-1 data tiles (each followed by one map DMA: uniform groups)
-    if constexpr (MAPS) {
-        for (int t = 0; t < AHEAD; ++t) map_dma(t);
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-    }
-    for (int t = 0; t < STAGES - 1; ++t)
-        if (t < n) { issue(t, t % STAGES); map_dma(t + AHEAD); }
-
-    // One K tile.  `stage` is a compile-time constant in the two-stage ring (the loop below is unrolled by hand over the two stages), so the
-    // fragment read addresses of a stage are loop-invariant registers instead of 2 (II + JJ) vector adds per K tile: the 64x64-tile kernels are
-    // instruction-issue bound (three workgroups' waves share a SIMD: ~150 instructions per wave per K tile against 8 MFMAs).
-    constexpr bool UNROLL2 = STAGES == 2 && BI == 64 && BJ == 64;       // (the 128x128 / 8-wave tiles sit at their 128-register cap: 16 more would spill)
-    unsigned fragA[UNROLL2 ? 2 : 1][II], fragB[UNROLL2 ? 2 : 1][JJ];
-    if constexpr (UNROLL2) {
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg) {
-            const unsigned baseA = lds_addr(smem + sg * STAGE_BYTES), baseB = baseA + A_BYTES;
-#pragma unroll
-            for (int i = 0; i < II; ++i) fragA[sg][i] = baseA + relA[i];
-#pragma unroll
-            for (int i = 0; i < JJ; ++i) fragB[sg][i] = baseB + relB[i];
-        }
-    }
-    auto k_tile = [&](int j, auto stage_tag) {
-        constexpr int SG = decltype(stage_tag)::value;             // >= 0: the stage of tile j (two-stage ring); -1: j % STAGES
-        const int stage = SG >= 0 ? SG : j % STAGES;
-        wait_groups<G>(min(STAGES - 2, n - 1 - j));
-        __builtin_amdgcn_s_barrier();
-        if (j + STAGES - 1 < n) { issue(j + STAGES - 1, SG >= 0 ? (SG ^ 1) : (j + STAGES - 1) % STAGES); map_dma(j + STAGES - 1 + AHEAD); }
-        const char* cA = smem + stage * STAGE_BYTES;
-        unsigned aA[II], aB[JJ];
-        if constexpr (SG >= 0) {
-#pragma unroll
-            for (int i = 0; i < II; ++i) aA[i] = fragA[SG][i];
-#pragma unroll
-            for (int i = 0; i < JJ; ++i) aB[i] = fragB[SG][i];
-        } else {
-            const unsigned baseA = lds_addr(cA), baseB = baseA + A_BYTES;
-#pragma unroll
-            for (int i = 0; i < II; ++i) aA[i] = baseA + relA[i];
-#pragma unroll
-            for (int i = 0; i < JJ; ++i) aB[i] = baseB + relB[i];
-        }
-        u64 al0[II], ah0[II], al1[II], ah1[II], bl0[JJ], bh0[JJ], bl1[JJ], bh1[JJ];
-        tr_read_frags<II, 4 * BI * 2, 32 * BI * 2>(aA, al0, ah0, al1, ah1);
-        tr_read_frags<JJ, 4 * BJ * 2, 32 * BJ * 2>(aB, bl0, bh0, bl1, bh1);
-#pragma unroll
-        for (int i = 0; i < II; ++i)
-#pragma unroll
-            for (int jj = 0; jj < JJ; ++jj) {
-                acc[i][jj] = mfma16<T>(frag_from(al0[i], ah0[i]), frag_from(bl0[jj], bh0[jj]), acc[i][jj]);
-                acc[i][jj] = mfma16<T>(frag_from(al1[i], ah1[i]), frag_from(bl1[jj], bh1[jj]), acc[i][jj]);
-            }
-        if constexpr (CS == 2) {
-            if (cs_wave) {
-#pragma unroll
-                for (int i = 0; i < II; ++i) {
-                    cacc[i] = mfma16<T>(frag_from(al0[i], ah0[i]), ones, cacc[i]);
-                    cacc[i] = mfma16<T>(frag_from(al1[i], ah1[i]), ones, cacc[i]);
-                }
-            }
-        }
-        if constexpr (CS == 1) {
-            if (do_colsum) {
-                const T* col = reinterpret_cast<const T*>(cA) + (tid & 7);
-#pragma unroll 8
-                for (int k = 0; k < BK; ++k) csum += to_f<T>(col[k * BI + (((tid >> 3) ^ tn_swz<A_CH>(k)) << 3)]);
-            }
-        }
-    };
-    if constexpr (UNROLL2) {
-        int j = 0;
-        for (; j + 1 < n; j += 2) { k_tile(j, std::integral_constant<int, 0>{}); k_tile(j + 1, std::integral_constant<int, 1>{}); }
-        if (j < n) k_tile(j, std::integral_constant<int, 0>{});
-    } else {
-        for (int j = 0; j < n; ++j) k_tile(j, std::integral_constant<int, -1>{});
-    }
-
-    // split reduction with a partials buffer: this piece's tile goes to partials[piece][I][J] as plain stores (tn_reduce_pieces adds the pieces
-    // into C afterwards); otherwise pieces meet in C through atomics
-    const bool to_parts = p.partials != nullptr && nsplit > 1;
-    float* const pbase = to_parts ? p.partials + (int64_t)bz * nsplit * ((int64_t)p.I * p.J + p.I) : nullptr;      // one [pieces][I][J] + [pieces][I] block per batch entry
-    float* C = to_parts ? pbase + (int64_t)split_idx * p.I * p.J : p.C + (int64_t)bz * p.strideC;
-    const int64_t ldc_out = to_parts ? p.J : p.ldc;
-    float* colsum_out = to_parts ? pbase + (int64_t)nsplit * p.I * p.J + (int64_t)split_idx * p.I : (p.colsum ? p.colsum + (int64_t)bz * p.strideColsum : nullptr);
-    const bool atomic = !to_parts && (nsplit > 1 || p.accumulate);
-#pragma unroll
-    for (int i = 0; i < II; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ii = i0 + wi * WI + i * 16 + 4 * (lane >> 4) + r;
-            if (ii >= p.I) continue;
-#pragma unroll
-            for (int j = 0; j < JJ; ++j) {
-                const int jj = j0 + wj * WJ + j * 16 + (lane & 15);
-                if (jj >= p.J) continue;
-                int64_t col = jj;
-                if (CONVP && p.c_conv_permute) { const int t2 = jj / p.conv_kc; col = (int64_t)(jj - t2 * p.conv_kc) * cg.taps + t2; }
-                float* dst = C + (int64_t)ii * ldc_out + col;
-                if (atomic) atomicAdd(dst, p.alpha * acc[i][j][r]); else *dst = p.alpha * acc[i][j][r];
-            }
-        }
-    }
-    if constexpr (CS == 1) {
-        if (do_colsum && i0 + tid < p.I) {
-            float* cs = colsum_out + i0 + tid;
-            if (atomic || (p.colsum_atomic && !to_parts)) atomicAdd(cs, csum * p.alpha); else *cs = csum * p.alpha;
-        }
-    }
-    if (CS == 2 && cs_wave && (lane & 15) == 0) {          // every column of cacc holds the same sums: lanes of column 0 write rows 4 (lane / 16) + r
-#pragma unroll
-        for (int i = 0; i < (CS == 2 ? II : 1); ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ii = i0 + wi * WI + i * 16 + 4 * (lane >> 4) + r;
-                if (ii >= p.I) continue;
-                float* cs = colsum_out + ii;
-                if (atomic || (p.colsum_atomic && !to_parts)) atomicAdd(cs, cacc[i][r] * p.alpha); else *cs = cacc[i][r] * p.alpha;      // one tile_j == 0 workgroup per I tile when the reduction is not split
-            }
-    }
-}
-
-template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS, bool CONVP = true>
-__global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_kernel(const lavt_gemm_tn_t p, int kt_per_split) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    tn_tile<BI, BJ, WAVES, STAGES, MAPS, CS, CONVP>(p, blockIdx.x, blockIdx.y, blockIdx.z, kt_per_split, gridDim.z, smem);
-}
-
-// Several independent weight-gradient problems in ONE launch (the four wgrads of a Swin block): together they fill the chip without
-// split-K, so each output element has a single writer and is stored plainly instead of through fp32 atomics, which execute at the memory
-// side at ~1.3 TB/s chip-wide (MI355X_MICROARCH.md) -- 44 MB of atomic traffic per stage-2 block with the per-problem split-K launches.
-constexpr int TN_GROUP_MAX = 6;          // four weight gradients of a block + side members (the padded-row column sums of the windowed qkv bias gradient)
-struct TnGroup {
-    lavt_gemm_tn_t p[TN_GROUP_MAX];
-    int tile_end[TN_GROUP_MAX];      // running count of workgroups (tiles x K splits) up to and including problem k
-    int split[TN_GROUP_MAX];         // K splits of problem k (1 = single writer per output element, plain stores)
-    int n;
-};
-template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS>
-__global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_grouped_kernel(const TnGroup g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int k = 0;
-    while (k + 1 < g.n && (int)blockIdx.x >= g.tile_end[k]) ++k;
-    const int local = blockIdx.x - (k ? g.tile_end[k - 1] : 0);
-    const lavt_gemm_tn_t& p = g.p[k];
-    const int ns = g.split[k], ktiles = (p.K + 63) / 64;
-    // the splits of a tile sit next to each other (local % ns): neighbours in time share the output tile's cache lines for their atomics
-    // a member without row maps / masks takes the map-free K loop also inside a group that has mapped members (the mapped loop carries ~14
-    // vector instructions per MFMA: tools/wgrad_group_probe.py -- 42.5 us with maps on two of the four members vs 33.4 us without any)
-    if constexpr (MAPS) {
-        if (!(p.a_rowmap || p.a_rowscale || p.b_rowmap)) {
-            tn_tile<BI, BJ, WAVES, STAGES, false, CS, false>(p, local / ns, 0, local % ns, (ktiles + ns - 1) / ns, ns, smem);
-            return;
-        }
-    }
-    tn_tile<BI, BJ, WAVES, STAGES, MAPS, CS, false>(p, local / ns, 0, local % ns, (ktiles + ns - 1) / ns, ns, smem);
-}
-
-// second stage of a split reduction through partial tiles: C[i][j] += sum_s parts[s][i][J + j], colsum[i] += sum_s parts[nsplit*I*J + s*I + i].
-// 64 outputs x 4 piece lanes per workgroup (coalesced 256-byte reads, four independent loads in flight per thread), one writer per output.
-__global__ __launch_bounds__(256) void tn_reduce_pieces(const float* __restrict__ parts, int nsplit, int I, int J, float* __restrict__ C, int64_t ldc,
-                                                        float* __restrict__ colsum, int64_t strideC, int64_t strideColsum) {
-    __shared__ float red[4][64];
-    const int64_t W = (int64_t)I * J, total = W + (colsum ? I : 0);
-    parts += (int64_t)blockIdx.y * nsplit * (W + I);          // batch entry
-    C += (int64_t)blockIdx.y * strideC;
-    if (colsum) colsum += (int64_t)blockIdx.y * strideColsum;
-    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int64_t e = (int64_t)blockIdx.x * 64 + col;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (e < total) {
-        // element e of piece s: the C part is [s][W], the colsum part [nsplit*W + s*I]
-        const float* q = e < W ? parts + e : parts + (int64_t)nsplit * W + (e - W);
-        const int64_t st = e < W ? W : I;
-        int s = sl;
-        for (; s + 12 < nsplit; s += 16) { a0 += q[(int64_t)s * st]; a1 += q[(int64_t)(s + 4) * st]; a2 += q[(int64_t)(s + 8) * st]; a3 += q[(int64_t)(s + 12) * st]; }
-        for (; s < nsplit; s += 4) a0 += q[(int64_t)s * st];
-    }
-    red[sl][col] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (sl == 0 && e < total) {
-        const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-        if (e < W) { const int64_t i = e / J; C[i * ldc + (e - i * J)] += t; }
-        else colsum[e - W] += t;
-    }
-}
-
-template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS, bool CONVP = !MAPS> int launch_tn_v2_(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
-    if constexpr (CONVP && !MAPS) {          // (mapped problems are never convolutions: tn_v2_eligible) the map-free kernel without the tap state for plain problems
-        if (p.conv_kc <= 0 && !p.c_conv_permute) return launch_tn_v2_<BI, BJ, WAVES, STAGES, MAPS, CS, false>(p, split, st);
-    }
-    constexpr size_t lds = STAGES * (size_t)(64 * (BI + BJ) * 2) + (MAPS ? (2 * (STAGES - 1) + 1) * 768 + 256 : 0);
-    static bool attr_set = false;
-    if (!attr_set && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS, CONVP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            lavt_set_error("lavt_gemm_tn(v2): cannot reserve %zu bytes of LDS", lds);
-            return LAVT_ERR_LAUNCH;
-        }
-        attr_set = true;
-    }
-    const int ktiles = cdiv(p.K, 64);
-    const int per = cdiv(ktiles, split);
-    dim3 grid(cdiv(p.I, BI) * cdiv(p.J, BJ), p.batch, cdiv(ktiles, per));
-    const int pieces = (int)grid.z;
-    // partial tiles instead of atomics when the caller lent scratch for them (plain problems only: no conv column permutation, batch 1)
-    const bool parts = pieces > 1 && p.partials && !p.c_conv_permute && p.partials_floats >= (int64_t)p.batch * pieces * ((int64_t)p.I * p.J + p.I);
-    if (!parts) {
-        lavt_gemm_tn_t q = p;
-        q.partials = nullptr;
-        hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS, CONVP>), grid, dim3(WAVES * 64), lds, st, q, per);
-    } else {
-        hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS, CONVP>), grid, dim3(WAVES * 64), lds, st, p, per);
-        const int64_t total = (int64_t)p.I * p.J + (p.colsum ? p.I : 0);
-        hipLaunchKernelGGL(tn_reduce_pieces, dim3((unsigned)cdiv(total, 64), p.batch), dim3(256), 0, st, p.partials, pieces, p.I, p.J, p.C, p.ldc, p.colsum, p.strideC, p.strideColsum);
-    }
-    LAVT_CHECK_LAUNCH("lavt_gemm_tn(v2)");
-    return LAVT_OK;
-}
-// two-stage ring only (3 / 4 stages cost a resident workgroup per CU and lost end to end in round 1: those instantiations are gone)
-template <int BI, int BJ, int WAVES> int launch_tn_v2(const lavt_gemm_tn_t& p, int split, hipStream_t st) {
-    const bool maps = p.a_rowmap || p.a_rowscale || p.b_rowmap;
-    // colsum on the matrix cores when the workgroups carrying it are a minority (>= 4 column tiles), the scalar walk otherwise; 128x128: scalar
-    const int cs = !p.colsum ? 0 : ((BI == 64 && cdiv(p.J, BJ) >= 4) ? 2 : 1);
-    if constexpr (BI == 64) {
-        if (cs == 2) return maps ? launch_tn_v2_<BI, BJ, WAVES, 2, true, 2>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 2, false, 2>(p, split, st);
-    }
-    if (cs) return maps ? launch_tn_v2_<BI, BJ, WAVES, 2, true, 1>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 2, false, 1>(p, split, st);
-    return maps ? launch_tn_v2_<BI, BJ, WAVES, 2, true, 0>(p, split, st) : launch_tn_v2_<BI, BJ, WAVES, 2, false, 0>(p, split, st);
-}
-
-// the same for the members of a grouped launch that were cut into pieces through partial tiles: blockIdx.y = member
-__global__ __launch_bounds__(256) void tn_reduce_pieces_group(const TnGroup g) {
-    const lavt_gemm_tn_t& p = g.p[blockIdx.y];
-    const int nsplit = g.split[blockIdx.y];
-    if (nsplit <= 1 || p.partials == nullptr) return;
-    __shared__ float red[4][64];
-    const int64_t W = (int64_t)p.I * p.J, total = W + (p.colsum ? p.I : 0);
-    if ((int64_t)blockIdx.x * 64 >= total) return;
-    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int64_t e = (int64_t)blockIdx.x * 64 + col;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (e < total) {
-        const float* q = e < W ? p.partials + e : p.partials + (int64_t)nsplit * W + (e - W);
-        const int64_t st = e < W ? W : p.I;
-        int s = sl;
-        for (; s + 12 < nsplit; s += 16) { a0 += q[(int64_t)s * st]; a1 += q[(int64_t)(s + 4) * st]; a2 += q[(int64_t)(s + 8) * st]; a3 += q[(int64_t)(s + 12) * st]; }
-        for (; s < nsplit; s += 4) a0 += q[(int64_t)s * st];
-    }
-    red[sl][col] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (sl == 0 && e < total) {
-        const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-        if (e < W) { const int64_t i = e / p.J; p.C[i * p.ldc + (e - i * p.J)] += t; }
-        else p.colsum[e - W] += t;
-    }
-}
-
 }  // namespace
 
 // returns 1 when the problem is not for this kernel (caller falls back to gemm.hip), else a LAVT status
@@ -1140,156 +567,4 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     if (stages == 3) { if (p.b_kmajor) GO(64, 64, true, 3, 4); else GO(64, 64, false, 3, 4); }
     if (p.b_kmajor) GO(64, 64, true, 4, 4); else GO(64, 64, false, 4, 4);
 #undef GO
-}
-
-static bool tn_v2_eligible(const lavt_gemm_tn_t& p) {
-    if (p.dtype != LAVT_BF16 || p.zeros == nullptr) return false;
-    if (p.lda % 8 || p.ldb % 8 || (p.B2 && p.ldb2 % 8)) return false;
-    if (p.a_rowscale && !p.a_rowscale_binary) return false;
-    if ((p.a_rowmap || p.a_rowscale || p.b_rowmap) && (p.conv_kc > 0 || p.B2)) return false;      // the mapped K loop has no taps / second source
-    if ((int64_t)p.K * (p.lda > p.ldb ? p.lda : p.ldb) >= (1LL << 31)) return false;                // 32-bit element offsets
-    return true;
-}
-
-// returns 1 when the group cannot run as one launch (the caller then issues the problems one by one)
-int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) {
-    const char* e = getenv("LAVT_GEMM_V2");
-    if ((e && e[0] == '0') || n < 2 || n > TN_GROUP_MAX) return 1;
-    TnGroup g;
-    bool maps = false;
-    int tiles = 0;
-    // Tile configuration of the grouped launch: LAVT_TNG_CFG = "tile,waves,stages" (64,4,2 = the round-1/2 form).
-    static int cfg_tile = 64, cfg_waves = 4, cfg_stages = 2;
-    static bool cfg_read = false;
-    if (!cfg_read) {
-        cfg_read = true;
-        const char* c = getenv("LAVT_TNG_CFG");
-        if (c) sscanf(c, "%d,%d,%d", &cfg_tile, &cfg_waves, &cfg_stages);
-    }
-    int TB = cfg_tile;
-    {   // the large tile only where its tiles still occupy most of the chip
-        long t128 = 0;
-        for (int i = 0; i < n; ++i) t128 += (long)cdiv(probs[i].I, 128) * cdiv(probs[i].J, 128);
-        if (TB == 128 && t128 < 128) TB = 64;
-    }
-    bool any_colsum = false;
-    // Pieces per member.  A member with a partials scratch (lavt_gemm_tn_t.partials: its pieces are stored as plain tiles and added into C by one
-    // small second kernel) may be cut as finely as its K allows -- the long-K weight gradients of PWAM (K = 28 800 rows = 450 K tiles on 4
-    // output tiles each) then run as ONE launch of ~1000 workgroups instead of four launches of ~230 at one workgroup per CU; a member
-    // without one is cut into at most 4 pieces that meet through atomics (only if its C holds zeros: split_k < 0), and a chain of more than
-    // 128 K tiles without a scratch keeps the group from forming (it would run serially while the short members supply the tile count).
-    static const int chain = getenv("LAVT_TNG_CHAIN") ? atoi(getenv("LAVT_TNG_CHAIN")) : 48;     // 32 / 48 / 64 / 128: video step 23.16 / 22.93 / 22.82 / 22.87 ms, image step level
-    static const int piece_tiles = getenv("LAVT_TNG_PIECE") ? atoi(getenv("LAVT_TNG_PIECE")) : 8;
-    bool any_parts = false;
-    int64_t max_total = 0;
-    for (int per_piece = piece_tiles; ; per_piece *= 2) {
-        tiles = 0; maps = false; any_colsum = false; any_parts = false; max_total = 0;
-        for (int i = 0; i < n; ++i) {
-            const lavt_gemm_tn_t& p = probs[i];
-            if (!tn_v2_eligible(p) || p.batch != 1 || p.conv_kc > 0 || p.B2 || p.I % 8 || p.J % 8) return 1;
-            const int ktiles = cdiv(p.K, 64);
-            maps = maps || p.a_rowmap || p.a_rowscale || p.b_rowmap;
-            any_colsum = any_colsum || p.colsum != nullptr;
-            g.p[i] = p;
-            int ns = 1;
-            const int want = cdiv(ktiles, per_piece);
-            const bool parts = p.partials != nullptr && !p.c_conv_permute && ktiles > chain && want > 1 &&
-                               p.partials_floats >= (int64_t)want * ((int64_t)p.I * p.J + p.I);
-            if (parts) ns = want;
-            else {
-                g.p[i].partials = nullptr;
-                if (ktiles > 128) return 1;
-                ns = (p.split_k < 0 && chain > 0) ? cdiv(ktiles, chain) : 1;
-                if (ns > 4) ns = 4;
-            }
-            const int per = cdiv(ktiles, ns);
-            ns = cdiv(ktiles, per);                      // no empty pieces
-            if (parts && ns > 1) { any_parts = true; max_total = max_total > (int64_t)p.I * p.J + p.I ? max_total : (int64_t)p.I * p.J + p.I; }
-            if (ns <= 1) g.p[i].partials = nullptr;
-            g.split[i] = ns;
-            tiles += cdiv(p.I, TB) * cdiv(p.J, TB) * ns;
-            g.tile_end[i] = tiles;
-        }
-        if (tiles <= 2048 || !any_parts || per_piece >= 64) break;      // too many workgroups: longer pieces
-    }
-    for (int i = n; i < TN_GROUP_MAX; ++i) { g.p[i] = probs[0]; g.p[i].partials = nullptr; g.tile_end[i] = tiles; g.split[i] = 1; }
-    g.n = n;
-    if (tiles < (TB == 128 ? 128 : 256)) return 1;   // too few workgroups to fill the chip
-    // (round 2: an XCD-contiguous tile order inside each member -- it cuts the 152 MB of fabric traffic -- and a 3-stage ring were both measured
-    // on the step: 10.63 vs 10.64 ms and 10.81 vs 10.62 ms; neither is kept)
-    if (TB == 128 || cfg_waves != 4 || cfg_stages != 2) {
-#define TNG_GO(BT_, WV_, SG_)                                                                                                                          \
-    do {                                                                                                                                               \
-        const size_t l = SG_ * (size_t)(64 * (BT_ + BT_) * 2) + (maps ? (2 * (SG_ - 1) + 1) * 768 + 256 : 0);                                          \
-        static bool attr = false;                                                                                                                      \
-        if (!attr && l > 65536) {                                                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);  \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
-            attr = true;                                                                                                                               \
-        }                                                                                                                                              \
-        if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, true, 2>), dim3(tiles), dim3(WV_ * 64), l, st, g);                 \
-        else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, false, 2>), dim3(tiles), dim3(WV_ * 64), l, st, g);                     \
-    } while (0)
-        bool done = true;
-        if (TB == 128 && cfg_waves == 8 && cfg_stages == 2) TNG_GO(128, 8, 2);
-        else if (TB == 128 && cfg_waves == 8 && cfg_stages == 3) TNG_GO(128, 8, 3);
-        else if (TB == 128 && cfg_waves == 8 && cfg_stages == 4) TNG_GO(128, 8, 4);
-        else if (TB == 128 && cfg_waves == 4 && cfg_stages == 2) TNG_GO(128, 4, 2);
-        else if (TB == 128 && cfg_waves == 4 && cfg_stages == 3) TNG_GO(128, 4, 3);
-        else if (TB == 128 && cfg_waves == 4 && cfg_stages == 4) TNG_GO(128, 4, 4);
-        else if (TB == 64 && cfg_waves == 4 && cfg_stages == 4) TNG_GO(64, 4, 4);
-        else if (TB == 64 && cfg_waves == 4 && cfg_stages == 3) TNG_GO(64, 4, 3);
-        else done = false;
-#undef TNG_GO
-        if (done) {
-            if (any_parts) hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
-            LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
-            return LAVT_OK;
-        }
-    }
-    const size_t lds = 2 * (size_t)(64 * (64 + 64) * 2) + (maps ? 3 * 768 + 256 : 0);
-    if (any_colsum) {
-        if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true, 2>), dim3(tiles), dim3(256), lds, st, g);
-        else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, false, 2>), dim3(tiles), dim3(256), lds, st, g);
-    } else {
-        if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true, 0>), dim3(tiles), dim3(256), lds, st, g);
-        else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, false, 0>), dim3(tiles), dim3(256), lds, st, g);
-    }
-    if (any_parts) hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
-    LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
-    return LAVT_OK;
-}
-
-int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st) {
-    if (p.dtype != LAVT_BF16 || p.zeros == nullptr) return 1;
-    const char* e = getenv("LAVT_GEMM_V2");
-    if (e && e[0] == '0') return 1;
-    if (!tn_v2_eligible(p)) return 1;                            // (only 0 / constant row masks can be folded into the row fetch)
-    // Measured (tools/gemm_bench.py tn): the 64x64 / 4-wave tile wins on every weight-gradient shape of the step, the conv wgrads included
-    // (369 vs 230 TF/s for 128x128); the split-K factor trades workgroup count (latency hiding) against fp32 atomic traffic.
-    const char* t = getenv("LAVT_GEMM_TILE");
-    const int force = t ? atoi(t) : 0;
-    const int ktiles = cdiv(p.K, 64);
-    const long tiles64 = (long)cdiv(p.I, 64) * cdiv(p.J, 64) * p.batch;
-    const long tiles128 = (long)cdiv(p.I, 128) * cdiv(p.J, 128) * p.batch;
-    // conv weight gradients (long K, >= 48 tiles of 128x128 -- the Swin-T decoder's 384-channel convolutions have 102): the larger tile halves the
-    // L2->LDS bytes per MFMA (measured 303 vs 357 us on Swin-B's; 16.9 -> 16.1 ms per Swin-T step)
-    static const bool tn128 = getenv("LAVT_TN_BIG") == nullptr || getenv("LAVT_TN_BIG")[0] != '0';
-    static const int tn_big_min = getenv("LAVT_TN_BIG_MIN") ? atoi(getenv("LAVT_TN_BIG_MIN")) : 48;
-    const bool big = force ? force == 128 : (tn128 && p.conv_kc > 0 && tiles128 >= tn_big_min && ktiles >= 64);
-    const long tiles = big ? tiles128 : tiles64;
-    int split = p.split_k;
-    { const char* se = getenv("LAVT_TN_SPLIT"); if (se) split = atoi(se); }
-    if (split <= 0) {
-        static const int target = getenv("LAVT_TN_TARGET") ? atoi(getenv("LAVT_TN_TARGET")) : 768;
-        split = big ? (int)((384 + tiles / 2) / tiles) : (int)((target + tiles / 2) / tiles);      // ~3 (64-tile) / ~1.5 (128-tile) workgroups per CU
-        const int long_k = (ktiles + 127) / 128;          // no workgroup walks more than ~128 K tiles
-        if (split < long_k) split = long_k;
-        const int max_split = (ktiles + 7) / 8;           // >= 8 K tiles per workgroup
-        if (split > max_split) split = max_split;
-        if (split < 1) split = 1;
-    }
-    if (split > ktiles) split = ktiles;
-    if (big) return launch_tn_v2<128, 128, 8>(p, split, st);
-    return launch_tn_v2<64, 64, 4>(p, split, st);
 }
