@@ -82,13 +82,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     }
 }
 
-template <typename T, int LPR, int CPL, int WAVES>
+// FLAGS: bit 0 = the rows may be gathered (PatchMerging's 2x2 form), bit 1 = the LayerNorm output is written on the way; the plain form carries
+// neither (a never-taken uniform branch is not free in these one-round kernels: DESIGN.md section 5)
+template <typename T, int LPR, int CPL, int WAVES, int FLAGS = 3>
 __global__ __launch_bounds__(WAVES * 64) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const int32_t* __restrict__ gather, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ partials, const T* __restrict__ dres, int rows, int C,
-                                                            T* __restrict__ xn_out, const float* __restrict__ beta) {
+                                                            T* __restrict__ xn_out_, const float* __restrict__ beta) {
+    if constexpr (!(FLAGS & 1)) gather = nullptr;
+    T* const xn_out = (FLAGS & 2) ? xn_out_ : nullptr;
     // CPL = chunks per lane (compile time: the row arrays are exactly as large as needed; LPR < 64 only with CPL == 1)
     constexpr int EPC = Chunk<T>::N, MAXC = CPL, RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, lir = lane % LPR, wave = threadIdx.x >> 6;
@@ -572,12 +576,14 @@ static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const in
     const int blocks = ln_bwd_geometry(dtype, rows, C, &lpr, &cpl, &waves);
     float* partials = (ws && ws_floats >= (int64_t)blocks * 2 * C) ? ws : nullptr;
     LAVT_CHECK_ARG(!partial_only || partials, "lavt_layernorm_bwd_partial: scratch of %ld floats needed", (long)blocks * 2 * C);
-#define LN_BWD(LPR_, CPL_, WV_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_, CPL_, WV_>), dim3(blocks), dim3(WV_ * 64), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, (const T*)dres, rows, C, (T*)xn_out, beta)
+#define LN_BWD_F(LPR_, CPL_, WV_, F_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR_, CPL_, WV_, F_>), dim3(blocks), dim3(WV_ * 64), 0, st, (const T*)dy, (const T*)x, gather, gamma, mean, rstd, (T*)dx, dgamma, dbeta, partials, (const T*)dres, rows, C, (T*)xn_out, beta)
+#define LN_BWD(LPR_, CPL_, WV_) do { if (gather) LN_BWD_F(LPR_, CPL_, WV_, 1); else if (xn_out) LN_BWD_F(LPR_, CPL_, WV_, 2); else LN_BWD_F(LPR_, CPL_, WV_, 0); } while (0)
     DISPATCH_T(dtype, "lavt_layernorm_bwd",
                if (waves == 8) { if (lpr == 16) LN_BWD(16, 1, 8); else if (lpr == 32) LN_BWD(32, 1, 8); else if (cpl == 1) LN_BWD(64, 1, 8); else LN_BWD(64, 2, 8); }
                else if (lpr == 16) LN_BWD(16, 1, 4); else if (lpr == 32) LN_BWD(32, 1, 4);
                else if (cpl == 1) LN_BWD(64, 1, 4); else if (cpl == 2) LN_BWD(64, 2, 4); else if (cpl <= 4) LN_BWD(64, 4, 4); else LN_BWD(64, 8, 4));
 #undef LN_BWD
+#undef LN_BWD_F
     if (partials && !partial_only) hipLaunchKernelGGL(reduce_partials_kernel, reduce_partials_grid(blocks, 2 * C), dim3(256), 0, st, partials, blocks, 2 * C, C, dgamma, dbeta);
     LAVT_CHECK_LAUNCH("lavt_layernorm_bwd");
     return LAVT_OK;
