@@ -439,7 +439,8 @@ extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
         LAVT_CHECK_ARG(p.M % vox == 0, "lavt_gemm_nt: conv rows %d not a multiple of D*H*W", p.M);
     }
     LAVT_CHECK_ARG((!p.R || p.ldr % 4 == 0) && (!p.Cpre || p.ldcpre % 4 == 0) && (!p.mul || p.ldmul % 4 == 0), "lavt_gemm_nt: ldr/ldcpre/ldmul must be multiples of 4");
-    LAVT_CHECK_ARG(p.act != LAVT_ACT_GELU_D || (p.ln_wsum && p.Cpre), "lavt_gemm_nt: LAVT_ACT_GELU_D exists in the LayerNorm-folded launch only (ln_wsum) and needs Cpre");
+    LAVT_CHECK_ARG(p.act != LAVT_ACT_GELU_D || (p.ln_wsum && p.Cpre && !p.mul && !p.C2 && !p.R && !p.row_scale && !p.c_rowmap),
+                   "lavt_gemm_nt: LAVT_ACT_GELU_D exists in the LayerNorm-folded launch only (ln_wsum), needs Cpre and takes no multiplier / split / residual / row scale / row map");
     LAVT_CHECK_ARG(!p.res_first || (p.dact_pre && p.R), "lavt_gemm_nt: res_first orders the residual before the fused activation gradient (needs dact_pre and R)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     { const char* e = getenv("LAVT_GEMM_EPI"); p.epi_lds = (e && e[0] == 'l') ? 1 : 0;

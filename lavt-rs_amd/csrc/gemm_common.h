@@ -164,6 +164,9 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32
     if constexpr (DACT && GD) {          // stored-derivative data gradient (launch_nt_v2_dact): C = acc * alpha * row_scale * dact_pre, nothing else
         p.dact = LAVT_ACT_STORED; p.R = nullptr; p.bias = nullptr; p.c_rowmap = nullptr; p.act = 0; p.mul = nullptr; p.Cpre = nullptr; p.C2 = nullptr;
     }
+    if constexpr (GD && !DACT) {         // fc1 of the LayerNorm-folded MLP node: folded bias, GELU + its derivative as second output, nothing else
+        p.mul = nullptr; p.C2 = nullptr; p.R = nullptr; p.row_scale = nullptr; p.c_rowmap = nullptr;
+    }
     if constexpr (LEAN >= 1) { p.act = 0; p.mul = nullptr; p.Cpre = nullptr; p.C2 = nullptr; }
     if constexpr (LEAN >= 2) { p.bias = nullptr; p.R = nullptr; p.row_scale = nullptr; p.c_rowmap = nullptr; }
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;

@@ -462,7 +462,7 @@ int launch_nt_v2_lna(const lavt_gemm_nt_t& p, hipStream_t st) {
     }
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128), tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
     // (LAVT_ACT_GELU_D is its own instantiation: with the branch on p.act inside one kernel, the classic form ran 3 us per launch slower)
-    if (p.act == LAVT_ACT_GELU_D) {
+    if (p.act == LAVT_ACT_GELU_D && !p.mul && !p.C2 && !p.R && !p.row_scale && !p.c_rowmap) {
         if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_<128, 128, false, 2, 8, 1, false, false, true, true>(p, st) : launch_nt_v2_<128, 128, false, 4, 8, 1, false, false, true, true>(p, st);
         return tiles64 >= 600 ? launch_nt_v2_<64, 64, false, 2, 4, 1, false, false, true, true>(p, st) : launch_nt_v2_<64, 64, false, 4, 4, 1, false, false, true, true>(p, st);
     }
