@@ -466,8 +466,10 @@ def main():
                        "timed_repetitions": len(reps_all), "ms_per_step_all_repetitions": [round(e / a.steps * 1e3, 3) for e in reps_all]},
         }
         if world > 1:
-            out["config"]["rccl"] = {"max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"), "bf16_buckets": bool(a.bf16_buckets),
-                                     "gradient_bytes_per_step": step.buckets.bytes_per_step() // (2 if a.bf16_buckets else 1)}
+            out["config"]["rccl"] = {"max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"), "bf16_buckets": bool(step.buckets.bf16), "ddp_mode": step.buckets.mode,
+                                     "gradient_bytes_per_step": step.buckets.bytes_per_step() // (2 if step.buckets.bf16 else 1),
+                                     "buckets": len(step.buckets.buckets), "overlappable_bytes": step.buckets.overlappable_bytes() // (2 if step.buckets.bf16 else 1),
+                                     "late_bucket_bytes": (step.buckets.bytes_per_step() - step.buckets.overlappable_bytes()) // (2 if step.buckets.bf16 else 1)}
         if world > 1 or force:
             # multi-rank runs: the per-family pass would issue eager collectives on one rank only; the dominant conv kernel is timed alone instead
             # (rank 0, after the timed region, the other ranks idle at the final barrier)

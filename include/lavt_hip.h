@@ -2,8 +2,12 @@
  * lavt_hip.h -- C ABI of the MI355X (gfx950) LAVT hot-path library (liblavt_hip.so).
  *
  * Every entry point is `extern "C"`, takes raw DEVICE pointers + sizes + a hipStream_t (as void*),
- * allocates nothing, keeps no global state besides the last-error string, launches asynchronously on
- * the given stream and returns 0 or a negative LAVT_ERR_* code.  No torch types anywhere.
+ * allocates nothing, launches asynchronously on the given stream and returns 0 or a negative LAVT_ERR_*
+ * code.  No torch types anywhere.  Global state: the (thread-local) last-error string and one table of
+ * tuning switches -- the LAVT_* environment variables listed in lavt-rs_amd/csrc/tuning.hip, which choose
+ * between equivalent kernel configurations (tile sizes, ring depths, A/B forms).  They are read once, at
+ * the first launch; lavt_tuning_reload() re-reads them.  No launch path calls getenv, and no switch makes
+ * a kernel skip work.
  *
  * The reference (Yxxxb/LAVT-RS) is pure PyTorch and has no native layer; each group of functions
  * below names the reference code (file:line under the reference root) whose arithmetic it replaces.
@@ -43,6 +47,7 @@ extern "C" {
 
 int lavt_abi_version(void);
 const char* lavt_last_error(void);
+int lavt_tuning_reload(void); /* re-read the LAVT_* tuning switches from the environment (tests that force a tile configuration) */
 
 /* ---------------------------------------------------------------------------------------------
  * Gather-GEMM, "NT" family:   C[M,N] = epilogue( alpha * A_op[M,K] x B_op[K,N] )

@@ -397,8 +397,7 @@ int lavt_window_attn_bwd_pieces_mfma(int nwin, int N, int heads);
 int64_t lavt_window_attn_bwd_ws_mfma(int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww);
 // LAVT_ATTN_SIMPLE=1 forces the VALU formulation for bf16 too (A/B tests of the MFMA kernels)
 static bool use_mfma(int dtype, int N, int bias_ld) {
-    const char* e = getenv("LAVT_ATTN_SIMPLE");
-    return dtype == LAVT_BF16 && N <= 400 && bias_ld >= (N <= 64 ? 64 : N <= 160 ? 160 : 416) && !(e && e[0] == '1');
+    return dtype == LAVT_BF16 && N <= 400 && bias_ld >= (N <= 64 ? 64 : N <= 160 ? 160 : 416) && !lavt_tuning().attn_simple;
 }
 
 extern "C" int lavt_window_attn_fwd(int dtype, const void* qkv, const float* bias, int bias_ld, const int8_t* region, int nw_img, void* out,

@@ -621,7 +621,7 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     } while (0)
     // 8 waves share one window-head, capped at 128 VGPRs so two workgroups (16 waves) sit on a CU: 5-9% faster than 4 waves x 2 at every
     // stage shape of Swin-B w12 @480 (measured, tools/attn_bench2.py).  LAVT_ATTN_BWD_WAVES=4 keeps the 4-wave variant reachable.
-    static const int force_waves = getenv("LAVT_ATTN_BWD_WAVES") ? atoi(getenv("LAVT_ATTN_BWD_WAVES")) : 0;
+    const int force_waves = lavt_tuning().attn_bwd_waves;
     const int waves = force_waves ? force_waves : 8;
     if (N <= 64) LAVT_BWD(4, 4, false);
     else if (N == 144) { if (waves == 8) LAVT_BWD(9, 8, true); else LAVT_BWD(9, 4, true); }

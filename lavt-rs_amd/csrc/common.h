@@ -33,6 +33,15 @@ void lavt_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- tuning / A-B switches (tuning.hip): the LAVT_* environment variables, read once per process (lavt_tuning_reload() re-reads) ---------
+struct lavt_tuning_t {
+    bool attn_simple, unpack_tiled, gemm_epi_lds, gemm_epi_narrow, gemm_v2_off, tn_big, gemm_general, gemm_wide;
+    int attn_bwd_waves, gemm_tile, tn_split, tng_tile, tng_waves, tng_stages, tng_chain, tng_piece, tn_big_min, tn_target, gemm_big_long, gemm_stages,
+        gemm_waves, ln_bwd_waves, tn_streamk, conv_stats;
+    int probe[8];          // LAVT_PROBE=a,b,...: free integers for experiment builds (unused by the shipped dispatch)
+};
+const lavt_tuning_t& lavt_tuning();
+
 // ---- scalar conversions -----------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }

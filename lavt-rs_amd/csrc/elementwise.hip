@@ -741,7 +741,7 @@ extern "C" int lavt_pack_conv3x3(const float* w, int dtype, void* packed, int Co
 extern "C" int lavt_unpack_conv_grad(const float* packed, float* dw, int Cout, int Cin, int taps, void* stream) {
     LAVT_CHECK_ARG(packed && dw && Cout > 0 && Cin > 0 && taps > 0, "lavt_unpack_conv_grad: bad arguments");
     const int64_t n = (int64_t)Cout * Cin * taps;
-    static const bool tiled = !(getenv("LAVT_UNPACK_TILED") && getenv("LAVT_UNPACK_TILED")[0] == '0');
+    const bool tiled = lavt_tuning().unpack_tiled;
     if (tiled && taps <= 32 && Cout <= 65535) hipLaunchKernelGGL(unpack_conv_grad_tiled_kernel, dim3((Cin + 127) / 128, Cout), dim3(256), (size_t)taps * 129 * 4, ST, packed, dw, Cin, taps);
     else hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, packed, dw, Cout, Cin, taps);
     LAVT_CHECK_LAUNCH("lavt_unpack_conv_grad");

@@ -205,8 +205,7 @@ template <typename T, int BM, int BN, bool BKM> int launch_nt(const lavt_gemm_nt
 }
 // LAVT_GEMM_TILE=128|64 forces a tile configuration (tests exercise both); unset = shape heuristic.
 static int forced_tile() {
-    const char* e = getenv("LAVT_GEMM_TILE");
-    return e ? atoi(e) : 0;
+    return lavt_tuning().gemm_tile;
 }
 template <typename T> int dispatch_nt(const lavt_gemm_nt_t& p, hipStream_t st) {
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
@@ -381,7 +380,7 @@ template <typename T, int BI, int BJ> int launch_tn(const lavt_gemm_tn_t& p, hip
     const int ktiles = cdiv(p.K, BK);
     int split = p.split_k;
     if (split <= 0) {
-        { const char* se = getenv("LAVT_TN_SPLIT"); if (se) split = atoi(se); }
+        split = lavt_tuning().tn_split;
         if (split <= 0) split = (int)(768 / ((long)tiles * p.batch));
         if (split < 1) split = 1;
         const int max_split = (ktiles + 3) / 4;        // at least 4 K tiles per workgroup
@@ -443,8 +442,8 @@ extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
                    "lavt_gemm_nt: LAVT_ACT_GELU_D exists in the LayerNorm-folded launch only (ln_wsum), needs Cpre and takes no multiplier / split / residual / row scale / row map");
     LAVT_CHECK_ARG(!p.res_first || (p.dact_pre && p.R), "lavt_gemm_nt: res_first orders the residual before the fused activation gradient (needs dact_pre and R)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    { const char* e = getenv("LAVT_GEMM_EPI"); p.epi_lds = (e && e[0] == 'l') ? 1 : 0;
-      static const bool wide_off = e && e[0] == 'n';          // LAVT_GEMM_EPI=narrow: the 8-byte store form
+    { p.epi_lds = lavt_tuning().gemm_epi_lds ? 1 : 0;
+      const bool wide_off = lavt_tuning().gemm_epi_narrow;          // LAVT_GEMM_EPI=narrow: the 8-byte store form
       p.epi_wide = (!wide_off && p.dtype != LAVT_F32 && !p.c_f32 && p.ldc % 8 == 0 && (!p.C2 || (p.ldc2 % 8 == 0 && p.c_split % 8 == 0)) && (!p.R || p.ldr % 4 == 0) &&
                     (!p.Cpre || p.ldcpre % 8 == 0) && (!p.dact_pre || p.lddact % 4 == 0) && (!p.bias || (p.strideBias % 4 == 0 && ((uintptr_t)p.bias % 16) == 0)) &&
                     ((uintptr_t)p.C % 16) == 0 && (!p.C2 || ((uintptr_t)p.C2 % 16) == 0) && (!p.Cpre || ((uintptr_t)p.Cpre % 16) == 0) && (p.strideC % 8 == 0)) ? 1 : 0; }
@@ -480,9 +479,9 @@ extern "C" int lavt_gemm_tn(const lavt_gemm_tn_t* pp, void* stream) {
 extern "C" int lavt_gemm_tn_pieces(const lavt_gemm_tn_t* p) {
     if (!p || p->K <= 0) return 1;
     const int ktiles = cdiv(p->K, 64);
-    const char* se = getenv("LAVT_TN_SPLIT");
+    const int se = lavt_tuning().tn_split;
     int n = cdiv(ktiles, 8);
-    if (se && atoi(se) > n) n = atoi(se);
+    if (se > n) n = se;
     if (n > ktiles) n = ktiles;
     return n < 1 ? 1 : n;
 }

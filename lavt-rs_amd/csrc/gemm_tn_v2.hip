@@ -479,6 +479,7 @@ __global__ __launch_bounds__(256) void tn_reduce_pieces_group(const TnGroup g) {
     if (sl == 0 && e < total) {
         const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
         if (e < W) { const int64_t i = e / p.J; p.C[i * p.ldc + (e - i * p.J)] += t; }
+        else if (p.colsum_atomic) atomicAdd(p.colsum + (e - W), t);      // another member of this launch (another blockIdx.y) adds into the same vector: two addends into zeros, order-independent
         else p.colsum[e - W] += t;
     }
 }
@@ -496,19 +497,13 @@ static bool tn_v2_eligible(const lavt_gemm_tn_t& p) {
 
 // returns 1 when the group cannot run as one launch (the caller then issues the problems one by one)
 int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) {
-    const char* e = getenv("LAVT_GEMM_V2");
-    if ((e && e[0] == '0') || n < 2 || n > TN_GROUP_MAX) return 1;
+    const lavt_tuning_t& tun = lavt_tuning();
+    if (tun.gemm_v2_off || n < 2 || n > TN_GROUP_MAX) return 1;
     TnGroup g;
     bool maps = false;
     int tiles = 0;
     // Tile configuration of the grouped launch: LAVT_TNG_CFG = "tile,waves,stages" (64,4,2 = the round-1/2 form).
-    static int cfg_tile = 64, cfg_waves = 4, cfg_stages = 2;
-    static bool cfg_read = false;
-    if (!cfg_read) {
-        cfg_read = true;
-        const char* c = getenv("LAVT_TNG_CFG");
-        if (c) sscanf(c, "%d,%d,%d", &cfg_tile, &cfg_waves, &cfg_stages);
-    }
+    const int cfg_tile = tun.tng_tile, cfg_waves = tun.tng_waves, cfg_stages = tun.tng_stages;
     int TB = cfg_tile;
     {   // the large tile only where its tiles still occupy most of the chip
         long t128 = 0;
@@ -521,8 +516,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     // output tiles each) then run as ONE launch of ~1000 workgroups instead of four launches of ~230 at one workgroup per CU; a member
     // without one is cut into at most 4 pieces that meet through atomics (only if its C holds zeros: split_k < 0), and a chain of more than
     // 128 K tiles without a scratch keeps the group from forming (it would run serially while the short members supply the tile count).
-    static const int chain = getenv("LAVT_TNG_CHAIN") ? atoi(getenv("LAVT_TNG_CHAIN")) : 48;     // 32 / 48 / 64 / 128: video step 23.16 / 22.93 / 22.82 / 22.87 ms, image step level
-    static const int piece_tiles = getenv("LAVT_TNG_PIECE") ? atoi(getenv("LAVT_TNG_PIECE")) : 8;
+    const int chain = tun.tng_chain, piece_tiles = tun.tng_piece;
     bool any_parts = false;
     int64_t max_total = 0;
     for (int per_piece = piece_tiles; ; per_piece *= 2) {
@@ -605,26 +599,25 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
 
 int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st) {
     if (p.dtype != LAVT_BF16 || p.zeros == nullptr) return 1;
-    const char* e = getenv("LAVT_GEMM_V2");
-    if (e && e[0] == '0') return 1;
+    const lavt_tuning_t& tun = lavt_tuning();
+    if (tun.gemm_v2_off) return 1;
     if (!tn_v2_eligible(p)) return 1;                            // (only 0 / constant row masks can be folded into the row fetch)
     // Measured (tools/gemm_bench.py tn): the 64x64 / 4-wave tile wins on every weight-gradient shape of the step, the conv wgrads included
     // (369 vs 230 TF/s for 128x128); the split-K factor trades workgroup count (latency hiding) against fp32 atomic traffic.
-    const char* t = getenv("LAVT_GEMM_TILE");
-    const int force = t ? atoi(t) : 0;
+    const int force = tun.gemm_tile;
     const int ktiles = cdiv(p.K, 64);
     const long tiles64 = (long)cdiv(p.I, 64) * cdiv(p.J, 64) * p.batch;
     const long tiles128 = (long)cdiv(p.I, 128) * cdiv(p.J, 128) * p.batch;
     // conv weight gradients (long K, >= 48 tiles of 128x128 -- the Swin-T decoder's 384-channel convolutions have 102): the larger tile halves the
     // L2->LDS bytes per MFMA (measured 303 vs 357 us on Swin-B's; 16.9 -> 16.1 ms per Swin-T step)
-    static const bool tn128 = getenv("LAVT_TN_BIG") == nullptr || getenv("LAVT_TN_BIG")[0] != '0';
-    static const int tn_big_min = getenv("LAVT_TN_BIG_MIN") ? atoi(getenv("LAVT_TN_BIG_MIN")) : 48;
+    const bool tn128 = tun.tn_big;
+    const int tn_big_min = tun.tn_big_min;
     const bool big = force ? force == 128 : (tn128 && p.conv_kc > 0 && tiles128 >= tn_big_min && ktiles >= 64);
     const long tiles = big ? tiles128 : tiles64;
     int split = p.split_k;
-    { const char* se = getenv("LAVT_TN_SPLIT"); if (se) split = atoi(se); }
+    if (tun.tn_split) split = tun.tn_split;
     if (split <= 0) {
-        static const int target = getenv("LAVT_TN_TARGET") ? atoi(getenv("LAVT_TN_TARGET")) : 768;
+        const int target = tun.tn_target;
         split = big ? (int)((384 + tiles / 2) / tiles) : (int)((target + tiles / 2) / tiles);      // ~3 (64-tile) / ~1.5 (128-tile) workgroups per CU
         const int long_k = (ktiles + 127) / 128;          // no workgroup walks more than ~128 K tiles
         if (split < long_k) split = long_k;

@@ -495,7 +495,7 @@ int launch_nt_v2_dact(const lavt_gemm_nt_t& p, hipStream_t st) {
     }
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch, tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;
     // the stored-derivative form (dact = LAVT_ACT_STORED, no residual) is its own instantiation (GD): a multiply, none of the transcendental forms
-    if (p.dact == LAVT_ACT_STORED && !p.R && !p.bias && !p.c_rowmap) {
+    if (p.dact == LAVT_ACT_STORED && !p.R && !p.bias && !p.c_rowmap && !p.act && !p.mul && !p.Cpre && !p.C2) {      // (its wide epilogue has none of these: any of them takes the general instantiation)
         if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_<128, 128, true, 2, 8, 1, true, false, false, true>(p, st) : launch_nt_v2_<128, 128, true, 4, 8, 1, true, false, false, true>(p, st);
         return tiles64 >= 600 ? launch_nt_v2_<64, 64, true, 2, 4, 1, true, false, false, true>(p, st) : launch_nt_v2_<64, 64, true, 4, 4, 1, true, false, false, true>(p, st);
     }
@@ -503,7 +503,7 @@ int launch_nt_v2_dact(const lavt_gemm_nt_t& p, hipStream_t st) {
     return tiles64 >= 600 ? launch_nt_v2_<64, 64, true, 2, 4, 1, true>(p, st) : launch_nt_v2_<64, 64, true, 4, 4, 1, true>(p, st);
 }
 template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
-    static const bool general_only = getenv("LAVT_GEMM_GENERAL") != nullptr;
+    const bool general_only = lavt_tuning().gemm_general;
     const bool simple = p.conv_kc <= 0 && p.A2 == nullptr && p.K % 64 == 0;
     const bool convfast = p.conv_kc > 0 && p.conv_kc % 64 == 0 && (p.A2 == nullptr || p.a_split % 64 == 0) && conv_taps_of(p) <= 32;     // (a bit per tap)
     if (simple && !general_only) return launch_nt_v2_<BM, BN, BKM, STAGES, WAVES, 1>(p, st);
@@ -518,34 +518,32 @@ template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(cons
 int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     if (p.dtype == LAVT_FP8) return launch_nt_v2_fp8(p, st);
     if (p.dtype != LAVT_BF16 || p.zeros == nullptr) return 1;
-    const char* e = getenv("LAVT_GEMM_V2");
-    if (e && e[0] == '0') return 1;
+    const lavt_tuning_t& tun = lavt_tuning();
+    if (tun.gemm_v2_off) return 1;
     if (p.lda % 8 || p.ldb % 8 || (p.A2 && p.lda2 % 8)) return 1;
     if (p.ln_wsum) return launch_nt_v2_lna(p, st);
     if (p.dact_pre) return launch_nt_v2_dact(p, st);
     // Dispatch measured on MI355X (tools/gemm_bench.py, hipGraph-timed): 128x128 tile with 8 waves (2 per SIMD: one wave's DMA issue and
     // LDS reads hide under the other's MFMAs) and a 2-stage ring (64-80 KiB -> 2 workgroups per CU) once there are >= 200 such tiles;
     // otherwise 64x64 tiles / 4 waves (5 workgroups per CU), 3 stages only for long-K problems with few tiles.
-    const char* t = getenv("LAVT_GEMM_TILE");
-    const int force = t ? atoi(t) : 0;
+    const int force = tun.gemm_tile;
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
     const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;
     // long reductions on few tiles (3-D convolutions of SepTPWAM: K = 27 C on 144 tiles of 128x128) also take the 128x128 tile: a launch lasts as
     // long as its serial chain of K tiles, and the larger tile moves half the bytes per K tile and flop
-    static const int big_long = getenv("LAVT_GEMM_BIG_LONG") ? atoi(getenv("LAVT_GEMM_BIG_LONG")) : 128;
+    const int big_long = tun.gemm_big_long;
     const bool big = force ? force == 128 : ((tiles128 >= 200 || (big_long > 0 && p.K >= 64 * 64 && tiles128 >= big_long)) && p.N >= 128);
-    const char* sg = getenv("LAVT_GEMM_STAGES");
+
     // Ring depth.  In isolation (operands L2-resident) 2 stages win everywhere; inside the training step the operands of the small
     // GEMMs arrive cold from HBM / Infinity Cache and a 4-deep ring is worth 0.8 ms per step.  The many-tile long-K problems (decoder
     // convolutions: every CU holds 2 workgroups and streams from L2) stay at 2 stages, which keeps two workgroups per CU resident.
     const long wgs = big ? tiles128 : tiles64;
-    const int stages = sg ? atoi(sg) : (wgs >= 600 ? 2 : 4);
-    const char* wv = getenv("LAVT_GEMM_WAVES");
-    const int waves = wv ? atoi(wv) : 8;
+    const int stages = tun.gemm_stages ? tun.gemm_stages : (wgs >= 600 ? 2 : 4);
+    const int waves = tun.gemm_waves;
 #define GO(BM_, BN_, KM_, ST_, WV_) return launch_nt_v2<BM_, BN_, KM_, ST_, WV_>(p, st)
     // 128x256 tile, 8 waves of 64x64: fewer LDS bytes (DMA fill and fragment reads) per MFMA than 128x128; for the long-K, many-tile problems
     const long tiles256 = (long)cdiv(p.M, 128) * cdiv(p.N, 256) * p.batch;
-    const bool wide = force ? force == 256 : (getenv("LAVT_GEMM_WIDE") != nullptr && tiles256 >= 256 && p.N % 256 == 0 && p.K >= 1024);
+    const bool wide = force ? force == 256 : (tun.gemm_wide && tiles256 >= 256 && p.N % 256 == 0 && p.K >= 1024);
     if (wide) { if (p.b_kmajor) GO(128, 256, true, 2, 8); else GO(128, 256, false, 2, 8); }
     // 256x256 tile, 16 waves (4 x 4 of 64x64), one workgroup per CU: 128 flop per byte of LDS fill.  The 128x128 tile cannot keep enough bytes
     // in flight per CU to cover the L2 latency at the MFMA rate (160 KiB of LDS); measured 1.02 vs 0.82 PFLOP/s on the decoder conv shape.

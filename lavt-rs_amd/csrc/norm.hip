@@ -556,7 +556,7 @@ static int ln_bwd_geometry(int dtype, int rows, int C, int* lpr_out, int* cpl_ou
     if (blocks > 1280) blocks = cdiv(rows, 2 * rpb);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    static const int old_geom = getenv("LAVT_LN_BWD_WAVES") ? atoi(getenv("LAVT_LN_BWD_WAVES")) : 0;
+    const int old_geom = lavt_tuning().ln_bwd_waves;
     if (old_geom == 8 && cpl <= 2 && rows > 256) { waves = 8; blocks = cdiv(rows, 8 * (64 / lpr)); if (blocks > 1024) blocks = 1024; }
     *lpr_out = lpr; *cpl_out = cpl;
     if (waves_out) *waves_out = waves;

@@ -65,7 +65,6 @@ struct WmsaArgs {
     const void* zeros;
     int nw_img, wh, ww, nwin, N, heads, C;
     float eps, scale;
-    int debug;
 };
 
 template <int NT, bool REGION, bool FULL>
@@ -138,7 +137,7 @@ __global__ __launch_bounds__(512, 4) void wmsa_fwd_fused_kernel(const WmsaArgs a
     for (int u = 0; u < SU; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
     typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2;
     const bf16x2 ones2 = {(bf16)1.0f, (bf16)1.0f};
-    const int ktiles = (a.debug & 2) ? 0 : (C >> 6);
+    const int ktiles = C >> 6;
     if (ktiles) issue(0);
     // the small tables are staged while the first K tile is in flight (they are first read after the loop's barriers)
     for (int e = tid; e < NP; e += NTHR) {
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(512, 4) void wmsa_fwd_fused_kernel(const WmsaArgs a
     // fragments are read per tile instead of being kept in registers) ---------------------------------------------------------------------------
     const float sc2 = a.scale * LOG2E;
     const int heads = a.heads;
-    for (int it = ((a.debug & 1) ? QT : wave); it < QT; it += NW) {
+    for (int it = wave; it < QT; it += NW) {
         const int i = 16 * it + c16;
         const bool vi = i < N;
         const bf16x8 qf = lds_row8(Qs, F_LD, i, 8 * g);
@@ -410,7 +409,6 @@ extern "C" int lavt_wmsa_fwd(const void* x, const int32_t* wmap, const void* Wg,
     a.x = (const bf16*)x; a.wmap = wmap; a.Wg = (const bf16*)Wg; a.wsum = wsum; a.biasp = biasp; a.bias = bias; a.gamma = gamma; a.beta = beta;
     a.table = table; a.region = region; a.out = (bf16*)out; a.lse = lse; a.qkv = (bf16*)qkv; a.xn = (bf16*)xn; a.mean = mean; a.rstd = rstd; a.zeros = zeros;
     a.nw_img = nw_img; a.wh = ws; a.ww = ws; a.nwin = nwin; a.N = N; a.heads = heads; a.C = C; a.eps = eps; a.scale = scale;
-    { const char* d = getenv("LAVT_WMSA_DEBUG"); a.debug = d ? atoi(d) : 0; }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (N <= 64) return launch_wmsa<4, false>(a, st);
     if (N == 144) return launch_wmsa<9, true>(a, st);

@@ -137,6 +137,7 @@ class GemmTN(C.Structure):
 # every symbol include/lavt_hip.h declares, with its argument types (tests check this list against the header)
 _PROTOTYPES = {
     "lavt_abi_version": [],
+    "lavt_tuning_reload": [],
     "lavt_gemm_nt": [C.POINTER(GemmNT), vp],
     "lavt_gemm_tn": [C.POINTER(GemmTN), vp],
     "lavt_splitk_reduce": [i32, vp, i32, i64, i32, vp, i64, vp],
@@ -221,7 +222,7 @@ if _cdll.lavt_abi_version() != EXPECTED_ABI:
 _cdll.lavt_last_error.restype = C.c_char_p
 _cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
 _cdll.lavt_last_error.argtypes = []
-for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts", "lavt_adamw_chunk_elems"):      # queries, not launches: never timed
+for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts", "lavt_adamw_chunk_elems", "lavt_tuning_reload"):      # queries, not launches: never timed
     setattr(lib, _name, getattr(_cdll, _name))
 
 EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)

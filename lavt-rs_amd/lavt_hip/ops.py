@@ -31,6 +31,8 @@ class _WeightCache:
     def __init__(self):
         self.store = {}
         self.epoch = 0
+        self.generation = 0          # bumped whenever a copy gets a NEW buffer (first use, shape change, re-homing into a stacked buffer): whoever
+                                     # baked copy addresses into a device table (FusedAdamW) keys the table on it
 
     def invalidate(self):
         self.epoch += 1
@@ -53,7 +55,11 @@ class _WeightCache:
         else:
             raise KeyError(kind)
         # keep the same storage across refreshes (static addresses for hipGraph replays)
-        out = ent[1] if ent is not None and tuple(ent[1].shape) == shape else torch.empty(shape, dtype=dtype, device=src.device)
+        if ent is not None and tuple(ent[1].shape) == shape:
+            out = ent[1]
+        else:
+            out = torch.empty(shape, dtype=dtype, device=src.device)
+            self.generation += 1
         if kind == "lin":
             K.check(K.lib.lavt_cast(K.F32, K.ptr(src), K.dt(dtype), K.ptr(out), src.numel(), K.stream()))
         else:
@@ -122,6 +128,7 @@ class _WeightCache:
                 off += p.shape[0]
             ent = (big, [weakref.ref(p) for p in ps])
             cats[key] = ent
+            self.generation += 1
             self.multi = None                                # a descriptor table built earlier points at the old per-parameter copies
         for p in ps:
             self.get(p, dtype, "lin")
@@ -140,13 +147,14 @@ class _WeightCache:
 
     def refresh_all(self, done=frozenset()):
         """Start of a step / end of an optimizer step: make every compute copy current (1 launch for all Linear weights + 1 per 3x3 conv + 1 for all
-        LayerNorm folds).  `done`: keys of 'lin' copies the caller has just written itself (FusedAdamW's update kernel): only their stamps move."""
+        LayerNorm folds).  `done`: {key: address} of 'lin' copies the caller has just written itself (FusedAdamW's update kernel): only their
+        stamps move -- provided the copy still lives at the address the caller wrote to (a re-homed or re-allocated copy is cast again)."""
         self.epoch += 1
         multi = getattr(self, "multi", None)
         fresh = set()
         for k in done:
             ent = self.store.get(k)
-            if ent is not None and ent[2]() is not None:
+            if ent is not None and ent[2]() is not None and (not isinstance(done, dict) or ent[1].data_ptr() == done[k]):
                 p = ent[2]()
                 self.store[k] = ((p._version, p.data_ptr(), self.epoch), ent[1], ent[2])
                 fresh.add(k)
@@ -474,6 +482,17 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     K.check(K.lib.lavt_gemm_tn(C.byref(p), K.stream()))
 
 
+def assign_partials(items, device):
+    """the members of one grouped launch write their partial tiles at the same time: disjoint regions of the per-device scratch"""
+    need = [int(q.partials_floats) if q.partials else 0 for q in items]
+    if sum(need):
+        base, off = _tn_parts(sum(need), device).data_ptr(), 0
+        for q, nf in zip(items, need):
+            if nf:
+                q.partials = base + 4 * off
+                off += nf
+
+
 class _WgradQueue:
     """Weight-gradient GEMMs of consecutive backward ops (the four Linear layers of a Swin block) are collected and issued as ONE grouped
     launch (lavt_gemm_tn_grouped): together they fill the chip without split-K, so the gradients are stored plainly instead of going
@@ -507,14 +526,7 @@ class _WgradQueue:
 
     def flush(self):
         if self.items:
-            need = [int(q.partials_floats) if q.partials else 0 for q in self.items]
-            if sum(need):                        # the members of one launch write their partial tiles at the same time: disjoint regions of the scratch
-                dev = next(t for t in self.keep[0] if t is not None).device
-                base, off = _tn_parts(sum(need), dev).data_ptr(), 0
-                for q, nf in zip(self.items, need):
-                    if nf:
-                        q.partials = base + 4 * off
-                        off += nf
+            assign_partials(self.items, next(t for t in self.keep[0] if t is not None).device)
             arr = (K.GemmTN * len(self.items))(*self.items)
             if K.prof.enabled:       # a grouped launch mixes scopes (qkv / proj with fc1 / fc2): the note carries the per-member flops and labels
                 fl = [2.0 * q.I * q.J * q.K for q in self.items]

@@ -32,6 +32,11 @@ def lavt_param_groups(model, text_encoder_layers: int = 10):
     return groups
 
 
+def ops_generation():
+    from . import ops
+    return ops.weights.generation
+
+
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params: Iterable, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, total_steps=0, power=0.9):
         if amsgrad:
@@ -62,7 +67,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 st["exp_avg"], st["exp_avg_sq"] = flat_m[off:off + n].view_as(p), flat_v[off:off + n].view_as(p)
                 off += n
         from . import ops
-        desc, hyper, missing, chunks, fused = [], [], [], [], []
+        desc, hyper, missing, chunks, fused = [], [], [], [], {}
         ce = int(K.lib.lavt_adamw_chunk_elems())
         for g, p in ps:
             if p.grad is None:
@@ -77,14 +82,15 @@ class FusedAdamW(torch.optim.Optimizer):
             copy = 0
             if ent is not None and ent[2]() is p and ent[1].numel() == p.numel() and ent[1].is_contiguous():
                 copy = ent[1].data_ptr()
-                fused.append(ck)
+                fused[ck] = copy
             for c in range(-(-p.numel() // ce)):
                 chunks.append([len(desc), c])
             desc.append([p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), copy])
             hyper.append([g["lr"], g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"]])
-        key = tuple(d[1] for d in desc) + tuple(tuple(h) for h in hyper) + (len(ops.weights.store),)
+        # (the copies' addresses are baked into the table: ops.weights.generation moves whenever one of them gets a new buffer)
+        key = tuple(d[1] for d in desc) + tuple(tuple(h) for h in hyper) + (ops.weights.generation,)
         self._tables = (key, torch.tensor(desc, dtype=torch.int64).to(dev), torch.tensor(hyper, dtype=torch.float32).to(dev), len(desc),
-                        torch.tensor(chunks, dtype=torch.int32).to(dev), len(chunks), frozenset(fused))
+                        torch.tensor(chunks, dtype=torch.int32).to(dev), len(chunks), dict(fused))
 
     def _current_key(self):
         out = []
@@ -95,7 +101,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     out.append(p.grad.data_ptr())
                     hy.append((g["lr"], g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"]))
         from . import ops
-        return tuple(out) + tuple(hy) + (len(ops.weights.store),)
+        return tuple(out) + tuple(hy) + (ops.weights.generation,)
 
     @torch.no_grad()
     def step(self, closure=None, check_tables=True):
@@ -105,6 +111,10 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._tables is None or (check_tables and self._tables[0] != self._current_key()):
             self._build()
         _, desc, hyper, n, chunks, nchunks, fused = self._tables
+        if not check_tables and self._tables[0][-1] != ops_generation():
+            # (captured steps skip the host-side scan, but a copy that moved since the table was built would be written at its OLD address)
+            raise RuntimeError("FusedAdamW.step(check_tables=False): a compute copy was re-allocated after the descriptor table was built; "
+                               "call step() once with check_tables=True (outside a capture) first")
         K.check(K.lib.lavt_adamw_step_chunks(K.ptr(desc), K.ptr(hyper), K.ptr(chunks), nchunks, K.ptr(self._step), self.total_steps, self.power, K.stream()))
         # The kernel writes the parameters through raw pointers: p._version does not move, so the cached compute copies (bf16 Linear weights,
         # packed conv weights) are stale now.  They are part of the optimizer's output (fp32 master weights + the compute-dtype copies the next

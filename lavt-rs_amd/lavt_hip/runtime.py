@@ -1,6 +1,7 @@
 """Process-wide switches of the HIP path (compute dtype)."""
 import contextlib
 import os
+import warnings
 
 import torch
 
@@ -22,19 +23,28 @@ def set_compute_dtype(dtype) -> None:
     _state["dtype"] = dtype
 
 
+_warned_fp16 = [False]
+
+
 def compute_dtype() -> torch.dtype:
-    """bf16 inside torch.autocast('cuda', dtype=bfloat16), else the configured dtype.  The reference's own AMP hook is
-    `torch.cuda.amp.autocast()` (train.py:452), i.e. float16: this path has no fp16 kernels (its low-precision type is bf16: same exponent range
-    as fp32, no loss scaling), so an fp16 autocast region is REFUSED rather than silently run in another precision -- use
-    torch.autocast('cuda', dtype=torch.bfloat16) or lavt_hip.set_compute_dtype (contract narrowings)."""
+    """bf16 inside torch.autocast('cuda', ...), else the configured dtype.  The reference's own AMP hook is `torch.cuda.amp.autocast()`
+    (train.py:452-459), i.e. float16 + GradScaler.  This path has no fp16 kernels -- its low-precision type is bf16 (fp32's exponent range) -- so an
+    fp16 autocast region runs the bf16 kernels, with ONE warning per process: `train_one_epoch_ytvos --use_amp` runs unchanged (the GradScaler's
+    loss scale passes through harmlessly: bf16 gradients cannot overflow where fp16 ones would, and `scaler.step` unscales the fp32 parameter
+    gradients as usual).  LAVT_STRICT_FP16_AUTOCAST=1 raises instead."""
     if torch.is_autocast_enabled():
         adt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
         if adt == torch.bfloat16:
             return torch.bfloat16
-        if adt == torch.float16 and os.environ.get("LAVT_ALLOW_FP16_AUTOCAST", "0") != "1":
-            raise RuntimeError("liblavt_hip: called inside torch.autocast(dtype=float16) (the reference's torch.cuda.amp.autocast(), train.py:452); this path "
-                               "computes in fp32 or bf16 only -- use torch.autocast('cuda', dtype=torch.bfloat16) or lavt_hip.set_compute_dtype('bf16') "
-                               "(LAVT_ALLOW_FP16_AUTOCAST=1 ignores the region and uses the configured dtype)")
+        if adt == torch.float16:
+            if os.environ.get("LAVT_STRICT_FP16_AUTOCAST", "0") == "1":
+                raise RuntimeError("liblavt_hip: called inside torch.autocast(dtype=float16) (the reference's torch.cuda.amp.autocast(), train.py:452) "
+                                   "with LAVT_STRICT_FP16_AUTOCAST=1; this path computes in fp32 or bf16 only")
+            if not _warned_fp16[0]:
+                _warned_fp16[0] = True
+                warnings.warn("liblavt_hip: torch.autocast(dtype=float16) region (train.py:452) -- this path has no fp16 kernels and computes the region in "
+                              "bfloat16 (fp32 accumulation; no loss scaling needed, a GradScaler is harmless)", RuntimeWarning, stacklevel=2)
+            return torch.bfloat16
     return _state["dtype"]
 
 

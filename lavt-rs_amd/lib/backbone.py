@@ -322,6 +322,14 @@ class MMBasicLayer(nn.Module):
             nn.init.zeros_(self.res_gate[2].weight)
         self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
 
+    def never_used_parameters(self):
+        """The last stage has no successor: its gated x is discarded and its gate never receives a gradient unless --hs returns the gated
+        features (reference lib/backbone.py:669-686; the reference needs find_unused_parameters=True for it, train.py:592).  Read by
+        lavt_hip.ddp.late_gradient_parameters."""
+        if self.downsample is None and self.version == "default" and not self.hs:
+            return list(self.res_gate.parameters())
+        return []
+
     def forward(self, x, H, W, l, l_mask):
         B, L, C = x.shape
         for blk in self.blocks:

@@ -257,6 +257,12 @@ class MMBasicLayer(nn.Module):
             nn.init.zeros_(self.res_gate[2].weight)
         self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
 
+    def never_used_parameters(self):
+        """the last stage's gate (when it exists) feeds only the discarded gated x: no gradient, see lib/backbone.py"""
+        if self.downsample is None and hasattr(self, "res_gate") and not self.hs:
+            return list(self.res_gate.parameters())
+        return []
+
     def rows(self, x, l, l_mask):
         """x (B, D, H, W, C) NDHWC -> (feature (B, D, H, W, C), next (B, D, H', W', C'))"""
         B, D, H, W, C = x.shape

@@ -249,9 +249,9 @@ class _FusedLinear(torch.autograd.Function):
     the sink (a view of GradBuckets.flat), the Function returns None for it, and -- for `defer` -- the write happens later, at the grouped launch."""
 
     @staticmethod
-    def forward(ctx, x, w, defer, queue):
+    def forward(ctx, x, w, defer, queue, log=None):
         ctx.save_for_backward(x, w)
-        ctx.defer, ctx.queue = defer, queue
+        ctx.defer, ctx.queue, ctx.log = defer, queue, log
         return x @ w.t()
 
     @staticmethod
@@ -260,14 +260,41 @@ class _FusedLinear(torch.autograd.Function):
         x, w = ctx.saved_tensors
         wbuf, is_sink = ops.sinks.buf(w, tuple(w.shape))
         assert is_sink
+        if ctx.log is not None:
+            ctx.log[0].append(("op", ctx.log[1]))
         if ctx.defer:
             ctx.queue.append((wbuf, dy.t() @ x))        # the grouped kernel does not exist yet: PyTorch will still fire w's hook right now
             ops.wgrads.notify(w)
             dw = None
+            if ctx.log is not None and len(ctx.queue) == 2:
+                ctx.log[2]()                            # the group is full: launch it from inside backward, as _WgradQueue.add does
         else:
             wbuf.copy_(dy.t() @ x)
             dw = ops.sinks.done(w, wbuf, True)
-        return dy @ w, dw, None, None
+        return dy @ w, dw, None, None, None
+
+
+class _DeferredAffine(torch.autograd.Function):
+    """What the LayerNorm ops do to gamma / beta under the step harness: the partial sums are parked, the parameters are `pending`
+    (lavt_hip.ops.ln_deferred.add) and ONE reduction at the end of backward writes the gradients and reports them."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, parked):
+        ctx.save_for_backward(x, g)
+        ctx.params, ctx.parked = (g, b), parked
+        return x * g + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        from lavt_hip import ops
+        x, g = ctx.saved_tensors
+        for prm, val in zip(ctx.params, ((dy * x).sum(0), dy.sum(0))):
+            buf, is_sink = ops.sinks.buf(prm, tuple(prm.shape))
+            assert is_sink
+            ctx.parked.append((buf, val))
+            ops.ln_deferred.params.append(prm)
+            ops.wgrads.pending.add(id(prm))
+        return dy * g, None, None, None
 
 
 def _fused_worker(rank, world, port, bucket_mib, out):
@@ -279,39 +306,74 @@ def _fused_worker(rank, world, port, bucket_mib, out):
     ws = nn.ParameterList([nn.Parameter(torch.randn(8, 8) * 0.3) for _ in range(6)])
     unused = nn.Parameter(torch.randn(8, 8))
     holder = nn.Module()
-    holder.ws, holder.unused = ws, unused
+    holder.ws0 = nn.ParameterList(list(ws[:3]))
+    holder.norm = nn.LayerNorm(8)                   # its gamma / beta stand for the deferred class: registered in the MIDDLE of the network
+    holder.unused = unused
+    holder.ws1 = nn.ParameterList(list(ws[3:]))
+    with torch.no_grad():
+        holder.norm.weight.add_(0.1 * torch.randn(8))
+        holder.norm.bias.add_(0.1 * torch.randn(8))
     gb = GradBuckets(holder, bucket_mib=bucket_mib, fused_accumulation=True)
+    assert gb.late_bucket is not None and gb.bucket_of[holder.norm.weight] == gb.late_bucket == gb.bucket_of[holder.norm.bias]
     xs = [torch.randn(5, 8, generator=torch.Generator().manual_seed(20 + r)) for r in range(world)]
+    events = []
+    orig_launch = gb._launch
+
+    def logged_launch(b):
+        events.append(("launch", b))
+        orig_launch(b)
+    gb._launch = logged_launch
     try:
         for step in range(2):
             gb.zero()
-            queue = []
-            h = xs[rank]
-            for i, w in enumerate(ws):
-                h = torch.tanh(_FusedLinear.apply(h, w, i % 2 == 1, queue))     # odd layers: weight gradient deferred to a grouped launch
-            loss = h.pow(2).mean()
-            flushed = []
+            del events[:]
+            queue, parked = [], []
 
             def flush():                         # the grouped launch: writes the queued gradients, THEN reports their parameters ready
                 for buf, val in queue:
                     buf.copy_(val)
-                flushed.append(len(queue))
                 queue.clear()
                 ops.wgrads.flush()
-            # backward with a flush every time two gradients are queued (the Swin block's grouped launch), and a final one
-            hooks = []
-            loss.backward()
-            flush()
+            h = xs[rank]
+            for i, w in enumerate(ws):
+                h = torch.tanh(_FusedLinear.apply(h, w, i % 2 == 1, queue, (events, i, flush)))     # odd layers: weight gradient deferred to a grouped launch
+                if i == 2:
+                    h = _DeferredAffine.apply(h, holder.norm.weight, holder.norm.bias, parked)
+            loss = h.pow(2).mean()
+            loss.backward()                      # the queue flushes itself inside backward whenever two gradients are queued (the Swin block's grouped launch)
+            flush()                              # TrainStep._body: ops.wgrads.flush() after backward
+            for buf, val in parked:              # the one deferred reduction launch (ops.ln_deferred.flush() inside finish() reports its parameters)
+                buf.copy_(val)
+            n_before_finish = len(events)
             gb.finish()
+            if step == 1:
+                # launch order against op order: every ordinary bucket was launched before finish(), and -- with one parameter per bucket -- the
+                # bucket of layer i's weight before the backward op of layer i-3 ran; only the late bucket (norm, unused) waits for finish()
+                launches = [(k, b) for k, (what, b) in enumerate(events) if what == "launch"]
+                in_finish = [b for k, b in launches if k >= n_before_finish]
+                assert in_finish == [gb.late_bucket], (in_finish, gb.late_bucket)
+                assert gb.bucket_of[unused] == gb.late_bucket
+                assert [w for _, _, w in gb.launch_log if w == "finish"] == ["finish"]
+                last_op = max(k for k, (what, i) in enumerate(events) if what == "op")
+                early = [b for k, b in launches if k < last_op]
+                if len(gb.buckets) > 3:          # tiny buckets: one per weight
+                    pos = {b: k for k, b in launches}
+                    opk = {i: k for k, (what, i) in enumerate(events) if what == "op"}
+                    for i in (5, 4, 3):          # (layer 5's gradient is queued until layer 3's joins it: its bucket goes out inside op 3)
+                        assert pos[gb.bucket_of[ws[i]]] < opk[i - 3], f"bucket of layer {i} not launched while backward was running"
+                    assert len(early) >= 4
         grads = []
         for r in range(world):
             ref = [w.detach().clone().requires_grad_(True) for w in ws]
+            gr, br = holder.norm.weight.detach().clone().requires_grad_(True), holder.norm.bias.detach().clone().requires_grad_(True)
             h = xs[r]
-            for w in ref:
+            for i, w in enumerate(ref):
                 h = torch.tanh(h @ w.t())
+                if i == 2:
+                    h = h * gr + br
             h.pow(2).mean().backward()
-            grads.append([w.grad for w in ref])
-        for i, w in enumerate(ws):
+            grads.append([w.grad for w in ref] + [gr.grad, br.grad])
+        for i, w in enumerate(list(ws) + [holder.norm.weight, holder.norm.bias]):
             want = sum(g[i] for g in grads) / world
             assert torch.allclose(w.grad, want, atol=1e-6), f"weight {i} (deferred: {i % 2 == 1})"
         assert float(unused.grad.abs().max()) == 0.0
@@ -319,14 +381,16 @@ def _fused_worker(rank, world, port, bucket_mib, out):
     finally:
         ops.sinks.clear()
         ops.wgrads.ready, ops.wgrads.pending = [], set()
+        ops.ln_deferred.params = []
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucket_mib", [64.0, 0.0003])
+@pytest.mark.parametrize("bucket_mib", [64.0, 0.0002])
 def test_fused_accumulation_buckets_world2(bucket_mib):
     """TrainStep's gradient protocol between two processes: gradients written into the flat buffer by the ops themselves (no AccumulateGrad),
-    half of them deferred to a later 'grouped launch' while PyTorch fires their hooks early, buckets all-reduced when complete, a parameter that
-    never gets a gradient -- and after finish() every .grad is the mean over the ranks."""
+    half of them deferred to a later 'grouped launch' while PyTorch fires their hooks early, LayerNorm-class gradients reduced by one deferred
+    launch at the end, a parameter that never gets a gradient -- buckets all-reduced when complete, the launch order recorded against the op
+    order (only the late bucket waits for finish()), and after finish() every .grad is the mean over the ranks."""
     port = _free_port()
     with mp.Manager() as mgr:
         out = mgr.dict()

@@ -690,6 +690,7 @@ def test_pwam_gate_fused_node(C, T, gate_live):
         ef = float((fus[k] - rv).norm()) / scale
         report[k] = (round(ec, 4), round(ef, 4))
         assert ef <= 1.5 * ec + 1e-2, (k, ec, ef, report)
+        assert ef <= 5e-2, (k, ef, report)          # absolute cap: 5 % of the tensor's norm (measured 0.8-3.4 % across the shapes)
     if not gate_live:
         for k in ("res_gate.0.weight", "res_gate.2.weight"):
             assert k not in fus or float(fus[k].abs().max()) == 0.0
@@ -744,8 +745,11 @@ def test_train_step_graph_sees_foreign_optimizer_updates():
 
 
 @pytest.mark.parametrize("feature", ["LAVT_WMSA_FUSED", "LAVT_LN_FOLD"])
-@pytest.mark.parametrize("C,ws,H,W,shifted", [(128, 12, 15, 15, 0), (128, 12, 15, 15, 1), (64, 7, 10, 9, 1), (512, 12, 30, 30, 1), (192, 7, 14, 14, 0), (384, 7, 7, 7, 1)])
-def test_wmsa_fused_forward_kernel(C, ws, H, W, shifted, feature):
+@pytest.mark.parametrize("C,ws,H,W,shifted,stats", [(128, 12, 15, 15, 0, "randn"), (128, 12, 15, 15, 1, "randn"), (64, 7, 10, 9, 1, "randn"), (512, 12, 30, 30, 1, "randn"),
+                                                    (192, 7, 14, 14, 0, "randn"), (384, 7, 7, 7, 1, "randn"), (1024, 12, 15, 15, 1, "randn"),
+                                                    (128, 12, 15, 15, 1, "mean10"), (128, 12, 15, 15, 1, "mean50"), (512, 12, 15, 15, 0, "mean50"),
+                                                    (128, 12, 15, 15, 1, "outlier"), (1024, 12, 15, 15, 0, "outlier")])
+def test_wmsa_fused_forward_kernel(C, ws, H, W, shifted, stats, feature):
     """The one-kernel W-MSA forward (csrc/wmsa_fused.hip: norm1 folded into the qkv contraction, padded / shifted windows through the row map,
     attention core on the LDS copies) inside a Swin block, against the fp32 CPU oracle of the reference block (lib/backbone.py:188-245), forward and
     every gradient; yardstick = the unfused bf16 path (LayerNorm kernel -> qkv GEMM -> attention kernel): fused error <= 1.5 x unfused + 1 %.
@@ -761,6 +765,17 @@ def test_wmsa_fused_forward_kernel(C, ws, H, W, shifted, feature):
     blk.to(DEV)
     blk.H, blk.W = H, W
     x0, wy = randn(21, B, H * W, C), randn(22, B, H * W, C)
+    # Row statistics of a trained Swin residual stream, not of randn: rows whose mean is 10 / 50 standard deviations away from zero (sign and size
+    # per row), or one channel 100 x larger than the rest.  Both LayerNorm folds take the variance as E[x^2] - mean^2 from fp32 dot2 sums and
+    # cancel `acc - mean * wsum` in the epilogue: these rows are where that form would lose its digits.  All three paths (oracle, unfused, fused)
+    # see the same bf16-rounded input, so what is compared is the arithmetic and not the rounding of the input.
+    if stats.startswith("mean"):
+        ratio = float(stats[4:])
+        x0 = x0 + ratio * (randn(23, B, H * W, 1).sign() * (0.5 + torch.rand(B, H * W, 1, generator=torch.Generator().manual_seed(24))))
+    elif stats == "outlier":
+        x0[..., 7] *= 100.0
+    if stats != "randn":
+        x0 = x0.to(torch.bfloat16).float()
     ps = {"blk." + k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
     xo = x0.clone().requires_grad_(True)
     y_ref = O.swin_block(ps, "blk", xo, H, W, nH, ws, shifted=bool(shifted))
@@ -794,8 +809,11 @@ def test_wmsa_fused_forward_kernel(C, ws, H, W, shifted, feature):
         ec, ef = float((comp[k] - rv).norm()) / scale, float((fus[k] - rv).norm()) / scale
         report[k] = (round(ec, 4), round(ef, 4))
         assert ef <= 1.5 * ec + 1e-2, (k, ec, ef, report)
+        # absolute cap next to the relative one (the unfused bf16 path is a yardstick, not a licence): 3 % of the tensor's norm; the residual
+        # output y = x + ... carries the offset itself, so its relative error is far below that
+        assert ef <= 3e-2, (k, ef, report)
     assert len(report) >= 14, report
-    print(f"\n[{feature}=1, relative l2 error vs the fp32 oracle: (feature off, feature on)]", report)
+    print(f"\n[{feature}=1 {stats} C={C}, relative l2 error vs the fp32 oracle: (feature off, feature on)]", report)
 
 
 def test_lavt_video_forward_feats_golden(golden):

@@ -88,10 +88,12 @@ def test_linear_plain(dtype, M, N, Kd):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("tile", ["128", "64"])
-def test_gemm_forced_tiles(dtype, tile, monkeypatch):
+def test_gemm_forced_tiles(dtype, tile, monkeypatch, request):
     """Both tile configurations of every GEMM family (NT k-contiguous, NT k-major, TN) and of the implicit-GEMM conv."""
-    from lavt_hip import ops
+    from lavt_hip import ops, _capi as K
     monkeypatch.setenv("LAVT_GEMM_TILE", tile)
+    K.lib.lavt_tuning_reload()             # the library reads its switches once per process; re-read after changing one
+    request.addfinalizer(lambda: (os.environ.pop("LAVT_GEMM_TILE", None), K.lib.lavt_tuning_reload()))
     M, N, Kd = 700, 328, 264
     inputs = {"x": (rnd(M, Kd, seed=1), "act"), "w": (rnd(N, Kd, seed=2, scale=Kd ** -0.5), "param"), "b": (rnd(N, seed=3), "param")}
     run_pair(lambda x, w, b: ops.linear(x, w, b), lambda x, w, b: F.linear(x, w, b), inputs, dtype, name=f"linear tile {tile}")
@@ -582,7 +584,7 @@ def test_gemm_tn_grouped_matches_individual():
         assert float((cr - co).abs().max()) <= 2e-3 * float(cr.abs().max())
 
 
-@pytest.mark.parametrize("B,H,ws,shift,Cc", [(2, 30, 12, 6, 512), (2, 15, 12, 0, 1024), (3, 10, 7, 3, 256)])
+@pytest.mark.parametrize("B,H,ws,shift,Cc", [(2, 30, 12, 6, 512), (2, 15, 12, 0, 1024), (3, 10, 7, 3, 256), (8, 30, 12, 6, 512)])
 def test_gemm_tn_token_order_matches_window_order(B, H, ws, shift, Cc):
     """The windowed members of a Swin block's grouped weight-gradient launch in TOKEN order (contraction over the real tokens through the inverse
     window map; the padded window rows -- zero input rows whose dq / dk / dv still count for the qkv bias gradient -- summed by a column-sum-only
@@ -617,6 +619,9 @@ def test_gemm_tn_token_order_matches_window_order(B, H, ws, shift, Cc):
     ops.gemm_tn(bf, 3 * Cc, 8, pad.numel(), dqkv, 3 * Cc, ops._zero_page_tensor(dev()), 0, dummy, 8, a_rowmap=pad, colsum=tb_qkv, colsum_atomic=True, defer=_Q(), extra=True)
     ops.gemm_tn(bf, 3 * Cc, Cc, T, dqkv, 3 * Cc, xn, Cc, t_qkv, Cc, a_rowmap=inv, colsum=tb_qkv, colsum_atomic=True, defer=_Q())
     assert len(structs) == 5
+    if B == 8:          # the reference's default batch per GPU: 3168 padded rows and 7200 tokens -- BOTH members that add into the qkv bias gradient are
+        assert pad.numel() >= 3136 and structs[3].partials and structs[4].partials      # cut into pieces through partial tiles (their sums met in a plain += of one launch)
+    ops.assign_partials(structs, dev())
     arr = (K.GemmTN * len(structs))(*structs)
     K.check(K.lib.lavt_gemm_tn_grouped(arr, len(structs), K.stream()))
     torch.cuda.synchronize()
@@ -902,12 +907,33 @@ def test_fp8_linear_matches_quantised_oracle(monkeypatch):
     assert float((xd.grad.float().cpu() - w.sum(0).to(torch.bfloat16).float()).abs().max()) <= 3e-2 * float(w.sum(0).abs().max())
 
 
-def test_fp16_autocast_is_refused():
-    """The reference's AMP hook is torch.cuda.amp.autocast() = float16 (train.py:452).  This path computes in fp32 / bf16 only: an fp16 autocast region
-    raises instead of silently running the configured dtype (contract narrowings); a bf16 region selects bf16."""
-    from lavt_hip.runtime import compute_dtype
+def test_fp16_autocast_runs_as_bf16(monkeypatch):
+    """The reference's AMP hook is torch.cuda.amp.autocast() = float16 + GradScaler (train.py:452-459).  This path has no fp16 kernels: an fp16
+    autocast region computes in bf16 with one warning per process, so `--use_amp` runs unchanged -- forward, scaled backward, unscale; a bf16
+    region selects bf16 silently; LAVT_STRICT_FP16_AUTOCAST=1 raises."""
+    import warnings
+    from lavt_hip import ops, runtime
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        assert compute_dtype() == torch.bfloat16
+        assert runtime.compute_dtype() == torch.bfloat16
+    runtime._warned_fp16[0] = False
+    x, w, b = rnd(96, 64, seed=1), rnd(48, 64, seed=2, scale=0.125), rnd(48, seed=3)
+    wd, bd = w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        with torch.autocast("cuda", dtype=torch.float16):
+            assert runtime.compute_dtype() == torch.bfloat16
+            y = ops.linear(x.to(dev()), wd, bd)
+            assert runtime.compute_dtype() == torch.bfloat16
+        assert len([r for r in rec if "float16" in str(r.message)]) == 1
+    assert y.dtype == torch.bfloat16
+    loss = y.float().pow(2).mean()
+    scaler.scale(loss).backward()
+    opt = torch.optim.SGD([wd, bd], lr=0.0)
+    scaler.unscale_(opt)
+    ref_w = torch.autograd.grad(F.linear(x, w.requires_grad_(True), b).pow(2).mean(), w)[0]
+    assert float((wd.grad.cpu() - ref_w).abs().max()) <= 3e-2 * float(ref_w.abs().max())
+    monkeypatch.setenv("LAVT_STRICT_FP16_AUTOCAST", "1")
     with torch.autocast("cuda", dtype=torch.float16):
         with pytest.raises(RuntimeError, match="float16"):
-            compute_dtype()
+            runtime.compute_dtype()

@@ -281,6 +281,66 @@ def test_grad_buckets_ignore_hooks_of_queued_weight_gradients():
         ops.wgrads.ready, ops.wgrads.pending = [], set()
 
 
+def test_grad_buckets_overlap_on_swin_b():
+    """the parameters whose gradient exists only after backward (LayerNorm gamma / beta, relative_position_bias_table: one
+    deferred reduction launch; layers.3.res_gate.*: never used) sit in ONE late bucket, so >= 95 % of the gradient bytes of Swin-B LAVT are in
+    buckets that complete -- and are all-reduced -- while backward is still running.  Round 3 had 393 of 475 MB gated by 1 MB of such parameters."""
+    from lib import segmentation
+    from lavt_hip.ddp import GradBuckets, late_gradient_parameters
+    model = segmentation.lavt("", SimpleNamespace(swin_type="base", window12=True))
+    names = {id(p): n for n, p in model.named_parameters()}
+    gb = GradBuckets(model, bucket_mib=32.0)
+    late = {names[id(p)] for p in late_gradient_parameters(model)}
+    assert "backbone.layers.3.res_gate.0.weight" in late and "backbone.layers.3.res_gate.2.weight" in late
+    assert "backbone.layers.2.blocks.7.norm1.weight" in late and "backbone.layers.2.blocks.7.attn.relative_position_bias_table" in late
+    assert "backbone.norm3.bias" in late and "backbone.layers.0.downsample.norm.weight" in late
+    assert not any("qkv" in n or "fc1" in n or "classifier" in n or n.endswith("res_gate.0.weight") and "layers.3" not in n for n in late)
+    deferred = [p for p in model.parameters() if names[id(p)] in late]
+    # every late parameter is in the last bucket and no ordinary bucket holds one
+    assert gb.late_bucket == len(gb.buckets) - 1
+    assert all(gb.bucket_of[p] == gb.late_bucket for p in deferred)
+    assert all(gb.bucket_of[p] != gb.late_bucket for p in model.parameters() if names[id(p)] not in late)
+    clean = gb.overlappable_bytes()
+    assert clean == sum(4 * (e - s) for b, (s, e) in enumerate(gb.buckets) if not any(gb.bucket_of[p] == b for p in deferred))
+    assert clean >= 0.95 * gb.bytes_per_step(), (clean, gb.bytes_per_step())
+    s, e = gb.buckets[gb.late_bucket]
+    assert 4 * (e - s) < 12 << 20                       # 1.03 MB of norm / table parameters + the dead 2 x 1024 x 1024 gate
+    # the views tile the flat buffer exactly once, in bucket order
+    spans = sorted((gb.offset_of[id(p)], p.numel()) for p in model.parameters())
+    off = 0
+    for o, n in spans:
+        assert o == off
+        off += n
+    assert off == gb.flat.numel()
+    for p in model.parameters():
+        assert p.grad.data_ptr() == gb.flat.data_ptr() + 4 * gb.offset_of[id(p)]
+
+
+def test_grad_buckets_learn_unreported_parameters():
+    """A parameter nothing reports during the first backward (unused in forward, unknown to late_gradient_parameters) is moved to the late
+    bucket at the next zero(): from the second step on no ordinary bucket waits for finish()."""
+    from lavt_hip.ddp import GradBuckets
+    net = torch.nn.Sequential(*[torch.nn.Linear(8, 8, bias=False) for _ in range(4)])
+    ps = list(net.parameters())
+    gb = GradBuckets(net, bucket_mib=2 * 64 * 4 / (1 << 20))          # two weights per bucket
+    assert len(gb.buckets) == 2 and gb.late_bucket is None
+    dead = ps[2]
+    for step in range(3):
+        gb.zero()
+        for p in reversed(ps):
+            if p is not dead:
+                gb._on_grad(p)
+        before = [l for l in gb.launch_log]
+        gb.finish()
+        if step == 0:
+            assert [b for b, _, _ in before] == [1] and gb.launch_log[-1][2] == "finish"       # bucket 0 = {ps[3], ps[2]} waited for finish()
+        else:
+            assert gb.late_bucket == 2 and gb.bucket_of[dead] == 2
+            assert sorted(b for b, _, w in before if w == "backward") == [0, 1]                 # both ordinary buckets complete during backward
+            assert [(b, w) for b, _, w in gb.launch_log[len(before):]] == [(2, "finish")]
+        assert all(gb.launched)
+
+
 def test_syncbn_rank_statistics_combination():
     """SyncBN forward: the ranks' (sum, centred M2) pairs, gathered with ONE collective, combine to the statistics of the whole batch --
     also when the channel means are large compared with the spread (no E[x^2] - E[x]^2 cancellation)"""
