@@ -465,7 +465,7 @@ def main():
                        "mfma_frac_of_step": round(train_tflops / world / BF16_DENSE_PEAK_TFLOPS, 4),
                        "timed_repetitions": len(reps_all), "ms_per_step_all_repetitions": [round(e / a.steps * 1e3, 3) for e in reps_all]},
         }
-        if world > 1:
+        if world > 1 or force:
             out["config"]["rccl"] = {"max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"), "bf16_buckets": bool(step.buckets.bf16), "ddp_mode": step.buckets.mode,
                                      "gradient_bytes_per_step": step.buckets.bytes_per_step() // (2 if step.buckets.bf16 else 1),
                                      "buckets": len(step.buckets.buckets), "overlappable_bytes": step.buckets.overlappable_bytes() // (2 if step.buckets.bf16 else 1),

@@ -350,7 +350,7 @@ template <typename T> __global__ __launch_bounds__(256) void cls_head_fwd_kernel
         if (lane == 0) { y[row * 2] = from_f<T>(a0 + bias[0]); y[row * 2 + 1] = from_f<T>(a1 + bias[1]); }
     }
 }
-template <typename T> __global__ __launch_bounds__(256) void cls_head_bwd_kernel(const T* x, const T* dy, const float* w, T* dx, float* dw, float* db, int64_t rows, int C) {
+template <typename T> __global__ __launch_bounds__(256) void cls_head_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, float* dw, float* db, int64_t rows, int C) {
     // thread owns one chunk column for a strip of rows: dx = dy0*w0 + dy1*w1 ; dw[c] += dy[c]*x ; db += dy
     constexpr int EPC = Chunk<T>::N;
     const int cpr = C / EPC;
@@ -360,14 +360,32 @@ template <typename T> __global__ __launch_bounds__(256) void cls_head_bwd_kernel
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { w0[e] = w[tc * EPC + e]; w1[e] = w[C + tc * EPC + e]; g0[e] = 0.f; g1[e] = 0.f; }
     float b0 = 0.f, b1 = 0.f;
-    for (int64_t row = (int64_t)blockIdx.x * rstep + tr; live && row < rows; row += (int64_t)gridDim.x * rstep) {
-        const float d0 = to_f<T>(dy[row * 2]), d1 = to_f<T>(dy[row * 2 + 1]);
-        float f[EPC], o[EPC];
-        chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + row * C + tc * EPC), f);
+    // four rows per trip, every load of the trip issued before the first use (one row per trip was a chain of ~14 dependent L2 / HBM round trips per
+    // thread: 40 us for the 2 x 120 x 120 x 512 map where the bytes take ~12)
+    const int64_t rs = (int64_t)gridDim.x * rstep;
+    for (int64_t row = (int64_t)blockIdx.x * rstep + tr; live && row < rows; row += 4 * rs) {
+        uint4 xv[4];
+        float d0[4], d1[4];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { o[e] = d0 * w0[e] + d1 * w1[e]; g0[e] += d0 * f[e]; g1[e] += d1 * f[e]; }
-        *reinterpret_cast<uint4*>(dx + row * C + tc * EPC) = f_to_chunk<T>(o);
-        if (tc == 0) { b0 += d0; b1 += d1; }
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = row + u * rs;
+            const bool ok = r < rows;
+            const int64_t rr = ok ? r : row;
+            xv[u] = *reinterpret_cast<const uint4*>(x + rr * C + tc * EPC);
+            d0[u] = ok ? to_f<T>(dy[rr * 2]) : 0.f;
+            d1[u] = ok ? to_f<T>(dy[rr * 2 + 1]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = row + u * rs;
+            if (r >= rows) break;
+            float f[EPC], o[EPC];
+            chunk_to_f<T>(xv[u], f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { o[e] = d0[u] * w0[e] + d1[u] * w1[e]; g0[e] += d0[u] * f[e]; g1[e] += d1[u] * f[e]; }
+            *reinterpret_cast<uint4*>(dx + r * C + tc * EPC) = f_to_chunk<T>(o);
+            if (tc == 0) { b0 += d0[u]; b1 += d1[u]; }
+        }
     }
     // combine the row-lanes of the workgroup in LDS first: 2*C (+2) atomics per workgroup instead of per row-lane
     __shared__ float red[2 * 2048 + 2];

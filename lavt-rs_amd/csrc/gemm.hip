@@ -489,6 +489,22 @@ extern "C" int lavt_gemm_tn_pieces(const lavt_gemm_tn_t* p) {
 int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st);
 // n independent weight-gradient problems issued together: one grouped launch without split-K when they qualify (bf16, plain / row-mapped
 // operands, >= 256 output tiles in total), else one lavt_gemm_tn call each.  Results are identical either way up to fp32 summation order.
+int64_t lavt_gemm_tn_grouped_sk_ws_v2(const lavt_gemm_tn_t* probs, int n);
+int lavt_gemm_tn_grouped_sk_v2(const lavt_gemm_tn_t* probs, int n, float* scratch, int64_t scratch_floats, hipStream_t st);
+// The stream-K form of the same launch (csrc/gemm_tn_v2.hip): 128x128 tiles, the K-tile iterations of all members dealt in equal runs to persistent
+// workgroups, split tiles through `scratch`.  _ws: floats of scratch the group wants, 0 = the group does not qualify (use lavt_gemm_tn_grouped).
+extern "C" int64_t lavt_gemm_tn_grouped_sk_ws(const lavt_gemm_tn_t* probs, int n) {
+    if (probs == nullptr || n < 1) return 0;
+    for (int i = 0; i < n; ++i)
+        if (!(probs[i].A && probs[i].B && probs[i].C && probs[i].I > 0 && probs[i].J > 0 && probs[i].K > 0)) return 0;
+    return lavt_gemm_tn_grouped_sk_ws_v2(probs, n);
+}
+extern "C" int lavt_gemm_tn_grouped_sk(const lavt_gemm_tn_t* probs, int n, float* scratch, int64_t scratch_floats, void* stream) {
+    LAVT_CHECK_ARG(probs != nullptr && n >= 1 && scratch != nullptr, "lavt_gemm_tn_grouped_sk: bad arguments");
+    const int rc = lavt_gemm_tn_grouped_sk_v2(probs, n, scratch, scratch_floats, reinterpret_cast<hipStream_t>(stream));
+    LAVT_CHECK_ARG(rc != 1, "lavt_gemm_tn_grouped_sk: the group does not qualify or the scratch is too small (ask lavt_gemm_tn_grouped_sk_ws first)");
+    return rc;
+}
 extern "C" int lavt_gemm_tn_grouped(const lavt_gemm_tn_t* probs, int n, void* stream) {
     LAVT_CHECK_ARG(probs != nullptr && n >= 1, "lavt_gemm_tn_grouped: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

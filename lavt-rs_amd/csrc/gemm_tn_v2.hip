@@ -22,9 +22,16 @@ __device__ __forceinline__ void dma4(const void* src, void* lds_dst) {
 // CS: how the bias gradient (colsum) is produced -- 0 none, 1 scalar walk of the LDS tile by the first BI threads, 2 on the matrix cores
 // CONVP: the problem may be a convolution weight gradient (tap-shifted B rows); the grouped launch never is, and without the tap state (per-DMA
 // coordinates, wrap tests behind uniform branches) its map-free K loop is shorter
+// where a tile's result goes: C[ii * ldc + col] / colsum[ii] with absolute (ii, col); `atomic` adds (split reductions meeting in C, accumulate),
+// else plain stores.  A tile-local scratch slot is expressed through the pointers (slot - i0 * BJ - j0 with ldc = BJ).
+struct TnOut {
+    float* C;
+    int64_t ldc;
+    float* colsum;
+    bool atomic, colsum_atomic;
+};
 template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS, bool CONVP = true>
-__device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_linear, const int bz, const int split_idx, const int kt_per_split,
-                                        const int nsplit, char* smem) {
+__device__ __forceinline__ void tn_tile_range(const lavt_gemm_tn_t& p, const int tile_linear, const int bz, const int kt_begin, const int kt_end, const TnOut o, char* smem) {
     using T = bf16;
     constexpr int BK = 64, EPC = 8;
     constexpr int WAVES_I = 2, WAVES_J = WAVES / WAVES_I;
@@ -48,8 +55,6 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
     const int tiles_j = (p.J + BJ - 1) / BJ;
     const int tile_i = tile_linear / tiles_j, tile_j = tile_linear % tiles_j;
     const int i0 = tile_i * BI, j0 = tile_j * BJ;
-    const int ktiles = (p.K + BK - 1) / BK;
-    const int kt_begin = split_idx * kt_per_split, kt_end = min(ktiles, kt_begin + kt_per_split);
     if (kt_begin >= kt_end) return;
     const int n = kt_end - kt_begin;
 
@@ -304,14 +309,10 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
         for (int j = 0; j < n; ++j) k_tile(j, std::integral_constant<int, -1>{});
     }
 
-    // split reduction with a partials buffer: this piece's tile goes to partials[piece][I][J] as plain stores (tn_reduce_pieces adds the pieces
-    // into C afterwards); otherwise pieces meet in C through atomics
-    const bool to_parts = p.partials != nullptr && nsplit > 1;
-    float* const pbase = to_parts ? p.partials + (int64_t)bz * nsplit * ((int64_t)p.I * p.J + p.I) : nullptr;      // one [pieces][I][J] + [pieces][I] block per batch entry
-    float* C = to_parts ? pbase + (int64_t)split_idx * p.I * p.J : p.C + (int64_t)bz * p.strideC;
-    const int64_t ldc_out = to_parts ? p.J : p.ldc;
-    float* colsum_out = to_parts ? pbase + (int64_t)nsplit * p.I * p.J + (int64_t)split_idx * p.I : (p.colsum ? p.colsum + (int64_t)bz * p.strideColsum : nullptr);
-    const bool atomic = !to_parts && (nsplit > 1 || p.accumulate);
+    float* const C = o.C;
+    const int64_t ldc_out = o.ldc;
+    float* const colsum_out = o.colsum;
+    const bool atomic = o.atomic;
 #pragma unroll
     for (int i = 0; i < II; ++i) {
 #pragma unroll
@@ -332,7 +333,7 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
     if constexpr (CS == 1) {
         if (do_colsum && i0 + tid < p.I) {
             float* cs = colsum_out + i0 + tid;
-            if (atomic || (p.colsum_atomic && !to_parts)) atomicAdd(cs, csum * p.alpha); else *cs = csum * p.alpha;
+            if (atomic || o.colsum_atomic) atomicAdd(cs, csum * p.alpha); else *cs = csum * p.alpha;
         }
     }
     if (CS == 2 && cs_wave && (lane & 15) == 0) {          // every column of cacc holds the same sums: lanes of column 0 write rows 4 (lane / 16) + r
@@ -343,9 +344,27 @@ __device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_
                 const int ii = i0 + wi * WI + i * 16 + 4 * (lane >> 4) + r;
                 if (ii >= p.I) continue;
                 float* cs = colsum_out + ii;
-                if (atomic || (p.colsum_atomic && !to_parts)) atomicAdd(cs, cacc[i][r] * p.alpha); else *cs = cacc[i][r] * p.alpha;      // one tile_j == 0 workgroup per I tile when the reduction is not split
+                if (atomic || o.colsum_atomic) atomicAdd(cs, cacc[i][r] * p.alpha); else *cs = cacc[i][r] * p.alpha;      // one tile_j == 0 workgroup per I tile when the reduction is not split
             }
     }
+}
+
+// one K piece of a tile, the pieces of a tile meeting in C through atomics or -- with a partials buffer -- stored as plain tiles partials[piece][I][J]
+// (+ [piece][I] column sums) that tn_reduce_pieces adds into C afterwards
+template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS, bool CONVP = true>
+__device__ __forceinline__ void tn_tile(const lavt_gemm_tn_t& p, const int tile_linear, const int bz, const int split_idx, const int kt_per_split,
+                                        const int nsplit, char* smem) {
+    const int ktiles = (p.K + 63) / 64;
+    const int kt_begin = split_idx * kt_per_split, kt_end = min(ktiles, kt_begin + kt_per_split);
+    const bool to_parts = p.partials != nullptr && nsplit > 1;
+    float* const pbase = to_parts ? p.partials + (int64_t)bz * nsplit * ((int64_t)p.I * p.J + p.I) : nullptr;      // one [pieces][I][J] + [pieces][I] block per batch entry
+    TnOut o;
+    o.C = to_parts ? pbase + (int64_t)split_idx * p.I * p.J : p.C + (int64_t)bz * p.strideC;
+    o.ldc = to_parts ? p.J : p.ldc;
+    o.colsum = to_parts ? pbase + (int64_t)nsplit * p.I * p.J + (int64_t)split_idx * p.I : (p.colsum ? p.colsum + (int64_t)bz * p.strideColsum : nullptr);
+    o.atomic = !to_parts && (nsplit > 1 || p.accumulate);
+    o.colsum_atomic = p.colsum_atomic && !to_parts;
+    tn_tile_range<BI, BJ, WAVES, STAGES, MAPS, CS, CONVP>(p, tile_linear, bz, kt_begin, kt_end, o, smem);
 }
 
 template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS, bool CONVP = true>
@@ -364,8 +383,9 @@ struct TnGroup {
     int split[TN_GROUP_MAX];         // K splits of problem k (1 = single writer per output element, plain stores)
     int n;
 };
+// (128x128 / 8 waves: capped at 128 registers -- second __launch_bounds__ value = waves per SIMD -- so that two workgroups share a CU)
 template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS>
-__global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_grouped_kernel(const TnGroup g) {
+__global__ __launch_bounds__(WAVES * 64, (BI == 128 && WAVES == 8) ? 4 : 1) void gemm_tn_v2_grouped_kernel(const TnGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int k = 0;
     while (k + 1 < g.n && (int)blockIdx.x >= g.tile_end[k]) ++k;
@@ -382,6 +402,88 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tn_v2_grouped_kernel(const Tn
         }
     }
     tn_tile<BI, BJ, WAVES, STAGES, MAPS, CS, false>(p, local / ns, 0, local % ns, (ktiles + ns - 1) / ns, ns, smem);
+}
+
+// ---- stream-K form of the grouped launch (round 4) ------------------------------------------------------------------------------------
+// The 64x64-tile launch is bound by what a CU can ingest: 792 workgroups x 29 K tiles x 16 KB = 367 MB of L2 -> LDS fill for the stage-2 Swin block
+// (9.7 TB/s over its 38 us; round-3 review).  128x128 tiles halve the bytes per flop but give 192 tiles for 256 CUs, each a serial chain of 29 K
+// tiles (measured 40 us).  Here the (member, tile, K tile) iterations form ONE list that `nw` persistent workgroups cut into equal runs: every
+// workgroup moves the same number of bytes.  A run that covers a tile's whole K range stores it directly; a run that starts or ends inside a
+// tile stores a partial tile into its own scratch slot ([nw][2] slots: a run has at most one partial head and one partial tail) and
+// tn_streamk_fixup adds the partials of a split tile in a fixed order (no atomics: run-to-run identical).
+struct TnSk {
+    int it_end[TN_GROUP_MAX];        // running count of K-tile iterations up to and including member k
+    int kt[TN_GROUP_MAX];            // K tiles of member k
+    int tiles_end[TN_GROUP_MAX];     // running count of output tiles
+    int total, nw;
+    float* slots;                    // [nw][2][BI * BJ + BI]
+};
+template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS>
+__global__ __launch_bounds__(WAVES * 64, (BI == 128 && WAVES == 8) ? 4 : 1) void gemm_tn_v2_streamk_kernel(const TnGroup g, const TnSk sk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = blockIdx.x;
+    const int lo = (int)((int64_t)w * sk.total / sk.nw), hi = (int)((int64_t)(w + 1) * sk.total / sk.nw);
+    int seg = 0;
+    for (int it = lo; it < hi; ++seg) {
+        int m = 0;
+        while (m + 1 < g.n && it >= sk.it_end[m]) ++m;
+        const int ktm = sk.kt[m], local = it - (m ? sk.it_end[m - 1] : 0);
+        const int tile = local / ktm, kb = local - tile * ktm, ke = min(ktm, kb + (hi - it));
+        const lavt_gemm_tn_t& p = g.p[m];
+        TnOut o;
+        if (kb == 0 && ke == ktm) {
+            o.C = p.C; o.ldc = p.ldc; o.colsum = p.colsum; o.atomic = p.accumulate != 0; o.colsum_atomic = p.colsum_atomic != 0;
+        } else {
+            const int tiles_j = (p.J + BJ - 1) / BJ, i0 = (tile / tiles_j) * BI, j0 = (tile % tiles_j) * BJ;
+            float* slot = sk.slots + ((int64_t)w * 2 + (seg ? 1 : 0)) * (BI * BJ + BI);
+            o.C = slot - (int64_t)i0 * BJ - j0; o.ldc = BJ; o.colsum = slot + BI * BJ - i0; o.atomic = false; o.colsum_atomic = false;
+        }
+        if (seg) __syncthreads();                                  // the previous run's last fragment reads are done before the ring is refilled
+        bool done = false;
+        if constexpr (MAPS) {
+            if (!(p.a_rowmap || p.a_rowscale || p.b_rowmap)) { tn_tile_range<BI, BJ, WAVES, STAGES, false, CS, false>(p, tile, 0, kb, ke, o, smem); done = true; }
+        }
+        if (!done) tn_tile_range<BI, BJ, WAVES, STAGES, MAPS, CS, false>(p, tile, 0, kb, ke, o, smem);
+        it += ke - kb;
+    }
+}
+// C tile (+)= the partial tiles of its runs, in run order.  blockIdx.x = output tile over all members, blockIdx.y = quarter of the tile.
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void tn_streamk_fixup(const TnGroup g, const TnSk sk) {
+    int m = 0;
+    while (m + 1 < g.n && (int)blockIdx.x >= sk.tiles_end[m]) ++m;
+    const lavt_gemm_tn_t& p = g.p[m];
+    const int tile = blockIdx.x - (m ? sk.tiles_end[m - 1] : 0), ktm = sk.kt[m];
+    const int it0 = (m ? sk.it_end[m - 1] : 0) + tile * ktm, it1 = it0 + ktm;
+    auto lo_of = [&](int w) { return (int)((int64_t)w * sk.total / sk.nw); };
+    int w0 = (int)((int64_t)it0 * sk.nw / sk.total);
+    while (w0 + 1 < sk.nw && lo_of(w0 + 1) <= it0) ++w0;
+    while (w0 > 0 && lo_of(w0) > it0) --w0;
+    int w1 = w0;
+    while (w1 + 1 < sk.nw && lo_of(w1 + 1) < it1) ++w1;
+    if (w0 == w1) return;                                          // one run covers the tile's whole K range: stored directly
+    const int tiles_j = (p.J + BJ - 1) / BJ, i0 = (tile / tiles_j) * BI, j0 = (tile % tiles_j) * BJ;
+    constexpr int SLOT = BI * BJ + BI, QUARTER = BI * BJ / 4;
+    for (int e = blockIdx.y * QUARTER + threadIdx.x; e < (blockIdx.y + 1) * QUARTER; e += 256) {
+        const int i = e / BJ, j = e - i * BJ;
+        if (i0 + i >= p.I || j0 + j >= p.J) continue;
+        float s = 0.f;
+        for (int w = w0; w <= w1; ++w) {
+            const int l = lo_of(w);
+            s += sk.slots[((int64_t)w * 2 + ((l >= it0 && l < it1) ? 0 : 1)) * SLOT + e];
+        }
+        float* dst = p.C + (int64_t)(i0 + i) * p.ldc + j0 + j;
+        if (p.accumulate) *dst += s; else *dst = s;
+    }
+    if (blockIdx.y == 0 && p.colsum != nullptr && j0 == 0 && threadIdx.x < BI && i0 + threadIdx.x < p.I) {
+        float s = 0.f;
+        for (int w = w0; w <= w1; ++w) {
+            const int l = lo_of(w);
+            s += sk.slots[((int64_t)w * 2 + ((l >= it0 && l < it1) ? 0 : 1)) * SLOT + BI * BJ + threadIdx.x];
+        }
+        float* dst = p.colsum + i0 + threadIdx.x;
+        if (p.colsum_atomic) atomicAdd(dst, s); else if (p.accumulate) *dst += s; else *dst = s;
+    }
 }
 
 // second stage of a split reduction through partial tiles: C[i][j] += sum_s parts[s][i][J + j], colsum[i] += sum_s parts[nsplit*I*J + s*I + i].
@@ -510,6 +612,8 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         for (int i = 0; i < n; ++i) t128 += (long)cdiv(probs[i].I, 128) * cdiv(probs[i].J, 128);
         if (TB == 128 && t128 < 128) TB = 64;
     }
+    // rectangular tiles (LAVT_TNG_CFG tile codes 6412 = 64 x 128, 12864 = 128 x 64; 4 waves, 2 stages): 24 KB per K tile for 1.05 MFLOP
+    const int TBI = TB == 6412 ? 64 : (TB == 12864 ? 128 : TB), TBJ = TB == 6412 ? 128 : (TB == 12864 ? 64 : TB);
     bool any_colsum = false;
     // Pieces per member.  A member with a partials scratch (lavt_gemm_tn_t.partials: its pieces are stored as plain tiles and added into C by one
     // small second kernel) may be cut as finely as its K allows -- the long-K weight gradients of PWAM (K = 28 800 rows = 450 K tiles on 4
@@ -519,6 +623,11 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     const int chain = tun.tng_chain, piece_tiles = tun.tng_piece;
     bool any_parts = false;
     int64_t max_total = 0;
+    // ... and only where cutting pays: a group whose uncut 64x64 tiles already give every CU two workgroups (>= 512: the Swin-block launch at
+    // 4 images per GPU, K = 3600 = 57 K tiles) runs faster uncut -- 64.9 vs 88.4 us (tools/wgrad_sk_time.py) -- unless a chain exceeds 128 K tiles
+    long uncut = 0;
+    for (int i = 0; i < n; ++i) uncut += (long)cdiv(probs[i].I, TBI) * cdiv(probs[i].J, TBJ);
+    const bool cut_pays = uncut < 512;
     for (int per_piece = piece_tiles; ; per_piece *= 2) {
         tiles = 0; maps = false; any_colsum = false; any_parts = false; max_total = 0;
         for (int i = 0; i < n; ++i) {
@@ -530,7 +639,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
             g.p[i] = p;
             int ns = 1;
             const int want = cdiv(ktiles, per_piece);
-            const bool parts = p.partials != nullptr && !p.c_conv_permute && ktiles > chain && want > 1 &&
+            const bool parts = p.partials != nullptr && !p.c_conv_permute && ktiles > chain && (cut_pays || ktiles > 128) && want > 1 &&
                                p.partials_floats >= (int64_t)want * ((int64_t)p.I * p.J + p.I);
             if (parts) ns = want;
             else {
@@ -544,28 +653,29 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
             if (parts && ns > 1) { any_parts = true; max_total = max_total > (int64_t)p.I * p.J + p.I ? max_total : (int64_t)p.I * p.J + p.I; }
             if (ns <= 1) g.p[i].partials = nullptr;
             g.split[i] = ns;
-            tiles += cdiv(p.I, TB) * cdiv(p.J, TB) * ns;
+            tiles += cdiv(p.I, TBI) * cdiv(p.J, TBJ) * ns;
             g.tile_end[i] = tiles;
         }
         if (tiles <= 2048 || !any_parts || per_piece >= 64) break;      // too many workgroups: longer pieces
     }
     for (int i = n; i < TN_GROUP_MAX; ++i) { g.p[i] = probs[0]; g.p[i].partials = nullptr; g.tile_end[i] = tiles; g.split[i] = 1; }
     g.n = n;
-    if (tiles < (TB == 128 ? 128 : 256)) return 1;   // too few workgroups to fill the chip
+    if (tiles < (TB == 64 ? 256 : 128)) return 1;   // too few workgroups to fill the chip
     // (round 2: an XCD-contiguous tile order inside each member -- it cuts the 152 MB of fabric traffic -- and a 3-stage ring were both measured
     // on the step: 10.63 vs 10.64 ms and 10.81 vs 10.62 ms; neither is kept)
-    if (TB == 128 || cfg_waves != 4 || cfg_stages != 2) {
-#define TNG_GO(BT_, WV_, SG_)                                                                                                                          \
+    if (TB != 64 || cfg_waves != 4 || cfg_stages != 2) {
+#define TNG_GO(BT_, WV_, SG_) TNG_GO2(BT_, BT_, WV_, SG_)
+#define TNG_GO2(BT_, BU_, WV_, SG_)                                                                                                                          \
     do {                                                                                                                                               \
-        const size_t l = SG_ * (size_t)(64 * (BT_ + BT_) * 2) + (maps ? (2 * (SG_ - 1) + 1) * 768 + 256 : 0);                                          \
+        const size_t l = SG_ * (size_t)(64 * (BT_ + BU_) * 2) + (maps ? (2 * (SG_ - 1) + 1) * 768 + 256 : 0);                                          \
         static bool attr = false;                                                                                                                      \
         if (!attr && l > 65536) {                                                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);  \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<BT_, BU_, WV_, SG_, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_grouped_kernel<BT_, BU_, WV_, SG_, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
             attr = true;                                                                                                                               \
         }                                                                                                                                              \
-        if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, true, 2>), dim3(tiles), dim3(WV_ * 64), l, st, g);                 \
-        else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<BT_, BT_, WV_, SG_, false, 2>), dim3(tiles), dim3(WV_ * 64), l, st, g);                     \
+        if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<BT_, BU_, WV_, SG_, true, 2>), dim3(tiles), dim3(WV_ * 64), l, st, g);                 \
+        else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<BT_, BU_, WV_, SG_, false, 2>), dim3(tiles), dim3(WV_ * 64), l, st, g);                     \
     } while (0)
         bool done = true;
         if (TB == 128 && cfg_waves == 8 && cfg_stages == 2) TNG_GO(128, 8, 2);
@@ -576,8 +686,11 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         else if (TB == 128 && cfg_waves == 4 && cfg_stages == 4) TNG_GO(128, 4, 4);
         else if (TB == 64 && cfg_waves == 4 && cfg_stages == 4) TNG_GO(64, 4, 4);
         else if (TB == 64 && cfg_waves == 4 && cfg_stages == 3) TNG_GO(64, 4, 3);
+        else if (TB == 6412) TNG_GO2(64, 128, 4, 2);
+        else if (TB == 12864) TNG_GO2(128, 64, 4, 2);
         else done = false;
 #undef TNG_GO
+#undef TNG_GO2
         if (done) {
             if (any_parts) hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
             LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
@@ -594,6 +707,63 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     }
     if (any_parts) hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
     LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
+    return LAVT_OK;
+}
+
+// ---- stream-K grouped launch: host side.  sk_plan fills g / sk and returns the scratch floats needed (0 = the group does not qualify).
+static int64_t sk_plan(const lavt_gemm_tn_t* probs, int n, TnGroup& g, TnSk& sk, bool& maps, bool& any_colsum) {
+    constexpr int TB = 128;
+    const lavt_tuning_t& tun = lavt_tuning();
+    if (tun.gemm_v2_off || !tun.tn_streamk || n < 2 || n > TN_GROUP_MAX) return 0;
+    maps = false; any_colsum = false;
+    int its = 0, tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const lavt_gemm_tn_t& p = probs[i];
+        if (!tn_v2_eligible(p) || p.batch != 1 || p.conv_kc > 0 || p.B2 || p.I % 8 || p.J % 8 || p.c_conv_permute) return 0;
+        const int kt = cdiv(p.K, 64), t = cdiv(p.I, TB) * cdiv(p.J, TB);
+        maps = maps || p.a_rowmap || p.a_rowscale || p.b_rowmap;
+        any_colsum = any_colsum || p.colsum != nullptr;
+        g.p[i] = p;
+        g.p[i].partials = nullptr;
+        g.split[i] = 1;
+        its += t * kt; tiles += t;
+        sk.it_end[i] = its; sk.kt[i] = kt; sk.tiles_end[i] = tiles;
+        g.tile_end[i] = tiles;
+    }
+    for (int i = n; i < TN_GROUP_MAX; ++i) { g.p[i] = probs[0]; g.p[i].partials = nullptr; g.tile_end[i] = tiles; g.split[i] = 1; sk.it_end[i] = its; sk.kt[i] = 1; sk.tiles_end[i] = tiles; }
+    g.n = n;
+    // worth it when the 128x128 tiles alone cannot fill the chip in whole rounds but there is enough work for every run to amortise its ring
+    // prologue (>= 6 K tiles per run) -- the Swin-block launches of stages 1-3; many-tile members (stage 0: K = 28 800) keep the piece form
+    int nw = tun.probe[0] > 0 ? tun.probe[0] : 512;
+    if (its / nw < 6) nw = its / 6;
+    if (nw < 128 || tiles < 32) return 0;
+    sk.total = its; sk.nw = nw;
+    return (int64_t)nw * 2 * (TB * TB + TB);
+}
+int64_t lavt_gemm_tn_grouped_sk_ws_v2(const lavt_gemm_tn_t* probs, int n) {
+    TnGroup g; TnSk sk; bool maps, cs;
+    return sk_plan(probs, n, g, sk, maps, cs);
+}
+int lavt_gemm_tn_grouped_sk_v2(const lavt_gemm_tn_t* probs, int n, float* scratch, int64_t scratch_floats, hipStream_t st) {
+    TnGroup g; TnSk sk; bool maps, any_colsum;
+    const int64_t need = sk_plan(probs, n, g, sk, maps, any_colsum);
+    if (need == 0 || scratch == nullptr || scratch_floats < need) return 1;
+    sk.slots = scratch;
+    const size_t lds = 2 * (size_t)(64 * (128 + 128) * 2) + (maps ? 3 * 768 + 256 : 0);
+#define SK_GO(MAPS_, CS_)                                                                                                                              \
+    do {                                                                                                                                               \
+        static bool attr = false;                                                                                                                      \
+        if (!attr) {                                                                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_streamk_kernel<128, 128, 8, 2, MAPS_, CS_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr = true;                                                                                                                               \
+        }                                                                                                                                              \
+        hipLaunchKernelGGL((gemm_tn_v2_streamk_kernel<128, 128, 8, 2, MAPS_, CS_>), dim3(sk.nw), dim3(512), lds, st, g, sk);                           \
+    } while (0)
+    if (any_colsum) { if (maps) SK_GO(true, 1); else SK_GO(false, 1); }          // (scalar column sums: the matrix-core form costs 16 accumulator registers the 128-register tile does not have)
+    else { if (maps) SK_GO(true, 0); else SK_GO(false, 0); }
+#undef SK_GO
+    hipLaunchKernelGGL((tn_streamk_fixup<128, 128>), dim3(sk.tiles_end[n - 1], 4), dim3(256), 0, st, g, sk);
+    LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped_sk");
     return LAVT_OK;
 }
 

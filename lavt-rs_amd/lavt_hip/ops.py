@@ -373,6 +373,7 @@ def _scratch(n_floats, device):
 
 
 _TN_PARTS = {}
+_TN_PARTIALS_MINK = int(os.environ.get("LAVT_TN_PARTIALS_MINK", "2048"))
 
 
 def _tn_parts(n_floats, device):
@@ -467,7 +468,7 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.c_conv_permute, p.split_k = int(c_conv_permute), (-1 if defer is not None else 0)     # deferred = into the zeroed flat gradient buffer: a grouped launch may split K
     p.colsum, p.strideColsum, p.colsum_atomic = K.ptr(colsum), strideColsum, int(colsum_atomic)
     p.zeros = _zero_page(A.device)
-    if dtype == torch.bfloat16 and conv is None and (batch == 1 or defer is None) and Kd >= (2048 if batch == 1 else 128) and not side.enabled and os.environ.get("LAVT_TN_PARTIALS", "1") != "0":      # (one scratch per device: single-stream order only)
+    if dtype == torch.bfloat16 and conv is None and (batch == 1 or defer is None) and Kd >= (_TN_PARTIALS_MINK if batch == 1 else 128) and not side.enabled and os.environ.get("LAVT_TN_PARTIALS", "1") != "0":      # (one scratch per device: single-stream order only)
         # scratch for split reductions through partial tiles (long-K weight gradients on few output tiles: PWAM's 1x1 convolutions over 28 800 rows;
         # batched: the per-sample word-side matrices of the fused PWAM node -- plain stores + a fixed-order sum, so the result is run-to-run identical)
         need = batch * int(K.lib.lavt_gemm_tn_pieces(C.byref(p))) * (I * J + I)
@@ -491,6 +492,12 @@ def assign_partials(items, device):
             if nf:
                 q.partials = base + 4 * off
                 off += nf
+
+
+_SK_SCRATCH = {}
+# measured (round 4, tools/wgrad_sk_time.py): 70-78 us against 39.6 us for the 64x64-tile launch of the stage-2 block -- contiguous runs lose the L2 / MALL sharing
+# of operand panels between workgroups that sweep K together.  Off by default; the launch stays reachable for experiments.
+_STREAMK = os.environ.get("LAVT_WGRAD_STREAMK", "0") == "1"
 
 
 class _WgradQueue:
@@ -534,9 +541,22 @@ class _WgradQueue:
                                "members": list(zip(self.scopes, fl))}
             n_items = len(self.items)
             tensors = [t for tup in self.keep for t in tup if t is not None]
+            sk = int(K.lib.lavt_gemm_tn_grouped_sk_ws(arr, n_items)) if _STREAMK else 0
+            if sk:
+                # stream-K form (csrc/gemm_tn_v2.hip): 128x128 tiles, equal runs of K-tile iterations per persistent workgroup, split tiles through a scratch
+                dev = tensors[0].device
+                scr = _SK_SCRATCH.get(dev)
+                if scr is None or scr.numel() < sk:
+                    scr = _SK_SCRATCH[dev] = torch.empty(sk, dtype=torch.float32, device=dev)
+                side.run(lambda: K.check(K.lib.lavt_gemm_tn_grouped_sk(arr, n_items, K.ptr(scr), scr.numel(), K.stream())), tensors, True)
+                self._after_flush()
+                return
             # the grouped launch is off the critical path of backward (only the optimizer / all-reduce consumes it): on a side stream it overlaps
             # the latency-bound data-gradient chain of the next block (LAVT_SIDE_STREAMS=1)
             side.run(lambda: K.check(K.lib.lavt_gemm_tn_grouped(arr, n_items, K.stream())), tensors, True)
+        self._after_flush()
+
+    def _after_flush(self):
         ready = self.ready
         self.items, self.keep, self.ready, self.scopes, self.primary = [], [], [], [], 0
         for prm in ready:
@@ -2205,6 +2225,18 @@ class _ConvTaps(torch.autograd.Function):
             db, bsink = sinks.buf(bias, (Cout,))
         # the GEMM writes [Cout][taps][Cin] (contiguous split-K atomics), a small kernel adds it into the [Cout][Cin][taps] gradient
         def _wgrad():
+            ws = 0
+            if dtype == torch.bfloat16 and (kd, kh, kw) == (1, 3, 3) and bias is None and D == 1 and os.environ.get("LAVT_CONV_WGRAD_TAPS", "1") != "0":
+                ws = int(K.lib.lavt_conv3x3_wgrad_ws(B, H, W, Cout, Cin, C1 if x2 is not None else Cin))
+            if ws:
+                # nine taps fused (csrc/conv_wgrad.hip): X rows in a rolling LDS window, partial tiles through the lent scratch, the reduction kernel
+                # accumulates straight into the [Cout][Cin][3][3] gradient -- no packed buffer, no zero fill, no unpack launch
+                scr = _tn_parts(ws, dy.device)
+                if K.prof.enabled:
+                    K.prof.note = {"flops": 2.0 * Cout * taps * Cin * M, "shape": f"conv-wgrad {Cout}x{taps * Cin}x{M}"}
+                K.check(K.lib.lavt_conv3x3_wgrad(K.ptr(dy), Cout, K.ptr(x1), C1, K.ptr(x2), C2, C1, B, H, W, Cout, Cin, K.ptr(scr), scr.numel(), K.ptr(dW),
+                                                 _zero_page(dy.device), K.stream()))
+                return
             packed = torch.zeros(Cout, taps * Cin, dtype=torch.float32, device=dy.device)
             gemm_tn(dtype, Cout, taps * Cin, M, dy, Cout, x1, C1, packed, taps * Cin, B2=x2, ldb2=C2, b_split=C1,
                     conv=(H, W, Cin, D, kd, kh, kw), colsum=db)

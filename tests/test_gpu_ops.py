@@ -23,6 +23,11 @@ def dev():
     return torch.device("cuda:0")
 
 
+def lavt_hip_dtype(dtype):
+    import lavt_hip
+    return lavt_hip.use_dtype(dtype)
+
+
 def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator("cpu").manual_seed(seed)) * scale
 
@@ -166,6 +171,42 @@ def test_conv3x3(dtype, B, H, W, C1, C2, Cout):
         y = F.conv2d(x.view(B, H, W, Cin).permute(0, 3, 1, 2), w, padding=1)
         return y.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
     run_pair(lambda x1, w, x2=None: ops.conv3x3(x1, x2, w, B, H, W), ref, inputs, dtype, name="conv3x3", bf16=4e-2)
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(2, 30, 30, 128, 64, 128), (1, 60, 60, 64, 64, 128), (2, 24, 96, 64, 0, 128), (2, 120, 120, 128, 64, 256),
+                                              (1, 16, 128, 64, 0, 128), (3, 7, 33, 64, 0, 128), (1, 5, 120, 64, 0, 128), (2, 120, 120, 512, 0, 512)])
+def test_conv3x3_wgrad_fused_taps(B, H, W, C1, C2, Cout, monkeypatch):
+    """csrc/conv_wgrad.hip (nine taps fused: image rows of X in a rolling LDS window with zero halo columns / a zero slot for rows outside the
+    image, the tap shift as an LDS address, partial tiles + one reducing / transposing kernel) against the fp32 weight gradient of F.conv2d and
+    against the tap-shifted TN GEMM form it replaces: every row count per k-step (W = 30 .. 128), two concat sources, image borders inside a
+    piece (B > 1), a piece count that does not divide the rows, and the decoder's own 2 x 120 x 120 x 512 -> 512 shape."""
+    from lavt_hip import ops, _capi as K
+    Cin = C1 + C2
+    assert int(K.lib.lavt_conv3x3_wgrad_ws(B, H, W, Cout, Cin, C1 if C2 else Cin)) > 0
+    bf = torch.bfloat16
+    x1 = rnd(B * H * W, C1, seed=1).to(bf)
+    x2 = rnd(B * H * W, C2, seed=2).to(bf) if C2 else None
+    dy = rnd(B * H * W, Cout, seed=3).to(bf)
+    w = rnd(Cout, Cin, 3, 3, seed=4, scale=(9 * Cin) ** -0.5)
+
+    def run(fused):
+        monkeypatch.setenv("LAVT_CONV_WGRAD_TAPS", "1" if fused else "0")
+        wd = w.to(dev()).requires_grad_(True)
+        a1 = x1.to(dev()).requires_grad_(True)
+        a2 = x2.to(dev()).requires_grad_(True) if C2 else None
+        with lavt_hip_dtype(bf):
+            y = ops.conv3x3(a1, a2, wd, B, H, W)
+            y.backward(dy.to(dev()))
+        torch.cuda.synchronize()
+        return wd.grad.detach().cpu()
+    got, old = run(True), run(False)
+    x = (x1 if x2 is None else torch.cat([x1, x2], 1)).float().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 3, 3), dy.float().view(B, H, W, Cout).permute(0, 3, 1, 2), padding=1)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-3 * scale, float((got - ref).abs().max()) / scale       # exact bf16 products, fp32 sums: summation order only
+    assert float((old - ref).abs().max()) <= 2e-3 * scale
+    # border taps really see zeros: the corner pixel's contribution to tap (dy, dx) = (-1, -1) is absent
+    assert torch.isfinite(got).all()
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -615,7 +656,7 @@ def test_gemm_tn_token_order_matches_window_order(B, H, ws, shift, Cc):
         out = torch.zeros(I, J, device=dev()); outs.append((out, A, Bm))
         ops.gemm_tn(bf, I, J, Kd, A, I, Bm, J, out, J, defer=_Q())
     ops.gemm_tn(bf, Cc, Cc, T, dy, Cc, o, Cc, t_proj, Cc, b_rowmap=inv, colsum=tb_proj, defer=_Q())
-    dummy = torch.empty(3 * Cc, 8, device=dev())
+    dummy = torch.zeros(3 * Cc, 8, device=dev())          # (zeros: a member cut into partial tiles ADDS its -- zero -- sum to what C holds)
     ops.gemm_tn(bf, 3 * Cc, 8, pad.numel(), dqkv, 3 * Cc, ops._zero_page_tensor(dev()), 0, dummy, 8, a_rowmap=pad, colsum=tb_qkv, colsum_atomic=True, defer=_Q(), extra=True)
     ops.gemm_tn(bf, 3 * Cc, Cc, T, dqkv, 3 * Cc, xn, Cc, t_qkv, Cc, a_rowmap=inv, colsum=tb_qkv, colsum_atomic=True, defer=_Q())
     assert len(structs) == 5
@@ -635,6 +676,56 @@ def test_gemm_tn_token_order_matches_window_order(B, H, ws, shift, Cc):
     # the qkv bias gradient really contains the padded rows' share
     share = dqkv[pad.long()].float().sum(0)
     assert float(share.abs().max()) > 0 and float((tb_qkv - b_qkv).abs().max()) < 0.05 * float(share.abs().max())
+
+
+@pytest.mark.parametrize("B,H,ws,shift,Cc", [(2, 30, 12, 6, 512), (2, 15, 12, 0, 1024), (4, 30, 12, 6, 512), (2, 60, 12, 6, 256)])
+def test_gemm_tn_grouped_streamk(B, H, ws, shift, Cc):
+    """Stream-K form of a Swin block's grouped weight-gradient launch (lavt_gemm_tn_grouped_sk: 128x128 tiles, equal runs of K-tile iterations per
+    persistent workgroup, split tiles through scratch slots + a fixed-order fix-up) on the five token-order members (row maps, matrix-core
+    column sums, the column-sum-only side member adding atomically into the shared bias gradient) against fp32 torch, and bit-identical
+    between two runs (no atomics in the split reductions)."""
+    from lavt_hip import _capi as K, ops, rowmaps
+    g = torch.Generator().manual_seed(7)
+    bf = torch.bfloat16
+    wmap = rowmaps.window_map(B, H, H, ws, shift, dev())
+    inv, pad = rowmaps.window_inverse(B, H, H, ws, shift, dev()), rowmaps.window_pad_rows(B, H, H, ws, shift, dev())
+    T, Mw = B * H * H, wmap.numel()
+    def mk(rows, cols):
+        return (torch.randn(rows, cols, generator=g) * 0.5).to(dev()).to(bf)
+    dqkv, xn, dy, o = mk(Mw, 3 * Cc), mk(T, Cc), mk(T, Cc), mk(Mw, Cc)
+    dpre, x2, dy2, h = mk(T, 4 * Cc), mk(T, Cc), mk(T, Cc), mk(T, 4 * Cc)
+
+    def run():
+        structs, keep = [], []
+        class _Q:
+            def add(self, p, t, extra=False): structs.append(p); keep.append(t)
+        outs = {k: torch.zeros(*shp, device=dev()) for k, shp in (("fc1.w", (4 * Cc, Cc)), ("fc1.b", (4 * Cc,)), ("fc2.w", (Cc, 4 * Cc)), ("fc2.b", (Cc,)), ("proj.w", (Cc, Cc)),
+                                                                   ("proj.b", (Cc,)), ("qkv.w", (3 * Cc, Cc)), ("qkv.b", (3 * Cc,)))}
+        ops.gemm_tn(bf, Cc, 4 * Cc, T, dy2, Cc, h, 4 * Cc, outs["fc2.w"], 4 * Cc, colsum=outs["fc2.b"], defer=_Q())
+        ops.gemm_tn(bf, 4 * Cc, Cc, T, dpre, 4 * Cc, x2, Cc, outs["fc1.w"], Cc, colsum=outs["fc1.b"], defer=_Q())
+        ops.gemm_tn(bf, Cc, Cc, T, dy, Cc, o, Cc, outs["proj.w"], Cc, b_rowmap=inv, colsum=outs["proj.b"], defer=_Q())
+        dummy = torch.zeros(3 * Cc, 8, device=dev())
+        if pad.numel():                 # (no side member when the grid is a whole number of windows: 60 = 5 x 12)
+            ops.gemm_tn(bf, 3 * Cc, 8, pad.numel(), dqkv, 3 * Cc, ops._zero_page_tensor(dev()), 0, dummy, 8, a_rowmap=pad, colsum=outs["qkv.b"], colsum_atomic=True, defer=_Q(), extra=True)
+        ops.gemm_tn(bf, 3 * Cc, Cc, T, dqkv, 3 * Cc, xn, Cc, outs["qkv.w"], Cc, a_rowmap=inv, colsum=outs["qkv.b"], colsum_atomic=True, defer=_Q())
+        arr = (K.GemmTN * len(structs))(*structs)
+        need = int(K.lib.lavt_gemm_tn_grouped_sk_ws(arr, len(structs)))
+        assert need > 0, "the Swin-block group must qualify for the stream-K launch"
+        scr = torch.full((need,), float("nan"), device=dev())             # stale scratch must never leak into a result
+        K.check(K.lib.lavt_gemm_tn_grouped_sk(arr, len(structs), K.ptr(scr), scr.numel(), K.stream()))
+        torch.cuda.synchronize()
+        return outs
+    a, b = run(), run()
+    f = lambda t: t.float()
+    ref = {"fc2.w": f(dy2).t() @ f(h), "fc2.b": f(dy2).sum(0), "fc1.w": f(dpre).t() @ f(x2), "fc1.b": f(dpre).sum(0),
+           "proj.w": f(dy).t() @ f(o)[inv.long()], "proj.b": f(dy).sum(0), "qkv.w": f(dqkv)[inv.long()].t() @ f(xn), "qkv.b": f(dqkv).sum(0)}
+    for k, r in ref.items():
+        scale = float(r.abs().max())
+        assert torch.isfinite(a[k]).all(), k
+        assert float((a[k] - r).abs().max()) <= 2e-3 * scale, (k, float((a[k] - r).abs().max()) / scale)
+        if k != "qkv.b":                      # (two members add into qkv.b atomically: two addends into zeros, order-independent -- also identical)
+            assert torch.equal(a[k], b[k]), f"{k}: two runs differ"
+    assert torch.equal(a["qkv.b"], b["qkv.b"])
 
 
 def test_gemm_tn_split_through_partial_tiles(monkeypatch):

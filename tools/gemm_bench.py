@@ -7,7 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lavt-rs_amd"))
 import torch  # noqa: E402
-from lavt_hip import ops  # noqa: E402
+from lavt_hip import ops, _capi as K  # noqa: E402
 
 dev = "cuda:0"
 bf = torch.bfloat16
@@ -68,10 +68,12 @@ def main():
                 for tile in ("64", "128"):
                     for sp in ("1", "2", "4", "8"):
                         os.environ.update(LAVT_GEMM_TILE=tile, LAVT_TN_SPLIT=sp, LAVT_GEMM_V2=v2)
+                        K.lib.lavt_tuning_reload()          # the library reads its switches once per process
                         t = timeit(tn(a, b, c), iters=5 if c > 20000 else 20)
                         res.append((f"v{int(v2)+1}t{tile}/s{sp}", t * 1e6, 2.0 * a * b * c / t / 1e12))
             for k in ("LAVT_GEMM_TILE", "LAVT_TN_SPLIT", "LAVT_GEMM_V2"):
                 os.environ.pop(k)
+            K.lib.lavt_tuning_reload()
             print(f"{name:9s} {kind:3s} {a:6d} {b:5d} {c:5d} | " + " | ".join(f"{k}: {us:5.1f}us" for k, us, tf in res))
             continue
         for tile, stages, v2, wv in (("64", "3", "0", "4"), ("64", "2", "1", "4"), ("64", "3", "1", "4"), ("128", "2", "1", "4"), ("128", "2", "1", "8"), ("128", "3", "1", "8"), ("256", "2", "1", "8"), ("512", "2", "1", "16")):
@@ -79,11 +81,13 @@ def main():
             os.environ["LAVT_GEMM_STAGES"] = stages
             os.environ["LAVT_GEMM_V2"] = v2
             os.environ["LAVT_GEMM_WAVES"] = wv
+            K.lib.lavt_tuning_reload()
             fn = nt(a, b, c) if kind == "nt" else nt(a, b, c, True) if kind == "ntk" else tn(a, b, c)
             t = timeit(fn)
             res.append((("v2" if v2 == "1" else "v1") + "-" + tile + ("s" + stages + "w" + wv if v2 == "1" else ""), t * 1e6, 2.0 * a * b * c / t / 1e12))
         for k in ("LAVT_GEMM_TILE", "LAVT_GEMM_STAGES", "LAVT_GEMM_V2", "LAVT_GEMM_WAVES"):
             os.environ.pop(k)
+        K.lib.lavt_tuning_reload()
         fn = nt(a, b, c) if kind == "nt" else nt(a, b, c, True) if kind == "ntk" else tn(a, b, c)
         t = timeit(fn)
         # yardstick only (never on the product path): the vendor library's GEMM on the same shape through torch.matmul (hipBLASLt)
