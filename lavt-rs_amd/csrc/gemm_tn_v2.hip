@@ -612,8 +612,9 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         for (int i = 0; i < n; ++i) t128 += (long)cdiv(probs[i].I, 128) * cdiv(probs[i].J, 128);
         if (TB == 128 && t128 < 128) TB = 64;
     }
-    // rectangular tiles (LAVT_TNG_CFG tile codes 6412 = 64 x 128, 12864 = 128 x 64; 4 waves, 2 stages): 24 KB per K tile for 1.05 MFLOP
-    const int TBI = TB == 6412 ? 64 : (TB == 12864 ? 128 : TB), TBJ = TB == 6412 ? 128 : (TB == 12864 ? 64 : TB);
+    // (rectangular 64 x 128 / 128 x 64 tiles, 4 waves -- 24 KB per K tile for 1.05 MFLOP -- measured level with the square tile in round 4: 39.0 / 41.2 vs
+    // 39.0 us per stage-2 launch, 8.66 / 8.74 vs 8.56 ms per step; the instantiations are gone)
+    const int TBI = TB, TBJ = TB;
     bool any_colsum = false;
     // Pieces per member.  A member with a partials scratch (lavt_gemm_tn_t.partials: its pieces are stored as plain tiles and added into C by one
     // small second kernel) may be cut as finely as its K allows -- the long-K weight gradients of PWAM (K = 28 800 rows = 450 K tiles on 4
@@ -686,8 +687,6 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         else if (TB == 128 && cfg_waves == 4 && cfg_stages == 4) TNG_GO(128, 4, 4);
         else if (TB == 64 && cfg_waves == 4 && cfg_stages == 4) TNG_GO(64, 4, 4);
         else if (TB == 64 && cfg_waves == 4 && cfg_stages == 3) TNG_GO(64, 4, 3);
-        else if (TB == 6412) TNG_GO2(64, 128, 4, 2);
-        else if (TB == 12864) TNG_GO2(128, 64, 4, 2);
         else done = false;
 #undef TNG_GO
 #undef TNG_GO2

