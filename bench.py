@@ -104,8 +104,11 @@ def measure_conv_kernel(device, iters=20):
     achieved = flops / (ms * 1e-3) / 1e12
     traffic, tsrc = None, None          # fabric-side bytes per launch from the committed rocprofv3 --pmc passes of this kernel: a recorded constant, not measured by this run
     try:
-        traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_conv_and_grouped_wgrad.json")))["conv_one"]["derived"]["fabric_bytes (FETCH_SIZE KB x2 gfx950 correction + WRITE_SIZE KB)"])
-        tsrc = "profiles/r02_pmc_conv_and_grouped_wgrad.json (recorded)"
+        for fn in ("r04_pmc.json", "r02_pmc_conv_and_grouped_wgrad.json"):          # the newest committed pass of this kernel (tools/pmc_passes.sh conv_one)
+            if os.path.exists(os.path.join(ROOT, "profiles", fn)):
+                traffic = int(json.load(open(os.path.join(ROOT, "profiles", fn)))["conv_one"]["derived"]["fabric_bytes (FETCH_SIZE KB x2 gfx950 correction + WRITE_SIZE KB)"])
+                tsrc = f"profiles/{fn} (recorded)"
+                break
     except Exception:  # noqa: BLE001
         try:
             traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")))["traffic_bytes_per_launch"]
@@ -185,9 +188,10 @@ def profile_step(step, cfg, device, reps=3):
         # fabric-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE on
         # tools/wgrad_group_one.py, the same five problems in token order): a recorded constant, not a measurement of this run
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_grouped_wgrad_and_wmsa.json")))["wgrad_group_one"]["derived"]
+            fn = "r04_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc.json")) else "r03_pmc_grouped_wgrad_and_wmsa.json"
+            pm = json.load(open(os.path.join(ROOT, "profiles", fn)))["wgrad_group_one"]["derived"]
             roof["traffic"] = int(pm["fabric_bytes (FETCH_SIZE KB x2 gfx950 correction + WRITE_SIZE KB)"])
-            roof["traffic_source"] = "profiles/r03_pmc_grouped_wgrad_and_wmsa.json (recorded)"
+            roof["traffic_source"] = f"profiles/{fn} (recorded)"
             # bf16 operands read once (fc2, fc1, proj, the 792 padded rows of dqkv, qkv) + fp32 gradients written once
             roof["algorithmic_bytes"] = int(2 * (2 * 1800 * (512 + 2048) + 1800 * (512 + 512) + 792 * 1536 + 1800 * (1536 + 512)) + 4 * (2 * 2048 * 512 + 512 * 512 + 1536 * 512))
         except Exception:  # noqa: BLE001

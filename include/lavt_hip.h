@@ -47,7 +47,7 @@ extern "C" {
 
 int lavt_abi_version(void);
 const char* lavt_last_error(void);
-int lavt_tuning_reload(void); /* re-read the LAVT_* tuning switches from the environment (tests that force a tile configuration) */
+int lavt_tuning_reload(void); /* ABI v5: re-read the LAVT_* tuning switches from the environment (tests that force a tile configuration) */
 
 /* ---------------------------------------------------------------------------------------------
  * Gather-GEMM, "NT" family:   C[M,N] = epilogue( alpha * A_op[M,K] x B_op[K,N] )
@@ -214,14 +214,14 @@ int lavt_gemm_tn_pieces(const lavt_gemm_tn_t* p);
  * give the same result: the grouped launch may then cut its reduction into up to 4 pieces that meet through atomics (the launch lasts as
  * long as its longest serial chain of K tiles). */
 int lavt_gemm_tn_grouped(const lavt_gemm_tn_t* probs, int n, void* stream);
-/* The same launch in stream-K form (round 4): 128x128 tiles, the K-tile iterations of all members cut into equal runs for ~512 persistent
+/* The same launch in stream-K form (ABI v5): 128x128 tiles, the K-tile iterations of all members cut into equal runs for ~512 persistent
  * workgroups (every workgroup ingests the same number of bytes); tiles whose reduction is split between runs meet through `scratch` (plain partial
  * tiles + a fixed-order sum: no atomics).  lavt_gemm_tn_grouped_sk_ws returns the floats of scratch the group wants, or 0 when it does not qualify
  * (conv taps, batch > 1, too little work): call lavt_gemm_tn_grouped then.  Members' `partials` fields are ignored. */
 int64_t lavt_gemm_tn_grouped_sk_ws(const lavt_gemm_tn_t* probs, int n);
 int lavt_gemm_tn_grouped_sk(const lavt_gemm_tn_t* probs, int n, float* scratch, int64_t scratch_floats, void* stream);
 
-/* 3x3 / pad 1 / no-bias convolution weight gradient with the nine taps fused (bf16; csrc/conv_wgrad.hip) -- the gradient autograd computes for
+/* 3x3 / pad 1 / no-bias convolution weight gradient with the nine taps fused (ABI v5; bf16; csrc/conv_wgrad.hip) -- the gradient autograd computes for
  * SimpleDecoding's conv1_4 .. conv2_2 (lib/mask_predictor.py:60-97):  dW[co][ci][tap] += sum_p dY[p][co] * X[p + (dy, dx)][ci],
  * tap = (dy + 1) * 3 + (dx + 1), pixels p over B images of H x W (NHWC rows), X = the channel concat of x1 (c1 channels) and x2 (Cin - c1; NULL
  * for a single source).  dW is the [Cout][Cin][3][3] parameter gradient itself (accumulated into).  `parts`: caller-lent fp32 scratch of

@@ -219,7 +219,7 @@ for _name, _args in _PROTOTYPES.items():
     _fn = getattr(_cdll, _name)          # AttributeError here = header/library mismatch: fail loudly
     _fn.argtypes = _args
     _fn.restype = C.c_int
-EXPECTED_ABI = 4          # the ctypes struct layouts and prototypes in this file were written for this lavt_abi_version()
+EXPECTED_ABI = 5          # the ctypes struct layouts and prototypes in this file were written for this lavt_abi_version()
 if _cdll.lavt_abi_version() != EXPECTED_ABI:
     raise ImportError(f"{LIB_PATH} reports ABI v{_cdll.lavt_abi_version()} but lavt_hip/_capi.py binds ABI v{EXPECTED_ABI}: rebuild the library "
                       "(`make -C lavt-rs_amd/csrc`) -- a mismatch would make the kernels read past the caller's parameter structs")

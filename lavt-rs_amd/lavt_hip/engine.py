@@ -63,6 +63,7 @@ class TrainStep:
         if self.refresh_in_step:
             ops.weights.refresh_all()            # re-cast weights inside the step (for optimizers that do not maintain the compute copies)
         self.buckets.zero()
+        ops.zero_arena.begin_step(self.x.device)          # one fill for every small zero-initialised buffer of the step
         if fp8_enabled():
             ops.fp8.advance()                    # delayed scaling: last step's |max| values become this step's quantisation scales
         if self.fused_loss:                       # upsample + weighted CE (+ I/U) fused: the (B,2,H,W) logits are never written
@@ -76,6 +77,7 @@ class TrainStep:
         ops.ln_deferred.flush()                  # all LayerNorm weight / bias partial sums of this backward: one reduction launch
         ops.side.join()                          # wgrad GEMMs ran on side streams: join before the step (or the graph capture) ends
         self.buckets.finish()                    # stragglers (never-used parameters) + join of the communication stream
+        ops.zero_arena.end_step()
         return loss.detach()
 
     def warmup_and_capture(self, eager_iters=3):

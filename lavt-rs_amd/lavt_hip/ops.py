@@ -396,6 +396,47 @@ def _discard_out(n_floats, device):
     return b
 
 
+class _ZeroArena:
+    """Small buffers that must START AS ZEROS (targets of split reductions in the fused PWAM node, padded key / value rows) were one torch.zeros each:
+    ~12 fill kernels of ~5 us per step, each a node of the captured chain.  Under the step harness they are carved from ONE arena whose used prefix
+    (the high-water mark of the previous step) is zeroed by a single fill at the start of the step; a request the prefix cannot serve -- the first
+    step, a different call sequence, a call outside the harness -- falls back to torch.zeros.  A buffer lives until the end of its step only."""
+    BYTES = int(os.environ.get("LAVT_ZERO_ARENA_MB", "64")) << 20
+
+    def __init__(self):
+        self.buf, self.off, self.hw, self.zeroed, self.active = None, 0, 0, 0, False
+
+    def begin_step(self, device):
+        if os.environ.get("LAVT_ZERO_ARENA", "1") == "0":
+            return
+        if self.buf is None or self.buf.device != device:
+            self.buf = torch.empty(self.BYTES, dtype=torch.uint8, device=device)
+            self.hw = 0
+        self.zeroed = min(self.hw, self.BYTES)
+        if self.zeroed:
+            self.buf[:self.zeroed].zero_()
+        self.off, self.hw, self.active = 0, 0, True
+
+    def end_step(self):
+        self.active = False
+
+    def take(self, shape, dtype, device):
+        n = 1
+        for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+            n *= int(d)
+        nbytes = -(-n * torch.empty(0, dtype=dtype).element_size() // 256) * 256
+        if self.active and self.buf is not None and self.buf.device == device:
+            start = self.off
+            self.off += nbytes
+            self.hw = max(self.hw, self.off)
+            if start + nbytes <= self.zeroed:
+                return self.buf[start:start + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(shape)
+        return torch.zeros(shape, dtype=dtype, device=device)
+
+
+zero_arena = _ZeroArena()
+
+
 def _zero_page_tensor(device):
     _zero_page(device)
     return _ZERO_PAGES[device]
@@ -1673,7 +1714,7 @@ class _PwamGate(torch.autograd.Function):
         P = torch.empty(M, KV_LD, dtype=dtype, device=dev)
         _note(f"words {M}x{Cc}", 2.0 * M * Cc * KV_LD)
         K.check(K.lib.lavt_pwam_words_fwd(K.ptr(q), Cc, K.ptr(k), kld, K.ptr(mean), K.ptr(rstd), K.ptr(maskbias), K.ptr(P), B, T, Cc, n_l, alpha, K.stream()))
-        st = torch.zeros(B * (KV_LD * KV_LD + KV_LD), dtype=torch.float32, device=dev)
+        st = zero_arena.take(B * (KV_LD * KV_LD + KV_LD), torch.float32, dev)
         PP, sumP = st[:B * KV_LD * KV_LD], st[B * KV_LD * KV_LD:]
         gemm_tn(dtype, KV_LD, KV_LD, T, P, KV_LD, P, KV_LD, PP, KV_LD, batch=B, strideA=T * KV_LD, strideB=T * KV_LD, strideC=KV_LD * KV_LD, colsum=sumP, strideColsum=KV_LD)
         VWc = torch.empty(B, Cc, KV_LD, dtype=dtype, device=dev)
@@ -1740,7 +1781,7 @@ class _PwamGate(torch.autograd.Function):
                                     B, T, Cc, K.stream()))
         # one zeroed side buffer for the targets of the split reductions (partial tiles, then += the fixed-order sum): H^T, s, G, colsum(dS)
         nz = B * (Cc * KV_LD + Cc + KV_LD * Cc + KV_LD)
-        z = torch.zeros(nz, dtype=torch.float32, device=dev)
+        z = zero_arena.take(nz, torch.float32, dev)
         o = 0
         HT = z[o:o + B * Cc * KV_LD]; o += B * Cc * KV_LD
         s = z[o:o + B * Cc]; o += B * Cc
@@ -1838,7 +1879,7 @@ class _KvAll(torch.autograd.Function):
         Nt, Kd = Wc.shape
         M = lt.shape[0]
         rows = ctx_kv.B * KV_LD
-        big = torch.zeros(rows, Nt, dtype=dtype, device=lt.device)
+        big = zero_arena.take((rows, Nt), dtype, lt.device)
         bias = torch.cat([_f32(b) for b in bs])
         gemm_nt(dtype, M, Nt, Kd, lt, Kd, Wc, Kd, big, Nt, bias=bias, row_scale=ctx_kv.mask_rows, c_rowmap=ctx_kv.kv_map)
         ctx.save_for_backward(lt, *wb)
