@@ -226,7 +226,7 @@ int lavt_gemm_tn_grouped_sk(const lavt_gemm_tn_t* probs, int n, float* scratch, 
  * tap = (dy + 1) * 3 + (dx + 1), pixels p over B images of H x W (NHWC rows), X = the channel concat of x1 (c1 channels) and x2 (Cin - c1; NULL
  * for a single source).  dW is the [Cout][Cin][3][3] parameter gradient itself (accumulated into).  `parts`: caller-lent fp32 scratch of
  * lavt_conv3x3_wgrad_ws(...) floats (partial tiles of the split pixel reduction; no atomics, run-to-run identical); _ws returns 0 for shapes the
- * kernel does not cover (Cout % 128, Cin % 64, c1 % 64, W <= 128) -- use lavt_gemm_tn's tap-shifted form + lavt_unpack_conv_grad then. */
+ * kernel does not cover (Cout % 128, Cin % 8, c1 % 64, W <= 128) -- use lavt_gemm_tn's tap-shifted form + lavt_unpack_conv_grad then. */
 int64_t lavt_conv3x3_wgrad_ws(int B, int H, int W, int Cout, int Cin, int c1);
 int lavt_conv3x3_wgrad(const void* dy, int64_t ldy, const void* x1, int64_t ldx1, const void* x2, int64_t ldx2, int c1, int B, int H, int W, int Cout,
                        int Cin, float* parts, int64_t parts_floats, float* dW, const void* zeros, void* stream);

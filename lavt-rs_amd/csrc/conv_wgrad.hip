@@ -89,7 +89,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wgrad3x3_kernel(const CwArgs 
     char* const sZ = sB + CW_NS * CW_SLOT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 2, wj = wave & 3;                       // 2 x 4 waves: 64 output channels x 16 input channels (x 9 taps) each
-    const int tiles_j = a.Cin / CW_BJ;
+    const int tiles_j = (a.Cin + CW_BJ - 1) / CW_BJ;          // Cin % 8 == 0; a last tile beyond Cin reads zeros and its columns are never reduced
     // Workgroups go round-robin over the 8 XCDs (private L2 each); with gridDim.x a multiple of 8 a tile keeps its XCD in every piece.  Give an XCD a
     // contiguous run of tiles (tile_j fastest): its workgroups of one piece then share the dY panel of (mostly) one tile_i -- measured before: every
     // dY panel crossed the fabric once per tile_j (8 x 29.5 MB of the 343 MB per launch).
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wgrad3x3_kernel(const CwArgs 
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
         const int q = (wave * B_INSTR + i) * 64 + lane, pos = 1 + (q >> 3), cc = (q & 7) ^ cw_bswz(pos);
-        b_ok[i] = pos - 1 < W;
+        b_ok[i] = pos - 1 < W && j0 + cc * 8 < a.Cin;
         b_src[i] = X + (int64_t)(pos - 1) * ldx + cc * 8;
     }
     const int64_t a_row = (int64_t)W * a.ldy, b_row = (int64_t)W * ldx;
@@ -258,22 +258,23 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_reduce(const float4* __rest
     }
     __syncthreads();
     const int co0 = tile_i * CW_BI + wi * 64 + i * 16;
+    const int ci0 = tile_j * CW_BJ + wj * 16, nvalid = min(16, Cin - ci0) * 9;          // (<= 0 for a 16-channel block beyond Cin)
     for (int e = threadIdx.x; e < 16 * 144; e += 256) {
         const int r = e / 144, c = e - r * 144;
-        dW[((int64_t)(co0 + r) * Cin + tile_j * CW_BJ + wj * 16) * 9 + c] += t[r][c];
+        if (c < nvalid) dW[((int64_t)(co0 + r) * Cin + ci0) * 9 + c] += t[r][c];
     }
 }
 
 // pieces so that tiles x pieces fills the 256 CUs in one round (one workgroup per CU: 145 KB of LDS), at least 8 image rows per piece
 int cw_pieces(int B, int H, int Cout, int Cin) {
-    const int tiles = (Cout / CW_BI) * (Cin / CW_BJ), rows = B * H;
+    const int tiles = (Cout / CW_BI) * ((Cin + CW_BJ - 1) / CW_BJ), rows = B * H;
     int p = 256 / tiles;
     if (p < 1) p = 1;
     const int maxp = rows / 8 > 0 ? rows / 8 : 1;
     return p > maxp ? maxp : p;
 }
 bool cw_supported(int B, int H, int W, int Cout, int Cin, int c1) {
-    return B > 0 && H > 0 && W > 0 && W <= 128 && Cout % CW_BI == 0 && Cin % CW_BJ == 0 && c1 % CW_BJ == 0 && (int64_t)B * H * W < (1LL << 24);
+    return B > 0 && H > 0 && W > 0 && W <= 128 && Cout % CW_BI == 0 && Cin % 8 == 0 && c1 % CW_BJ == 0 && c1 <= Cin && (int64_t)B * H * W < (1LL << 24);
 }
 
 }  // namespace
@@ -281,26 +282,27 @@ bool cw_supported(int B, int H, int W, int Cout, int Cin, int c1) {
 /* floats of scratch lavt_conv3x3_wgrad needs for this shape; 0 = shape not covered (the caller uses lavt_gemm_tn's tap-shifted form) */
 extern "C" int64_t lavt_conv3x3_wgrad_ws(int B, int H, int W, int Cout, int Cin, int c1) {
     if (!cw_supported(B, H, W, Cout, Cin, c1 > 0 ? c1 : Cin)) return 0;
-    return (int64_t)cw_pieces(B, H, Cout, Cin) * Cout * 9 * Cin;
+    return (int64_t)cw_pieces(B, H, Cout, Cin) * Cout * 9 * (((Cin + CW_BJ - 1) / CW_BJ) * CW_BJ);
 }
 
 extern "C" int lavt_conv3x3_wgrad(const void* dy, int64_t ldy, const void* x1, int64_t ldx1, const void* x2, int64_t ldx2, int c1, int B, int H, int W, int Cout,
                                   int Cin, float* parts, int64_t parts_floats, float* dW, const void* zeros, void* stream) {
     if (x2 == nullptr) c1 = Cin;
     LAVT_CHECK_ARG(dy && x1 && parts && dW && zeros, "lavt_conv3x3_wgrad: null argument");
-    LAVT_CHECK_ARG(cw_supported(B, H, W, Cout, Cin, c1), "lavt_conv3x3_wgrad: needs Cout %% 128 == 0, Cin %% 64 == 0, c1 %% 64 == 0, W <= 128 (ask lavt_conv3x3_wgrad_ws first)");
+    LAVT_CHECK_ARG(cw_supported(B, H, W, Cout, Cin, c1), "lavt_conv3x3_wgrad: needs Cout %% 128 == 0, Cin %% 8 == 0, c1 %% 64 == 0, W <= 128 (ask lavt_conv3x3_wgrad_ws first)");
     LAVT_CHECK_ARG(ldy % 8 == 0 && ldx1 % 8 == 0 && (x2 == nullptr || ldx2 % 8 == 0), "lavt_conv3x3_wgrad: leading dimensions must be multiples of 8 elements");
     int pieces = cw_pieces(B, H, Cout, Cin);
     const int rpp = (B * H + pieces - 1) / pieces;
     pieces = (B * H + rpp - 1) / rpp;                                  // no empty piece: the reduction reads every piece's tile
-    LAVT_CHECK_ARG(parts_floats >= (int64_t)pieces * Cout * 9 * Cin, "lavt_conv3x3_wgrad: scratch too small (lavt_conv3x3_wgrad_ws)");
+    LAVT_CHECK_ARG(parts_floats >= (int64_t)pieces * Cout * 9 * (((Cin + CW_BJ - 1) / CW_BJ) * CW_BJ), "lavt_conv3x3_wgrad: scratch too small (lavt_conv3x3_wgrad_ws)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CwArgs a;
     a.dy = (const bf16*)dy; a.ldy = ldy; a.x1 = (const bf16*)x1; a.ldx1 = ldx1; a.x2 = (const bf16*)x2; a.ldx2 = ldx2; a.c1 = c1;
     a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.Cin = Cin; a.parts = parts; a.pieces = pieces; a.zeros = zeros;
     a.rows_per_piece = rpp;
     a.xcd_order = lavt_tuning().probe[1] ? 0 : 1;
-    const dim3 grid((Cout / CW_BI) * (Cin / CW_BJ), pieces);
+    const int tiles_j = (Cin + CW_BJ - 1) / CW_BJ;
+    const dim3 grid((Cout / CW_BI) * tiles_j, pieces);
 #define CW_LAUNCH(KS_)                                                                                                                          \
     do {                                                                                                                                        \
         static bool attr = false;                                                                                                               \
@@ -316,7 +318,7 @@ extern "C" int lavt_conv3x3_wgrad(const void* dy, int64_t ldy, const void* x1, i
     const int ks = (W + 31) / 32;
     if (ks == 1) CW_LAUNCH(1); else if (ks == 2) CW_LAUNCH(2); else if (ks == 3) CW_LAUNCH(3); else CW_LAUNCH(4);
 #undef CW_LAUNCH
-    hipLaunchKernelGGL(conv_wgrad3x3_reduce, dim3(grid.x, 32), dim3(256), 0, st, reinterpret_cast<const float4*>(parts), pieces, (int)grid.x, Cin / CW_BJ, Cin, dW);
+    hipLaunchKernelGGL(conv_wgrad3x3_reduce, dim3(grid.x, 32), dim3(256), 0, st, reinterpret_cast<const float4*>(parts), pieces, (int)grid.x, tiles_j, Cin, dW);
     LAVT_CHECK_LAUNCH("lavt_conv3x3_wgrad");
     return LAVT_OK;
 }

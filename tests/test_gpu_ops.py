@@ -174,12 +174,14 @@ def test_conv3x3(dtype, B, H, W, C1, C2, Cout):
 
 
 @pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(2, 30, 30, 128, 64, 128), (1, 60, 60, 64, 64, 128), (2, 24, 96, 64, 0, 128), (2, 120, 120, 128, 64, 256),
-                                              (1, 16, 128, 64, 0, 128), (3, 7, 33, 64, 0, 128), (1, 5, 120, 64, 0, 128), (2, 120, 120, 512, 0, 512)])
+                                              (1, 16, 128, 64, 0, 128), (3, 7, 33, 64, 0, 128), (1, 5, 120, 64, 0, 128), (2, 120, 120, 512, 0, 512),
+                                              (2, 20, 24, 64, 32, 128), (1, 16, 120, 384, 96, 384)])
 def test_conv3x3_wgrad_fused_taps(B, H, W, C1, C2, Cout, monkeypatch):
     """csrc/conv_wgrad.hip (nine taps fused: image rows of X in a rolling LDS window with zero halo columns / a zero slot for rows outside the
     image, the tap shift as an LDS address, partial tiles + one reducing / transposing kernel) against the fp32 weight gradient of F.conv2d and
     against the tap-shifted TN GEMM form it replaces: every row count per k-step (W = 30 .. 128), two concat sources, image borders inside a
-    piece (B > 1), a piece count that does not divide the rows, and the decoder's own 2 x 120 x 120 x 512 -> 512 shape."""
+    piece (B > 1), a piece count that does not divide the rows, the decoder's own 2 x 120 x 120 x 512 -> 512 shape, and a skip source whose
+    channels do not fill the last 64-channel tile (Swin-T's conv1_2: 384 + 96)."""
     from lavt_hip import ops, _capi as K
     Cin = C1 + C2
     assert int(K.lib.lavt_conv3x3_wgrad_ws(B, H, W, Cout, Cin, C1 if C2 else Cin)) > 0
