@@ -224,12 +224,13 @@ int lavt_gemm_tn_grouped_sk(const lavt_gemm_tn_t* probs, int n, float* scratch, 
 /* 3x3 / pad 1 / no-bias convolution weight gradient with the nine taps fused (ABI v5; bf16; csrc/conv_wgrad.hip) -- the gradient autograd computes for
  * SimpleDecoding's conv1_4 .. conv2_2 (lib/mask_predictor.py:60-97):  dW[co][ci][tap] += sum_p dY[p][co] * X[p + (dy, dx)][ci],
  * tap = (dy + 1) * 3 + (dx + 1), pixels p over B images of H x W (NHWC rows), X = the channel concat of x1 (c1 channels) and x2 (Cin - c1; NULL
- * for a single source).  dW is the [Cout][Cin][3][3] parameter gradient itself (accumulated into).  `parts`: caller-lent fp32 scratch of
+ * for a single source).  dW is the [Cout][Cin][3][3] parameter gradient itself: accumulate != 0 adds to it, 0 overwrites it (a zeroed buffer with
+ * this one writer: saves reading it).  `parts`: caller-lent fp32 scratch of
  * lavt_conv3x3_wgrad_ws(...) floats (partial tiles of the split pixel reduction; no atomics, run-to-run identical); _ws returns 0 for shapes the
  * kernel does not cover (Cout % 128, Cin % 8, c1 % 64, W <= 128) -- use lavt_gemm_tn's tap-shifted form + lavt_unpack_conv_grad then. */
 int64_t lavt_conv3x3_wgrad_ws(int B, int H, int W, int Cout, int Cin, int c1);
 int lavt_conv3x3_wgrad(const void* dy, int64_t ldy, const void* x1, int64_t ldx1, const void* x2, int64_t ldx2, int c1, int B, int H, int W, int Cout,
-                       int Cin, float* parts, int64_t parts_floats, float* dW, const void* zeros, void* stream);
+                       int Cin, float* parts, int64_t parts_floats, float* dW, int accumulate, const void* zeros, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Shifted-window attention core (WindowAttention.forward, lib/backbone.py:123-140; mask :634-652).
@@ -353,6 +354,11 @@ int lavt_norm_bwd_apply(int dtype, const void* dy, const void* x, const void* y,
 /* dx = dy * act'(pre)   (GELU of Mlp / PWAM projections, ReLU of res_gate) */
 int lavt_act_bwd(int dtype, int act, const void* dy, const void* pre, void* dx, int64_t n, void* stream);
 /* language gate, lib/backbone.py:669:  xo = x + tanh(gpre) * r ;  backward gives dgpre, dr (+= into dr_acc semantics: written) */
+/* O(batch) glue of a forward, one launch each (ABI v5).  lavt_lang_mask: l_mask [B][n_l] (float32, or int64 with is_int64 = 1) -> mask_rows [B * n_l]
+ * (float) and maskbias [B][ld] = 1e4 * m - 1e4, -1e4 beyond n_l (lib/backbone.py:1360).  lavt_droppath_factors: f[n][B] = floor(keep[n] + u[n][B]) / keep[n]
+ * (timm drop_path, the reference's DropPath: lib/backbone.py:6, 240-245) from one uniform draw u. */
+int lavt_lang_mask(const void* l_mask, int is_int64, float* mask_rows, float* maskbias, int B, int n_l, int ld, void* stream);
+int lavt_droppath_factors(const float* u, const float* keep, float* f, int n, int B, void* stream);
 int lavt_gate_fwd(int dtype, const void* x, const void* gpre, const void* r, void* xo, int64_t n, void* stream);
 int lavt_gate_bwd(int dtype, const void* dxo, const void* gpre, const void* r, const void* dr_add, void* dgpre, void* dr, int64_t n, void* stream); /* dr = dxo * tanh(gpre) (+ dr_add) */
 

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wgrad3x3_kernel(const CwArgs 
 // (1024 blocks for the 512 -> 512 convolution: the 75 MB of partial tiles are read by the whole chip).  Reads: the pieces' float4 records,
 // lane-linear (1 KB per wave-load, four pieces in flight per thread); the sums are scattered into an LDS image of the 16 x 144 output block and
 // leave as 16 contiguous runs of 144 floats.
-__global__ __launch_bounds__(256) void conv_wgrad3x3_reduce(const float4* __restrict__ parts, int pieces, int tiles, int tiles_j, int Cin, float* __restrict__ dW) {
+__global__ __launch_bounds__(256) void conv_wgrad3x3_reduce(const float4* __restrict__ parts, int pieces, int tiles, int tiles_j, int Cin, float* __restrict__ dW, int accumulate) {
     __shared__ float t[16][145];
     const int tile = blockIdx.x, wave = blockIdx.y >> 2, i = blockIdx.y & 3, wi = wave >> 2, wj = wave & 3;
     const int tile_i = tile / tiles_j, tile_j = tile - tile_i * tiles_j;
@@ -261,7 +261,10 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_reduce(const float4* __rest
     const int ci0 = tile_j * CW_BJ + wj * 16, nvalid = min(16, Cin - ci0) * 9;          // (<= 0 for a 16-channel block beyond Cin)
     for (int e = threadIdx.x; e < 16 * 144; e += 256) {
         const int r = e / 144, c = e - r * 144;
-        if (c < nvalid) dW[((int64_t)(co0 + r) * Cin + ci0) * 9 + c] += t[r][c];
+        if (c < nvalid) {
+            float* dst = dW + ((int64_t)(co0 + r) * Cin + ci0) * 9 + c;
+            *dst = accumulate ? *dst + t[r][c] : t[r][c];          // (a zeroed gradient buffer with one writer: plain stores save the read of dW -- 9-28 MB per launch)
+        }
     }
 }
 
@@ -286,7 +289,7 @@ extern "C" int64_t lavt_conv3x3_wgrad_ws(int B, int H, int W, int Cout, int Cin,
 }
 
 extern "C" int lavt_conv3x3_wgrad(const void* dy, int64_t ldy, const void* x1, int64_t ldx1, const void* x2, int64_t ldx2, int c1, int B, int H, int W, int Cout,
-                                  int Cin, float* parts, int64_t parts_floats, float* dW, const void* zeros, void* stream) {
+                                  int Cin, float* parts, int64_t parts_floats, float* dW, int accumulate, const void* zeros, void* stream) {
     if (x2 == nullptr) c1 = Cin;
     LAVT_CHECK_ARG(dy && x1 && parts && dW && zeros, "lavt_conv3x3_wgrad: null argument");
     LAVT_CHECK_ARG(cw_supported(B, H, W, Cout, Cin, c1), "lavt_conv3x3_wgrad: needs Cout %% 128 == 0, Cin %% 8 == 0, c1 %% 64 == 0, W <= 128 (ask lavt_conv3x3_wgrad_ws first)");
@@ -318,7 +321,7 @@ extern "C" int lavt_conv3x3_wgrad(const void* dy, int64_t ldy, const void* x1, i
     const int ks = (W + 31) / 32;
     if (ks == 1) CW_LAUNCH(1); else if (ks == 2) CW_LAUNCH(2); else if (ks == 3) CW_LAUNCH(3); else CW_LAUNCH(4);
 #undef CW_LAUNCH
-    hipLaunchKernelGGL(conv_wgrad3x3_reduce, dim3(grid.x, 32), dim3(256), 0, st, reinterpret_cast<const float4*>(parts), pieces, (int)grid.x, tiles_j, Cin, dW);
+    hipLaunchKernelGGL(conv_wgrad3x3_reduce, dim3(grid.x, 32), dim3(256), 0, st, reinterpret_cast<const float4*>(parts), pieces, (int)grid.x, tiles_j, Cin, dW, accumulate);
     LAVT_CHECK_LAUNCH("lavt_conv3x3_wgrad");
     return LAVT_OK;
 }

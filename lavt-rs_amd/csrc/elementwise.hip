@@ -609,6 +609,43 @@ extern "C" int lavt_act_bwd(int dtype, int act, const void* dy, const void* pre,
     LAVT_CHECK_LAUNCH("lavt_act_bwd");
     return LAVT_OK;
 }
+// ---------------------------------------------------------------------------------------------- O(batch) glue of a forward, one launch each
+// (as torch ops these were ~10 element-wise launches of ~5 us per step, each a node of the captured chain)
+// language mask l_mask [B][n_l] (float32 or int64, 0 / 1) -> mask_rows [B * n_l] (the float mask) and maskbias [B][ld] = 1e4 * m - 1e4, -1e4 beyond
+// n_l (reference lib/backbone.py:1360: padded words get -1e4 before the softmax over words)
+__global__ void lang_mask_kernel(const float* mf, const int64_t* mi, float* rows, float* bias, int B, int n_l, int ld) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * ld) return;
+    const int b = e / ld, j = e - b * ld;
+    float m = 0.f;
+    if (j < n_l) {
+        m = mf ? mf[b * n_l + j] : (float)mi[b * n_l + j];
+        rows[b * n_l + j] = m;
+    }
+    bias[e] = j < n_l ? 1e4f * m - 1e4f : -1e4f;
+}
+extern "C" int lavt_lang_mask(const void* l_mask, int is_int64, float* mask_rows, float* maskbias, int B, int n_l, int ld, void* stream) {
+    LAVT_CHECK_ARG(l_mask && mask_rows && maskbias && B > 0 && n_l > 0 && ld >= n_l, "lavt_lang_mask: bad arguments");
+    hipLaunchKernelGGL(lang_mask_kernel, dim3(cdiv((long)B * ld, 256)), dim3(256), 0, ST, is_int64 ? nullptr : (const float*)l_mask, is_int64 ? (const int64_t*)l_mask : nullptr,
+                       mask_rows, maskbias, B, n_l, ld);
+    LAVT_CHECK_LAUNCH("lavt_lang_mask");
+    return LAVT_OK;
+}
+// DropPath factors of all branches of a forward from one uniform draw u [n][B]: f = floor(keep[n] + u) / keep[n] (timm's drop_path; reference
+// lib/backbone.py:6, 240-245)
+__global__ void droppath_factors_kernel(const float* u, const float* keep, float* f, int n, int B) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * B) return;
+    const float k = keep[e / B];
+    f[e] = floorf(k + u[e]) / k;
+}
+extern "C" int lavt_droppath_factors(const float* u, const float* keep, float* f, int n, int B, void* stream) {
+    LAVT_CHECK_ARG(u && keep && f && n > 0 && B > 0, "lavt_droppath_factors: bad arguments");
+    hipLaunchKernelGGL(droppath_factors_kernel, dim3(cdiv((long)n * B, 256)), dim3(256), 0, ST, u, keep, f, n, B);
+    LAVT_CHECK_LAUNCH("lavt_droppath_factors");
+    return LAVT_OK;
+}
+
 extern "C" int lavt_gate_fwd(int dtype, const void* x, const void* gpre, const void* r, void* xo, int64_t n, void* stream) {
     LAVT_CHECK_ARG(x && gpre && r && xo && n > 0 && n % EPC_OF(dtype) == 0, "lavt_gate_fwd: bad arguments");
     const int64_t nc = n / EPC_OF(dtype);

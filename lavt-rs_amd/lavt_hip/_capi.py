@@ -138,10 +138,12 @@ class GemmTN(C.Structure):
 _PROTOTYPES = {
     "lavt_abi_version": [],
     "lavt_tuning_reload": [],
+    "lavt_lang_mask": [vp, i32, vp, vp, i32, i32, i32, vp],
+    "lavt_droppath_factors": [vp, vp, vp, i32, i32, vp],
     "lavt_conv3x3_wgrad_ws": [i32, i32, i32, i32, i32, i32],
     "lavt_gemm_tn_grouped_sk_ws": [C.POINTER(GemmTN), i32],
     "lavt_gemm_tn_grouped_sk": [C.POINTER(GemmTN), i32, vp, i64, vp],
-    "lavt_conv3x3_wgrad": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp, vp, vp],
+    "lavt_conv3x3_wgrad": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp, i32, vp, vp],
     "lavt_gemm_nt": [C.POINTER(GemmNT), vp],
     "lavt_gemm_tn": [C.POINTER(GemmTN), vp],
     "lavt_splitk_reduce": [i32, vp, i32, i64, i32, vp, i64, vp],

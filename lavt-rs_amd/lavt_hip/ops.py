@@ -674,6 +674,25 @@ class _LnDeferred:
 ln_deferred = _LnDeferred()
 
 
+def lang_mask(l_mask, B, n_l):
+    """(B, n_l[, 1]) 0 / 1 language mask -> (mask_rows [B * n_l] float32, maskbias [B, KV_LD] = 1e4 * m - 1e4 with -1e4 in the padding slots)"""
+    m = l_mask.reshape(B, n_l)
+    if m.dtype not in (torch.float32, torch.int64):
+        m = m.to(torch.float32)
+    m = m.contiguous()
+    rows = torch.empty(B * n_l, dtype=torch.float32, device=m.device)
+    bias = torch.empty(B, KV_LD, dtype=torch.float32, device=m.device)
+    K.check(K.lib.lavt_lang_mask(K.ptr(m), int(m.dtype == torch.int64), K.ptr(rows), K.ptr(bias), B, n_l, KV_LD, K.stream()))
+    return rows, bias
+
+
+def droppath_factors(u, keep):
+    """u [n, B] uniform draws, keep [n, 1] keep probabilities -> floor(keep + u) / keep (timm's drop_path factors), one launch"""
+    f = torch.empty_like(u)
+    K.check(K.lib.lavt_droppath_factors(K.ptr(u), K.ptr(keep.contiguous()), K.ptr(f), u.shape[0], u.shape[1], K.stream()))
+    return f
+
+
 def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     if x.dtype == dtype:
         return x
@@ -2275,7 +2294,9 @@ class _ConvTaps(torch.autograd.Function):
                 scr = _tn_parts(ws, dy.device)
                 if K.prof.enabled:
                     K.prof.note = {"flops": 2.0 * Cout * taps * Cin * M, "shape": f"conv-wgrad {Cout}x{taps * Cin}x{M}"}
-                K.check(K.lib.lavt_conv3x3_wgrad(K.ptr(dy), Cout, K.ptr(x1), C1, K.ptr(x2), C2, C1, B, H, W, Cout, Cin, K.ptr(scr), scr.numel(), K.ptr(dW),
+                # dW is either the parameter's slice of the zeroed flat gradient buffer (one weight gradient per parameter per step: sinks.buf refuses a
+                # second) or fresh zeros: the reduction overwrites instead of adding
+                K.check(K.lib.lavt_conv3x3_wgrad(K.ptr(dy), Cout, K.ptr(x1), C1, K.ptr(x2), C2, C1, B, H, W, Cout, Cin, K.ptr(scr), scr.numel(), K.ptr(dW), 0,
                                                  _zero_page(dy.device), K.stream()))
                 return
             packed = torch.zeros(Cout, taps * Cin, dtype=torch.float32, device=dy.device)

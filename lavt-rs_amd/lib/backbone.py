@@ -39,11 +39,7 @@ class _LangCtx:
             raise ValueError(f"PWAM supports at most {ops.KV_LD} language tokens, got {n_l}")
         self.B, self.n_l = B, n_l
         self.lt = ops.transpose_last2(l.float(), dtype).view(B * n_l, Cl)            # (B*N_l, 768) token-major
-        m = l_mask.reshape(B, n_l).to(torch.float32)
-        self.mask_rows = m.reshape(B * n_l).contiguous()
-        bias = torch.full((B, ops.KV_LD), -1e4, dtype=torch.float32, device=l.device)
-        bias[:, :n_l] = 1e4 * m - 1e4                                                # lib/backbone.py:1360
-        self.maskbias = bias
+        self.mask_rows, self.maskbias = ops.lang_mask(l_mask, B, n_l)                 # float mask rows, 1e4 * m - 1e4 (lib/backbone.py:1360): one launch
         self.kv_map = rowmaps.kv_pad_map(B, n_l, ops.KV_LD, l.device)
         self.plan, self.kv_done = None, None
 
@@ -427,7 +423,7 @@ class MultiModalSwinTransformer(nn.Module):
         if keep is None or keep.device != device or keep.shape[0] != 2 * len(live):
             keep = torch.tensor([1.0 - d.drop_prob for d in live for _ in (0, 1)], dtype=torch.float32, device=device)[:, None]
             self._dp_keep = keep
-        f = torch.floor(keep + torch.rand(2 * len(live), B, device=device, dtype=torch.float32)) / keep
+        f = ops.droppath_factors(torch.rand(2 * len(live), B, device=device, dtype=torch.float32), keep)      # floor(keep + u) / keep, one launch
         for i, d in enumerate(live):
             d._batched = [f[2 * i], f[2 * i + 1]]
 

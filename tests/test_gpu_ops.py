@@ -1030,3 +1030,22 @@ def test_fp16_autocast_runs_as_bf16(monkeypatch):
     with torch.autocast("cuda", dtype=torch.float16):
         with pytest.raises(RuntimeError, match="float16"):
             runtime.compute_dtype()
+
+
+def test_forward_glue_kernels():
+    """The O(batch) glue of a forward as single launches: language mask -> float rows + the -1e4 word bias (lib/backbone.py:1360) for float and
+    int64 masks, and timm's drop_path factors floor(keep + u) / keep -- bit-identical to the torch expressions they replace."""
+    from lavt_hip import ops
+    g = torch.Generator().manual_seed(3)
+    B, n_l = 3, 20
+    m = (torch.rand(B, n_l, 1, generator=g) > 0.4)
+    for mm in (m.float(), m.long(), m):
+        rows, bias = ops.lang_mask(mm.to(dev()), B, n_l)
+        mf = m.float().reshape(B, n_l)
+        ref = torch.full((B, ops.KV_LD), -1e4)
+        ref[:, :n_l] = 1e4 * mf - 1e4
+        assert torch.equal(rows.cpu(), mf.reshape(-1)) and torch.equal(bias.cpu(), ref)
+    u = torch.rand(48, 2, generator=g)
+    keep = (1.0 - torch.linspace(0.0125, 0.3, 48))[:, None]
+    f = ops.droppath_factors(u.to(dev()), keep.to(dev()))
+    assert torch.equal(f.cpu(), torch.floor(keep + u) / keep)

@@ -14,5 +14,5 @@ dW = torch.zeros(Cout, Cin * 9, device=dev)
 ws = int(K.lib.lavt_conv3x3_wgrad_ws(B, H, W, Cout, Cin, Cin))
 scr = ops._tn_parts(ws, dev)
 for _ in range(6):
-    K.check(K.lib.lavt_conv3x3_wgrad(K.ptr(dy), Cout, K.ptr(x), Cin, None, 0, Cin, B, H, W, Cout, Cin, K.ptr(scr), scr.numel(), K.ptr(dW), ops._zero_page(dev), K.stream()))
+    K.check(K.lib.lavt_conv3x3_wgrad(K.ptr(dy), Cout, K.ptr(x), Cin, None, 0, Cin, B, H, W, Cout, Cin, K.ptr(scr), scr.numel(), K.ptr(dW), 0, ops._zero_page(dev), K.stream()))
 torch.cuda.synchronize()

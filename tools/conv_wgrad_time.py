@@ -26,7 +26,7 @@ for (B, H, W, C1, C2, Cout) in shapes:
     scr = ops._tn_parts(ws, dev)
 
     def new():
-        K.check(K.lib.lavt_conv3x3_wgrad(K.ptr(dy), Cout, K.ptr(x1), C1, K.ptr(x2), C2, C1, B, H, W, Cout, Cin, K.ptr(scr), scr.numel(), K.ptr(dW), ops._zero_page(dev), K.stream()))
+        K.check(K.lib.lavt_conv3x3_wgrad(K.ptr(dy), Cout, K.ptr(x1), C1, K.ptr(x2), C2, C1, B, H, W, Cout, Cin, K.ptr(scr), scr.numel(), K.ptr(dW), 0, ops._zero_page(dev), K.stream()))
     dW.zero_(); old(); torch.cuda.synchronize(); ref = dW.clone()
     dW.zero_(); new(); torch.cuda.synchronize()
     err = float((dW - ref).abs().max() / ref.abs().max())
