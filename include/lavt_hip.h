@@ -254,6 +254,20 @@ int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bias, int bias
                          const void* out, const void* dout, const float* lse, void* dqkv, const float* table, float* dtable,
                          float* ws, int64_t ws_floats, float* parts, int wd, int wh, int ww, int nwin, int N, int heads, int head_dim, float scale,
                          void* stream);
+/* Chained table-gradient binning (ABI v5, bf16 MFMA path, deferred form).  The binning of a launch's dS slabs is needed by nothing before the end of
+ * backward, yet as its own launch it sat on the critical chain (7.5 us x 24 per Swin-B step).  lavt_window_attn_bwd_chained does not launch it: it
+ * describes it in *mine, and runs the job `prev` describes -- the binning of an EARLIER launch, whose slabs must still be alive -- as extra
+ * workgroups of this launch (they fill CU slots the (window, head) workgroups leave free).  lavt_attn_dtable_run launches a job on its own (the last
+ * one of a backward pass).  parts as in lavt_window_attn_bwd. */
+typedef struct {
+    const void* slab;
+    float* part;
+    int32_t slab_ld, wd, wh, ww, nwin, N, heads, rows_per_block, win_per_group, gx, gz;
+} lavt_dtable_job_t;
+int lavt_window_attn_bwd_chained(int dtype, const void* qkv, int bias_ld, const int8_t* region, int nw_img, const void* out, const void* dout,
+                                 const float* lse, void* dqkv, const float* table, float* ws, int64_t ws_floats, float* parts, int wd, int wh, int ww,
+                                 int nwin, int N, int heads, int head_dim, float scale, const lavt_dtable_job_t* prev, lavt_dtable_job_t* mine, void* stream);
+int lavt_attn_dtable_run(const lavt_dtable_job_t* job, void* stream);
 /* 1 when lavt_window_attn_fwd/bwd take the bias from the table for this (dtype, N) -- no dense bias / lavt_relpos_expand needed */
 int lavt_attn_uses_table(int dtype, int N);
 /* Deferred table gradient (bf16 MFMA path): with `parts` != NULL (a caller-owned buffer of lavt_window_attn_bwd_pieces(...) * heads * (2wd-1)(2wh-1)(2ww-1)

@@ -391,7 +391,8 @@ int lavt_window_attn_fwd_mfma(const void* qkv, const float* table, const int8_t*
                               int wd, int wh, int ww, int nwin, int N, int heads, float scale, hipStream_t st);
 int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, const void* out, const void* dout,
                               const float* lse, void* dqkv, float* dtable, int bias_ld, float* ws, float* parts, int wd, int wh, int ww, int nwin, int N,
-                              int heads, float scale, hipStream_t st);
+                              int heads, float scale, hipStream_t st, const lavt_dtable_job_t* prev, lavt_dtable_job_t* mine);
+int lavt_attn_dtable_run_mfma(const lavt_dtable_job_t* jb, hipStream_t st);
 int lavt_attn_dtable_finish_multi_impl(const int64_t* desc, int n, int max_R, int max_heads, hipStream_t st);
 int lavt_window_attn_bwd_pieces_mfma(int nwin, int N, int heads);
 int64_t lavt_window_attn_bwd_ws_mfma(int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww);
@@ -426,13 +427,31 @@ extern "C" int lavt_window_attn_bwd(int dtype, const void* qkv, const float* bia
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // the bf16 MFMA kernel takes the bias values from an LDS copy of the table and needs one fp32 [N][bias_ld] slab per (window, head)
     const bool fast = use_mfma(dtype, N, bias_ld) && ws && ws_floats >= lavt_window_attn_bwd_ws_mfma(nwin, N, heads, bias_ld, wd, wh, ww);
-    if (fast) return lavt_window_attn_bwd_mfma(qkv, table, region, nw_img, out, dout, lse, dqkv, dtable, bias_ld, ws, parts, wd, wh, ww, nwin, N, heads, scale, st);
+    if (fast) return lavt_window_attn_bwd_mfma(qkv, table, region, nw_img, out, dout, lse, dqkv, dtable, bias_ld, ws, parts, wd, wh, ww, nwin, N, heads, scale, st, nullptr, nullptr);
     LAVT_CHECK_ARG(parts == nullptr && dtable, "lavt_window_attn_bwd: the deferred table-gradient form exists on the bf16 MFMA path only");
     LAVT_CHECK_ARG(bias && bias_ld >= N, "lavt_window_attn_bwd: the exact-fp32 kernel needs the dense bias (lavt_relpos_expand)");
     if (dtype == LAVT_F32) return launch_bwd<float>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, nullptr, dtable, wd, wh, ww, nwin, N, heads, scale, st);
     if (dtype == LAVT_BF16) return launch_bwd<bf16>(qkv, bias, bias_ld, region, nw_img, out, dout, lse, dqkv, nullptr, dtable, wd, wh, ww, nwin, N, heads, scale, st);
     lavt_set_error("lavt_window_attn_bwd: bad dtype %d", dtype);
     return LAVT_ERR_INVALID;
+}
+// The bf16 MFMA backward in its deferred-table form with the binning CHAINED: this launch's binning is not launched but described in *mine, and the
+// binning `prev` describes (an earlier launch's, NULL for none) runs as extra workgroups of this launch.  lavt_attn_dtable_run launches a job alone.
+extern "C" int lavt_window_attn_bwd_chained(int dtype, const void* qkv, int bias_ld, const int8_t* region, int nw_img, const void* out, const void* dout,
+                                            const float* lse, void* dqkv, const float* table, float* ws, int64_t ws_floats, float* parts, int wd, int wh, int ww,
+                                            int nwin, int N, int heads, int head_dim, float scale, const lavt_dtable_job_t* prev, lavt_dtable_job_t* mine,
+                                            void* stream) {
+    LAVT_CHECK_ARG(head_dim == HD, "lavt_window_attn_bwd_chained: head_dim %d != 32", head_dim);
+    LAVT_CHECK_ARG(qkv && out && dout && lse && dqkv && table && parts && mine && nwin > 0 && N > 0 && heads > 0, "lavt_window_attn_bwd_chained: bad arguments");
+    LAVT_CHECK_ARG(wd > 0 && wh > 0 && ww > 0 && N <= wd * wh * ww, "lavt_window_attn_bwd_chained: window shape (wd, wh, ww) must cover N tokens");
+    LAVT_CHECK_ARG(use_mfma(dtype, N, bias_ld) && ws && ws_floats >= lavt_window_attn_bwd_ws_mfma(nwin, N, heads, bias_ld, wd, wh, ww),
+                   "lavt_window_attn_bwd_chained: bf16 MFMA path only (N <= 400, scratch of lavt_window_attn_bwd_ws floats)");
+    return lavt_window_attn_bwd_mfma(qkv, table, region, nw_img, out, dout, lse, dqkv, nullptr, bias_ld, ws, parts, wd, wh, ww, nwin, N, heads, scale,
+                                     reinterpret_cast<hipStream_t>(stream), prev, mine);
+}
+extern "C" int lavt_attn_dtable_run(const lavt_dtable_job_t* job, void* stream) {
+    LAVT_CHECK_ARG(job && job->slab && job->part && job->gx > 0 && job->gz > 0 && job->heads > 0, "lavt_attn_dtable_run: bad job");
+    return lavt_attn_dtable_run_mfma(job, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t lavt_window_attn_bwd_ws(int dtype, int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww) {

@@ -14,6 +14,8 @@
 //   dV = P^T dO, dK = dS^T Q, dQ = dS K with MFMA, reading the k-major operands with the transposing LDS read.
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -205,15 +207,41 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
 // gradient (dbias) is only written when no table pointer is given.
 constexpr int R_LD = 40;        // bf16 elements per LDS row of Q / K / V / dO (80 B rows, 16-byte aligned chunks)
 
+// Table-gradient binning of ONE attention-backward launch (wattn_dtable_kernel's arguments).  The binning kernel (7.5 us x 24 per Swin-B step)
+// sits between the attention backward and the qkv data gradient without either needing it: a launch can carry the job of the PREVIOUS
+// launch (the layer processed just before in backward, whose dS slabs are still in the Infinity Cache) as extra workgroups that run in the
+// CU slots its own 288 workgroups leave free (lavt_window_attn_bwd_chained).
+struct DtableJob {
+    const bf16* slab;
+    float* part;
+    int slab_ld, wd, wh, ww, nwin, N, heads, rows_per_block, win_per_group, gx, gz;      // gx, gz: the binning grid (gy = heads)
+};
+__device__ void dtable_block(const bf16* __restrict__ slab, float* __restrict__ part, int slab_ld, int wd, int wh, int ww, int nwin, int N, int heads,
+                             int rows_per_block, int win_per_group, int bx, int h, int bz, int gx, int tid, char* smem_raw);
+
 template <int NT, int WAVES, bool REGION, bool FULL>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void wattn_bwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                       const int8_t* __restrict__ region, int nw_img, const bf16* __restrict__ out,
                                                       const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                       bf16* __restrict__ dqkv, bf16* __restrict__ slab, int slab_ld,
-                                                      int wd, int wh, int ww, int nwin, int N, int heads, float scale, int win_per_block) {
+                                                      int wd, int wh, int ww, int nwin, int N, int heads, float scale, int win_per_block,
+                                                      int attn_blocks, const DtableJob job) {
     constexpr int KS = (NT + 1) / 2, NP = KS * 32;         // tiles are consumed in pairs (k = 32)
     constexpr int NTHR = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if constexpr (WAVES == 8) {
+        if ((int)blockIdx.x >= attn_blocks) {              // riders: the previous launch's binning, two 256-thread binning blocks per workgroup
+            const int half = threadIdx.x >> 8, u = 2 * ((int)blockIdx.x - attn_blocks) + half;
+            const int units = job.gx * job.heads * job.gz;
+            // (both halves take the same barriers: a half without a unit runs on unit 0's geometry with its stores masked off)
+            const int uu = u < units ? u : 0;
+            const int bx = uu % job.gx, hh = (uu / job.gx) % job.heads, bz = uu / (job.gx * job.heads);
+            const int R = (2 * job.wd - 1) * (2 * job.wh - 1) * (2 * job.ww - 1);
+            dtable_block(job.slab, u < units ? job.part : nullptr, job.slab_ld, job.wd, job.wh, job.ww, job.nwin, job.N, job.heads, job.rows_per_block,
+                         job.win_per_group, bx, hh, bz, job.gx, threadIdx.x & 255, smem_raw + half * (size_t)((R + job.N) * 4 + 16));
+            return;
+        }
+    }
     bf16* Qs = reinterpret_cast<bf16*>(smem_raw);
     bf16* Ks = Qs + NP * R_LD;
     bf16* Vs = Ks + NP * R_LD;
@@ -420,22 +448,21 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
 // grid = (row chunks, heads, window groups).  A wave walks rows i of its chunk, lanes cover the keys j (coalesced row reads), the sum over
 // the group's windows stays in registers; the (i, j) -> table-index binning then costs one LDS atomic per (i, j) per workgroup (not per
 // window), and one global atomic per touched table entry per workgroup.
-__global__ __launch_bounds__(256) void wattn_dtable_kernel(const bf16* __restrict__ slab, float* __restrict__ part, int slab_ld, int wd, int wh,
-                                                           int ww, int nwin, int N, int heads, int rows_per_block, int win_per_group) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ void dtable_block(const bf16* __restrict__ slab, float* __restrict__ part, int slab_ld, int wd, int wh, int ww, int nwin, int N, int heads,
+                             int rows_per_block, int win_per_group, int bx, int h, int bz, int gx, int tid, char* smem_raw) {
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
     const int centre = ((wd - 1) * (2 * wh - 1) + (wh - 1)) * (2 * ww - 1) + (ww - 1);
     float* hist = reinterpret_cast<float*>(smem_raw);
     int* bs = reinterpret_cast<int*>(hist + R);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y;
+    const int lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < R; e += 256) hist[e] = 0.f;
     for (int e = tid; e < N; e += 256) {
         const int dz = e / (wh * ww), hy = (e / ww) % wh, wx = e % ww;
         bs[e] = (dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx;
     }
     __syncthreads();
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
-    const int w0 = blockIdx.z * win_per_group, w1 = min(nwin, w0 + win_per_group);
+    const int r0 = bx * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    const int w0 = bz * win_per_group, w1 = min(nwin, w0 + win_per_group);
     const int64_t wstride = (int64_t)heads * N * slab_ld;
     for (int i = r0 + wave; i < r1; i += 4) {
         const bf16* row = slab + ((int64_t)w0 * heads + h) * N * slab_ld + (int64_t)i * slab_ld;
@@ -472,9 +499,16 @@ __global__ __launch_bounds__(256) void wattn_dtable_kernel(const bf16* __restric
     __syncthreads();
     // this workgroup's histogram -> part[(z * chunks + chunk) * heads + h][R] (contiguous, plain stores); wattn_dtable_finish adds the pieces up.
     // (Flushing with atomics straight into dtable[R][heads] puts every lane in a different 64-byte segment: ~17x below the atomic rate.)
-    float* dst = part + (((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * heads + h) * R;
+    if (part == nullptr) return;                           // (a rider half without a unit)
+    float* dst = part + (((int64_t)bz * gx + bx) * heads + h) * R;
     for (int e = tid; e < R; e += 256) dst[e] = hist[e];
 }
+__global__ __launch_bounds__(256) void wattn_dtable_kernel(const bf16* __restrict__ slab, float* __restrict__ part, int slab_ld, int wd, int wh,
+                                                           int ww, int nwin, int N, int heads, int rows_per_block, int win_per_group) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    dtable_block(slab, part, slab_ld, wd, wh, ww, nwin, N, heads, rows_per_block, win_per_group, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, threadIdx.x, smem_raw);
+}
+
 __global__ void wattn_dtable_finish(const float* __restrict__ part, float* __restrict__ dtable, int pieces, int per_z, int heads, int R) {
     // blockIdx.z walks a group of per-workgroup histograms (8 loads in flight per thread); the groups meet in dtable through atomics
     const int e = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y;
@@ -590,16 +624,44 @@ int lavt_window_attn_bwd_pieces_mfma(int nwin, int N, int heads) {
     return wgroups * cdiv(N, rpb);
 }
 
+static_assert(sizeof(DtableJob) == sizeof(lavt_dtable_job_t), "lavt_dtable_job_t mirrors DtableJob");
+int lavt_attn_dtable_run_mfma(const lavt_dtable_job_t* jb, hipStream_t st) {
+    const int R = (2 * jb->wd - 1) * (2 * jb->wh - 1) * (2 * jb->ww - 1);
+    hipLaunchKernelGGL(wattn_dtable_kernel, dim3(jb->gx, jb->heads, jb->gz), dim3(256), (size_t)(R + jb->N) * 4, st, reinterpret_cast<const bf16*>(jb->slab), jb->part,
+                       jb->slab_ld, jb->wd, jb->wh, jb->ww, jb->nwin, jb->N, jb->heads, jb->rows_per_block, jb->win_per_group);
+    LAVT_CHECK_LAUNCH("lavt_attn_dtable_run");
+    return LAVT_OK;
+}
+// prev: the binning job of an EARLIER launch to run inside this one (8-wave variants; launched on its own in front otherwise); mine != NULL: this
+// launch's own binning is NOT launched but described in *mine (the caller hands it to the next launch or to lavt_attn_dtable_run)
 int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t* region, int nw_img, const void* out, const void* dout,
                               const float* lse, void* dqkv, float* dtable, int bias_ld, float* ws, float* parts, int wd, int wh, int ww, int nwin, int N,
-                              int heads, float scale, hipStream_t st) {
+                              int heads, float scale, hipStream_t st, const lavt_dtable_job_t* prev, lavt_dtable_job_t* mine) {
     if (N > 400 || !table || !(dtable || parts) || !ws || bias_ld % 4) { lavt_set_error("lavt_window_attn_bwd(mfma): N=%d (<= 400), table, dtable and scratch required", N); return LAVT_ERR_INVALID; }
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
     // >= 2 workgroups per CU when there is that much work
     int wpb = (int)(((long)nwin * heads + 767) / 768);
     if (wpb < 1) wpb = 1;
     const int chunks = cdiv(nwin, wpb);
-    dim3 grid(chunks * heads);
+    const int force_waves = lavt_tuning().attn_bwd_waves;
+    const int waves = force_waves ? force_waves : 8;
+    // riders only on the 8-wave variants that sit two per CU (N <= 160): a rider occupies a whole workgroup slot, and the 392-token video kernel (149 KB of
+    // LDS, one workgroup per CU) would run them as an extra round
+    const bool eight = !(N <= 64) && !(N == 144 && waves != 8) && N <= 160;
+    DtableJob job{};
+    int riders = 0;
+    if (prev != nullptr) {
+        const int Rp = (2 * prev->wd - 1) * (2 * prev->wh - 1) * (2 * prev->ww - 1);
+        if (eight && 2 * (size_t)((Rp + prev->N) * 4 + 16) <= 32768) {
+            memcpy(&job, prev, sizeof(job));
+            riders = cdiv(prev->gx * prev->heads * prev->gz, 2);
+        } else {
+            const int rc = lavt_attn_dtable_run_mfma(prev, st);
+            if (rc != LAVT_OK) return rc;
+        }
+    }
+    dim3 grid(chunks * heads + riders);
+    const int attn_blocks = chunks * heads;
 #define LAVT_BWD_K(NT_, WV_, RG_, FULL_)                                                                                                    \
     do {                                                                                                                                     \
         const size_t lds = bwd_lds_bytes<NT_>(R);                                                                                            \
@@ -612,7 +674,7 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
             reserved = lds;                                                                                                                  \
         }                                                                                                                                    \
         hipLaunchKernelGGL((wattn_bwd_mfma<NT_, WV_, RG_, FULL_>), grid, dim3(WV_ * 64), lds, st, (const bf16*)qkv, table, region, nw_img,   \
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, reinterpret_cast<bf16*>(ws), bias_ld, wd, wh, ww, nwin, N, heads, scale, wpb); \
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, reinterpret_cast<bf16*>(ws), bias_ld, wd, wh, ww, nwin, N, heads, scale, wpb, attn_blocks, job); \
     } while (0)
 #define LAVT_BWD(NT_, WV_, FULL_)                                                                                                            \
     do {                                                                                                                                     \
@@ -621,8 +683,6 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     } while (0)
     // 8 waves share one window-head, capped at 128 VGPRs so two workgroups (16 waves) sit on a CU: 5-9% faster than 4 waves x 2 at every
     // stage shape of Swin-B w12 @480 (measured, tools/attn_bench2.py).  LAVT_ATTN_BWD_WAVES=4 keeps the 4-wave variant reachable.
-    const int force_waves = lavt_tuning().attn_bwd_waves;
-    const int waves = force_waves ? force_waves : 8;
     if (N <= 64) LAVT_BWD(4, 4, false);
     else if (N == 144) { if (waves == 8) LAVT_BWD(9, 8, true); else LAVT_BWD(9, 4, true); }
     else if (N <= 144) LAVT_BWD(9, 8, false);
@@ -636,6 +696,11 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     // per-workgroup histograms [wgroups * chunks][heads][R]: after the slabs, or -- deferred form -- in the caller's persistent buffer, to be
     // summed into the table gradients of all layers by one lavt_attn_dtable_finish_multi launch at the end of backward
     float* part = parts ? parts : ws + (int64_t)nwin * heads * N * bias_ld;
+    if (mine != nullptr) {
+        mine->slab = ws; mine->part = part; mine->slab_ld = bias_ld; mine->wd = wd; mine->wh = wh; mine->ww = ww; mine->nwin = nwin; mine->N = N; mine->heads = heads;
+        mine->rows_per_block = rpb; mine->win_per_group = wpg; mine->gx = cdiv(N, rpb); mine->gz = wgroups;
+        return LAVT_OK;
+    }
     hipLaunchKernelGGL(wattn_dtable_kernel, dim3(cdiv(N, rpb), heads, wgroups), dim3(256), (size_t)(R + N) * 4, st, reinterpret_cast<const bf16*>(ws), part, bias_ld, wd, wh, ww, nwin,
                        N, heads, rpb, wpg);
     const int pieces = wgroups * cdiv(N, rpb), per_z = 16;

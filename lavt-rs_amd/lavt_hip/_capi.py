@@ -121,6 +121,12 @@ class GemmNT(C.Structure):
     ]
 
 
+class DtableJob(C.Structure):
+    """lavt_dtable_job_t: the table-gradient binning of one attention-backward launch (chained form)"""
+    _fields_ = [("slab", vp), ("part", vp), ("slab_ld", i32), ("wd", i32), ("wh", i32), ("ww", i32), ("nwin", i32), ("N", i32), ("heads", i32),
+                ("rows_per_block", i32), ("win_per_group", i32), ("gx", i32), ("gz", i32)]
+
+
 class GemmTN(C.Structure):
     _fields_ = [
         ("dtype", i32), ("I", i32), ("J", i32), ("K", i32), ("batch", i32),
@@ -138,6 +144,8 @@ class GemmTN(C.Structure):
 _PROTOTYPES = {
     "lavt_abi_version": [],
     "lavt_tuning_reload": [],
+    "lavt_window_attn_bwd_chained": [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, f32, C.POINTER(DtableJob), C.POINTER(DtableJob), vp],
+    "lavt_attn_dtable_run": [C.POINTER(DtableJob), vp],
     "lavt_lang_mask": [vp, i32, vp, vp, i32, i32, i32, vp],
     "lavt_droppath_factors": [vp, vp, vp, i32, i32, vp],
     "lavt_conv3x3_wgrad_ws": [i32, i32, i32, i32, i32, i32],

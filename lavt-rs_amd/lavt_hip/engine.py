@@ -64,6 +64,7 @@ class TrainStep:
             ops.weights.refresh_all()            # re-cast weights inside the step (for optimizers that do not maintain the compute copies)
         self.buckets.zero()
         ops.zero_arena.begin_step(self.x.device)          # one fill for every small zero-initialised buffer of the step
+        ops.dtable_chain.job, ops.dtable_chain.keep = None, None          # (a backward that raised mid-way must not leave its binning job to the next step)
         if fp8_enabled():
             ops.fp8.advance()                    # delayed scaling: last step's |max| values become this step's quantisation scales
         if self.fused_loss:                       # upsample + weighted CE (+ I/U) fused: the (B,2,H,W) logits are never written

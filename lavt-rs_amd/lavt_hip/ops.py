@@ -646,6 +646,7 @@ class _LnDeferred:
         wgrads.pending.add(id(param))
 
     def flush(self):
+        dtable_chain.flush()                     # the last attention-backward launch's binning job (chained form) runs on its own
         if self.tables:
             key = tuple(self.tables)
             if key != self.tdesc_key:
@@ -672,6 +673,31 @@ class _LnDeferred:
 
 
 ln_deferred = _LnDeferred()
+
+
+class _DtableChain:
+    """Chained table-gradient binning (lavt_window_attn_bwd_chained): an attention-backward launch leaves the binning of its dS slabs to the NEXT
+    attention-backward launch of the backward pass, which runs it as extra workgroups; the last job of a pass is launched on its own from
+    ln_deferred.flush().  The slabs (and the histogram scratch) of a pending job are kept alive here until it has run."""
+
+    def __init__(self):
+        self.job, self.keep = None, None
+        self.enabled = os.environ.get("LAVT_DTABLE_CHAIN", "1") != "0"
+
+    def launch(self, dtype, qkv, ld, region, nw_img, out, dout, lse, dqkv, table, wsb, parts, wd, wh, ww, nwin, N, heads, hd, scale):
+        mine = K.DtableJob()
+        prev = C.byref(self.job) if self.job is not None else None
+        K.check(K.lib.lavt_window_attn_bwd_chained(K.dt(dtype), K.ptr(qkv), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(_f32(table)),
+                                                   K.ptr(wsb), wsb.numel(), K.ptr(parts), wd, wh, ww, nwin, N, heads, hd, scale, prev, C.byref(mine), K.stream()))
+        self.job, self.keep = mine, (wsb, parts)
+
+    def flush(self):
+        if self.job is not None:
+            K.check(K.lib.lavt_attn_dtable_run(C.byref(self.job), K.stream()))
+            self.job, self.keep = None, None
+
+
+dtable_chain = _DtableChain()
 
 
 def lang_mask(l_mask, B, n_l):
@@ -1158,9 +1184,12 @@ class _WindowAttn(torch.autograd.Function):
         pieces = int(K.lib.lavt_window_attn_bwd_pieces(K.dt(qkv.dtype), nwin, N, heads, ld)) if (ts and ln_deferred.active()) else 0
         parts = ln_deferred.alloc(pieces * heads * R, qkv.device) if pieces > 0 else None
         _note(f"wattn-bwd {nwin * N}x{Cc} N{N}", 10.0 * nwin * heads * N * N * 32)
-        K.check(K.lib.lavt_window_attn_bwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout),
-                                           K.ptr(lse), K.ptr(dqkv), K.ptr(_f32(table)), None if parts is not None else K.ptr(dtable), K.ptr(ws),
-                                           ws.numel() if ws is not None else 0, K.ptr(parts), wd, wh, ww, nwin, N, heads, Cc // heads, scale, K.stream()))
+        if parts is not None and ws is not None and dtable_chain.enabled:
+            dtable_chain.launch(qkv.dtype, qkv, ld, region, nw_img, out, dout, lse, dqkv, table, ws, parts, wd, wh, ww, nwin, N, heads, Cc // heads, scale)
+        else:
+            K.check(K.lib.lavt_window_attn_bwd(K.dt(qkv.dtype), K.ptr(qkv), K.ptr(dense), ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout),
+                                               K.ptr(lse), K.ptr(dqkv), K.ptr(_f32(table)), None if parts is not None else K.ptr(dtable), K.ptr(ws),
+                                               ws.numel() if ws is not None else 0, K.ptr(parts), wd, wh, ww, nwin, N, heads, Cc // heads, scale, K.stream()))
         if parts is not None:          # table gradient finished with the other layers' in one launch at the end of backward
             ln_deferred.add_table(parts, pieces, heads, R, dtable, table)
             return dqkv, None, None, None, None, None
@@ -1283,9 +1312,12 @@ class _WmsaFused(torch.autograd.Function):
         pieces = int(K.lib.lavt_window_attn_bwd_pieces(K.dt(dtype), nwin, N, heads, ld)) if (ts and ln_deferred.active()) else 0
         parts = ln_deferred.alloc(pieces * heads * R, dev) if pieces > 0 else None
         _note(f"wattn-bwd {Mw}x{Cc} N{N}", 10.0 * nwin * heads * N * N * 32)
-        K.check(K.lib.lavt_window_attn_bwd(K.dt(dtype), K.ptr(qkv), None, ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(_f32(table)),
-                                           None if parts is not None else K.ptr(dtable), K.ptr(wsb), wsb.numel() if wsb is not None else 0, K.ptr(parts), 1, ws_, ws_,
-                                           nwin, N, heads, Cc // heads, scale, K.stream()))
+        if parts is not None and wsb is not None and dtable_chain.enabled:
+            dtable_chain.launch(dtype, qkv, ld, region, nw_img, out, dout, lse, dqkv, table, wsb, parts, 1, ws_, ws_, nwin, N, heads, Cc // heads, scale)
+        else:
+            K.check(K.lib.lavt_window_attn_bwd(K.dt(dtype), K.ptr(qkv), None, ld, K.ptr(region), nw_img, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(_f32(table)),
+                                               None if parts is not None else K.ptr(dtable), K.ptr(wsb), wsb.numel() if wsb is not None else 0, K.ptr(parts), 1, ws_, ws_,
+                                               nwin, N, heads, Cc // heads, scale, K.stream()))
         if parts is not None:
             ln_deferred.add_table(parts, pieces, heads, R, dtable, table)
             g_table = None
