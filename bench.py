@@ -184,7 +184,7 @@ def profile_step(step, cfg, device, reps=3):
                 "bytes_per_launch": dv[3] / dv[0], "launches_per_step": round(dv[0] / reps, 1), "us_per_step": round(dv[1] / reps, 1), "traffic": None}
     if top[0][0] != (dname, dshape):
         roof["unannotated_top"] = {"entry": top[0][0][0], "us_per_step": round(top[0][1][1] / reps, 1)}
-    if dname == "lavt_gemm_tn_grouped":
+    if dname in ("lavt_gemm_tn_grouped", "lavt_gemm_tn_grouped_ln"):          # (_ln: the same launch carrying norm1's LayerNorm backward as rider workgroups)
         # fabric-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE on
         # tools/wgrad_group_one.py, the same five problems in token order): a recorded constant, not a measurement of this run
         try:

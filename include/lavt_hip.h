@@ -214,6 +214,13 @@ int lavt_gemm_tn_pieces(const lavt_gemm_tn_t* p);
  * give the same result: the grouped launch may then cut its reduction into up to 4 pieces that meet through atomics (the launch lasts as
  * long as its longest serial chain of K tiles). */
 int lavt_gemm_tn_grouped(const lavt_gemm_tn_t* probs, int n, void* stream);
+/* lavt_gemm_tn_grouped + ONE LayerNorm backward as rider workgroups (ABI v5): the partial-sum form of lavt_layernorm_bwd_partial (bf16, no gather; dy, x,
+ * gamma, mean, rstd, dx, dres, rows, C, ws as there) needs nothing from the grouped launch and the launch nothing from it, so when the group runs on the
+ * 64x64 launch with column sums (the four weight gradients of a Swin block) the LayerNorm's workgroups are appended to its grid instead of being a launch
+ * of their own on the critical chain (norm1's backward of a Swin block: 7.7 us x 24 per Swin-B step).  In every other case the two are issued one after
+ * the other: same result. */
+int lavt_gemm_tn_grouped_ln(const lavt_gemm_tn_t* probs, int n, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                            void* dx, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream);
 /* The same launch in stream-K form (ABI v5): 128x128 tiles, the K-tile iterations of all members cut into equal runs for ~512 persistent
  * workgroups (every workgroup ingests the same number of bytes); tiles whose reduction is split between runs meet through `scratch` (plain partial
  * tiles + a fixed-order sum: no atomics).  lavt_gemm_tn_grouped_sk_ws returns the floats of scratch the group wants, or 0 when it does not qualify

@@ -486,7 +486,11 @@ extern "C" int lavt_gemm_tn_pieces(const lavt_gemm_tn_t* p) {
     return n < 1 ? 1 : n;
 }
 
-int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st);
+struct lavt_ln_rider_t { const void* dy; const void* x; const float* gamma; const float* mean; const float* rstd; void* dx; float* partials; const void* dres; int rows, C; };
+int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st, const lavt_ln_rider_t* ln);
+int lavt_layernorm_bwd_partial_impl(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* ws,
+                                    int64_t ws_floats, const void* dres, int rows, int C, void* stream);
+int lavt_ln_bwd_geometry(int dtype, int rows, int C, int* lpr, int* cpl, int* waves);
 // n independent weight-gradient problems issued together: one grouped launch without split-K when they qualify (bf16, plain / row-mapped
 // operands, >= 256 output tiles in total), else one lavt_gemm_tn call each.  Results are identical either way up to fp32 summation order.
 int64_t lavt_gemm_tn_grouped_sk_ws_v2(const lavt_gemm_tn_t* probs, int n);
@@ -505,13 +509,37 @@ extern "C" int lavt_gemm_tn_grouped_sk(const lavt_gemm_tn_t* probs, int n, float
     LAVT_CHECK_ARG(rc != 1, "lavt_gemm_tn_grouped_sk: the group does not qualify or the scratch is too small (ask lavt_gemm_tn_grouped_sk_ws first)");
     return rc;
 }
+// lavt_gemm_tn_grouped + ONE LayerNorm backward (the partial-sum form of lavt_layernorm_bwd_partial, bf16, no gather) that rides as extra workgroups of the
+// grouped launch when the group runs on the 64x64 launch with column sums; in every other case the two are issued one after the other -- the result is
+// the same either way.  ws / ws_floats: the LayerNorm's partial-sum scratch (lavt_layernorm_bwd_blocks(...) * 2 * C floats).
+extern "C" int lavt_gemm_tn_grouped_ln(const lavt_gemm_tn_t* probs, int n, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                       void* dx, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream) {
+    LAVT_CHECK_ARG(probs != nullptr && n >= 1 && dy && x && gamma && mean && rstd && dx && ws && rows > 0 && C > 0 && C % 8 == 0, "lavt_gemm_tn_grouped_ln: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    bool ok = true;
+    for (int i = 0; i < n; ++i) ok = ok && probs[i].A && probs[i].B && probs[i].C && probs[i].I > 0 && probs[i].J > 0 && probs[i].K > 0;
+    LAVT_CHECK_ARG(ok, "lavt_gemm_tn_grouped_ln: null operand / bad shape");
+    int lpr, cpl, waves;
+    const int blocks = lavt_ln_bwd_geometry(LAVT_BF16, rows, C, &lpr, &cpl, &waves);
+    LAVT_CHECK_ARG(ws_floats >= (int64_t)blocks * 2 * C, "lavt_gemm_tn_grouped_ln: LayerNorm scratch of %ld floats needed", (long)blocks * 2 * C);
+    lavt_ln_rider_t ln{dy, x, gamma, mean, rstd, dx, ws, dres, rows, C};
+    int rc = lavt_gemm_tn_grouped_v2(probs, n, st, &ln);
+    if (rc == LAVT_OK) return rc;                                  // both launched, the LayerNorm as riders
+    if (rc == 1) {                                                 // the group does not form: one launch per problem
+        for (int i = 0; i < n; ++i) {
+            const int r = lavt_gemm_tn(&probs[i], stream);
+            if (r != LAVT_OK) return r;
+        }
+    } else if (rc != 3) return rc;
+    return lavt_layernorm_bwd_partial_impl(LAVT_BF16, dy, x, gamma, mean, rstd, dx, ws, ws_floats, dres, rows, C, stream);
+}
 extern "C" int lavt_gemm_tn_grouped(const lavt_gemm_tn_t* probs, int n, void* stream) {
     LAVT_CHECK_ARG(probs != nullptr && n >= 1, "lavt_gemm_tn_grouped: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     bool ok = true;
     for (int i = 0; i < n; ++i) ok = ok && probs[i].A && probs[i].B && probs[i].C && probs[i].I > 0 && probs[i].J > 0 && probs[i].K > 0;
     LAVT_CHECK_ARG(ok, "lavt_gemm_tn_grouped: null operand / bad shape");
-    const int rc = lavt_gemm_tn_grouped_v2(probs, n, st);
+    const int rc = lavt_gemm_tn_grouped_v2(probs, n, st, nullptr);
     if (rc != 1) return rc;
     for (int i = 0; i < n; ++i) {
         const int r = lavt_gemm_tn(&probs[i], stream);

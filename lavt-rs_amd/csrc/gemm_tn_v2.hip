@@ -1,6 +1,7 @@
 // Gather-GEMM, second generation (bf16), TN family: weight gradients (split from gemm_v2.hip so that the two families compile in parallel;
 // the design notes at the top of gemm_v2.hip apply).
 #include "gemm_v2_helpers.h"
+#include "ln_bwd_body.h"
 
 namespace {
 
@@ -385,11 +386,10 @@ struct TnGroup {
 };
 // (128x128 / 8 waves: capped at 128 registers -- second __launch_bounds__ value = waves per SIMD -- so that two workgroups share a CU)
 template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS>
-__global__ __launch_bounds__(WAVES * 64, (BI == 128 && WAVES == 8) ? 4 : 1) void gemm_tn_v2_grouped_kernel(const TnGroup g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void grouped_tile(const TnGroup& g, const int bid, char* smem) {
     int k = 0;
-    while (k + 1 < g.n && (int)blockIdx.x >= g.tile_end[k]) ++k;
-    const int local = blockIdx.x - (k ? g.tile_end[k - 1] : 0);
+    while (k + 1 < g.n && bid >= g.tile_end[k]) ++k;
+    const int local = bid - (k ? g.tile_end[k - 1] : 0);
     const lavt_gemm_tn_t& p = g.p[k];
     const int ns = g.split[k], ktiles = (p.K + 63) / 64;
     // the splits of a tile sit next to each other (local % ns): neighbours in time share the output tile's cache lines for their atomics
@@ -402,6 +402,28 @@ __global__ __launch_bounds__(WAVES * 64, (BI == 128 && WAVES == 8) ? 4 : 1) void
         }
     }
     tn_tile<BI, BJ, WAVES, STAGES, MAPS, CS, false>(p, local / ns, 0, local % ns, (ktiles + ns - 1) / ns, ns, smem);
+}
+template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS>
+__global__ __launch_bounds__(WAVES * 64, (BI == 128 && WAVES == 8) ? 4 : 1) void gemm_tn_v2_grouped_kernel(const TnGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    grouped_tile<BI, BJ, WAVES, STAGES, MAPS, CS>(g, blockIdx.x, smem);
+}
+// The same launch carrying a LayerNorm backward as RIDER workgroups (round 4).  norm1's backward of a Swin block needs the qkv data gradient, which is
+// complete when the block's grouped weight-gradient launch is enqueued, and the launch needs nothing from it: as 450 extra 256-thread workgroups of
+// the launch it costs no launch of its own on the critical chain (7.7 us x 24 per Swin-B step).  The rider's LDS scratch is the (idle) tile ring.
+struct LnRider {
+    const bf16* dy; const bf16* x; const float* gamma; const float* mean; const float* rstd; bf16* dx; float* partials; const bf16* dres;
+    int rows, C, blocks;
+};
+template <bool MAPS, int CS, int LPR, int CPL>
+__global__ __launch_bounds__(256) void gemm_tn_v2_grouped_ln_kernel(const TnGroup g, const int tiles, const LnRider ln) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= tiles) {
+        layernorm_bwd_body<bf16, LPR, CPL, 4, 0>(ln.dy, ln.x, nullptr, ln.gamma, ln.mean, ln.rstd, ln.dx, nullptr, nullptr, ln.partials, ln.dres, ln.rows, ln.C, nullptr,
+                                                 nullptr, (int)blockIdx.x - tiles, ln.blocks, threadIdx.x, reinterpret_cast<float*>(smem));
+        return;
+    }
+    grouped_tile<64, 64, 4, 2, MAPS, CS>(g, blockIdx.x, smem);
 }
 
 // ---- stream-K form of the grouped launch (round 4) ------------------------------------------------------------------------------------
@@ -598,7 +620,10 @@ static bool tn_v2_eligible(const lavt_gemm_tn_t& p) {
 }
 
 // returns 1 when the group cannot run as one launch (the caller then issues the problems one by one)
-int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) {
+struct lavt_ln_rider_t { const void* dy; const void* x; const float* gamma; const float* mean; const float* rstd; void* dx; float* partials; const void* dres; int rows, C; };
+int lavt_ln_bwd_geometry(int dtype, int rows, int C, int* lpr, int* cpl, int* waves);
+// ln != NULL: a LayerNorm backward to run as rider workgroups of the launch; returns 3 when the group was launched WITHOUT it (the caller launches it)
+int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st, const lavt_ln_rider_t* ln) {
     const lavt_tuning_t& tun = lavt_tuning();
     if (tun.gemm_v2_off || n < 2 || n > TN_GROUP_MAX) return 1;
     TnGroup g;
@@ -693,10 +718,32 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
         if (done) {
             if (any_parts) hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
             LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
-            return LAVT_OK;
+            return ln ? 3 : LAVT_OK;
         }
     }
     const size_t lds = 2 * (size_t)(64 * (64 + 64) * 2) + (maps ? 3 * 768 + 256 : 0);
+    if (ln != nullptr && any_colsum && lavt_tuning().probe[2] == 0) {
+        int lpr, cpl, waves;
+        const int blocks = lavt_ln_bwd_geometry(LAVT_BF16, ln->rows, ln->C, &lpr, &cpl, &waves);
+        LnRider r{(const bf16*)ln->dy, (const bf16*)ln->x, ln->gamma, ln->mean, ln->rstd, (bf16*)ln->dx, ln->partials, (const bf16*)ln->dres, ln->rows, ln->C, blocks};
+        bool rode = true;
+#define TNG_LN(LPR_, CPL_)                                                                                                                            \
+    do {                                                                                                                                               \
+        if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_ln_kernel<true, 2, LPR_, CPL_>), dim3(tiles + blocks), dim3(256), lds, st, g, tiles, r);      \
+        else hipLaunchKernelGGL((gemm_tn_v2_grouped_ln_kernel<false, 2, LPR_, CPL_>), dim3(tiles + blocks), dim3(256), lds, st, g, tiles, r);          \
+    } while (0)
+        if (waves != 4 || (size_t)3 * lpr * cpl * 8 * 4 > lds) rode = false;
+        else if (lpr == 16 && cpl == 1) TNG_LN(16, 1);
+        else if (lpr == 32 && cpl == 1) TNG_LN(32, 1);
+        else if (lpr == 64 && cpl == 1) TNG_LN(64, 1);
+        else rode = false;          // (C = 1024: two chunks per lane need 164 registers -- a fourth workgroup per CU no longer fits; the two stage-3 blocks launch it on its own)
+#undef TNG_LN
+        if (rode) {
+            if (any_parts) hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
+            LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped_ln(v2)");
+            return LAVT_OK;
+        }
+    }
     if (any_colsum) {
         if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true, 2>), dim3(tiles), dim3(256), lds, st, g);
         else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, false, 2>), dim3(tiles), dim3(256), lds, st, g);
@@ -706,7 +753,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st) 
     }
     if (any_parts) hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
     LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
-    return LAVT_OK;
+    return ln ? 3 : LAVT_OK;
 }
 
 // ---- stream-K grouped launch: host side.  sk_plan fills g / sk and returns the scratch floats needed (0 = the group does not qualify).

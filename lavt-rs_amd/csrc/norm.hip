@@ -2,6 +2,7 @@
 // normalisation kernels behind InstanceNorm1d (PWAM) and BatchNorm2d(+ReLU) (decoder).  All HBM-bound:
 // 16-byte accesses, one wave per LayerNorm row (row kept in registers, fp32 math), wave-shuffle reductions.
 #include "common.h"
+#include "ln_bwd_body.h"
 
 namespace {
 
@@ -17,23 +18,6 @@ template <int EPC> __device__ __forceinline__ void ldc(const float* p, float* ou
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm
-template <typename T>
-__device__ __forceinline__ const T* ln_src(const T* x, const int32_t* gather, int64_t row, int C, int col, bool& ok) {
-    if (!gather) { ok = true; return x + row * C + col; }
-    const int cq = C >> 2, q = col / cq;
-    const int src = gather[row * 4 + q];
-    ok = src >= 0;
-    return x + (int64_t)src * cq + (col - q * cq);
-}
-
-// LPR = lanes per row (16 / 32 / 64): a wave normalises 64/LPR rows at once so that narrow rows (C = 96..256) still use
-// every lane; reductions are xor-shuffles inside the LPR-lane group.
-template <int LPR> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 template <typename T, int LPR>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const int32_t* __restrict__ gather,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -82,8 +66,6 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     }
 }
 
-// FLAGS: bit 0 = the rows may be gathered (PatchMerging's 2x2 form), bit 1 = the LayerNorm output is written on the way; the plain form carries
-// neither (a never-taken uniform branch is not free in these one-round kernels: DESIGN.md section 5)
 template <typename T, int LPR, int CPL, int WAVES, int FLAGS = 3>
 __global__ __launch_bounds__(WAVES * 64) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const int32_t* __restrict__ gather, const float* __restrict__ gamma,
@@ -91,117 +73,9 @@ __global__ __launch_bounds__(WAVES * 64) void layernorm_bwd_kernel(const T* __re
                                                             T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ partials, const T* __restrict__ dres, int rows, int C,
                                                             T* __restrict__ xn_out_, const float* __restrict__ beta) {
-    if constexpr (!(FLAGS & 1)) gather = nullptr;
-    T* const xn_out = (FLAGS & 2) ? xn_out_ : nullptr;
-    // CPL = chunks per lane (compile time: the row arrays are exactly as large as needed; LPR < 64 only with CPL == 1)
-    constexpr int EPC = Chunk<T>::N, MAXC = CPL, RPW = 64 / LPR;
-    const int lane = threadIdx.x & 63, lir = lane % LPR, wave = threadIdx.x >> 6;
-    const int nchunk = C / EPC;
-    constexpr int cpl = CPL;
-    float dg[MAXC * EPC], db[MAXC * EPC];
-#pragma unroll
-    for (int e = 0; e < MAXC * EPC; ++e) { dg[e] = 0.f; db[e] = 0.f; }
-    const int64_t rstride = (int64_t)gridDim.x * WAVES * RPW;
-    for (int64_t row0 = ((int64_t)blockIdx.x * WAVES + wave) * RPW; row0 < rows; row0 += rstride) {
-        const int64_t row = row0 + lane / LPR;
-        const bool live = row < rows;
-        const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
-        float xh[MAXC * EPC], g[MAXC * EPC];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = lir + LPR * c;
-            const bool on = live && c < cpl && ch < nchunk;
-            float fx[EPC], fg[EPC];
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) { fx[e] = 0.f; fg[e] = 0.f; }
-            if (on) {
-                bool ok;
-                const T* src = ln_src<T>(x, gather, row, C, ch * EPC, ok);
-                if (ok) chunk_to_f<T>(*reinterpret_cast<const uint4*>(src), fx);
-                chunk_to_f<T>(*reinterpret_cast<const uint4*>(dy + row * C + ch * EPC), fg);
-            }
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const int k = c * EPC + e;
-                xh[k] = on ? (fx[e] - mu) * rs : 0.f;
-                const float gg = on ? fg[e] * gamma[ch * EPC + e] : 0.f;
-                g[k] = gg;
-                s1 += gg; s2 += gg * xh[k];
-                dg[k] += fg[e] * xh[k];
-                db[k] += fg[e];
-            }
-            if (xn_out && on) {          // the LayerNorm OUTPUT, for a consumer whose forward folded the norm into its GEMM (the weight gradient's operand)
-                float fy[EPC];
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) fy[e] = xh[c * EPC + e] * gamma[ch * EPC + e] + beta[ch * EPC + e];
-                *reinterpret_cast<uint4*>(xn_out + row * C + ch * EPC) = f_to_chunk<T>(fy);
-            }
-        }
-        s1 = group_sum<LPR>(s1) / C; s2 = group_sum<LPR>(s2) / C;
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = lir + LPR * c;
-            if (live && c < cpl && ch < nchunk) {
-                float f[EPC];
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) f[e] = rs * (g[c * EPC + e] - s1 - xh[c * EPC + e] * s2);
-                if (dres) {                       // gradient of the residual branch that bypassed this LayerNorm: dx = LN'(dy) + dres (no gather form)
-                    float fr[EPC];
-                    chunk_to_f<T>(*reinterpret_cast<const uint4*>(dres + row * C + ch * EPC), fr);
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) f[e] += fr[e];
-                }
-                if (!gather) *reinterpret_cast<uint4*>(dx + row * C + ch * EPC) = f_to_chunk<T>(f);
-                else {
-                    const int cq = C >> 2, col = ch * EPC, qd = col / cq;
-                    const int src = gather[row * 4 + qd];
-                    if (src >= 0) *reinterpret_cast<uint4*>(dx + (int64_t)src * cq + (col - qd * cq)) = f_to_chunk<T>(f);
-                }
-            }
-        }
-    }
-    // sum the RPW row groups of the wave, then the waves through LDS, then ONE partial (or atomic) per channel per workgroup
-#pragma unroll
-    for (int e = 0; e < MAXC * EPC; ++e) {
-#pragma unroll
-        for (int o = LPR; o < 64; o <<= 1) { dg[e] += __shfl_xor(dg[e], o, 64); db[e] += __shfl_xor(db[e], o, 64); }
-    }
-    __shared__ float red[(WAVES - 1) * (LPR * CPL * EPC)];
-    constexpr int RW = LPR * CPL * EPC;                    // >= C
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        float* part = pass == 0 ? dg : db;
-        float* dst = pass == 0 ? dgamma : dbeta;
-        __syncthreads();
-        if (wave > 0 && lane < LPR) {
-#pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                const int ch = lir + LPR * c;
-                if (c < cpl && ch < nchunk)
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) red[(wave - 1) * RW + ch * EPC + e] = part[c * EPC + e];
-            }
-        }
-        __syncthreads();
-        if (wave == 0 && lane < LPR) {
-#pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                const int ch = lir + LPR * c;
-                if (c < cpl && ch < nchunk)
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        const int col = ch * EPC + e;
-                        float tot = part[c * EPC + e];
-#pragma unroll
-                        for (int w = 0; w < WAVES - 1; ++w) tot += red[w * RW + col];
-                        // hundreds of workgroups adding to the SAME C addresses serialise in L2: write per-workgroup partials instead
-                        if (partials) partials[((int64_t)blockIdx.x * 2 + pass) * C + col] = tot;
-                        else atomicAdd(dst + col, tot);
-                    }
-            }
-        }
-    }
+    __shared__ float red[(WAVES - 1) * (LPR * CPL * Chunk<T>::N)];
+    layernorm_bwd_body<T, LPR, CPL, WAVES, FLAGS>(dy, x, gather, gamma, mean, rstd, dx, dgamma, dbeta, partials, dres, rows, C, xn_out_, beta, blockIdx.x, gridDim.x,
+                                                  threadIdx.x, red);
 }
 
 // Second stage of the two-stage reductions: partials [nblk][W] (W = groups*2*C: per group first the C "sum-1" values, then the C
@@ -563,6 +437,10 @@ static int ln_bwd_geometry(int dtype, int rows, int C, int* lpr_out, int* cpl_ou
     return blocks;
 }
 extern "C" int lavt_layernorm_bwd_blocks(int dtype, int rows, int C) { int a, b; return ln_bwd_geometry(dtype, rows, C, &a, &b, nullptr); }
+// geometry of the plain (no gather, no xn output) partial-sum form, for the grouped weight-gradient launch that runs it in rider workgroups
+int lavt_ln_bwd_geometry(int dtype, int rows, int C, int* lpr, int* cpl, int* waves) { return ln_bwd_geometry(dtype, rows, C, lpr, cpl, waves); }
+int lavt_layernorm_bwd_partial_impl(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* ws,
+                                    int64_t ws_floats, const void* dres, int rows, int C, void* stream);
 
 static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma,
                               const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats,
@@ -596,6 +474,10 @@ extern "C" int lavt_layernorm_bwd(int dtype, const void* dy, const void* x, cons
 extern "C" int lavt_layernorm_bwd_partial(int dtype, const void* dy, const void* x, const int32_t* gather, const float* gamma, const float* mean,
                                           const float* rstd, void* dx, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream) {
     return layernorm_bwd_impl(dtype, dy, x, gather, gamma, mean, rstd, dx, nullptr, nullptr, ws, ws_floats, dres, rows, C, stream, true);
+}
+int lavt_layernorm_bwd_partial_impl(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* ws,
+                                    int64_t ws_floats, const void* dres, int rows, int C, void* stream) {
+    return layernorm_bwd_impl(dtype, dy, x, nullptr, gamma, mean, rstd, dx, nullptr, nullptr, ws, ws_floats, dres, rows, C, stream, true);
 }
 // the same + the LayerNorm output xn = xhat * gamma + beta written on the way (no gather form): for a forward that folded the norm into the consumer's
 // GEMM (lavt_gemm_nt.ln_wsum) and therefore never materialised it -- the consumer's weight gradient reads it

@@ -491,7 +491,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
 
 def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, strideB=0, strideC=0, a_rowmap=None,
             a_rowscale=None, a_rowscale_div=1, a_rowscale_binary=False, accumulate=False, B2=None, ldb2=0, b_split=0, b_rowmap=None, conv=None, alpha=1.0, c_conv_permute=False, colsum=None,
-            strideColsum=0, a_off=0, b_off=0, c_off=0, defer=None, colsum_atomic=False, extra=False):
+            strideColsum=0, a_off=0, b_off=0, c_off=0, defer=None, colsum_atomic=False, extra=False, rider=None):
     es = 4 if dtype == torch.float32 else 2
     assert Cout.dtype == torch.float32
     p = K.GemmTN()
@@ -517,7 +517,10 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
             scr = _tn_parts(need, A.device)
             p.partials, p.partials_floats = K.ptr(scr), (need if defer is not None else scr.numel())     # queued: flush() hands every member its own region
     if defer is not None:
-        defer.add(p, (A, B, Cout, a_rowmap, a_rowscale, b_rowmap, colsum), extra=extra)
+        if rider is not None:
+            defer.add(p, (A, B, Cout, a_rowmap, a_rowscale, b_rowmap, colsum) + tuple(t for t in rider if torch.is_tensor(t)), extra=extra, rider=rider)
+        else:
+            defer.add(p, (A, B, Cout, a_rowmap, a_rowscale, b_rowmap, colsum), extra=extra)
         return
     if K.prof.enabled:
         K.prof.note = {"flops": 2.0 * I * J * Kd * batch, "shape": f"tn {I}x{J}x{Kd}" + (f" b{batch}" if batch > 1 else "") + (" conv" if conv is not None else "")}
@@ -533,6 +536,15 @@ def assign_partials(items, device):
             if nf:
                 q.partials = base + 4 * off
                 off += nf
+
+
+_LN_RIDER = os.environ.get("LAVT_LN_RIDER", "1") != "0"
+
+
+def _launch_ln_partial(rider):
+    dy_, x_, g_, mean_, rstd_, dx_, ws_, dres_, rows_, C_ = rider
+    K.check(K.lib.lavt_layernorm_bwd_partial(K.dt(x_.dtype), K.ptr(dy_), K.ptr(x_), None, K.ptr(g_), K.ptr(mean_), K.ptr(rstd_), K.ptr(dx_), K.ptr(ws_), ws_.numel(),
+                                             K.ptr(dres_), rows_, C_, K.stream()))
 
 
 _SK_SCRATCH = {}
@@ -556,14 +568,22 @@ class _WgradQueue:
     def active(self):
         return self.enabled and sinks.map and os.environ.get("LAVT_WGRAD_GROUP", "1") != "0"
 
-    def add(self, p, tensors, extra=False):
-        """extra: a side member (at most two per group: lavt_gemm_tn_grouped takes six problems) that does not count towards the four-member flush"""
+    def add(self, p, tensors, extra=False, rider=None):
+        """extra: a side member (at most two per group: lavt_gemm_tn_grouped takes six problems) that does not count towards the four-member flush.
+        rider: (dy, x, gamma, mean, rstd, dx, ws, dres, rows, C) of a LayerNorm backward (partial-sum form) that must be launched with or right after
+        this member: if the member completes the group, the LayerNorm rides as extra workgroups of the grouped launch (lavt_gemm_tn_grouped_ln);
+        otherwise it is launched on its own at once."""
         self.items.append(p)
         self.keep.append(tensors)
         self.scopes.append(K.prof.label)
         self.primary += 0 if extra else 1
-        if self.primary == 4 or len(self.items) == 6:
-            self.flush()
+        # a member that brings a rider closes the group: it is the last weight gradient of its Swin block (qkv), so groups are the block's own four
+        # members + side member -- without this the four-member count ran one member out of phase (fc1, proj, side, qkv of a block + fc2 of the next)
+        # and the launch was issued from the next block's MLP backward, where no LayerNorm waits to ride
+        if self.primary == 4 or len(self.items) == 6 or (rider is not None and _LN_RIDER):
+            self.flush(rider)
+        elif rider is not None:
+            _launch_ln_partial(rider)
 
     def notify(self, param):
         # The op returns None for this parameter's gradient, and PyTorch runs the parameter's post-accumulate hook all the same -- BEFORE the
@@ -572,7 +592,9 @@ class _WgradQueue:
         self.ready.append(param)
         self.pending.add(id(param))
 
-    def flush(self):
+    def flush(self, rider=None):
+        if not self.items and rider is not None:
+            _launch_ln_partial(rider)
         if self.items:
             assign_partials(self.items, next(t for t in self.keep[0] if t is not None).device)
             arr = (K.GemmTN * len(self.items))(*self.items)
@@ -590,11 +612,21 @@ class _WgradQueue:
                 if scr is None or scr.numel() < sk:
                     scr = _SK_SCRATCH[dev] = torch.empty(sk, dtype=torch.float32, device=dev)
                 side.run(lambda: K.check(K.lib.lavt_gemm_tn_grouped_sk(arr, n_items, K.ptr(scr), scr.numel(), K.stream())), tensors, True)
+                if rider is not None:
+                    _launch_ln_partial(rider)
+                self._after_flush()
+                return
+            if rider is not None and not side.enabled and _LN_RIDER:
+                dy_, x_, g_, mean_, rstd_, dx_, ws_, dres_, rows_, C_ = rider
+                K.check(K.lib.lavt_gemm_tn_grouped_ln(arr, n_items, K.ptr(dy_), K.ptr(x_), K.ptr(g_), K.ptr(mean_), K.ptr(rstd_), K.ptr(dx_), K.ptr(ws_), ws_.numel(),
+                                                      K.ptr(dres_), rows_, C_, K.stream()))
                 self._after_flush()
                 return
             # the grouped launch is off the critical path of backward (only the optimizer / all-reduce consumes it): on a side stream it overlaps
             # the latency-bound data-gradient chain of the next block (LAVT_SIDE_STREAMS=1)
             side.run(lambda: K.check(K.lib.lavt_gemm_tn_grouped(arr, n_items, K.stream())), tensors, True)
+            if rider is not None:
+                _launch_ln_partial(rider)
         self._after_flush()
 
     def _after_flush(self):
@@ -1333,8 +1365,23 @@ class _WmsaFused(torch.autograd.Function):
             gemm_nt(dtype, M, Cc, 3 * Cc, dqkv, 3 * Cc, Wc, Cc, dxn, Cc, b_kmajor=True, a_rowmap=inv)
         else:
             gemm_nt(dtype, Mw, Cc, 3 * Cc, dqkv, 3 * Cc, Wc, Cc, dxn, Cc, b_kmajor=True, c_rowmap=wmap)
+        # ---- LayerNorm backward (the residual branch's gradient joins inside the kernel, as _LayerNorm.backward), prepared FIRST: under the step harness its
+        # launch rides on the block's grouped weight-gradient launch, which the qkv member below completes (ops._WgradQueue.add(rider=...))
+        if dres is not None:
+            dres = dres.contiguous()
+        dx = torch.empty_like(x)
+        dg, gs = sinks.buf(gamma, (Cc,))
+        db, bs_ = sinks.buf(beta, (Cc,))
+        rider, nblk, wsd = None, 0, None
+        if gs and bs_ and ln_deferred.active():
+            nblk = int(K.lib.lavt_layernorm_bwd_blocks(K.dt(dtype), M, Cc))
+            wsd = ln_deferred.alloc(nblk * 2 * Cc, dev)
+            if wsd is not None:
+                rider = (dxn, x, _f32(gamma), st[0], st[1], dx, wsd, dres, M, Cc)
+        # ---- qkv weight / bias gradient ----
         wbuf, wsink = sinks.buf(wq, (3 * Cc, Cc))
         bbuf, bsink = sinks.buf(bq, (3 * Cc,))
+        rode = False
         if wgrads.active() and wsink and bsink and inv is not None and padrows.numel() > 0 and os.environ.get("LAVT_TOKEN_ORDER_WGRAD", "1") != "0":
             # token order: dW = sum over the REAL tokens of dqkv[inv[t]]^T xn[t] (padded window positions have xn = 0: K = tokens instead of window
             # rows); their dq / dk / dv still belong to the bias gradient (the reference pads after norm1): a side member of the grouped launch sums
@@ -1342,36 +1389,27 @@ class _WmsaFused(torch.autograd.Function):
             dummy = _discard_out(3 * Cc * 8, dev)
             zp = _zero_page_tensor(dev)
             gemm_tn(dtype, 3 * Cc, 8, padrows.numel(), dqkv, 3 * Cc, zp, 0, dummy, 8, a_rowmap=padrows, colsum=bbuf, colsum_atomic=True, defer=wgrads, extra=True)
-            gemm_tn(dtype, 3 * Cc, Cc, M, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, a_rowmap=inv, colsum=bbuf, colsum_atomic=True, defer=wgrads)
+            gemm_tn(dtype, 3 * Cc, Cc, M, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, a_rowmap=inv, colsum=bbuf, colsum_atomic=True, defer=wgrads, rider=rider)
+            rode = rider is not None
             wgrads.notify(wq)
             wgrads.notify(bq)
             g_w = g_b = None
         elif wgrads.active() and wsink and bsink:
-            gemm_tn(dtype, 3 * Cc, Cc, Mw, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, b_rowmap=wmap, colsum=bbuf, defer=wgrads)
+            gemm_tn(dtype, 3 * Cc, Cc, Mw, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, b_rowmap=wmap, colsum=bbuf, defer=wgrads, rider=rider)
+            rode = rider is not None
             wgrads.notify(wq)
             wgrads.notify(bq)
             g_w = g_b = None
         else:
             gemm_tn(dtype, 3 * Cc, Cc, Mw, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, b_rowmap=wmap, colsum=bbuf)
             g_w, g_b = sinks.done(wq, wbuf, wsink), sinks.done(bq, bbuf, bsink)
-        # ---- LayerNorm backward, the residual branch's gradient joining inside the kernel (as _LayerNorm.backward) ----
-        if dres is not None:
-            dres = dres.contiguous()
-        dx = torch.empty_like(x)
-        dg, gs = sinks.buf(gamma, (Cc,))
-        db, bs_ = sinks.buf(beta, (Cc,))
-        done = False
-        if gs and bs_ and ln_deferred.active():
-            nblk = int(K.lib.lavt_layernorm_bwd_blocks(K.dt(dtype), M, Cc))
-            wsd = ln_deferred.alloc(nblk * 2 * Cc, dev)
-            if wsd is not None:
+        if rider is not None:
+            if not rode:
                 _note(f"ln-bwd {M}x{Cc}", nbytes=(4.0 if dres is not None else 3.0) * M * Cc * x.element_size())
-                K.check(K.lib.lavt_layernorm_bwd_partial(K.dt(dtype), K.ptr(dxn), K.ptr(x), None, K.ptr(_f32(gamma)), K.ptr(st[0]), K.ptr(st[1]), K.ptr(dx), K.ptr(wsd),
-                                                         wsd.numel(), K.ptr(dres), M, Cc, K.stream()))
-                ln_deferred.add(wsd, nblk, Cc, dg, db, (gamma, beta))
-                g_g = g_be = None
-                done = True
-        if not done:
+                _launch_ln_partial(rider)
+            ln_deferred.add(wsd, nblk, Cc, dg, db, (gamma, beta))
+            g_g = g_be = None
+        else:
             wsl = _scratch(int(K.lib.lavt_layernorm_bwd_blocks(K.dt(dtype), M, Cc)) * 2 * Cc, dev)
             K.check(K.lib.lavt_layernorm_bwd(K.dt(dtype), K.ptr(dxn), K.ptr(x), None, K.ptr(_f32(gamma)), K.ptr(st[0]), K.ptr(st[1]), K.ptr(dx), K.ptr(dg), K.ptr(db),
                                              K.ptr(wsl), wsl.numel(), K.ptr(dres), M, Cc, K.stream()))

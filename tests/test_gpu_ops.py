@@ -730,6 +730,56 @@ def test_gemm_tn_grouped_streamk(B, H, ws, shift, Cc):
     assert torch.equal(a["qkv.b"], b["qkv.b"])
 
 
+@pytest.mark.parametrize("Cc,T", [(512, 1800), (128, 28800), (256, 7200), (1024, 450)])
+def test_grouped_wgrad_with_layernorm_rider(Cc, T):
+    """lavt_gemm_tn_grouped_ln: the partial-sum LayerNorm backward as rider workgroups of a Swin block's grouped weight-gradient launch (C = 1024 and
+    groups that do not form fall back to two launches inside the call) -- dx and the per-workgroup d gamma / d beta partials bit-identical to
+    lavt_layernorm_bwd_partial on its own, the weight gradients identical to lavt_gemm_tn_grouped."""
+    from lavt_hip import _capi as K, ops
+    g = torch.Generator().manual_seed(11)
+    bf = torch.bfloat16
+    def mk(rows, cols, s=0.5):
+        return (torch.randn(rows, cols, generator=g) * s).to(dev()).to(bf)
+    dy2, h, dpre, x2, dyp, o, dqkv, xn = mk(T, Cc), mk(T, 4 * Cc), mk(T, 4 * Cc), mk(T, Cc), mk(T, Cc), mk(T, Cc), mk(T, 3 * Cc), mk(T, Cc)
+    dxn, x, dres = mk(T, Cc), mk(T, Cc, 1.0), mk(T, Cc)
+    gamma = (1.0 + 0.1 * torch.randn(Cc, generator=g)).to(dev())
+    mean, rstd = x.float().mean(1), torch.rsqrt(x.float().var(1, unbiased=False) + 1e-5)
+    nblk = int(K.lib.lavt_layernorm_bwd_blocks(K.BF16, T, Cc))
+
+    def run(ride):
+        structs, keep = [], []
+        class _Q:
+            def add(self, p, t, extra=False, rider=None): structs.append(p); keep.append(t)
+        outs = [torch.zeros(Cc, 4 * Cc, device=dev()), torch.zeros(4 * Cc, Cc, device=dev()), torch.zeros(Cc, Cc, device=dev()), torch.zeros(3 * Cc, Cc, device=dev())]
+        bs = [torch.zeros(Cc, device=dev()), torch.zeros(4 * Cc, device=dev()), torch.zeros(Cc, device=dev()), torch.zeros(3 * Cc, device=dev())]
+        ops.gemm_tn(bf, Cc, 4 * Cc, T, dy2, Cc, h, 4 * Cc, outs[0], 4 * Cc, colsum=bs[0], defer=_Q())
+        ops.gemm_tn(bf, 4 * Cc, Cc, T, dpre, 4 * Cc, x2, Cc, outs[1], Cc, colsum=bs[1], defer=_Q())
+        ops.gemm_tn(bf, Cc, Cc, T, dyp, Cc, o, Cc, outs[2], Cc, colsum=bs[2], defer=_Q())
+        ops.gemm_tn(bf, 3 * Cc, Cc, T, dqkv, 3 * Cc, xn, Cc, outs[3], Cc, colsum=bs[3], defer=_Q())
+        ops.assign_partials(structs, dev())
+        arr = (K.GemmTN * len(structs))(*structs)
+        dx = torch.empty_like(x)
+        ws = torch.full((nblk * 2 * Cc,), float("nan"), device=dev())
+        if ride:
+            K.check(K.lib.lavt_gemm_tn_grouped_ln(arr, len(structs), K.ptr(dxn), K.ptr(x), K.ptr(gamma), K.ptr(mean), K.ptr(rstd), K.ptr(dx), K.ptr(ws), ws.numel(),
+                                                  K.ptr(dres), T, Cc, K.stream()))
+        else:
+            K.check(K.lib.lavt_gemm_tn_grouped(arr, len(structs), K.stream()))
+            K.check(K.lib.lavt_layernorm_bwd_partial(K.BF16, K.ptr(dxn), K.ptr(x), None, K.ptr(gamma), K.ptr(mean), K.ptr(rstd), K.ptr(dx), K.ptr(ws), ws.numel(),
+                                                     K.ptr(dres), T, Cc, K.stream()))
+        torch.cuda.synchronize()
+        return outs + bs + [dx, ws]
+    a, b = run(True), run(False)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.isfinite(u.float()).all(), i
+        assert torch.equal(u, v), f"tensor {i}: ridden and separate launches differ"
+    # and the LayerNorm backward itself against fp32 torch
+    xh = (x.float() - mean[:, None]) * rstd[:, None]
+    gg = dxn.float() * gamma
+    ref = rstd[:, None] * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True)) + dres.float()
+    assert float((a[8].float() - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
+
+
 def test_gemm_tn_split_through_partial_tiles(monkeypatch):
     """Long-K weight gradients on few output tiles (PWAM's 1x1 convolutions: K = 28 800 rows on 4 tiles): the K pieces store plain partial tiles
     into the lent scratch and a second kernel adds them into C (lavt_gemm_tn_t.partials, ABI v3) -- against the atomic form of the same launch
