@@ -647,7 +647,7 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     const int waves = force_waves ? force_waves : 8;
     // riders only on the 8-wave variants that sit two per CU (N <= 160): a rider occupies a whole workgroup slot, and the 392-token video kernel (149 KB of
     // LDS, one workgroup per CU) would run them as an extra round
-    const bool eight = !(N <= 64) && !(N == 144 && waves != 8) && N <= 160;
+    const bool eight = !(N <= 64) && !(N == 144 && waves != 8) && (N <= 160 || lavt_tuning().probe[3] != 0);
     DtableJob job{};
     int riders = 0;
     if (prev != nullptr) {

@@ -1388,17 +1388,17 @@ class _WmsaFused(torch.autograd.Function):
             # those rows alone (B = the zero page, 8 dummy columns), both column sums added atomically into the zeroed bias gradient
             dummy = _discard_out(3 * Cc * 8, dev)
             zp = _zero_page_tensor(dev)
+            wgrads.notify(wq)          # (before the member is queued: it closes the group, and the flush reports what has been notified)
+            wgrads.notify(bq)
             gemm_tn(dtype, 3 * Cc, 8, padrows.numel(), dqkv, 3 * Cc, zp, 0, dummy, 8, a_rowmap=padrows, colsum=bbuf, colsum_atomic=True, defer=wgrads, extra=True)
             gemm_tn(dtype, 3 * Cc, Cc, M, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, a_rowmap=inv, colsum=bbuf, colsum_atomic=True, defer=wgrads, rider=rider)
             rode = rider is not None
-            wgrads.notify(wq)
-            wgrads.notify(bq)
             g_w = g_b = None
         elif wgrads.active() and wsink and bsink:
-            gemm_tn(dtype, 3 * Cc, Cc, Mw, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, b_rowmap=wmap, colsum=bbuf, defer=wgrads, rider=rider)
-            rode = rider is not None
             wgrads.notify(wq)
             wgrads.notify(bq)
+            gemm_tn(dtype, 3 * Cc, Cc, Mw, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, b_rowmap=wmap, colsum=bbuf, defer=wgrads, rider=rider)
+            rode = rider is not None
             g_w = g_b = None
         else:
             gemm_tn(dtype, 3 * Cc, Cc, Mw, dqkv, 3 * Cc, xn, Cc, wbuf, Cc, b_rowmap=wmap, colsum=bbuf)
