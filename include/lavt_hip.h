@@ -398,6 +398,13 @@ int lavt_ln_fold_multi(const int64_t* desc, int count, void* stream);
 int lavt_wmsa_fwd(const void* x, const int32_t* wmap, const void* Wg, const float* wsum, const float* biasp, const float* bias, const float* gamma,
                   const float* beta, const float* table, const int8_t* region, int nw_img, void* out, float* lse, void* qkv, void* xn, float* mean,
                   float* rstd, const void* zeros, int ws, int nwin, int N, int heads, int C, float eps, float scale, void* stream);
+/* The same launch with a zero-fill RIDER (ABI v5): fill_bytes bytes at fill (16-byte aligned, multiples of 16) are set to zero by extra workgroups appended
+ * to the launch's grid.  The step harness zeroes its flat gradient buffer this way, a slice per stage-2 block: the fill is needed by nothing before
+ * backward, and as its own launch (58 us at the HBM rate for Swin-B's 475 MB) it headed the captured chain. */
+int lavt_wmsa_fwd_rider(const void* x, const int32_t* wmap, const void* Wg, const float* wsum, const float* biasp, const float* bias, const float* gamma,
+                        const float* beta, const float* table, const int8_t* region, int nw_img, void* out, float* lse, void* qkv, void* xn, float* mean,
+                        float* rstd, const void* zeros, int ws, int nwin, int N, int heads, int C, float eps, float scale, void* fill, int64_t fill_bytes,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused PWAM (ABI v4, bf16).  Replaces, with the GEMMs above, PWAM.forward (lib/backbone.py:1265-1278),

@@ -65,10 +65,22 @@ struct WmsaArgs {
     const void* zeros;
     int nw_img, wh, ww, nwin, N, heads, C;
     float eps, scale;
+    uint4* fill;              // rider: this many 16-byte words are set to zero by extra workgroups (a slice of the step's gradient buffer)
+    int64_t fill_words;
+    int fill_blocks;
 };
 
 template <int NT, bool REGION, bool FULL>
 __global__ __launch_bounds__(512, 4) void wmsa_fwd_fused_kernel(const WmsaArgs a) {
+    // Riders: the zero fill of the step's flat gradient buffer (475 MB for Swin-B, 58 us at the HBM rate) is needed by nothing before backward, yet as
+    // its own launch it headed the captured chain.  The forward launches of the stage-2 blocks (288 workgroups for 512 resident slots) each zero a slice
+    // of it with extra workgroups (lavt_wmsa_fwd_rider).
+    if ((int)blockIdx.x >= a.nwin * a.heads) {
+        const int64_t rb = (int64_t)blockIdx.x - (int64_t)a.nwin * a.heads;
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (int64_t e = rb * 512 + threadIdx.x; e < a.fill_words; e += (int64_t)a.fill_blocks * 512) a.fill[e] = z;
+        return;
+    }
     // 8 waves (two workgroups per CU at <= 128 registers).  With 4 waves the K loop of phase 1 was bound by the ISSUE cost of the LDS-DMA instructions
     // (8 per wave per K tile at ~130 cycles each against 36 MFMAs: 10.4 of the kernel's 26 us at C = 512); here a wave issues 4 and owns a
     // (m-tile group, n half) block of the 144 x 96 product.
@@ -376,7 +388,7 @@ template <int NT, bool FULL> int launch_wmsa(const WmsaArgs& a, hipStream_t st) 
         }
         reserved = lds;
     }
-    const dim3 grid(a.nwin * a.heads);
+    const dim3 grid(a.nwin * a.heads + a.fill_blocks);
     if (a.region) hipLaunchKernelGGL((wmsa_fwd_fused_kernel<NT, true, FULL>), grid, dim3(512), lds, st, a);
     else hipLaunchKernelGGL((wmsa_fwd_fused_kernel<NT, false, FULL>), grid, dim3(512), lds, st, a);
     LAVT_CHECK_LAUNCH("lavt_wmsa_fwd");
@@ -399,9 +411,27 @@ extern "C" int lavt_ln_fold_multi(const int64_t* desc, int count, void* stream) 
     return LAVT_OK;
 }
 
+static int wmsa_fwd_impl(const void* x, const int32_t* wmap, const void* Wg, const float* wsum, const float* biasp, const float* bias, const float* gamma,
+                         const float* beta, const float* table, const int8_t* region, int nw_img, void* out, float* lse, void* qkv, void* xn, float* mean,
+                         float* rstd, const void* zeros, int ws, int nwin, int N, int heads, int C, float eps, float scale, void* fill, int64_t fill_bytes, void* stream);
 extern "C" int lavt_wmsa_fwd(const void* x, const int32_t* wmap, const void* Wg, const float* wsum, const float* biasp, const float* bias, const float* gamma,
                              const float* beta, const float* table, const int8_t* region, int nw_img, void* out, float* lse, void* qkv, void* xn, float* mean,
                              float* rstd, const void* zeros, int ws, int nwin, int N, int heads, int C, float eps, float scale, void* stream) {
+    return wmsa_fwd_impl(x, wmap, Wg, wsum, biasp, bias, gamma, beta, table, region, nw_img, out, lse, qkv, xn, mean, rstd, zeros, ws, nwin, N, heads, C, eps, scale, nullptr, 0,
+                         stream);
+}
+// the same launch with a zero-fill rider: `fill_bytes` bytes at `fill` (both multiples of 16) are set to zero by extra workgroups of the launch
+extern "C" int lavt_wmsa_fwd_rider(const void* x, const int32_t* wmap, const void* Wg, const float* wsum, const float* biasp, const float* bias, const float* gamma,
+                                   const float* beta, const float* table, const int8_t* region, int nw_img, void* out, float* lse, void* qkv, void* xn, float* mean,
+                                   float* rstd, const void* zeros, int ws, int nwin, int N, int heads, int C, float eps, float scale, void* fill, int64_t fill_bytes,
+                                   void* stream) {
+    LAVT_CHECK_ARG(fill_bytes == 0 || (fill && fill_bytes > 0 && fill_bytes % 16 == 0 && ((uintptr_t)fill % 16) == 0), "lavt_wmsa_fwd_rider: fill region must be 16-byte aligned");
+    return wmsa_fwd_impl(x, wmap, Wg, wsum, biasp, bias, gamma, beta, table, region, nw_img, out, lse, qkv, xn, mean, rstd, zeros, ws, nwin, N, heads, C, eps, scale, fill,
+                         fill_bytes, stream);
+}
+static int wmsa_fwd_impl(const void* x, const int32_t* wmap, const void* Wg, const float* wsum, const float* biasp, const float* bias, const float* gamma,
+                         const float* beta, const float* table, const int8_t* region, int nw_img, void* out, float* lse, void* qkv, void* xn, float* mean,
+                         float* rstd, const void* zeros, int ws, int nwin, int N, int heads, int C, float eps, float scale, void* fill, int64_t fill_bytes, void* stream) {
     LAVT_CHECK_ARG(x && wmap && Wg && wsum && biasp && bias && gamma && beta && table && out && lse && qkv && xn && mean && rstd && zeros, "lavt_wmsa_fwd: null argument");
     LAVT_CHECK_ARG(nwin > 0 && heads > 0 && C == heads * HD && C % 64 == 0 && ws > 0 && N > 0 && N <= ws * ws && N <= 160 && (!region || nw_img > 0),
                    "lavt_wmsa_fwd: needs C = 32 * heads, C %% 64 == 0, windows of <= 160 tokens");
@@ -409,6 +439,8 @@ extern "C" int lavt_wmsa_fwd(const void* x, const int32_t* wmap, const void* Wg,
     a.x = (const bf16*)x; a.wmap = wmap; a.Wg = (const bf16*)Wg; a.wsum = wsum; a.biasp = biasp; a.bias = bias; a.gamma = gamma; a.beta = beta;
     a.table = table; a.region = region; a.out = (bf16*)out; a.lse = lse; a.qkv = (bf16*)qkv; a.xn = (bf16*)xn; a.mean = mean; a.rstd = rstd; a.zeros = zeros;
     a.nw_img = nw_img; a.wh = ws; a.ww = ws; a.nwin = nwin; a.N = N; a.heads = heads; a.C = C; a.eps = eps; a.scale = scale;
+    a.fill = reinterpret_cast<uint4*>(fill); a.fill_words = fill_bytes / 16;
+    a.fill_blocks = fill_bytes > 0 ? (int)((a.fill_words + 16383) / 16384 < 224 ? (a.fill_words + 16383) / 16384 : 224) : 0;      // <= 224 riders (the slots 288 workgroups leave free), >= 256 KB each
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (N <= 64) return launch_wmsa<4, false>(a, st);
     if (N == 144) return launch_wmsa<9, true>(a, st);

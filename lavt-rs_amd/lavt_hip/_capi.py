@@ -191,6 +191,7 @@ _PROTOTYPES = {
     "lavt_gate_bwd": [i32, vp, vp, vp, vp, vp, vp, i64, vp],
     "lavt_ln_fold": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "lavt_wmsa_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp],
+    "lavt_wmsa_fwd_rider": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp, i64, vp],
     "lavt_pwam_words_fwd": [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "lavt_pwam_words_bwd": [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "lavt_pwam_q_parts": [i32],

@@ -140,7 +140,9 @@ class GradBuckets:
         return sum(4 * (e - s) for b, (s, e) in enumerate(self.buckets) if b != self.late_bucket)
 
     # ---- step protocol: zero() -> forward/backward -> finish() -------------------------------------------------
-    def zero(self):
+    def zero(self, defer_fill=False):
+        """defer_fill (step harness): the zero fill of the flat buffer is handed to lavt_hip.ops.fill_riders -- forward launches zero it slice by slice
+        with rider workgroups, and the harness calls ops.fill_riders.finish() before backward starts"""
         if self._relayout:          # learnt in the first step: parameters nothing reports during backward join the late bucket
             if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("GradBuckets: the bucket layout changes after the first step; run one eager step before capturing")
@@ -149,7 +151,12 @@ class GradBuckets:
                 from . import ops
                 ops.sinks.set(self.params, on_ready=self._on_grad)
         self._relayout = None
-        self.flat.zero_()
+        taken = False
+        if defer_fill:
+            from . import ops
+            taken = ops.fill_riders.begin(self.flat)
+        if not taken:
+            self.flat.zero_()
         lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * 4
         for p in self.params:                      # an optimizer / user may have detached .grad; re-point it
             if p.grad is None or p.grad.data_ptr() != lo + 4 * self.offset_of[id(p)]:

@@ -62,7 +62,7 @@ class TrainStep:
     def _body(self):
         if self.refresh_in_step:
             ops.weights.refresh_all()            # re-cast weights inside the step (for optimizers that do not maintain the compute copies)
-        self.buckets.zero()
+        self.buckets.zero(defer_fill=True)       # the 475 MB zero fill rides on forward launches (ops.fill_riders); the rest is filled before backward
         ops.zero_arena.begin_step(self.x.device)          # one fill for every small zero-initialised buffer of the step
         ops.dtable_chain.job, ops.dtable_chain.keep = None, None          # (a backward that raised mid-way must not leave its binning job to the next step)
         if fp8_enabled():
@@ -73,6 +73,7 @@ class TrainStep:
         else:
             out = self.model(self.x, self.l, self.m)
             loss = F.cross_entropy(out, self.t, weight=self.w)
+        ops.fill_riders.finish()                 # whatever of the gradient buffer no forward launch has zeroed
         loss.backward()
         ops.wgrads.flush()                       # weight-gradient GEMMs still queued for a grouped launch
         ops.ln_deferred.flush()                  # all LayerNorm weight / bias partial sums of this backward: one reduction launch
