@@ -480,7 +480,10 @@ extern "C" int lavt_gemm_tn_pieces(const lavt_gemm_tn_t* p) {
     if (!p || p->K <= 0) return 1;
     const int ktiles = cdiv(p->K, 64);
     const int se = lavt_tuning().tn_split;
-    int n = cdiv(ktiles, 8);
+    // (batched problems -- the per-sample word-side reductions of the fused PWAM node: 2-4 output tiles -- are cut down to 2 K tiles per piece, LAVT_PROBE[4]
+    // overrides: a piece is a serial chain of ~1 us per K tile on the 2-stage ring, and the launch sits on the critical chain)
+    const int min_kt = p->batch > 1 ? (lavt_tuning().probe[4] > 0 ? lavt_tuning().probe[4] : 2) : 8;
+    int n = cdiv(ktiles, min_kt);
     if (se > n) n = se;
     if (n > ktiles) n = ktiles;
     return n < 1 ? 1 : n;

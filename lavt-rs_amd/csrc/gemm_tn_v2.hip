@@ -837,7 +837,8 @@ int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st) {
         split = big ? (int)((384 + tiles / 2) / tiles) : (int)((target + tiles / 2) / tiles);      // ~3 (64-tile) / ~1.5 (128-tile) workgroups per CU
         const int long_k = (ktiles + 127) / 128;          // no workgroup walks more than ~128 K tiles
         if (split < long_k) split = long_k;
-        const int max_split = (ktiles + 7) / 8;           // >= 8 K tiles per workgroup
+        const int min_kt = p.batch > 1 ? (tun.probe[4] > 0 ? tun.probe[4] : 2) : 8;          // (as lavt_gemm_tn_pieces: batched problems down to 2 K tiles per piece)
+        const int max_split = (ktiles + min_kt - 1) / min_kt;           // >= 8 K tiles per workgroup (2 for batched problems)
         if (split > max_split) split = max_split;
         if (split < 1) split = 1;
     }

@@ -82,13 +82,13 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
 
     // ---- prologue: the word matrix and the per-word constants of this sample ----
     const int nch = C >> 3;
-    // (four chunks per thread per pass, every load issued before the first use: as a one-chunk loop the 32 x 1024 matrix of the last stage was a
-    // chain of 16 exposed round trips per thread -- 22 us for a launch whose rows take 2)
-    for (int e0 = tid; e0 < 32 * nch; e0 += 1024) {
-        uint4 raw[4];
-        float4 r0[4], r1[4];
+    // (eight chunks per thread per pass, every load issued before the first use: as a one-chunk loop the 32 x 1024 matrix of the last stage was a
+    // chain of 16 exposed round trips per thread -- 22 us for a launch whose rows take 2; four per pass were still 4 round trips)
+    for (int e0 = tid; e0 < 32 * nch; e0 += 2048) {
+        uint4 raw[8];
+        float4 r0[8], r1[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int e = e0 + 256 * u;
             if (e < 32 * nch) {
                 const int j = e / nch, cc = e - j * nch;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int e = e0 + 256 * u;
             if (e < 32 * nch) {
                 const int j = e / nch, cc = e - j * nch;
@@ -117,9 +117,17 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
         }
     }
     if constexpr (BWD) {
+        // (n_l carries the record count in this mode.)  Eight records per round, every load of a round issued before the first add: as a plain loop over
+        // the records each element was a chain of `records` exposed round trips at the head of a kernel that sits on the critical chain
         for (int e = tid; e < 1024; e += 256) {
             float q = 0.f;
-            for (int wq = 0; wq < a.n_l; ++wq) q += a.Qf[((int64_t)b * a.n_l + wq) * 1056 + e];          // (n_l carries the record count in this mode)
+            for (int w0 = 0; w0 < a.n_l; w0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = w0 + u < a.n_l ? a.Qf[((int64_t)b * a.n_l + w0 + u) * 1056 + e] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q += v[u];          // (fixed order: run-to-run identical)
+            }
             Qn[(e >> 5) * 40 + (e & 31)] = (bf16)(-q);
         }
     }
@@ -142,7 +150,13 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
         if (part == 0) {
             if constexpr (BWD) {
                 float uj = 0.f;
-                for (int wq = 0; wq < a.n_l; ++wq) uj += a.Qf[((int64_t)b * a.n_l + wq) * 1056 + 1024 + j];
+                for (int w0 = 0; w0 < a.n_l; w0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = w0 + u < a.n_l ? a.Qf[((int64_t)b * a.n_l + w0 + u) * 1056 + 1024 + j] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) uj += v[u];
+                }
                 vec[j] = s - uj;
             } else vec[j] = a.vec[b * 32 + j] * LOG2E - s;
         }
@@ -160,6 +174,16 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
         const bf16* w0 = Wm + c16 * LDW + 8 * g;
         const bf16* w1 = w0 + 16 * LDW;
         int ks = 0;
+        for (; ks + 8 <= ksteps; ks += 8) {          // (C >= 256: eight k-steps of row loads in flight -- the last stage's 1024-channel rows were 8 rounds of 4)
+            bf16x8 xf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xf[u] = ldg8(xp + 32 * (ks + u));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(w0 + 32 * (ks + u)), xf[u], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(w1 + 32 * (ks + u)), xf[u], acc[1], 0, 0, 0);
+            }
+        }
         for (; ks + 4 <= ksteps; ks += 4) {
             bf16x8 xf[4];
 #pragma unroll
@@ -367,7 +391,17 @@ __global__ __launch_bounds__(256) void pwam_lang_fwd_kernel(const bf16* __restri
     const bf16* vp1 = vp0 + 16 * ldv;
     const int ksteps = C >> 5;
     int ks = 0;
-    for (; ks + 4 <= ksteps; ks += 4) {          // four k-steps of loads in flight (one per step was a chain of C / 32 exposed round trips)
+    for (; ks + 8 <= ksteps; ks += 8) {          // eight k-steps of loads in flight (one per step was a chain of C / 32 exposed round trips, four per round 8 rounds at C = 1024)
+        bf16x8 wf[8], a0[8], a1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { wf[u] = ldg8(wp + 32 * (ks + u)); a0[u] = ldg8(vp0 + 32 * (ks + u)); a1[u] = ldg8(vp1 + 32 * (ks + u)); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[u], wf[u], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u], wf[u], acc[1], 0, 0, 0);
+        }
+    }
+    for (; ks + 4 <= ksteps; ks += 4) {
         bf16x8 wf[4], a0[4], a1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { wf[u] = ldg8(wp + 32 * (ks + u)); a0[u] = ldg8(vp0 + 32 * (ks + u)); a1[u] = ldg8(vp1 + 32 * (ks + u)); }
@@ -507,7 +541,9 @@ int rows_grid(int tiles_per_sample, int B) {
 #define ST ((hipStream_t)stream)
 
 // workgroups per sample of lavt_pwam_lang_bwd1 = partial [1024 Q | 32 u] records per sample that lavt_pwam_words_bwd sums
-extern "C" int lavt_pwam_q_parts(int C) { const int n = C / 16; return n < 8 ? (n < 1 ? 1 : n) : 8; }
+// workgroups (= partial Q / u records) of lavt_pwam_lang_bwd1 per sample: 16 channels per workgroup per trip; up to 16 workgroups (C = 1024: four
+// trips each instead of eight -- every trip is a barrier-separated round of loads -- and the consumer sums the records eight at a time)
+extern "C" int lavt_pwam_q_parts(int C) { const int n = C / 16; return n < 16 ? (n < 1 ? 1 : n) : 16; }
 
 extern "C" int lavt_pwam_words_fwd(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
                                    void* P, int B, int T, int C, int n_l, float alpha, void* stream) {
