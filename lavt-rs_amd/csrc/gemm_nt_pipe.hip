@@ -1,0 +1,500 @@
+// Gather-GEMM, NT family, software-pipelined K loop (bf16): the long-K problems of the decoder (3x3 convolutions forward and data gradient as
+// implicit GEMMs, reference lib/mask_predictor.py:60-97) and every other problem that takes the 256x256 tile.
+//
+// Why a third K loop.  gemm_v2.hip leaves the order of fragment reads, MFMAs and DMA issue to hipcc, which schedules for register pressure: per K
+// tile a wave issues a few ds_read_b128, waits `lgkmcnt(0)`, runs 4-8 MFMAs, reads again, waits again -- four full LDS round trips per K tile with
+// nothing in flight -- and the ~130 instructions that issue the next tile's DMA run as one block behind the barrier, in every wave at the same
+// time, with the matrix pipe idle.  Its 256x256 form needed 16 waves (128 registers per lane) and spilled 60-78 registers in the epilogue.
+//
+// This kernel:
+//   * 8 waves (2 per SIMD, 256 registers per lane) as 2 (M) x 4 (N) -- wave tiles of 128 x 64 (256x256 tile) or 64 x 32 (128x128 tile): the
+//     256x256 tile moves 192 KB of fragments per K tile from LDS instead of 256 KB; no spills, no scratch;
+//   * fragment reads are issued from inline asm one MFMA GROUP ahead (double-buffered registers: A halves x k-steps for the large tile, k-steps for
+//     the small one) and waited for with counted `s_waitcnt lgkmcnt(n)`: a group's operands land under the previous group's MFMAs;
+//   * ONE barrier per K tile, placed in front of the LAST group: by then every read of the tile has completed (lgkmcnt(0)), so the stage can be
+//     refilled at once (DMA of tile kt + STAGES goes into the stage tile kt occupied: a full ring of STAGES tiles in flight or resident) and the
+//     first fragments of tile kt + 1 are requested;
+//   * the DMA issue is spread over the last group: two MFMAs, one DMA instruction with its address arithmetic, L times.  The K loop is ONE basic
+//     block (tiles beyond K are issued against the zero page, cursor updates are selects), so nothing the compiler does can regroup it;
+//   * convolutions walk K with the TAPS FASTEST (channel block outer): the 9 (27) shifted reads of a 64-channel block of the activations follow each
+//     other, so 8 of 9 come from the XCD's L2; the concat source switches once per launch instead of being selected per DMA instruction.
+// Measured (tools/conv_small_probe.py, hipGraph-timed, against the gemm_v2 form on the same box): 2x120x120 512->512 forward 134.7 -> 125.6 us,
+// 640->512 158.6 -> 146.1 (0.47 of the bf16 peak), 2x60x60 512->512 56.6 -> 50.4, 768->512 80.5 -> 69.2, plain 7200x512x4608 47.4 -> 38.0; data
+// gradients (k-major weight reads) level to -4 %.  What bounds it now (ablation builds, same tool): the DMA stream alone takes 85 us on the
+// 125 us convolution (every CU ingests ~52 GB/s whatever the tile size or ring depth: 12 TB/s over the chip, L2-hit traffic), MFMA + fragment
+// reads alone 99 us (the chip holds ~1.7 GHz under this load: 0.57 of the nominal peak is what an MFMA-only loop reaches) -- the two overlap to 125.
+// DMA geometry (lane-linear LDS images, chunk / slot swizzles applied to the per-lane SOURCE address, zero page for padding and halos) and the
+// epilogue are those of gemm_v2.hip.
+#include "gemm_v2_helpers.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// N ds_read_b128 at addr + BASE + i * STRIDE, issued only (no wait): outputs are early-clobber so that no destination aliases the address
+template <int N, int BASE, int STRIDE> __device__ __forceinline__ void pipe_issue(u32x4 (&f)[N], unsigned addr) {
+    static_assert(N == 2 || N == 4, "N");
+    if constexpr (N == 4)
+        asm volatile("ds_read_b128 %0, %4 offset:%c5\n\tds_read_b128 %1, %4 offset:%c5+%c6\n\tds_read_b128 %2, %4 offset:%c5+%c6*2\n\tds_read_b128 %3, %4 offset:%c5+%c6*3"
+                     : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]) : "v"(addr), "n"(BASE), "n"(STRIDE) : "memory");
+    else
+        asm volatile("ds_read_b128 %0, %2 offset:%c3\n\tds_read_b128 %1, %2 offset:%c3+%c4" : "=&v"(f[0]), "=&v"(f[1]) : "v"(addr), "n"(BASE), "n"(STRIDE) : "memory");
+}
+// transposing reads of NF fragments of a k-major tile (one address register per fragment: the slot swizzle differs per lane), k-step offset KOFF
+template <int NF, int HO, int KOFF> __device__ __forceinline__ void pipe_issue_tr(const unsigned (&a)[NF], u64 (&l)[NF], u64 (&h)[NF]) {
+    static_assert(NF == 2 || NF == 4, "NF");
+    if constexpr (NF == 4)
+        asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%c13\n\tds_read_b64_tr_b16 %1, %8 offset:%c13+%c12\n\t"
+                     "ds_read_b64_tr_b16 %2, %9 offset:%c13\n\tds_read_b64_tr_b16 %3, %9 offset:%c13+%c12\n\t"
+                     "ds_read_b64_tr_b16 %4, %10 offset:%c13\n\tds_read_b64_tr_b16 %5, %10 offset:%c13+%c12\n\t"
+                     "ds_read_b64_tr_b16 %6, %11 offset:%c13\n\tds_read_b64_tr_b16 %7, %11 offset:%c13+%c12"
+                     : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]), "=&v"(l[2]), "=&v"(h[2]), "=&v"(l[3]), "=&v"(h[3])
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(HO), "n"(KOFF) : "memory");
+    else
+        asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%c7\n\tds_read_b64_tr_b16 %1, %4 offset:%c7+%c6\n\t"
+                     "ds_read_b64_tr_b16 %2, %5 offset:%c7\n\tds_read_b64_tr_b16 %3, %5 offset:%c7+%c6"
+                     : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]) : "v"(a[0]), "v"(a[1]), "n"(HO), "n"(KOFF) : "memory");
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): indices that stay compile-time constants inside a lambda (a `#pragma unroll` loop over a
+// lambda's int parameter left the per-instruction pointer arrays dynamically indexed in the prologue: 64 bytes of scratch per lane)
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+template <int CNT> __device__ __forceinline__ void pipe_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory"); }
+// ties registers to the wait in front of it: consumers of `f` cannot be scheduled above this (empty) statement, which stays behind the wait
+template <int N> __device__ __forceinline__ void pipe_tie(u32x4 (&f)[N]) {
+    if constexpr (N == 4) asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+    else asm volatile("" : "+v"(f[0]), "+v"(f[1]));
+}
+template <int N> __device__ __forceinline__ void pipe_tie(u64 (&l)[N], u64 (&h)[N]) {
+    if constexpr (N == 4) asm volatile("" : "+v"(l[0]), "+v"(h[0]), "+v"(l[1]), "+v"(h[1]), "+v"(l[2]), "+v"(h[2]), "+v"(l[3]), "+v"(h[3]));
+    else asm volatile("" : "+v"(l[0]), "+v"(h[0]), "+v"(l[1]), "+v"(h[1]));
+}
+
+// B fragments of one k-step: k-contiguous tiles are read like A (ds_read_b128), k-major tiles by two transposing reads per fragment
+template <bool BKM, int NI> struct BFrags {
+    u32x4 kc[BKM ? 1 : NI];
+    u64 lo[BKM ? NI : 1], hi[BKM ? NI : 1];
+    __device__ __forceinline__ bf16x8 get(int j) const {
+        if constexpr (BKM) return frag_from(lo[j], hi[j]);
+        else return __builtin_bit_cast(bf16x8, kc[j]);
+    }
+    __device__ __forceinline__ void tie() {
+        if constexpr (BKM) pipe_tie<NI>(lo, hi);
+        else pipe_tie<NI>(kc);
+    }
+};
+
+template <int BM, int BN, bool BKM, int STAGES, int MODE, int LEAN>
+__global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t p) {
+    constexpr bool SIMPLE = MODE == 1, CONVFAST = MODE == 2;
+    using T = bf16;
+    constexpr int WAVES = 8, BK = 64, EPC = 8;
+    constexpr int WAVES_N = 4;
+    constexpr int A_INSTR = BM / (8 * WAVES), B_INSTR = BN / (8 * WAVES);      // DMA instructions per wave per K tile (8 rows x 8 chunks each)
+    constexpr int B_CH = BN / EPC;
+    constexpr int L = A_INSTR + B_INSTR;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int WM = BM / 2, WN = BN / WAVES_N, MI = WM / 16, NI = WN / 16;
+    constexpr bool SPLITA = MI == 8;                                         // large tile: MFMA groups of (half the A fragments) x (all B fragments) of a k-step
+    constexpr int MIH = SPLITA ? MI / 2 : MI;
+    static_assert(MIH == 4 && (NI == 2 || NI == 4), "wave tiles of 128 x 64 or 64 x 32");
+    // lgkmcnt is a 4-bit counter: the largest batch that stays in flight behind a counted wait
+    constexpr int NB = BKM ? 2 * NI : NI;                                    // LDS instructions of one k-step of B fragments
+    static_assert(MIH + NB <= 15, "counted LDS waits");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (scalar: LDS destinations of the DMA go through M0)
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_id = xcd_tile_id(blockIdx.x, gridDim.x);
+    const int tile_m = tile_id / tiles_n, tile_n = tile_id % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int bz = blockIdx.y;
+
+    const T* A = reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.strideA;
+    const T* A2 = reinterpret_cast<const T*>(p.A2);
+    const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.strideB;
+    const T* Z = reinterpret_cast<const T*>(p.zeros);
+    const bool conv = p.conv_kc > 0;
+    const ConvGeom cg = conv_geom(p);
+
+    // ---- per-lane DMA geometry (as gemm_v2.hip) --------------------------------------------------------------------
+    const int cl = (lane & 7) ^ (lane >> 3);
+    int a_src[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int m = m0 + (wave * A_INSTR + i) * 8 + (lane >> 3);
+        int src = -1;
+        if (m < p.M) src = p.a_rowmap ? p.a_rowmap[m] : m;
+        a_src[i] = src;
+    }
+    int b_row[B_INSTR], b_col[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        if constexpr (!BKM) {
+            const int n = n0 + (wave * B_INSTR + i) * 8 + (lane >> 3);
+            b_row[i] = n < p.N ? n : -1;
+            b_col[i] = 0;
+        } else {
+            const int q = (wave * B_INSTR + i) * 64 + lane;
+            const int kr = q / B_CH, cc = (q - kr * B_CH) ^ tn_swz<B_CH>(kr);
+            const int n = n0 + cc * EPC;
+            b_row[i] = n < p.N ? kr : -1;
+            b_col[i] = n;
+        }
+    }
+    const T* a_ptr[A_INSTR];
+    const T* b_ptr[B_INSTR];
+    int64_t b_step[B_INSTR];
+    int a_step[A_INSTR];
+    if constexpr (SIMPLE) {
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            a_ptr[i] = a_src[i] >= 0 ? A + (int64_t)a_src[i] * p.lda + cl * EPC : Z;
+            a_step[i] = a_src[i] >= 0 ? BK : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            if constexpr (!BKM) {
+                b_ptr[i] = b_row[i] >= 0 ? B + (int64_t)b_row[i] * p.ldb + cl * EPC : Z;
+                b_step[i] = b_row[i] >= 0 ? BK : 0;
+            } else {
+                b_ptr[i] = b_row[i] >= 0 ? B + (int64_t)b_row[i] * p.ldb + b_col[i] : Z;
+                b_step[i] = b_row[i] >= 0 ? (int64_t)BK * p.ldb : 0;
+            }
+        }
+    }
+    // CONVFAST: a bit per tap "this row's neighbour lies inside the volume" and the row's pointers into the two sources at the lane's channel chunk
+    unsigned a_vmask[A_INSTR];
+    const T* a_p1[A_INSTR];
+    const T* a_p2[A_INSTR];
+    int64_t b_lane_off[B_INSTR];
+    int c_kin = 0, c_tap = 0, c_dz = 0, c_dy = 0, c_dx = 0, c_tap0 = 0, c_ntap = cg.taps;
+    if constexpr (CONVFAST) {
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            unsigned m = 0;
+            if (a_src[i] >= 0) {
+                int z, y, x;
+                conv_coords(cg, a_src[i], z, y, x);
+                for (int t = 0; t < cg.taps; ++t) {
+                    int dz, dy, dx;
+                    conv_tap(cg, t, dz, dy, dx);
+                    if (p.conv_flip) { dz = -dz; dy = -dy; dx = -dx; }
+                    const bool ok = ((unsigned)(z + dz) < (unsigned)cg.d) & ((unsigned)(y + dy) < (unsigned)cg.h) & ((unsigned)(x + dx) < (unsigned)cg.w);
+                    m |= (ok ? 1u : 0u) << t;
+                }
+            }
+            a_vmask[i] = m;
+            const int64_t row = a_src[i] >= 0 ? a_src[i] : 0;
+            a_p1[i] = A + row * p.lda + cl * EPC;
+            a_p2[i] = A2 ? A2 + row * p.lda2 + cl * EPC : a_p1[i];
+        }
+        if (p.conv_tap_split > 0) { c_tap = bz * p.conv_tap_split; c_ntap = p.conv_tap_split; }
+        c_tap0 = c_tap;
+        conv_tap(cg, c_tap, c_dz, c_dy, c_dx);
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            if constexpr (!BKM) {
+                b_ptr[i] = b_row[i] >= 0 ? B + (int64_t)b_row[i] * p.ldb + cl * EPC : Z;
+                b_step[i] = b_row[i] >= 0 ? BK : 0;
+            } else {
+                b_lane_off[i] = b_row[i] >= 0 ? (int64_t)b_row[i] * p.ldb + b_col[i] : -1;
+            }
+        }
+    }
+    const bool has_a2 = p.A2 != nullptr;
+    const int64_t lda1 = p.lda, lda2 = p.lda2;
+    const int a_split = p.a_split, conv_kc = p.conv_kc, flip = p.conv_flip;
+
+    // ---- DMA issue of one K tile, in three parts so that the L instructions can be spread between MFMAs ---------------------------------
+    // issue_begin: the wave-uniform part (scalar unit); issue_one(idx): DMA instruction idx (A rows first, then B); issue_end: cursor advance.
+    // `past` = the tile lies beyond K (the loop issues STAGES tiles ahead unconditionally, so that it has no branches and the counted waits
+    // are constants): such a tile reads the zero page / the start of the weight rows.
+    // the concat source the channel blocks currently come from: with taps fastest the channel block only grows, so the rows switch from the first
+    // source to the second ONCE (issue_end) instead of being selected per DMA instruction
+    const T* a_cur[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) a_cur[i] = CONVFAST ? a_p1[i] : nullptr;
+    int64_t cur_lda = lda1;
+    int cur_base = 0;
+    int64_t u_off = 0;
+    bool u_past = false;
+    unsigned u_bit = 0;
+    int u_boff = 0, u_kt = 0;
+    const T* u_bb = B;
+    int t0_dz = c_dz, t0_dy = c_dy, t0_dx = c_dx;
+    // running position in the weight operand (advanced in issue_end: no 64-bit multiplies per K tile): k-major B -- pointer to (tap, channel block);
+    // k-contiguous B -- column offset of (tap, channel block) inside the [Cout][taps][Cin] rows
+    const T* c_bb = B + (int64_t)c_tap0 * p.b_tap_stride;
+    const int64_t bb_tap = p.b_tap_stride, bb_wrap = (int64_t)BK * p.ldb - (int64_t)(c_ntap - 1) * p.b_tap_stride;
+    int c_boff = 0;
+    const int boff_wrap = BK - (c_ntap - 1) * conv_kc;
+    auto issue_begin = [&](int kt, bool past) {
+        u_past = past; u_kt = kt;
+        if constexpr (CONVFAST) {
+            const int delta = ((c_dz * cg.h + c_dy) * cg.w + c_dx) * (flip ? -1 : 1);          // element offset of this K tile's (tap, channel block) relative to a row pointer
+            u_off = (int64_t)delta * cur_lda + (c_kin - cur_base);
+            u_bit = past ? 0u : 1u << c_tap;
+            u_boff = past ? 0 : c_boff;
+            u_bb = past ? B : c_bb;
+        }
+    };
+    auto issue_one = [&](auto idx_c, char* sbase) {
+        constexpr int idx = decltype(idx_c)::value;
+        if constexpr (idx < A_INSTR) {
+            constexpr int i = idx;
+            char* dst = sbase + (wave * A_INSTR + i) * 1024;
+            if constexpr (SIMPLE) {
+                dma16(u_past ? Z : a_ptr[i], dst);
+                a_ptr[i] += a_step[i];
+            } else if constexpr (CONVFAST) {
+                dma16((a_vmask[i] & u_bit) ? a_cur[i] + u_off : Z, dst);
+            } else {
+                const int k = u_kt * BK + cl * EPC;
+                int kin = k, dz = 0, dy = 0, dx = 0;
+                if (conv) {
+                    const int tap = k / p.conv_kc;
+                    kin = k - tap * p.conv_kc;
+                    conv_tap(cg, tap, dz, dy, dx);
+                    if (p.conv_flip) { dz = -dz; dy = -dy; dx = -dx; }
+                }
+                const bool second = (p.A2 != nullptr) && kin >= p.a_split;
+                const T* base = second ? A2 : A;
+                const int64_t ld = second ? p.lda2 : p.lda;
+                const int kk = second ? kin - p.a_split : kin;
+                int src = a_src[i];
+                if (conv) src = conv_nbr(cg, src, dz, dy, dx);
+                dma16((src >= 0 && k < p.K) ? base + (int64_t)src * ld + kk : Z, dst);
+            }
+        } else {
+            constexpr int i = idx - A_INSTR;
+            char* dst = sbase + A_BYTES + (wave * B_INSTR + i) * 1024;
+            if constexpr (SIMPLE) {
+                dma16(u_past ? Z : b_ptr[i], dst);
+                b_ptr[i] += b_step[i];
+            } else if constexpr (CONVFAST) {
+                if constexpr (!BKM) dma16(b_step[i] ? b_ptr[i] + u_boff : Z, dst);
+                else dma16(b_lane_off[i] >= 0 ? u_bb + b_lane_off[i] : Z, dst);
+            } else {
+                const int k = u_kt * BK + cl * EPC;
+                const T* g = Z;
+                if constexpr (!BKM) {
+                    if (b_row[i] >= 0 && k < p.K) g = B + (int64_t)b_row[i] * p.ldb + k;
+                } else {
+                    const int kb = u_kt * BK + b_row[i];
+                    if (b_row[i] >= 0 && kb < p.K) {
+                        int64_t off;
+                        if (conv) { const int t2 = kb / p.conv_kc; off = (int64_t)(kb - t2 * p.conv_kc) * p.ldb + (int64_t)t2 * p.b_tap_stride; }
+                        else off = (int64_t)kb * p.ldb;
+                        g = B + off + b_col[i];
+                    }
+                }
+                dma16(g, dst);
+            }
+        }
+    };
+    auto issue_end = [&]() {
+        if constexpr (CONVFAST) {
+            // taps fastest: the nine (27) shifted reads of a 64-channel block follow each other, so all but the first are served by the XCD's L2.
+            // Selects, no branches: the whole K tile is one basic block.
+            ++c_tap;
+            ++c_dx;
+            const bool wx = c_dx > (cg.kw >> 1);
+            c_dx = wx ? -(cg.kw >> 1) : c_dx;
+            c_dy += wx ? 1 : 0;
+            const bool wy = c_dy > (cg.kh >> 1);
+            c_dy = wy ? -(cg.kh >> 1) : c_dy;
+            c_dz += wy ? 1 : 0;
+            const bool wt = c_tap == c_tap0 + c_ntap;
+            c_tap = wt ? c_tap0 : c_tap;
+            c_dz = wt ? t0_dz : c_dz; c_dy = wt ? t0_dy : c_dy; c_dx = wt ? t0_dx : c_dx;
+            c_kin += wt ? BK : 0;
+            if (has_a2 && wt && c_kin == a_split) {           // (uniform, taken once per launch)
+#pragma unroll
+                for (int i = 0; i < A_INSTR; ++i) a_cur[i] = a_p2[i];
+                cur_lda = lda2; cur_base = a_split;
+            }
+            c_bb += wt ? bb_wrap : bb_tap;
+            c_boff += wt ? boff_wrap : conv_kc;
+        }
+    };
+
+    // ---- fragment read addresses (bytes inside a stage; + the stage base at the read) -----------------------------------
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const unsigned lds0 = lds_addr(smem);
+    unsigned a_rd[2], b_rd[2];                    // k-contiguous tiles: 128-byte rows, chunk index XOR (row & 7); k-step 1 flips chunk bit 2
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_rd[ks] = lds0 + (unsigned)((wm * WM + l15) * 128 + (((ks * 4 + g4) ^ (l15 & 7)) << 4));
+        b_rd[ks] = lds0 + (unsigned)(A_BYTES + (wn * WN + l15) * 128 + (((ks * 4 + g4) ^ (l15 & 7)) << 4));
+    }
+    unsigned b_tr[NI];                            // k-major tiles: swizzled 32-byte slot of column wn*WN + 16 j, row 8 (lane / 16) + (lane % 16) / 4
+    {
+        const int row_off = 8 * g4 + (l15 >> 2), sw = tn_swz<B_CH>(row_off);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            b_tr[j] = lds0 + (unsigned)(A_BYTES + (row_off * BN + ((((wn * WN) / 8 + 2 * j) ^ sw) + ((lane & 3) >> 1)) * 8 + (lane & 1) * 4) * 2);
+    }
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 fa[2][MIH];
+    BFrags<BKM, NI> fb[2];
+
+    // reads of k-step KS of B into buffer `dst`, of A fragments [H * MIH, (H + 1) * MIH) of k-step KS into buffer `dst`
+#define PIPE_LOAD_B(KS, dst, soff)                                                                                                   \
+    do {                                                                                                                              \
+        if constexpr (BKM) {                                                                                                          \
+            unsigned ab_[NI];                                                                                                         \
+            _Pragma("unroll") for (int j_ = 0; j_ < NI; ++j_) ab_[j_] = b_tr[j_] + (soff);                                           \
+            pipe_issue_tr<NI, 4 * BN * 2, (KS) * 32 * BN * 2>(ab_, fb[dst].lo, fb[dst].hi);                                          \
+        } else {                                                                                                                      \
+            pipe_issue<NI, 0, 2048>(fb[dst].kc, b_rd[KS] + (soff));                                                                   \
+        }                                                                                                                             \
+    } while (0)
+#define PIPE_LOAD_A(KS, H, dst, soff) pipe_issue<MIH, (H) * MIH * 2048, 2048>(fa[dst], a_rd[KS] + (soff))
+#define PIPE_MFMA(H, abuf, bbuf)                                                                                                      \
+    do {                                                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < MIH; ++i_) {                                                                          \
+            const bf16x8 av_ = __builtin_bit_cast(bf16x8, fa[abuf][i_]);                                                              \
+            _Pragma("unroll") for (int j_ = 0; j_ < NI; ++j_) acc[(H) * MIH + i_][j_] = mfma16<T>(fb[bbuf].get(j_), av_, acc[(H) * MIH + i_][j_]); \
+        }                                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+    } while (0)
+
+    // MFMAs [C * PER, (C + 1) * PER) of a group (row-major over (A fragment, B fragment)), for the group that shares its time with the DMA issue
+#define PIPE_MFMA_PART(H, abuf, bbuf, C, PER)                                                                                         \
+    do {                                                                                                                              \
+        _Pragma("unroll") for (int m_ = (C) * (PER); m_ < ((C) + 1) * (PER); ++m_) {                                                  \
+            const int i_ = m_ / NI, j_ = m_ % NI;                                                                                     \
+            acc[(H) * MIH + i_][j_] = mfma16<T>(fb[bbuf].get(j_), __builtin_bit_cast(bf16x8, fa[abuf][i_]), acc[(H) * MIH + i_][j_]); \
+        }                                                                                                                             \
+    } while (0)
+    // last group of a K tile: behind the barrier every read of the tile has completed, so its stage is refilled (tile kt + STAGES) while the
+    // group's MFMAs run -- PER MFMAs, then one DMA instruction with its address arithmetic, L times (as one block after the barrier the ~130
+    // instructions of the issue kept the matrix pipe of every wave idle at the same time: 0.3-0.5 us of a 1.8 us K tile)
+#define PIPE_LAST_GROUP(H, abuf, bbuf)                                                                                                \
+    do {                                                                                                                              \
+        wait_vmcnt<(STAGES - 2) * L>();                                                                                               \
+        __builtin_amdgcn_s_barrier();                                                                                                 \
+        PIPE_LOAD_A(0, 0, 0, sn);                                                                                                     \
+        PIPE_LOAD_B(0, 0, sn);                                                                                                        \
+        issue_begin(kt + STAGES, kt + STAGES >= ktiles);                                                                              \
+        static_for<L>([&](auto c_) {                                                                                                  \
+            PIPE_MFMA_PART(H, abuf, bbuf, decltype(c_)::value, (MIH * NI) / L);                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                                        \
+            issue_one(c_, smem + (kt % STAGES) * STAGE_BYTES);                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                        \
+        });                                                                                                                           \
+        issue_end();                                                                                                                  \
+    } while (0)
+    static_assert((MIH * NI) % L == 0, "MFMAs of the last group spread evenly over the DMA instructions");
+
+    const int ktiles = (p.K + BK - 1) / BK;
+#pragma unroll
+    for (int t = 0; t < STAGES; ++t) {
+        issue_begin(t, t >= ktiles);
+        static_for<L>([&](auto c) { issue_one(c, smem + t * STAGE_BYTES); });
+        issue_end();
+    }
+    wait_vmcnt<(STAGES - 1) * L>();                                // tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    PIPE_LOAD_A(0, 0, 0, 0u);
+    PIPE_LOAD_B(0, 0, 0u);
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const unsigned so = (unsigned)((kt % STAGES) * STAGE_BYTES);
+        const unsigned sn = (unsigned)(((kt + 1) % STAGES) * STAGE_BYTES);
+        if constexpr (SPLITA) {
+            // group 0: A lower half x k-step 0          (in flight behind it: A upper half of k-step 0, B of k-step 1)
+            PIPE_LOAD_A(0, 1, 1, so);
+            PIPE_LOAD_B(1, 1, so);
+            pipe_wait<MIH + NB>();
+            pipe_tie<MIH>(fa[0]); fb[0].tie();
+            PIPE_MFMA(0, 0, 0);
+            // group 1: A upper half x k-step 0          (A lower half of k-step 1)
+            PIPE_LOAD_A(1, 0, 0, so);
+            pipe_wait<MIH>();
+            pipe_tie<MIH>(fa[1]); fb[1].tie();
+            PIPE_MFMA(1, 1, 0);
+            // group 2: A lower half x k-step 1          (A upper half of k-step 1)
+            PIPE_LOAD_A(1, 1, 1, so);
+            pipe_wait<MIH>();
+            pipe_tie<MIH>(fa[0]);
+            PIPE_MFMA(0, 0, 1);
+            // group 3: A upper half x k-step 1
+            pipe_wait<0>();
+            pipe_tie<MIH>(fa[1]);
+            PIPE_LAST_GROUP(1, 1, 1);
+        } else {
+            // group 0: k-step 0          (in flight behind it: k-step 1)
+            PIPE_LOAD_A(1, 0, 1, so);
+            PIPE_LOAD_B(1, 1, so);
+            pipe_wait<MIH + NB>();
+            pipe_tie<MIH>(fa[0]); fb[0].tie();
+            PIPE_MFMA(0, 0, 0);
+            // group 1: k-step 1
+            pipe_wait<0>();
+            pipe_tie<MIH>(fa[1]); fb[1].tie();
+            PIPE_LAST_GROUP(0, 1, 1);
+        }
+    }
+    wait_vmcnt<0>();                                               // the tiles issued beyond K
+#undef PIPE_LAST_GROUP
+#undef PIPE_MFMA_PART
+#undef PIPE_LOAD_A
+#undef PIPE_LOAD_B
+#undef PIPE_MFMA
+    nt_epilogue<T, MI, NI, false, false, LEAN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
+}
+
+static inline int conv_taps_of(const lavt_gemm_nt_t& p) {
+    return (p.conv_kd > 0 ? p.conv_kd : 1) * (p.conv_kh > 0 ? p.conv_kh : 3) * (p.conv_kw > 0 ? p.conv_kw : 3);
+}
+template <int BM, int BN, bool BKM, int STAGES, int MODE, int LEAN> int launch_pipe_(const lavt_gemm_nt_t& p, hipStream_t st) {
+    constexpr size_t lds = STAGES * (size_t)(BM * 128 + BN * 128);
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pipe_kernel<BM, BN, BKM, STAGES, MODE, LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            lavt_set_error("lavt_gemm_nt(pipe): cannot reserve %zu bytes of LDS", lds);
+            return LAVT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch);
+    hipLaunchKernelGGL((gemm_nt_pipe_kernel<BM, BN, BKM, STAGES, MODE, LEAN>), grid, dim3(512), lds, st, p);
+    LAVT_CHECK_LAUNCH("lavt_gemm_nt(pipe)");
+    return LAVT_OK;
+}
+template <int BM, int BN, bool BKM, int STAGES, int MODE> int launch_pipe_lean(const lavt_gemm_nt_t& p, hipStream_t st) {
+    if (MODE != 0 && p.act == 0 && !p.mul && !p.Cpre && !p.C2) {      // epilogue instantiations without the features a launch does not use (gemm_common.h)
+        if (!p.bias && !p.R && !p.row_scale && !p.c_rowmap) return launch_pipe_<BM, BN, BKM, STAGES, MODE, 2>(p, st);
+        return launch_pipe_<BM, BN, BKM, STAGES, MODE, 1>(p, st);
+    }
+    return launch_pipe_<BM, BN, BKM, STAGES, MODE, 0>(p, st);
+}
+template <int BM, int BN, bool BKM, int STAGES> int launch_pipe(const lavt_gemm_nt_t& p, hipStream_t st) {
+    const bool simple = p.conv_kc <= 0 && p.A2 == nullptr && p.K % 64 == 0;
+    const bool convfast = p.conv_kc > 0 && p.conv_kc % 64 == 0 && (p.A2 == nullptr || p.a_split % 64 == 0) && conv_taps_of(p) <= 32;
+    if (simple && !lavt_tuning().gemm_general) return launch_pipe_lean<BM, BN, BKM, STAGES, 1>(p, st);
+    if (convfast && !lavt_tuning().gemm_general) return launch_pipe_lean<BM, BN, BKM, STAGES, 2>(p, st);
+    return launch_pipe_lean<BM, BN, BKM, STAGES, 0>(p, st);
+}
+
+}  // namespace
+
+// tile: 256 = the 256x256 tile (2-stage ring, 128 KB of LDS), 128 = the 128x128 tile with `stages` (2 or 4) stages.  bf16 problems with a zero page only
+// (checked by the caller, lavt_gemm_nt_v2).
+int lavt_gemm_nt_pipe(const lavt_gemm_nt_t& p, int tile, int stages, hipStream_t st) {
+    if (tile == 256) return p.b_kmajor ? launch_pipe<256, 256, true, 2>(p, st) : launch_pipe<256, 256, false, 2>(p, st);
+    if (stages == 2) return p.b_kmajor ? launch_pipe<128, 128, true, 2>(p, st) : launch_pipe<128, 128, false, 2>(p, st);
+    return p.b_kmajor ? launch_pipe<128, 128, true, 4>(p, st) : launch_pipe<128, 128, false, 4>(p, st);
+}

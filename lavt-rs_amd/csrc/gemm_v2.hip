@@ -43,7 +43,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
     using T = typename std::conditional<F8, unsigned char, bf16>::type;
     constexpr int BK = F8 ? 128 : 64, EPC = F8 ? 16 : 8;
     static_assert(!(F8 && (BKM || DACT)), "fp8: k-contiguous operands, plain epilogue");
-    constexpr int WAVES_M = WAVES == 16 ? 4 : 2;             // wave grid: WAVES_M (M) x WAVES_N (N); 16 waves: 4 x 4 waves of 64 x 64
+    constexpr int WAVES_M = 2;                               // wave grid: WAVES_M (M) x WAVES_N (N)
     constexpr int WAVES_N = WAVES / WAVES_M;
     constexpr int A_INSTR = BM / (8 * WAVES);                // DMA instructions per wave per K tile for A (8 rows x 8 chunks each)
     constexpr int B_CH = BN / EPC;                           // chunks per k-major B row: [BK][BN] unpadded, 32-byte slots swizzled by tn_swz
@@ -318,31 +318,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
         } else {
         const T* cA = reinterpret_cast<const T*>(smem + (kt % STAGES) * STAGE_BYTES);
         const T* cB = reinterpret_cast<const T*>(smem + (kt % STAGES) * STAGE_BYTES + A_BYTES);
-        if constexpr (WAVES == 16 && BKM) {
-            // one k-step of fragments at a time (64 accumulator + 32 fragment registers of the 128 a lane has with 16 waves per workgroup);
-            // the k-contiguous form below is plain ds_reads the compiler schedules itself (measured 137 vs 142 us on the decoder conv)
-            unsigned ab[NI];
-            const int row_off = 8 * (lane >> 4) + ((lane & 15) >> 2), sw = tn_swz<B_CH>(row_off);
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-                ab[j] = lds_addr(cB) + (unsigned)(row_off * BN + ((((wn * WN) / 8 + 2 * j) ^ sw) + ((lane & 3) >> 1)) * 8 + (lane & 1) * 4) * 2;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 ga[MI], gb[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) ga[i] = frag_kc<T>(cA, wm * WM + i * 16, ks, lane);
-                u64 l[NI], h[NI];
-                if (ks == 0) tr_read_frags_step<NI, 4 * BN * 2, 0>(ab, l, h);
-                else tr_read_frags_step<NI, 4 * BN * 2, 32 * BN * 2>(ab, l, h);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) gb[j] = frag_from(l[j], h[j]);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma16<T>(gb[j], ga[i], acc[i][j]);
-            }
-            continue;
-        }
         bf16x8 fa[2][MI], fb[2][NI];
         if constexpr (BKM) {
             // lane address of (k-step 0, fragment j): row 8*(lane>>4) + ((lane&15)>>2), swizzled 32-byte slot of column wn*WN + 16*j, 8-byte half
@@ -514,6 +489,8 @@ template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(cons
 
 }  // namespace
 
+int lavt_gemm_nt_pipe(const lavt_gemm_nt_t& p, int tile, int stages, hipStream_t st);          // gemm_nt_pipe.hip: software-pipelined K loop
+
 // returns 1 when the problem is not for this kernel (caller falls back to gemm.hip), else a LAVT status
 int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     if (p.dtype == LAVT_FP8) return launch_nt_v2_fp8(p, st);
@@ -545,14 +522,16 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     const long tiles256 = (long)cdiv(p.M, 128) * cdiv(p.N, 256) * p.batch;
     const bool wide = force ? force == 256 : (tun.gemm_wide && tiles256 >= 256 && p.N % 256 == 0 && p.K >= 1024);
     if (wide) { if (p.b_kmajor) GO(128, 256, true, 2, 8); else GO(128, 256, false, 2, 8); }
-    // 256x256 tile, 16 waves (4 x 4 of 64x64), one workgroup per CU: 128 flop per byte of LDS fill.  The 128x128 tile cannot keep enough bytes
-    // in flight per CU to cover the L2 latency at the MFMA rate (160 KiB of LDS); measured 1.02 vs 0.82 PFLOP/s on the decoder conv shape.
+    // 256x256 tile (gemm_nt_pipe.hip: 8 waves of 128 x 64), one workgroup per CU: 128 flop per byte of LDS fill -- every CU ingests at ~50 GB/s whatever
+    // the tile, so the 128x128 tile is fill-bound at half the rate (measured 1.05-1.1 vs 0.6-0.85 PFLOP/s on the decoder conv shapes).
     // Only when its tiles fill the 256 CUs well (whole rounds at >= 80 %).
     const long tiles256x = (long)cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch;
     const long rounds = (tiles256x + 255) / 256;
     const bool huge = force ? force == 512 : (p.N % 256 == 0 && p.K >= 1024 && tiles256x >= 128 && tiles256x * 10 >= rounds * 256 * 8);
-    if (huge) { if (p.b_kmajor) GO(256, 256, true, 2, 16); else GO(256, 256, false, 2, 16); }
+    const int pipe = tun.gemm_pipe;                 // 0: gemm_v2 K loops only; 1: pipelined 256x256; 2: + 128x128 for K >= 1024; 3: + every 128x128 problem
+    if (huge && pipe >= 1) return lavt_gemm_nt_pipe(p, 256, 2, st);          // (the 16-wave 256x256 form of rounds 2-3 is gone: 128 registers per lane, 60-78 spilled in its epilogue)
     if (big) {
+        if (waves == 8 && (pipe >= 3 || (pipe == 2 && p.K >= 1024))) return lavt_gemm_nt_pipe(p, 128, stages == 2 ? 2 : 4, st);
         if (waves == 8) {
             if (stages == 2) { if (p.b_kmajor) GO(128, 128, true, 2, 8); else GO(128, 128, false, 2, 8); }
             if (stages == 3) { if (p.b_kmajor) GO(128, 128, true, 3, 8); else GO(128, 128, false, 3, 8); }

@@ -63,21 +63,6 @@ __device__ __forceinline__ void tr_read_frags(const unsigned (&a)[NF], u64 (&l0)
     }
     __builtin_amdgcn_sched_barrier(0);
 }
-// One k-step (32 K rows) only: the 16-wave 256x256 tiles have 128 registers per lane and hold one k-step of operands at a time.
-template <int NF, int HO, int KOFF>
-__device__ __forceinline__ void tr_read_frags_step(const unsigned (&a)[NF], u64 (&l)[NF], u64 (&h)[NF]) {
-    static_assert(NF == 4, "NF");
-    asm volatile(
-        "ds_read_b64_tr_b16 %0, %8 offset:%c13\n\tds_read_b64_tr_b16 %1, %8 offset:%c13+%c12\n\t"
-        "ds_read_b64_tr_b16 %2, %9 offset:%c13\n\tds_read_b64_tr_b16 %3, %9 offset:%c13+%c12\n\t"
-        "ds_read_b64_tr_b16 %4, %10 offset:%c13\n\tds_read_b64_tr_b16 %5, %10 offset:%c13+%c12\n\t"
-        "ds_read_b64_tr_b16 %6, %11 offset:%c13\n\tds_read_b64_tr_b16 %7, %11 offset:%c13+%c12\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]), "=&v"(l[2]), "=&v"(h[2]), "=&v"(l[3]), "=&v"(h[3])
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(HO), "n"(KOFF)
-        : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
 // 32-byte slot swizzle of a k-major [64][CH x 16 B] tile: the 16 K rows one transposing read touches (rows r, r+1, r+2, r+3 of four 8-row
 // blocks) land in different slots.  Uses row bits 0, 1, 3, 4 only, so rows r + 4 and r + 32 share the swizzle of row r.
 template <int CH> __device__ __forceinline__ int tn_swz(int kr) {

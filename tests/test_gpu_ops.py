@@ -112,6 +112,43 @@ def test_gemm_forced_tiles(dtype, tile, monkeypatch, request):
     run_pair(lambda x1, w, x2: ops.conv3x3(x1, x2, w, B, H, W), ref, inputs, dtype, name=f"conv tile {tile}", bf16=4e-2)
 
 
+@pytest.mark.parametrize("tile,stages", [("512", "0"), ("128", "4"), ("128", "2")])
+def test_gemm_pipelined_k_loop(tile, stages, monkeypatch, request):
+    """csrc/gemm_nt_pipe.hip (software-pipelined K loop, 8 waves: fragment reads one MFMA group ahead, one barrier per K tile, DMA issue spread between
+    the MFMAs of the last group, taps-fastest K order for convolutions) in its three configurations -- 256x256 tile, 128x128 tile with a 4- and a
+    2-stage ring -- and its three DMA modes: plain (K % 64 == 0), tap-walking convolution (channels % 64 == 0, with a concat source and with a
+    tap-split reduction), general decode (K tail / odd channel counts); k-contiguous (forward) and k-major (data gradient) weight reads."""
+    from lavt_hip import ops, _capi as K
+    for k, v in (("LAVT_GEMM_TILE", tile), ("LAVT_GEMM_STAGES", stages), ("LAVT_GEMM_PIPE", "3")):
+        monkeypatch.setenv(k, v)
+    K.lib.lavt_tuning_reload()
+    request.addfinalizer(lambda: ([os.environ.pop(k, None) for k in ("LAVT_GEMM_TILE", "LAVT_GEMM_STAGES", "LAVT_GEMM_PIPE")], K.lib.lavt_tuning_reload()))
+    dtype = torch.bfloat16
+    for (M, N, Kd) in ((700, 328, 256), (700, 328, 264), (130, 520, 64), (1000, 256, 1024)):
+        inputs = {"x": (rnd(M, Kd, seed=1), "act"), "w": (rnd(N, Kd, seed=2, scale=Kd ** -0.5), "param"), "b": (rnd(N, seed=3), "param")}
+        run_pair(lambda x, w, b: ops.linear(x, w, b), lambda x, w, b: F.linear(x, w, b), inputs, dtype, name=f"pipe linear {M}x{N}x{Kd} tile {tile}/{stages}")
+    for (B, H, W, C1, C2, Cout) in ((2, 13, 11, 128, 64, 136), (2, 13, 11, 96, 32, 136), (1, 30, 30, 512, 0, 128), (2, 9, 20, 64, 0, 256), (1, 24, 24, 256, 128, 256)):
+        Cin = C1 + C2
+        inputs = {"x1": (rnd(B * H * W, C1, seed=1), "act"), "w": (rnd(Cout, Cin, 3, 3, seed=3, scale=(9 * Cin) ** -0.5), "param")}
+        if C2:
+            inputs["x2"] = (rnd(B * H * W, C2, seed=2), "act")
+
+        def ref(x1, w, x2=None):
+            x = x1 if x2 is None else torch.cat([x1, x2], 1)
+            y = F.conv2d(x.view(B, H, W, Cin).permute(0, 3, 1, 2), w, padding=1)
+            return y.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+        run_pair(lambda x1, w, x2=None: ops.conv3x3(x1, x2, w, B, H, W), ref, inputs, dtype, name=f"pipe conv {B}x{H}x{W} {C1}+{C2}->{Cout} tile {tile}/{stages}", bf16=4e-2)
+    # Conv3d of SepTPWAM (27 taps, bias + GELU epilogue, tap-split forward at few rows)
+    from lavt_hip._capi import ACT_GELU
+    B, D, H, W, Cin, Cout, ks = 1, 4, 6, 6, 64, 64, (3, 3, 3)
+    inputs = {"x": (rnd(B * D * H * W, Cin, seed=1), "act"), "w": (rnd(Cout, Cin, *ks, seed=3, scale=(27 * Cin) ** -0.5), "param"), "b": (0.1 * rnd(Cout, seed=4), "param")}
+
+    def ref3(x, w, b):
+        y = F.conv3d(x.view(B, D, H, W, Cin).permute(0, 4, 1, 2, 3), w, b, padding=1)
+        return F.gelu(y.permute(0, 2, 3, 4, 1).reshape(B * D * H * W, Cout))
+    run_pair(lambda x, w, b: ops.conv3d(x, w, b, B, D, H, W, act=ACT_GELU), ref3, inputs, dtype, name=f"pipe conv3d tile {tile}/{stages}", bf16=4e-2)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_linear_gelu_residual(dtype):
     from lavt_hip import ops
