@@ -150,9 +150,23 @@ typedef struct lavt_gemm_nt {
     float* ln_mean;
     float* ln_rstd;
     float ln_eps;
+    /* Column statistics of the output from the epilogue (ABI v6): BatchNorm statistics of a bias-free convolution without a pass over its output
+     * (reference lib/mask_predictor.py:60-97: conv -> BatchNorm2d -> ReLU).  colstats != NULL: every block of `rows_per_block` output rows (both as
+     * reported by lavt_gemm_nt_colstats_plan for this problem) stores, per column n, the sum of its rows and their second moment about the block's
+     * own mean -- colstats[(block * 2 + 0) * N + n], colstats[(block * 2 + 1) * N + n] -- taken from the fp32 accumulators (alpha applied, before
+     * the rounding to bf16).  lavt_colstats_finish_blocks combines the blocks (parallel-variance form, no E[x^2] - E[x]^2).  Only for launches
+     * lavt_gemm_nt_colstats_plan accepts (LAVT_ERR_INVALID otherwise): bf16, batch 1, no bias / activation / residual / row map / fp32 output. */
+    float* colstats;
 } lavt_gemm_nt_t;
 
 int lavt_gemm_nt(const lavt_gemm_nt_t* p, void* stream);
+/* -> number of row blocks whose partial statistics lavt_gemm_nt(p) would store into p->colstats (0: this problem's kernel has no statistics
+ * epilogue -- leave colstats NULL and take the statistics from the output with lavt_colstats_meanrstd); *rows_per_block = rows per block */
+int lavt_gemm_nt_colstats_plan(const lavt_gemm_nt_t* p, int* rows_per_block);
+/* second stage: blocks' (sum, centred second moment) pairs -> mean / rstd (+ running estimates, momentum form of nn.BatchNorm2d) and / or the
+ * (sum, M2) pair of all `rows` rows (sum_out / m2_out: what the SyncBatchNorm exchange carries).  Any of the output groups may be NULL. */
+int lavt_colstats_finish_blocks(const float* partials, int nblk, int rows_per_block, int rows, int C, float eps, float* mean, float* rstd,
+                                float* sum_out, float* m2_out, float* running_mean, float* running_var, float momentum, void* stream);
 /* out[m][n] (dtype) = sum_s parts[s][m][n] (fp32): second stage of a split reduction of lavt_gemm_nt (c_f32 partial outputs, one per batch entry) */
 int lavt_splitk_reduce(int dtype, const float* parts, int splits, int64_t M, int N, void* out, int64_t ldc, void* stream);
 
@@ -347,6 +361,8 @@ int lavt_reduce_partials_multi(const int64_t* desc, int n, void* stream);
  *   hundreds of workgroups adding to the same C addresses).
  * lavt_norm_apply: y = ((x-mean)*rstd*gamma + beta) (*mul) with optional ReLU; mean/rstd [groups][C]; gamma/beta/mul optional.
  * lavt_norm_bwd_stats: s1 = sum(g), s2 = sum(g*xhat) (cleared by the call when scratch is given, else added to the zeroed buffers passed in) with g = dy (*mul) masked by relu (y>0);  [groups][C].
+ *   With relu, gamma / beta given and no mul (BatchNorm + ReLU of the decoder) the mask is recomputed from x with lavt_norm_apply's own expression and y is not read
+ *   (lavt_norm_bwd_apply likewise): two of the seven map passes of the BatchNorm backward less.
  * lavt_norm_bwd_apply: dx = gamma*rstd*(g - s1/n - xhat*s2/n); dmul = dy*xhat_affine (optional).
  * ------------------------------------------------------------------------------------------- */
 int lavt_colstats(int dtype, const void* x, float* sum, float* m2, float* ws, int64_t ws_floats, int groups, int rows, int C, void* stream);

@@ -412,6 +412,8 @@ template <typename T> int dispatch_tn(const lavt_gemm_tn_t& p, hipStream_t st) {
 }  // namespace
 
 int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st);
+int lavt_gemm_nt_pipe_tile(const lavt_gemm_nt_t& p, int* stages_out);          // gemm_nt_pipe.hip: software-pipelined K loop
+int lavt_gemm_nt_pipe(const lavt_gemm_nt_t& p, int tile, int stages, hipStream_t st);
 int lavt_gemm_tn_v2(const lavt_gemm_tn_t& p, hipStream_t st);
 
 extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
@@ -447,6 +449,15 @@ extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
       p.epi_wide = (!wide_off && p.dtype != LAVT_F32 && !p.c_f32 && p.ldc % 8 == 0 && (!p.C2 || (p.ldc2 % 8 == 0 && p.c_split % 8 == 0)) && (!p.R || p.ldr % 4 == 0) &&
                     (!p.Cpre || p.ldcpre % 8 == 0) && (!p.dact_pre || p.lddact % 4 == 0) && (!p.bias || (p.strideBias % 4 == 0 && ((uintptr_t)p.bias % 16) == 0)) &&
                     ((uintptr_t)p.C % 16) == 0 && (!p.C2 || ((uintptr_t)p.C2 % 16) == 0) && (!p.Cpre || ((uintptr_t)p.Cpre % 16) == 0) && (p.strideC % 8 == 0)) ? 1 : 0; }
+    if (p.colstats) {
+        int rpb = 0;
+        LAVT_CHECK_ARG(lavt_gemm_nt_colstats_plan(&p, &rpb) > 0, "lavt_gemm_nt: colstats only where lavt_gemm_nt_colstats_plan accepts the problem (pipelined bf16 tiles, plain epilogue)");
+    }
+    {
+        int pipe_stages = 0;
+        const int pipe_tile = lavt_gemm_nt_pipe_tile(p, &pipe_stages);          // the 256x256 tile and the long-K 128x128 problems (gemm_nt_pipe.hip)
+        if (pipe_tile) return lavt_gemm_nt_pipe(p, pipe_tile, pipe_stages, st);
+    }
     const int rc2 = lavt_gemm_nt_v2(p, st);          // bf16 LDS-DMA pipeline (gemm_v2.hip); 1 = not applicable
     if (rc2 != 1) return rc2;
     LAVT_CHECK_ARG(p.ln_wsum == nullptr, "lavt_gemm_nt: ln_wsum (LayerNorm-folded A operand) exists on the bf16 LDS-DMA path only");

@@ -88,6 +88,56 @@ template <bool BKM, int NI> struct BFrags {
     }
 };
 
+// sum over the 16 lanes of a DPP row, left in every lane: four v_add_f32 with a DPP operand (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror --
+// the mirrors act as xor 4 / xor 8 once the lanes of a quad / half row agree).  (As __shfl_xor = ds_bpermute the 128 exchanges of the statistics
+// epilogue cost 4 us on a 123 us convolution.)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// Column statistics of a wave's [MI * 16 rows] x [NI * 16 columns] accumulator tile (lavt_gemm_nt_t.colstats): per column the sum over the
+// wave's valid rows and the second moment about THEIR mean -- both passes run on registers, so no E[x^2] - E[x]^2 -- stored as block `blk` of
+// the partial table.  C^T accumulator layout: a lane holds 4 consecutive columns of row (lane % 16) of every fragment, the 16 rows of a fragment
+// sit in the 16 lanes of a DPP row: 8 (4) in-register adds + 4 DPP adds per column.
+template <int MI, int NI>
+__device__ __forceinline__ void pipe_colstats(const lavt_gemm_nt_t& p, const f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int blk) {
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nvalid = min(max(p.M - m_base, 0), MI * 16);
+    const float inv = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
+    float* out = p.colstats + (int64_t)blk * 2 * p.N;
+    bool ok[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) ok[i] = m_base + i * 16 + l15 < p.M;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] += ok[i] ? p.alpha * acc[i][j][r] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = row16_sum(s[r]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = p.alpha * acc[i][j][r] - s[r] * inv;
+                q[r] += ok[i] ? d * d : 0.f;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[r] = row16_sum(q[r]);
+        const int n = n_base + j * 16 + 4 * g;
+        if (l15 == 0 && n + 3 < p.N) {                       // (N % 4 == 0: lavt_gemm_nt_colstats_plan)
+            *reinterpret_cast<float4*>(out + n) = make_float4(s[0], s[1], s[2], s[3]);
+            *reinterpret_cast<float4*>(out + p.N + n) = make_float4(q[0], q[1], q[2], q[3]);
+        }
+    }
+}
+
 template <int BM, int BN, bool BKM, int STAGES, int MODE, int LEAN>
 __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t p) {
     constexpr bool SIMPLE = MODE == 1, CONVFAST = MODE == 2;
@@ -453,6 +503,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
 #undef PIPE_LOAD_A
 #undef PIPE_LOAD_B
 #undef PIPE_MFMA
+    if (p.colstats) pipe_colstats<MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, tile_m * 2 + wm);
     nt_epilogue<T, MI, NI, false, false, LEAN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
 }
 
@@ -491,10 +542,50 @@ template <int BM, int BN, bool BKM, int STAGES> int launch_pipe(const lavt_gemm_
 
 }  // namespace
 
-// tile: 256 = the 256x256 tile (2-stage ring, 128 KB of LDS), 128 = the 128x128 tile with `stages` (2 or 4) stages.  bf16 problems with a zero page only
-// (checked by the caller, lavt_gemm_nt_v2).
+// Which tile of this kernel family a problem takes (0: none -- it goes to gemm_v2.hip / gemm.hip) and the ring depth.  Measured on MI355X
+// (tools/gemm_bench.py, tools/conv_small_probe.py): the 256x256 tile (one workgroup per CU, 128 flop per byte of LDS fill -- every CU ingests ~50 GB/s
+// whatever the tile, so the 128x128 tile is fill-bound at half the rate) only when its tiles fill the 256 CUs well (whole rounds at >= 80 %); the 128x128
+// tile for long reductions (K >= 1024; LAVT_GEMM_PIPE=3: every 128x128 problem) where gemm_v2.hip would take its 8-wave 128x128 form.
+int lavt_gemm_nt_pipe_tile(const lavt_gemm_nt_t& p, int* stages_out) {
+    if (p.dtype != LAVT_BF16 || p.zeros == nullptr) return 0;
+    const lavt_tuning_t& tun = lavt_tuning();
+    const int pipe = tun.gemm_pipe;                 // 0: gemm_v2 K loops only; 1: the 256x256 tile; 2: + 128x128 for K >= 1024; 3: + every 128x128 problem
+    if (tun.gemm_v2_off || pipe < 1) return 0;
+    if (p.lda % 8 || p.ldb % 8 || (p.A2 && p.lda2 % 8)) return 0;
+    if (p.ln_wsum || p.dact_pre) return 0;
+    const int force = tun.gemm_tile;
+    const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
+    const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;
+    const int big_long = tun.gemm_big_long;
+    const bool big = force ? force == 128 : ((tiles128 >= 200 || (big_long > 0 && p.K >= 64 * 64 && tiles128 >= big_long)) && p.N >= 128);
+    const long wgs = big ? tiles128 : tiles64;
+    const int stages = tun.gemm_stages ? tun.gemm_stages : (wgs >= 600 ? 2 : 4);
+    const long tiles256 = (long)cdiv(p.M, 128) * cdiv(p.N, 256) * p.batch;
+    const bool wide = force ? force == 256 : (tun.gemm_wide && tiles256 >= 256 && p.N % 256 == 0 && p.K >= 1024);
+    if (wide) return 0;
+    const long tiles256x = (long)cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch;
+    const long rounds = (tiles256x + 255) / 256;
+    const bool huge = force ? force == 512 : (p.N % 256 == 0 && p.K >= 1024 && tiles256x >= 128 && tiles256x * 10 >= rounds * 256 * 8);
+    if (huge) { *stages_out = 2; return 256; }
+    if (big && tun.gemm_waves == 8 && (pipe >= 3 || (pipe == 2 && p.K >= 1024))) { *stages_out = stages == 2 ? 2 : 4; return 128; }
+    return 0;
+}
+
+// tile: 256 = the 256x256 tile (2-stage ring, 128 KB of LDS), 128 = the 128x128 tile with `stages` (2 or 4) stages
 int lavt_gemm_nt_pipe(const lavt_gemm_nt_t& p, int tile, int stages, hipStream_t st) {
     if (tile == 256) return p.b_kmajor ? launch_pipe<256, 256, true, 2>(p, st) : launch_pipe<256, 256, false, 2>(p, st);
     if (stages == 2) return p.b_kmajor ? launch_pipe<128, 128, true, 2>(p, st) : launch_pipe<128, 128, false, 2>(p, st);
     return p.b_kmajor ? launch_pipe<128, 128, true, 4>(p, st) : launch_pipe<128, 128, false, 4>(p, st);
+}
+
+extern "C" int lavt_gemm_nt_colstats_plan(const lavt_gemm_nt_t* pp, int* rows_per_block) {
+    if (!pp || !rows_per_block) return 0;
+    const lavt_gemm_nt_t& p = *pp;
+    *rows_per_block = 0;
+    if (p.batch != 1 || p.bias || p.act || p.R || p.row_scale || p.c_rowmap || p.c_f32 || p.C2 || p.Cpre || p.mul || p.N % 4 || p.M <= 0 || p.N <= 0) return 0;
+    int stages = 0;
+    const int tile = lavt_gemm_nt_pipe_tile(p, &stages);
+    if (!tile) return 0;
+    *rows_per_block = tile / 2;                      // a wave row of the 2 x 4 wave grid
+    return cdiv(p.M, tile) * 2;
 }

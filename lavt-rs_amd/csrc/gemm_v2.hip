@@ -489,8 +489,6 @@ template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(cons
 
 }  // namespace
 
-int lavt_gemm_nt_pipe(const lavt_gemm_nt_t& p, int tile, int stages, hipStream_t st);          // gemm_nt_pipe.hip: software-pipelined K loop
-
 // returns 1 when the problem is not for this kernel (caller falls back to gemm.hip), else a LAVT status
 int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     if (p.dtype == LAVT_FP8) return launch_nt_v2_fp8(p, st);
@@ -528,10 +526,8 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     const long tiles256x = (long)cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch;
     const long rounds = (tiles256x + 255) / 256;
     const bool huge = force ? force == 512 : (p.N % 256 == 0 && p.K >= 1024 && tiles256x >= 128 && tiles256x * 10 >= rounds * 256 * 8);
-    const int pipe = tun.gemm_pipe;                 // 0: gemm_v2 K loops only; 1: pipelined 256x256; 2: + 128x128 for K >= 1024; 3: + every 128x128 problem
-    if (huge && pipe >= 1) return lavt_gemm_nt_pipe(p, 256, 2, st);          // (the 16-wave 256x256 form of rounds 2-3 is gone: 128 registers per lane, 60-78 spilled in its epilogue)
+    (void)huge;                                     // (the 256x256 tile and the long-K 128x128 problems are taken by gemm_nt_pipe.hip before this dispatcher: gemm.hip)
     if (big) {
-        if (waves == 8 && (pipe >= 3 || (pipe == 2 && p.K >= 1024))) return lavt_gemm_nt_pipe(p, 128, stages == 2 ? 2 : 4, st);
         if (waves == 8) {
             if (stages == 2) { if (p.b_kmajor) GO(128, 128, true, 2, 8); else GO(128, 128, false, 2, 8); }
             if (stages == 3) { if (p.b_kmajor) GO(128, 128, true, 3, 8); else GO(128, 128, false, 3, 8); }

@@ -139,7 +139,8 @@ template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, const T* __restrict__ xin, const T* __restrict__ yout,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const T* __restrict__ mul, int relu, float* __restrict__ o1,
-                                                       float* __restrict__ o2, float* __restrict__ partials, int rows, int C, int rows_per_block, int zero_out) {
+                                                       float* __restrict__ o2, float* __restrict__ partials, int rows, int C, int rows_per_block, int zero_out,
+                                                       const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr) {
     // !BWD: a = x; o1 += sum (x-K), o2 += sum (x-K)^2, K = x[g][0][:].     BWD: a = dy; g = dy (*mul) (masked y>0); o1 += sum g, o2 += sum g*xhat
     constexpr int EPC = Chunk<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -160,10 +161,19 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, 
         const int tc = threadIdx.x % span, tr = threadIdx.x / span, rstep = 256 / span;
         if (tr < rstep) {
             const int col = (cbase + tc) * EPC;
-            float mu[EPC], rs[EPC];
+            float mu[EPC], rs[EPC], sc[EPC], sh[EPC];
+            // BWD with ReLU behind an affine normalisation and no multiplier: the mask y > 0 is recomputed from x with the forward's own expression
+            // (norm_apply_kernel: x * sc + sh) instead of reading the output map -- one of three input streams less
+            const bool remask = BWD && relu && !mul && gamma;
             if (BWD) {
                 ldc<EPC>(mean + (int64_t)g * C + col, mu);
                 ldc<EPC>(rstd + (int64_t)g * C + col, rs);
+                if (remask) {
+                    float ga[EPC], be[EPC];
+                    ldc<EPC>(gamma + col, ga); ldc<EPC>(beta + col, be);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) { sc[e] = rs[e] * ga[e]; sh[e] = be[e] - mu[e] * rs[e] * ga[e]; }
+                }
             } else {
                 // shifted sums: accumulate (x - K) and (x - K)^2 with K = the group's first row, so that the variance does not
                 // come out of E[x^2] - E[x]^2 of large-mean data (colstats_center_kernel undoes the shift)
@@ -188,7 +198,10 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ a, 
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) f[e] *= fm[e];
                     }
-                    if (relu) {
+                    if (remask) {
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) if (!(fx[e] * sc[e] + sh[e] > 0.f)) f[e] = 0.f;
+                    } else if (relu) {
                         float fy[EPC];
                         chunk_to_f<T>(*reinterpret_cast<const uint4*>(yout + off), fy);
 #pragma unroll
@@ -277,6 +290,47 @@ __global__ __launch_bounds__(1024) void colstats_finish_kernel(const float* __re
     }
 }
 
+// Second stage for block statistics that a GEMM epilogue stored (lavt_gemm_nt_t.colstats: per block of rows the column sums and the second moments
+// about the block's own mean): parallel-variance combination in ONE pass over the (small) table, about a pivot p = the mean of block 0:
+//   M2 = sum_b [ M2_b + n_b (mean_b - p)^2 ] - N (mean - p)^2      (the correction term is ~1/rows_per_block of M2: no cancellation to speak of)
+// Workgroup = 32 columns x 32 block slices.
+__global__ __launch_bounds__(1024) void colstats_finish_blocks_kernel(const float* __restrict__ partials, int nblk, int rpb, int rows, int C, float eps,
+                                                                      float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ sum_out,
+                                                                      float* __restrict__ m2_out, float* __restrict__ running_mean,
+                                                                      float* __restrict__ running_var, float momentum) {
+    __shared__ float red[2][32][33];
+    const int c32 = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + c32;
+    const int64_t W = 2 * (int64_t)C;
+    float a = 0.f, b = 0.f, piv = 0.f;
+    if (c < C) {
+        piv = partials[c] / (float)min(rows, rpb);
+        for (int k = slice; k < nblk; k += 32) {
+            const int nb = min(max(rows - k * rpb, 0), rpb);
+            if (nb > 0) {
+                const float sb = partials[(int64_t)k * W + c], qb = partials[(int64_t)k * W + C + c];
+                const float d = sb / (float)nb - piv;
+                a += sb;
+                b += qb + (float)nb * d * d;
+            }
+        }
+    }
+    red[0][slice][c32] = a;
+    red[1][slice][c32] = b;
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        float sum = 0.f, q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { sum += red[0][k][c32]; q += red[1][k][c32]; }
+        const float n = (float)rows, mu = sum / n;
+        const float m2 = fmaxf(q - n * (mu - piv) * (mu - piv), 0.f), var = m2 / n;
+        if (mean) { mean[c] = mu; rstd[c] = rsqrtf(var + eps); }
+        if (sum_out) { sum_out[c] = sum; m2_out[c] = m2; }
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+    }
+}
+
 __global__ void stats_finalize_kernel(const float* sum, const float* m2, float count, float eps, float* mean, float* rstd,
                                       float* running_mean, float* running_var, float momentum, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,10 +411,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
         ldc<EPC>(s1 + (int64_t)g * C + col, a1);
         ldc<EPC>(s2 + (int64_t)g * C + col, a2);
         if (gamma) { ldc<EPC>(gamma + col, ga); ldc<EPC>(beta + col, be); }
+        const bool remask = relu && !mul && gamma;          // the ReLU mask from x with the forward's expression (x * sc + sh > 0): the output map is not read
+        float sc[EPC], sh[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             a1[e] *= inv_count; a2[e] *= inv_count;
             if (!gamma) { ga[e] = 1.f; be[e] = 0.f; }
+            sc[e] = rs[e] * ga[e]; sh[e] = be[e] - mu[e] * rs[e] * ga[e];
         }
 #pragma unroll 2
         for (int r = r_begin + tr; r < r_end; r += rstep) {
@@ -369,13 +426,14 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
             chunk_to_f<T>(*reinterpret_cast<const uint4*>(dy + off), fg);
             chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + off), fx);
             if (mul) chunk_to_f<T>(*reinterpret_cast<const uint4*>(mul + off), fm);
-            if (relu) chunk_to_f<T>(*reinterpret_cast<const uint4*>(yout + off), fy);
+            if (relu && !remask) chunk_to_f<T>(*reinterpret_cast<const uint4*>(yout + off), fy);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 const float xh = (fx[e] - mu[e]) * rs[e];
                 float gg = fg[e];
                 if (mul) { fdm[e] = gg * (xh * ga[e] + be[e]); gg *= fm[e]; }
-                if (relu && !(fy[e] > 0.f)) gg = 0.f;
+                if (remask) { if (!(fx[e] * sc[e] + sh[e] > 0.f)) gg = 0.f; }
+                else if (relu && !(fy[e] > 0.f)) gg = 0.f;
                 fg[e] = ga[e] * rs[e] * (gg - a1[e] - xh * a2[e]);
             }
             *reinterpret_cast<uint4*>(dx + off) = f_to_chunk<T>(fg);
@@ -537,6 +595,17 @@ extern "C" int lavt_colstats(int dtype, const void* x, float* sum, float* sumsq,
     return LAVT_OK;
 }
 
+extern "C" int lavt_colstats_finish_blocks(const float* partials, int nblk, int rows_per_block, int rows, int C, float eps, float* mean, float* rstd,
+                                           float* sum_out, float* m2_out, float* running_mean, float* running_var, float momentum, void* stream) {
+    LAVT_CHECK_ARG(partials && nblk > 0 && rows_per_block > 0 && rows > 0 && C > 0 && (int64_t)nblk * rows_per_block >= rows, "lavt_colstats_finish_blocks: bad arguments");
+    LAVT_CHECK_ARG((mean != nullptr) == (rstd != nullptr) && (sum_out != nullptr) == (m2_out != nullptr) && (mean || sum_out), "lavt_colstats_finish_blocks: mean / rstd and sum / M2 come in pairs");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(colstats_finish_blocks_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, st, partials, nblk, rows_per_block, rows, C, eps, mean, rstd, sum_out, m2_out,
+                       running_mean, running_var, momentum);
+    LAVT_CHECK_LAUNCH("lavt_colstats_finish_blocks");
+    return LAVT_OK;
+}
+
 extern "C" int lavt_colstats_meanrstd(int dtype, const void* x, float* mean, float* rstd, float* ws, int64_t ws_floats, int groups, int rows, int C,
                                       float eps, float* running_mean, float* running_var, float momentum, void* stream) {
     const int epc = dtype == LAVT_F32 ? 4 : 8;
@@ -606,17 +675,16 @@ extern "C" int lavt_norm_apply(int dtype, const void* x, const float* mean, cons
 extern "C" int lavt_norm_bwd_stats(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* rstd,
                                    const float* gamma, const float* beta, const void* mul, int relu, float* s1, float* s2,
                                    float* ws, int64_t ws_floats, int groups, int rows, int C, void* stream) {
-    (void)gamma; (void)beta;
     const int zero_out = 1;          // with scratch (two-stage form) s1 / s2 are cleared by this call; without it they must arrive zeroed (atomics)
     const int epc = dtype == LAVT_F32 ? 4 : 8;
-    LAVT_CHECK_ARG(dy && x && mean && rstd && s1 && s2 && (!relu || y) && groups > 0 && rows > 0 && C % epc == 0, "lavt_norm_bwd_stats: bad arguments");
+    LAVT_CHECK_ARG(dy && x && mean && rstd && s1 && s2 && (!relu || y) && groups > 0 && rows > 0 && C % epc == 0 && (gamma == nullptr) == (beta == nullptr), "lavt_norm_bwd_stats: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rpb;
     const int blocks = stats_launch_geometry(rows, groups, C, epc, &rpb);
     float* partials = (ws && ws_floats >= (int64_t)blocks * groups * 2 * C) ? ws : nullptr;
     DISPATCH_T(dtype, "lavt_norm_bwd_stats",
                hipLaunchKernelGGL((colstats_kernel<T, true>), dim3(blocks, groups), dim3(256), 256 * 2 * Chunk<T>::N * sizeof(float), st,
-                                  (const T*)dy, (const T*)x, (const T*)y, mean, rstd, (const T*)mul, relu, s1, s2, partials, rows, C, rpb, zero_out));
+                                  (const T*)dy, (const T*)x, (const T*)y, mean, rstd, (const T*)mul, relu, s1, s2, partials, rows, C, rpb, zero_out, gamma, beta));
     if (partials) hipLaunchKernelGGL(reduce_partials_kernel, reduce_partials_grid(blocks, groups * 2 * C), dim3(256), 0, st, partials, blocks, groups * 2 * C, C, s1, s2);
     LAVT_CHECK_LAUNCH("lavt_norm_bwd_stats");
     return LAVT_OK;

@@ -117,7 +117,7 @@ class GemmNT(C.Structure):
         ("c_f32", i32), ("zeros", vp), ("epi_lds", i32), ("conv_d", i32), ("conv_kd", i32), ("conv_kh", i32), ("conv_kw", i32),
         ("dact_pre", vp), ("lddact", i64), ("dact", i32), ("deq_a", vp), ("deq_b", vp), ("epi_wide", i32),
         ("mul", vp), ("ldmul", i64), ("res_first", i32), ("conv_tap_split", i32),
-        ("ln_wsum", vp), ("ln_mean", vp), ("ln_rstd", vp), ("ln_eps", f32),
+        ("ln_wsum", vp), ("ln_mean", vp), ("ln_rstd", vp), ("ln_eps", f32), ("colstats", vp),
     ]
 
 
@@ -144,6 +144,8 @@ class GemmTN(C.Structure):
 _PROTOTYPES = {
     "lavt_abi_version": [],
     "lavt_tuning_reload": [],
+    "lavt_gemm_nt_colstats_plan": [C.POINTER(GemmNT), C.POINTER(i32)],
+    "lavt_colstats_finish_blocks": [vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, f32, vp],
     "lavt_window_attn_bwd_chained": [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, f32, C.POINTER(DtableJob), C.POINTER(DtableJob), vp],
     "lavt_attn_dtable_run": [C.POINTER(DtableJob), vp],
     "lavt_lang_mask": [vp, i32, vp, vp, i32, i32, i32, vp],
@@ -231,7 +233,7 @@ for _name, _args in _PROTOTYPES.items():
     _fn = getattr(_cdll, _name)          # AttributeError here = header/library mismatch: fail loudly
     _fn.argtypes = _args
     _fn.restype = C.c_int
-EXPECTED_ABI = 5          # the ctypes struct layouts and prototypes in this file were written for this lavt_abi_version()
+EXPECTED_ABI = 6          # the ctypes struct layouts and prototypes in this file were written for this lavt_abi_version()
 if _cdll.lavt_abi_version() != EXPECTED_ABI:
     raise ImportError(f"{LIB_PATH} reports ABI v{_cdll.lavt_abi_version()} but lavt_hip/_capi.py binds ABI v{EXPECTED_ABI}: rebuild the library "
                       "(`make -C lavt-rs_amd/csrc`) -- a mismatch would make the kernels read past the caller's parameter structs")
@@ -240,7 +242,7 @@ _cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
 _cdll.lavt_conv3x3_wgrad_ws.restype = C.c_int64
 _cdll.lavt_gemm_tn_grouped_sk_ws.restype = C.c_int64
 _cdll.lavt_last_error.argtypes = []
-for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts", "lavt_adamw_chunk_elems", "lavt_tuning_reload", "lavt_conv3x3_wgrad_ws", "lavt_gemm_tn_grouped_sk_ws"):      # queries, not launches: never timed
+for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts", "lavt_adamw_chunk_elems", "lavt_tuning_reload", "lavt_conv3x3_wgrad_ws", "lavt_gemm_tn_grouped_sk_ws", "lavt_gemm_nt_colstats_plan"):      # queries, not launches: never timed
     setattr(lib, _name, getattr(_cdll, _name))
 
 EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)

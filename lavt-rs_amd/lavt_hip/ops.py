@@ -496,9 +496,11 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
             a_split=0, a_rowmap=None, conv=None, b_kmajor=False, b_tap_stride=0, alpha=1.0, bias=None, strideBias=0,
             row_scale=None, strideRowScale=0, row_scale_div=1, act=K.ACT_NONE, Cpre=None, ldcpre=0, R=None, ldr=0, C2=None, ldc2=0,
             c_split=0, c_rowmap=None, c_f32=False, a_off=0, b_off=0, c_off=0, dact_pre=None, lddact=0, dact=K.ACT_NONE, deq=None,
-            mul=None, ldmul=0, res_first=False, conv_tap_split=0, ln=None):
+            mul=None, ldmul=0, res_first=False, conv_tap_split=0, ln=None, want_colstats=False):
     """A/B/Cout are tensors; *_off are element offsets into them (column sub-blocks).  dtype torch.uint8 = e4m3 operands (A, B 1 byte per
-    element; C / residual bf16) with the two dequantisation |max| pointers in `deq`."""
+    element; C / residual bf16) with the two dequantisation |max| pointers in `deq`.
+    want_colstats: if this problem's kernel has the statistics epilogue (lavt_gemm_nt_colstats_plan), the launch also stores per-row-block column
+    sums / centred second moments of the output; returns (partials, blocks, rows_per_block) then, else None."""
     f8 = dtype == torch.uint8
     es = 4 if dtype == torch.float32 else (1 if f8 else 2)
     p = K.GemmNT()
@@ -524,10 +526,19 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
         p.ln_wsum, p.ln_mean, p.ln_rstd, p.ln_eps = K.ptr(ln[0]), K.ptr(ln[1]), K.ptr(ln[2]), ln[3]
     if deq is not None:
         p.deq_a, p.deq_b = deq
+    stats = None
+    if want_colstats:
+        rpb = C.c_int32(0)
+        nblk = int(K.lib.lavt_gemm_nt_colstats_plan(C.byref(p), C.byref(rpb)))
+        if nblk > 0:
+            parts = torch.empty(nblk * 2 * N, dtype=torch.float32, device=A.device)
+            p.colstats = K.ptr(parts)
+            stats = (parts, nblk, int(rpb.value))
     if K.prof.enabled:
         K.prof.note = {"flops": 2.0 * M * N * Kd * batch, "shape": f"nt {M}x{N}x{Kd}" + (f" b{batch}" if batch > 1 else "") + (" conv" if conv is not None else "")
                        + (" kmajor" if b_kmajor else "")}
     K.check(K.lib.lavt_gemm_nt(C.byref(p), K.stream()))
+    return stats
 
 
 def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, strideB=0, strideC=0, a_rowmap=None,
@@ -1575,6 +1586,30 @@ def syncbn_exchange_backward(s: torch.Tensor, group):
     return s
 
 
+_CONV_STATS = os.environ.get("LAVT_CONV_STATS", "1") != "0"
+
+
+class _ConvStats:
+    """Column statistics that a convolution's epilogue stored beside its output (csrc/gemm_nt_pipe.hip: per block of rows the column sums and the second
+    moments about the block's mean, from the fp32 accumulators): the BatchNorm that follows (reference lib/mask_predictor.py:60-97) combines the blocks
+    instead of reading the [M, C] map again.  Keyed by the output's storage; one entry per device is enough (the consumer is the next op)."""
+
+    def __init__(self):
+        self.ent = {}
+
+    def put(self, y, st):
+        self.ent[y.device] = (y.data_ptr(), tuple(y.shape), st)
+
+    def take(self, x):
+        e = self.ent.pop(x.device, None)
+        if e is not None and e[0] == x.data_ptr() and e[1] == tuple(x.shape):
+            return e[2]
+        return None
+
+
+conv_stats = _ConvStats()
+
+
 class _HipBnKernels:
     """The local passes of BatchNorm + ReLU on NHWC rows (csrc/norm.hip).  _BatchNormRelu talks to them through this small interface so that the
     multi-rank protocol around them (what is exchanged, when, with which counts) can be driven by a CPU stand-in in the gloo tests."""
@@ -1582,6 +1617,12 @@ class _HipBnKernels:
 
     @staticmethod
     def stats(x):
+        st = conv_stats.take(x)
+        if st is not None:              # the producing convolution left block statistics: combine them (no pass over x)
+            parts, nblk, rpb = st
+            s = torch.empty(2, 1, x.shape[1], dtype=torch.float32, device=x.device)
+            K.check(K.lib.lavt_colstats_finish_blocks(K.ptr(parts), nblk, rpb, x.shape[0], x.shape[1], 0.0, None, None, K.ptr(s[0]), K.ptr(s[1]), None, None, 0.0, K.stream()))
+            return s
         return _stats(x, 1, x.shape[0], x.shape[1])                      # [2, 1, C]: sum, centred second moment of the local rows
 
     @staticmethod
@@ -1590,6 +1631,12 @@ class _HipBnKernels:
         R, Cc = x.shape
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
+        st = conv_stats.take(x)
+        if st is not None:              # the producing convolution left block statistics: one small launch, no pass over x
+            parts, nblk, rpb = st
+            K.check(K.lib.lavt_colstats_finish_blocks(K.ptr(parts), nblk, rpb, R, Cc, eps, K.ptr(mean), K.ptr(rstd), None, None, K.ptr(running_mean),
+                                                      K.ptr(running_var), momentum, K.stream()))
+            return mean, rstd
         ws = _scratch(1025 * 2 * Cc, x.device)
         K.check(K.lib.lavt_colstats_meanrstd(K.dt(x.dtype), K.ptr(x), K.ptr(mean), K.ptr(rstd), K.ptr(ws), ws.numel(), 1, R, Cc, eps, K.ptr(running_mean),
                                              K.ptr(running_var), momentum, K.stream()))
@@ -2345,8 +2392,11 @@ class _ConvTaps(torch.autograd.Function):
                     batch=sp, strideB=(taps // sp) * Cin, strideC=M * Cout, c_f32=True, conv_tap_split=taps // sp)
             K.check(K.lib.lavt_splitk_reduce(K.dt(dtype), K.ptr(parts), sp, M, Cout, K.ptr(y), Cout, K.stream()))
         else:
-            gemm_nt(dtype, M, Cout, taps * Cin, x1, C1, Wp, taps * Cin, y, Cout, A2=x2, lda2=C2, a_split=C1,
-                    conv=(H, W, Cin, 0, D, kd, kh, kw), bias=_f32(bias), act=act, Cpre=pre, ldcpre=Cout)
+            st = gemm_nt(dtype, M, Cout, taps * Cin, x1, C1, Wp, taps * Cin, y, Cout, A2=x2, lda2=C2, a_split=C1,
+                         conv=(H, W, Cin, 0, D, kd, kh, kw), bias=_f32(bias), act=act, Cpre=pre, ldcpre=Cout,
+                         want_colstats=_CONV_STATS and bias is None and act == K.ACT_NONE)
+            if st is not None:
+                conv_stats.put(y, st)
         ctx.save_for_backward(x1, x2, weight, bias, pre)
         ctx.dims = (B, D, H, W, C1, C2, Cout, kd, kh, kw, act)
         return y

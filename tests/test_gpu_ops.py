@@ -149,6 +149,68 @@ def test_gemm_pipelined_k_loop(tile, stages, monkeypatch, request):
     run_pair(lambda x, w, b: ops.conv3d(x, w, b, B, D, H, W, act=ACT_GELU), ref3, inputs, dtype, name=f"pipe conv3d tile {tile}/{stages}", bf16=4e-2)
 
 
+@pytest.mark.parametrize("tile,stages", [("512", "0"), ("128", "4")])
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(2, 13, 11, 128, 64, 136), (1, 30, 30, 128, 0, 256), (2, 16, 8, 64, 0, 64)])
+def test_conv_epilogue_column_statistics(tile, stages, B, H, W, C1, C2, Cout, monkeypatch, request):
+    """BatchNorm statistics from the convolution's epilogue (lavt_gemm_nt_t.colstats, csrc/gemm_nt_pipe.hip + lavt_colstats_finish_blocks): per block of
+    rows the column sums and the second moments about the block's own mean, combined in parallel-variance form.  Row counts that leave a block partly
+    or wholly empty, columns that do not fill the last tile; a large common offset (|mean| / sigma ~ 50) must not cost the variance its digits.  Then the
+    conv -> BatchNorm -> ReLU pair through the product ops (reference lib/mask_predictor.py:60-97) against PyTorch, forward and every gradient."""
+    from lavt_hip import ops, _capi as K
+    for k, v in (("LAVT_GEMM_TILE", tile), ("LAVT_GEMM_STAGES", stages), ("LAVT_GEMM_PIPE", "3")):
+        monkeypatch.setenv(k, v)
+    K.lib.lavt_tuning_reload()
+    request.addfinalizer(lambda: ([os.environ.pop(k, None) for k in ("LAVT_GEMM_TILE", "LAVT_GEMM_STAGES", "LAVT_GEMM_PIPE")], K.lib.lavt_tuning_reload()))
+    bf = torch.bfloat16
+    Cin, M = C1 + C2, B * H * W
+    w = rnd(Cout, Cin, 3, 3, seed=3, scale=(9 * Cin) ** -0.5)
+    w[:, 0, 1, 1] += 4.0                                    # with x[:, 0] = 12.5 below: every output channel carries a common offset of ~50 sigma
+    x1 = rnd(M, C1, seed=1)
+    x1[:, 0] = 12.5
+    x2 = rnd(M, C2, seed=2) if C2 else None
+    with lavt_hip_dtype(bf):
+        y = ops.conv3x3(x1.to(dev()).to(bf), x2.to(dev()).to(bf) if C2 else None, w.to(dev()), B, H, W)
+        st = ops.conv_stats.take(y)
+        assert st is not None, "the forced pipelined tile has the statistics epilogue"
+        parts, nblk, rpb = st
+        assert nblk * rpb >= M and (nblk - 1) * rpb < M + rpb
+        mean = torch.empty(Cout, dtype=torch.float32, device=dev())
+        rstd = torch.empty_like(mean)
+        s12 = torch.empty(2, Cout, dtype=torch.float32, device=dev())
+        K.check(K.lib.lavt_colstats_finish_blocks(K.ptr(parts), nblk, rpb, M, Cout, 1e-5, K.ptr(mean), K.ptr(rstd), K.ptr(s12[0]), K.ptr(s12[1]), None, None, 0.0, K.stream()))
+    torch.cuda.synchronize()
+    xf = (x1 if x2 is None else torch.cat([x1, x2], 1)).to(bf).float()
+    yr = F.conv2d(xf.view(B, H, W, Cin).permute(0, 3, 1, 2), w.to(bf).float(), padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    mu, var = yr.mean(0), yr.var(0, unbiased=False)
+    assert float(mu.abs().mean() / var.sqrt().mean()) > 20      # the offset case is what this test is about
+    assert float((mean.cpu() - mu).abs().max()) <= 2e-3 * float(mu.abs().max())
+    assert float((rstd.cpu() * (var + 1e-5).sqrt() - 1).abs().max()) <= 2e-3, float((rstd.cpu() * (var + 1e-5).sqrt() - 1).abs().max())
+    assert float((s12[0].cpu() - yr.sum(0)).abs().max()) <= 2e-3 * float(yr.sum(0).abs().max())
+    assert float((s12[1].cpu() / (var * M) - 1).abs().max()) <= 4e-3
+
+    bn = torch.nn.BatchNorm2d(Cout)
+    with torch.no_grad():
+        bn.weight.copy_(1.0 + 0.2 * rnd(Cout, seed=7)); bn.bias.copy_(0.1 * rnd(Cout, seed=8))
+    bn_ref = torch.nn.BatchNorm2d(Cout)
+    bn_ref.load_state_dict(bn.state_dict())
+    bn = bn.to(dev())
+    w0 = rnd(Cout, Cin, 3, 3, seed=3, scale=(9 * Cin) ** -0.5)
+    inputs = {"x1": (rnd(M, C1, seed=1), "act"), "w": (w0, "param")}
+    if C2:
+        inputs["x2"] = (rnd(M, C2, seed=2), "act")
+
+    def hip(x1, w, x2=None):
+        y = ops.conv3x3(x1, x2, w, B, H, W)
+        return ops.batch_norm_relu(y, bn)
+
+    def ref(x1, w, x2=None):
+        x = x1 if x2 is None else torch.cat([x1, x2], 1)
+        y = F.conv2d(x.view(B, H, W, Cin).permute(0, 3, 1, 2), w, padding=1)
+        return F.relu(bn_ref(y)).permute(0, 2, 3, 1).reshape(M, Cout)
+    run_pair(hip, ref, inputs, bf, name=f"conv+bn (epilogue statistics) tile {tile}", bf16=8e-2)      # (two bf16 ops: the BatchNorm backward scales the conv's rounding by gamma * rstd)
+    assert float((bn.running_mean.cpu() - bn_ref.running_mean).abs().max()) <= 2e-3 and float((bn.running_var.cpu() - bn_ref.running_var).abs().max()) <= 2e-3
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_linear_gelu_residual(dtype):
     from lavt_hip import ops
