@@ -157,6 +157,12 @@ typedef struct lavt_gemm_nt {
      * the rounding to bf16).  lavt_colstats_finish_blocks combines the blocks (parallel-variance form, no E[x^2] - E[x]^2).  Only for launches
      * lavt_gemm_nt_colstats_plan accepts (LAVT_ERR_INVALID otherwise): bf16, batch 1, no bias / activation / residual / row map / fp32 output. */
     float* colstats;
+    /* conv_kc_split > 0 (ABI v6): the reduction of a convolution is cut over CHANNEL blocks instead of taps -- entry bz of the batch contracts channels
+     * [bz * conv_kc_split, (bz + 1) * conv_kc_split) of every tap (K = taps * conv_kc_split, batch * conv_kc_split = conv_kc, conv_kc_split % 64 == 0,
+     * strideB = 0: both weight layouts are offset inside the kernel).  Any divisor of conv_kc / 64 is a split count, where conv_tap_split offers 3 or 9:
+     * the decoder's 1 800-row convolutions run as 480 workgroups instead of 180.  With c_f32 + strideC as split-K through fp32 partial outputs
+     * (lavt_splitk_reduce).  Pipelined tap-walking kernel only (csrc/gemm_nt_pipe.hip: conv_kc % 64 == 0, a_split % 64 == 0, bf16). */
+    int32_t conv_kc_split;
 } lavt_gemm_nt_t;
 
 int lavt_gemm_nt(const lavt_gemm_nt_t* p, void* stream);

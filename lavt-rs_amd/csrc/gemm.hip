@@ -432,7 +432,12 @@ extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
     if (p.conv_kc > 0) {
         const int taps = (p.conv_kd > 0 ? p.conv_kd : 1) * (p.conv_kh > 0 ? p.conv_kh : 3) * (p.conv_kw > 0 ? p.conv_kw : 3);
         const int vox = (p.conv_d > 0 ? p.conv_d : 1) * p.conv_h * p.conv_w;
-        if (p.conv_tap_split > 0)
+        if (p.conv_kc_split > 0) {
+            int st_ = 0;
+            LAVT_CHECK_ARG(p.dtype == LAVT_BF16 && p.conv_tap_split == 0 && p.conv_kc_split % 64 == 0 && p.batch * p.conv_kc_split == p.conv_kc && p.K == taps * p.conv_kc_split &&
+                           p.strideB == 0 && taps <= 32 && (!p.A2 || p.a_split % 64 == 0) && p.zeros && lavt_gemm_nt_pipe_tile(p, &st_) == 128,
+                           "lavt_gemm_nt: conv_kc_split needs batch * conv_kc_split == conv_kc, K == taps * conv_kc_split, strideB == 0 and the pipelined tap-walking kernel (bf16, conv_kc %% 64 == 0)");
+        } else if (p.conv_tap_split > 0)
             LAVT_CHECK_ARG(p.dtype == LAVT_BF16 && p.K == p.conv_tap_split * p.conv_kc && p.batch * p.conv_tap_split == taps && p.conv_kc % 64 == 0 && taps <= 32 &&
                            (!p.A2 || p.a_split % 64 == 0) && p.zeros, "lavt_gemm_nt: conv_tap_split needs batch * conv_tap_split == taps and the tap-walking path (conv_kc %% 64 == 0)");
         else

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
             a_p2[i] = A2 ? A2 + row * p.lda2 + cl * EPC : a_p1[i];
         }
         if (p.conv_tap_split > 0) { c_tap = bz * p.conv_tap_split; c_ntap = p.conv_tap_split; }
+        if (p.conv_kc_split > 0) c_kin = bz * p.conv_kc_split;          // split over channel blocks: this entry's first channel
         c_tap0 = c_tap;
         conv_tap(cg, c_tap, c_dz, c_dy, c_dx);
 #pragma unroll
@@ -272,6 +273,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
     for (int i = 0; i < A_INSTR; ++i) a_cur[i] = CONVFAST ? a_p1[i] : nullptr;
     int64_t cur_lda = lda1;
     int cur_base = 0;
+    if (CONVFAST && has_a2 && c_kin >= a_split) {          // (a channel-split entry that starts inside the second source)
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) a_cur[i] = a_p2[i];
+        cur_lda = lda2; cur_base = a_split;
+    }
     int64_t u_off = 0;
     bool u_past = false;
     unsigned u_bit = 0;
@@ -280,9 +286,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
     int t0_dz = c_dz, t0_dy = c_dy, t0_dx = c_dx;
     // running position in the weight operand (advanced in issue_end: no 64-bit multiplies per K tile): k-major B -- pointer to (tap, channel block);
     // k-contiguous B -- column offset of (tap, channel block) inside the [Cout][taps][Cin] rows
-    const T* c_bb = B + (int64_t)c_tap0 * p.b_tap_stride;
+    const T* c_bb = B + (int64_t)c_kin * p.ldb + (int64_t)c_tap0 * p.b_tap_stride;
     const int64_t bb_tap = p.b_tap_stride, bb_wrap = (int64_t)BK * p.ldb - (int64_t)(c_ntap - 1) * p.b_tap_stride;
-    int c_boff = 0;
+    int c_boff = c_kin;
     const int boff_wrap = BK - (c_ntap - 1) * conv_kc;
     auto issue_begin = [&](int kt, bool past) {
         u_past = past; u_kt = kt;
@@ -553,6 +559,7 @@ int lavt_gemm_nt_pipe_tile(const lavt_gemm_nt_t& p, int* stages_out) {
     if (tun.gemm_v2_off || pipe < 1) return 0;
     if (p.lda % 8 || p.ldb % 8 || (p.A2 && p.lda2 % 8)) return 0;
     if (p.ln_wsum || p.dact_pre) return 0;
+    if (p.conv_kc_split > 0) { *stages_out = 4; return 128; }          // the channel-split reduction exists in this kernel only
     const int force = tun.gemm_tile;
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
     const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;

@@ -117,7 +117,7 @@ class GemmNT(C.Structure):
         ("c_f32", i32), ("zeros", vp), ("epi_lds", i32), ("conv_d", i32), ("conv_kd", i32), ("conv_kh", i32), ("conv_kw", i32),
         ("dact_pre", vp), ("lddact", i64), ("dact", i32), ("deq_a", vp), ("deq_b", vp), ("epi_wide", i32),
         ("mul", vp), ("ldmul", i64), ("res_first", i32), ("conv_tap_split", i32),
-        ("ln_wsum", vp), ("ln_mean", vp), ("ln_rstd", vp), ("ln_eps", f32), ("colstats", vp),
+        ("ln_wsum", vp), ("ln_mean", vp), ("ln_rstd", vp), ("ln_eps", f32), ("colstats", vp), ("conv_kc_split", i32),
     ]
 
 

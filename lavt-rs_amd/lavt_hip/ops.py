@@ -496,7 +496,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
             a_split=0, a_rowmap=None, conv=None, b_kmajor=False, b_tap_stride=0, alpha=1.0, bias=None, strideBias=0,
             row_scale=None, strideRowScale=0, row_scale_div=1, act=K.ACT_NONE, Cpre=None, ldcpre=0, R=None, ldr=0, C2=None, ldc2=0,
             c_split=0, c_rowmap=None, c_f32=False, a_off=0, b_off=0, c_off=0, dact_pre=None, lddact=0, dact=K.ACT_NONE, deq=None,
-            mul=None, ldmul=0, res_first=False, conv_tap_split=0, ln=None, want_colstats=False):
+            mul=None, ldmul=0, res_first=False, conv_tap_split=0, conv_kc_split=0, ln=None, want_colstats=False):
     """A/B/Cout are tensors; *_off are element offsets into them (column sub-blocks).  dtype torch.uint8 = e4m3 operands (A, B 1 byte per
     element; C / residual bf16) with the two dequantisation |max| pointers in `deq`.
     want_colstats: if this problem's kernel has the statistics epilogue (lavt_gemm_nt_colstats_plan), the launch also stores per-row-block column
@@ -521,7 +521,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.c_rowmap, p.c_f32 = K.ptr(c_rowmap), int(c_f32)
     p.zeros = _zero_page(A.device)
     p.dact_pre, p.lddact, p.dact = K.ptr(dact_pre), lddact, dact
-    p.mul, p.ldmul, p.res_first, p.conv_tap_split = K.ptr(mul), ldmul, int(res_first), conv_tap_split
+    p.mul, p.ldmul, p.res_first, p.conv_tap_split, p.conv_kc_split = K.ptr(mul), ldmul, int(res_first), conv_tap_split, conv_kc_split
     if ln is not None:          # (wsum, mean out, rstd out, eps): LayerNorm-folded A operand
         p.ln_wsum, p.ln_mean, p.ln_rstd, p.ln_eps = K.ptr(ln[0]), K.ptr(ln[1]), K.ptr(ln[2]), ln[3]
     if deq is not None:
@@ -2383,13 +2383,17 @@ class _ConvTaps(torch.autograd.Function):
             x2q = fp8.quantize(x2, id(weight))[0] if x2 is not None else None
             gemm_nt(torch.uint8, M, Cout, taps * Cin, x1q, C1, Wq, taps * Cin, y, Cout, A2=x2q, lda2=C2, a_split=C1,
                     conv=(H, W, Cin, 0, D, kd, kh, kw), bias=_f32(bias), act=act, Cpre=pre, ldcpre=Cout, deq=(a_ptr, w_amax.data_ptr()))
-        elif _conv_split(dtype, M, Cout, Cin, C1, C2, taps, bias, act):
+        elif _conv_split(dtype, M, Cout, Cin, C1, C2, taps, bias, act)[0]:
             # few pixels, long reduction (decoder level 4: 1 800 rows x K = 13 824 = 60-232 tiles walking 72-216 K tiles each): the reduction is cut
             # at tap boundaries over the batch index into fp32 partial outputs, a second small kernel adds them
-            sp = _conv_split(dtype, M, Cout, Cin, C1, C2, taps, bias, act)
+            sp, over_ch = _conv_split(dtype, M, Cout, Cin, C1, C2, taps, bias, act)
             parts = torch.empty(sp, M, Cout, dtype=torch.float32, device=x1.device)
-            gemm_nt(dtype, M, Cout, (taps // sp) * Cin, x1, C1, Wp, taps * Cin, parts, Cout, A2=x2, lda2=C2, a_split=C1, conv=(H, W, Cin, 0, D, kd, kh, kw),
-                    batch=sp, strideB=(taps // sp) * Cin, strideC=M * Cout, c_f32=True, conv_tap_split=taps // sp)
+            if over_ch:
+                gemm_nt(dtype, M, Cout, taps * (Cin // sp), x1, C1, Wp, taps * Cin, parts, Cout, A2=x2, lda2=C2, a_split=C1, conv=(H, W, Cin, 0, D, kd, kh, kw),
+                        batch=sp, strideC=M * Cout, c_f32=True, conv_kc_split=Cin // sp)
+            else:
+                gemm_nt(dtype, M, Cout, (taps // sp) * Cin, x1, C1, Wp, taps * Cin, parts, Cout, A2=x2, lda2=C2, a_split=C1, conv=(H, W, Cin, 0, D, kd, kh, kw),
+                        batch=sp, strideB=(taps // sp) * Cin, strideC=M * Cout, c_f32=True, conv_tap_split=taps // sp)
             K.check(K.lib.lavt_splitk_reduce(K.dt(dtype), K.ptr(parts), sp, M, Cout, K.ptr(y), Cout, K.stream()))
         else:
             st = gemm_nt(dtype, M, Cout, taps * Cin, x1, C1, Wp, taps * Cin, y, Cout, A2=x2, lda2=C2, a_split=C1,
@@ -2424,20 +2428,28 @@ class _ConvTaps(torch.autograd.Function):
                 # fell back to 128x128 tiles (239 us at 2x120x120).  As two launches over column blocks of the packed weight the 512-channel part
                 # runs on the 256x256 tile and the skip part on its own.
                 for dxo, Cn, boff in ((dx1, C1, 0), (dx2, C2, C1)):
-                    sp = _conv_split(dtype, M, Cn, Cout, Cout, 0, taps, None, K.ACT_NONE)
+                    sp, over_ch = _conv_split(dtype, M, Cn, Cout, Cout, 0, taps, None, K.ACT_NONE)
                     if sp:
                         parts = torch.empty(sp, M, Cn, dtype=torch.float32, device=dy.device)
-                        gemm_nt(dtype, M, Cn, (taps // sp) * Cout, dy, Cout, Wp, taps * Cin, parts, Cn, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
-                                b_tap_stride=Cin, b_off=boff, batch=sp, strideC=M * Cn, c_f32=True, conv_tap_split=taps // sp)
+                        if over_ch:
+                            gemm_nt(dtype, M, Cn, taps * (Cout // sp), dy, Cout, Wp, taps * Cin, parts, Cn, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
+                                    b_tap_stride=Cin, b_off=boff, batch=sp, strideC=M * Cn, c_f32=True, conv_kc_split=Cout // sp)
+                        else:
+                            gemm_nt(dtype, M, Cn, (taps // sp) * Cout, dy, Cout, Wp, taps * Cin, parts, Cn, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
+                                    b_tap_stride=Cin, b_off=boff, batch=sp, strideC=M * Cn, c_f32=True, conv_tap_split=taps // sp)
                         K.check(K.lib.lavt_splitk_reduce(K.dt(dtype), K.ptr(parts), sp, M, Cn, K.ptr(dxo), Cn, K.stream()))
                     else:
                         gemm_nt(dtype, M, Cn, taps * Cout, dy, Cout, Wp, taps * Cin, dxo, Cn, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True, b_tap_stride=Cin,
                                 b_off=boff)
-            elif x2 is None and _conv_split(dtype, M, Cin, Cout, Cout, 0, taps, None, K.ACT_NONE):
-                sp = _conv_split(dtype, M, Cin, Cout, Cout, 0, taps, None, K.ACT_NONE)
+            elif x2 is None and _conv_split(dtype, M, Cin, Cout, Cout, 0, taps, None, K.ACT_NONE)[0]:
+                sp, over_ch = _conv_split(dtype, M, Cin, Cout, Cout, 0, taps, None, K.ACT_NONE)
                 parts = torch.empty(sp, M, Cin, dtype=torch.float32, device=dy.device)
-                gemm_nt(dtype, M, Cin, (taps // sp) * Cout, dy, Cout, Wp, taps * Cin, parts, Cin, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
-                        b_tap_stride=Cin, batch=sp, strideC=M * Cin, c_f32=True, conv_tap_split=taps // sp)
+                if over_ch:
+                    gemm_nt(dtype, M, Cin, taps * (Cout // sp), dy, Cout, Wp, taps * Cin, parts, Cin, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
+                            b_tap_stride=Cin, batch=sp, strideC=M * Cin, c_f32=True, conv_kc_split=Cout // sp)
+                else:
+                    gemm_nt(dtype, M, Cin, (taps // sp) * Cout, dy, Cout, Wp, taps * Cin, parts, Cin, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
+                            b_tap_stride=Cin, batch=sp, strideC=M * Cin, c_f32=True, conv_tap_split=taps // sp)
                 K.check(K.lib.lavt_splitk_reduce(K.dt(dtype), K.ptr(parts), sp, M, Cin, K.ptr(dx1), Cin, K.stream()))
             else:
                 gemm_nt(dtype, M, Cin, taps * Cout, dy, Cout, Wp, taps * Cin, dx1, C1, conv=(H, W, Cout, 1, D, kd, kh, kw), b_kmajor=True,
@@ -2475,13 +2487,36 @@ _CONV_SPLIT_MAX_ROWS = int(os.environ.get("LAVT_CONV_SPLIT_ROWS", "2048"))
 
 
 def _conv_split(dtype, M, N, Kc, C1, C2, taps, bias, act):
-    """number of tap groups a convolution's reduction is cut into (0 = not split): bf16 tap-walking problems (channels % 64 == 0) without a fused
-    epilogue, few rows (<= 2048: the fp32 partials are M x N x splits x 4 bytes written and re-read) and a long reduction"""
+    """-> (pieces, over_channels): the number of pieces a convolution's reduction is cut into (0 = not split) and whether they are channel blocks
+    (lavt_gemm_nt_t.conv_kc_split) or tap groups (conv_tap_split): bf16 tap-walking problems (channels % 64 == 0) without a fused epilogue, few rows
+    (<= 2048: the fp32 partials are M x N x pieces x 4 bytes written and re-read) and a long reduction"""
     if dtype != torch.bfloat16 or bias is not None or act != K.ACT_NONE or fp8_enabled() or M > _CONV_SPLIT_MAX_ROWS or taps % 3 or taps > 27:
-        return 0
+        return 0, False
     if Kc % 64 or C1 % 64 or C2 % 64 or N % 8 or taps * Kc < 4096:
+        return 0, False
+    d = _kc_pieces(M, N, Kc) if taps == 9 else 0
+    if d:
+        return d, True
+    return (int(os.environ.get("LAVT_CONV_SPLIT_N", "3")) if taps == 9 else taps // 3), False
+
+
+# Channel-block pieces of a few-pixel 3x3 convolution's reduction (0 = cut at tap boundaries instead: 3 pieces).  Measured on MI355X (tools/conv_small_probe.py,
+# 2 x 30 x 30 pixels): what matters is ONE full round of 128x128-tile workgroups on the 256 CUs (the 4-stage ring takes a CU's LDS) -- 1536 -> 512 forward:
+# 180 workgroups (3 tap groups) 52-60 us, 240 (4 channel pieces) 45 us, 480 (8) 59 us; 512 -> 512: 33 / 29 / 42 us; data gradient onto 1024 channels: 360 (3 tap
+# groups) 56 us, 240 (2 pieces) 39 us, 480 (4) 52 us.  LAVT_CONV_KC_SPLITS: "auto" (largest divisor of the channel blocks that keeps the launch within one round),
+# a number (that many pieces where it divides), 0 (off).
+_CONV_KC_SPLITS = os.environ.get("LAVT_CONV_KC_SPLITS", "auto")
+
+
+def _kc_pieces(M, N, Kc):
+    if _CONV_KC_SPLITS == "0" or os.environ.get("LAVT_GEMM_PIPE", "2") == "0" or Kc % 64:
         return 0
-    return int(os.environ.get("LAVT_CONV_SPLIT_N", "3")) if taps == 9 else taps // 3
+    cb, tiles = Kc // 64, -(-M // 128) * -(-N // 128)
+    if _CONV_KC_SPLITS != "auto":
+        d = int(_CONV_KC_SPLITS)
+        return d if d > 1 and cb % d == 0 else 0
+    best = max((d for d in range(2, cb + 1) if cb % d == 0 and tiles * d <= 256), default=0)
+    return best if best and tiles * best > min(tiles * 3, 256) * 0.9 else 0          # (not worse filled than the 3 tap groups it replaces)
 
 
 def conv3x3(x1, x2, weight, B, H, W):

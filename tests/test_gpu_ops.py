@@ -127,7 +127,9 @@ def test_gemm_pipelined_k_loop(tile, stages, monkeypatch, request):
     for (M, N, Kd) in ((700, 328, 256), (700, 328, 264), (130, 520, 64), (1000, 256, 1024)):
         inputs = {"x": (rnd(M, Kd, seed=1), "act"), "w": (rnd(N, Kd, seed=2, scale=Kd ** -0.5), "param"), "b": (rnd(N, seed=3), "param")}
         run_pair(lambda x, w, b: ops.linear(x, w, b), lambda x, w, b: F.linear(x, w, b), inputs, dtype, name=f"pipe linear {M}x{N}x{Kd} tile {tile}/{stages}")
-    for (B, H, W, C1, C2, Cout) in ((2, 13, 11, 128, 64, 136), (2, 13, 11, 96, 32, 136), (1, 30, 30, 512, 0, 128), (2, 9, 20, 64, 0, 256), (1, 24, 24, 256, 128, 256)):
+    # (the 1024 + 512 and 512 -> 512 cases: few pixels, long reduction -- split-K over channel blocks, conv_kc_split, forward across the concat boundary and backward)
+    for (B, H, W, C1, C2, Cout) in ((2, 13, 11, 128, 64, 136), (2, 13, 11, 96, 32, 136), (1, 30, 30, 512, 0, 128), (2, 9, 20, 64, 0, 256), (1, 24, 24, 256, 128, 256),
+                                    (1, 20, 20, 1024, 512, 128), (1, 16, 16, 512, 0, 512)):
         Cin = C1 + C2
         inputs = {"x1": (rnd(B * H * W, C1, seed=1), "act"), "w": (rnd(Cout, Cin, 3, 3, seed=3, scale=(9 * Cin) ** -0.5), "param")}
         if C2:
@@ -138,6 +140,18 @@ def test_gemm_pipelined_k_loop(tile, stages, monkeypatch, request):
             y = F.conv2d(x.view(B, H, W, Cin).permute(0, 3, 1, 2), w, padding=1)
             return y.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
         run_pair(lambda x1, w, x2=None: ops.conv3x3(x1, x2, w, B, H, W), ref, inputs, dtype, name=f"pipe conv {B}x{H}x{W} {C1}+{C2}->{Cout} tile {tile}/{stages}", bf16=4e-2)
+    # two channel pieces of four 64-channel blocks each: the second piece starts in the first concat source and crosses into the second
+    monkeypatch.setattr(ops, "_CONV_KC_SPLITS", "2")
+    B, H, W, C1, C2, Cout = 1, 24, 24, 320, 192, 128
+    Cin = C1 + C2
+    assert ops._conv_split(dtype, B * H * W, Cout, Cin, C1, C2, 9, None, 0) == (2, True)
+    inputs = {"x1": (rnd(B * H * W, C1, seed=1), "act"), "x2": (rnd(B * H * W, C2, seed=2), "act"), "w": (rnd(Cout, Cin, 3, 3, seed=3, scale=(9 * Cin) ** -0.5), "param")}
+
+    def ref2(x1, w, x2):
+        y = F.conv2d(torch.cat([x1, x2], 1).view(B, H, W, Cin).permute(0, 3, 1, 2), w, padding=1)
+        return y.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    run_pair(lambda x1, w, x2: ops.conv3x3(x1, x2, w, B, H, W), ref2, inputs, dtype, name=f"pipe conv, 2 channel pieces across the concat boundary, tile {tile}/{stages}", bf16=4e-2)
+    monkeypatch.setattr(ops, "_CONV_KC_SPLITS", "auto")
     # Conv3d of SepTPWAM (27 taps, bias + GELU epilogue, tap-split forward at few rows)
     from lavt_hip._capi import ACT_GELU
     B, D, H, W, Cin, Cout, ks = 1, 4, 6, 6, 64, 64, (3, 3, 3)

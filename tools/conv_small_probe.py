@@ -64,7 +64,19 @@ for (B, H, C1, C2, Cout) in shapes:
     dy = torch.randn(M, Cout, device=dev).to(bf)
     dx = torch.empty(M, C1, device=dev, dtype=bf)
     def dgrad():          # data gradient of the first source (k-major read of the packed weight), as ops._ConvTaps.backward issues it
-        ops.gemm_nt(bf, M, C1, 9 * Cout, dy, Cout, Wpk, 9 * Cin, dx, C1, conv=(H, H, Cout, 1, 1, 1, 3, 3), b_kmajor=True, b_tap_stride=Cin, b_off=0)
+        sp, over_ch = ops._conv_split(bf, M, C1, Cout, Cout, 0, 9, None, K.ACT_NONE)
+        if sp and over_ch:
+            parts = torch.empty(sp, M, C1, dtype=torch.float32, device=dev)
+            ops.gemm_nt(bf, M, C1, 9 * (Cout // sp), dy, Cout, Wpk, 9 * Cin, parts, C1, conv=(H, H, Cout, 1, 1, 1, 3, 3), b_kmajor=True, b_tap_stride=Cin, b_off=0,
+                        batch=sp, strideC=M * C1, c_f32=True, conv_kc_split=Cout // sp)
+            K.check(K.lib.lavt_splitk_reduce(K.dt(bf), K.ptr(parts), sp, M, C1, K.ptr(dx), C1, K.stream()))
+        elif sp:
+            parts = torch.empty(sp, M, C1, dtype=torch.float32, device=dev)
+            ops.gemm_nt(bf, M, C1, (9 // sp) * Cout, dy, Cout, Wpk, 9 * Cin, parts, C1, conv=(H, H, Cout, 1, 1, 1, 3, 3), b_kmajor=True, b_tap_stride=Cin, b_off=0,
+                        batch=sp, strideC=M * C1, c_f32=True, conv_tap_split=9 // sp)
+            K.check(K.lib.lavt_splitk_reduce(K.dt(bf), K.ptr(parts), sp, M, C1, K.ptr(dx), C1, K.stream()))
+        else:
+            ops.gemm_nt(bf, M, C1, 9 * Cout, dy, Cout, Wpk, 9 * Cin, dx, C1, conv=(H, H, Cout, 1, 1, 1, 3, 3), b_kmajor=True, b_tap_stride=Cin, b_off=0)
         return dx
     d_ref = dgrad().float().clone()
     gfd = 2.0 * M * C1 * 9 * Cout * 1e-9
@@ -75,15 +87,18 @@ for (B, H, C1, C2, Cout) in shapes:
                 ("pipe 128 st4", {"LAVT_GEMM_PIPE": 3, "LAVT_GEMM_TILE": 128, "LAVT_GEMM_STAGES": 4}, 0),
                 ("pipe 128 st2", {"LAVT_GEMM_PIPE": 3, "LAVT_GEMM_TILE": 128, "LAVT_GEMM_STAGES": 2}, 0),
                 ("v2 256", {"LAVT_GEMM_PIPE": 0, "LAVT_GEMM_TILE": 512}, 0), ("pipe 256", {"LAVT_GEMM_PIPE": 2, "LAVT_GEMM_TILE": 512}, 0))
+    variants = variants + tuple((f"kc-split {k}", {"LAVT_GEMM_PIPE": 2}, None, k) for k in ("0", "2", "4", "8", "auto")) if M <= 2048 else variants
     if os.environ.get("PROBE_FULL"):
         variants = variants + (("tile64", {"LAVT_GEMM_PIPE": 0, "LAVT_GEMM_TILE": 64}, 0), ("split-all", {"LAVT_GEMM_PIPE": 2}, 1 << 20))
     if os.environ.get("PROBE_VARIANTS"):
         variants = tuple(v for v in variants if v[0] in os.environ["PROBE_VARIANTS"].split(",") or v[0] == "v2 default")
-    for tag, env, rows in variants:
+    for tag, env, rows, *kc in variants:
         setenv(LAVT_GEMM_TILE=None, LAVT_GEMM_STAGES=None, LAVT_GEMM_PIPE=None)
         setenv(**env)
         old = ops._CONV_SPLIT_MAX_ROWS
         if rows is not None: ops._CONV_SPLIT_MAX_ROWS = rows
+        old_kc = ops._CONV_KC_SPLITS
+        if kc: ops._CONV_KC_SPLITS = kc[0]
         try:
             err = float((conv().float() - y_ref).abs().max() / y_ref.abs().max())
             plain(); c_chk = Cc.float().clone()
@@ -97,4 +112,5 @@ for (B, H, C1, C2, Cout) in shapes:
         except Exception as e:
             print(f"  {tag:14s} failed: {e}", flush=True)
         ops._CONV_SPLIT_MAX_ROWS = old
+        ops._CONV_KC_SPLITS = old_kc
     setenv(LAVT_GEMM_TILE=None, LAVT_GEMM_STAGES=None, LAVT_GEMM_PIPE=None)
