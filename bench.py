@@ -464,7 +464,7 @@ def main():
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": a.workload, "global_batch": cfg["batch"] * world, "image": cfg["size"], "n_l": 20,
-                       "parallelism": f"dp{world}", "hip_graph": bool(step.captured), "drop_path": a.drop_path,
+                       "parallelism": f"dp{world}", "hip_graph": bool(step.captured), "zero_fill_skipped_values": int(getattr(step, "zero_skip_values", 0)), "drop_path": a.drop_path,
                        "loss": round(loss, 5), "loss_kernel": "fused upsample+CE" if step.fused_loss else "torch CE", "optimizer_ms_separate": None if opt_ms is None else round(opt_ms, 3), "step_tflops_3x_fwd": round(train_tflops, 2),
                        "mfma_frac_of_step": round(train_tflops / world / BF16_DENSE_PEAK_TFLOPS, 4),
                        "timed_repetitions": len(reps_all), "ms_per_step_all_repetitions": [round(e / a.steps * 1e3, 3) for e in reps_all]},

@@ -99,6 +99,7 @@ class GradBuckets:
         """flat = [ordinary parameters in reverse registration order ~ the order backward produces their gradients, cut into buckets of `cap`
         floats] + [the late parameters: ONE bucket, reduced at finish()].  The layout depends on the module alone: identical on every rank."""
         self.late_ids = set(late_ids)
+        self._zero_views, self._skip_views = None, []          # (a zero-fill skip list refers to the old offsets)
         order = [p for p in reversed(self.params) if id(p) not in self.late_ids]
         late = [p for p in reversed(self.params) if id(p) in self.late_ids]
         self.buckets = []          # (start, end) element ranges of `flat`
@@ -135,6 +136,27 @@ class GradBuckets:
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
 
+    def set_zero_skip(self, param_ids):
+        """Parameters whose weight-gradient launch overwrites the whole gradient with plain stores (ops.sinks.assigned after a step: the grouped Linear
+        gradients, the fused-tap convolution gradients -- 102 of Swin-B LAVT's 119 M values) need no zero fill: zero() then clears only the rest of the
+        flat buffer, as one multi-tensor launch (475 MB at the HBM write rate were 58 us at the head of every step).  Only the step harness sets this,
+        for a CAPTURED step whose launch sequence is frozen, and it verifies the set on the captured graph (engine.TrainStep); None / empty = fill everything."""
+        self._zero_views, self._skip_views = None, []
+        ids = {i for i in (param_ids or ()) if i in self.offset_of}
+        if not ids:
+            return 0
+        spans = sorted((self.offset_of[id(p)], p.numel()) for p in self.params if id(p) in ids)
+        views, pos = [], 0
+        for off, n in spans:
+            if off > pos:
+                views.append(self.flat[pos:off])
+            pos = max(pos, off + n)
+        if pos < self.flat.numel():
+            views.append(self.flat[pos:])
+        self._zero_views = views
+        self._skip_views = [self.flat[off:off + n] for off, n in spans]
+        return sum(n for _, n in spans)
+
     def overlappable_bytes(self) -> int:
         """bytes of the buckets that can be reduced while backward is still running (every bucket but the late one)"""
         return sum(4 * (e - s) for b, (s, e) in enumerate(self.buckets) if b != self.late_bucket)
@@ -156,7 +178,10 @@ class GradBuckets:
             from . import ops
             taken = ops.fill_riders.begin(self.flat)
         if not taken:
-            self.flat.zero_()
+            if self._zero_views is not None:
+                torch._foreach_zero_(self._zero_views)          # everything but the parameters whose gradient launch overwrites its buffer (set_zero_skip)
+            else:
+                self.flat.zero_()
         lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * 4
         for p in self.params:                      # an optimizer / user may have detached .grad; re-point it
             if p.grad is None or p.grad.data_ptr() != lo + 4 * self.offset_of[id(p)]:

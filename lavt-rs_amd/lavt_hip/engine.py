@@ -42,6 +42,7 @@ class TrainStep:
         self.loss = None
         self.use_graph = use_graph and (world == 1 or os.environ.get("LAVT_DDP_GRAPH", "1") != "0")
         self.captured = False
+        self.zero_skip_values = 0                # gradient values left out of the captured zero fill (GradBuckets.set_zero_skip)
         ops.wgrads.enabled = True                # one weight gradient per parameter per step into the zeroed flat buffer: grouped, plainly stored
         self.fused_loss = fused_loss and hasattr(model, "forward_lowres")
         self.stats = None                        # fused loss: [loss, sum of weights, I, U] of the last step (device tensor)
@@ -108,6 +109,41 @@ class TrainStep:
             torch.distributed.barrier()
             torch.cuda.synchronize()
             time.sleep(float(os.environ.get("LAVT_CAPTURE_SETTLE_S", "0.35")))
+        # Zero-fill skip: parameters whose gradient launch overwrote its buffer with plain stores in the last eager step (ops.sinks.assigned: members of the
+        # grouped weight-gradient launches, the fused-tap convolution gradients) are CANDIDATES for being left out of the captured zero fill.  The captured
+        # graph itself decides: the candidates' gradients are poisoned, the graph replayed once, and whatever still holds NaN -- a member the library cut
+        # into pieces that meet through atomics, a buffer not fully written -- goes back into the fill and the step is captured again (at most three
+        # rounds; the launch sequence of a captured step is frozen, so what passes here holds for every replay).
+        cand = set(ops.sinks.assigned) if os.environ.get("LAVT_ZERO_SKIP", "1") != "0" else set()
+        self.zero_skip_values = 0
+        for attempt in range(4):
+            skipped = self.buckets.set_zero_skip(cand if attempt < 3 else None)
+            self._capture()
+            if not self.captured:
+                self.buckets.set_zero_skip(None)         # eager fallback: the full fill
+                break
+            if not skipped:
+                break
+            import math
+            for v in self.buckets._skip_views:
+                v.fill_(math.nan)
+            self.graph.replay()
+            torch.cuda.synchronize()
+            flags = torch.stack([v.isnan().any() for v in self.buckets._skip_views]).tolist()
+            if not any(flags):
+                self.zero_skip_values = skipped
+                break
+            by_start = {self.buckets.flat.data_ptr() + 4 * self.buckets.offset_of[id(p)]: p for p in self.buckets.params}
+            bad = [by_start[v.data_ptr()] for v, f in zip(self.buckets._skip_views, flags) if f]
+            cand -= {id(p) for p in bad}
+            if os.environ.get("LAVT_ZERO_SKIP_VERBOSE"):
+                names = {id(p): n for n, p in self.model.named_parameters()}
+                print(f"[lavt_hip.engine] zero-fill skip: {len(bad)} candidates are accumulated into or not fully written (e.g. {', '.join(names.get(id(p), '?') for p in bad[:4])}); "
+                      "they stay in the fill, capturing again", file=sys.stderr)
+            self.graph = None
+
+    def _capture(self):
+        self.captured = False
         try:
             g = torch.cuda.CUDAGraph()
             # thread_local: ProcessGroupNCCL's watchdog thread polls events of earlier (eager warm-up) collectives with hipEventQuery; under the

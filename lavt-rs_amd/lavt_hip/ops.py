@@ -263,18 +263,31 @@ class _GradSinks:
         self.map = {}
         self.on_ready = None
         self.used = set()
+        self.by_ptr = {}
+        self.assigned = set()
 
     def set(self, params, on_ready=None):
         self.map = {id(p): (weakref.ref(p), p.grad) for p in params if p.grad is not None}
+        self.by_ptr = {ent[1].data_ptr(): pid for pid, ent in self.map.items()}
         self.on_ready = on_ready
         self.used = set()
+        self.assigned = set()
 
     def clear(self):
         self.map, self.on_ready, self.used = {}, None, set()
+        self.by_ptr, self.assigned = {}, set()
 
     def begin_step(self):
         """the flat gradient buffer has just been zeroed (GradBuckets.zero): every parameter may receive ONE weight gradient until the next call"""
         self.used = set()
+        self.assigned = set()
+
+    def mark_assigned_ptr(self, ptr):
+        """the launch that has just been enqueued OVERWRITES the whole gradient buffer at `ptr` with plain stores (a grouped weight-gradient member, the
+        fused-tap convolution weight gradient): such a parameter does not need the step's zero fill (GradBuckets.set_zero_skip, engine.TrainStep)"""
+        pid = self.by_ptr.get(ptr) if ptr else None
+        if pid is not None:
+            self.assigned.add(pid)
 
     def buf(self, p, shape):
         """-> (fp32 buffer of `shape` to accumulate into, is_sink)"""
@@ -648,6 +661,10 @@ class _WgradQueue:
         if not self.items and rider is not None:
             _launch_ln_partial(rider)
         if self.items:
+            if not _STREAMK:             # grouped members store plainly (direct tiles and the reduction of partial tiles alike) unless asked to accumulate
+                for q in self.items:
+                    if not q.accumulate:
+                        sinks.mark_assigned_ptr(q.C)
             assign_partials(self.items, next(t for t in self.keep[0] if t is not None).device)
             arr = (K.GemmTN * len(self.items))(*self.items)
             if K.prof.enabled:       # a grouped launch mixes scopes (qkv / proj with fc1 / fc2): the note carries the per-member flops and labels
@@ -1596,14 +1613,18 @@ class _ConvStats:
 
     def __init__(self):
         self.ent = {}
+        self.hits = 0
 
     def put(self, y, st):
-        self.ent[y.device] = (y.data_ptr(), tuple(y.shape), st)
+        self.ent[y.device] = (weakref.ref(y), y.data_ptr(), tuple(y.shape), st)
 
     def take(self, x):
+        """the statistics of x if x IS the tensor the last convolution on its device returned (same object, same storage): a tensor that merely
+        reuses a freed output's address does not qualify"""
         e = self.ent.pop(x.device, None)
-        if e is not None and e[0] == x.data_ptr() and e[1] == tuple(x.shape):
-            return e[2]
+        if e is not None and e[0]() is x and e[1] == x.data_ptr() and e[2] == tuple(x.shape):
+            self.hits += 1
+            return e[3]
         return None
 
 
@@ -2358,7 +2379,7 @@ class _ConvTaps(torch.autograd.Function):
     (Conv3d of SepTPWAM); the input may be the channel concat of x1 and x2; optional fused GELU (pre-activation saved)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, B, D, H, W, act):
+    def forward(ctx, x1, x2, weight, bias, B, D, H, W, act, stats=False):
         x1 = x1.contiguous()
         dtype = x1.dtype
         C1 = x1.shape[1]
@@ -2398,7 +2419,7 @@ class _ConvTaps(torch.autograd.Function):
         else:
             st = gemm_nt(dtype, M, Cout, taps * Cin, x1, C1, Wp, taps * Cin, y, Cout, A2=x2, lda2=C2, a_split=C1,
                          conv=(H, W, Cin, 0, D, kd, kh, kw), bias=_f32(bias), act=act, Cpre=pre, ldcpre=Cout,
-                         want_colstats=_CONV_STATS and bias is None and act == K.ACT_NONE)
+                         want_colstats=_CONV_STATS and stats and bias is None and act == K.ACT_NONE)
             if st is not None:
                 conv_stats.put(y, st)
         ctx.save_for_backward(x1, x2, weight, bias, pre)
@@ -2473,6 +2494,8 @@ class _ConvTaps(torch.autograd.Function):
                 # second) or fresh zeros: the reduction overwrites instead of adding
                 K.check(K.lib.lavt_conv3x3_wgrad(K.ptr(dy), Cout, K.ptr(x1), C1, K.ptr(x2), C2, C1, B, H, W, Cout, Cin, K.ptr(scr), scr.numel(), K.ptr(dW), 0,
                                                  _zero_page(dy.device), K.stream()))
+                if wsink:
+                    sinks.mark_assigned_ptr(dW.data_ptr())
                 return
             packed = torch.zeros(Cout, taps * Cin, dtype=torch.float32, device=dy.device)
             gemm_tn(dtype, Cout, taps * Cin, M, dy, Cout, x1, C1, packed, taps * Cin, B2=x2, ldb2=C2, b_split=C1,
@@ -2480,7 +2503,7 @@ class _ConvTaps(torch.autograd.Function):
             K.check(K.lib.lavt_unpack_conv_grad(K.ptr(packed), K.ptr(dW), Cout, Cin, taps, K.stream()))
         side.run(_wgrad, (dy, x1, x2), wsink and (db is None or bsink))
         return (dx1, dx2, sinks.done(weight, dW, wsink), sinks.done(bias, db, bsink) if bias is not None else None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 _CONV_SPLIT_MAX_ROWS = int(os.environ.get("LAVT_CONV_SPLIT_ROWS", "2048"))
@@ -2520,7 +2543,8 @@ def _kc_pieces(M, N, Kc):
 
 
 def conv3x3(x1, x2, weight, B, H, W):
-    return _ConvTaps.apply(x1, x2, weight, None, B, 1, H, W, K.ACT_NONE)
+    # under autograd (training) the launch also leaves the column statistics of its output for the BatchNorm that follows (ops.conv_stats)
+    return _ConvTaps.apply(x1, x2, weight, None, B, 1, H, W, K.ACT_NONE, torch.is_grad_enabled())
 
 
 def conv3d(x, weight, bias, B, D, H, W, act=K.ACT_NONE):

@@ -183,6 +183,9 @@ def test_conv_epilogue_column_statistics(tile, stages, B, H, W, C1, C2, Cout, mo
     x1[:, 0] = 12.5
     x2 = rnd(M, C2, seed=2) if C2 else None
     with lavt_hip_dtype(bf):
+        with torch.no_grad():
+            y = ops.conv3x3(x1.to(dev()).to(bf), x2.to(dev()).to(bf) if C2 else None, w.to(dev()), B, H, W)
+        assert ops.conv_stats.take(y) is None, "no statistics epilogue outside autograd"
         y = ops.conv3x3(x1.to(dev()).to(bf), x2.to(dev()).to(bf) if C2 else None, w.to(dev()), B, H, W)
         st = ops.conv_stats.take(y)
         assert st is not None, "the forced pipelined tile has the statistics epilogue"
@@ -221,7 +224,9 @@ def test_conv_epilogue_column_statistics(tile, stages, B, H, W, C1, C2, Cout, mo
         x = x1 if x2 is None else torch.cat([x1, x2], 1)
         y = F.conv2d(x.view(B, H, W, Cin).permute(0, 3, 1, 2), w, padding=1)
         return F.relu(bn_ref(y)).permute(0, 2, 3, 1).reshape(M, Cout)
+    hits0 = ops.conv_stats.hits
     run_pair(hip, ref, inputs, bf, name=f"conv+bn (epilogue statistics) tile {tile}", bf16=8e-2)      # (two bf16 ops: the BatchNorm backward scales the conv's rounding by gamma * rstd)
+    assert ops.conv_stats.hits == hits0 + 1, "the BatchNorm took its statistics from the convolution's epilogue"
     assert float((bn.running_mean.cpu() - bn_ref.running_mean).abs().max()) <= 2e-3 and float((bn.running_var.cpu() - bn_ref.running_var).abs().max()) <= 2e-3
 
 

@@ -341,6 +341,32 @@ def test_grad_buckets_learn_unreported_parameters():
         assert all(gb.launched)
 
 
+def test_grad_buckets_zero_fill_skip_list():
+    """GradBuckets.set_zero_skip: zero() clears everything of the flat buffer EXCEPT the parameters whose gradient launch overwrites its buffer (the
+    step harness verifies the list on the captured graph); the list dies with a layout change and with set_zero_skip(None)."""
+    from lavt_hip.ddp import GradBuckets
+    net = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.LayerNorm(8), torch.nn.Linear(8, 4), torch.nn.Linear(4, 4, bias=False))
+    ps = list(net.parameters())
+    gb = GradBuckets(net, bucket_mib=2 * 64 * 4 / (1 << 20))
+    weights = [p for p in ps if p.dim() == 2]
+    n = gb.set_zero_skip({id(p) for p in weights} | {12345})          # (an id it does not own is ignored)
+    assert n == sum(p.numel() for p in weights)
+    assert sum(v.numel() for v in gb._zero_views) + n == gb.flat.numel()
+    gb.flat.fill_(7.0)
+    gb.zero()
+    for p in ps:
+        want = 7.0 if p.dim() == 2 else 0.0
+        assert float(p.grad.min()) == want and float(p.grad.max()) == want, (tuple(p.shape), want)
+    assert float(gb.flat.sum()) == 7.0 * n                               # padding between buckets, if any, is cleared too
+    gb.set_zero_skip(None)
+    gb.flat.fill_(7.0)
+    gb.zero()
+    assert float(gb.flat.abs().sum()) == 0.0
+    gb.set_zero_skip({id(weights[0])})
+    gb._layout(gb.late_ids)                                              # a new layout invalidates the offsets the list was built from
+    assert gb._zero_views is None
+
+
 def test_syncbn_rank_statistics_combination():
     """SyncBN forward: the ranks' (sum, centred M2) pairs, gathered with ONE collective, combine to the statistics of the whole batch --
     also when the channel means are large compared with the spread (no E[x^2] - E[x]^2 cancellation)"""
