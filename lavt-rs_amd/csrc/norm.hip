@@ -105,16 +105,37 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 // Several partial sets in one launch (deferred LayerNorm weight / bias gradients): grid = (column blocks of 32, row slices, sets).
 // desc[s] = {partials, nblk, C, o1, o2}; partials [nblk][2][C]; the row slices of a set meet through atomics.
-__global__ __launch_bounds__(256) void reduce_partials_multi_kernel(const int64_t* __restrict__ desc) {
-    const int64_t* d = desc + (int64_t)blockIdx.z * 5;
+// COMPACT: blockIdx.x runs over the column blocks of ALL sets (the host passes their total): the (128 column blocks, 8 slices, sets) grid of the first
+// version started 57 344 workgroups for Swin-B's 56 sets, two thirds of which found no columns (34 us for ~80 MB of partial sums).
+template <bool COMPACT>
+__global__ __launch_bounds__(256) void reduce_partials_multi_kernel(const int64_t* __restrict__ desc, int nsets) {
+    int set = blockIdx.z, cb = blockIdx.x;
+    if constexpr (COMPACT) {
+        // (set, column block) of this workgroup: lane s of every wave reads the width of set s (nsets <= 64), an inclusive prefix sum over the lanes, and
+        // the first lane whose sum exceeds blockIdx.x names the set -- one round trip (as a serial scan over the descriptors every workgroup paid
+        // up to 56 dependent loads: slower than the empty workgroups it was meant to save)
+        const int ln = threadIdx.x & 63;
+        int nb = ln < nsets ? (2 * (int)desc[(int64_t)ln * 5 + 2] + 31) / 32 : 0;
+        int pre = nb;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(pre, o, 64);
+            if (ln >= o) pre += up;
+        }
+        const unsigned long long hit = __ballot(pre > (int)blockIdx.x);
+        set = hit ? __ffsll((long long)hit) - 1 : nsets - 1;
+        const int before = __shfl(pre - nb, set, 64);
+        cb = (int)blockIdx.x - before;
+    }
+    const int64_t* d = desc + (int64_t)set * 5;
     const float* partials = reinterpret_cast<const float*>(d[0]);
     const int nblk = (int)d[1], C = (int)d[2], W = 2 * C;
     float* o1 = reinterpret_cast<float*>(d[3]);
     float* o2 = reinterpret_cast<float*>(d[4]);
-    if ((int)blockIdx.x * 32 >= W) return;
+    if (cb * 32 >= W) return;
     __shared__ float red[8][33];
     const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    const int w = blockIdx.x * 32 + col;
+    const int w = cb * 32 + col;
     const int per = (nblk + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * per, k1 = min(nblk, k0 + per);
     float a = 0.f, b = 0.f;
     if (w < W) {
@@ -549,10 +570,12 @@ extern "C" int lavt_layernorm_bwd_xn(int dtype, const void* dy, const void* x, c
     LAVT_CHECK_ARG(xn && beta, "lavt_layernorm_bwd_xn: xn and beta required");
     return layernorm_bwd_impl(dtype, dy, x, nullptr, gamma, mean, rstd, dx, dgamma, dbeta, ws, ws_floats, dres, rows, C, stream, false, xn, beta);
 }
-extern "C" int lavt_reduce_partials_multi(const int64_t* desc, int n, void* stream) {
+extern "C" int lavt_reduce_partials_multi(const int64_t* desc, int n, int total_column_blocks, void* stream) {
     LAVT_CHECK_ARG(desc && n > 0, "lavt_reduce_partials_multi: bad arguments");
-    // widest supported set: C = 2048 -> 128 column blocks; 8 row slices per set
-    hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(128, 8, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
+    if (total_column_blocks > 0 && n <= 64)          // sum over the sets of ceil(2 C / 32): one workgroup column per 32 columns that exist
+        hipLaunchKernelGGL(reduce_partials_multi_kernel<true>, dim3(total_column_blocks, 8, 1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, n);
+    else          // (the caller does not know the widths: widest supported set C = 2048 -> 128 column blocks per set)
+        hipLaunchKernelGGL(reduce_partials_multi_kernel<false>, dim3(128, 8, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, n);
     LAVT_CHECK_LAUNCH("lavt_reduce_partials_multi");
     return LAVT_OK;
 }

@@ -177,7 +177,7 @@ _PROTOTYPES = {
     "lavt_layernorm_bwd_partial": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
     "lavt_layernorm_bwd_partial_xn": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
     "lavt_layernorm_bwd_xn": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
-    "lavt_reduce_partials_multi": [vp, i32, vp],
+    "lavt_reduce_partials_multi": [vp, i32, i32, vp],
     "lavt_colstats": [i32, vp, vp, vp, vp, i64, i32, i32, i32, vp],
     "lavt_syncbn_combine": [vp, i32, f32, f32, vp, vp, vp, vp, f32, i32, vp],
     "lavt_colstats_meanrstd": [i32, vp, vp, vp, vp, i64, i32, i32, i32, f32, vp, vp, f32, vp],

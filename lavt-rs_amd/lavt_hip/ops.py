@@ -710,6 +710,9 @@ class _WgradQueue:
 wgrads = _WgradQueue()
 
 
+_LN_REDUCE_COMPACT = os.environ.get("LAVT_LN_REDUCE_COMPACT", "1") != "0"          # A/B switch: 0 = the (128 column blocks x sets) grid of round 3
+
+
 class _LnDeferred:
     """LayerNorm weight / bias gradients feed nothing but the gradient buffer, so under the step harness their per-workgroup partial sums are
     parked in a persistent arena and reduced by ONE launch at the end of backward (lavt_reduce_partials_multi) instead of one two-kernel
@@ -764,7 +767,7 @@ class _LnDeferred:
                     raise RuntimeError("deferred LayerNorm reductions: the step being captured differs from the warm-up steps (descriptor table would need a host copy)")
                 self.desc = torch.tensor(self.items, dtype=torch.int64).to(self.arena.device)
                 self.desc_key = key
-            K.check(K.lib.lavt_reduce_partials_multi(K.ptr(self.desc), len(self.items), K.stream()))
+            K.check(K.lib.lavt_reduce_partials_multi(K.ptr(self.desc), len(self.items), sum((2 * it[2] + 31) // 32 for it in self.items) if _LN_REDUCE_COMPACT else 0, K.stream()))
         params = self.params
         self.items, self.params, self.off = [], [], 0
         for p in params:
