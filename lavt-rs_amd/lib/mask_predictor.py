@@ -55,9 +55,9 @@ class SimpleDecoding(nn.Module):
         elif xhw != (H, W):
             raise ValueError("decoder: top-down map larger than the skip feature")
         x = ops.conv3x3(x, nchw_rows(skip, dtype), getattr(self, f"conv1_{tag}").weight, B, H, W)
-        x = ops.batch_norm_relu(x, getattr(self, f"bn1_{tag}"))
+        x = ops.batch_norm_relu(x, getattr(self, f"bn1_{tag}"), track=False)          # (num_batches_tracked: one launch for all layers, _run_scoped)
         x = ops.conv3x3(x, None, getattr(self, f"conv2_{tag}").weight, B, H, W)
-        x = ops.batch_norm_relu(x, getattr(self, f"bn2_{tag}"))
+        x = ops.batch_norm_relu(x, getattr(self, f"bn2_{tag}"), track=False)
         return x, (H, W)
 
     def _run(self, x_c4, x_c3, x_c2, x_c1):
@@ -77,6 +77,7 @@ class SimpleDecoding(nn.Module):
         if not self.lazy_pred:
             x, hw = self._level(2, x, hw, x_c1, B, dtype)
             feats.append((x, hw))
+        ops.bn_count_batches([getattr(self, f"bn{i}_{tag}") for tag in ((4, 3) if self.lazy_pred else (4, 3, 2)) for i in (1, 2)])
         y = ops.cls_head(x, self.conv1_1.weight, self.conv1_1.bias)
         as_nchw = lambda r, s: r.view(B, s[0], s[1], r.shape[1]).permute(0, 3, 1, 2)     # noqa: E731
         return as_nchw(y, hw), [as_nchw(f, s) for f, s in feats]

@@ -115,7 +115,10 @@ def test_decoder_golden(golden):
     dec.to(DEV)
     feats = [randn(int(s), 2, c, hw, hw).to(DEV) for s, (c, hw) in zip(g["seeds"], ((64, 4), (32, 8), (16, 16), (8, 32)))]
     close(dec.eval()(*feats), g["y_eval"], 2e-4, "decoder eval")
+    n0 = {k: int(v) for k, v in dec.state_dict().items() if k.endswith("num_batches_tracked")}
     close(dec.train()(*feats), g["y_train"], 3e-4, "decoder train-mode BN")
+    n1 = {k: int(v) for k, v in dec.state_dict().items() if k.endswith("num_batches_tracked")}
+    assert len(n0) == 6 and all(n1[k] == n0[k] + 1 for k in n0), "every BatchNorm layer counted the training batch once (one multi-tensor launch), none counted the eval pass"
 
 
 def _build(embed_dim, depths, heads, ws, dpr=0.3):
