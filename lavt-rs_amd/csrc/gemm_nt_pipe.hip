@@ -559,7 +559,11 @@ int lavt_gemm_nt_pipe_tile(const lavt_gemm_nt_t& p, int* stages_out) {
     if (tun.gemm_v2_off || pipe < 1) return 0;
     if (p.lda % 8 || p.ldb % 8 || (p.A2 && p.lda2 % 8)) return 0;
     if (p.ln_wsum || p.dact_pre) return 0;
-    if (p.conv_kc_split > 0) { *stages_out = 4; return 128; }          // the channel-split reduction exists in this kernel only
+    if (p.conv_kc_split > 0) {          // the channel-split reduction exists in this kernel's tap-walking mode only
+        if (tun.gemm_general) return 0;          // (LAVT_GEMM_GENERAL forces the general decode: lavt_gemm_nt then refuses the problem)
+        *stages_out = 4;
+        return 128;
+    }
     const int force = tun.gemm_tile;
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
     const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;

@@ -2544,7 +2544,7 @@ _CONV_KC_SPLITS = os.environ.get("LAVT_CONV_KC_SPLITS", "auto")
 
 
 def _kc_pieces(M, N, Kc):
-    if _CONV_KC_SPLITS == "0" or os.environ.get("LAVT_GEMM_PIPE", "2") == "0" or Kc % 64:
+    if _CONV_KC_SPLITS == "0" or os.environ.get("LAVT_GEMM_PIPE", "2") == "0" or os.environ.get("LAVT_GEMM_GENERAL") is not None or os.environ.get("LAVT_GEMM_V2", "1") == "0" or Kc % 64:
         return 0
     cb, tiles = Kc // 64, -(-M // 128) * -(-N // 128)
     if _CONV_KC_SPLITS != "auto":
