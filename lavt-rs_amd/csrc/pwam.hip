@@ -87,47 +87,52 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
     for (int e0 = tid; e0 < 32 * nch; e0 += 2048) {
         uint4 raw[8];
         float4 r0[8], r1[8];
+        // (loads unconditional on a clamped chunk index, only the LDS store below is predicated: with the loads under `if (e < ...)` hipcc kept raw[] in
+        // scratch -- 144 bytes per lane, eight scratch round trips at the head of the kernel)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int e = e0 + 256 * u;
-            if (e < 32 * nch) {
-                const int j = e / nch, cc = e - j * nch;
-                raw[u] = *reinterpret_cast<const uint4*>(a.Wsrc + ((int64_t)b * 32 + j) * a.ldw + cc * 8);
-                if constexpr (!BWD) {
-                    r0[u] = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + cc * 8);
-                    r1[u] = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + cc * 8 + 4);
-                }
+            const int e = min(e0 + 256 * u, 32 * nch - 1);
+            const int j = e / nch, cc = e - j * nch;
+            raw[u] = *reinterpret_cast<const uint4*>(a.Wsrc + ((int64_t)b * 32 + j) * a.ldw + cc * 8);
+            if constexpr (!BWD) {
+                r0[u] = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + cc * 8);
+                r1[u] = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + cc * 8 + 4);
             }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + 256 * u;
+            uint4 val = raw[u];
+            if constexpr (!BWD) {
+                float f[8];
+                chunk_to_f<bf16>(val, f);
+                const float s = a.alpha * LOG2E;
+                f[0] *= r0[u].x * s; f[1] *= r0[u].y * s; f[2] *= r0[u].z * s; f[3] *= r0[u].w * s;
+                f[4] *= r1[u].x * s; f[5] *= r1[u].y * s; f[6] *= r1[u].z * s; f[7] *= r1[u].w * s;
+                val = f_to_chunk<bf16>(f);
+            }
             if (e < 32 * nch) {
                 const int j = e / nch, cc = e - j * nch;
-                if constexpr (!BWD) {
-                    float f[8];
-                    chunk_to_f<bf16>(raw[u], f);
-                    const float s = a.alpha * LOG2E;
-                    f[0] *= r0[u].x * s; f[1] *= r0[u].y * s; f[2] *= r0[u].z * s; f[3] *= r0[u].w * s;
-                    f[4] *= r1[u].x * s; f[5] *= r1[u].y * s; f[6] *= r1[u].z * s; f[7] *= r1[u].w * s;
-                    raw[u] = f_to_chunk<bf16>(f);
-                }
-                *reinterpret_cast<uint4*>(Wm + j * LDW + cc * 8) = raw[u];
+                *reinterpret_cast<uint4*>(Wm + j * LDW + cc * 8) = val;
             }
         }
     }
     if constexpr (BWD) {
         // (n_l carries the record count in this mode.)  Eight records per round, every load of a round issued before the first add: as a plain loop over
         // the records each element was a chain of `records` exposed round trips at the head of a kernel that sits on the critical chain
-        for (int e = tid; e < 1024; e += 256) {
+        // (round 4: all 4 x 16 loads of a thread in flight at once -- two rounds of eight per element were still eight serial round trips, ~8 us at the
+        // head of the 450-row launch of the last stage; lavt_pwam_q_parts caps the record count at 16)
+        float v[4][16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[k][u] = u < a.n_l ? a.Qf[((int64_t)b * a.n_l + u) * 1056 + tid + 256 * k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
             float q = 0.f;
-            for (int w0 = 0; w0 < a.n_l; w0 += 8) {
-                float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = w0 + u < a.n_l ? a.Qf[((int64_t)b * a.n_l + w0 + u) * 1056 + e] : 0.f;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) q += v[u];          // (fixed order: run-to-run identical)
-            }
+            for (int u = 0; u < 16; ++u) q += v[k][u];          // (fixed order: run-to-run identical)
+            const int e = tid + 256 * k;
             Qn[(e >> 5) * 40 + (e & 31)] = (bf16)(-q);
         }
     }
@@ -149,14 +154,11 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
         if (part == 0) {
             if constexpr (BWD) {
-                float uj = 0.f;
-                for (int w0 = 0; w0 < a.n_l; w0 += 8) {
-                    float v[8];
+                float uj = 0.f, vu[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = w0 + u < a.n_l ? a.Qf[((int64_t)b * a.n_l + w0 + u) * 1056 + 1024 + j] : 0.f;
+                for (int u = 0; u < 16; ++u) vu[u] = u < a.n_l ? a.Qf[((int64_t)b * a.n_l + u) * 1056 + 1024 + j] : 0.f;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) uj += v[u];
-                }
+                for (int u = 0; u < 16; ++u) uj += vu[u];
                 vec[j] = s - uj;
             } else vec[j] = a.vec[b * 32 + j] * LOG2E - s;
         }
