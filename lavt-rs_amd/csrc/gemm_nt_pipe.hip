@@ -18,9 +18,9 @@
 //     block (tiles beyond K are issued against the zero page, cursor updates are selects), so nothing the compiler does can regroup it;
 //   * convolutions walk K with the TAPS FASTEST (channel block outer): the 9 (27) shifted reads of a 64-channel block of the activations follow each
 //     other, so 8 of 9 come from the XCD's L2; the concat source switches once per launch instead of being selected per DMA instruction.
-// Measured (tools/conv_small_probe.py, hipGraph-timed, against the gemm_v2 form on the same box): 2x120x120 512->512 forward 134.7 -> 125.6 us,
-// 640->512 158.6 -> 146.1 (0.47 of the bf16 peak), 2x60x60 512->512 56.6 -> 50.4, 768->512 80.5 -> 69.2, plain 7200x512x4608 47.4 -> 38.0; data
-// gradients (k-major weight reads) level to -4 %.  What bounds it now (ablation builds, same tool): the DMA stream alone takes 85 us on the
+// Measured (tools/conv_small_probe.py, hipGraph-timed, against the gemm_v2 form): 2x120x120 512->512 forward 134.7 -> 124.4 us, 640->512 158.6 -> 140.8
+// (0.48 of the bf16 peak), data gradient 127 -> 120 (0.45); 2x60x60 512->512 56.6 -> 45.2, 768->512 80.5 -> 62.1, data gradient 57 -> 48; plain
+// 7200x512x4608 47.4 -> 37.0.  What bounds it now (ablation builds, same tool): the DMA stream alone takes 85 us on the
 // 125 us convolution (every CU ingests ~52 GB/s whatever the tile size or ring depth: 12 TB/s over the chip, L2-hit traffic), MFMA + fragment
 // reads alone 99 us (the chip holds ~1.7 GHz under this load: 0.57 of the nominal peak is what an MFMA-only loop reaches) -- the two overlap to 125.
 // DMA geometry (lane-linear LDS images, chunk / slot swizzles applied to the per-lane SOURCE address, zero page for padding and halos) and the
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
     const T* a_p1[A_INSTR];
     const T* a_p2[A_INSTR];
     int64_t b_lane_off[B_INSTR];
-    int c_kin = 0, c_tap = 0, c_dz = 0, c_dy = 0, c_dx = 0, c_tap0 = 0, c_ntap = cg.taps;
+    int c_kin = 0, c_tap = 0, c_tap0 = 0, c_ntap = cg.taps;
     if constexpr (CONVFAST) {
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
@@ -247,7 +247,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
         if (p.conv_tap_split > 0) { c_tap = bz * p.conv_tap_split; c_ntap = p.conv_tap_split; }
         if (p.conv_kc_split > 0) c_kin = bz * p.conv_kc_split;          // split over channel blocks: this entry's first channel
         c_tap0 = c_tap;
-        conv_tap(cg, c_tap, c_dz, c_dy, c_dx);
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
             if constexpr (!BKM) {
@@ -283,7 +282,19 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
     unsigned u_bit = 0;
     int u_boff = 0, u_kt = 0;
     const T* u_bb = B;
-    int t0_dz = c_dz, t0_dy = c_dy, t0_dx = c_dx;
+    // Row offset of every tap, (dz h + dy) w + dx in elements of the current source's rows, as a 64-bit table over the lanes (lane t = tap t, taps <= 32):
+    // the K loop fetches its tap's entry with two v_readlane.  (Kept as running (dz, dy, dx) + a 64-bit multiply per K tile the tap walk was ~70 scalar
+    // instructions per wave per K tile -- 5.5 x the plain GEMM's, on the ONE scalar unit a CU's eight waves share: rocprofv3 SQ_INSTS_SALU 11.8 M vs
+    // 2.2 M per launch at 2 x 60 x 60, where the convolution ran 33 % longer than a plain GEMM of its size.)
+    int tap_lo = 0, tap_hi = 0;
+    auto tap_table = [&](int64_t ld) {
+        int dz, dy, dx;
+        conv_tap(cg, lane < cg.taps ? lane : 0, dz, dy, dx);
+        const int64_t v = (int64_t)(((dz * cg.h + dy) * cg.w + dx) * (flip ? -1 : 1)) * ld;
+        tap_lo = (int)(v & 0xffffffffll);
+        tap_hi = (int)(v >> 32);
+    };
+    if constexpr (CONVFAST) tap_table(cur_lda);
     // running position in the weight operand (advanced in issue_end: no 64-bit multiplies per K tile): k-major B -- pointer to (tap, channel block);
     // k-contiguous B -- column offset of (tap, channel block) inside the [Cout][taps][Cin] rows
     const T* c_bb = B + (int64_t)c_kin * p.ldb + (int64_t)c_tap0 * p.b_tap_stride;
@@ -293,8 +304,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
     auto issue_begin = [&](int kt, bool past) {
         u_past = past; u_kt = kt;
         if constexpr (CONVFAST) {
-            const int delta = ((c_dz * cg.h + c_dy) * cg.w + c_dx) * (flip ? -1 : 1);          // element offset of this K tile's (tap, channel block) relative to a row pointer
-            u_off = (int64_t)delta * cur_lda + (c_kin - cur_base);
+            const int64_t shift = ((int64_t)__builtin_amdgcn_readlane(tap_hi, c_tap) << 32) | (unsigned)__builtin_amdgcn_readlane(tap_lo, c_tap);
+            u_off = shift + (c_kin - cur_base);          // element offset of this K tile's (tap, channel block) relative to a row pointer
             u_bit = past ? 0u : 1u << c_tap;
             u_boff = past ? 0 : c_boff;
             u_bb = past ? B : c_bb;
@@ -359,21 +370,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
             // taps fastest: the nine (27) shifted reads of a 64-channel block follow each other, so all but the first are served by the XCD's L2.
             // Selects, no branches: the whole K tile is one basic block.
             ++c_tap;
-            ++c_dx;
-            const bool wx = c_dx > (cg.kw >> 1);
-            c_dx = wx ? -(cg.kw >> 1) : c_dx;
-            c_dy += wx ? 1 : 0;
-            const bool wy = c_dy > (cg.kh >> 1);
-            c_dy = wy ? -(cg.kh >> 1) : c_dy;
-            c_dz += wy ? 1 : 0;
             const bool wt = c_tap == c_tap0 + c_ntap;
             c_tap = wt ? c_tap0 : c_tap;
-            c_dz = wt ? t0_dz : c_dz; c_dy = wt ? t0_dy : c_dy; c_dx = wt ? t0_dx : c_dx;
             c_kin += wt ? BK : 0;
             if (has_a2 && wt && c_kin == a_split) {           // (uniform, taken once per launch)
 #pragma unroll
                 for (int i = 0; i < A_INSTR; ++i) a_cur[i] = a_p2[i];
                 cur_lda = lda2; cur_base = a_split;
+                tap_table(lda2);
             }
             c_bb += wt ? bb_wrap : bb_tap;
             c_boff += wt ? boff_wrap : conv_kc;
