@@ -96,14 +96,20 @@ __device__ __forceinline__ void tn_tile_range(const lavt_gemm_tn_t& p, const int
     const int amask = p.a_rowmap ? -1 : 0, bmask = p.b_rowmap ? -1 : 0;
     const unsigned nors = p.a_rowscale ? 0u : 1u, lda_u = (unsigned)p.lda;
     const int Kdim = p.K;
+    // (the side-input pointers as locals: read through `p` -- a reference into the grouped launch's 1.2 KB argument block, member chosen at run time -- the
+    // compiler re-fetched them with four s_load per K tile, each behind its own `s_waitcnt lgkmcnt(0)` in the middle of the LDS traffic)
+    const int32_t* const map_a = p.a_rowmap;
+    const int32_t* const map_b = p.b_rowmap;
+    const void* const map_rs = p.a_rowscale;
+    const int rs_div = p.a_rowscale_div;
     auto map_dma = [&](int t) {
         if constexpr (MAPS) {
             int k = (kt_begin + t) * BK + lane;
-            k = k < p.K ? k : p.K - 1;
+            k = k < Kdim ? k : Kdim - 1;
             const void* src = Z;
-            if (wave == 0 && p.a_rowmap) src = p.a_rowmap + k;
-            if (wave == 1 && p.a_rowscale) src = p.a_rowscale + (p.a_rowscale_div > 1 ? fdiv(k, p.a_rowscale_div, inv_rsdiv) : k);
-            if (wave == 2 && p.b_rowmap) src = p.b_rowmap + k;
+            if (wave == 0 && map_a) src = map_a + k;
+            if (wave == 1 && map_rs) src = reinterpret_cast<const unsigned*>(map_rs) + (rs_div > 1 ? fdiv(k, rs_div, inv_rsdiv) : k);
+            if (wave == 2 && map_b) src = map_b + k;
             dma4(src, wave < 3 ? maps + (t % NSLOT) * SLOT_BYTES + wave * 256 : maps + NSLOT * SLOT_BYTES);
         }
     };
