@@ -18,18 +18,34 @@
 //     block (tiles beyond K are issued against the zero page, cursor updates are selects), so nothing the compiler does can regroup it;
 //   * convolutions walk K with the TAPS FASTEST (channel block outer): the 9 (27) shifted reads of a 64-channel block of the activations follow each
 //     other, so 8 of 9 come from the XCD's L2; the concat source switches once per launch instead of being selected per DMA instruction.
-// Measured (tools/conv_small_probe.py, hipGraph-timed, against the gemm_v2 form): 2x120x120 512->512 forward 134.7 -> 124.4 us, 640->512 158.6 -> 140.8
-// (0.48 of the bf16 peak), data gradient 127 -> 120 (0.45); 2x60x60 512->512 56.6 -> 45.2, 768->512 80.5 -> 62.1, data gradient 57 -> 48; plain
+// Measured (tools/conv_small_probe.py, hipGraph-timed, against the gemm_v2 form): 2x120x120 512->512 forward 134.7 -> 120.5 us (0.45 of the bf16 peak),
+// 640->512 158.6 -> 138.3 (0.49), data gradient 127 -> 115 (0.47); 2x60x60 512->512 56.6 -> 42.0, 768->512 80.5 -> 59.7, data gradient 57 -> 44; plain
 // 7200x512x4608 47.4 -> 37.0.  What bounds it now (ablation builds, same tool): the DMA stream alone takes 85 us on the
 // 125 us convolution (every CU ingests ~52 GB/s whatever the tile size or ring depth: 12 TB/s over the chip, L2-hit traffic), MFMA + fragment
 // reads alone 99 us (the chip holds ~1.7 GHz under this load: 0.57 of the nominal peak is what an MFMA-only loop reaches) -- the two overlap to 125.
-// DMA geometry (lane-linear LDS images, chunk / slot swizzles applied to the per-lane SOURCE address, zero page for padding and halos) and the
-// epilogue are those of gemm_v2.hip.
+// DMA geometry (lane-linear LDS images, chunk / slot swizzles applied to the per-lane SOURCE address) and the epilogue are those of gemm_v2.hip; the
+// tap-walking mode addresses its operands through buffer descriptors (zeros for halo / padding = an offset beyond the descriptor's range).
 #include "gemm_v2_helpers.h"
 
 namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer-descriptor LDS-DMA (buffer_load_dwordx4 ... offen lds).  The resource type and its builtins exist in the device pass only; the host pass, which
+// still parses the kernel body to emit its launch stub, sees placeholders.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t buf_make(const void* base) {          // 2 GB window, raw (stride 0) addressing, offsets beyond it read zero
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void buf_dma16(buf_rsrc_t rs, void* lds_dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, voff, soff, 0, 0);
+}
+#else
+struct buf_rsrc_t { int unused; };
+__host__ __device__ inline buf_rsrc_t buf_make(const void*) { return buf_rsrc_t{0}; }
+__host__ __device__ inline void buf_dma16(buf_rsrc_t, void*, unsigned, unsigned) {}
+#endif
 
 // N ds_read_b128 at addr + BASE + i * STRIDE, issued only (no wait): outputs are early-clobber so that no destination aliases the address
 template <int N, int BASE, int STRIDE> __device__ __forceinline__ void pipe_issue(u32x4 (&f)[N], unsigned addr) {
@@ -219,10 +235,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
         }
     }
     // CONVFAST: a bit per tap "this row's neighbour lies inside the volume" and the row's pointers into the two sources at the lane's channel chunk
-    unsigned a_vmask[A_INSTR];
-    const T* a_p1[A_INSTR];
-    const T* a_p2[A_INSTR];
-    int64_t b_lane_off[B_INSTR];
+    // The operands are addressed through buffer descriptors (buffer_load ... lds): a lane's offset is a 32-bit register that never changes, the (tap,
+    // channel block) of a K tile is the scalar offset of the instruction, and a chunk that must read zero -- halo, padding rows, columns beyond N --
+    // is an offset beyond the descriptor's range (the hardware writes zeros).  Against per-lane 64-bit pointers + a zero page this is 3 vector
+    // instructions per A instruction (mask test + select) and none per B instruction instead of ~7 / ~4.  lavt_gemm_nt_pipe_tile sends operands of
+    // 2 GB or more to the general mode.
+    constexpr unsigned BUF_OOB = 0x80000000u;
+    unsigned a_vmask[A_INSTR], a_vo1[A_INSTR], a_vo2[A_INSTR], b_vo[B_INSTR];
     int c_kin = 0, c_tap = 0, c_tap0 = 0, c_ntap = cg.taps;
     if constexpr (CONVFAST) {
 #pragma unroll
@@ -240,21 +259,17 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
                 }
             }
             a_vmask[i] = m;
-            const int64_t row = a_src[i] >= 0 ? a_src[i] : 0;
-            a_p1[i] = A + row * p.lda + cl * EPC;
-            a_p2[i] = A2 ? A2 + row * p.lda2 + cl * EPC : a_p1[i];
+            // byte offset of the lane's chunk in either source, or out of the descriptor's range (a row that does not exist: the load then writes zeros)
+            a_vo1[i] = a_src[i] >= 0 ? (unsigned)(((int64_t)a_src[i] * p.lda + cl * EPC) * 2) : BUF_OOB;
+            a_vo2[i] = (A2 && a_src[i] >= 0) ? (unsigned)(((int64_t)a_src[i] * p.lda2 + cl * EPC) * 2) : BUF_OOB;
         }
         if (p.conv_tap_split > 0) { c_tap = bz * p.conv_tap_split; c_ntap = p.conv_tap_split; }
         if (p.conv_kc_split > 0) c_kin = bz * p.conv_kc_split;          // split over channel blocks: this entry's first channel
         c_tap0 = c_tap;
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            if constexpr (!BKM) {
-                b_ptr[i] = b_row[i] >= 0 ? B + (int64_t)b_row[i] * p.ldb + cl * EPC : Z;
-                b_step[i] = b_row[i] >= 0 ? BK : 0;
-            } else {
-                b_lane_off[i] = b_row[i] >= 0 ? (int64_t)b_row[i] * p.ldb + b_col[i] : -1;
-            }
+            if constexpr (!BKM) b_vo[i] = b_row[i] >= 0 ? (unsigned)(((int64_t)b_row[i] * p.ldb + cl * EPC) * 2) : BUF_OOB;
+            else b_vo[i] = b_row[i] >= 0 ? (unsigned)(((int64_t)b_row[i] * p.ldb + b_col[i]) * 2) : BUF_OOB;
         }
     }
     const bool has_a2 = p.A2 != nullptr;
@@ -267,48 +282,55 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
     // are constants): such a tile reads the zero page / the start of the weight rows.
     // the concat source the channel blocks currently come from: with taps fastest the channel block only grows, so the rows switch from the first
     // source to the second ONCE (issue_end) instead of being selected per DMA instruction
-    const T* a_cur[A_INSTR];
+    unsigned a_vo[A_INSTR];
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) a_cur[i] = CONVFAST ? a_p1[i] : nullptr;
+    for (int i = 0; i < A_INSTR; ++i) a_vo[i] = CONVFAST ? a_vo1[i] : 0u;
     int64_t cur_lda = lda1;
     int cur_base = 0;
+    // descriptor bases sit `bias` bytes below the tensors so that the scalar offset bias + (tap shift) + channel offset is never negative
+    const int max_rows = ((cg.kd >> 1) * cg.h + (cg.kh >> 1)) * cg.w + (cg.kw >> 1);
+    const unsigned bias1 = (unsigned)((int64_t)max_rows * lda1 * 2), bias2 = (unsigned)((int64_t)max_rows * lda2 * 2);
+    buf_rsrc_t rs_a = buf_make(reinterpret_cast<const char*>(A) - bias1);
+    const buf_rsrc_t rs_a2 = buf_make(reinterpret_cast<const char*>(A2 ? A2 : A) - bias2);
+    const buf_rsrc_t rs_b = buf_make(B);
+    unsigned cur_bias = bias1;
     if (CONVFAST && has_a2 && c_kin >= a_split) {          // (a channel-split entry that starts inside the second source)
 #pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) a_cur[i] = a_p2[i];
-        cur_lda = lda2; cur_base = a_split;
+        for (int i = 0; i < A_INSTR; ++i) a_vo[i] = a_vo2[i];
+        cur_lda = lda2; cur_base = a_split; rs_a = rs_a2; cur_bias = bias2;
     }
-    int64_t u_off = 0;
+
+    // ---- DMA issue of one K tile, in three parts so that the L instructions can be spread between MFMAs ---------------------------------
+    // issue_begin: the wave-uniform part (scalar unit); issue_one(idx): DMA instruction idx (A rows first, then B); issue_end: cursor advance.
+    // `past` = the tile lies beyond K (the loop issues STAGES tiles ahead unconditionally, so that it has no branches and the counted waits
+    // are constants): such a tile reads the zero page / the start of the weight rows.
+    unsigned u_soff_a = 0, u_soff_b = 0;
     bool u_past = false;
     unsigned u_bit = 0;
-    int u_boff = 0, u_kt = 0;
-    const T* u_bb = B;
-    // Row offset of every tap, (dz h + dy) w + dx in elements of the current source's rows, as a 64-bit table over the lanes (lane t = tap t, taps <= 32):
-    // the K loop fetches its tap's entry with two v_readlane.  (Kept as running (dz, dy, dx) + a 64-bit multiply per K tile the tap walk was ~70 scalar
+    int u_kt = 0;
+    // Row offset of every tap, ((dz h + dy) w + dx) rows of the current source in BYTES, as a table over the lanes (lane t = tap t, taps <= 32): the K loop
+    // fetches its tap's entry with one v_readlane.  (Kept as running (dz, dy, dx) + a 64-bit multiply per K tile the tap walk was ~70 scalar
     // instructions per wave per K tile -- 5.5 x the plain GEMM's, on the ONE scalar unit a CU's eight waves share: rocprofv3 SQ_INSTS_SALU 11.8 M vs
     // 2.2 M per launch at 2 x 60 x 60, where the convolution ran 33 % longer than a plain GEMM of its size.)
-    int tap_lo = 0, tap_hi = 0;
+    int tap_sh = 0;
     auto tap_table = [&](int64_t ld) {
         int dz, dy, dx;
         conv_tap(cg, lane < cg.taps ? lane : 0, dz, dy, dx);
-        const int64_t v = (int64_t)(((dz * cg.h + dy) * cg.w + dx) * (flip ? -1 : 1)) * ld;
-        tap_lo = (int)(v & 0xffffffffll);
-        tap_hi = (int)(v >> 32);
+        tap_sh = (int)((int64_t)(((dz * cg.h + dy) * cg.w + dx) * (flip ? -1 : 1)) * ld * 2);
     };
     if constexpr (CONVFAST) tap_table(cur_lda);
-    // running position in the weight operand (advanced in issue_end: no 64-bit multiplies per K tile): k-major B -- pointer to (tap, channel block);
-    // k-contiguous B -- column offset of (tap, channel block) inside the [Cout][taps][Cin] rows
-    const T* c_bb = B + (int64_t)c_kin * p.ldb + (int64_t)c_tap0 * p.b_tap_stride;
-    const int64_t bb_tap = p.b_tap_stride, bb_wrap = (int64_t)BK * p.ldb - (int64_t)(c_ntap - 1) * p.b_tap_stride;
+    // running position in the weight operand (advanced in issue_end), in bytes from B: k-major B -- (tap, channel block) rows; k-contiguous B -- the columns
+    // of (tap, channel block) inside the [Cout][taps][Cin] rows
+    unsigned c_bbo = (unsigned)(((int64_t)c_kin * p.ldb + (int64_t)c_tap0 * p.b_tap_stride) * 2);
+    const unsigned bb_tap = (unsigned)(p.b_tap_stride * 2), bb_wrap = (unsigned)(((int64_t)BK * p.ldb - (int64_t)(c_ntap - 1) * p.b_tap_stride) * 2);
     int c_boff = c_kin;
     const int boff_wrap = BK - (c_ntap - 1) * conv_kc;
     auto issue_begin = [&](int kt, bool past) {
         u_past = past; u_kt = kt;
         if constexpr (CONVFAST) {
-            const int64_t shift = ((int64_t)__builtin_amdgcn_readlane(tap_hi, c_tap) << 32) | (unsigned)__builtin_amdgcn_readlane(tap_lo, c_tap);
-            u_off = shift + (c_kin - cur_base);          // element offset of this K tile's (tap, channel block) relative to a row pointer
-            u_bit = past ? 0u : 1u << c_tap;
-            u_boff = past ? 0 : c_boff;
-            u_bb = past ? B : c_bb;
+            u_soff_a = cur_bias + (unsigned)(__builtin_amdgcn_readlane(tap_sh, c_tap) + (c_kin - cur_base) * 2);
+            u_bit = past ? 0u : 1u << c_tap;                                          // (a tile beyond K: every A lane out of range, B from the start of the rows)
+            u_soff_b = past ? 0u : (BKM ? c_bbo : (unsigned)(c_boff * 2));
         }
     };
     auto issue_one = [&](auto idx_c, char* sbase) {
@@ -320,7 +342,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
                 dma16(u_past ? Z : a_ptr[i], dst);
                 a_ptr[i] += a_step[i];
             } else if constexpr (CONVFAST) {
-                dma16((a_vmask[i] & u_bit) ? a_cur[i] + u_off : Z, dst);
+                buf_dma16(rs_a, dst, (a_vmask[i] & u_bit) ? a_vo[i] : BUF_OOB, u_soff_a);
             } else {
                 const int k = u_kt * BK + cl * EPC;
                 int kin = k, dz = 0, dy = 0, dx = 0;
@@ -345,8 +367,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
                 dma16(u_past ? Z : b_ptr[i], dst);
                 b_ptr[i] += b_step[i];
             } else if constexpr (CONVFAST) {
-                if constexpr (!BKM) dma16(b_step[i] ? b_ptr[i] + u_boff : Z, dst);
-                else dma16(b_lane_off[i] >= 0 ? u_bb + b_lane_off[i] : Z, dst);
+                buf_dma16(rs_b, dst, b_vo[i], u_soff_b);
             } else {
                 const int k = u_kt * BK + cl * EPC;
                 const T* g = Z;
@@ -375,11 +396,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
             c_kin += wt ? BK : 0;
             if (has_a2 && wt && c_kin == a_split) {           // (uniform, taken once per launch)
 #pragma unroll
-                for (int i = 0; i < A_INSTR; ++i) a_cur[i] = a_p2[i];
-                cur_lda = lda2; cur_base = a_split;
+                for (int i = 0; i < A_INSTR; ++i) a_vo[i] = a_vo2[i];
+                cur_lda = lda2; cur_base = a_split; rs_a = rs_a2; cur_bias = bias2;
                 tap_table(lda2);
             }
-            c_bb += wt ? bb_wrap : bb_tap;
+            c_bbo += wt ? bb_wrap : bb_tap;
             c_boff += wt ? boff_wrap : conv_kc;
         }
     };
@@ -544,7 +565,12 @@ template <int BM, int BN, bool BKM, int STAGES, int MODE> int launch_pipe_lean(c
 }
 template <int BM, int BN, bool BKM, int STAGES> int launch_pipe(const lavt_gemm_nt_t& p, hipStream_t st) {
     const bool simple = p.conv_kc <= 0 && p.A2 == nullptr && p.K % 64 == 0;
-    const bool convfast = p.conv_kc > 0 && p.conv_kc % 64 == 0 && (p.A2 == nullptr || p.a_split % 64 == 0) && conv_taps_of(p) <= 32;
+    // (tap-walking mode: operands through 32-bit buffer offsets -- each of them below 2 GB, the halo margin included)
+    const int64_t lim = (1ll << 31) - (1ll << 24);
+    const int64_t a_rows = (int64_t)p.M + 2 * ((int64_t)(p.conv_h > 0 ? p.conv_h : 1) * p.conv_w + p.conv_w + 1);
+    const int64_t b_rows = p.b_kmajor ? (int64_t)conv_taps_of(p) * p.conv_kc : p.N;
+    const bool small = a_rows * p.lda * 2 < lim && (p.A2 == nullptr || a_rows * p.lda2 * 2 < lim) && b_rows * p.ldb * 2 + (int64_t)p.batch * p.strideB * 2 < lim;
+    const bool convfast = p.conv_kc > 0 && p.conv_kc % 64 == 0 && (p.A2 == nullptr || p.a_split % 64 == 0) && conv_taps_of(p) <= 32 && small;
     if (simple && !lavt_tuning().gemm_general) return launch_pipe_lean<BM, BN, BKM, STAGES, 1>(p, st);
     if (convfast && !lavt_tuning().gemm_general) return launch_pipe_lean<BM, BN, BKM, STAGES, 2>(p, st);
     return launch_pipe_lean<BM, BN, BKM, STAGES, 0>(p, st);
