@@ -30,6 +30,7 @@
 namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(8 * sizeof(int)))) int i32x8;
 
 // Buffer-descriptor LDS-DMA (buffer_load_dwordx4 ... offen lds).  The resource type and its builtins exist in the device pass only; the host pass, which
 // still parses the kernel body to emit its launch stub, sees placeholders.
@@ -78,6 +79,9 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
         static_for<N - 1>(f);
         f(std::integral_constant<int, N - 1>{});
     }
+}
+__device__ __forceinline__ i32x8 pipe8_pack(u32x4 lo, u32x4 hi) {          // the 32 bytes of a row an fp8 MFMA takes from a lane: chunks g and g + 4
+    return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
 }
 template <int CNT> __device__ __forceinline__ void pipe_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory"); }
 // ties registers to the wait in front of it: consumers of `f` cannot be scheduled above this (empty) statement, which stays behind the wait
@@ -154,11 +158,16 @@ __device__ __forceinline__ void pipe_colstats(const lavt_gemm_nt_t& p, const f32
     }
 }
 
-template <int BM, int BN, bool BKM, int STAGES, int MODE, int LEAN>
+// F8 (BASELINE.json configs[4]): e4m3 operands, k-contiguous.  The operand tiles are the same BYTES as the bf16 ones (rows of 128 B = 128 elements),
+// so the DMA geometry, the ring and the fragment read addresses do not change; the two ds_read_b128 a lane issues for the two bf16 k-steps of a row
+// (chunks g and g + 4) are the 32 bytes ONE v_mfma_scale_f32_16x16x128_f8f6f4 takes from it.  The MFMA groups are therefore cut over A fragments (pairs of
+// fragments x every B fragment x both k-steps) instead of over k-steps: same register budget, same counted waits (see the F8 branch of the K loop).
+template <int BM, int BN, bool BKM, int STAGES, int MODE, int LEAN, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t p) {
     constexpr bool SIMPLE = MODE == 1, CONVFAST = MODE == 2;
-    using T = bf16;
-    constexpr int WAVES = 8, BK = 64, EPC = 8;
+    using T = typename std::conditional<F8, unsigned char, bf16>::type;
+    constexpr int WAVES = 8, BK = F8 ? 128 : 64, EPC = F8 ? 16 : 8, ES = (int)sizeof(T);
+    static_assert(!(F8 && BKM), "fp8: k-contiguous operands");
     constexpr int WAVES_N = 4;
     constexpr int A_INSTR = BM / (8 * WAVES), B_INSTR = BN / (8 * WAVES);      // DMA instructions per wave per K tile (8 rows x 8 chunks each)
     constexpr int B_CH = BN / EPC;
@@ -260,16 +269,16 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
             }
             a_vmask[i] = m;
             // byte offset of the lane's chunk in either source, or out of the descriptor's range (a row that does not exist: the load then writes zeros)
-            a_vo1[i] = a_src[i] >= 0 ? (unsigned)(((int64_t)a_src[i] * p.lda + cl * EPC) * 2) : BUF_OOB;
-            a_vo2[i] = (A2 && a_src[i] >= 0) ? (unsigned)(((int64_t)a_src[i] * p.lda2 + cl * EPC) * 2) : BUF_OOB;
+            a_vo1[i] = a_src[i] >= 0 ? (unsigned)(((int64_t)a_src[i] * p.lda + cl * EPC) * ES) : BUF_OOB;
+            a_vo2[i] = (A2 && a_src[i] >= 0) ? (unsigned)(((int64_t)a_src[i] * p.lda2 + cl * EPC) * ES) : BUF_OOB;
         }
         if (p.conv_tap_split > 0) { c_tap = bz * p.conv_tap_split; c_ntap = p.conv_tap_split; }
         if (p.conv_kc_split > 0) c_kin = bz * p.conv_kc_split;          // split over channel blocks: this entry's first channel
         c_tap0 = c_tap;
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            if constexpr (!BKM) b_vo[i] = b_row[i] >= 0 ? (unsigned)(((int64_t)b_row[i] * p.ldb + cl * EPC) * 2) : BUF_OOB;
-            else b_vo[i] = b_row[i] >= 0 ? (unsigned)(((int64_t)b_row[i] * p.ldb + b_col[i]) * 2) : BUF_OOB;
+            if constexpr (!BKM) b_vo[i] = b_row[i] >= 0 ? (unsigned)(((int64_t)b_row[i] * p.ldb + cl * EPC) * ES) : BUF_OOB;
+            else b_vo[i] = b_row[i] >= 0 ? (unsigned)(((int64_t)b_row[i] * p.ldb + b_col[i]) * ES) : BUF_OOB;
         }
     }
     const bool has_a2 = p.A2 != nullptr;
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
     int cur_base = 0;
     // descriptor bases sit `bias` bytes below the tensors so that the scalar offset bias + (tap shift) + channel offset is never negative
     const int max_rows = ((cg.kd >> 1) * cg.h + (cg.kh >> 1)) * cg.w + (cg.kw >> 1);
-    const unsigned bias1 = (unsigned)((int64_t)max_rows * lda1 * 2), bias2 = (unsigned)((int64_t)max_rows * lda2 * 2);
+    const unsigned bias1 = (unsigned)((int64_t)max_rows * lda1 * ES), bias2 = (unsigned)((int64_t)max_rows * lda2 * ES);
     buf_rsrc_t rs_a = buf_make(reinterpret_cast<const char*>(A) - bias1);
     const buf_rsrc_t rs_a2 = buf_make(reinterpret_cast<const char*>(A2 ? A2 : A) - bias2);
     const buf_rsrc_t rs_b = buf_make(B);
@@ -316,21 +325,21 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
     auto tap_table = [&](int64_t ld) {
         int dz, dy, dx;
         conv_tap(cg, lane < cg.taps ? lane : 0, dz, dy, dx);
-        tap_sh = (int)((int64_t)(((dz * cg.h + dy) * cg.w + dx) * (flip ? -1 : 1)) * ld * 2);
+        tap_sh = (int)((int64_t)(((dz * cg.h + dy) * cg.w + dx) * (flip ? -1 : 1)) * ld * ES);
     };
     if constexpr (CONVFAST) tap_table(cur_lda);
     // running position in the weight operand (advanced in issue_end), in bytes from B: k-major B -- (tap, channel block) rows; k-contiguous B -- the columns
     // of (tap, channel block) inside the [Cout][taps][Cin] rows
-    unsigned c_bbo = (unsigned)(((int64_t)c_kin * p.ldb + (int64_t)c_tap0 * p.b_tap_stride) * 2);
-    const unsigned bb_tap = (unsigned)(p.b_tap_stride * 2), bb_wrap = (unsigned)(((int64_t)BK * p.ldb - (int64_t)(c_ntap - 1) * p.b_tap_stride) * 2);
+    unsigned c_bbo = (unsigned)(((int64_t)c_kin * p.ldb + (int64_t)c_tap0 * p.b_tap_stride) * ES);
+    const unsigned bb_tap = (unsigned)(p.b_tap_stride * ES), bb_wrap = (unsigned)(((int64_t)BK * p.ldb - (int64_t)(c_ntap - 1) * p.b_tap_stride) * ES);
     int c_boff = c_kin;
     const int boff_wrap = BK - (c_ntap - 1) * conv_kc;
     auto issue_begin = [&](int kt, bool past) {
         u_past = past; u_kt = kt;
         if constexpr (CONVFAST) {
-            u_soff_a = cur_bias + (unsigned)(__builtin_amdgcn_readlane(tap_sh, c_tap) + (c_kin - cur_base) * 2);
+            u_soff_a = cur_bias + (unsigned)(__builtin_amdgcn_readlane(tap_sh, c_tap) + (c_kin - cur_base) * ES);
             u_bit = past ? 0u : 1u << c_tap;                                          // (a tile beyond K: every A lane out of range, B from the start of the rows)
-            u_soff_b = past ? 0u : (BKM ? c_bbo : (unsigned)(c_boff * 2));
+            u_soff_b = past ? 0u : (BKM ? c_bbo : (unsigned)(c_boff * ES));
         }
     };
     auto issue_one = [&](auto idx_c, char* sbase) {
@@ -489,6 +498,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
     }
     wait_vmcnt<(STAGES - 1) * L>();                                // tile 0 landed
     __builtin_amdgcn_s_barrier();
+    if constexpr (!F8) {
     PIPE_LOAD_A(0, 0, 0, 0u);
     PIPE_LOAD_B(0, 0, 0u);
     for (int kt = 0; kt < ktiles; ++kt) {
@@ -528,31 +538,130 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
             PIPE_LAST_GROUP(0, 1, 1);
         }
     }
+    } else {
+        // ---- fp8 K loop: MFMA groups = (a pair of A fragments) x (every B fragment), both k-steps of the byte tile in one instruction ------------
+        // NP groups per K tile (4 for the 256x256 tile, 2 for the 128x128 one).  A pairs are double-buffered (fa8[buf][k-step][fragment of the pair]),
+        // the B fragments of a tile (fb8[k-step][fragment]) are used by every group, so the next tile's B reads are issued behind the last group and
+        // are the one LDS round trip of a K tile that is waited for in the open (at the top of the loop); the next tile's first A pair is requested
+        // right behind the barrier and lands under the last group.  At most 4 + 2 NI reads are in flight (lgkmcnt is a 4-bit counter).
+        constexpr int NP = MI / 2;
+        static_assert(NP == 2 || NP == 4, "A fragment pairs");
+        static_assert((2 * NI) % L == 0, "MFMAs of the last group spread evenly over the DMA instructions");
+        u32x4 fa8[2][2][2], fb8[2][NI];
+#define PIPE8_LOAD_A(P, dst, soff)                                                                                                   \
+    do {                                                                                                                              \
+        pipe_issue<2, (P) * 2 * 2048, 2048>(fa8[dst][0], a_rd[0] + (soff));                                                          \
+        pipe_issue<2, (P) * 2 * 2048, 2048>(fa8[dst][1], a_rd[1] + (soff));                                                          \
+    } while (0)
+#define PIPE8_LOAD_B(soff)                                                                                                            \
+    do {                                                                                                                              \
+        pipe_issue<NI, 0, 2048>(fb8[0], b_rd[0] + (soff));                                                                            \
+        pipe_issue<NI, 0, 2048>(fb8[1], b_rd[1] + (soff));                                                                            \
+    } while (0)
+#define PIPE8_TIE_A(buf) do { pipe_tie<2>(fa8[buf][0]); pipe_tie<2>(fa8[buf][1]); } while (0)
+        // MFMA m of group P (row-major over (fragment of the pair, B fragment)); (B, A) operand order as in the bf16 path: the accumulators hold C^T
+        // tiles; formats 0 = e4m3, scales 0x7F = 2^0
+        // The MFMA is issued from inline asm (unit block scales = the unscaled form; cbsz / blgp 0 = e4m3 x e4m3): as a builtin, hipcc's scheduler sank all the
+        // MFMAs of a K tile behind the DMA issue (its high-register-pressure pass drops the sched_barrier edges), with every A pair live at once.
+#define PIPE8_MFMA_ONE(P, abuf, f_, j_)                                                                                               \
+    do {                                                                                                                              \
+        const i32x8 b_ = pipe8_pack(fb8[0][j_], fb8[1][j_]), a_ = pipe8_pack(fa8[abuf][0][f_], fa8[abuf][1][f_]);                     \
+        asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+v"(acc[(P) * 2 + (f_)][j_]) : "v"(b_), "v"(a_));               \
+    } while (0)
+#define PIPE8_MFMA(P, abuf)                                                                                                           \
+    do {                                                                                                                              \
+        _Pragma("unroll") for (int f_ = 0; f_ < 2; ++f_) {                                                                            \
+            _Pragma("unroll") for (int j_ = 0; j_ < NI; ++j_) PIPE8_MFMA_ONE(P, abuf, f_, j_);                                        \
+        }                                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+    } while (0)
+        // MFMAs [C * PER, (C + 1) * PER) of the last group (row-major over (fragment of the pair, B fragment))
+#define PIPE8_MFMA_PART(P, abuf, C, PER)                                                                                              \
+    do {                                                                                                                              \
+        _Pragma("unroll") for (int m_ = (C) * (PER); m_ < ((C) + 1) * (PER); ++m_) {                                                  \
+            const int f_ = m_ / NI, j_ = m_ % NI;                                                                                     \
+            PIPE8_MFMA_ONE(P, abuf, f_, j_);                                                                                          \
+        }                                                                                                                             \
+    } while (0)
+        PIPE8_LOAD_A(0, 0, 0u);
+        PIPE8_LOAD_B(0u);
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const unsigned so = (unsigned)((kt % STAGES) * STAGE_BYTES);
+            const unsigned sn = (unsigned)(((kt + 1) % STAGES) * STAGE_BYTES);
+            // group 0: pair 0 (requested behind the previous tile's barrier) x B (requested behind the previous tile's last group)
+            pipe_wait<0>();
+            PIPE8_TIE_A(0); pipe_tie<NI>(fb8[0]); pipe_tie<NI>(fb8[1]);
+            PIPE8_LOAD_A(1, 1, so);
+            PIPE8_MFMA(0, 0);
+            if constexpr (NP == 4) {          // 256x256 tile: pairs 1 and 2, each with the next pair requested into the other buffer
+                PIPE8_LOAD_A(2, 0, so);
+                pipe_wait<4>();
+                PIPE8_TIE_A(1);
+                PIPE8_MFMA(1, 1);
+                PIPE8_LOAD_A(3, 1, so);
+                pipe_wait<4>();
+                PIPE8_TIE_A(0);
+                PIPE8_MFMA(2, 0);
+            }
+            // last group: behind the barrier the stage is refilled (tile kt + STAGES), one DMA instruction per (2 NI / L) MFMAs
+            pipe_wait<0>();
+            PIPE8_TIE_A(1);
+            wait_vmcnt<(STAGES - 2) * L>();
+            __builtin_amdgcn_s_barrier();
+            PIPE8_LOAD_A(0, 0, sn);
+            issue_begin(kt + STAGES, kt + STAGES >= ktiles);
+            static_for<L>([&](auto c_) {
+                PIPE8_MFMA_PART(NP - 1, 1, decltype(c_)::value, (2 * NI) / L);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_one(c_, smem + (kt % STAGES) * STAGE_BYTES);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            issue_end();
+            PIPE8_LOAD_B(sn);
+        }
+        pipe_wait<0>();                                            // (the reads requested for a tile beyond K)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");         // the last MFMAs retire before the epilogue reads the accumulators (asm MFMAs are invisible to the hazard recogniser)
+#undef PIPE8_MFMA_PART
+#undef PIPE8_MFMA
+#undef PIPE8_MFMA_ONE
+#undef PIPE8_TIE_A
+#undef PIPE8_LOAD_B
+#undef PIPE8_LOAD_A
+    }
     wait_vmcnt<0>();                                               // the tiles issued beyond K
 #undef PIPE_LAST_GROUP
 #undef PIPE_MFMA_PART
 #undef PIPE_LOAD_A
 #undef PIPE_LOAD_B
 #undef PIPE_MFMA
-    if (p.colstats) pipe_colstats<MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, tile_m * 2 + wm);
-    nt_epilogue<T, MI, NI, false, false, LEAN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
+    if constexpr (F8) {
+        // dequantisation: the tensors were quantised as q = e4m3(x * 448 / amax); amax <= 0 stands for "scale 1" (uncalibrated first step)
+        lavt_gemm_nt_t q = p;
+        const float da = p.deq_a ? *p.deq_a : 0.f, db = p.deq_b ? *p.deq_b : 0.f;
+        q.alpha = p.alpha * (da > 0.f ? da * (1.f / 448.f) : 1.f) * (db > 0.f ? db * (1.f / 448.f) : 1.f);
+        if (p.colstats) pipe_colstats<MI, NI>(q, acc, m0 + wm * WM, n0 + wn * WN, lane, tile_m * 2 + wm);
+        nt_epilogue<bf16, MI, NI, false, false, LEAN>(q, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
+    } else {
+        if (p.colstats) pipe_colstats<MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, tile_m * 2 + wm);
+        nt_epilogue<T, MI, NI, false, false, LEAN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);
+    }
 }
 
 static inline int conv_taps_of(const lavt_gemm_nt_t& p) {
     return (p.conv_kd > 0 ? p.conv_kd : 1) * (p.conv_kh > 0 ? p.conv_kh : 3) * (p.conv_kw > 0 ? p.conv_kw : 3);
 }
-template <int BM, int BN, bool BKM, int STAGES, int MODE, int LEAN> int launch_pipe_(const lavt_gemm_nt_t& p, hipStream_t st) {
+template <int BM, int BN, bool BKM, int STAGES, int MODE, int LEAN, bool F8 = false> int launch_pipe_(const lavt_gemm_nt_t& p, hipStream_t st) {
     constexpr size_t lds = STAGES * (size_t)(BM * 128 + BN * 128);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pipe_kernel<BM, BN, BKM, STAGES, MODE, LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pipe_kernel<BM, BN, BKM, STAGES, MODE, LEAN, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             lavt_set_error("lavt_gemm_nt(pipe): cannot reserve %zu bytes of LDS", lds);
             return LAVT_ERR_LAUNCH;
         }
         attr_set = true;
     }
     dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch);
-    hipLaunchKernelGGL((gemm_nt_pipe_kernel<BM, BN, BKM, STAGES, MODE, LEAN>), grid, dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_nt_pipe_kernel<BM, BN, BKM, STAGES, MODE, LEAN, F8>), grid, dim3(512), lds, st, p);
     LAVT_CHECK_LAUNCH("lavt_gemm_nt(pipe)");
     return LAVT_OK;
 }
@@ -562,6 +671,25 @@ template <int BM, int BN, bool BKM, int STAGES, int MODE> int launch_pipe_lean(c
         return launch_pipe_<BM, BN, BKM, STAGES, MODE, 1>(p, st);
     }
     return launch_pipe_<BM, BN, BKM, STAGES, MODE, 0>(p, st);
+}
+// fp8 operands: the plain and the tap-walking issue only (lavt_gemm_nt_pipe_tile sends everything else to gemm_v2.hip), lean epilogues as above
+template <int BM, int BN, int STAGES, int MODE> int launch_pipe_f8_lean(const lavt_gemm_nt_t& p, hipStream_t st) {
+    if (p.act == 0 && !p.mul && !p.Cpre && !p.C2) {
+        if (!p.bias && !p.R && !p.row_scale && !p.c_rowmap) return launch_pipe_<BM, BN, false, STAGES, MODE, 2, true>(p, st);
+        return launch_pipe_<BM, BN, false, STAGES, MODE, 1, true>(p, st);
+    }
+    return launch_pipe_<BM, BN, false, STAGES, MODE, 0, true>(p, st);
+}
+static inline bool pipe_f8_simple(const lavt_gemm_nt_t& p) { return p.conv_kc <= 0 && p.A2 == nullptr && p.K % 128 == 0; }
+static inline bool pipe_f8_convfast(const lavt_gemm_nt_t& p) {
+    const int64_t lim = (1ll << 31) - (1ll << 24);
+    const int64_t a_rows = (int64_t)p.M + 2 * ((int64_t)(p.conv_h > 0 ? p.conv_h : 1) * p.conv_w + p.conv_w + 1);
+    const bool small = a_rows * p.lda < lim && (p.A2 == nullptr || a_rows * p.lda2 < lim) && (int64_t)p.N * p.ldb + (int64_t)p.batch * p.strideB < lim;
+    return p.conv_kc > 0 && p.conv_kc % 128 == 0 && (p.A2 == nullptr || p.a_split % 128 == 0) && conv_taps_of(p) <= 32 && small;
+}
+template <int BM, int BN, int STAGES> int launch_pipe_f8(const lavt_gemm_nt_t& p, hipStream_t st) {
+    if (pipe_f8_simple(p)) return launch_pipe_f8_lean<BM, BN, STAGES, 1>(p, st);
+    return launch_pipe_f8_lean<BM, BN, STAGES, 2>(p, st);
 }
 template <int BM, int BN, bool BKM, int STAGES> int launch_pipe(const lavt_gemm_nt_t& p, hipStream_t st) {
     const bool simple = p.conv_kc <= 0 && p.A2 == nullptr && p.K % 64 == 0;
@@ -583,10 +711,14 @@ template <int BM, int BN, bool BKM, int STAGES> int launch_pipe(const lavt_gemm_
 // whatever the tile, so the 128x128 tile is fill-bound at half the rate) only when its tiles fill the 256 CUs well (whole rounds at >= 80 %); the 128x128
 // tile for long reductions (K >= 1024; LAVT_GEMM_PIPE=3: every 128x128 problem) where gemm_v2.hip would take its 8-wave 128x128 form.
 int lavt_gemm_nt_pipe_tile(const lavt_gemm_nt_t& p, int* stages_out) {
-    if (p.dtype != LAVT_BF16 || p.zeros == nullptr) return 0;
+    if ((p.dtype != LAVT_BF16 && p.dtype != LAVT_FP8) || p.zeros == nullptr) return 0;
     const lavt_tuning_t& tun = lavt_tuning();
     const int pipe = tun.gemm_pipe;                 // 0: gemm_v2 K loops only; 1: the 256x256 tile; 2: + 128x128 for K >= 1024; 3: + every 128x128 problem
     if (tun.gemm_v2_off || pipe < 1) return 0;
+    if (p.dtype == LAVT_FP8) {          // e4m3 operands: k-contiguous, 128-element K tiles, plain or tap-walking issue (anything else: gemm_v2.hip's fp8 form)
+        if (tun.gemm_general || tun.fp8_pipe_off || p.b_kmajor || p.c_f32 || p.conv_kc_split > 0 || p.conv_tap_split > 0 || p.lda % 16 || p.ldb % 16 || (p.A2 && p.lda2 % 16)) return 0;
+        if (!pipe_f8_simple(p) && !pipe_f8_convfast(p)) return 0;
+    }
     if (p.lda % 8 || p.ldb % 8 || (p.A2 && p.lda2 % 8)) return 0;
     if (p.ln_wsum || p.dact_pre) return 0;
     if (p.conv_kc_split > 0) {          // the channel-split reduction exists in this kernel's tap-walking mode only
@@ -614,6 +746,10 @@ int lavt_gemm_nt_pipe_tile(const lavt_gemm_nt_t& p, int* stages_out) {
 
 // tile: 256 = the 256x256 tile (2-stage ring, 128 KB of LDS), 128 = the 128x128 tile with `stages` (2 or 4) stages
 int lavt_gemm_nt_pipe(const lavt_gemm_nt_t& p, int tile, int stages, hipStream_t st) {
+    if (p.dtype == LAVT_FP8) {
+        if (tile == 256) return launch_pipe_f8<256, 256, 2>(p, st);
+        return stages == 2 ? launch_pipe_f8<128, 128, 2>(p, st) : launch_pipe_f8<128, 128, 4>(p, st);
+    }
     if (tile == 256) return p.b_kmajor ? launch_pipe<256, 256, true, 2>(p, st) : launch_pipe<256, 256, false, 2>(p, st);
     if (stages == 2) return p.b_kmajor ? launch_pipe<128, 128, true, 2>(p, st) : launch_pipe<128, 128, false, 2>(p, st);
     return p.b_kmajor ? launch_pipe<128, 128, true, 4>(p, st) : launch_pipe<128, 128, false, 4>(p, st);

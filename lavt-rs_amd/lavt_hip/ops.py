@@ -2414,8 +2414,11 @@ class _ConvTaps(torch.autograd.Function):
             Wq, w_amax = weights.get_fp8(weight, "conv3")
             x1q, a_ptr = fp8.quantize(x1, id(weight))
             x2q = fp8.quantize(x2, id(weight))[0] if x2 is not None else None
-            gemm_nt(torch.uint8, M, Cout, taps * Cin, x1q, C1, Wq, taps * Cin, y, Cout, A2=x2q, lda2=C2, a_split=C1,
-                    conv=(H, W, Cin, 0, D, kd, kh, kw), bias=_f32(bias), act=act, Cpre=pre, ldcpre=Cout, deq=(a_ptr, w_amax.data_ptr()))
+            st = gemm_nt(torch.uint8, M, Cout, taps * Cin, x1q, C1, Wq, taps * Cin, y, Cout, A2=x2q, lda2=C2, a_split=C1,
+                         conv=(H, W, Cin, 0, D, kd, kh, kw), bias=_f32(bias), act=act, Cpre=pre, ldcpre=Cout, deq=(a_ptr, w_amax.data_ptr()),
+                         want_colstats=_CONV_STATS and stats and bias is None and act == K.ACT_NONE)
+            if st is not None:          # (the pipelined e4m3 kernel has the statistics epilogue of the bf16 one)
+                conv_stats.put(y, st)
         elif _conv_split(dtype, M, Cout, Cin, C1, C2, taps, bias, act)[0]:
             # few pixels, long reduction (decoder level 4: 1 800 rows x K = 13 824 = 60-232 tiles walking 72-216 K tiles each): the reduction is cut
             # at tap boundaries over the batch index into fp32 partial outputs, a second small kernel adds them
