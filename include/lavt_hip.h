@@ -493,7 +493,13 @@ int lavt_upsample_dice_bwd(int dtype, const void* x, const int64_t* target, cons
  *   [Cout][Cin][taps] convolution weight as [Cout][taps][Cin] (the implicit-GEMM layout) on the way. */
 int lavt_fp8_quantize(int src_dtype, const void* src, void* dst, int64_t n, const float* amax_prev, float* amax_cur, void* stream);
 int lavt_fp8_advance(float* amax_prev, float* amax_cur, int n, void* stream);
+/* lavt_fp8_quantize_current: CURRENT scaling for tensors whose range moves from step to step (the dY operand of the e4m3 data gradients): *amax = max |src|
+ *   of THIS tensor (computed here, one extra read pass), dst[i] = e4m3(src[i] * 448 / *amax); the GEMM reads *amax through deq_a.  No calibration step. */
+int lavt_fp8_quantize_current(int src_dtype, const void* src, void* dst, int64_t n, float* amax, void* stream);
 int lavt_fp8_quantize_weight(const float* src, void* dst, float* amax, int cout, int cin, int taps, void* stream);
+/* lavt_fp8_quantize_weight_t: the same scaling, packed TRANSPOSED as [Cin][taps][Cout] -- the k-contiguous weight operand of the e4m3 data gradient
+ *   (reference lib/mask_predictor.py:60-97, backward of the 3x3 convolutions: dX[m][ci] = sum over (tap, co) of dY[m - tap][co] * W[co][ci][tap]). */
+int lavt_fp8_quantize_weight_t(const float* src, void* dst, float* amax, int cout, int cin, int taps, void* stream);
 /* classifier head conv1_1: 1x1 conv hidden->2 with bias (lib/mask_predictor.py:50,99) */
 int lavt_cls_head_fwd(int dtype, const void* x, const float* w, const float* b, void* y, int64_t rows, int C, void* stream);
 int lavt_cls_head_bwd(int dtype, const void* x, const void* dy, const float* w, void* dx, float* dw, float* db,

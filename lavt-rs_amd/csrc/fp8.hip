@@ -60,6 +60,32 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__
     }
 }
 
+// |max| of a bf16 / fp32 tensor, 16 elements per thread per iteration (the pass in front of a CURRENT-scaling quantisation: lavt_fp8_quantize_current)
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_amax16_kernel(const T* __restrict__ src, int64_t n16, float* __restrict__ amax) {
+    float m = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+        float f[16];
+        if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) chunk_to_f<float>(*reinterpret_cast<const uint4*>(src + i * 16 + q * 4), f + q * 4);
+        } else {
+            chunk_to_f<T>(*reinterpret_cast<const uint4*>(src + i * 16), f);
+            chunk_to_f<T>(*reinterpret_cast<const uint4*>(src + i * 16 + 8), f + 8);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(f[e]));
+    }
+    __shared__ float red[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > __builtin_nontemporal_load(amax)) atomic_max_nonneg(amax, m);
+    }
+}
+
 __global__ void fp8_advance_kernel(float* prev, float* cur, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -94,6 +120,20 @@ __global__ __launch_bounds__(256) void fp8_weight_kernel(const float* __restrict
     }
 }
 
+// transposed pack for the data gradient: dst[c][t][o] = e4m3(src[o][c][t] * 448 / amax): thread per 4 consecutive o of one (c, t)
+__global__ __launch_bounds__(256) void fp8_weight_t_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, const float* __restrict__ amax,
+                                                           int cout, int cin, int taps) {
+    const float a = *amax;
+    const float s = a > 0.f ? E4M3_MAX / a : 1.f;
+    const int64_t n4 = (int64_t)cin * taps * (cout / 4), os = (int64_t)cin * taps;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int o4 = (int)(i % (cout / 4)), t = (int)((i / (cout / 4)) % taps), c = (int)(i / (cout / 4) / taps);
+        const float* sp = src + ((int64_t)o4 * 4 * cin + c) * taps + t;
+        *reinterpret_cast<unsigned*>(dst + ((int64_t)c * taps + t) * cout + o4 * 4) =
+            pack4_e4m3(clamp448(sp[0] * s), clamp448(sp[os] * s), clamp448(sp[2 * os] * s), clamp448(sp[3 * os] * s));
+    }
+}
+
 }  // namespace
 
 static inline int fp8_grid(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b)); }
@@ -121,5 +161,31 @@ extern "C" int lavt_fp8_quantize_weight(const float* src, void* dst, float* amax
     hipLaunchKernelGGL(fp8_amax_kernel, dim3(fp8_grid(n)), dim3(256), 0, st, src, n, amax);
     hipLaunchKernelGGL(fp8_weight_kernel, dim3(fp8_grid(n / 4)), dim3(256), 0, st, src, (unsigned char*)dst, amax, cout, cin, taps);
     LAVT_CHECK_LAUNCH("lavt_fp8_quantize_weight");
+    return LAVT_OK;
+}
+extern "C" int lavt_fp8_quantize_weight_t(const float* src, void* dst, float* amax, int cout, int cin, int taps, void* stream) {
+    LAVT_CHECK_ARG(src && dst && amax && cout > 0 && cout % 4 == 0 && cin > 0 && taps > 0, "lavt_fp8_quantize_weight_t: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)cout * cin * taps;
+    if (hipMemsetAsync(amax, 0, sizeof(float), st) != hipSuccess) { lavt_set_error("lavt_fp8_quantize_weight_t: memset failed"); return LAVT_ERR_LAUNCH; }
+    hipLaunchKernelGGL(fp8_amax_kernel, dim3(fp8_grid(n)), dim3(256), 0, st, src, n, amax);
+    hipLaunchKernelGGL(fp8_weight_t_kernel, dim3(fp8_grid(n / 4)), dim3(256), 0, st, src, (unsigned char*)dst, amax, cout, cin, taps);
+    LAVT_CHECK_LAUNCH("lavt_fp8_quantize_weight_t");
+    return LAVT_OK;
+}
+
+extern "C" int lavt_fp8_quantize_current(int src_dtype, const void* src, void* dst, int64_t n, float* amax, void* stream) {
+    LAVT_CHECK_ARG(src && dst && amax && n > 0 && n % 16 == 0, "lavt_fp8_quantize_current: bad arguments (n=%ld must be a multiple of 16)", (long)n);
+    LAVT_CHECK_ARG(src_dtype == LAVT_F32 || src_dtype == LAVT_BF16, "lavt_fp8_quantize_current: source dtype %d", src_dtype);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(amax, 0, sizeof(float), st) != hipSuccess) { lavt_set_error("lavt_fp8_quantize_current: memset failed"); return LAVT_ERR_LAUNCH; }
+    if (src_dtype == LAVT_F32) {
+        hipLaunchKernelGGL(fp8_amax16_kernel<float>, dim3(fp8_grid(n / 16)), dim3(256), 0, st, (const float*)src, n / 16, amax);
+        hipLaunchKernelGGL(fp8_quantize_kernel<float>, dim3(fp8_grid(n / 16)), dim3(256), 0, st, (const float*)src, (unsigned char*)dst, n / 16, (const float*)amax, (float*)nullptr);
+    } else {
+        hipLaunchKernelGGL(fp8_amax16_kernel<bf16>, dim3(fp8_grid(n / 16)), dim3(256), 0, st, (const bf16*)src, n / 16, amax);
+        hipLaunchKernelGGL(fp8_quantize_kernel<bf16>, dim3(fp8_grid(n / 16)), dim3(256), 0, st, (const bf16*)src, (unsigned char*)dst, n / 16, (const float*)amax, (float*)nullptr);
+    }
+    LAVT_CHECK_LAUNCH("lavt_fp8_quantize_current");
     return LAVT_OK;
 }

@@ -219,6 +219,8 @@ _PROTOTYPES = {
     "lavt_fp8_quantize": [i32, vp, vp, i64, vp, vp, vp],
     "lavt_fp8_advance": [vp, vp, i32, vp],
     "lavt_fp8_quantize_weight": [vp, vp, vp, i32, i32, i32, vp],
+    "lavt_fp8_quantize_weight_t": [vp, vp, vp, i32, i32, i32, vp],
+    "lavt_fp8_quantize_current": [i32, vp, vp, i64, vp, vp],
     "lavt_cls_head_fwd": [i32, vp, vp, vp, vp, i64, i32, vp],
     "lavt_cls_head_bwd": [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp],
     "lavt_im2col4": [i32, vp, vp, i32, i32, i32, vp],

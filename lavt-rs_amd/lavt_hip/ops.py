@@ -71,7 +71,7 @@ class _WeightCache:
 
     def get_fp8(self, p: torch.Tensor, kind: str = "lin"):
         """-> (e4m3 copy as a uint8 tensor, device float [1] holding the |max| it was quantised against).  'lin' = [N, K] rows as stored,
-        'conv3' = [Cout][taps][Cin].  Current scaling: |max| is recomputed at every refresh."""
+        'conv3' = [Cout][taps][Cin], 'conv3t' = [Cin][taps][Cout] (the data gradient's operand).  Current scaling: |max| is recomputed at every refresh."""
         key = (id(p), "fp8", kind)
         ent = self.store.get(key)
         if ent is not None and ent[2]() is not p:
@@ -81,10 +81,14 @@ class _WeightCache:
             return ent[1]
         src = p.detach()
         cout = src.shape[0]
-        cin = src.shape[1] if kind == "conv3" else src.numel() // cout
+        cin = src.shape[1] if kind in ("conv3", "conv3t") else src.numel() // cout
         taps = src.numel() // (cout * cin)
-        q, amax = ent[1] if ent is not None else (torch.empty(cout, taps * cin, dtype=torch.uint8, device=src.device), torch.zeros(1, dtype=torch.float32, device=src.device))
-        K.check(K.lib.lavt_fp8_quantize_weight(K.ptr(src), K.ptr(q), K.ptr(amax), cout, cin, taps, K.stream()))
+        shape = (cin, taps * cout) if kind == "conv3t" else (cout, taps * cin)
+        q, amax = ent[1] if ent is not None else (torch.empty(shape, dtype=torch.uint8, device=src.device), torch.zeros(1, dtype=torch.float32, device=src.device))
+        if kind == "conv3t":
+            K.check(K.lib.lavt_fp8_quantize_weight_t(K.ptr(src), K.ptr(q), K.ptr(amax), cout, cin, taps, K.stream()))
+        else:
+            K.check(K.lib.lavt_fp8_quantize_weight(K.ptr(src), K.ptr(q), K.ptr(amax), cout, cin, taps, K.stream()))
         self.store[key] = (stamp, (q, amax), weakref.ref(p))
         return q, amax
 
@@ -243,6 +247,16 @@ class _Fp8State:
         K.check(K.lib.lavt_fp8_quantize(K.dt(x.dtype), K.ptr(x), K.ptr(q), x.numel(), self.prev.data_ptr() + 4 * i, self.cur.data_ptr() + 4 * i, K.stream()))
         return q, self.prev.data_ptr() + 4 * i
 
+    def quantize_current(self, x, key):
+        """the same with CURRENT scaling (|max| of x itself, one extra read pass; lavt_fp8_quantize_current): for gradients, whose range moves from step to
+        step and which an uncalibrated (scale 1) first step would flush to zero.  The |max| lives in the site's `prev` slot (advance() leaves it alone:
+        the site never writes `cur`)."""
+        i = self.slot(key, x.device)
+        x = x.contiguous()
+        q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        K.check(K.lib.lavt_fp8_quantize_current(K.dt(x.dtype), K.ptr(x), K.ptr(q), x.numel(), self.prev.data_ptr() + 4 * i, K.stream()))
+        return q, self.prev.data_ptr() + 4 * i
+
 
 fp8 = _Fp8State()
 # Linear layers take the fp8 path from this many GEMM rows up; by default NONE does (the decoder's 3x3 convolutions, 54 % of the FLOPs, are the
@@ -251,6 +265,8 @@ fp8 = _Fp8State()
 # decisive pixels 0.753 and 19.31 ms/step: per-tensor e4m3 on the early backbone features costs accuracy and, at one quantisation launch per
 # GEMM, time.  LAVT_FP8_LINEAR_MIN_ROWS=<rows> enables it for experiments.
 _FP8_LINEAR_MIN_ROWS = int(os.environ.get("LAVT_FP8_LINEAR_MIN_ROWS", str(1 << 30)))
+# data gradients of the decoder's convolutions in e4m3 as well (dY quantised with current scaling against its own |max|); 0 = bf16 data gradients
+_FP8_DGRAD = os.environ.get("LAVT_FP8_DGRAD", "1") != "0"
 
 
 class _GradSinks:
@@ -2459,7 +2475,15 @@ class _ConvTaps(torch.autograd.Function):
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             dx1 = torch.empty_like(x1)
             dx2 = torch.empty_like(x2) if x2 is not None else None
-            if x2 is not None and C1 % 256 == 0 and C2 % 64 == 0 and dtype == torch.bfloat16 and os.environ.get("LAVT_DGRAD_SPLIT", "1") != "0":
+            if dtype == torch.bfloat16 and fp8_enabled() and _FP8_DGRAD and Cout % 16 == 0 and C1 % 4 == 0 and C2 % 4 == 0:
+                # configs[4]: e4m3 dY (current scaling: its own |max|, computed in front of the quantiser) x the transposed e4m3 weight copy [Cin][taps][Cout] on the fp8 MFMA; a concat
+                # convolution runs as one launch per source (row blocks of the transposed weight), like the bf16 split below
+                WqT, w_amax = weights.get_fp8(weight, "conv3t")
+                dyq, a_ptr = fp8.quantize_current(dy, (id(weight), "dy"))
+                for dxo, Cn, roff in ((dx1, C1, 0),) + (((dx2, C2, C1),) if x2 is not None else ()):
+                    gemm_nt(torch.uint8, M, Cn, taps * Cout, dyq, Cout, WqT, taps * Cout, dxo, Cn, conv=(H, W, Cout, 1, D, kd, kh, kw),
+                            b_off=roff * taps * Cout, deq=(a_ptr, w_amax.data_ptr()))
+            elif x2 is not None and C1 % 256 == 0 and C2 % 64 == 0 and dtype == torch.bfloat16 and os.environ.get("LAVT_DGRAD_SPLIT", "1") != "0":
                 # concat convolution (conv1_2: 512 + 128 input channels): N = 640 is not a multiple of the 256-wide tile, so the whole data gradient
                 # fell back to 128x128 tiles (239 us at 2x120x120).  As two launches over column blocks of the packed weight the 512-channel part
                 # runs on the 256x256 tile and the skip part on its own.

@@ -36,3 +36,10 @@ def linear_fp8(x, w, b, amax_x, amax_w):
 
 def conv3x3_fp8(x_nchw, w, amax_x, amax_w):
     return F.conv2d(dequantize(x_nchw, amax_x), dequantize(w, amax_w), padding=1)
+
+
+def conv3x3_fp8_dgrad(dy_nchw, w, amax_dy, amax_w):
+    """data gradient of the 3x3 convolution on quantise-dequantised dY and W (the transposed convolution PyTorch's autograd runs for
+    F.conv2d(padding=1); reference lib/mask_predictor.py:60-97 backward)"""
+    return F.conv_transpose2d(dequantize(dy_nchw, amax_dy), dequantize(w, amax_w), padding=1)
+

@@ -1146,6 +1146,48 @@ def test_fp8_conv3x3_matches_quantised_oracle(cat):
     assert rel < 0.06, rel                                               # e4m3 has 3 mantissa bits: ~3-4 % rms on a 1000-term contraction
 
 
+@pytest.mark.parametrize("cat", [False, True])
+@pytest.mark.parametrize("shape", [(2, 20, 24, 128, 256), (2, 48, 48, 256, 512)])
+def test_fp8_conv3x3_data_gradient_matches_quantised_oracle(cat, shape):
+    """e4m3 data gradient of the decoder convolutions (dY quantised with current scaling against its own |max|, weights as the transposed
+    [Cin][taps][Cout] e4m3 copy; the larger shape takes the software-pipelined kernel): against the fp32 transposed convolution of the
+    quantise-dequantised tensors; the weight gradient stays bf16 and must equal the bf16 path's"""
+    import lavt_hip
+    from lavt_hip import ops
+    from oracle import fp8_oracle as F8
+    B, H, W, C1, Cout = shape
+    C2 = 128 if cat else 0
+    x1 = rnd(B * H * W, C1, seed=1).to(torch.bfloat16)
+    x2 = (rnd(B * H * W, C2, seed=2) * 2.0).to(torch.bfloat16) if cat else None
+    w = rnd(Cout, C1 + C2, 3, 3, seed=5) * (9 * (C1 + C2)) ** -0.5
+    dy = (rnd(B * H * W, Cout, seed=7) * 1e-3).to(torch.bfloat16)          # gradient-sized values: nothing would survive a scale-1 quantisation
+    dy[3, 5] = 0.05                                                        # one outlier sets the scale: the bulk sits ~50x below |max|
+    ops.fp8.__init__()
+    grads = {}
+    for mode in ("fp8", "bf16"):
+        wd = torch.nn.Parameter(w.clone().to(dev()))
+        with lavt_hip.use_dtype(mode):
+            for it in range(2):                                            # second pass: calibrated scales
+                ops.fp8.advance()
+                a1 = x1.to(dev()).requires_grad_(True)
+                a2 = x2.to(dev()).requires_grad_(True) if cat else None
+                wd.grad = None
+                y = ops.conv3x3(a1, a2, wd, B, H, W)
+                y.backward(dy.to(dev()))
+        torch.cuda.synchronize()
+        grads[mode] = (torch.cat([a1.grad, a2.grad], 1) if cat else a1.grad).float().cpu(), wd.grad.float().cpu()
+    amax_dy, amax_w = float(dy.float().abs().max()), float(w.abs().max())
+    ref = F8.conv3x3_fp8_dgrad(dy.float().view(B, H, W, Cout).permute(0, 3, 1, 2), w, amax_dy, amax_w).permute(0, 2, 3, 1).reshape(B * H * W, -1)
+    dx, dw = grads["fp8"]
+    err = float((dx - ref).abs().max())
+    assert err <= 1e-2 * float(ref.abs().max()), err / float(ref.abs().max())     # bf16 rounding of the output
+    exact = F.conv_transpose2d(dy.float().view(B, H, W, Cout).permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1).reshape(B * H * W, -1)
+    rel = float((dx - exact).norm() / exact.norm())
+    assert rel < 0.08, rel
+    assert float((grads["bf16"][0] - exact).norm() / exact.norm()) < 0.01
+    assert float((dw - grads["bf16"][1]).abs().max()) <= 1e-6 * float(dw.abs().max()) + 1e-12      # weight gradient: the same bf16 kernel in both modes
+
+
 def test_fp8_linear_matches_quantised_oracle(monkeypatch):
     """the Linear form of the fp8 contraction (off by default: ops._FP8_LINEAR_MIN_ROWS) against the quantised oracle"""
     import lavt_hip
