@@ -265,6 +265,15 @@ fp8 = _Fp8State()
 # decisive pixels 0.753 and 19.31 ms/step: per-tensor e4m3 on the early backbone features costs accuracy and, at one quantisation launch per
 # GEMM, time.  LAVT_FP8_LINEAR_MIN_ROWS=<rows> enables it for experiments.
 _FP8_LINEAR_MIN_ROWS = int(os.environ.get("LAVT_FP8_LINEAR_MIN_ROWS", str(1 << 30)))
+# e4m3 convolutions only where the problem fills the chip with 128x128 tiles (the pipelined fp8 kernel's smallest): below that -- the 30x30 maps of decoder
+# level 4 -- the fp8 launch falls to gemm_v2's 64x64 K loop (55 us at 4x30x30 against 44 us for the bf16 pipelined kernel) and buys nothing
+_FP8_CONV_MIN_TILES = int(os.environ.get("LAVT_FP8_CONV_MIN_TILES", "200"))
+
+
+def _fp8_conv_fills(M, N):
+    return -(-M // 128) * -(-N // 128) >= _FP8_CONV_MIN_TILES
+
+
 # data gradients of the decoder's convolutions in e4m3 as well (dY quantised with current scaling against its own |max|); 0 = bf16 data gradients
 _FP8_DGRAD = os.environ.get("LAVT_FP8_DGRAD", "1") != "0"
 
@@ -2424,7 +2433,7 @@ class _ConvTaps(torch.autograd.Function):
         M = B * D * H * W
         y = torch.empty(M, Cout, dtype=dtype, device=x1.device)
         pre = torch.empty_like(y) if act != K.ACT_NONE else None
-        if dtype == torch.bfloat16 and fp8_enabled() and C1 % 16 == 0 and C2 % 16 == 0:
+        if dtype == torch.bfloat16 and fp8_enabled() and C1 % 16 == 0 and C2 % 16 == 0 and _fp8_conv_fills(M, Cout):
             # configs[4]: e4m3 activations (both concat sources against ONE scale: they feed one contraction) x e4m3 weights on the fp8 MFMA;
             # the bf16 tensors stay saved for the (bf16) backward
             Wq, w_amax = weights.get_fp8(weight, "conv3")
@@ -2475,7 +2484,7 @@ class _ConvTaps(torch.autograd.Function):
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             dx1 = torch.empty_like(x1)
             dx2 = torch.empty_like(x2) if x2 is not None else None
-            if dtype == torch.bfloat16 and fp8_enabled() and _FP8_DGRAD and Cout % 16 == 0 and C1 % 4 == 0 and C2 % 4 == 0:
+            if dtype == torch.bfloat16 and fp8_enabled() and _FP8_DGRAD and Cout % 16 == 0 and C1 % 4 == 0 and C2 % 4 == 0 and _fp8_conv_fills(M, C1):
                 # configs[4]: e4m3 dY (current scaling: its own |max|, computed in front of the quantiser) x the transposed e4m3 weight copy [Cin][taps][Cout] on the fp8 MFMA; a concat
                 # convolution runs as one launch per source (row blocks of the transposed weight), like the bf16 split below
                 WqT, w_amax = weights.get_fp8(weight, "conv3t")

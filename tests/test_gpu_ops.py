@@ -1117,13 +1117,14 @@ def test_fp8_quantizer_bit_exact_and_delayed_scaling():
 
 
 @pytest.mark.parametrize("cat", [False, True])
-def test_fp8_conv3x3_matches_quantised_oracle(cat):
+def test_fp8_conv3x3_matches_quantised_oracle(cat, monkeypatch):
     """decoder 3x3 convolution on e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales): both concat sources against one scale,
     weights with current scaling; against the fp32 convolution of the quantise-dequantised tensors"""
     import lavt_hip
     from lavt_hip import ops
     from oracle import fp8_oracle as F8
     B, H, W, C1, C2, Cout = 2, 20, 24, 128, (128 if cat else 0), 256
+    monkeypatch.setattr(ops, "_FP8_CONV_MIN_TILES", 0)                 # (the product keeps maps this small in bf16)
     x1 = (rnd(B * H * W, C1, seed=1)).to(torch.bfloat16)
     x2 = (rnd(B * H * W, C2, seed=2) * 2.0).to(torch.bfloat16) if cat else None
     w = rnd(Cout, C1 + C2, 3, 3, seed=5) * (9 * (C1 + C2)) ** -0.5
@@ -1148,7 +1149,7 @@ def test_fp8_conv3x3_matches_quantised_oracle(cat):
 
 @pytest.mark.parametrize("cat", [False, True])
 @pytest.mark.parametrize("shape", [(2, 20, 24, 128, 256), (2, 48, 48, 256, 512)])
-def test_fp8_conv3x3_data_gradient_matches_quantised_oracle(cat, shape):
+def test_fp8_conv3x3_data_gradient_matches_quantised_oracle(cat, shape, monkeypatch):
     """e4m3 data gradient of the decoder convolutions (dY quantised with current scaling against its own |max|, weights as the transposed
     [Cin][taps][Cout] e4m3 copy; the larger shape takes the software-pipelined kernel): against the fp32 transposed convolution of the
     quantise-dequantised tensors; the weight gradient stays bf16 and must equal the bf16 path's"""
@@ -1157,6 +1158,7 @@ def test_fp8_conv3x3_data_gradient_matches_quantised_oracle(cat, shape):
     from oracle import fp8_oracle as F8
     B, H, W, C1, Cout = shape
     C2 = 128 if cat else 0
+    monkeypatch.setattr(ops, "_FP8_CONV_MIN_TILES", 0)                 # (the product keeps maps this small in bf16)
     x1 = rnd(B * H * W, C1, seed=1).to(torch.bfloat16)
     x2 = (rnd(B * H * W, C2, seed=2) * 2.0).to(torch.bfloat16) if cat else None
     w = rnd(Cout, C1 + C2, 3, 3, seed=5) * (9 * (C1 + C2)) ** -0.5

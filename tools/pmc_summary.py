@@ -21,7 +21,7 @@ def derive(c, us):
             d["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), 4)
         if "SQ_LDS_IDX_ACTIVE" in c:
             d["lds_array_busy_frac"] = round(c["SQ_LDS_IDX_ACTIVE"] / (256 * cyc), 4)
-    if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in c:
+    if c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0) > 0:          # (zero for the fp8 kernels: their MFMAs count in another class)
         d["mfma_flops"] = c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512
         mf = d["mfma_flops"] / 16384.0
         if "SQ_INSTS_VALU" in c:
