@@ -88,14 +88,20 @@ def measure_conv_kernel(device, iters=20):
     B, H, W, Cin, Cout = 2, 120, 120, 512, 512
     x = torch.randn(B * H * W, Cin, device=device).to(torch.bfloat16)
     w = torch.randn(Cout, Cin, 3, 3, device=device) * (9 * Cin) ** -0.5
+    import lavt_hip
+    f8 = lavt_hip.fp8_enabled()          # fp8 workload: the same convolution on e4m3 operands (v_mfma 16x16x128 f8f6f4: dense peak 5 PFLOP/s)
     with torch.no_grad():
-        y_ref = ops.conv3x3(x, None, w, B, H, W)            # the product op (packs the weight copy)
+        y_ref = ops.conv3x3(x, None, w, B, H, W)            # the product op (packs the weight copy; fp8: quantises x and the weight)
         # ... then the very launch it issues (ops._ConvTaps.forward), with the output buffer and the packed weight prepared once: per call the host spends
         # ~20 us on the parameter struct, so the 20 launches queue up and the events bracket GPU time (through the autograd Function the host needed
         # longer per call than the kernel runs)
         Wp = ops.weights.get(w, torch.bfloat16, "conv3")
         y = torch.empty_like(y_ref)
         launch = lambda: ops.gemm_nt(torch.bfloat16, B * H * W, Cout, 9 * Cin, x, Cin, Wp, 9 * Cin, y, Cout, conv=(H, W, Cin, 0, 1, 1, 3, 3))
+        if f8:          # the e4m3 contraction the product op issued, operands quantised once (same |max| slot, not advanced in between: identical bytes)
+            Wq, wa = ops.weights.get_fp8(w, "conv3")
+            xq, ap = ops.fp8.quantize(x, id(w))
+            launch = lambda: ops.gemm_nt(torch.uint8, B * H * W, Cout, 9 * Cin, xq, Cin, Wq, 9 * Cin, y, Cout, conv=(H, W, Cin, 0, 1, 1, 3, 3), deq=(ap, wa.data_ptr()))
         for _ in range(3):
             launch()
         torch.cuda.synchronize()
@@ -123,10 +129,15 @@ def measure_conv_kernel(device, iters=20):
             tsrc = "profiles/pmc_dominant_kernel.json (recorded)"
         except Exception:  # noqa: BLE001
             pass
-    import lavt_hip
-    f8 = lavt_hip.fp8_enabled()          # fp8 workload: the same convolution on e4m3 operands (v_mfma_scale 16x16x128: dense peak 5 PFLOP/s), quantisation launches included
     peak = 2.0 * BF16_DENSE_PEAK_TFLOPS if f8 else BF16_DENSE_PEAK_TFLOPS
-    return {"bound": "mfma", "kernel": "implicit-GEMM conv3x3 512->512 @120x120, batch 2 (decoder conv2_2), timed alone" + (" [fp8: incl. the activation quantiser]" if f8 else ""),
+    if f8:
+        traffic, tsrc = None, None
+        try:
+            traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_conv_fp8.json")))["conv_fp8_one"]["derived"]["fabric_bytes (FETCH_SIZE KB x2 gfx950 correction + WRITE_SIZE KB)"])
+            tsrc = "profiles/r04_pmc_conv_fp8.json (recorded)"
+        except Exception:  # noqa: BLE001
+            pass
+    return {"bound": "mfma", "kernel": "implicit-GEMM conv3x3 512->512 @120x120, batch 2 (decoder conv2_2), timed alone" + (" [fp8: the e4m3 contraction; the activation quantiser is a launch of its own]" if f8 else ""),
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "avg_launch_us": round(ms * 1e3, 2), "flops_per_launch": flops, "traffic": traffic, "traffic_source": tsrc}
 
