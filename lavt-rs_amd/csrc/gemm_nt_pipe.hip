@@ -1,5 +1,6 @@
-// Gather-GEMM, NT family, software-pipelined K loop (bf16): the long-K problems of the decoder (3x3 convolutions forward and data gradient as
-// implicit GEMMs, reference lib/mask_predictor.py:60-97) and every other problem that takes the 256x256 tile.
+// Gather-GEMM, NT family, software-pipelined K loop (bf16, and e4m3 operands for BASELINE configs[4]: the F8 variant below): the long-K problems of
+// the decoder (3x3 convolutions forward and data gradient as implicit GEMMs, reference lib/mask_predictor.py:60-97) and every other problem that takes
+// the 256x256 tile.
 //
 // Why a third K loop.  gemm_v2.hip leaves the order of fragment reads, MFMAs and DMA issue to hipcc, which schedules for register pressure: per K
 // tile a wave issues a few ds_read_b128, waits `lgkmcnt(0)`, runs 4-8 MFMAs, reads again, waits again -- four full LDS round trips per K tile with

@@ -1190,13 +1190,15 @@ def test_fp8_conv3x3_data_gradient_matches_quantised_oracle(cat, shape, monkeypa
     assert float((dw - grads["bf16"][1]).abs().max()) <= 1e-6 * float(dw.abs().max()) + 1e-12      # weight gradient: the same bf16 kernel in both modes
 
 
-def test_fp8_linear_matches_quantised_oracle(monkeypatch):
-    """the Linear form of the fp8 contraction (off by default: ops._FP8_LINEAR_MIN_ROWS) against the quantised oracle"""
+@pytest.mark.parametrize("shape", [(4608, 256, 384), (6656, 1024, 512), (26368, 1024, 512)])
+def test_fp8_linear_matches_quantised_oracle(monkeypatch, shape):
+    """the Linear form of the fp8 contraction (off by default: ops._FP8_LINEAR_MIN_ROWS) against the quantised oracle; the second and third shapes
+    take the plain-issue form of the software-pipelined fp8 kernel (128x128 and 256x256 tiles), the first gemm_v2's K loop"""
     import lavt_hip
     from lavt_hip import ops
     from oracle import fp8_oracle as F8
     monkeypatch.setattr(ops, "_FP8_LINEAR_MIN_ROWS", 4096)
-    M, Kd, N = 4608, 256, 384
+    M, Kd, N = shape
     x = rnd(M, Kd, seed=7).to(torch.bfloat16)
     w, b = rnd(N, Kd, seed=8) * Kd ** -0.5, rnd(N, seed=9) * 0.1
     wd, bd = torch.nn.Parameter(w.clone().to(dev())), torch.nn.Parameter(b.clone().to(dev()))
