@@ -56,6 +56,12 @@ def late_gradient_parameters(module: torch.nn.Module):
     return [p for p in late.values() if p.requires_grad]
 
 
+# Moves every time a GradBuckets instance (re-)lays out its flat buffer: every p.grad address may change then (first construction, and the relayout in
+# the second zero() that sends unreported parameters to the late bucket).  FusedAdamW folds it into its descriptor-table key, so that
+# step(check_tables=False) -- which skips the host-side pointer scan -- refuses a table built for the previous layout instead of reading stale offsets.
+layout_generation = [0]
+
+
 class GradBuckets:
     def __init__(self, module: torch.nn.Module, bucket_mib: float = 64.0, group=None, broadcast_params: bool = True, fused_accumulation: bool = False,
                  late="auto"):
@@ -99,6 +105,7 @@ class GradBuckets:
         """flat = [ordinary parameters in reverse registration order ~ the order backward produces their gradients, cut into buckets of `cap`
         floats] + [the late parameters: ONE bucket, reduced at finish()].  The layout depends on the module alone: identical on every rank."""
         self.late_ids = set(late_ids)
+        layout_generation[0] += 1
         self._zero_views, self._skip_views = None, []          # (a zero-fill skip list refers to the old offsets)
         order = [p for p in reversed(self.params) if id(p) not in self.late_ids]
         late = [p for p in reversed(self.params) if id(p) in self.late_ids]
@@ -264,6 +271,13 @@ class GradBuckets:
             # Whatever has not reported by now (a parameter the forward never uses, a deferred reduction late_gradient_parameters() did not
             # know about) moves to the late bucket from the next step on.  Deterministic given the model: the same decision on every rank.
             miss = {id(p) for p in self.params if id(p) not in self._seen and id(p) not in self.late_ids}
+            if self.world > 1 and dist.is_initialized():
+                # the new layout must be the same on every rank (bucket boundaries = all-reduce chunk sizes): the union of the ranks' unreported
+                # sets decides, so a parameter whose use was data-dependent in step 1 cannot give two ranks two layouts
+                mask = torch.tensor([1 if id(p) in miss else 0 for p in self.params], dtype=torch.int32,
+                                    device=self.flat.device if dist.get_backend(self.group) == "nccl" else "cpu")
+                dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+                miss = {id(p) for p, f in zip(self.params, mask.tolist()) if f and id(p) not in self.late_ids}
             if miss:
                 self._relayout = miss
                 if os.environ.get("LAVT_DDP_VERBOSE", "0") == "1":

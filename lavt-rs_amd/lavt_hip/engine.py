@@ -84,6 +84,10 @@ class TrainStep:
         return loss.detach()
 
     def warmup_and_capture(self, eager_iters=3):
+        """Side effects beyond `eager_iters` steps: one more eager step when the bucket layout is still to settle (eager_iters = 1), and the zero-fill-skip validation below replays the captured step up to three more times on
+        NaN-poisoned gradient buffers.  Each of those replays is a real training step of the forward pass -- BatchNorm running statistics and
+        `num_batches_tracked`, the fp8 |max| history and the DropPath generator advance, and with world > 1 the poisoned buckets are all-reduced
+        (NaN on every rank alike) -- the gradients of such a replay are discarded by the next step's fill.  LAVT_ZERO_SKIP=0 captures once."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -92,6 +96,10 @@ class TrainStep:
                 if it == 0:                      # every compute copy exists now: one descriptor table for the one-launch refresh
                     ops.weights.build_multicast(compute_dtype())
                     ops.weights.refresh_all()
+            if self.use_graph and self.buckets._relayout:
+                # GradBuckets lays the flat buffer out again in the zero() after its first step (parameters nothing reported join the late bucket): that
+                # moves p.grad and must happen in an eager step -- inside the capture window zero() would raise and the harness would silently run eagerly
+                self.loss = self._body()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._seen = self._param_stamp()

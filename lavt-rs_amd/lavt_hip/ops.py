@@ -2535,7 +2535,9 @@ class _ConvTaps(torch.autograd.Function):
             if ws:
                 # nine taps fused (csrc/conv_wgrad.hip): X rows in a rolling LDS window, partial tiles through the lent scratch, the reduction kernel
                 # accumulates straight into the [Cout][Cin][3][3] gradient -- no packed buffer, no zero fill, no unpack launch
-                scr = _tn_parts(ws, dy.device)
+                # (the shared per-device scratch is single-stream only: under LAVT_SIDE_STREAMS consecutive conv weight gradients alternate between two
+                # side streams, so each launch takes a scratch of its own, allocated on -- and stream-ordered with -- the side stream it runs on)
+                scr = _scratch(ws, dy.device) if side.enabled else _tn_parts(ws, dy.device)
                 if K.prof.enabled:
                     K.prof.note = {"flops": 2.0 * Cout * taps * Cin * M, "shape": f"conv-wgrad {Cout}x{taps * Cin}x{M}"}
                 # dW is either the parameter's slice of the zeroed flat gradient buffer (one weight gradient per parameter per step: sinks.buf refuses a

@@ -33,8 +33,10 @@ def lavt_param_groups(model, text_encoder_layers: int = 10):
 
 
 def ops_generation():
-    from . import ops
-    return ops.weights.generation
+    """what a descriptor table depends on besides the gradient pointers it lists: the compute copies' buffers (ops.weights.generation) and the layout
+    of the flat gradient buffer (ddp.layout_generation: GradBuckets re-lays it out once, in the second zero())"""
+    from . import ops, ddp
+    return (ops.weights.generation, ddp.layout_generation[0])
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -45,6 +47,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.total_steps, self.power = float(total_steps), float(power)
         self.fuse_copies = os.environ.get("LAVT_ADAMW_FUSE_COPIES", "1") != "0"
         self._tables = None
+        self._probe = []
         self._step = None
 
     # ---- flat optimizer state + device descriptor tables (built lazily: gradients must exist / be re-pointed first) ----
@@ -88,7 +91,9 @@ class FusedAdamW(torch.optim.Optimizer):
             desc.append([p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), copy])
             hyper.append([g["lr"], g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"]])
         # (the copies' addresses are baked into the table: ops.weights.generation moves whenever one of them gets a new buffer)
-        key = tuple(d[1] for d in desc) + tuple(tuple(h) for h in hyper) + (ops.weights.generation,)
+        key = tuple(d[1] for d in desc) + tuple(tuple(h) for h in hyper) + (ops_generation(),)
+        # (first / middle / last described parameter: an O(1) probe of the gradient addresses for step(check_tables=False))
+        self._probe = [(p, p.grad.data_ptr()) for _, p in (ps[0], ps[len(ps) // 2], ps[-1]) if p.grad is not None]
         self._tables = (key, torch.tensor(desc, dtype=torch.int64).to(dev), torch.tensor(hyper, dtype=torch.float32).to(dev), len(desc),
                         torch.tensor(chunks, dtype=torch.int32).to(dev), len(chunks), dict(fused))
 
@@ -100,8 +105,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 if p.requires_grad and p.grad is not None:
                     out.append(p.grad.data_ptr())
                     hy.append((g["lr"], g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"]))
-        from . import ops
-        return tuple(out) + tuple(hy) + (ops.weights.generation,)
+        return tuple(out) + tuple(hy) + (ops_generation(),)
 
     @torch.no_grad()
     def step(self, closure=None, check_tables=True):
@@ -111,10 +115,13 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._tables is None or (check_tables and self._tables[0] != self._current_key()):
             self._build()
         _, desc, hyper, n, chunks, nchunks, fused = self._tables
-        if not check_tables and self._tables[0][-1] != ops_generation():
-            # (captured steps skip the host-side scan, but a copy that moved since the table was built would be written at its OLD address)
-            raise RuntimeError("FusedAdamW.step(check_tables=False): a compute copy was re-allocated after the descriptor table was built; "
-                               "call step() once with check_tables=True (outside a capture) first")
+        if not check_tables and (self._tables[0][-1] != ops_generation()
+                                 or any(p.grad is None or p.grad.data_ptr() != a for p, a in self._probe)):
+            # (captured steps skip the host-side scan, but a copy that moved since the table was built would be written at its OLD address, and a
+            # gradient buffer that was laid out again -- GradBuckets moves unreported parameters to the late bucket in its second zero() -- would be
+            # read at its OLD offsets)
+            raise RuntimeError("FusedAdamW.step(check_tables=False): a compute copy was re-allocated or the flat gradient buffer was laid out again "
+                               "after the descriptor table was built; call step() once with check_tables=True (outside a capture) first")
         K.check(K.lib.lavt_adamw_step_chunks(K.ptr(desc), K.ptr(hyper), K.ptr(chunks), nchunks, K.ptr(self._step), self.total_steps, self.power, K.stream()))
         # The kernel writes the parameters through raw pointers: p._version does not move, so the cached compute copies (bf16 Linear weights,
         # packed conv weights) are stale now.  They are part of the optimizer's output (fp32 master weights + the compute-dtype copies the next

@@ -31,7 +31,8 @@ def compute_dtype() -> torch.dtype:
     (train.py:452-459), i.e. float16 + GradScaler.  This path has no fp16 kernels -- its low-precision type is bf16 (fp32's exponent range) -- so an
     fp16 autocast region runs the bf16 kernels, with ONE warning per process: `train_one_epoch_ytvos --use_amp` runs unchanged (the GradScaler's
     loss scale passes through harmlessly: bf16 gradients cannot overflow where fp16 ones would, and `scaler.step` unscales the fp32 parameter
-    gradients as usual).  LAVT_STRICT_FP16_AUTOCAST=1 raises instead."""
+    gradients as usual; its scale only ever grows, since no step is skipped).  LAVT_STRICT_FP16_AUTOCAST=1 raises instead;
+    LAVT_ALLOW_FP16_AUTOCAST=1 ignores the region and computes in the configured dtype."""
     if torch.is_autocast_enabled():
         adt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
         if adt == torch.bfloat16:
@@ -40,6 +41,9 @@ def compute_dtype() -> torch.dtype:
             if os.environ.get("LAVT_STRICT_FP16_AUTOCAST", "0") == "1":
                 raise RuntimeError("liblavt_hip: called inside torch.autocast(dtype=float16) (the reference's torch.cuda.amp.autocast(), train.py:452) "
                                    "with LAVT_STRICT_FP16_AUTOCAST=1; this path computes in fp32 or bf16 only")
+            if os.environ.get("LAVT_ALLOW_FP16_AUTOCAST", "0") == "1":
+                # rounds 1-3 meaning of this switch, kept: ignore the fp16 region and compute in the configured dtype (e.g. fp32)
+                return _state["dtype"]
             if not _warned_fp16[0]:
                 _warned_fp16[0] = True
                 warnings.warn("liblavt_hip: torch.autocast(dtype=float16) region (train.py:452) -- this path has no fp16 kernels and computes the region in "

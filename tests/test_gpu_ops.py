@@ -37,18 +37,42 @@ def tol(dtype, ref, f32=2e-4, bf16=3e-2):
     return f32 * max(scale, 1.0) if dtype == torch.float32 else bf16 * max(scale, 1e-3)
 
 
-def assert_close(got, ref, dtype, name="", f32=2e-4, bf16=3e-2):
+def assert_close(got, ref, dtype, name="", f32=2e-4, bf16=3e-2, l2=None):
+    """max-norm gate relative to the reference's scale; `l2` adds the norm-wise gate ||got - ref||_2 <= l2 * ||ref||_2 (both sides of run_pair start
+    from the same bf16-representable values, so a bf16 output differs from the fp32 reference by its final rounding -- 2^-9 / sqrt(3) = 1.1e-3 rms --
+    plus the summation order: a kernel that drops or misplaces a few terms moves the norm-wise error long before it moves a loose max-norm)"""
     got = got.detach().float().cpu()
     ref = ref.detach().float()
     assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
     err = float((got - ref).abs().max())
     t = tol(dtype, ref, f32, bf16)
     assert math.isfinite(err) and err <= t, f"{name}: max abs err {err:.3e} > {t:.3e} (ref scale {float(ref.abs().max()):.3e})"
+    if l2 is not None:
+        rel = float((got - ref).norm()) / max(float(ref.norm()), 1e-30)
+        assert rel <= l2, f"{name}: relative l2 error {rel:.3e} > {l2:.1e}"
 
 
-def run_pair(hip_fn, ref_fn, inputs, dtype, requires=None, f32=2e-4, bf16=3e-2, name=""):
+def border_rows(B, H, W):
+    """row indices (NHWC token order) of the image-border pixels: where a 3x3 tap that must read the zero halo reads a neighbour instead"""
+    y, x = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    m = ((y == 0) | (y == H - 1) | (x == 0) | (x == W - 1)).reshape(-1)
+    return torch.cat([torch.nonzero(m).reshape(-1) + b * H * W for b in range(B)])
+
+
+def assert_border_close(got, ref, bhw, tol_rel, name=""):
+    """border-only max check of an [B*H*W, C] map at a tight tolerance (relative to the whole map's scale): one wrong halo tap is ~0.07 x max|ref|"""
+    got, ref = got.detach().float().cpu(), ref.detach().float()
+    rows = border_rows(*bhw)
+    err = float((got[rows] - ref[rows]).abs().max())
+    scale = float(ref.abs().max())
+    assert err <= tol_rel * scale, f"{name}: border pixels differ by {err / scale:.3e} x max|ref| > {tol_rel:.1e}"
+
+
+def run_pair(hip_fn, ref_fn, inputs, dtype, requires=None, f32=2e-4, bf16=3e-2, name="", l2=None, border=None, border_tol=8e-3):
     """inputs: dict name -> (cpu fp32 tensor, kind) with kind in {'act','param','const'}.
-    act tensors are cast to `dtype` on the GPU, params stay fp32.  Compares outputs and all gradients."""
+    act tensors are cast to `dtype` on the GPU, params stay fp32.  Compares outputs and all gradients.
+    l2: norm-wise gate on the output and on every gradient (assert_close); border = (B, H, W): the output and every activation gradient are
+    [B*H*W, C] maps whose border pixels get their own max check at `border_tol` x max|ref| (x 1.5 for gradients)."""
     from lavt_hip import ops
     d = dev()
     cpu, gpu = {}, {}
@@ -68,7 +92,9 @@ def run_pair(hip_fn, ref_fn, inputs, dtype, requires=None, f32=2e-4, bf16=3e-2, 
     ops.weights.invalidate()
     y_ref = ref_fn(**cpu)
     y = hip_fn(**gpu)
-    assert_close(y, y_ref, dtype, name + " forward", f32, bf16)
+    assert_close(y, y_ref, dtype, name + " forward", f32, bf16, l2)
+    if border is not None and dtype == torch.bfloat16:
+        assert_border_close(y, y_ref, border, border_tol, name + " forward")
     go = rnd(*y_ref.shape, seed=99)
     if dtype == torch.bfloat16:
         go = go.to(torch.bfloat16).float()
@@ -79,7 +105,9 @@ def run_pair(hip_fn, ref_fn, inputs, dtype, requires=None, f32=2e-4, bf16=3e-2, 
         if kind == "const":
             continue
         assert gpu[k].grad is not None, f"{name}: no grad for {k}"
-        assert_close(gpu[k].grad, cpu[k].grad, dtype, f"{name} grad[{k}]", f32 * 5, bf16 * 1.5)
+        assert_close(gpu[k].grad, cpu[k].grad, dtype, f"{name} grad[{k}]", f32 * 5, bf16 * 1.5, l2)
+        if border is not None and dtype == torch.bfloat16 and kind == "act" and gpu[k].grad.dim() == 2 and gpu[k].grad.shape[0] == border[0] * border[1] * border[2]:
+            assert_border_close(gpu[k].grad, cpu[k].grad, border, border_tol * 1.5, f"{name} grad[{k}]")
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
@@ -126,10 +154,14 @@ def test_gemm_pipelined_k_loop(tile, stages, monkeypatch, request):
     dtype = torch.bfloat16
     for (M, N, Kd) in ((700, 328, 256), (700, 328, 264), (130, 520, 64), (1000, 256, 1024)):
         inputs = {"x": (rnd(M, Kd, seed=1), "act"), "w": (rnd(N, Kd, seed=2, scale=Kd ** -0.5), "param"), "b": (rnd(N, seed=3), "param")}
-        run_pair(lambda x, w, b: ops.linear(x, w, b), lambda x, w, b: F.linear(x, w, b), inputs, dtype, name=f"pipe linear {M}x{N}x{Kd} tile {tile}/{stages}")
+        run_pair(lambda x, w, b: ops.linear(x, w, b), lambda x, w, b: F.linear(x, w, b), inputs, dtype, name=f"pipe linear {M}x{N}x{Kd} tile {tile}/{stages}", l2=5e-3)
     # (the 1024 + 512 and 512 -> 512 cases: few pixels, long reduction -- split-K over channel blocks, conv_kc_split, forward across the concat boundary and backward)
+    # (no fp32 instantiation of this kernel exists, so its index arithmetic -- tap walking, halo zeros through out-of-range buffer offsets, channel-split
+    # pieces -- is gated norm-wise (5e-3) and on the border pixels alone (8e-3 x max|ref|) next to the max-norm; the last shapes are the products' own:
+    # Swin-T's 384 + 96 -> 384 concat convolution at 2 x 120 x 120 and, on the default configuration, Swin-B's 512 -> 512 at 4 x 120 x 120)
+    real = ((2, 120, 120, 384, 96, 384),) + (((4, 120, 120, 512, 0, 512),) if tile == "512" else ())
     for (B, H, W, C1, C2, Cout) in ((2, 13, 11, 128, 64, 136), (2, 13, 11, 96, 32, 136), (1, 30, 30, 512, 0, 128), (2, 9, 20, 64, 0, 256), (1, 24, 24, 256, 128, 256),
-                                    (1, 20, 20, 1024, 512, 128), (1, 16, 16, 512, 0, 512)):
+                                    (1, 20, 20, 1024, 512, 128), (1, 16, 16, 512, 0, 512)) + real:
         Cin = C1 + C2
         inputs = {"x1": (rnd(B * H * W, C1, seed=1), "act"), "w": (rnd(Cout, Cin, 3, 3, seed=3, scale=(9 * Cin) ** -0.5), "param")}
         if C2:
@@ -139,7 +171,8 @@ def test_gemm_pipelined_k_loop(tile, stages, monkeypatch, request):
             x = x1 if x2 is None else torch.cat([x1, x2], 1)
             y = F.conv2d(x.view(B, H, W, Cin).permute(0, 3, 1, 2), w, padding=1)
             return y.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
-        run_pair(lambda x1, w, x2=None: ops.conv3x3(x1, x2, w, B, H, W), ref, inputs, dtype, name=f"pipe conv {B}x{H}x{W} {C1}+{C2}->{Cout} tile {tile}/{stages}", bf16=4e-2)
+        run_pair(lambda x1, w, x2=None: ops.conv3x3(x1, x2, w, B, H, W), ref, inputs, dtype, name=f"pipe conv {B}x{H}x{W} {C1}+{C2}->{Cout} tile {tile}/{stages}", bf16=4e-2,
+                 l2=5e-3, border=(B, H, W))
     # two channel pieces of four 64-channel blocks each: the second piece starts in the first concat source and crosses into the second
     monkeypatch.setattr(ops, "_CONV_KC_SPLITS", "2")
     B, H, W, C1, C2, Cout = 1, 24, 24, 320, 192, 128
@@ -150,7 +183,8 @@ def test_gemm_pipelined_k_loop(tile, stages, monkeypatch, request):
     def ref2(x1, w, x2):
         y = F.conv2d(torch.cat([x1, x2], 1).view(B, H, W, Cin).permute(0, 3, 1, 2), w, padding=1)
         return y.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
-    run_pair(lambda x1, w, x2: ops.conv3x3(x1, x2, w, B, H, W), ref2, inputs, dtype, name=f"pipe conv, 2 channel pieces across the concat boundary, tile {tile}/{stages}", bf16=4e-2)
+    run_pair(lambda x1, w, x2: ops.conv3x3(x1, x2, w, B, H, W), ref2, inputs, dtype, name=f"pipe conv, 2 channel pieces across the concat boundary, tile {tile}/{stages}", bf16=4e-2,
+             l2=5e-3, border=(B, H, W))
     monkeypatch.setattr(ops, "_CONV_KC_SPLITS", "auto")
     # Conv3d of SepTPWAM (27 taps, bias + GELU epilogue, tap-split forward at few rows)
     from lavt_hip._capi import ACT_GELU
@@ -160,7 +194,7 @@ def test_gemm_pipelined_k_loop(tile, stages, monkeypatch, request):
     def ref3(x, w, b):
         y = F.conv3d(x.view(B, D, H, W, Cin).permute(0, 4, 1, 2, 3), w, b, padding=1)
         return F.gelu(y.permute(0, 2, 3, 4, 1).reshape(B * D * H * W, Cout))
-    run_pair(lambda x, w, b: ops.conv3d(x, w, b, B, D, H, W, act=ACT_GELU), ref3, inputs, dtype, name=f"pipe conv3d tile {tile}/{stages}", bf16=4e-2)
+    run_pair(lambda x, w, b: ops.conv3d(x, w, b, B, D, H, W, act=ACT_GELU), ref3, inputs, dtype, name=f"pipe conv3d tile {tile}/{stages}", bf16=4e-2, l2=5e-3)
 
 
 @pytest.mark.parametrize("tile,stages", [("512", "0"), ("128", "4")])
@@ -325,6 +359,10 @@ def test_conv3x3_wgrad_fused_taps(B, H, W, C1, C2, Cout, monkeypatch):
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) <= 2e-3 * scale, float((got - ref).abs().max()) / scale       # exact bf16 products, fp32 sums: summation order only
     assert float((old - ref).abs().max()) <= 2e-3 * scale
+    assert float((got - ref).norm() / ref.norm()) <= 2e-4                                               # norm-wise: a dropped / doubled row of one piece shows here first
+    # the three tap rows / columns that touch the halo, each against its own scale (a wrong zero row or column lands in exactly these taps)
+    for ky, kx in ((0, 1), (2, 1), (1, 0), (1, 2), (0, 0), (2, 2)):
+        assert float((got[:, :, ky, kx] - ref[:, :, ky, kx]).abs().max()) <= 2e-3 * float(ref[:, :, ky, kx].abs().max()), (ky, kx)
     # border taps really see zeros: the corner pixel's contribution to tap (dy, dx) = (-1, -1) is absent
     assert torch.isfinite(got).all()
 
@@ -706,6 +744,47 @@ def test_fused_adamw_in_hip_graph():
     assert captured.steps_taken() == 4
     for p, q in zip(eager_p, graph_p):
         assert float((p - q).abs().max()) <= 1e-7 * max(1.0, float(p.abs().max()))
+
+
+def test_fused_adamw_refuses_a_table_from_before_the_bucket_relayout():
+    """GradBuckets lays its flat buffer out again in the second zero() (a parameter nothing reported in step 1 joins the late bucket): every p.grad
+    may move.  step(check_tables=False) skips the host-side pointer scan, so it must refuse the descriptor table built on the old layout instead of
+    reading gradients at stale offsets; a step with check_tables=True rebuilds it and the update then equals torch.optim.AdamW's."""
+    from lavt_hip.ddp import GradBuckets
+    from lavt_hip.optim import FusedAdamW
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(*[torch.nn.Linear(16, 16, bias=False) for _ in range(4)]).to(dev())
+    twin = torch.nn.Sequential(*[torch.nn.Linear(16, 16, bias=False) for _ in range(4)]).to(dev())
+    twin.load_state_dict(net.state_dict())
+    ps, dead = list(net.parameters()), 2
+    gb = GradBuckets(net, bucket_mib=2 * 256 * 4 / (1 << 20))          # two weights per bucket: the dead one gates bucket 0 in step 1
+    opt = FusedAdamW(ps, lr=1e-2, total_steps=0)
+    ref = torch.optim.AdamW(twin.parameters(), lr=1e-2)
+    g = [torch.randn(16, 16, generator=torch.Generator("cpu").manual_seed(i)).to(dev()) for i in range(4)]
+
+    def backward():
+        gb.zero()
+        for i in reversed(range(4)):
+            if i != dead:
+                ps[i].grad.copy_(g[i])
+                gb._on_grad(ps[i])
+        gb.finish()
+    backward()
+    before = [p.grad.data_ptr() for p in ps]
+    opt.step()                                       # tables built on the first layout
+    backward()                                       # second zero(): relayout
+    assert [p.grad.data_ptr() for p in ps] != before
+    with pytest.raises(RuntimeError, match="laid out again"):
+        opt.step(check_tables=False)
+    opt.step()                                       # rebuilds
+    opt.step(check_tables=False)                     # and the rebuilt table is accepted
+    for i, q in enumerate(twin.parameters()):
+        q.grad = torch.zeros_like(q) if i == dead else g[i].clone()
+    for _ in range(3):
+        ref.step()
+    torch.cuda.synchronize()
+    for p, q in zip(ps, twin.parameters()):
+        assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max()))
 
 
 # ------------------------------------------------------------------------------------------------ grouped weight-gradient launch
@@ -1142,6 +1221,8 @@ def test_fp8_conv3x3_matches_quantised_oracle(cat, monkeypatch):
     ref = F8.conv3x3_fp8(xs.float().view(B, H, W, -1).permute(0, 3, 1, 2), w, amax_x, amax_w).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
     err = float((y.float().cpu() - ref).abs().max())
     assert err <= 1e-2 * float(ref.abs().max()), err / float(ref.abs().max())
+    assert float((y.float().cpu() - ref).norm() / ref.norm()) <= 5e-3                                   # bf16 rounding of the output: 1.1e-3 rms
+    assert_border_close(y, ref, (B, H, W), 8e-3, "fp8 conv forward")
     exact = F.conv2d(xs.float().view(B, H, W, -1).permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
     rel = float((y.float().cpu() - exact).norm() / exact.norm())
     assert rel < 0.06, rel                                               # e4m3 has 3 mantissa bits: ~3-4 % rms on a 1000-term contraction
@@ -1183,6 +1264,8 @@ def test_fp8_conv3x3_data_gradient_matches_quantised_oracle(cat, shape, monkeypa
     dx, dw = grads["fp8"]
     err = float((dx - ref).abs().max())
     assert err <= 1e-2 * float(ref.abs().max()), err / float(ref.abs().max())     # bf16 rounding of the output
+    assert float((dx - ref).norm() / ref.norm()) <= 5e-3
+    assert_border_close(dx, ref, (B, H, W), 8e-3, "fp8 conv data gradient")
     exact = F.conv_transpose2d(dy.float().view(B, H, W, Cout).permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1).reshape(B * H * W, -1)
     rel = float((dx - exact).norm() / exact.norm())
     assert rel < 0.08, rel

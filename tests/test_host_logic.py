@@ -325,8 +325,16 @@ def test_grad_buckets_learn_unreported_parameters():
     gb = GradBuckets(net, bucket_mib=2 * 64 * 4 / (1 << 20))          # two weights per bucket
     assert len(gb.buckets) == 2 and gb.late_bucket is None
     dead = ps[2]
+    from lavt_hip import ddp, optim
+    gen0, grads0 = ddp.layout_generation[0], [p.grad.data_ptr() for p in ps]
     for step in range(3):
         gb.zero()
+        if step == 1:
+            # the relayout moved gradient views: the generation FusedAdamW keys its descriptor table on (also under check_tables=False) moved with it
+            assert ddp.layout_generation[0] == gen0 + 1 and [p.grad.data_ptr() for p in ps] != grads0
+            assert optim.ops_generation()[1] == ddp.layout_generation[0]
+        if step == 2:
+            assert ddp.layout_generation[0] == gen0 + 1
         for p in reversed(ps):
             if p is not dead:
                 gb._on_grad(p)
