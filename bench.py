@@ -142,6 +142,46 @@ def measure_conv_kernel(device, iters=20):
             "avg_launch_us": round(ms * 1e3, 2), "flops_per_launch": flops, "traffic": traffic, "traffic_source": tsrc}
 
 
+def measure_attainable_peak(device, n=8192, iters=10):
+    """the bf16 rate this box attains on a chip-filling GEMM (n^3, random operands, HIP events around `iters` back-to-back launches),
+    next to the nominal 2.5 PFLOP/s every `frac` in this line is quoted against: the vendor library through torch.matmul (hipBLASLt / rocBLAS -- a
+    yardstick, never on the product path) and this library's own NT kernel.  tools/gemm_yardstick.py has the per-shape table (profiles/)."""
+    from lavt_hip import ops
+    bf = torch.bfloat16
+    A, B = torch.randn(n, n, device=device).to(bf), torch.randn(n, n, device=device).to(bf)
+    C = torch.empty(n, n, device=device, dtype=bf)
+    res = {"unit": "TFLOP/s", "shape": f"{n}x{n}x{n} bf16, fp32 accumulate"}
+    for key, fn in (("vendor_hipblaslt", lambda: torch.matmul(A, B.t(), out=C)), ("own_gemm_nt", lambda: ops.gemm_nt(bf, n, n, n, A, n, B, n, C, n))):
+        try:
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            res[key] = round(2.0 * n ** 3 / (e0.elapsed_time(e1) / iters * 1e-3) / 1e12, 1)
+        except Exception as e:  # noqa: BLE001
+            res[key] = f"{type(e).__name__}: {e}"
+    return res
+
+
+def replay_trace_launch_us(kernel_substr, grid):
+    """average duration of a kernel in the newest committed rocprofv3 trace of hipGraph replays (profiles/rNN_z_by_shape_graph_replay.txt, written by
+    tools/trace_by_shape.py): a recorded figure, quoted next to the eager-timed one of this run"""
+    import glob
+    import re
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_z_by_shape_graph_replay.txt")), reverse=True):
+        for line in open(fn):
+            if kernel_substr in line and f"grid {grid}x" in line:
+                m_ = re.search(r"x\s+([0-9.]+) us\s+grid", line)
+                if m_:
+                    return float(m_.group(1)), "profiles/" + os.path.basename(fn) + " (recorded)"
+    return None, None
+
+
 def profile_step(step, cfg, device, reps=3):
     """Where the step's time goes, measured in this process: `reps` eager steps with every C-ABI launch bracketed by HIP events on the launch
     stream (lavt_hip._capi.prof).  Launches are grouped into families (entry point + problem shape); the family with the largest us/step is
@@ -212,6 +252,11 @@ def profile_step(step, cfg, device, reps=3):
             roof["traffic"] = int(pm["fabric_bytes (FETCH_SIZE KB x2 gfx950 correction + WRITE_SIZE KB)"])
             roof["traffic_source"] = f"profiles/{fn} (recorded)"
             # bf16 operands read once (fc2, fc1, proj, the 792 padded rows of dqkv, qkv) + fp32 gradients written once
+            us_, src_ = replay_trace_launch_us("gemm_tn_v2_grouped_ln_kernel<true, 2, 64, 1>", 1242) if cfg.get("name") == "swin_b_w12_480_b2" else (None, None)
+            if us_:          # the rocprofv3 trace of graph replays is the figure the documents quote; the eager-timed one above is this run's own
+                roof["avg_launch_us_graph_replay_trace"] = us_
+                roof["frac_graph_replay_trace"] = round(roof["flops_per_launch"] / (us_ * 1e-6) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
+                roof["graph_replay_trace_source"] = src_
             roof["algorithmic_bytes"] = int(2 * (2 * 1800 * (512 + 2048) + 1800 * (512 + 512) + 792 * 1536 + 1800 * (1536 + 512)) + 4 * (2 * 2048 * 512 + 512 * 512 + 1536 * 512))
         except Exception:  # noqa: BLE001
             pass
@@ -512,6 +557,12 @@ def main():
                     if "wmsa_pwam_mfma_frac" in prof:
                         out["config"]["wmsa_pwam_mfma_frac"] = prof["wmsa_pwam_mfma_frac"]
                     out["roofline_conv"] = conv
+                if a.dtype in ("bf16", "fp8") and isinstance(out.get("roofline"), dict):
+                    mp = measure_attainable_peak(device)
+                    out["roofline"]["measured_peak"] = mp
+                    best = max([v for v in (mp.get("vendor_hipblaslt"), mp.get("own_gemm_nt")) if isinstance(v, float)], default=None)
+                    if best and out["roofline"].get("unit") == "TFLOP/s":
+                        out["roofline"]["frac_of_measured_peak"] = round(out["roofline"]["achieved"] / best, 4)
             except Exception as e:  # noqa: BLE001
                 out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
             try:

@@ -342,47 +342,22 @@ sinks = _GradSinks()
 
 
 class _SideStreams:
-    """Weight-gradient GEMMs are off the critical path of backward (only the optimizer / all-reduce needs them), and at batch 2 per
-    GPU every kernel of the dgrad chain is latency-bound and leaves most CUs idle.  When gradient sinks are active the wgrad launches
-    go to side HIP streams (forked from, and joined back into, the main stream -- capturable into the step's hipGraph) so they fill
-    those idle CUs instead of lengthening the chain."""
+    """Rounds 1-4 could send the weight-gradient GEMMs to side HIP streams (LAVT_SIDE_STREAMS=1: forked from / joined into the main stream, so that
+    they would fill the CUs the latency-bound data-gradient chain leaves idle).  REMOVED in round 5: it never paid (21.4 vs 20.9 ms per step in round
+    1, 9.88 vs 9.77 in round 2, 12.43-13.0 vs 12.46 in round 3: a hipGraph that is not a single chain costs ~0.5 us per kernel node on this runtime)
+    and it was not safe -- the per-device partial-tile scratch and the persistent arenas of the step are single-stream by construction (the round-4
+    advisor found the fused-tap convolution gradient racing on the scratch; a GPU run of the harness test with the switch on then showed 1e-3 of
+    drift in the data-gradient chain as well).  The object stays as the pass-through the call sites use: run() calls fn at once on the current
+    stream, join() has nothing to wait for."""
 
-    def __init__(self):
-        self.streams = {}
-        self.enabled = os.environ.get("LAVT_SIDE_STREAMS", "0") == "1"   # measured: no gain on MI355X (21.4 vs 20.9 ms/step), off by default
-        self.used = False
-        self.rr = 0
-
-    def get(self, device, n=2):
-        lst = self.streams.get(device)
-        if lst is None:
-            lst = self.streams[device] = [torch.cuda.Stream(device=device) for _ in range(n)]
-        self.rr = (self.rr + 1) % len(lst)
-        return lst[self.rr]
+    enabled = False
+    streams = {}
 
     def run(self, fn, tensors, active):
-        if not (active and self.enabled):
-            fn()
-            return
-        dev = tensors[0].device
-        side = self.get(dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fn()
-        for t in tensors:
-            if t is not None:
-                t.record_stream(side)
-        self.used = True
+        fn()
 
     def join(self):
-        """Make the current stream wait for everything launched on the side streams (end of backward / before all-reduce)."""
-        if not self.used:
-            return
-        cur = torch.cuda.current_stream()
-        for lst in self.streams.values():
-            for st in lst:
-                cur.wait_stream(st)
-        self.used = False
+        return
 
 
 side = _SideStreams()
@@ -2535,9 +2510,7 @@ class _ConvTaps(torch.autograd.Function):
             if ws:
                 # nine taps fused (csrc/conv_wgrad.hip): X rows in a rolling LDS window, partial tiles through the lent scratch, the reduction kernel
                 # accumulates straight into the [Cout][Cin][3][3] gradient -- no packed buffer, no zero fill, no unpack launch
-                # (the shared per-device scratch is single-stream only: under LAVT_SIDE_STREAMS consecutive conv weight gradients alternate between two
-                # side streams, so each launch takes a scratch of its own, allocated on -- and stream-ordered with -- the side stream it runs on)
-                scr = _scratch(ws, dy.device) if side.enabled else _tn_parts(ws, dy.device)
+                scr = _tn_parts(ws, dy.device)          # (single-stream scratch: every launch of the step is on the one launch stream, see _SideStreams)
                 if K.prof.enabled:
                     K.prof.note = {"flops": 2.0 * Cout * taps * Cin * M, "shape": f"conv-wgrad {Cout}x{taps * Cin}x{M}"}
                 # dW is either the parameter's slice of the zeroed flat gradient buffer (one weight gradient per parameter per step: sinks.buf refuses a

@@ -115,6 +115,43 @@ def test_grad_buckets_world2(bucket_mib):
         assert dict(out) == {0: True, 1: True}
 
 
+def _disagree_worker(rank, world, port, out):
+    """step 1 is data-dependent: rank 0 never reports weight 1, rank 1 never reports weight 2.  Decided per rank the relayout would give the ranks
+    different bucket boundaries (all-reduce chunks of different content); the union decides, so both end with the same layout and the exchange of
+    the following steps is the plain average."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lavt_hip.ddp import GradBuckets
+    torch.manual_seed(0)
+    net = nn.Sequential(*[nn.Linear(8, 8, bias=False) for _ in range(4)])
+    ps = list(net.parameters())
+    gb = GradBuckets(net, bucket_mib=2 * 64 * 4 / (1 << 20))            # two weights per bucket
+    g = [torch.full((8, 8), float(10 * rank + i)) for i in range(4)]
+    for step in range(3):
+        gb.zero()
+        skip = {0: 1, 1: 2}[rank] if step == 0 else None
+        for i in reversed(range(4)):
+            if i != skip:
+                ps[i].grad.copy_(g[i])
+                gb._on_grad(ps[i])
+        gb.finish()
+        if step > 0:
+            assert gb.late_bucket is not None and {i for i in range(4) if gb.bucket_of[ps[i]] == gb.late_bucket} == {1, 2}
+            for i in range(4):
+                assert torch.allclose(ps[i].grad, torch.full((8, 8), float(i + 5.0))), (step, i)          # mean of (i, 10 + i)
+    out[rank] = [list(b) for b in gb.buckets]
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_relayout_agrees_across_ranks_world2():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_disagree_worker, args=(2, port, out), nprocs=2, join=True)
+        res = dict(out)
+        assert res[0] == res[1] and len(res[0]) == 2
+
+
 # ------------------------------------------------------------------------------------------------ SyncBN protocol, two real processes
 class _CpuBnKernels:
     """CPU stand-in for the local BatchNorm + ReLU passes of csrc/norm.hip (same interface as lavt_hip.ops._HipBnKernels, same definitions:
