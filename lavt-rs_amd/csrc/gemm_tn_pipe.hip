@@ -1,0 +1,460 @@
+// Gather-GEMM, TN family, software-pipelined K loop (bf16, round 5): the grouped weight gradients of a Swin block -- the four Linear layers'
+// dW = dY^T X over the tokens (reference lib/backbone.py:24-30, 121, 141: the backward autograd derives for fc1 / fc2 / qkv / proj) -- when the
+// reduction is short enough for every output tile to have ONE writer (K <= 128 K tiles: stage 2 / 3 of the image models at 2-4 images per GPU,
+// the video stages 2 / 3).
+//
+// Why a second TN kernel.  gemm_tn_v2.hip's grouped launch uses 64x64 output tiles so that ~800 workgroups fill the chip three deep; both operands
+// are k-major, so every tile streams its own [K][64] panels: 367 MB of L2 -> LDS fill for the 44 MB of operands of a stage-2 block, a serial chain
+// of 29 K tiles of ~1.2 us per workgroup, MFMA busy 12 % (rocprofv3 --pmc, profiles/r04_pmc.json) -- 0.11 of the bf16 peak for three rounds.
+// Every rearrangement inside that structure (deeper rings, 128x128 tiles under a 128-register cap, rectangular tiles, stream-K, k-split waves) measured
+// slower.  What the decoder's pipelined NT kernel showed in round 4 is that a CU ingests ~54 GB/s whatever the tile, and that
+// this rate is only reached when fragment reads, MFMAs and the DMA issue are overlapped BY HAND.  So:
+//   * 128x128 output tiles, one workgroup of 8 waves (2 x 4, wave tiles of 64 x 32, up to 256 registers per lane) per CU: half the fill bytes per
+//     flop of the 64x64 launch (183 MB for the stage-2 block: 198 tiles x 29 K tiles x 32 KB);
+//   * both operand tiles k-major [64 k][128] in a STAGES-deep LDS ring filled by buffer-descriptor LDS-DMA (a lane's offset is one 32-bit
+//     register; rows beyond K and columns beyond I / J are offsets beyond the descriptor's range: the hardware writes zeros -- no zero page, no
+//     per-lane validity arithmetic on the unmapped path);
+//   * every fragment through the transposing LDS read (ds_read_b64_tr_b16, slot-swizzled tiles as in gemm_tn_v2.hip), issued from inline asm one
+//     MFMA group ahead into double-buffered registers and waited for with counted `s_waitcnt lgkmcnt(n)`; ONE barrier per K tile in front of the
+//     second group, after which the stage just consumed is refilled, two MFMAs per DMA instruction;
+//   * row maps (window order <-> token order) arrive through the SCALAR unit: a wave's two DMA instructions per operand cover 8 consecutive K rows,
+//     so one s_load_dwordx8 per mapped operand per K tile, issued at the top of the K tile and complete at its `lgkmcnt(0)` -- no vector-memory
+//     load whose position in the in-order vmcnt queue would drain the ring (the reason gemm_tn_v2.hip carries its maps through an LDS ring);
+//     the DropPath row mask is a 64-bit keep mask over the samples, read once;
+//   * bias gradients (column sums of A) on the matrix cores against a fragment of ones, by the first wave column of the tile_j == 0 workgroups;
+//   * a LayerNorm backward can ride as extra workgroups (two 256-thread units per 512-thread workgroup) on the CUs the 198 tiles leave idle.
+// Accumulators hold C^T fragments (B fragment as the first MFMA operand): a lane owns 4 consecutive j of one row i -- 16-byte stores.
+#include "gemm_v2_helpers.h"
+#include "ln_bwd_body.h"
+
+namespace {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t tnp_rsrc_t;
+__device__ __forceinline__ tnp_rsrc_t tnp_buf(const void* base, unsigned bytes) {          // raw (stride 0) addressing, offsets >= bytes read zero
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void tnp_dma16(tnp_rsrc_t rs, void* lds_dst, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, voff, 0, 0, 0);
+}
+#else
+struct tnp_rsrc_t { int unused; };
+__host__ __device__ inline tnp_rsrc_t tnp_buf(const void*, unsigned) { return tnp_rsrc_t{0}; }
+__host__ __device__ inline void tnp_dma16(tnp_rsrc_t, void*, unsigned) {}
+#endif
+
+typedef int tnp_i32x8 __attribute__((ext_vector_type(8)));
+typedef tnp_i32x8 __attribute__((aligned(4))) tnp_i32x8_u;          // (row maps are 4-byte aligned: s_load_dwordx8 needs no more)
+typedef __attribute__((address_space(4))) const tnp_i32x8_u* tnp_cptr8;
+
+// transposing reads of NF fragments of one k-step (two reads per fragment: K rows r and r + 4 of the lane's 8-row block), issued only
+template <int NF, int HO, int KOFF> __device__ __forceinline__ void tnp_issue_tr(const unsigned (&a)[NF], u64 (&l)[NF], u64 (&h)[NF]) {
+    static_assert(NF == 2 || NF == 4, "NF");
+    if constexpr (NF == 4)
+        asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%c13\n\tds_read_b64_tr_b16 %1, %8 offset:%c13+%c12\n\t"
+                     "ds_read_b64_tr_b16 %2, %9 offset:%c13\n\tds_read_b64_tr_b16 %3, %9 offset:%c13+%c12\n\t"
+                     "ds_read_b64_tr_b16 %4, %10 offset:%c13\n\tds_read_b64_tr_b16 %5, %10 offset:%c13+%c12\n\t"
+                     "ds_read_b64_tr_b16 %6, %11 offset:%c13\n\tds_read_b64_tr_b16 %7, %11 offset:%c13+%c12"
+                     : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]), "=&v"(l[2]), "=&v"(h[2]), "=&v"(l[3]), "=&v"(h[3])
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(HO), "n"(KOFF) : "memory");
+    else
+        asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%c7\n\tds_read_b64_tr_b16 %1, %4 offset:%c7+%c6\n\t"
+                     "ds_read_b64_tr_b16 %2, %5 offset:%c7\n\tds_read_b64_tr_b16 %3, %5 offset:%c7+%c6"
+                     : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]) : "v"(a[0]), "v"(a[1]), "n"(HO), "n"(KOFF) : "memory");
+}
+template <int CNT> __device__ __forceinline__ void tnp_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory"); }
+// ties registers to the wait in front of it (consumers cannot be scheduled above this empty statement, which stays behind the wait)
+template <int N> __device__ __forceinline__ void tnp_tie(u64 (&l)[N], u64 (&h)[N]) {
+    if constexpr (N == 4) asm volatile("" : "+v"(l[0]), "+v"(h[0]), "+v"(l[1]), "+v"(h[1]), "+v"(l[2]), "+v"(h[2]), "+v"(l[3]), "+v"(h[3]));
+    else asm volatile("" : "+v"(l[0]), "+v"(h[0]), "+v"(l[1]), "+v"(h[1]));
+}
+template <int N, typename F> __device__ __forceinline__ void tnp_static_for(F&& f) {
+    if constexpr (N > 0) {
+        tnp_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+constexpr int TNP_MAX = 6;
+enum { TNP_ACCUMULATE = 1, TNP_COLSUM_ATOMIC = 2, TNP_NO_B = 4, TNP_VEC4 = 8 };
+struct TnpMember {
+    const bf16* A; const bf16* B; float* C; float* colsum;
+    const int32_t* a_map; const int32_t* b_map; const float* a_rs;
+    int64_t ldc;
+    int lda, ldb, I, J, K, tiles_j, tile_end, rs_div, rs_n, flags;
+    float alpha;
+};
+struct TnpGroup { TnpMember m[TNP_MAX]; int n, tiles, dbg; };
+struct TnpRider {
+    const bf16* dy; const bf16* x; const float* gamma; const float* mean; const float* rstd; bf16* dx; float* partials; const bf16* dres;
+    int rows, C, blocks;
+};
+
+constexpr unsigned TNP_OOB = 0x80000000u;
+// Ablation builds (tools/r05_tnp_ablate.sh compiles this file with -DTNP_ABL=n into libraries OUTSIDE the shipped one; the shipped build has no switch):
+// bit 0: no MFMAs; bit 1: no fragment reads; bit 2: no DMA inside the K loop (the ring keeps the prologue's tiles)
+#ifndef TNP_ABL
+#define TNP_ABL 0
+#endif
+
+// One 128x128 output tile of member m.  MAPS: the member has a row map or a row mask (per-K-tile offset arithmetic); else the K rows are
+// consecutive and a lane's offsets just advance.
+template <int STAGES, bool MAPS>
+__device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, char* smem) {
+    constexpr int BT = 128, BK = 64, CH = BT / 8, L = 4;
+    constexpr int TILE_BYTES = BK * BT * 2, STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int HO = 4 * BT * 2, KOFF = 32 * BT * 2;
+    static_assert(STAGES >= 3 && STAGES <= 4, "ring depth");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 2, wj = wave & 3;                       // 2 (i) x 4 (j) waves: wave tile 64 x 32
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int tile_i = tile / m.tiles_j, tile_j = tile - tile_i * m.tiles_j;
+    const int i0 = tile_i * BT, j0 = tile_j * BT;
+    const int Kd = m.K, ktiles = (Kd + BK - 1) / BK;
+    const int lda2 = m.lda * 2, ldb2 = m.ldb * 2;                 // row strides in bytes
+    const bool has_b = !(m.flags & TNP_NO_B);
+
+    // ---- DMA geometry: instruction i of wave w fills LDS chunks q = (2 w + i) * 64 + lane of an operand tile: K row q / 16 = 8 w + 4 i + lane / 16,
+    //      slot q % 16 holding the column chunk (q % 16) ^ swizzle(row) -------------------------------------------------------------------
+    // descriptor ranges: an unmapped operand ends behind its K rows (tiles beyond K read zeros with no arithmetic); a mapped one is addressed by
+    // source-row index into a tensor whose extent the problem does not state -- a 2 GB window, rows beyond K masked in the offset arithmetic
+    const int32_t* const map_a = m.a_map;
+    const int32_t* const map_b = m.b_map;
+    const bool has_rs = m.a_rs != nullptr;
+    const tnp_rsrc_t rs_a = tnp_buf(m.A, (MAPS && map_a) ? 0x7fffffffu : (unsigned)Kd * (unsigned)lda2);
+    const tnp_rsrc_t rs_b = tnp_buf(has_b ? m.B : m.A, !has_b ? 0u : (MAPS && map_b) ? 0x7fffffffu : (unsigned)Kd * (unsigned)ldb2);
+    unsigned a_vo[2], b_vo[2];          // MAPS: column byte offset (or TNP_OOB); else the running byte offset of the lane's chunk
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = (wave * 2 + i) * 64 + lane, kr = q >> 4;
+        const int cc = (q & 15) ^ tn_swz<CH>(kr);
+        const int ca = i0 + cc * 8, cb = j0 + cc * 8;
+        if constexpr (MAPS) {
+            a_vo[i] = ca < m.I ? (unsigned)ca * 2u : TNP_OOB;
+            b_vo[i] = (has_b && cb < m.J) ? (unsigned)cb * 2u : TNP_OOB;
+        } else {
+            a_vo[i] = ca < m.I ? (unsigned)kr * (unsigned)lda2 + (unsigned)ca * 2u : TNP_OOB;
+            b_vo[i] = (has_b && cb < m.J) ? (unsigned)kr * (unsigned)ldb2 + (unsigned)cb * 2u : TNP_OOB;
+        }
+    }
+    const unsigned a_adv = (unsigned)BK * (unsigned)lda2, b_adv = (unsigned)BK * (unsigned)ldb2;
+
+    // ---- MAPS: side inputs.  Row maps through the scalar unit (8 consecutive entries per wave per operand per K tile); the DropPath / language
+    //      row mask as a keep bit per sample (<= 64 samples) with a running (row mod rows-per-sample, sample) pair per DMA instruction ---------
+    const int amask = map_a ? -1 : 0, bmask = map_b ? -1 : 0;
+    unsigned long long keep = ~0ull;
+    int rs_k[2] = {0, 0}, rs_s[2] = {0, 0};
+    const int rs_div = m.rs_div;
+    if constexpr (MAPS) {
+        if (has_rs) {
+            const float f = lane < m.rs_n ? m.a_rs[lane] : 1.0f;
+            keep = __ballot(f != 0.0f);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { rs_k[i] = wave * 8 + i * 4 + g4; rs_s[i] = 0; }          // (rs_div >= 64 > the first row index: sample 0)
+        }
+    }
+    tnp_i32x8 sa = {0, 0, 0, 0, 0, 0, 0, 0}, sb = {0, 0, 0, 0, 0, 0, 0, 0};
+    // rows of K tile t for this wave: entries [t * 64 + 8 wave, + 8) of either map (K % 8 == 0 on this path: a wave's eight rows are all inside K
+    // or all beyond it; beyond K nothing is read -- entry 0 stands in and the rows are masked by k < K below)
+    auto map_fetch = [&](int t) {
+        if constexpr (MAPS) {
+            int e = t * BK + wave * 8;
+            e = e < Kd ? e : 0;
+            if (map_a) sa = *reinterpret_cast<tnp_cptr8>(reinterpret_cast<uintptr_t>(map_a + e));
+            if (map_b) sb = *reinterpret_cast<tnp_cptr8>(reinterpret_cast<uintptr_t>(map_b + e));
+        }
+    };
+    auto sel4 = [&](const tnp_i32x8& s, int i) -> int {          // entry 4 i + lane / 16
+        const int v0 = i ? s[4] : s[0], v1 = i ? s[5] : s[1], v2 = i ? s[6] : s[2], v3 = i ? s[7] : s[3];
+        return g4 == 0 ? v0 : g4 == 1 ? v1 : g4 == 2 ? v2 : v3;
+    };
+    // DMA instruction idx (0, 1: A rows; 2, 3: B rows) of K tile t into the stage at sbase
+    auto issue_one = [&](auto idx_c, int t, char* sbase) {
+        constexpr int idx = decltype(idx_c)::value;
+        constexpr int i = idx & 1;
+        if constexpr (idx < 2) {
+            char* dst = sbase + (wave * 2 + i) * 1024;
+            if constexpr (MAPS) {
+                const int k = t * BK + wave * 8 + i * 4 + g4;
+                const int src = (sel4(sa, i) & amask) | (k & ~amask);
+                const bool ok = (src >= 0) & (k < Kd) & (((keep >> rs_s[i]) & 1ull) != 0ull);
+                tnp_dma16(rs_a, dst, ok ? (unsigned)src * (unsigned)lda2 + a_vo[i] : TNP_OOB);
+            } else {
+                tnp_dma16(rs_a, dst, a_vo[i]);
+                a_vo[i] += a_adv;
+            }
+        } else {
+            char* dst = sbase + TILE_BYTES + (wave * 2 + i) * 1024;
+            if constexpr (MAPS) {
+                const int k = t * BK + wave * 8 + i * 4 + g4;
+                const int src = (sel4(sb, i) & bmask) | (k & ~bmask);
+                const bool ok = (src >= 0) & (k < Kd);
+                tnp_dma16(rs_b, dst, ok ? (unsigned)src * (unsigned)ldb2 + b_vo[i] : TNP_OOB);
+            } else {
+                tnp_dma16(rs_b, dst, b_vo[i]);
+                b_vo[i] += b_adv;
+            }
+        }
+    };
+    auto issue_end = [&]() {
+        if constexpr (MAPS) {
+            if (has_rs) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    rs_k[i] += BK;
+                    const bool w = rs_k[i] >= rs_div;
+                    rs_k[i] -= w ? rs_div : 0;
+                    rs_s[i] += w ? 1 : 0;
+                }
+            }
+        }
+    };
+
+    // ---- fragment read addresses (bytes inside a stage): K row 8 (lane / 16) + (lane % 16) / 4 of the k-step, swizzled 32-byte slot of the
+    //      fragment's 16 columns, 8-byte half by the lane's low bits (gemm_tn_v2.hip's relA / relB) ---------------------------------------
+    const unsigned lds0 = lds_addr(smem);
+    unsigned a_tr[4], b_tr[2];
+    {
+        const int row_off = 8 * g4 + (l15 >> 2), sw = tn_swz<CH>(row_off);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            a_tr[f] = lds0 + (unsigned)(row_off * BT + ((((wi * 64) / 8 + 2 * f) ^ sw) + ((lane & 3) >> 1)) * 8 + (lane & 1) * 4) * 2u;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+            b_tr[f] = lds0 + (unsigned)TILE_BYTES + (unsigned)(row_off * BT + ((((wj * 32) / 8 + 2 * f) ^ sw) + ((lane & 3) >> 1)) * 8 + (lane & 1) * 4) * 2u;
+    }
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool cs_wave = (m.colsum != nullptr) && tile_j == 0 && wj == 0;
+    f32x4 cacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+    u64 fal[2][4], fah[2][4], fbl[2][2], fbh[2][2];
+    if constexpr (TNP_ABL & 2) {
+#pragma unroll
+        for (int b_ = 0; b_ < 2; ++b_) {
+#pragma unroll
+            for (int f_ = 0; f_ < 4; ++f_) { fal[b_][f_] = 0x3f803f803f803f80ull; fah[b_][f_] = 0x3f803f803f803f80ull; }
+#pragma unroll
+            for (int f_ = 0; f_ < 2; ++f_) { fbl[b_][f_] = 0x3f803f803f803f80ull; fbh[b_][f_] = 0x3f803f803f803f80ull; }
+        }
+    }
+#define TNP_LOAD(KS, dst, soff)                                                                                      \
+    do {                                                                                                              \
+        unsigned aa_[4], bb_[2];                                                                                      \
+        _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) aa_[f_] = a_tr[f_] + (soff);                                 \
+        _Pragma("unroll") for (int f_ = 0; f_ < 2; ++f_) bb_[f_] = b_tr[f_] + (soff);                                 \
+        if constexpr (!(TNP_ABL & 2)) {                                                                               \
+            tnp_issue_tr<4, HO, (KS) * KOFF>(aa_, fal[dst], fah[dst]);                                                \
+            tnp_issue_tr<2, HO, (KS) * KOFF>(bb_, fbl[dst], fbh[dst]);                                                \
+        }                                                                                                             \
+    } while (0)
+#define TNP_TIE(buf) do { tnp_tie<4>(fal[buf], fah[buf]); tnp_tie<2>(fbl[buf], fbh[buf]); } while (0)
+    // MFMA mi of a k-step (row-major over (A fragment, B fragment)): C^T fragment -- B as the first operand
+#define TNP_MFMA_ONE(buf, mi_)                                                                                        \
+    do {                                                                                                              \
+        constexpr int fi_ = (mi_) / 2, fj_ = (mi_) % 2;                                                               \
+        if constexpr (!(TNP_ABL & 1)) acc[fi_][fj_] = mfma16<bf16>(frag_from(fbl[buf][fj_], fbh[buf][fj_]), frag_from(fal[buf][fi_], fah[buf][fi_]), acc[fi_][fj_]); \
+    } while (0)
+#define TNP_COLSUM(buf)                                                                                               \
+    do {                                                                                                              \
+        if (cs_wave) {                                                                                                \
+            _Pragma("unroll") for (int fi_ = 0; fi_ < 4; ++fi_)                                                       \
+                cacc[fi_] = mfma16<bf16>(ones, frag_from(fal[buf][fi_], fah[buf][fi_]), cacc[fi_]);                   \
+        }                                                                                                             \
+    } while (0)
+
+    // ---- prologue: the first STAGES tiles -------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < STAGES; ++t) {
+        map_fetch(t);
+        tnp_static_for<L>([&](auto c) { issue_one(c, t, smem + t * STAGE_BYTES); });
+        issue_end();
+    }
+    wait_vmcnt<(STAGES - 1) * L>();                                // tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    TNP_LOAD(0, 0, 0u);
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int st = kt % STAGES;
+        const unsigned so = (unsigned)(st * STAGE_BYTES);
+        const unsigned sn = (unsigned)(((kt + 1) % STAGES) * STAGE_BYTES);
+        map_fetch(kt + STAGES);                                    // (scalar loads: complete at the lgkmcnt(0) in front of the barrier)
+        __builtin_amdgcn_sched_barrier(0);
+        // group 0: k-step 0          (in flight behind it: the fragments of k-step 1)
+        TNP_LOAD(1, 1, so);
+        tnp_wait<12>();
+        TNP_TIE(0);
+        tnp_static_for<8>([&](auto c) { TNP_MFMA_ONE(0, decltype(c)::value); });
+        TNP_COLSUM(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // group 1: k-step 1.  Behind the barrier every read of the tile has completed: its stage is refilled (tile kt + STAGES) while the group's
+        // MFMAs run -- two MFMAs, then one DMA instruction with its address arithmetic, four times -- and the next tile's first fragments are requested
+        tnp_wait<0>();
+        TNP_TIE(1);
+        if constexpr (TNP_ABL & 4) wait_vmcnt<0>(); else wait_vmcnt<(STAGES - 2) * L>();
+        __builtin_amdgcn_s_barrier();
+        TNP_LOAD(0, 0, sn);
+        __builtin_amdgcn_sched_barrier(0);
+        tnp_static_for<L>([&](auto c) {
+            constexpr int ci = decltype(c)::value;
+            TNP_MFMA_ONE(1, 2 * ci);
+            TNP_MFMA_ONE(1, 2 * ci + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(TNP_ABL & 4)) issue_one(c, kt + STAGES, smem + st * STAGE_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        TNP_COLSUM(1);
+        issue_end();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    tnp_wait<0>();                                                 // (the reads requested for the tile beyond K)
+    wait_vmcnt<0>();                                               // the tiles issued beyond K
+#undef TNP_COLSUM
+#undef TNP_MFMA_ONE
+#undef TNP_TIE
+#undef TNP_LOAD
+
+    // ---- epilogue: acc[fi][fj][r] = C[i0 + wi*64 + fi*16 + lane%16][j0 + wj*32 + fj*16 + 4 (lane/16) + r] ---------------------------------
+    const float alpha = m.alpha;
+    float* const Cp = m.C;
+    const int64_t ldc = m.ldc;
+    const bool accum = m.flags & TNP_ACCUMULATE, vec4 = m.flags & TNP_VEC4;
+    if (has_b) {
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            const int ii = i0 + wi * 64 + fi * 16 + l15;
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj) {
+                const int jj = j0 + wj * 32 + fj * 16 + 4 * g4;
+                if (ii < m.I && jj < m.J) {                        // (J % 4 == 0: the four columns of a lane are inside J together)
+                    float* dst = Cp + (int64_t)ii * ldc + jj;
+                    float4 v = make_float4(alpha * acc[fi][fj][0], alpha * acc[fi][fj][1], alpha * acc[fi][fj][2], alpha * acc[fi][fj][3]);
+                    if (vec4) {
+                        if (accum) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                        *reinterpret_cast<float4*>(dst) = v;
+                    } else {
+                        if (accum) { v.x += dst[0]; v.y += dst[1]; v.z += dst[2]; v.w += dst[3]; }
+                        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                    }
+                }
+            }
+        }
+    }
+    if (cs_wave && g4 == 0) {          // every row n of the ones-product holds the same sums: lanes of the first lane group write column i = lane % 16
+        const bool cat = (m.flags & TNP_COLSUM_ATOMIC) || accum;
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            const int ii = i0 + wi * 64 + fi * 16 + l15;
+            if (ii < m.I) {
+                float* cs = m.colsum + ii;
+                if (cat) atomicAdd(cs, alpha * cacc[fi][0]); else *cs = alpha * cacc[fi][0];
+            }
+        }
+    }
+}
+
+// blockIdx < g.tiles: output tile (XCD-contiguous order: the tiles of one XCD share operand panels); beyond: LayerNorm rider units (LPR > 0)
+template <int STAGES, int LPR>
+__global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const TnpGroup g, const TnpRider ln) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    if (bid >= g.tiles) {
+        if constexpr (LPR > 0) {
+            // two 256-thread LayerNorm units per workgroup (ln_bwd_body.h is written for 4 waves); an odd unit count repeats the last unit in the spare
+            // half: the same rows, the same values, written twice
+            int unit = 2 * (bid - g.tiles) + (int)(threadIdx.x >> 8);
+            unit = unit < ln.blocks ? unit : ln.blocks - 1;
+            layernorm_bwd_body<bf16, LPR, 1, 4, 0>(ln.dy, ln.x, nullptr, ln.gamma, ln.mean, ln.rstd, ln.dx, nullptr, nullptr, ln.partials, ln.dres, ln.rows, ln.C, nullptr,
+                                                   nullptr, unit, ln.blocks, (int)(threadIdx.x & 255), reinterpret_cast<float*>(smem + (threadIdx.x >> 8) * 16384));
+        }
+        return;
+    }
+    const int t = (g.dbg & 2) ? bid : xcd_tile_id(bid, g.tiles);
+    int k = 0;
+    while (k + 1 < g.n && t >= g.m[k].tile_end) ++k;
+    const TnpMember& m = g.m[k];
+    const int local = t - (k ? g.m[k - 1].tile_end : 0);
+    if (m.a_map || m.b_map || m.a_rs) tnp_tile<STAGES, true>(m, local, smem);
+    else tnp_tile<STAGES, false>(m, local, smem);
+}
+
+template <int STAGES, int LPR> void tnp_launch(const TnpGroup& g, const TnpRider& r, int rider_wgs, hipStream_t st) {
+    constexpr size_t lds = (size_t)STAGES * 2 * 64 * 128 * 2;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pipe_kernel<STAGES, LPR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_pipe_kernel<STAGES, LPR>), dim3(g.tiles + rider_wgs), dim3(512), lds, st, g, r);
+}
+
+}  // namespace
+
+struct lavt_ln_rider_t { const void* dy; const void* x; const float* gamma; const float* mean; const float* rstd; void* dx; float* partials; const void* dres; int rows, C; };
+int lavt_ln_bwd_geometry(int dtype, int rows, int C, int* lpr, int* cpl, int* waves);
+
+// The grouped weight-gradient launch on 128x128 pipelined tiles.  Returns 1 when the group does not qualify (the caller takes gemm_tn_v2.hip's
+// launch), LAVT_OK when it was launched (with the LayerNorm rider if `ln` was given), 3 when it was launched WITHOUT the rider it was offered.
+int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st, const lavt_ln_rider_t* ln) {
+    const lavt_tuning_t& tun = lavt_tuning();
+    if (tun.tn_pipe == 0 || n < 2 || n > TNP_MAX) return 1;
+    TnpGroup g;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const lavt_gemm_tn_t& p = probs[i];
+        const bool no_b = p.ldb == 0;                             // (the column-sum-only side member: B = the zero page)
+        if (p.dtype != LAVT_BF16 || p.batch != 1 || p.conv_kc > 0 || p.B2 || p.c_conv_permute) return 1;
+        if (p.I % 8 || p.J % 4 || p.lda % 8 || p.ldb % 8 || p.K < 64 || p.K > 128 * 64) return 1;
+        if ((int64_t)(p.K + 1024) * p.lda * 2 >= (1LL << 30) || (int64_t)(p.K + 1024) * p.ldb * 2 >= (1LL << 30)) return 1;          // 32-bit byte offsets inside a 2 GB descriptor, with room for the source rows of a mapped operand and the tiles issued beyond K
+        if (p.a_rowscale && (!p.a_rowscale_binary || p.a_rowscale_div < 64 || (p.K + p.a_rowscale_div - 1) / p.a_rowscale_div > 64)) return 1;
+        if ((p.a_rowmap || p.b_rowmap) && p.K % 8) return 1;     // a wave's eight K rows come from one aligned scalar load inside the map
+        if (no_b && !p.colsum) return 1;
+        if (!no_b && p.J % 8) return 1;
+        // a mapped operand is addressed by row index: the descriptor must span its whole tensor, whose extent the problem does not state -- 2 GB windows
+        TnpMember& m = g.m[i];
+        m.A = (const bf16*)p.A; m.B = (const bf16*)p.B; m.C = p.C; m.colsum = p.colsum;
+        m.a_map = p.a_rowmap; m.b_map = p.b_rowmap; m.a_rs = p.a_rowscale;
+        m.ldc = p.ldc; m.lda = (int)p.lda; m.ldb = (int)p.ldb; m.I = p.I; m.J = no_b ? 8 : p.J; m.K = p.K;
+        m.tiles_j = no_b ? 1 : cdiv(p.J, 128);
+        m.rs_div = p.a_rowscale ? p.a_rowscale_div : 1 << 30;
+        m.rs_n = p.a_rowscale ? (p.K + p.a_rowscale_div - 1) / p.a_rowscale_div : 0;
+        m.flags = (p.accumulate ? TNP_ACCUMULATE : 0) | (p.colsum_atomic ? TNP_COLSUM_ATOMIC : 0) | (no_b ? TNP_NO_B : 0) |
+                  ((((uintptr_t)p.C & 15) == 0 && p.ldc % 4 == 0) ? TNP_VEC4 : 0);
+        m.alpha = p.alpha;
+        tiles += cdiv(p.I, 128) * m.tiles_j;
+        m.tile_end = tiles;
+    }
+    for (int i = n; i < TNP_MAX; ++i) { g.m[i] = g.m[0]; g.m[i].tile_end = tiles; }
+    g.n = n; g.tiles = tiles; g.dbg = tun.probe[6];
+    if (tiles < tun.tn_pipe_min_tiles) return 1;                  // too few 128x128 tiles for the chip: the 64x64 launch (with K pieces) serves these
+    TnpRider r{};
+    int rider_wgs = 0, lpr = 0;
+    if (ln != nullptr) {
+        int cpl, waves;
+        const int blocks = lavt_ln_bwd_geometry(LAVT_BF16, ln->rows, ln->C, &lpr, &cpl, &waves);
+        if (waves == 4 && cpl == 1 && (lpr == 16 || lpr == 32 || lpr == 64) && blocks > 0) {
+            r = TnpRider{(const bf16*)ln->dy, (const bf16*)ln->x, ln->gamma, ln->mean, ln->rstd, (bf16*)ln->dx, ln->partials, (const bf16*)ln->dres, ln->rows, ln->C, blocks};
+            rider_wgs = (blocks + 1) / 2;
+        } else lpr = 0;
+    }
+    const int stages = tun.tn_pipe_stages == 3 ? 3 : 4;
+#define TNP_GO(S_)                                                                  \
+    do {                                                                            \
+        if (lpr == 64) tnp_launch<S_, 64>(g, r, rider_wgs, st);                     \
+        else if (lpr == 32) tnp_launch<S_, 32>(g, r, rider_wgs, st);                \
+        else if (lpr == 16) tnp_launch<S_, 16>(g, r, rider_wgs, st);                \
+        else tnp_launch<S_, 0>(g, r, 0, st);                                        \
+    } while (0)
+    if (stages == 3) TNP_GO(3); else TNP_GO(4);
+#undef TNP_GO
+    LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(pipe)");
+    return (ln != nullptr && lpr == 0) ? 3 : LAVT_OK;
+}

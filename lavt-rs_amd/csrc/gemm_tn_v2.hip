@@ -629,9 +629,14 @@ static bool tn_v2_eligible(const lavt_gemm_tn_t& p) {
 struct lavt_ln_rider_t { const void* dy; const void* x; const float* gamma; const float* mean; const float* rstd; void* dx; float* partials; const void* dres; int rows, C; };
 int lavt_ln_bwd_geometry(int dtype, int rows, int C, int* lpr, int* cpl, int* waves);
 // ln != NULL: a LayerNorm backward to run as rider workgroups of the launch; returns 3 when the group was launched WITHOUT it (the caller launches it)
+int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st, const lavt_ln_rider_t* ln);
 int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st, const lavt_ln_rider_t* ln) {
     const lavt_tuning_t& tun = lavt_tuning();
     if (tun.gemm_v2_off || n < 2 || n > TN_GROUP_MAX) return 1;
+    {   // short reductions on enough 128x128 tiles (the Swin-block groups of stages 2 / 3): the software-pipelined launch of gemm_tn_pipe.hip
+        const int rc = lavt_gemm_tn_grouped_pipe(probs, n, st, ln);
+        if (rc != 1) return rc;
+    }
     TnGroup g;
     bool maps = false;
     int tiles = 0;

@@ -47,6 +47,9 @@ void read_tuning(lavt_tuning_t& t) {
     t.tn_streamk = env_int("LAVT_TNG_STREAMK", 1);
     t.fp8_pipe_off = env_is("LAVT_FP8_PIPE", '0');               // e4m3 problems on gemm_v2.hip's K loop instead of the pipelined one (A/B switch)
     t.gemm_pipe = env_int("LAVT_GEMM_PIPE", 2);                  // gemm_nt_pipe.hip: 0 off, 1 the 256x256 tile, 2 + 128x128 tiles with K >= 1024, 3 + every 128x128 problem
+    t.tn_pipe = env_int("LAVT_TN_PIPE", 1);                      // gemm_tn_pipe.hip: grouped weight gradients on 128x128 pipelined tiles (0: always gemm_tn_v2.hip's 64x64 launch)
+    t.tn_pipe_min_tiles = env_int("LAVT_TN_PIPE_MIN_TILES", 128);
+    t.tn_pipe_stages = env_int("LAVT_TN_PIPE_STAGES", 4);
     for (int i = 0; i < 8; ++i) t.probe[i] = 0;
     if (const char* c = getenv("LAVT_PROBE")) sscanf(c, "%d,%d,%d,%d,%d,%d,%d,%d", &t.probe[0], &t.probe[1], &t.probe[2], &t.probe[3], &t.probe[4], &t.probe[5], &t.probe[6], &t.probe[7]);
 }

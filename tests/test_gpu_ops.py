@@ -824,6 +824,101 @@ def test_gemm_tn_grouped_matches_individual():
         assert float((cr - co).abs().max()) <= 2e-3 * float(cr.abs().max())
 
 
+@pytest.mark.parametrize("stages", ["4", "3"])
+@pytest.mark.parametrize("Kd", [1800, 7200, 456])
+def test_gemm_tn_grouped_pipelined_tiles(Kd, stages, monkeypatch, request):
+    """csrc/gemm_tn_pipe.hip (round 5: the grouped weight-gradient launch on 128x128 software-pipelined tiles -- buffer-descriptor LDS-DMA of two
+    k-major operand tiles, transposing fragment reads one MFMA group ahead, row maps through scalar loads, the DropPath mask as a keep bit per
+    sample, column sums on the matrix cores) against fp32 torch and against gemm_tn_v2.hip's 64x64 launch (LAVT_TN_PIPE=0): six members with
+    every feature at once -- tiles that overhang I and J (I = 192, J = 328), a K tail of 8 rows (1800 = 28 x 64 + 8; 456 = 7 x 64 + 8), a long chain
+    (7200 = 113 K tiles), gathered A rows with masked (-1) entries, gathered B rows, a row mask folded into alpha, accumulate into a non-zero C,
+    a column-sum-only member adding atomically into a bias gradient it shares with a second member, an unaligned C (4-byte stores) -- in both ring depths."""
+    from lavt_hip import _capi as K, ops
+    monkeypatch.setenv("LAVT_TN_PIPE_STAGES", stages)
+    monkeypatch.setenv("LAVT_TN_PIPE_MIN_TILES", "8")
+    request.addfinalizer(lambda: ([os.environ.pop(k, None) for k in ("LAVT_TN_PIPE", "LAVT_TN_PIPE_STAGES", "LAVT_TN_PIPE_MIN_TILES")], K.lib.lavt_tuning_reload()))
+    g = torch.Generator().manual_seed(77)
+    bf = torch.bfloat16
+    Ms = Kd + 640                                                               # rows of the gathered sources
+    def mk(rows, cols):
+        return (torch.randn(rows, cols, generator=g) * 0.5).to(dev()).to(bf)
+    amap = torch.randint(-1, Ms, (Kd,), generator=g, dtype=torch.int32).to(dev())
+    bmap = torch.randint(0, Ms, (Kd,), generator=g, dtype=torch.int32).to(dev())
+    nsmp = 4 if Kd % 4 == 0 else 2
+    mask = torch.tensor([1.0, 0.0, 1.0, 1.0][:nsmp]).to(dev())
+    shared_bias = lambda: torch.zeros(384, device=dev())
+    flat = torch.zeros(512 * 512 + 3, device=dev())
+    def members(bias):
+        return [
+            (2048, 512, mk(Kd, 2048), mk(Kd, 512), dict(), None),                                                              # plain (fc1)
+            (512, 2048, mk(Kd, 512), mk(Kd, 2048), dict(a_rowscale=mask, a_rowscale_div=Kd // nsmp, a_rowscale_binary=True, alpha=1.25), None),   # row mask (fc2 + DropPath)
+            (192, 328, mk(Ms, 192), mk(Ms, 328), dict(a_rowmap=amap, b_rowmap=bmap, accumulate=True), None),                  # both gathered, overhanging tiles, accumulate
+            (384, 8, mk(Ms, 384), None, dict(a_rowmap=bmap, colsum_atomic=True), bias),                                        # column sums only (padded rows' bias share)
+            (384, 256, mk(Ms, 384), mk(Kd, 256), dict(a_rowmap=amap, colsum_atomic=True), bias),                               # gathered A + shared bias gradient
+            (512, 512, mk(Kd, 512), mk(Kd, 512), dict(), "unaligned"),                                                         # C at a 12-byte offset
+        ]
+    def run(pipe):
+        monkeypatch.setenv("LAVT_TN_PIPE", pipe)
+        K.lib.lavt_tuning_reload()
+        g.manual_seed(77)
+        torch.randint(-1, Ms, (Kd,), generator=g); torch.randint(0, Ms, (Kd,), generator=g)          # (same operand stream in both runs)
+        bias = shared_bias()
+        structs, keep, outs = [], [], []
+        class _Q:
+            def add(self, p, t, extra=False, rider=None): structs.append(p); keep.append(t)
+        for I, J, A, B, kw, extra in members(bias):
+            if extra == "unaligned":
+                flat.zero_()
+                out = flat[3:3 + I * J].view(I, J)
+            else:
+                out = torch.full((I, J), 0.25 if kw.get("accumulate") else 0.0, device=dev())
+            cs = extra if torch.is_tensor(extra) else torch.zeros(I, device=dev())
+            if B is None:
+                ops.gemm_tn(bf, I, 8, Kd, A, I, ops._zero_page_tensor(dev()), 0, out, 8, colsum=cs, defer=_Q(), extra=True, **kw)
+            else:
+                ops.gemm_tn(bf, I, J, Kd, A, I, B, J, out, J, colsum=cs, defer=_Q(), **kw)
+            outs.append((out, cs, A, B, kw))
+        ops.assign_partials(structs, dev())
+        arr = (K.GemmTN * len(structs))(*structs)
+        K.check(K.lib.lavt_gemm_tn_grouped(arr, len(structs), K.stream()))
+        torch.cuda.synchronize()
+        return [(o.clone(), c.clone(), A, B, kw) for o, c, A, B, kw in outs]
+    new, old = run("1"), run("0")
+    rows = torch.arange(Kd, device=dev())
+    for idx, ((o, c, A, B, kw), (o0, c0, _, _, _)) in enumerate(zip(new, old)):
+        Af = A.float()
+        if "a_rowmap" in kw:
+            m = kw["a_rowmap"].long()
+            Af = torch.where(m[:, None] >= 0, Af[m.clamp(min=0)], torch.zeros(1, device=dev()))
+        if "a_rowscale" in kw:
+            Af = Af * mask[(rows // kw["a_rowscale_div"]).clamp(max=nsmp - 1)][:, None] * kw["alpha"]
+        if B is not None:
+            Bf = B.float()[kw["b_rowmap"].long()] if "b_rowmap" in kw else B.float()
+            ref = Af.t() @ Bf + (0.25 if kw.get("accumulate") else 0.0)
+            scale = float(ref.abs().max())
+            assert torch.isfinite(o).all(), idx
+            assert float((o - ref).abs().max()) <= 2e-3 * scale, (idx, float((o - ref).abs().max()) / scale)
+            assert float((o - ref).norm() / ref.norm()) <= 1e-4, idx                                    # exact bf16 products, fp32 sums
+            assert float((o - o0).abs().max()) <= 1e-3 * scale, idx                                    # and the 64x64 launch agrees
+        else:
+            assert float(o.abs().max()) == 0.0
+    bias_ref = sum(torch.where(kw["a_rowmap"].long()[:, None] >= 0, A.float()[kw["a_rowmap"].long().clamp(min=0)], torch.zeros(1, device=dev())).sum(0)
+                   for o, c, A, B, kw in new if kw.get("colsum_atomic"))
+    for res in (new, old):
+        got = res[3][1]
+        assert float((got - bias_ref).abs().max()) <= 2e-3 * float(bias_ref.abs().max())
+    for idx in (0, 1, 2, 5):
+        c, A, kw = new[idx][1], new[idx][2], new[idx][4]
+        Af = A.float()
+        if "a_rowmap" in kw:
+            m = kw["a_rowmap"].long()
+            Af = torch.where(m[:, None] >= 0, Af[m.clamp(min=0)], torch.zeros(1, device=dev()))
+        if "a_rowscale" in kw:
+            Af = Af * mask[(rows // kw["a_rowscale_div"]).clamp(max=nsmp - 1)][:, None] * kw["alpha"]
+        cref = Af.sum(0)
+        assert float((c - cref).abs().max()) <= 2e-3 * float(cref.abs().max()), idx
+
+
 @pytest.mark.parametrize("B,H,ws,shift,Cc", [(2, 30, 12, 6, 512), (2, 15, 12, 0, 1024), (3, 10, 7, 3, 256), (8, 30, 12, 6, 512)])
 def test_gemm_tn_token_order_matches_window_order(B, H, ws, shift, Cc):
     """The windowed members of a Swin block's grouped weight-gradient launch in TOKEN order (contraction over the real tokens through the inverse
@@ -927,10 +1022,12 @@ def test_gemm_tn_grouped_streamk(B, H, ws, shift, Cc):
     assert torch.equal(a["qkv.b"], b["qkv.b"])
 
 
-@pytest.mark.parametrize("Cc,T", [(512, 1800), (128, 28800), (256, 7200), (1024, 450)])
+@pytest.mark.parametrize("Cc,T", [(512, 1800), (128, 28800), (256, 7200), (1024, 450), (512, 1804), (256, 3600)])
 def test_grouped_wgrad_with_layernorm_rider(Cc, T):
     """lavt_gemm_tn_grouped_ln: the partial-sum LayerNorm backward as rider workgroups of a Swin block's grouped weight-gradient launch (C = 1024 and
-    groups that do not form fall back to two launches inside the call) -- dx and the per-workgroup d gamma / d beta partials bit-identical to
+    groups that do not form fall back to two launches inside the call; (512, 1800) rides on the 128x128 pipelined launch of round 5 as two 256-thread
+    units per 512-thread workgroup, (512, 1804) with an odd unit count -- the spare half repeats the last unit --, (256, 3600) with 32 lanes per row)
+    -- dx and the per-workgroup d gamma / d beta partials bit-identical to
     lavt_layernorm_bwd_partial on its own, the weight gradients identical to lavt_gemm_tn_grouped."""
     from lavt_hip import _capi as K, ops
     g = torch.Generator().manual_seed(11)

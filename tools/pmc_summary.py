@@ -3,7 +3,7 @@
 usage: pmc_summary.py <gpurun_out/r02_pmc> <out.json>"""
 import csv, glob, json, os, sys
 root, out = sys.argv[1], sys.argv[2]
-TARGET = {"conv_one": ["gemm_nt_pipe_kernel<256, 256, false, 2, 2, 2"], "wgrad_group_one": ["gemm_tn_v2_grouped_kernel"],
+TARGET = {"conv_one": ["gemm_nt_pipe_kernel<256, 256, false, 2, 2, 2"], "wgrad_group_one": ["gemm_tn_pipe_kernel", "gemm_tn_v2_grouped"],
           "attn_one": ["wattn_bwd_mfma", "wattn_fwd_mfma"], "wmsa_one": ["wmsa_fwd_fused_kernel"], "conv_wgrad_one": ["conv_wgrad3x3_kernel"],
           "conv_fp8_one": ["gemm_nt_pipe_kernel<256, 256, false, 2, 2, 2, true"]}
 
@@ -36,6 +36,8 @@ def derive(c, us):
             ("VALU incl. MFMA issue (SQ_ACTIVE_INST_VALU)", "SQ_ACTIVE_INST_VALU")) if n in c}
     if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
         d["lds_bank_conflict_frac_of_lds_cycles"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4)
+    if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0:
+        d["l2_hit_rate (TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum))"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         d["fabric_bytes (FETCH_SIZE KB x2 gfx950 correction + WRITE_SIZE KB)"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
     return d
