@@ -153,6 +153,19 @@ __device__ __forceinline__ float act_grad(int act, float pre) {
 // lanes g and g ^ 1 swap one packed pair (ds_bpermute, no memory), after which an even group owns columns 4g .. 4g+7 of the first fragment and
 // an odd group columns 4(g-1) .. 4(g-1)+7 of the second -- one 16-byte store per lane, 64 contiguous bytes per row per wave-instruction, half
 // the store instructions.  Bias is read as float4.  Conditions are checked by the caller (whole 32-column pairs inside N, 16-byte aligned rows).
+// 16-byte output store of the wide epilogue: write-through (`sc0 sc1`) -- the bytes leave the XCD's L2 as they are stored instead of at the kernel's
+// end-of-launch release (MI355X_MICROARCH.md, price list: a dependent kernel boundary costs + B / 6 TB/s behind B dirty bytes; the consumer launch
+// reads them from another XCD's side of the fabric seven times out of eight anyway).  Round 5, same box, alternating libraries: 7.832 / 7.828 ms per
+// step against 7.866 / 7.851 with plain stores (-DLAVT_ST_PLAIN builds the plain form).
+__device__ __forceinline__ void st16_out(void* p, const uint4& v) {
+#if !defined(LAVT_ST_PLAIN)
+    typedef unsigned st16_u32x4 __attribute__((ext_vector_type(4)));
+    const st16_u32x4 w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
 __device__ __forceinline__ uint2 xchg16(uint2 v) { return make_uint2((unsigned)__shfl_xor((int)v.x, 16, 64), (unsigned)__shfl_xor((int)v.y, 16, 64)); }
 // LEAN: the launch uses none of {activation, multiplier, second (pre-activation) output, split output}: those branches are compiled out.  Carrying
 // them as not-taken uniform branches costs every plain GEMM of the step (tools/ab_lib.sh: -0.2 ms per step with all of them compiled out, of which
@@ -283,12 +296,12 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32
             if (p.Cpre) {
                 const uint2 gp = xchg16(odd ? packed_pre[0] : packed_pre[1]);
                 const uint4 op = odd ? make_uint4(gp.x, gp.y, packed_pre[1].x, packed_pre[1].y) : make_uint4(packed_pre[0].x, packed_pre[0].y, gp.x, gp.y);
-                if (live) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.Cpre) + (int64_t)orow * p.ldcpre + n_out) = op;
+                if (live) st16_out(reinterpret_cast<bf16*>(p.Cpre) + (int64_t)orow * p.ldcpre + n_out, op);
             }
             if (live) {
                 const bool second = p.C2 != nullptr && n_out >= p.c_split;
                 bf16* cp = reinterpret_cast<bf16*>(second ? p.C2 : p.C) + c_off + (int64_t)orow * (second ? p.ldc2 : p.ldc) + (second ? n_out - p.c_split : n_out);
-                *reinterpret_cast<uint4*>(cp) = out;
+                st16_out(cp, out);
             }
         }
     }

@@ -62,6 +62,10 @@ template <int NF, int HO, int KOFF> __device__ __forceinline__ void tnp_issue_tr
                      "ds_read_b64_tr_b16 %2, %5 offset:%c7\n\tds_read_b64_tr_b16 %3, %5 offset:%c7+%c6"
                      : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]) : "v"(a[0]), "v"(a[1]), "n"(HO), "n"(KOFF) : "memory");
 }
+template <int OFF> __device__ __forceinline__ void tnp_rd1(unsigned a, u64& d) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%c2" : "=&v"(d) : "v"(a), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void tnp_tie1(u64& l, u64& h) { asm volatile("" : "+v"(l), "+v"(h)); }
 template <int CNT> __device__ __forceinline__ void tnp_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory"); }
 // ties registers to the wait in front of it (consumers cannot be scheduled above this empty statement, which stays behind the wait)
 template <int N> __device__ __forceinline__ void tnp_tie(u64 (&l)[N], u64 (&h)[N]) {
@@ -92,7 +96,8 @@ struct TnpRider {
 
 constexpr unsigned TNP_OOB = 0x80000000u;
 // Ablation builds (tools/r05_tnp_ablate.sh compiles this file with -DTNP_ABL=n into libraries OUTSIDE the shipped one; the shipped build has no switch):
-// bit 0: no MFMAs; bit 1: no fragment reads; bit 2: no DMA inside the K loop (the ring keeps the prologue's tiles)
+// bit 0: no MFMAs; bit 1: no fragment reads; bit 2: no DMA inside the K loop (the ring keeps the prologue's tiles); bit 3: ONE K tile (what a launch costs
+// outside its K loop: dispatch, prologue, epilogue)
 #ifndef TNP_ABL
 #define TNP_ABL 0
 #endif
@@ -104,13 +109,13 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
     constexpr int BT = 128, BK = 64, CH = BT / 8, L = 4;
     constexpr int TILE_BYTES = BK * BT * 2, STAGE_BYTES = 2 * TILE_BYTES;
     constexpr int HO = 4 * BT * 2, KOFF = 32 * BT * 2;
-    static_assert(STAGES >= 3 && STAGES <= 4, "ring depth");
+    static_assert(STAGES >= 3 && STAGES <= 5, "ring depth (5 x 32 KB = the whole 160 KB of a CU)");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 2, wj = wave & 3;                       // 2 (i) x 4 (j) waves: wave tile 64 x 32
     const int l15 = lane & 15, g4 = lane >> 4;
     const int tile_i = tile / m.tiles_j, tile_j = tile - tile_i * m.tiles_j;
     const int i0 = tile_i * BT, j0 = tile_j * BT;
-    const int Kd = m.K, ktiles = (Kd + BK - 1) / BK;
+    const int Kd = m.K, ktiles = (TNP_ABL & 8) ? 1 : (Kd + BK - 1) / BK;
     const int lda2 = m.lda * 2, ldb2 = m.ldb * 2;                 // row strides in bytes
     const bool has_b = !(m.flags & TNP_NO_B);
 
@@ -247,17 +252,22 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
             for (int f_ = 0; f_ < 2; ++f_) { fbl[b_][f_] = 0x3f803f803f803f80ull; fbh[b_][f_] = 0x3f803f803f803f80ull; }
         }
     }
-#define TNP_LOAD(KS, dst, soff)                                                                                      \
-    do {                                                                                                              \
-        unsigned aa_[4], bb_[2];                                                                                      \
-        _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) aa_[f_] = a_tr[f_] + (soff);                                 \
-        _Pragma("unroll") for (int f_ = 0; f_ < 2; ++f_) bb_[f_] = b_tr[f_] + (soff);                                 \
-        if constexpr (!(TNP_ABL & 2)) {                                                                               \
-            tnp_issue_tr<4, HO, (KS) * KOFF>(aa_, fal[dst], fah[dst]);                                                \
-            tnp_issue_tr<2, HO, (KS) * KOFF>(bb_, fbl[dst], fbh[dst]);                                                \
-        }                                                                                                             \
-    } while (0)
-#define TNP_TIE(buf) do { tnp_tie<4>(fal[buf], fah[buf]); tnp_tie<2>(fbl[buf], fbh[buf]); } while (0)
+    // The 12 transposing reads of a k-step, as a list r = 0 .. 11 in the order their data is needed: B fragments first (every MFMA takes one), then the A
+    // fragments in MFMA order.  Read r of (k-step KS, stage offset in aa_ / bb_) into register buffer `dst`.
+    unsigned aa_[4], bb_[2];
+    auto rd_addr = [&](unsigned soff) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) aa_[f] = a_tr[f] + soff;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) bb_[f] = b_tr[f] + soff;
+    };
+    auto rd = [&](auto r_c, auto ks_c, auto dst_c) {
+        constexpr int r = decltype(r_c)::value, KS = decltype(ks_c)::value, dst = decltype(dst_c)::value;
+        if constexpr (!(TNP_ABL & 2)) {
+            if constexpr (r < 4) tnp_rd1<KS * KOFF + (r & 1) * HO>(bb_[r >> 1], (r & 1) ? fbh[dst][r >> 1] : fbl[dst][r >> 1]);
+            else tnp_rd1<KS * KOFF + (r & 1) * HO>(aa_[(r - 4) >> 1], (r & 1) ? fah[dst][(r - 4) >> 1] : fal[dst][(r - 4) >> 1]);
+        }
+    };
     // MFMA mi of a k-step (row-major over (A fragment, B fragment)): C^T fragment -- B as the first operand
 #define TNP_MFMA_ONE(buf, mi_)                                                                                        \
     do {                                                                                                              \
@@ -271,6 +281,47 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
                 cacc[fi_] = mfma16<bf16>(ones, frag_from(fal[buf][fi_], fah[buf][fi_]), cacc[fi_]);                   \
         }                                                                                                             \
     } while (0)
+    // One MFMA group = the 8 MFMAs of a k-step (buffer CUR) with the 12 reads of the NEXT k-step (into buffer 1 - CUR) spread between them, three per
+    // MFMA pair: a burst of 12 reads in front of a group (the first form of this kernel) kept the matrix pipe of every wave idle while the LDS unit
+    // worked through 96 instructions -- MFMA + reads alone took 24.7 us of the 38 us launch (profiles/r05_a_tnp_ablate_burst_reads.txt).
+    // Counted waits: reads return in order, so at the start of a group all but the last three of the CURRENT k-step's reads (A fragments 2.h, 3.l, 3.h)
+    // have landed (lgkmcnt(3)) -- enough for MFMAs 0 .. 3 --, and after the first six new reads have been issued lgkmcnt(6) covers the rest.
+    // BARRIER (second group of a K tile): every read of the tile must have completed before its stage is refilled: lgkmcnt(0), then the tile-landed wait
+    // and the barrier, and the new reads are those of the next tile's first k-step; the stage is refilled one DMA instruction per MFMA pair.
+#define TNP_GROUP(CUR, NKS, nsoff, BARRIER, kt_)                                                                      \
+    do {                                                                                                              \
+        if constexpr (BARRIER) {                                                                                      \
+            tnp_wait<0>();                                                                                            \
+            tnp_tie<4>(fal[CUR], fah[CUR]); tnp_tie<2>(fbl[CUR], fbh[CUR]);                                           \
+            if constexpr (TNP_ABL & 4) wait_vmcnt<0>(); else wait_vmcnt<(STAGES - 2) * L>();                          \
+            __builtin_amdgcn_s_barrier();                                                                             \
+        } else {                                                                                                      \
+            tnp_wait<3>();                                                                                            \
+            tnp_tie<2>(fbl[CUR], fbh[CUR]); tnp_tie1(fal[CUR][0], fah[CUR][0]); tnp_tie1(fal[CUR][1], fah[CUR][1]);   \
+        }                                                                                                             \
+        rd_addr(nsoff);                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        tnp_static_for<4>([&](auto c_) {                                                                              \
+            constexpr int ci_ = decltype(c_)::value;                                                                  \
+            if constexpr (!(BARRIER) && ci_ == 2) {                                                                   \
+                tnp_wait<6>();                                                                                        \
+                tnp_tie1(fal[CUR][2], fah[CUR][2]); tnp_tie1(fal[CUR][3], fah[CUR][3]);                               \
+            }                                                                                                         \
+            rd(std::integral_constant<int, 3 * ci_>{}, std::integral_constant<int, NKS>{}, std::integral_constant<int, 1 - (CUR)>{});      \
+            rd(std::integral_constant<int, 3 * ci_ + 1>{}, std::integral_constant<int, NKS>{}, std::integral_constant<int, 1 - (CUR)>{});  \
+            rd(std::integral_constant<int, 3 * ci_ + 2>{}, std::integral_constant<int, NKS>{}, std::integral_constant<int, 1 - (CUR)>{});  \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            TNP_MFMA_ONE(CUR, 2 * ci_);                                                                               \
+            TNP_MFMA_ONE(CUR, 2 * ci_ + 1);                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            if constexpr (BARRIER) {                                                                                  \
+                if constexpr (!(TNP_ABL & 4)) issue_one(c_, (kt_) + STAGES, smem + ((kt_) % STAGES) * STAGE_BYTES);   \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+            }                                                                                                         \
+        });                                                                                                           \
+        TNP_COLSUM(CUR);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    } while (0)
 
     // ---- prologue: the first STAGES tiles -------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -281,46 +332,23 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
     }
     wait_vmcnt<(STAGES - 1) * L>();                                // tile 0 landed
     __builtin_amdgcn_s_barrier();
-    TNP_LOAD(0, 0, 0u);
+    rd_addr(0u);
+    tnp_static_for<12>([&](auto r) { rd(r, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); });
     for (int kt = 0; kt < ktiles; ++kt) {
-        const int st = kt % STAGES;
-        const unsigned so = (unsigned)(st * STAGE_BYTES);
+        const unsigned so = (unsigned)((kt % STAGES) * STAGE_BYTES);
         const unsigned sn = (unsigned)(((kt + 1) % STAGES) * STAGE_BYTES);
         map_fetch(kt + STAGES);                                    // (scalar loads: complete at the lgkmcnt(0) in front of the barrier)
         __builtin_amdgcn_sched_barrier(0);
-        // group 0: k-step 0          (in flight behind it: the fragments of k-step 1)
-        TNP_LOAD(1, 1, so);
-        tnp_wait<12>();
-        TNP_TIE(0);
-        tnp_static_for<8>([&](auto c) { TNP_MFMA_ONE(0, decltype(c)::value); });
-        TNP_COLSUM(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // group 1: k-step 1.  Behind the barrier every read of the tile has completed: its stage is refilled (tile kt + STAGES) while the group's
-        // MFMAs run -- two MFMAs, then one DMA instruction with its address arithmetic, four times -- and the next tile's first fragments are requested
-        tnp_wait<0>();
-        TNP_TIE(1);
-        if constexpr (TNP_ABL & 4) wait_vmcnt<0>(); else wait_vmcnt<(STAGES - 2) * L>();
-        __builtin_amdgcn_s_barrier();
-        TNP_LOAD(0, 0, sn);
-        __builtin_amdgcn_sched_barrier(0);
-        tnp_static_for<L>([&](auto c) {
-            constexpr int ci = decltype(c)::value;
-            TNP_MFMA_ONE(1, 2 * ci);
-            TNP_MFMA_ONE(1, 2 * ci + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(TNP_ABL & 4)) issue_one(c, kt + STAGES, smem + st * STAGE_BYTES);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        TNP_COLSUM(1);
+        TNP_GROUP(0, 1, so, false, kt);                            // k-step 0; the reads of k-step 1 between its MFMAs
+        TNP_GROUP(1, 0, sn, true, kt);                             // k-step 1; barrier, the next tile's first reads and the refill of this tile's stage
         issue_end();
         __builtin_amdgcn_sched_barrier(0);
     }
     tnp_wait<0>();                                                 // (the reads requested for the tile beyond K)
     wait_vmcnt<0>();                                               // the tiles issued beyond K
+#undef TNP_GROUP
 #undef TNP_COLSUM
 #undef TNP_MFMA_ONE
-#undef TNP_TIE
-#undef TNP_LOAD
 
     // ---- epilogue: acc[fi][fj][r] = C[i0 + wi*64 + fi*16 + lane%16][j0 + wj*32 + fj*16 + 4 (lane/16) + r] ---------------------------------
     const float alpha = m.alpha;
@@ -361,7 +389,7 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
     }
 }
 
-// blockIdx < g.tiles: output tile (XCD-contiguous order: the tiles of one XCD share operand panels); beyond: LayerNorm rider units (LPR > 0)
+// blockIdx < g.tiles: output tile; beyond: LayerNorm rider units (LPR > 0)
 template <int STAGES, int LPR>
 __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const TnpGroup g, const TnpRider ln) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -377,7 +405,8 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const TnpGroup g, con
         }
         return;
     }
-    const int t = (g.dbg & 2) ? bid : xcd_tile_id(bid, g.tiles);
+    // (tile = block index: an XCD-contiguous order measured 1 us slower -- 38.3 vs 37.2 us -- the eight L2s then see the members one after the other)
+    const int t = (g.dbg & 2) ? xcd_tile_id(bid, g.tiles) : bid;
     int k = 0;
     while (k + 1 < g.n && t >= g.m[k].tile_end) ++k;
     const TnpMember& m = g.m[k];
@@ -445,7 +474,7 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
             rider_wgs = (blocks + 1) / 2;
         } else lpr = 0;
     }
-    const int stages = tun.tn_pipe_stages == 3 ? 3 : 4;
+    const int stages = tun.tn_pipe_stages == 3 ? 3 : tun.tn_pipe_stages == 5 ? 5 : 4;
 #define TNP_GO(S_)                                                                  \
     do {                                                                            \
         if (lpr == 64) tnp_launch<S_, 64>(g, r, rider_wgs, st);                     \
@@ -453,7 +482,7 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
         else if (lpr == 16) tnp_launch<S_, 16>(g, r, rider_wgs, st);                \
         else tnp_launch<S_, 0>(g, r, 0, st);                                        \
     } while (0)
-    if (stages == 3) TNP_GO(3); else TNP_GO(4);
+    if (stages == 3) TNP_GO(3); else if (stages == 5) TNP_GO(5); else TNP_GO(4);
 #undef TNP_GO
     LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(pipe)");
     return (ln != nullptr && lpr == 0) ? 3 : LAVT_OK;

@@ -10,7 +10,10 @@ from gemm_bench import timeit
 dev, bf = torch.device("cuda:0"), torch.bfloat16
 g = torch.Generator().manual_seed(3)
 mk = lambda r, c: (torch.randn(r, c, generator=g) * 0.5).to(dev).to(bf)
-for (B, H, ws, shift, Cc) in ((2, 30, 12, 6, 512), (2, 60, 12, 6, 256), (2, 120, 12, 6, 128)):
+CFGS = ((2, 30, 12, 6, 512), (2, 60, 12, 6, 256), (2, 120, 12, 6, 128))
+if os.environ.get("TNP_SCALING"):          # the stage-2 group at 2 / 4 / 6 / 8 images: time against K = 1800 .. 7200 rows (slope = us per K tile, intercept = the launch's fixed cost)
+    CFGS = tuple((b, 30, 12, 6, 512) for b in (2, 4, 6, 8))
+for (B, H, ws, shift, Cc) in CFGS:
     inv, pad = rowmaps.window_inverse(B, H, H, ws, shift, dev), rowmaps.window_pad_rows(B, H, H, ws, shift, dev)
     T, Mw = B * H * H, B * (-(-H // ws) * ws) ** 2
     dqkv, xn, dy, o = mk(Mw, 3 * Cc), mk(T, Cc), mk(T, Cc), mk(Mw, Cc)
