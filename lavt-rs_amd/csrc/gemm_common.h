@@ -161,7 +161,9 @@ __device__ __forceinline__ void st16_out(void* p, const uint4& v) {
 #if !defined(LAVT_ST_PLAIN)
     typedef unsigned st16_u32x4 __attribute__((ext_vector_type(4)));
     const st16_u32x4 w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+    // (s_nop 1: a VMEM store of more than 8 bytes reads its data registers after issue -- the next instruction must not overwrite them; hipcc's hazard
+    // recogniser inserts the wait state for its own stores, it cannot see into an asm statement.  Without it the 256x256 instantiations stored garbage.)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 #else
     *reinterpret_cast<uint4*>(p) = v;
 #endif

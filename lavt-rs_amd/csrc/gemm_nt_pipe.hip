@@ -40,12 +40,16 @@ typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
 __device__ __forceinline__ buf_rsrc_t buf_make(const void* base) {          // 2 GB window, raw (stride 0) addressing, offsets beyond it read zero
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
+__device__ __forceinline__ buf_rsrc_t buf_make_n(const void* base, unsigned bytes) {          // offsets >= bytes read zero
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
 __device__ __forceinline__ void buf_dma16(buf_rsrc_t rs, void* lds_dst, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, voff, soff, 0, 0);
 }
 #else
 struct buf_rsrc_t { int unused; };
 __host__ __device__ inline buf_rsrc_t buf_make(const void*) { return buf_rsrc_t{0}; }
+__host__ __device__ inline buf_rsrc_t buf_make_n(const void*, unsigned) { return buf_rsrc_t{0}; }
 __host__ __device__ inline void buf_dma16(buf_rsrc_t, void*, unsigned, unsigned) {}
 #endif
 
@@ -165,7 +169,10 @@ __device__ __forceinline__ void pipe_colstats(const lavt_gemm_nt_t& p, const f32
 // fragments x every B fragment x both k-steps) instead of over k-steps: same register budget, same counted waits (see the F8 branch of the K loop).
 template <int BM, int BN, bool BKM, int STAGES, int MODE, int LEAN, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t p) {
-    constexpr bool SIMPLE = MODE == 1, CONVFAST = MODE == 2;
+    // MODE 3 (round 5): the tap-walking issue for a channel count that is not a multiple of 64 (Swin-T's conv1_2: 384 + 96 = 480 input channels,
+    // reference lib/mask_predictor.py:30-38): the LAST 64-channel block of the reduction is partial, its missing 16-byte chunks are offsets beyond the
+    // descriptors' range (zeros) in both operands -- instead of the general decode (MODE 0: per-instruction divisions, 0.19 of peak on that convolution)
+    constexpr bool SIMPLE = MODE == 1, CONVFAST = MODE == 2 || MODE == 3, CTAIL = MODE == 3;
     using T = typename std::conditional<F8, unsigned char, bf16>::type;
     constexpr int WAVES = 8, BK = F8 ? 128 : 64, EPC = F8 ? 16 : 8, ES = (int)sizeof(T);
     static_assert(!(F8 && BKM), "fp8: k-contiguous operands");
@@ -302,7 +309,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
     const unsigned bias1 = (unsigned)((int64_t)max_rows * lda1 * ES), bias2 = (unsigned)((int64_t)max_rows * lda2 * ES);
     buf_rsrc_t rs_a = buf_make(reinterpret_cast<const char*>(A) - bias1);
     const buf_rsrc_t rs_a2 = buf_make(reinterpret_cast<const char*>(A2 ? A2 : A) - bias2);
-    const buf_rsrc_t rs_b = buf_make(B);
+    // (CTAIL: the weight descriptor ends with the weights -- the partial block of the last row's last tap would otherwise read past the allocation)
+    const buf_rsrc_t rs_b = CTAIL ? buf_make_n(B, (unsigned)((int64_t)p.N * p.ldb * ES)) : buf_make(B);
     unsigned cur_bias = bias1;
     if (CONVFAST && has_a2 && c_kin >= a_split) {          // (a channel-split entry that starts inside the second source)
 #pragma unroll
@@ -318,6 +326,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
     bool u_past = false;
     unsigned u_bit = 0;
     int u_kt = 0;
+    int u_nch = 8;          // CTAIL: 16-byte chunks of the current channel block that hold channels (8 everywhere but in the last, partial block)
     // Row offset of every tap, ((dz h + dy) w + dx) rows of the current source in BYTES, as a table over the lanes (lane t = tap t, taps <= 32): the K loop
     // fetches its tap's entry with one v_readlane.  (Kept as running (dz, dy, dx) + a 64-bit multiply per K tile the tap walk was ~70 scalar
     // instructions per wave per K tile -- 5.5 x the plain GEMM's, on the ONE scalar unit a CU's eight waves share: rocprofv3 SQ_INSTS_SALU 11.8 M vs
@@ -341,6 +350,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
             u_soff_a = cur_bias + (unsigned)(__builtin_amdgcn_readlane(tap_sh, c_tap) + (c_kin - cur_base) * ES);
             u_bit = past ? 0u : 1u << c_tap;                                          // (a tile beyond K: every A lane out of range, B from the start of the rows)
             u_soff_b = past ? 0u : (BKM ? c_bbo : (unsigned)(c_boff * ES));
+            if constexpr (CTAIL) u_nch = min(8, (conv_kc - c_kin) >> 3);
         }
     };
     auto issue_one = [&](auto idx_c, char* sbase) {
@@ -352,7 +362,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
                 dma16(u_past ? Z : a_ptr[i], dst);
                 a_ptr[i] += a_step[i];
             } else if constexpr (CONVFAST) {
-                buf_dma16(rs_a, dst, (a_vmask[i] & u_bit) ? a_vo[i] : BUF_OOB, u_soff_a);
+                if constexpr (CTAIL) buf_dma16(rs_a, dst, ((a_vmask[i] & u_bit) && cl < u_nch) ? a_vo[i] : BUF_OOB, u_soff_a);
+                else buf_dma16(rs_a, dst, (a_vmask[i] & u_bit) ? a_vo[i] : BUF_OOB, u_soff_a);
             } else {
                 const int k = u_kt * BK + cl * EPC;
                 int kin = k, dz = 0, dy = 0, dx = 0;
@@ -377,7 +388,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
                 dma16(u_past ? Z : b_ptr[i], dst);
                 b_ptr[i] += b_step[i];
             } else if constexpr (CONVFAST) {
-                buf_dma16(rs_b, dst, b_vo[i], u_soff_b);
+                if constexpr (CTAIL && !BKM) buf_dma16(rs_b, dst, cl < u_nch ? b_vo[i] : BUF_OOB, u_soff_b);
+                else buf_dma16(rs_b, dst, b_vo[i], u_soff_b);
             } else {
                 const int k = u_kt * BK + cl * EPC;
                 const T* g = Z;
@@ -490,7 +502,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const lavt_gemm_nt_t 
     } while (0)
     static_assert((MIH * NI) % L == 0, "MFMAs of the last group spread evenly over the DMA instructions");
 
-    const int ktiles = (p.K + BK - 1) / BK;
+    // (CTAIL: a K tile is a (channel block, tap) pair and the last block is partial: taps x ceil(channels / 64) tiles)
+    const int ktiles = CTAIL ? c_ntap * ((conv_kc + BK - 1) / BK) : (p.K + BK - 1) / BK;
 #pragma unroll
     for (int t = 0; t < STAGES; ++t) {
         issue_begin(t, t >= ktiles);
@@ -702,6 +715,12 @@ template <int BM, int BN, bool BKM, int STAGES> int launch_pipe(const lavt_gemm_
     const bool convfast = p.conv_kc > 0 && p.conv_kc % 64 == 0 && (p.A2 == nullptr || p.a_split % 64 == 0) && conv_taps_of(p) <= 32 && small;
     if (simple && !lavt_tuning().gemm_general) return launch_pipe_lean<BM, BN, BKM, STAGES, 1>(p, st);
     if (convfast && !lavt_tuning().gemm_general) return launch_pipe_lean<BM, BN, BKM, STAGES, 2>(p, st);
+    if constexpr (!BKM) {          // k-contiguous weights [Cout][taps][Cin] with Cin % 64 != 0 (Cin % 8 == 0; a concat boundary on a 64-channel block): the partial-block form
+        const bool convtail = p.conv_kc > 0 && p.conv_kc % 64 != 0 && p.conv_kc % 8 == 0 && (p.A2 == nullptr || p.a_split % 64 == 0) && conv_taps_of(p) <= 32 && small &&
+                              p.conv_kc_split <= 0 && p.conv_tap_split <= 0 && p.batch == 1 && p.K == conv_taps_of(p) * p.conv_kc && p.ldb >= (int64_t)conv_taps_of(p) * p.conv_kc &&
+                              !lavt_tuning().conv_tail_off;
+        if (convtail && !lavt_tuning().gemm_general) return launch_pipe_lean<BM, BN, BKM, STAGES, 3>(p, st);
+    }
     return launch_pipe_lean<BM, BN, BKM, STAGES, 0>(p, st);
 }
 

@@ -159,7 +159,9 @@ def test_gemm_pipelined_k_loop(tile, stages, monkeypatch, request):
     # (no fp32 instantiation of this kernel exists, so its index arithmetic -- tap walking, halo zeros through out-of-range buffer offsets, channel-split
     # pieces -- is gated norm-wise (5e-3) and on the border pixels alone (8e-3 x max|ref|) next to the max-norm; the last shapes are the products' own:
     # Swin-T's 384 + 96 -> 384 concat convolution at 2 x 120 x 120 and, on the default configuration, Swin-B's 512 -> 512 at 4 x 120 x 120)
-    real = ((2, 120, 120, 384, 96, 384),) + (((4, 120, 120, 512, 0, 512),) if tile == "512" else ())
+    # (round 5: channel counts that are not a multiple of 64 take the tap walk with a partial last block -- MODE 3 -- when the concat boundary sits on a
+    # 64-channel block: 384 + 96 (Swin-T conv1_2), a single source of 96 / 160 channels, 128 + 40 (a 5-chunk tail))
+    real = ((2, 120, 120, 384, 96, 384), (1, 20, 20, 96, 0, 128), (2, 9, 20, 160, 0, 256), (1, 24, 24, 128, 40, 256)) + (((4, 120, 120, 512, 0, 512),) if tile == "512" else ())
     for (B, H, W, C1, C2, Cout) in ((2, 13, 11, 128, 64, 136), (2, 13, 11, 96, 32, 136), (1, 30, 30, 512, 0, 128), (2, 9, 20, 64, 0, 256), (1, 24, 24, 256, 128, 256),
                                     (1, 20, 20, 1024, 512, 128), (1, 16, 16, 512, 0, 512)) + real:
         Cin = C1 + C2
