@@ -453,7 +453,9 @@ extern "C" int lavt_gemm_nt(const lavt_gemm_nt_t* pp, void* stream) {
       const bool wide_off = lavt_tuning().gemm_epi_narrow;          // LAVT_GEMM_EPI=narrow: the 8-byte store form
       p.epi_wide = (!wide_off && p.dtype != LAVT_F32 && !p.c_f32 && p.ldc % 8 == 0 && (!p.C2 || (p.ldc2 % 8 == 0 && p.c_split % 8 == 0)) && (!p.R || p.ldr % 4 == 0) &&
                     (!p.Cpre || p.ldcpre % 8 == 0) && (!p.dact_pre || p.lddact % 4 == 0) && (!p.bias || (p.strideBias % 4 == 0 && ((uintptr_t)p.bias % 16) == 0)) &&
-                    ((uintptr_t)p.C % 16) == 0 && (!p.C2 || ((uintptr_t)p.C2 % 16) == 0) && (!p.Cpre || ((uintptr_t)p.Cpre % 16) == 0) && (p.strideC % 8 == 0)) ? 1 : 0; }
+                    ((uintptr_t)p.C % 16) == 0 && (!p.C2 || ((uintptr_t)p.C2 % 16) == 0) && (!p.Cpre || ((uintptr_t)p.Cpre % 16) == 0) && (p.strideC % 8 == 0)) ? 1 : 0;
+      // bit 1: the epilogue's side inputs are requested before the K loop (gemm_common.h NtSide; LAVT_SIDE_PRE=0: at the head of the epilogue, the round-2 form)
+      if (p.epi_wide && !lavt_tuning().side_pre_off && p.batch == 1) p.epi_wide |= 2; }
     if (p.colstats) {
         int rpb = 0;
         LAVT_CHECK_ARG(lavt_gemm_nt_colstats_plan(&p, &rpb) > 0, "lavt_gemm_nt: colstats only where lavt_gemm_nt_colstats_plan accepts the problem (pipelined bf16 tiles, plain epilogue)");

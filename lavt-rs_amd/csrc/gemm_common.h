@@ -173,8 +173,57 @@ __device__ __forceinline__ uint2 xchg16(uint2 v) { return make_uint2((unsigned)_
 // them as not-taken uniform branches costs every plain GEMM of the step (tools/ab_lib.sh: -0.2 ms per step with all of them compiled out, of which
 // about half is the launches that do use them).
 // LEAN = 2 (data gradients, convolutions without bias): additionally no bias / residual / row scale / output row map -- a plain store.
+// Side inputs of the wide epilogue (pre-activation of the activation gradient, residual, multiplier) for a wave tile of <= 8 fragments.  Loaded at the
+// head of the epilogue they are one exposed round trip to L2 / HBM behind the K loop of a launch whose K loop lasts 3-10 us (proj forward 1800 x 512 x
+// 512: 5.2 us as a plain GEMM, ~10 with residual + DropPath scale); `nt_side_load` issues the same loads BEFORE the K loop (round 5) -- they are the
+// oldest vector-memory operations of the wave, so the first counted vmcnt wait of the loop covers them and they cost 8 bytes of registers per fragment
+// across the loop.  Kernels call it only where those registers are free (64x64 / 4-wave tiles: 100 -> 116 VGPRs; the activation-gradient kernels).
+template <int MI, int NI> struct NtSide {
+    uint2 d[MI][NI], r[MI][NI], m[MI][NI];
+    bool have;
+};
 template <int MI, int NI, bool DACT, bool GD = false, int LEAN = 0>
-__device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz) {
+__device__ __forceinline__ void nt_side_load(const lavt_gemm_nt_t& p_in, NtSide<MI, NI>& s, int m_base, int n_base, int lane) {
+    lavt_gemm_nt_t p = p_in;
+    if constexpr (DACT && GD) { p.R = nullptr; p.c_rowmap = nullptr; p.mul = nullptr; }
+    if constexpr (GD && !DACT) { p.mul = nullptr; p.R = nullptr; p.c_rowmap = nullptr; }
+    if constexpr (LEAN >= 1) p.mul = nullptr;
+    if constexpr (LEAN >= 2) { p.R = nullptr; p.c_rowmap = nullptr; }
+    const int g = lane >> 4;
+    int64_t srow[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m_base + i * 16 + (lane & 15);
+        int orow = -1;
+        if (m < p.M) orow = p.c_rowmap ? p.c_rowmap[m] : m;
+        srow[i] = orow >= 0 ? orow : 0;
+    }
+    if constexpr (DACT) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                s.d[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.dact_pre) + srow[i] * p.lddact + n_base + j * 16 + 4 * g);
+    }
+    if (p.R) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                s.r[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.R) + srow[i] * p.ldr + n_base + j * 16 + 4 * g);
+    }
+    if (p.mul) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                s.m[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.mul) + srow[i] * p.ldmul + n_base + j * 16 + 4 * g);
+    }
+    s.have = true;
+}
+template <int MI, int NI, bool DACT, bool GD = false, int LEAN = 0>
+__device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz,
+                                                 const NtSide<(MI * NI <= 8 ? MI : 1), NI>* pre = nullptr) {
     lavt_gemm_nt_t p = p_in;
     if constexpr (DACT && GD) {          // stored-derivative data gradient (launch_nt_v2_dact): C = acc * alpha * row_scale * dact_pre, nothing else
         p.dact = LAVT_ACT_STORED; p.R = nullptr; p.bias = nullptr; p.c_rowmap = nullptr; p.act = 0; p.mul = nullptr; p.Cpre = nullptr; p.C2 = nullptr;
@@ -196,6 +245,12 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32
     constexpr bool PF = MI * NI <= 8;
     uint2 q_d[PF ? MI : 1][NI], q_r[PF ? MI : 1][NI], q_m[PF ? MI : 1][NI];
     if constexpr (PF) {
+      if (pre != nullptr && pre->have) {          // (wave-uniform: loaded before the K loop)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) { q_d[i][j] = pre->d[i][j]; q_r[i][j] = pre->r[i][j]; q_m[i][j] = pre->m[i][j]; }
+      } else {
         int64_t srow[MI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -225,6 +280,7 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32
                 for (int j = 0; j < NI; ++j)
                     q_m[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(p.mul) + srow[i] * p.ldmul + n_base + j * 16 + 4 * g);
         }
+      }
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -309,11 +365,17 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32
     }
 }
 
+// wave-uniform: this wave's tile takes the wide epilogue
+template <typename T, int MI, int NI> __device__ __forceinline__ bool nt_takes_wide(const lavt_gemm_nt_t& p, int n_base) {
+    if constexpr (std::is_same<T, bf16>::value && NI % 2 == 0) return !p.c_f32 && p.epi_wide && n_base + NI * 16 <= p.N;
+    else return false;
+}
 template <typename T, int MI, int NI, bool DACT = false, bool GD = false, int LEAN = 0>
-__device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz) {
+__device__ __forceinline__ void nt_epilogue(const lavt_gemm_nt_t& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, int bz,
+                                            const NtSide<(MI * NI <= 8 ? MI : 1), NI>* pre = nullptr) {
     if constexpr (std::is_same<T, bf16>::value && NI % 2 == 0) {
         // wave-uniform conditions: the whole wave takes one path (the exchanges need every lane)
-        if (!p.c_f32 && p.epi_wide && n_base + NI * 16 <= p.N) { nt_epilogue_wide<MI, NI, DACT, GD, LEAN>(p, acc, m_base, n_base, lane, bz); return; }
+        if (!p.c_f32 && p.epi_wide && n_base + NI * 16 <= p.N) { nt_epilogue_wide<MI, NI, DACT, GD, LEAN>(p, acc, m_base, n_base, lane, bz, pre); return; }
     }
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
     const float* rscale = p.row_scale ? p.row_scale + (int64_t)bz * p.strideRowScale : nullptr;

@@ -262,6 +262,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // side inputs of the epilogue, requested before the first tile (gemm_common.h, NtSide): where their registers are free -- the 64x64 / 4-wave tiles and
+    // the activation-gradient kernels (8-wave 128x128 tiles with residual only sit at 116 of the 128 registers that let two workgroups share a CU)
+    constexpr bool SIDE_PRE = std::is_same<T, bf16>::value && NI % 2 == 0 && MI * NI <= 8 && !LNA && !F8 && ((BM == 64 && WAVES == 4) || DACT) && LEAN < 2;
+    NtSide<(MI * NI <= 8 ? MI : 1), NI> side;
+    side.have = false;
+    if constexpr (SIDE_PRE) {
+        if ((p.epi_wide & 2) && nt_takes_wide<T, MI, NI>(p, n0 + wn * WN) && (DACT || p.R || p.mul) && (!p.epi_lds || p.mul || (p.ldc % 8)))
+            nt_side_load<MI, NI, DACT, GD, LEAN>(p, side, m0 + wm * WM, n0 + wn * WN, lane);
+    }
     const int ktiles = (p.K + BK - 1) / BK;
     constexpr int LN_SU = LNA ? (BM * 8) / (WAVES * 64) : 1;           // 16-byte chunks of an A tile per thread
     static_assert(!LNA || LN_SU * WAVES * 64 == BM * 8, "LNA: whole chunks per thread");
@@ -397,9 +406,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
             }
         }
     }
-    if constexpr (DACT) { nt_epilogue<T, MI, NI, true, GD>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz); return; }
+    if constexpr (DACT) { nt_epilogue<T, MI, NI, true, GD>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz, SIDE_PRE ? &side : nullptr); return; }
     if (!p.epi_lds || p.mul || p.c_f32 || (p.ldc % 8) || (p.C2 && (p.ldc2 % 8 || p.c_split % 8)) || (p.R && p.ldr % 8) || (p.Cpre && p.ldcpre % 8))
-        nt_epilogue<T, MI, NI, false, GD, LEAN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz);           // (GD = LAVT_ACT_GELU_D: its own instantiation of the LayerNorm-folded launch)
+        nt_epilogue<T, MI, NI, false, GD, LEAN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz, SIDE_PRE ? &side : nullptr);           // (GD = LAVT_ACT_GELU_D: its own instantiation of the LayerNorm-folded launch)
     else
         nt_epilogue_lds<BM, BN, MI, NI, GD>(p, acc, reinterpret_cast<bf16*>(smem), m0, n0, wm * WM, wn * WN, tid, lane, bz);
     }

@@ -65,6 +65,9 @@ for tgt, pat in [(t, p) for t, ps in TARGET.items() for p in ps]:
     if ent["counters_per_launch"]:
         us = ent["launch_us_under_profiler"]
         ent["derived"] = derive(ent["counters_per_launch"], us.get("GRBM_GUI_ACTIVE", sorted(us.values())[len(us) // 2]))
-    res[tgt if len(TARGET[tgt]) == 1 else tgt + ":" + pat] = ent
+    if not ent["counters_per_launch"]:
+        continue
+    key = tgt if tgt not in res else tgt + ":" + pat          # (several patterns per target: the first one that matched a kernel keeps the plain key)
+    res[key] = ent
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
