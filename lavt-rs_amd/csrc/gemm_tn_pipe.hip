@@ -80,13 +80,17 @@ template <int N, typename F> __device__ __forceinline__ void tnp_static_for(F&& 
 }
 
 constexpr int TNP_MAX = 6;
-enum { TNP_ACCUMULATE = 1, TNP_COLSUM_ATOMIC = 2, TNP_NO_B = 4, TNP_VEC4 = 8 };
+enum { TNP_ACCUMULATE = 1, TNP_COLSUM_ATOMIC = 2, TNP_NO_B = 4, TNP_VEC4 = 8, TNP_PART_VEC4 = 16 };
 struct TnpMember {
     const bf16* A; const bf16* B; float* C; float* colsum;
     const int32_t* a_map; const int32_t* b_map; const float* a_rs;
     int64_t ldc;
     int lda, ldb, I, J, K, tiles_j, tile_end, rs_div, rs_n, flags;
     float alpha;
+    // K pieces (long reductions on few output tiles: the stage-0 / stage-1 blocks, PWAM's 1x1 convolutions): workgroup (tile, piece) contracts K tiles
+    // [piece * kt_per, + kt_per) and stores its tile plainly into part[piece][I][J] (+ [pieces][I] column sums behind them); tnp_reduce_pieces adds them into C
+    float* part;
+    int pieces, kt_per, tiles;
 };
 struct TnpGroup { TnpMember m[TNP_MAX]; int n, tiles, dbg; };
 struct TnpRider {
@@ -105,7 +109,7 @@ constexpr unsigned TNP_OOB = 0x80000000u;
 // One 128x128 output tile of member m.  MAPS: the member has a row map or a row mask (per-K-tile offset arithmetic); else the K rows are
 // consecutive and a lane's offsets just advance.
 template <int STAGES, bool MAPS>
-__device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, char* smem) {
+__device__ __forceinline__ void tnp_tile(const TnpMember& m, const int local, char* smem) {
     constexpr int BT = 128, BK = 64, CH = BT / 8, L = 4;
     constexpr int TILE_BYTES = BK * BT * 2, STAGE_BYTES = 2 * TILE_BYTES;
     constexpr int HO = 4 * BT * 2, KOFF = 32 * BT * 2;
@@ -113,9 +117,14 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 2, wj = wave & 3;                       // 2 (i) x 4 (j) waves: wave tile 64 x 32
     const int l15 = lane & 15, g4 = lane >> 4;
+    // piece-major: the workgroups of one piece sweep the same K range together (they share operand panels in time)
+    const int piece = m.pieces > 1 ? local / m.tiles : 0, tile = local - piece * m.tiles;
     const int tile_i = tile / m.tiles_j, tile_j = tile - tile_i * m.tiles_j;
     const int i0 = tile_i * BT, j0 = tile_j * BT;
-    const int Kd = m.K, ktiles = (TNP_ABL & 8) ? 1 : (Kd + BK - 1) / BK;
+    const int kt_all = (m.K + BK - 1) / BK, kt0 = piece * m.kt_per;
+    const int ktiles = (TNP_ABL & 8) ? 1 : min(kt_all, kt0 + m.kt_per) - kt0;          // K tiles of this workgroup: [kt0, kt0 + ktiles)
+    const int Kd = min(m.K, (kt0 + ktiles) * BK);                                      // rows behind this workgroup's range read zeros (descriptor range / row test)
+    const int k_first = kt0 * BK;
     const int lda2 = m.lda * 2, ldb2 = m.ldb * 2;                 // row strides in bytes
     const bool has_b = !(m.flags & TNP_NO_B);
 
@@ -138,8 +147,8 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
             a_vo[i] = ca < m.I ? (unsigned)ca * 2u : TNP_OOB;
             b_vo[i] = (has_b && cb < m.J) ? (unsigned)cb * 2u : TNP_OOB;
         } else {
-            a_vo[i] = ca < m.I ? (unsigned)kr * (unsigned)lda2 + (unsigned)ca * 2u : TNP_OOB;
-            b_vo[i] = (has_b && cb < m.J) ? (unsigned)kr * (unsigned)ldb2 + (unsigned)cb * 2u : TNP_OOB;
+            a_vo[i] = ca < m.I ? (unsigned)(k_first + kr) * (unsigned)lda2 + (unsigned)ca * 2u : TNP_OOB;
+            b_vo[i] = (has_b && cb < m.J) ? (unsigned)(k_first + kr) * (unsigned)ldb2 + (unsigned)cb * 2u : TNP_OOB;
         }
     }
     const unsigned a_adv = (unsigned)BK * (unsigned)lda2, b_adv = (unsigned)BK * (unsigned)ldb2;
@@ -155,7 +164,11 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
             const float f = lane < m.rs_n ? m.a_rs[lane] : 1.0f;
             keep = __ballot(f != 0.0f);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { rs_k[i] = wave * 8 + i * 4 + g4; rs_s[i] = 0; }          // (rs_div >= 64 > the first row index: sample 0)
+            for (int i = 0; i < 2; ++i) {          // (sample, row inside the sample) of this lane's first K row
+                const int k0 = k_first + wave * 8 + i * 4 + g4;
+                rs_s[i] = k0 / rs_div;
+                rs_k[i] = k0 - rs_s[i] * rs_div;
+            }
         }
     }
     tnp_i32x8 sa = {0, 0, 0, 0, 0, 0, 0, 0}, sb = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -163,7 +176,7 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
     // or all beyond it; beyond K nothing is read -- entry 0 stands in and the rows are masked by k < K below)
     auto map_fetch = [&](int t) {
         if constexpr (MAPS) {
-            int e = t * BK + wave * 8;
+            int e = k_first + t * BK + wave * 8;
             e = e < Kd ? e : 0;
             if (map_a) sa = *reinterpret_cast<tnp_cptr8>(reinterpret_cast<uintptr_t>(map_a + e));
             if (map_b) sb = *reinterpret_cast<tnp_cptr8>(reinterpret_cast<uintptr_t>(map_b + e));
@@ -180,7 +193,7 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
         if constexpr (idx < 2) {
             char* dst = sbase + (wave * 2 + i) * 1024;
             if constexpr (MAPS) {
-                const int k = t * BK + wave * 8 + i * 4 + g4;
+                const int k = k_first + t * BK + wave * 8 + i * 4 + g4;
                 const int src = (sel4(sa, i) & amask) | (k & ~amask);
                 const bool ok = (src >= 0) & (k < Kd) & (((keep >> rs_s[i]) & 1ull) != 0ull);
                 tnp_dma16(rs_a, dst, ok ? (unsigned)src * (unsigned)lda2 + a_vo[i] : TNP_OOB);
@@ -191,7 +204,7 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
         } else {
             char* dst = sbase + TILE_BYTES + (wave * 2 + i) * 1024;
             if constexpr (MAPS) {
-                const int k = t * BK + wave * 8 + i * 4 + g4;
+                const int k = k_first + t * BK + wave * 8 + i * 4 + g4;
                 const int src = (sel4(sb, i) & bmask) | (k & ~bmask);
                 const bool ok = (src >= 0) & (k < Kd);
                 tnp_dma16(rs_b, dst, ok ? (unsigned)src * (unsigned)ldb2 + b_vo[i] : TNP_OOB);
@@ -352,9 +365,10 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
 
     // ---- epilogue: acc[fi][fj][r] = C[i0 + wi*64 + fi*16 + lane%16][j0 + wj*32 + fj*16 + 4 (lane/16) + r] ---------------------------------
     const float alpha = m.alpha;
-    float* const Cp = m.C;
-    const int64_t ldc = m.ldc;
-    const bool accum = m.flags & TNP_ACCUMULATE, vec4 = m.flags & TNP_VEC4;
+    const bool to_part = m.pieces > 1;
+    float* const Cp = to_part ? m.part + (int64_t)piece * m.I * m.J : m.C;
+    const int64_t ldc = to_part ? m.J : m.ldc;
+    const bool accum = !to_part && (m.flags & TNP_ACCUMULATE), vec4 = to_part ? (m.flags & TNP_PART_VEC4) != 0 : (m.flags & TNP_VEC4) != 0;
     if (has_b) {
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi) {
@@ -377,12 +391,13 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int tile, cha
         }
     }
     if (cs_wave && g4 == 0) {          // every row n of the ones-product holds the same sums: lanes of the first lane group write column i = lane % 16
-        const bool cat = (m.flags & TNP_COLSUM_ATOMIC) || accum;
+        const bool cat = !to_part && ((m.flags & TNP_COLSUM_ATOMIC) || accum);
+        float* const csb = to_part ? m.part + (int64_t)m.pieces * m.I * m.J + (int64_t)piece * m.I : m.colsum;
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi) {
             const int ii = i0 + wi * 64 + fi * 16 + l15;
             if (ii < m.I) {
-                float* cs = m.colsum + ii;
+                float* cs = csb + ii;
                 if (cat) atomicAdd(cs, alpha * cacc[fi][0]); else *cs = alpha * cacc[fi][0];
             }
         }
@@ -415,6 +430,89 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const TnpGroup g, con
     else tnp_tile<STAGES, false>(m, local, smem);
 }
 
+// second stage of the K pieces: C[i][j] += sum_s part[s][i][j], colsum[i] += sum_s part[pieces][s][i] (fixed order: run-to-run identical; a member whose bias
+// gradient is shared with another member of the launch adds atomically -- two addends into zeros).  blockIdx.y = member; a thread owns 4 consecutive outputs
+// (16-byte loads of every piece, four pieces in flight) -- as 64 outputs x 4 piece lanes per workgroup the launch took 8 us for 19 MB of partials.
+__global__ __launch_bounds__(256) void tnp_reduce_pieces(const TnpGroup g) {
+    const TnpMember& m = g.m[blockIdx.y];
+    const int ns = m.pieces;
+    if (ns <= 1) return;
+    const int64_t W = (int64_t)m.I * m.J, total = W + (m.colsum ? m.I : 0);
+    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e0 >= total) return;
+    const bool v4 = (m.flags & TNP_PART_VEC4) && (m.flags & TNP_VEC4) && (m.J % 4 == 0);
+    if (v4 && e0 + 3 < W) {
+        const float* q = m.part + e0;
+        // eight pieces in flight per thread (stage 0 cuts its members into ~20 pieces: four in flight were five serial round trips)
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        int s = 0;
+        for (; s + 7 < ns; s += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(q + (int64_t)(s + u) * W);
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) {
+                a0.x += v[u].x; a0.y += v[u].y; a0.z += v[u].z; a0.w += v[u].w; a1.x += v[u + 1].x; a1.y += v[u + 1].y; a1.z += v[u + 1].z; a1.w += v[u + 1].w;
+                a2.x += v[u + 2].x; a2.y += v[u + 2].y; a2.z += v[u + 2].z; a2.w += v[u + 2].w; a3.x += v[u + 3].x; a3.y += v[u + 3].y; a3.z += v[u + 3].z; a3.w += v[u + 3].w;
+            }
+        }
+        if (s < ns) {          // the remaining <= 7 pieces, all requested before the first add (a clamped index re-reads the last piece: its value is not added)
+            float4 v[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) v[u] = *reinterpret_cast<const float4*>(q + (int64_t)min(s + u, ns - 1) * W);
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                if (s + u < ns) { a0.x += v[u].x; a0.y += v[u].y; a0.z += v[u].z; a0.w += v[u].w; }
+        }
+        const int64_t i = e0 / m.J;
+        float4* c = reinterpret_cast<float4*>(m.C + i * m.ldc + (e0 - i * m.J));
+        float4 o = *c;
+        o.x += (a0.x + a1.x) + (a2.x + a3.x); o.y += (a0.y + a1.y) + (a2.y + a3.y); o.z += (a0.z + a1.z) + (a2.z + a3.z); o.w += (a0.w + a1.w) + (a2.w + a3.w);
+        *c = o;
+        return;
+    }
+    for (int k = 0; k < 4; ++k) {
+        const int64_t e = e0 + k;
+        if (e >= total) break;
+        const float* q = e < W ? m.part + e : m.part + (int64_t)ns * W + (e - W);
+        const int64_t st = e < W ? W : m.I;
+        float t = 0.f;
+        for (int s = 0; s < ns; ++s) t += q[(int64_t)s * st];
+        if (e < W) { const int64_t i = e / m.J; m.C[i * m.ldc + (e - i * m.J)] += t; }
+        else if (m.flags & TNP_COLSUM_ATOMIC) atomicAdd(m.colsum + (e - W), t);
+        else m.colsum[e - W] += t;
+    }
+}
+
+// the same for members cut into MANY pieces on small outputs (stage 0: ~20 pieces of 16-64 K outputs): 64 outputs x 4 piece lanes per workgroup -- four
+// times the workgroups and the piece loop four ways parallel (the 4-outputs-per-thread form above took 53 instead of 44 us for the stage-0 group)
+__global__ __launch_bounds__(256) void tnp_reduce_pieces_deep(const TnpGroup g) {
+    const TnpMember& m = g.m[blockIdx.y];
+    const int ns = m.pieces;
+    if (ns <= 1) return;
+    __shared__ float red[4][64];
+    const int64_t W = (int64_t)m.I * m.J, total = W + (m.colsum ? m.I : 0);
+    if ((int64_t)blockIdx.x * 64 >= total) return;
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + col;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < total) {
+        const float* q = e < W ? m.part + e : m.part + (int64_t)ns * W + (e - W);
+        const int64_t st = e < W ? W : m.I;
+        int s = sl;
+        for (; s + 12 < ns; s += 16) { a0 += q[(int64_t)s * st]; a1 += q[(int64_t)(s + 4) * st]; a2 += q[(int64_t)(s + 8) * st]; a3 += q[(int64_t)(s + 12) * st]; }
+        for (; s < ns; s += 4) a0 += q[(int64_t)s * st];
+    }
+    red[sl][col] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && e < total) {
+        const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        if (e < W) { const int64_t i = e / m.J; m.C[i * m.ldc + (e - i * m.J)] += t; }
+        else if (m.flags & TNP_COLSUM_ATOMIC) atomicAdd(m.colsum + (e - W), t);
+        else m.colsum[e - W] += t;
+    }
+}
+
 template <int STAGES, int LPR> void tnp_launch(const TnpGroup& g, const TnpRider& r, int rider_wgs, hipStream_t st) {
     constexpr size_t lds = (size_t)STAGES * 2 * 64 * 128 * 2;
     static bool attr = false;
@@ -436,34 +534,81 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
     const lavt_tuning_t& tun = lavt_tuning();
     if (tun.tn_pipe == 0 || n < 2 || n > TNP_MAX) return 1;
     TnpGroup g;
-    int tiles = 0;
+    int base_tiles = 0;
+    long work = 0;                                                // (output tile, K tile) pairs of the launch
     for (int i = 0; i < n; ++i) {
         const lavt_gemm_tn_t& p = probs[i];
         const bool no_b = p.ldb == 0;                             // (the column-sum-only side member: B = the zero page)
         if (p.dtype != LAVT_BF16 || p.batch != 1 || p.conv_kc > 0 || p.B2 || p.c_conv_permute) return 1;
-        if (p.I % 8 || p.J % 4 || p.lda % 8 || p.ldb % 8 || p.K < 64 || p.K > 128 * 64) return 1;
+        if (p.I % 8 || p.J % 4 || p.lda % 8 || p.ldb % 8 || p.K < 8) return 1;
         if ((int64_t)(p.K + 1024) * p.lda * 2 >= (1LL << 30) || (int64_t)(p.K + 1024) * p.ldb * 2 >= (1LL << 30)) return 1;          // 32-bit byte offsets inside a 2 GB descriptor, with room for the source rows of a mapped operand and the tiles issued beyond K
         if (p.a_rowscale && (!p.a_rowscale_binary || p.a_rowscale_div < 64 || (p.K + p.a_rowscale_div - 1) / p.a_rowscale_div > 64)) return 1;
         if ((p.a_rowmap || p.b_rowmap) && p.K % 8) return 1;     // a wave's eight K rows come from one aligned scalar load inside the map
         if (no_b && !p.colsum) return 1;
         if (!no_b && p.J % 8) return 1;
-        // a mapped operand is addressed by row index: the descriptor must span its whole tensor, whose extent the problem does not state -- 2 GB windows
         TnpMember& m = g.m[i];
         m.A = (const bf16*)p.A; m.B = (const bf16*)p.B; m.C = p.C; m.colsum = p.colsum;
         m.a_map = p.a_rowmap; m.b_map = p.b_rowmap; m.a_rs = p.a_rowscale;
         m.ldc = p.ldc; m.lda = (int)p.lda; m.ldb = (int)p.ldb; m.I = p.I; m.J = no_b ? 8 : p.J; m.K = p.K;
         m.tiles_j = no_b ? 1 : cdiv(p.J, 128);
+        m.tiles = cdiv(p.I, 128) * m.tiles_j;
         m.rs_div = p.a_rowscale ? p.a_rowscale_div : 1 << 30;
         m.rs_n = p.a_rowscale ? (p.K + p.a_rowscale_div - 1) / p.a_rowscale_div : 0;
         m.flags = (p.accumulate ? TNP_ACCUMULATE : 0) | (p.colsum_atomic ? TNP_COLSUM_ATOMIC : 0) | (no_b ? TNP_NO_B : 0) |
                   ((((uintptr_t)p.C & 15) == 0 && p.ldc % 4 == 0) ? TNP_VEC4 : 0);
         m.alpha = p.alpha;
-        tiles += cdiv(p.I, 128) * m.tiles_j;
-        m.tile_end = tiles;
+        m.part = nullptr; m.pieces = 1; m.kt_per = cdiv(p.K, 64);
+        base_tiles += m.tiles;
+        work += (long)m.tiles * cdiv(p.K, 64);
     }
-    for (int i = n; i < TNP_MAX; ++i) { g.m[i] = g.m[0]; g.m[i].tile_end = tiles; }
+    // K pieces.  A group whose 128x128 tiles fill the chip (>= tn_pipe_min_tiles: the stage-2 / stage-3 Swin-block groups) runs uncut: one writer per output,
+    // chains of <= 128 K tiles.  Otherwise (long reductions on few tiles: stage 0 / 1, PWAM's 1x1 convolutions) every member is cut into pieces of about
+    // work / 248 K tiles -- one round of workgroups of equal length -- through its partials scratch; a member without one keeps the group on the 64x64 launch.
+    int tiles = 0;
+    bool any_pieces = false;
+    int64_t max_total = 0;
+    if (base_tiles >= tun.tn_pipe_min_tiles) {
+        for (int i = 0; i < n; ++i) {
+            if (cdiv(probs[i].K, 64) > 128) return 1;
+            tiles += g.m[i].tiles;
+            g.m[i].tile_end = tiles;
+        }
+    } else {
+        if (tun.tn_pipe < 2) return 1;                            // LAVT_TN_PIPE=1: the uncut groups only
+        // ONE round of workgroups (a workgroup holds a CU: 128 KB of LDS), of equal length: the smallest piece length whose workgroup count stays inside the
+        // chip -- and leaves a fifth of it to the LayerNorm riders when the launch carries them (they would otherwise queue behind the tiles: +13 us at stage 0)
+        const int budget = ln ? 208 : 250;
+        int len = (int)((work + budget - 1) / budget);
+        if (len < 8) len = 8;
+        for (;; ++len) {
+            long wgs = 0;
+            for (int i = 0; i < n; ++i) wgs += (long)g.m[i].tiles * cdiv(cdiv(probs[i].K, 64), len);
+            if (wgs <= budget || len >= 128) break;
+        }
+        for (int i = 0; i < n; ++i) {
+            const lavt_gemm_tn_t& p = probs[i];
+            TnpMember& m = g.m[i];
+            const int kt = cdiv(p.K, 64);
+            int ns = cdiv(kt, len);
+            const int per = cdiv(kt, ns);
+            ns = cdiv(kt, per);                                   // no empty pieces
+            if (per > 128) return 1;
+            if (ns > 1) {
+                const int64_t need = (int64_t)ns * ((int64_t)p.I * m.J + p.I);
+                if (p.partials == nullptr || p.partials_floats < need) return 1;
+                m.part = p.partials; m.pieces = ns; m.kt_per = per;
+                if ((((uintptr_t)p.partials & 15) == 0) && ((int64_t)p.I * m.J) % 4 == 0 && m.J % 4 == 0) m.flags |= TNP_PART_VEC4;
+                any_pieces = true;
+                const int64_t tot = (int64_t)p.I * m.J + p.I;
+                max_total = max_total > tot ? max_total : tot;
+            }
+            tiles += m.tiles * ns;
+            m.tile_end = tiles;
+        }
+        if (tiles < 96 || tiles > 256) return 1;
+    }
+    for (int i = n; i < TNP_MAX; ++i) { g.m[i] = g.m[0]; g.m[i].tile_end = tiles; g.m[i].pieces = 1; }
     g.n = n; g.tiles = tiles; g.dbg = tun.probe[6];
-    if (tiles < tun.tn_pipe_min_tiles) return 1;                  // too few 128x128 tiles for the chip: the 64x64 launch (with K pieces) serves these
     TnpRider r{};
     int rider_wgs = 0, lpr = 0;
     if (ln != nullptr) {
@@ -484,6 +629,12 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
     } while (0)
     if (stages == 3) TNP_GO(3); else if (stages == 5) TNP_GO(5); else TNP_GO(4);
 #undef TNP_GO
+    if (any_pieces) {
+        int max_ns = 1;
+        for (int i = 0; i < n; ++i) max_ns = max_ns > g.m[i].pieces ? max_ns : g.m[i].pieces;
+        if (max_ns > 8) hipLaunchKernelGGL(tnp_reduce_pieces_deep, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(tnp_reduce_pieces, dim3((unsigned)cdiv(max_total, 1024), n), dim3(256), 0, st, g);
+    }
     LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(pipe)");
     return (ln != nullptr && lpr == 0) ? 3 : LAVT_OK;
 }

@@ -826,18 +826,20 @@ def test_gemm_tn_grouped_matches_individual():
         assert float((cr - co).abs().max()) <= 2e-3 * float(cr.abs().max())
 
 
-@pytest.mark.parametrize("stages", ["4", "3"])
-@pytest.mark.parametrize("Kd", [1800, 7200, 456])
-def test_gemm_tn_grouped_pipelined_tiles(Kd, stages, monkeypatch, request):
+@pytest.mark.parametrize("stages,Kd,min_tiles", [("4", 1800, "8"), ("4", 7200, "8"), ("4", 456, "8"), ("3", 1800, "8"), ("3", 7200, "8"),
+                                                  ("4", 7200, "4096"), ("4", 28800, "4096")])
+def test_gemm_tn_grouped_pipelined_tiles(Kd, stages, min_tiles, monkeypatch, request):
     """csrc/gemm_tn_pipe.hip (round 5: the grouped weight-gradient launch on 128x128 software-pipelined tiles -- buffer-descriptor LDS-DMA of two
     k-major operand tiles, transposing fragment reads one MFMA group ahead, row maps through scalar loads, the DropPath mask as a keep bit per
     sample, column sums on the matrix cores) against fp32 torch and against gemm_tn_v2.hip's 64x64 launch (LAVT_TN_PIPE=0): six members with
     every feature at once -- tiles that overhang I and J (I = 192, J = 328), a K tail of 8 rows (1800 = 28 x 64 + 8; 456 = 7 x 64 + 8), a long chain
     (7200 = 113 K tiles), gathered A rows with masked (-1) entries, gathered B rows, a row mask folded into alpha, accumulate into a non-zero C,
-    a column-sum-only member adding atomically into a bias gradient it shares with a second member, an unaligned C (4-byte stores) -- in both ring depths."""
+    a column-sum-only member adding atomically into a bias gradient it shares with a second member, an unaligned C (4-byte stores) -- in both ring depths.
+    min_tiles = 4096: the same group CUT INTO K PIECES (the form long reductions on few output tiles take: every member through its partials scratch,
+    pieces of equal length, one reduction kernel)."""
     from lavt_hip import _capi as K, ops
     monkeypatch.setenv("LAVT_TN_PIPE_STAGES", stages)
-    monkeypatch.setenv("LAVT_TN_PIPE_MIN_TILES", "8")
+    monkeypatch.setenv("LAVT_TN_PIPE_MIN_TILES", min_tiles)
     request.addfinalizer(lambda: ([os.environ.pop(k, None) for k in ("LAVT_TN_PIPE", "LAVT_TN_PIPE_STAGES", "LAVT_TN_PIPE_MIN_TILES")], K.lib.lavt_tuning_reload()))
     g = torch.Generator().manual_seed(77)
     bf = torch.bfloat16
@@ -860,7 +862,7 @@ def test_gemm_tn_grouped_pipelined_tiles(Kd, stages, monkeypatch, request):
             (512, 512, mk(Kd, 512), mk(Kd, 512), dict(), "unaligned"),                                                         # C at a 12-byte offset
         ]
     def run(pipe):
-        monkeypatch.setenv("LAVT_TN_PIPE", pipe)
+        monkeypatch.setenv("LAVT_TN_PIPE", "2" if pipe == "1" else "0")
         K.lib.lavt_tuning_reload()
         g.manual_seed(77)
         torch.randint(-1, Ms, (Kd,), generator=g); torch.randint(0, Ms, (Kd,), generator=g)          # (same operand stream in both runs)
@@ -1068,6 +1070,11 @@ def test_grouped_wgrad_with_layernorm_rider(Cc, T):
     a, b = run(True), run(False)
     for i, (u, v) in enumerate(zip(a, b)):
         assert torch.isfinite(u.float()).all(), i
+        if i < 8 and not torch.equal(u, v):
+            # (weight / bias gradients of a group that is cut into K pieces: with riders on board the launch leaves a fifth of the chip to them, so its
+            # pieces are longer than without -- the same sums in another fp32 order; uncut groups are bit-identical)
+            assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()), f"tensor {i}: ridden and separate launches differ beyond fp32 summation order"
+            continue
         assert torch.equal(u, v), f"tensor {i}: ridden and separate launches differ"
     # and the LayerNorm backward itself against fp32 torch
     xh = (x.float() - mean[:, None]) * rstd[:, None]
