@@ -80,7 +80,7 @@ template <int N, typename F> __device__ __forceinline__ void tnp_static_for(F&& 
 }
 
 constexpr int TNP_MAX = 6;
-enum { TNP_ACCUMULATE = 1, TNP_COLSUM_ATOMIC = 2, TNP_NO_B = 4, TNP_VEC4 = 8, TNP_PART_VEC4 = 16 };
+enum { TNP_ACCUMULATE = 1, TNP_COLSUM_ATOMIC = 2, TNP_NO_B = 4, TNP_VEC4 = 8, TNP_PART_VEC4 = 16, TNP_WT = 32 };
 struct TnpMember {
     const bf16* A; const bf16* B; float* C; float* colsum;
     const int32_t* a_map; const int32_t* b_map; const float* a_rs;
@@ -369,6 +369,7 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int local, ch
     float* const Cp = to_part ? m.part + (int64_t)piece * m.I * m.J : m.C;
     const int64_t ldc = to_part ? m.J : m.ldc;
     const bool accum = !to_part && (m.flags & TNP_ACCUMULATE), vec4 = to_part ? (m.flags & TNP_PART_VEC4) != 0 : (m.flags & TNP_VEC4) != 0;
+    const bool wt = !to_part && (m.flags & TNP_WT) != 0;          // final gradients leave the L2 as they are stored; partial tiles are re-read by the reduction at once
     if (has_b) {
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi) {
@@ -381,7 +382,8 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int local, ch
                     float4 v = make_float4(alpha * acc[fi][fj][0], alpha * acc[fi][fj][1], alpha * acc[fi][fj][2], alpha * acc[fi][fj][3]);
                     if (vec4) {
                         if (accum) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                        *reinterpret_cast<float4*>(dst) = v;
+                        if (wt) st16_out(dst, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));      // write-through (gemm_common.h)
+                        else *reinterpret_cast<float4*>(dst) = v;
                     } else {
                         if (accum) { v.x += dst[0]; v.y += dst[1]; v.z += dst[2]; v.w += dst[3]; }
                         dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
@@ -555,7 +557,7 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
         m.rs_div = p.a_rowscale ? p.a_rowscale_div : 1 << 30;
         m.rs_n = p.a_rowscale ? (p.K + p.a_rowscale_div - 1) / p.a_rowscale_div : 0;
         m.flags = (p.accumulate ? TNP_ACCUMULATE : 0) | (p.colsum_atomic ? TNP_COLSUM_ATOMIC : 0) | (no_b ? TNP_NO_B : 0) |
-                  ((((uintptr_t)p.C & 15) == 0 && p.ldc % 4 == 0) ? TNP_VEC4 : 0);
+                  ((((uintptr_t)p.C & 15) == 0 && p.ldc % 4 == 0) ? TNP_VEC4 : 0) | (tun.probe[5] == 1 ? 0 : TNP_WT);
         m.alpha = p.alpha;
         m.part = nullptr; m.pieces = 1; m.kt_per = cdiv(p.K, 64);
         base_tiles += m.tiles;
