@@ -567,7 +567,7 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
     // chains of <= 128 K tiles.  Otherwise (long reductions on few tiles: stage 0 / 1, PWAM's 1x1 convolutions) every member is cut into pieces of about
     // work / 248 K tiles -- one round of workgroups of equal length -- through its partials scratch; a member without one keeps the group on the 64x64 launch.
     int tiles = 0;
-    bool any_pieces = false;
+    bool any_pieces = false, drop_rider = false;
     int64_t max_total = 0;
     if (base_tiles >= tun.tn_pipe_min_tiles) {
         for (int i = 0; i < n; ++i) {
@@ -579,13 +579,24 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
         if (tun.tn_pipe < 2) return 1;                            // LAVT_TN_PIPE=1: the uncut groups only
         // ONE round of workgroups (a workgroup holds a CU: 128 KB of LDS), of equal length: the smallest piece length whose workgroup count stays inside the
         // chip -- and leaves a fifth of it to the LayerNorm riders when the launch carries them (they would otherwise queue behind the tiles: +13 us at stage 0)
-        const int budget = ln ? 208 : 250;
-        int len = (int)((work + budget - 1) / budget);
-        if (len < 8) len = 8;
-        for (;; ++len) {
-            long wgs = 0;
-            for (int i = 0; i < n; ++i) wgs += (long)g.m[i].tiles * cdiv(cdiv(probs[i].K, 64), len);
-            if (wgs <= budget || len >= 128) break;
+        auto piece_len = [&](int budget) {
+            int l = (int)((work + budget - 1) / budget);
+            if (l < 8) l = 8;
+            for (;; ++l) {
+                long wgs = 0;
+                for (int i = 0; i < n; ++i) wgs += (long)g.m[i].tiles * cdiv(cdiv(probs[i].K, 64), l);
+                if (wgs <= budget || l >= 128) break;
+            }
+            return l;
+        };
+        int len = piece_len(ln ? 208 : 250);
+        if (ln != nullptr) {
+            // ... unless giving the riders their fifth costs more than their own launch: with the measured 0.8 us per K tile, a LayerNorm launch of
+            // ~4 us + its bytes at ~3 TB/s (Swin-T's stage 2 at 8 images: 117 tiles of 113 K tiles stay uncut under the rider budget -- 96 us -- and take
+            // 57 K tiles + the reduction without riders: 63 + 16 us).  The caller then launches the LayerNorm itself (return code 3).
+            const int len_free = piece_len(250);
+            const double ln_us = 4.0 + 6.0 * (double)ln->rows * ln->C / 3.0e6;
+            if (0.8 * len > 0.8 * len_free + ln_us + 1.0) { len = len_free; drop_rider = true; }
         }
         for (int i = 0; i < n; ++i) {
             const lavt_gemm_tn_t& p = probs[i];
@@ -613,7 +624,7 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
     g.n = n; g.tiles = tiles; g.dbg = tun.probe[6];
     TnpRider r{};
     int rider_wgs = 0, lpr = 0;
-    if (ln != nullptr) {
+    if (ln != nullptr && !drop_rider) {
         int cpl, waves;
         const int blocks = lavt_ln_bwd_geometry(LAVT_BF16, ln->rows, ln->C, &lpr, &cpl, &waves);
         if (waves == 4 && cpl == 1 && (lpr == 16 || lpr == 32 || lpr == 64) && blocks > 0) {

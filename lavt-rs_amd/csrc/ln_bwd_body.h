@@ -49,6 +49,7 @@ __device__ __forceinline__ void layernorm_bwd_body(const T* __restrict__ dy, con
         const bool live = row < rows;
         const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
         float xh[MAXC * EPC], g[MAXC * EPC];
+        uint4 rres[MAXC];          // the residual branch's gradient, requested with the row (round 5: loaded behind the two reductions it was one more exposed round trip per row)
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
@@ -62,6 +63,7 @@ __device__ __forceinline__ void layernorm_bwd_body(const T* __restrict__ dy, con
                 const T* src = ln_src<T>(x, gather, row, C, ch * EPC, ok);
                 if (ok) chunk_to_f<T>(*reinterpret_cast<const uint4*>(src), fx);
                 chunk_to_f<T>(*reinterpret_cast<const uint4*>(dy + row * C + ch * EPC), fg);
+                if (dres) rres[c] = *reinterpret_cast<const uint4*>(dres + row * C + ch * EPC);
             }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
@@ -90,7 +92,7 @@ __device__ __forceinline__ void layernorm_bwd_body(const T* __restrict__ dy, con
                 for (int e = 0; e < EPC; ++e) f[e] = rs * (g[c * EPC + e] - s1 - xh[c * EPC + e] * s2);
                 if (dres) {                       // gradient of the residual branch that bypassed this LayerNorm: dx = LN'(dy) + dres (no gather form)
                     float fr[EPC];
-                    chunk_to_f<T>(*reinterpret_cast<const uint4*>(dres + row * C + ch * EPC), fr);
+                    chunk_to_f<T>(rres[c], fr);
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) f[e] += fr[e];
                 }
