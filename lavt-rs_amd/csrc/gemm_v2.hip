@@ -264,7 +264,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_v2_kernel(const lavt_gemm_
 
     // side inputs of the epilogue, requested before the first tile (gemm_common.h, NtSide): where their registers are free -- the 64x64 / 4-wave tiles and
     // the activation-gradient kernels (8-wave 128x128 tiles with residual only sit at 116 of the 128 registers that let two workgroups share a CU)
-    constexpr bool SIDE_PRE = std::is_same<T, bf16>::value && NI % 2 == 0 && MI * NI <= 8 && !LNA && !F8 && ((BM == 64 && WAVES == 4) || DACT) && LEAN < 2;
+    // (the general activation-gradient kernel on 8-wave tiles -- three side inputs of 8 fragments: 48 registers on top of 110 -- is left out: hipcc kept the
+    // kernel at 128 registers and moved the struct to scratch, 208 bytes per lane; the stored-derivative form, GD, carries one input and fits)
+    constexpr bool SIDE_PRE = std::is_same<T, bf16>::value && NI % 2 == 0 && MI * NI <= 8 && !LNA && !F8 && ((BM == 64 && WAVES == 4) || (DACT && GD)) && LEAN < 2;
     NtSide<(MI * NI <= 8 ? MI : 1), NI> side;
     side.have = false;
     if constexpr (SIDE_PRE) {

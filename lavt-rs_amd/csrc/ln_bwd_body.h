@@ -49,7 +49,10 @@ __device__ __forceinline__ void layernorm_bwd_body(const T* __restrict__ dy, con
         const bool live = row < rows;
         const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
         float xh[MAXC * EPC], g[MAXC * EPC];
-        uint4 rres[MAXC];          // the residual branch's gradient, requested with the row (round 5: loaded behind the two reductions it was one more exposed round trip per row)
+        // the residual branch's gradient, requested with the row (round 5: loaded behind the two reductions it was one more exposed round trip per row); rows of
+        // more than two chunks per lane (C > 1024: no benchmarked shape) keep the load at its use -- eight more chunks in flight spilled 50-100 registers
+        constexpr bool RES_PRE = MAXC <= 2;
+        uint4 rres[RES_PRE ? MAXC : 1];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
@@ -63,7 +66,7 @@ __device__ __forceinline__ void layernorm_bwd_body(const T* __restrict__ dy, con
                 const T* src = ln_src<T>(x, gather, row, C, ch * EPC, ok);
                 if (ok) chunk_to_f<T>(*reinterpret_cast<const uint4*>(src), fx);
                 chunk_to_f<T>(*reinterpret_cast<const uint4*>(dy + row * C + ch * EPC), fg);
-                if (dres) rres[c] = *reinterpret_cast<const uint4*>(dres + row * C + ch * EPC);
+                if constexpr (RES_PRE) { if (dres) rres[c] = *reinterpret_cast<const uint4*>(dres + row * C + ch * EPC); }
             }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
@@ -92,7 +95,8 @@ __device__ __forceinline__ void layernorm_bwd_body(const T* __restrict__ dy, con
                 for (int e = 0; e < EPC; ++e) f[e] = rs * (g[c * EPC + e] - s1 - xh[c * EPC + e] * s2);
                 if (dres) {                       // gradient of the residual branch that bypassed this LayerNorm: dx = LN'(dy) + dres (no gather form)
                     float fr[EPC];
-                    chunk_to_f<T>(rres[c], fr);
+                    if constexpr (RES_PRE) chunk_to_f<T>(rres[c], fr);
+                    else chunk_to_f<T>(*reinterpret_cast<const uint4*>(dres + row * C + ch * EPC), fr);
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) f[e] += fr[e];
                 }
