@@ -56,6 +56,7 @@ class TrainStep:
         # FusedAdamW writes through raw pointers (versions do not move) and refreshes the copies itself.
         self._params = [p for p in model.parameters()]
         self._seen = None
+        self._one = None
 
     def _param_stamp(self):
         return sum(p._version for p in self._params), sum(p.data_ptr() for p in self._params)
@@ -75,7 +76,9 @@ class TrainStep:
             out = self.model(self.x, self.l, self.m)
             loss = F.cross_entropy(out, self.t, weight=self.w)
         ops.fill_riders.finish()                 # whatever of the gradient buffer no forward launch has zeroed
-        loss.backward()
+        if self._one is None or self._one.shape != loss.shape or self._one.dtype != loss.dtype:
+            self._one = torch.ones_like(loss)    # (first eager step) the root gradient as a persistent tensor: `loss.backward()` fills a fresh ones_like every step,
+        loss.backward(self._one)                 # one more 4.5 us launch on the captured chain
         ops.wgrads.flush()                       # weight-gradient GEMMs still queued for a grouped launch
         ops.ln_deferred.flush()                  # all LayerNorm weight / bias partial sums of this backward: one reduction launch
         ops.side.join()                          # wgrad GEMMs ran on side streams: join before the step (or the graph capture) ends
