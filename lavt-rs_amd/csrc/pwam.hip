@@ -77,61 +77,121 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
     bf16* Wm = reinterpret_cast<bf16*>(smem_raw);                   // [32][LDW]
     float* vec = reinterpret_cast<float*>(Wm + 32 * LDW);           // [32]
     bf16* Qn = reinterpret_cast<bf16*>(vec + 32);                   // backward: -Q as bf16 [32][40]
+    float* meanS = reinterpret_cast<float*>(Qn + 32 * 40);          // forward: mu_q of this sample [C]
+    float* rstdS = meanS + C;                                       // forward: rstd_q of this sample [C]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int b = blockIdx.y;
 
+    // ---- (round 5) requests that depend on nothing: the first 16 k-steps of this wave's first row tile, its P fragments (backward), the q means /
+    // mask bias (forward), the u records and Pbar (backward).  Issued here they travel under the word-matrix prologue; issued where they are used they
+    // were 2 (forward: 5) more exposed L2 round trips in a launch that is a chain of round trips (the backward launches ran 6-8 us behind the forward
+    // ones of the same shape, the 8-workgroup launch of the last stage 20 us for 2 us of rows).
+    const int ntiles = (a.T + 15) >> 4;
+    const int ksteps = C >> 5;
+    constexpr int PRE = 16;
+    bf16x8 xpre[PRE] = {};
+    bf16x8 pf_pre = {};
+    uint2 p0_pre = make_uint2(0u, 0u), p1_pre = make_uint2(0u, 0u);
+    {
+        const int tile = min((int)blockIdx.x * 4 + wave, ntiles - 1);
+        const int64_t row = (int64_t)b * a.T + min(tile * 16 + c16, a.T - 1);
+        const bf16* xp = a.X + row * a.ldx + 8 * g;
+#pragma unroll
+        for (int u = 0; u < PRE; ++u)
+            if (u < ksteps) xpre[u] = ldg8(xp + 32 * u);          // (wave-uniform: the 128-channel stage has 4 k-steps, not 16 requests)
+        if constexpr (BWD) {
+            pf_pre = ldg8(a.P + row * 32 + 8 * g);
+            p0_pre = *reinterpret_cast<const uint2*>(a.P + row * 32 + 4 * g);
+            p1_pre = *reinterpret_cast<const uint2*>(a.P + row * 32 + 16 + 4 * g);
+        }
+    }
+    float uj_pre = 0.f, pb_pre[4] = {0.f, 0.f, 0.f, 0.f}, mb_pre = 0.f;
+    float4 mean_pre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, rstd_pre[2] = {mean_pre[0], mean_pre[0]};
+    if constexpr (!BWD) {
+        mb_pre = a.vec[b * 32 + (tid >> 3)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)          // (C <= 2048: two float4 per thread)
+            if (tid + 256 * i < (C >> 2)) {
+                mean_pre[i] = *reinterpret_cast<const float4*>(a.mean + (int64_t)b * C + 4 * (tid + 256 * i));
+                rstd_pre[i] = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + 4 * (tid + 256 * i));
+            }
+    } else {
+        const int j = tid >> 3, part = tid & 7;
+        float vu[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) vu[u] = a.Qf[((int64_t)b * a.n_l + min(u, a.n_l - 1)) * 1056 + 1024 + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pb_pre[i] = a.pbar[b * 32 + part + 8 * i];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) uj_pre += u < a.n_l ? vu[u] : 0.f;          // (fixed order: run-to-run identical)
+    }
+
+    // backward: the Q records (requested in front of the word matrix: the vector-memory counter retires in order, so summing them below does not wait
+    // for the matrix, and the matrix does not wait for them -- behind the matrix loop they were a second dependent round trip)
+    float v[BWD ? 4 : 1][16];
+    if constexpr (BWD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[k][u] = a.Qf[((int64_t)b * a.n_l + min(u, a.n_l - 1)) * 1056 + tid + 256 * k];
+    }
+
     // ---- prologue: the word matrix and the per-word constants of this sample ----
     const int nch = C >> 3;
-    // (eight chunks per thread per pass, every load issued before the first use: as a one-chunk loop the 32 x 1024 matrix of the last stage was a
-    // chain of 16 exposed round trips per thread -- 22 us for a launch whose rows take 2; four per pass were still 4 round trips)
-    for (int e0 = tid; e0 < 32 * nch; e0 += 2048) {
-        uint4 raw[8];
-        float4 r0[8], r1[8];
+    // (sixteen chunks per thread per pass = one pass at C = 1024, every load issued before the first use: as a one-chunk loop the 32 x 1024 matrix of
+    // the last stage was a chain of 16 exposed round trips per thread -- 22 us for a launch whose rows take 2.  Forward: rstd_q and mu_q travel with
+    // the first pass in registers, are parked in LDS, and the chunks are scaled behind ONE barrier -- as global loads per chunk they halved the pass.)
+    constexpr int UW = 16;
+    for (int base = 0; base < 32 * nch; base += 256 * UW) {          // (uniform trip count: the forward pass holds a barrier)
+        const int e0 = base + tid;
+        uint4 raw[UW];
         // (loads unconditional on a clamped chunk index, only the LDS store below is predicated: with the loads under `if (e < ...)` hipcc kept raw[] in
         // scratch -- 144 bytes per lane, eight scratch round trips at the head of the kernel)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UW; ++u) {
             const int e = min(e0 + 256 * u, 32 * nch - 1);
             const int j = e / nch, cc = e - j * nch;
             raw[u] = *reinterpret_cast<const uint4*>(a.Wsrc + ((int64_t)b * 32 + j) * a.ldw + cc * 8);
-            if constexpr (!BWD) {
-                r0[u] = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + cc * 8);
-                r1[u] = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + cc * 8 + 4);
+        }
+        if constexpr (!BWD) {
+            if (base == 0) {                          // (first pass, every thread)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    if (tid + 256 * i < (C >> 2)) {
+                        *reinterpret_cast<float4*>(meanS + 4 * (tid + 256 * i)) = mean_pre[i];
+                        *reinterpret_cast<float4*>(rstdS + 4 * (tid + 256 * i)) = rstd_pre[i];
+                    }
+                __syncthreads();
             }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UW; ++u) {
             const int e = e0 + 256 * u;
             uint4 val = raw[u];
-            if constexpr (!BWD) {
-                float f[8];
-                chunk_to_f<bf16>(val, f);
-                const float s = a.alpha * LOG2E;
-                f[0] *= r0[u].x * s; f[1] *= r0[u].y * s; f[2] *= r0[u].z * s; f[3] *= r0[u].w * s;
-                f[4] *= r1[u].x * s; f[5] *= r1[u].y * s; f[6] *= r1[u].z * s; f[7] *= r1[u].w * s;
-                val = f_to_chunk<bf16>(f);
-            }
             if (e < 32 * nch) {
                 const int j = e / nch, cc = e - j * nch;
+                if constexpr (!BWD) {
+                    float f[8];
+                    chunk_to_f<bf16>(val, f);
+                    const float s = a.alpha * LOG2E;
+                    const float4 r0 = *reinterpret_cast<const float4*>(rstdS + cc * 8), r1 = *reinterpret_cast<const float4*>(rstdS + cc * 8 + 4);
+                    f[0] *= r0.x * s; f[1] *= r0.y * s; f[2] *= r0.z * s; f[3] *= r0.w * s;
+                    f[4] *= r1.x * s; f[5] *= r1.y * s; f[6] *= r1.z * s; f[7] *= r1.w * s;
+                    val = f_to_chunk<bf16>(f);
+                }
                 *reinterpret_cast<uint4*>(Wm + j * LDW + cc * 8) = val;
             }
         }
     }
     if constexpr (BWD) {
-        // (n_l carries the record count in this mode.)  Eight records per round, every load of a round issued before the first add: as a plain loop over
+        // (n_l carries the record count in this mode.)  Every load of a thread in flight at once, summed in a fixed order: as a plain loop over
         // the records each element was a chain of `records` exposed round trips at the head of a kernel that sits on the critical chain
-        // (round 4: all 4 x 16 loads of a thread in flight at once -- two rounds of eight per element were still eight serial round trips, ~8 us at the
-        // head of the 450-row launch of the last stage; lavt_pwam_q_parts caps the record count at 16)
-        float v[4][16];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[k][u] = u < a.n_l ? a.Qf[((int64_t)b * a.n_l + u) * 1056 + tid + 256 * k] : 0.f;
+        // (lavt_pwam_q_parts caps the record count at 16)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float q = 0.f;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) q += v[k][u];          // (fixed order: run-to-run identical)
+            for (int u = 0; u < 16; ++u) q += u < a.n_l ? v[k][u] : 0.f;          // (fixed order: run-to-run identical)
             const int e = tid + 256 * k;
             Qn[(e >> 5) * 40 + (e & 31)] = (bf16)(-q);
         }
@@ -145,28 +205,22 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
             for (int cc = part; cc < nch; cc += 8) {
                 float f[8];
                 chunk_to_f<bf16>(*reinterpret_cast<const uint4*>(Wm + j * LDW + cc * 8), f);
-                const float4 m0 = *reinterpret_cast<const float4*>(a.mean + (int64_t)b * C + cc * 8), m1 = *reinterpret_cast<const float4*>(a.mean + (int64_t)b * C + cc * 8 + 4);
+                const float4 m0 = *reinterpret_cast<const float4*>(meanS + cc * 8), m1 = *reinterpret_cast<const float4*>(meanS + cc * 8 + 4);
                 s += f[0] * m0.x + f[1] * m0.y + f[2] * m0.z + f[3] * m0.w + f[4] * m1.x + f[5] * m1.y + f[6] * m1.z + f[7] * m1.w;
             }
         } else {
-            for (int k = part; k < 32; k += 8) s += a.pbar[b * 32 + k] * (-(float)Qn[k * 40 + j]);       // Pbar Q with the bf16 Q the MFMA sees
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += pb_pre[i] * (-(float)Qn[(part + 8 * i) * 40 + j]);       // Pbar Q with the bf16 Q the MFMA sees
         }
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
         if (part == 0) {
-            if constexpr (BWD) {
-                float uj = 0.f, vu[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) vu[u] = u < a.n_l ? a.Qf[((int64_t)b * a.n_l + u) * 1056 + 1024 + j] : 0.f;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) uj += vu[u];
-                vec[j] = s - uj;
-            } else vec[j] = a.vec[b * 32 + j] * LOG2E - s;
+            if constexpr (BWD) vec[j] = s - uj_pre;
+            else vec[j] = mb_pre * LOG2E - s;
         }
     }
     __syncthreads();
 
-    const int ntiles = (a.T + 15) >> 4;
-    const int ksteps = C >> 5;
+    bool first = true;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const int t = tile * 16 + c16;
         const bool vr = t < a.T;
@@ -175,13 +229,29 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         const bf16* w0 = Wm + c16 * LDW + 8 * g;
         const bf16* w1 = w0 + 16 * LDW;
+        bf16x8 pf = pf_pre;
+        uint2 pp0 = p0_pre, pp1 = p1_pre;
         int ks = 0;
-        for (; ks + 8 <= ksteps; ks += 8) {          // (C >= 256: eight k-steps of row loads in flight -- the last stage's 1024-channel rows were 8 rounds of 4)
-            bf16x8 xf[8];
+        if (first) {                                 // (wave-uniform) the k-steps requested at the head of the kernel
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xf[u] = ldg8(xp + 32 * (ks + u));
+            for (int u = 0; u < PRE; ++u)
+                if (u < ksteps) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(w0 + 32 * u), xpre[u], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(w1 + 32 * u), xpre[u], acc[1], 0, 0, 0);
+                }
+            ks = min(PRE, ksteps);
+            first = false;
+        } else if constexpr (BWD) {
+            pf = ldg8(a.P + row * 32 + 8 * g);
+            pp0 = *reinterpret_cast<const uint2*>(a.P + row * 32 + 4 * g);
+            pp1 = *reinterpret_cast<const uint2*>(a.P + row * 32 + 16 + 4 * g);
+        }
+        for (; ks + 16 <= ksteps; ks += 16) {        // (C >= 512: sixteen k-steps of row loads in flight -- the last stage's 1024-channel rows were 4 rounds of 8)
+            bf16x8 xf[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) xf[u] = ldg8(xp + 32 * (ks + u));
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(w0 + 32 * (ks + u)), xf[u], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(w1 + 32 * (ks + u)), xf[u], acc[1], 0, 0, 0);
             }
@@ -228,12 +298,11 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
             for (int r = 0; r < 4; ++r) { o0[r] *= inv; o1[r] *= inv; }
         } else {
             // second contraction: - P Q (k = words of P): A = -Q rows (word 16wt + c16, k-words 8g..), B = P row fragment
-            const bf16x8 pf = ldg8(a.P + row * 32 + 8 * g);
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(Qn + c16 * 40 + 8 * g), pf, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds8(Qn + (16 + c16) * 40 + 8 * g), pf, acc[1], 0, 0, 0);
             float p0[4], p1[4], dot = 0.f;
-            unpack4(*reinterpret_cast<const uint2*>(a.P + row * 32 + 4 * g), p0);
-            unpack4(*reinterpret_cast<const uint2*>(a.P + row * 32 + 16 + 4 * g), p1);
+            unpack4(pp0, p0);
+            unpack4(pp1, p1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 o0[r] = acc[0][r] + v0[r];
@@ -365,81 +434,88 @@ __global__ __launch_bounds__(256) void pwam_mix_kernel(const MixArgs a) {
 
 // ================================================================================================ language side
 // forward: VW = V Wo^T on the matrix cores, Cov_T(P) from the second-moment matrix, var_w -> VW' in both layouts, beta = -Pbar VW'.
-// grid (C / 64, B), 256 threads: wave w owns channels 16 w .. 16 w + 15 of the block's 64.
+// grid (C / 16, B), 256 threads: a workgroup owns 16 channels, its four waves a quarter of the reduction each (round 5: as 64 channels per workgroup
+// with the whole reduction in every wave the C = 1024 launch was 32 workgroups x 4 dependent rounds of cold loads of Wo -- 18 us; every load of a
+// wave is now one round, requested in front of everything else).
+constexpr int LF_MAXK = 8;          // k-steps per wave held in registers per round (C <= 1024: one round)
 __global__ __launch_bounds__(256) void pwam_lang_fwd_kernel(const bf16* __restrict__ V, int64_t ldv, const bf16* __restrict__ Wo, const float* __restrict__ PP,
                                                             const float* __restrict__ sumP, bf16* __restrict__ VWc, bf16* __restrict__ VWw, float* __restrict__ beta,
                                                             float* __restrict__ rw, float* __restrict__ pbar_out, float* __restrict__ cov_out, int T, int C, float eps) {
-    __shared__ float vw[64][33];
+    __shared__ float part_vw[4][16][33];
+    __shared__ float vw[16][33];
     __shared__ float cov[32][33];
     __shared__ float pb[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.y, c0 = blockIdx.x * 64;
+    const int b = blockIdx.y, c0 = blockIdx.x * 16;
     const float invT = 1.0f / (float)T;
-    if (tid < 32) pb[tid] = sumP[b * 32 + tid] * invT;
-    __syncthreads();
-    for (int e = tid; e < 1024; e += 256) {
-        const int j = e >> 5, k = e & 31;
-        const float cv = PP[(int64_t)b * 1024 + e] * invT - pb[j] * pb[k];
-        cov[j][k] = cv;
-        if (blockIdx.x == 0) cov_out[(int64_t)b * 1024 + e] = cv;
-    }
-    if (blockIdx.x == 0 && tid < 32) pbar_out[b * 32 + tid] = pb[tid];
-    // VW[word][channel] for this wave's 16 channels
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    const int ch = c0 + wave * 16 + c16;
+    // this wave's k-steps [k_lo, k_hi) of the C / 32
+    const int ksteps = C >> 5, per = (ksteps + 3) >> 2;
+    const int k_lo = min(wave * per, ksteps), k_hi = min(k_lo + per, ksteps);
+    const int ch = c0 + c16;
     const bool vc = ch < C;
     const bf16* wp = Wo + (int64_t)(vc ? ch : C - 1) * C + 8 * g;
     const bf16* vp0 = V + ((int64_t)b * 32 + c16) * ldv + 8 * g;
     const bf16* vp1 = vp0 + 16 * ldv;
-    const int ksteps = C >> 5;
-    int ks = 0;
-    for (; ks + 8 <= ksteps; ks += 8) {          // eight k-steps of loads in flight (one per step was a chain of C / 32 exposed round trips, four per round 8 rounds at C = 1024)
-        bf16x8 wf[8], a0[8], a1[8];
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    bf16x8 wf[LF_MAXK], a0[LF_MAXK], a1[LF_MAXK];
+    // first round of operand loads (clamped k-step: a dead slot re-reads the last live one and is not used)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { wf[u] = ldg8(wp + 32 * (ks + u)); a0[u] = ldg8(vp0 + 32 * (ks + u)); a1[u] = ldg8(vp1 + 32 * (ks + u)); }
+    for (int u = 0; u < LF_MAXK; ++u) {
+        const int ks = min(k_lo + u, max(k_hi - 1, 0));
+        wf[u] = ldg8(wp + 32 * ks); a0[u] = ldg8(vp0 + 32 * ks); a1[u] = ldg8(vp1 + 32 * ks);
+    }
+    // second-moment matrix and word means: 4 + 5 independent loads per thread, no LDS hop in between
+    float ppv[4], sj[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+    for (int i = 0; i < 4; ++i) { ppv[i] = PP[(int64_t)b * 1024 + tid + 256 * i]; sj[i] = sumP[b * 32 + (tid >> 5) + 8 * i]; }
+    const float sk = sumP[b * 32 + (tid & 31)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i;
+        const float cv = ppv[i] * invT - (sj[i] * invT) * (sk * invT);
+        cov[e >> 5][e & 31] = cv;
+        if (blockIdx.x == 0) cov_out[(int64_t)b * 1024 + e] = cv;
+    }
+    if (tid < 32) {
+        pb[tid] = sk * invT;
+        if (blockIdx.x == 0) pbar_out[b * 32 + tid] = sk * invT;
+    }
+#pragma unroll
+    for (int u = 0; u < LF_MAXK; ++u)
+        if (k_lo + u < k_hi) {
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[u], wf[u], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u], wf[u], acc[1], 0, 0, 0);
         }
+    for (int ks = k_lo + LF_MAXK; ks < k_hi; ++ks) {          // (C > 1024)
+        const bf16x8 w = ldg8(wp + 32 * ks);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(vp0 + 32 * ks), w, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(vp1 + 32 * ks), w, acc[1], 0, 0, 0);
     }
-    for (; ks + 4 <= ksteps; ks += 4) {
-        bf16x8 wf[4], a0[4], a1[4];
+    // lane: channel c16, words 4g + r (tile 0) and 16 + 4g + r (tile 1)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { wf[u] = ldg8(wp + 32 * (ks + u)); a0[u] = ldg8(vp0 + 32 * (ks + u)); a1[u] = ldg8(vp1 + 32 * (ks + u)); }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[u], wf[u], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u], wf[u], acc[1], 0, 0, 0);
-        }
-    }
-    for (; ks < ksteps; ++ks) {
-        const bf16x8 wf = ldg8(wp + 32 * ks);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(vp0 + 32 * ks), wf, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(vp1 + 32 * ks), wf, acc[1], 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { vw[wave * 16 + c16][4 * g + r] = acc[0][r]; vw[wave * 16 + c16][16 + 4 * g + r] = acc[1][r]; }
+    for (int r = 0; r < 4; ++r) { part_vw[wave][c16][4 * g + r] = acc[0][r]; part_vw[wave][c16][16 + 4 * g + r] = acc[1][r]; }
     __syncthreads();
-    const int c = tid >> 2, part = tid & 3;
-    float var = 0.f;
-    for (int j = part * 8; j < part * 8 + 8; ++j) {
-        float t = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) t += cov[j][k] * vw[c][k];
-        var += vw[c][j] * t;
+    for (int e = tid; e < 512; e += 256) {
+        const int c = e >> 5, j = e & 31;
+        vw[c][j] = (part_vw[0][c][j] + part_vw[1][c][j]) + (part_vw[2][c][j] + part_vw[3][c][j]);          // (fixed order)
     }
-    var += __shfl_xor(var, 1, 64); var += __shfl_xor(var, 2, 64);
+    __syncthreads();
+    // thread (channel tid / 16, word pair tid % 16)
+    const int c = tid >> 4, j0 = 2 * (tid & 15);
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) { const float v = vw[c][k]; t0 += cov[j0][k] * v; t1 += cov[j0 + 1][k] * v; }
+    float var = vw[c][j0] * t0 + vw[c][j0 + 1] * t1;
+    var += __shfl_xor(var, 1, 64); var += __shfl_xor(var, 2, 64); var += __shfl_xor(var, 4, 64); var += __shfl_xor(var, 8, 64);
     const float rs = rsqrtf(fmaxf(var, 0.f) + eps);
-    float f[8], bsum = 0.f;
-#pragma unroll
-    for (int x = 0; x < 8; ++x) { f[x] = bf16_round(vw[c][part * 8 + x] * rs); bsum -= pb[part * 8 + x] * f[x]; }
-    bsum += __shfl_xor(bsum, 1, 64); bsum += __shfl_xor(bsum, 2, 64);
+    const float f0 = bf16_round(vw[c][j0] * rs), f1 = bf16_round(vw[c][j0 + 1] * rs);
+    float bsum = -(pb[j0] * f0 + pb[j0 + 1] * f1);
+    bsum += __shfl_xor(bsum, 1, 64); bsum += __shfl_xor(bsum, 2, 64); bsum += __shfl_xor(bsum, 4, 64); bsum += __shfl_xor(bsum, 8, 64);
     if (c0 + c < C) {
-        *reinterpret_cast<uint4*>(VWc + ((int64_t)b * C + c0 + c) * 32 + part * 8) = f_to_chunk<bf16>(f);
-#pragma unroll
-        for (int x = 0; x < 8; ++x) VWw[((int64_t)b * 32 + part * 8 + x) * C + c0 + c] = (bf16)f[x];
-        if (part == 0) { beta[(int64_t)b * C + c0 + c] = bsum; rw[(int64_t)b * C + c0 + c] = rs; }
+        *reinterpret_cast<uint32_t*>(VWc + ((int64_t)b * C + c0 + c) * 32 + j0) = pack_bf16x2(f0, f1);
+        VWw[((int64_t)b * 32 + j0) * C + c0 + c] = (bf16)f0;
+        VWw[((int64_t)b * 32 + j0 + 1) * C + c0 + c] = (bf16)f1;
+        if ((tid & 15) == 0) { beta[(int64_t)b * C + c0 + c] = bsum; rw[(int64_t)b * C + c0 + c] = rs; }
     }
 }
 
@@ -457,26 +533,40 @@ __global__ __launch_bounds__(256) void pwam_lang_bwd1_kernel(const float* __rest
     __shared__ float av[16], bv[16];
     const int tid = threadIdx.x, b = blockIdx.y;
     const float Tf = (float)T, invT = 1.0f / Tf;
+    float qacc[4] = {0.f, 0.f, 0.f, 0.f}, uacc = 0.f;
+    // (round 5) the global loads of a trip are requested one trip ahead (registers), so only the first trip's round trip is exposed: as loads at the
+    // head of every trip + the per-channel scalars behind its barrier, the C = 1024 launch (4 trips) was 8 dependent round trips, 14.5 us
+    const int c = tid >> 4, j0 = 2 * (tid & 15);
+    float n_vw[2], n_h[2], n_sc, n_rs;
+    auto request = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 256 * i;
+            n_vw[i] = (float)VWc[((int64_t)b * C + c0 + (e >> 5)) * 32 + (e & 31)];
+            n_h[i] = HT[((int64_t)b * C + c0 + (e >> 5)) * 32 + (e & 31)];
+        }
+        n_sc = s[(int64_t)b * C + c0 + c];
+        n_rs = rw[(int64_t)b * C + c0 + c];
+    };
+    request(min((int)blockIdx.x * 16, C - 16));
     if (tid < 32) pb[tid] = pbar[b * 32 + tid];
 #pragma unroll
     for (int e = tid; e < 1024; e += 256) cov[e >> 5][e & 31] = cov_in[(int64_t)b * 1024 + e];
-    float qacc[4] = {0.f, 0.f, 0.f, 0.f}, uacc = 0.f;
     for (int c0 = blockIdx.x * 16; c0 < C; c0 += gridDim.x * 16) {
     __syncthreads();
 #pragma unroll
-    for (int e = tid; e < 16 * 32; e += 256) {
-        const int c = e >> 5, j = e & 31;
-        vw[c][j] = (float)VWc[((int64_t)b * C + c0 + c) * 32 + j];
-        h[c][j] = HT[((int64_t)b * C + c0 + c) * 32 + j];
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + 256 * i;
+        vw[e >> 5][e & 31] = n_vw[i];
+        h[e >> 5][e & 31] = n_h[i];
     }
+    const float sc = n_sc, rs = n_rs;
+    if (c0 + (int)gridDim.x * 16 < C) request(c0 + gridDim.x * 16);
     __syncthreads();
-    const int c = tid >> 4, j0 = 2 * (tid & 15);
-    const float sc = s[(int64_t)b * C + c0 + c];
     float bs = vw[c][j0] * (h[c][j0] - pb[j0] * sc) + vw[c][j0 + 1] * (h[c][j0 + 1] - pb[j0 + 1] * sc);
     bs += __shfl_xor(bs, 1, 64); bs += __shfl_xor(bs, 2, 64); bs += __shfl_xor(bs, 4, 64); bs += __shfl_xor(bs, 8, 64);
     const float bc = bs * invT, ac = sc * invT;
     if ((tid & 15) == 0) { av[c] = ac; bv[c] = bc; }
-    const float rs = rw[(int64_t)b * C + c0 + c];
     float t0 = 0.f, t1 = 0.f;
 #pragma unroll 8
     for (int k = 0; k < 32; ++k) { const float v = vw[c][k]; t0 += cov[j0][k] * v; t1 += cov[j0 + 1][k] * v; }
@@ -554,7 +644,7 @@ extern "C" int lavt_pwam_words_fwd(const void* q, int64_t ldq, const void* K, in
     WordsArgs a{};
     a.X = (const bf16*)q; a.ldx = ldq; a.Wsrc = (const bf16*)K; a.ldw = ldk; a.mean = mean; a.rstd = rstd; a.vec = maskbias; a.out = (bf16*)P;
     a.T = T; a.C = C; a.n_l = n_l; a.alpha = alpha;
-    const size_t lds = (size_t)32 * (C + 8) * 2 + 128 + 32 * 40 * 2;
+    const size_t lds = (size_t)32 * (C + 8) * 2 + 128 + 32 * 40 * 2 + (size_t)C * 8;
     static size_t reserved = 0;
     if (lds > 65536 && lds > reserved) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pwam_words_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { lavt_set_error("lavt_pwam_words_fwd: cannot reserve LDS"); return LAVT_ERR_LAUNCH; }
@@ -571,7 +661,7 @@ extern "C" int lavt_pwam_words_bwd(const void* dwhat, int64_t ldx, const void* V
     WordsArgs a{};
     a.X = (const bf16*)dwhat; a.ldx = ldx; a.Wsrc = (const bf16*)VWw; a.ldw = C; a.Qf = Qp; a.pbar = pbar; a.P = (const bf16*)P; a.out = (bf16*)dS;
     a.T = T; a.C = C; a.n_l = lavt_pwam_q_parts(C); a.alpha = 1.f;
-    const size_t lds = (size_t)32 * (C + 8) * 2 + 128 + 32 * 40 * 2;
+    const size_t lds = (size_t)32 * (C + 8) * 2 + 128 + 32 * 40 * 2 + (size_t)C * 8;
     static size_t reserved = 0;
     if (lds > 65536 && lds > reserved) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pwam_words_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { lavt_set_error("lavt_pwam_words_bwd: cannot reserve LDS"); return LAVT_ERR_LAUNCH; }
@@ -601,7 +691,7 @@ extern "C" int lavt_pwam_mix(int mode, const void* Wd, const void* Wc, const flo
 extern "C" int lavt_pwam_lang_fwd(const void* V, int64_t ldv, const void* Wo, const float* PP, const float* sumP, void* VWc, void* VWw, float* beta, float* rw,
                                   float* pbar, float* cov, int B, int T, int C, float eps, void* stream) {
     LAVT_CHECK_ARG(V && Wo && PP && sumP && VWc && VWw && beta && rw && pbar && cov && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && ldv % 8 == 0, "lavt_pwam_lang_fwd: bad arguments");
-    hipLaunchKernelGGL(pwam_lang_fwd_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, ST, (const bf16*)V, ldv, (const bf16*)Wo, PP, sumP, (bf16*)VWc, (bf16*)VWw, beta, rw, pbar, cov, T, C, eps);
+    hipLaunchKernelGGL(pwam_lang_fwd_kernel, dim3(cdiv(C, 16), B), dim3(256), 0, ST, (const bf16*)V, ldv, (const bf16*)Wo, PP, sumP, (bf16*)VWc, (bf16*)VWw, beta, rw, pbar, cov, T, C, eps);
     LAVT_CHECK_LAUNCH("lavt_pwam_lang_fwd");
     return LAVT_OK;
 }

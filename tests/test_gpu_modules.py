@@ -699,7 +699,7 @@ def test_fused_adamw_with_model_forward_outside_train_step():
         assert torch.equal(ops.weights.get(qk, torch.bfloat16), qk.detach().to(torch.bfloat16)), "stale bf16 weight copy after FusedAdamW.step()"
 
 
-@pytest.mark.parametrize("C,T,gate_live", [(64, 90, True), (96, 200, True), (128, 1000, True), (256, 77, False), (512, 130, True)])
+@pytest.mark.parametrize("C,T,gate_live", [(64, 90, True), (96, 200, True), (128, 1000, True), (256, 77, False), (512, 130, True), (1024, 225, True)])
 def test_pwam_gate_fused_node(C, T, gate_live):
     """The fused PWAM + language-gate node (csrc/pwam.hip: instance norm of q folded into the keys, W projection collapsed onto the word
     probabilities) against the fp32 CPU oracle of the reference (lib/backbone.py:1265-1278, 1329-1372, 604-611, 669), forward and every gradient;

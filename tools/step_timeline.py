@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""One hipGraph replay of the training step as an ordered list of launches: offset from the step's first launch, duration, the idle gap in front of the
+launch (start - previous end), grid, kernel.  Read from a `rocprofv3 --kernel-trace --output-format csv` trace of `bench.py --steps N` (a replay is
+delimited by `upsample_ce_finish_kernel`, the loss: the launches after it are the backward of the same step).
+usage: step_timeline.py <kernel_trace.csv> [> profiles/rNN_step_timeline.txt]"""
+import csv
+import sys
+
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").replace("_ZN12_GLOBAL__N_1", "")[:110]
+fin = [i for i, r in enumerate(rows) if "upsample_ce_finish_kernel" in r["Kernel_Name"]]
+# the last occurrence is bench.py's eager loss check; a replay runs from the launch after loss k - 1's backward to the end of loss k's backward.  The first
+# launch of a replay is the one that follows the longest idle gap between two losses (the host's replay call).
+a, b = fin[-4], fin[-3]
+seg = rows[a:b + 1]
+gaps = [(int(seg[i + 1]["Start_Timestamp"]) - int(seg[i]["End_Timestamp"]), i + 1) for i in range(len(seg) - 1)]
+first = a + max(gaps)[1]
+seg2 = rows[fin[-3]:fin[-2] + 1]
+gaps2 = [(int(seg2[i + 1]["Start_Timestamp"]) - int(seg2[i]["End_Timestamp"]), i + 1) for i in range(len(seg2) - 1)]
+last = fin[-3] + max(gaps2)[1]
+step = rows[first:last]
+t0 = int(step[0]["Start_Timestamp"])
+span = (int(step[-1]["End_Timestamp"]) - t0) / 1e3
+busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step) / 1e3
+print(f"# {len(step)} launches, span {span:.1f} us, sum of kernel durations {busy:.1f} us, idle between launches {span - busy:.1f} us")
+print(f"# {'#':>4s} {'at us':>8s} {'dur us':>7s} {'gap us':>6s}  {'grid':>12s} wg    kernel")
+prev_end = t0
+for i, r in enumerate(step):
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    grid = f"{int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1)}x{int(r['Grid_Size_Y']) // max(int(r['Workgroup_Size_Y']), 1)}"
+    print(f"  {i:4d} {(s - t0) / 1e3:8.1f} {(e - s) / 1e3:7.1f} {(s - prev_end) / 1e3:6.1f}  {grid:>12s} {r['Workgroup_Size_X']:>4s}  {short(r['Kernel_Name'])}")
+    prev_end = e
