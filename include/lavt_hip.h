@@ -504,6 +504,11 @@ int lavt_fp8_quantize_weight_t(const float* src, void* dst, float* amax, int cou
 int lavt_cls_head_fwd(int dtype, const void* x, const float* w, const float* b, void* y, int64_t rows, int C, void* stream);
 int lavt_cls_head_bwd(int dtype, const void* x, const void* dy, const float* w, void* dx, float* dw, float* db,
                       int64_t rows, int C, void* stream);
+/* the same backward with the weight / bias gradient sums left as one record per workgroup (pw [blocks][2 C], pb [blocks][2], blocks =
+ *   lavt_cls_head_bwd_blocks) for lavt_reduce_partials_multi: no global atomics, run-to-run identical sums */
+int lavt_cls_head_bwd_blocks(int dtype, int64_t rows, int C);
+int lavt_cls_head_bwd_partial(int dtype, const void* x, const void* dy, const float* w, void* dx, float* pw, float* pb,
+                              int64_t rows, int C, void* stream);
 /* PatchEmbed im2col: NCHW fp32 image -> [B*H4*W4][48] patches (zero padded to x4), lib/backbone.py:318-324;
  * col2im scatters the patch gradient back to an NCHW fp32 image gradient. */
 int lavt_im2col4(int dtype, const float* img, void* cols, int B, int H, int W, void* stream);

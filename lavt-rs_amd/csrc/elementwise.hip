@@ -290,6 +290,75 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(const T* __restric
     }
 }
 
+// Tiled form (round 5): a workgroup owns TL x TL low-resolution pixels.  Phase 1 evaluates every full-resolution pixel that can touch the tile ONCE
+// (target, four neighbours, softmax) and parks w_t (softmax_c - [c == t]) in LDS; phase 2 gathers each low-resolution pixel's candidates from LDS, four
+// lanes per pixel.  The wave-per-pixel form above evaluates ~100 candidates per low-resolution pixel (every full-resolution pixel up to 4 x, plus the
+// zero-weight ring): 27.7 us at 2 x 480 x 480 -> 120 x 120 where this form evaluates ~27 per pixel.
+constexpr int UPCE_TL = 8;
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_ce_bwd_tile_kernel(const T* __restrict__ x, const int64_t* __restrict__ target, float w0, float w1,
+                                                                   const float* __restrict__ stats, const float* __restrict__ dloss, T* __restrict__ dx,
+                                                                   int B, int Hi, int Wi, int Ho, int Wo, float sh, float sw, int lds_pixels) {
+    extern __shared__ __attribute__((aligned(16))) char upce_smem[];
+    float2* g = reinterpret_cast<float2*>(upce_smem);
+    const int tiles_x = (Wi + UPCE_TL - 1) / UPCE_TL, tiles_y = (Hi + UPCE_TL - 1) / UPCE_TL;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+    const int yi0 = ty * UPCE_TL, xi0 = tx * UPCE_TL, yi1 = min(yi0 + UPCE_TL - 1, Hi - 1), xi1 = min(xi0 + UPCE_TL - 1, Wi - 1);
+    int ylo, yhi, xlo, xhi, tmp;
+    bl_range(yi0, sh, Hi, Ho, ylo, tmp); bl_range(yi1, sh, Hi, Ho, tmp, yhi);
+    bl_range(xi0, sw, Wi, Wo, xlo, tmp); bl_range(xi1, sw, Wi, Wo, tmp, xhi);
+    const int nx = xhi - xlo + 1, ny = yhi - ylo + 1;
+    const T* base = x + (int64_t)b * Hi * Wi * 2;
+    const float gscale = (stats[1] > 0.f ? 1.f / stats[1] : 0.f) * (dloss ? dloss[0] : 1.f);
+    for (int idx = threadIdx.x; idx < nx * ny && idx < lds_pixels; idx += 256) {
+        const int yo = ylo + idx / nx, xo = xlo + idx % nx;
+        const int64_t t = target[((int64_t)b * Ho + yo) * Wo + xo];
+        float2 v = make_float2(0.f, 0.f);
+        if (t == 0 || t == 1) {
+            int y0, y1, x0, x1; float ly, lx;
+            bl_coord(yo, sh, Hi, y0, y1, ly);
+            bl_coord(xo, sw, Wi, x0, x1, lx);
+            const UpCe u = upce_at<T>(base, Wi, y0, y1, ly, x0, x1, lx);
+            const float w = t ? w1 : w0;
+            v.x = w * (expf(u.up0 - u.lse) - (t == 0 ? 1.f : 0.f));
+            v.y = w * (expf(u.up1 - u.lse) - (t == 1 ? 1.f : 0.f));
+        }
+        g[idx] = v;
+    }
+    __syncthreads();
+    const int p = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    const int yi = yi0 + p / UPCE_TL, xi = xi0 + p % UPCE_TL;
+    const bool live = yi < Hi && xi < Wi;
+    float a0 = 0.f, a1 = 0.f;
+    if (live) {
+        int cylo, cyhi, cxlo, cxhi;
+        bl_range(yi, sh, Hi, Ho, cylo, cyhi);
+        bl_range(xi, sw, Wi, Wo, cxlo, cxhi);
+        for (int yo = cylo; yo <= cyhi; ++yo) {
+            int y0, y1; float ly;
+            bl_coord(yo, sh, Hi, y0, y1, ly);
+            const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
+            if (wy == 0.f) continue;
+            const float2* row = g + (yo - ylo) * nx - xlo;
+            for (int xo = cxlo + sub; xo <= cxhi; xo += 4) {
+                int x0, x1; float lx;
+                bl_coord(xo, sw, Wi, x0, x1, lx);
+                const float wx = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
+                const float2 v = row[xo];
+                a0 += wy * wx * v.x;
+                a1 += wy * wx * v.y;
+            }
+        }
+    }
+    a0 += __shfl_xor(a0, 1, 64); a0 += __shfl_xor(a0, 2, 64);
+    a1 += __shfl_xor(a1, 1, 64); a1 += __shfl_xor(a1, 2, 64);
+    if (live && sub == 0) {
+        const int64_t i = ((int64_t)b * Hi + yi) * Wi + xi;
+        dx[i * 2] = from_f<T>(a0 * gscale);
+        dx[i * 2 + 1] = from_f<T>(a1 * gscale);
+    }
+}
+
 template <typename T> __global__ void logits_up_fwd_kernel(const T* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, float sh, float sw) {
     const int64_t n = (int64_t)B * Ho * Wo;
     GRID_STRIDE(i, n) {
@@ -350,9 +419,12 @@ template <typename T> __global__ __launch_bounds__(256) void cls_head_fwd_kernel
         if (lane == 0) { y[row * 2] = from_f<T>(a0 + bias[0]); y[row * 2 + 1] = from_f<T>(a1 + bias[1]); }
     }
 }
-template <typename T> __global__ __launch_bounds__(256) void cls_head_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, float* dw, float* db, int64_t rows, int C) {
+// PART: the workgroup's sums go to its own record of a partial table (pw [blocks][2 C], pb [blocks][2]; reduced with the LayerNorm partial sums by
+// lavt_reduce_partials_multi at the end of backward) instead of 2 C + 2 global atomics per workgroup: 450 workgroups adding to the same 1026 addresses
+// were most of the launch (31 us for 59 MB of rows at 2 x 120 x 120 x 512), and their order changed the sums from run to run.
+template <typename T, bool PART> __global__ __launch_bounds__(256) void cls_head_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, float* dw, float* db, int64_t rows, int C) {
     // thread owns one chunk column for a strip of rows: dx = dy0*w0 + dy1*w1 ; dw[c] += dy[c]*x ; db += dy
-    constexpr int EPC = Chunk<T>::N;
+    constexpr int EPC = Chunk<T>::N, U = 8;
     const int cpr = C / EPC;
     const int tc = threadIdx.x % cpr, tr = threadIdx.x / cpr, rstep = blockDim.x / cpr;
     const bool live = tr < rstep;
@@ -360,14 +432,14 @@ template <typename T> __global__ __launch_bounds__(256) void cls_head_bwd_kernel
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { w0[e] = w[tc * EPC + e]; w1[e] = w[C + tc * EPC + e]; g0[e] = 0.f; g1[e] = 0.f; }
     float b0 = 0.f, b1 = 0.f;
-    // four rows per trip, every load of the trip issued before the first use (one row per trip was a chain of ~14 dependent L2 / HBM round trips per
+    // eight rows per trip, every load of the trip issued before the first use (one row per trip was a chain of ~14 dependent L2 / HBM round trips per
     // thread: 40 us for the 2 x 120 x 120 x 512 map where the bytes take ~12)
     const int64_t rs = (int64_t)gridDim.x * rstep;
-    for (int64_t row = (int64_t)blockIdx.x * rstep + tr; live && row < rows; row += 4 * rs) {
-        uint4 xv[4];
-        float d0[4], d1[4];
+    for (int64_t row = (int64_t)blockIdx.x * rstep + tr; live && row < rows; row += U * rs) {
+        uint4 xv[U];
+        float d0[U], d1[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int64_t r = row + u * rs;
             const bool ok = r < rows;
             const int64_t rr = ok ? r : row;
@@ -376,7 +448,7 @@ template <typename T> __global__ __launch_bounds__(256) void cls_head_bwd_kernel
             d1[u] = ok ? to_f<T>(dy[rr * 2 + 1]) : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int64_t r = row + u * rs;
             if (r >= rows) break;
             float f[EPC], o[EPC];
@@ -387,18 +459,25 @@ template <typename T> __global__ __launch_bounds__(256) void cls_head_bwd_kernel
             if (tc == 0) { b0 += d0[u]; b1 += d1[u]; }
         }
     }
-    // combine the row-lanes of the workgroup in LDS first: 2*C (+2) atomics per workgroup instead of per row-lane
+    // combine the row-lanes of the workgroup in LDS first (fixed order: row-lane by row-lane)
     __shared__ float red[2 * 2048 + 2];
     for (int e = threadIdx.x; e < 2 * C + 2; e += blockDim.x) red[e] = 0.f;
     __syncthreads();
-    if (live) {
+    for (int k = 0; k < rstep; ++k) {
+        if (live && tr == k) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { atomicAdd(red + tc * EPC + e, g0[e]); atomicAdd(red + C + tc * EPC + e, g1[e]); }
-        if (tc == 0) { atomicAdd(red + 2 * C, b0); atomicAdd(red + 2 * C + 1, b1); }
+            for (int e = 0; e < EPC; ++e) { red[tc * EPC + e] += g0[e]; red[C + tc * EPC + e] += g1[e]; }
+            if (tc == 0) { red[2 * C] += b0; red[2 * C + 1] += b1; }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) atomicAdd(dw + e, red[e]);
-    if (threadIdx.x < 2) atomicAdd(db + threadIdx.x, red[2 * C + threadIdx.x]);
+    if constexpr (PART) {
+        for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) dw[(int64_t)blockIdx.x * 2 * C + e] = red[e];
+        if (threadIdx.x < 2) db[blockIdx.x * 2 + threadIdx.x] = red[2 * C + threadIdx.x];
+    } else {
+        for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) atomicAdd(dw + e, red[e]);
+        if (threadIdx.x < 2) atomicAdd(db + threadIdx.x, red[2 * C + threadIdx.x]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- patch-embed im2col (4x4 / stride 4)
@@ -716,6 +795,18 @@ extern "C" int lavt_upsample_ce_bwd(int dtype, const void* x, const int64_t* tar
                                     void* dx, int B, int Hi, int Wi, int Ho, int Wo, void* stream) {
     LAVT_CHECK_ARG(x && target && out4 && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "lavt_upsample_ce_bwd: bad arguments");
     const int64_t n = (int64_t)B * Hi * Wi;
+    // tiled form: the full-resolution region of a TL x TL tile must fit LDS (bl_range: (TL + 1) / scale + 5 rows / columns)
+    const float sh = bl_scale(Hi, Ho), sw = bl_scale(Wi, Wo);
+    if (sh > 0.f && sw > 0.f && !lavt_tuning().upce_tile_off) {
+        const long ny = (long)((UPCE_TL + 1) / sh) + 6, nx = (long)((UPCE_TL + 1) / sw) + 6;
+        const long tiles = (long)B * cdiv(Hi, UPCE_TL) * cdiv(Wi, UPCE_TL);
+        if (ny * nx * 8 <= 48 * 1024 && tiles < (1L << 30)) {
+            DISPATCH_T(dtype, "lavt_upsample_ce_bwd", hipLaunchKernelGGL(upsample_ce_bwd_tile_kernel<T>, dim3((unsigned)tiles), dim3(256), (size_t)(ny * nx * 8), ST, (const T*)x, target, w0, w1, out4, dloss,
+                                                                          (T*)dx, B, Hi, Wi, Ho, Wo, sh, sw, (int)(ny * nx)));
+            LAVT_CHECK_LAUNCH("lavt_upsample_ce_bwd");
+            return LAVT_OK;
+        }
+    }
     const int blocks = (int)((n + 3) / 4 > 8192 ? 8192 : (n + 3) / 4);          // a wave per low-resolution pixel
     DISPATCH_T(dtype, "lavt_upsample_ce_bwd", hipLaunchKernelGGL(upsample_ce_bwd_kernel<T>, dim3(blocks), dim3(256), 0, ST, (const T*)x, target, w0, w1, out4, dloss, (T*)dx, B, Hi, Wi, Ho, Wo, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
     LAVT_CHECK_LAUNCH("lavt_upsample_ce_bwd");
@@ -729,16 +820,29 @@ extern "C" int lavt_cls_head_fwd(int dtype, const void* x, const float* w, const
     LAVT_CHECK_LAUNCH("lavt_cls_head_fwd");
     return LAVT_OK;
 }
+static int cls_head_bwd_blocks(int dtype, int64_t rows, int C) {
+    const int cpr = C / EPC_OF(dtype), rstep = 256 / (cpr > 0 ? cpr : 1);
+    int blocks = (int)cdiv(rows, (long)(rstep > 0 ? rstep : 1) * 16);
+    if (blocks > 512) blocks = 512;       // each workgroup ends with 2 C + 2 atomics / one partial record (after an LDS combine of its row-lanes)
+    return blocks < 1 ? 1 : blocks;
+}
+extern "C" int lavt_cls_head_bwd_blocks(int dtype, int64_t rows, int C) { return cls_head_bwd_blocks(dtype, rows, C); }
 extern "C" int lavt_cls_head_bwd(int dtype, const void* x, const void* dy, const float* w, void* dx, float* dw, float* db,
                                  int64_t rows, int C, void* stream) {
     const int cpr = C / EPC_OF(dtype);
     LAVT_CHECK_ARG(x && dy && w && dx && dw && db && rows > 0 && C % EPC_OF(dtype) == 0 && cpr <= 256 && C <= 2048, "lavt_cls_head_bwd: bad arguments");
-    const int rstep = 256 / cpr;
-    int blocks = cdiv(rows, (long)rstep * 16);
-    if (blocks > 512) blocks = 512;       // each workgroup ends with 2*C atomics (after an LDS combine of its row-lanes)
-    if (blocks < 1) blocks = 1;
-    DISPATCH_T(dtype, "lavt_cls_head_bwd", hipLaunchKernelGGL(cls_head_bwd_kernel<T>, dim3(blocks), dim3(256), 0, ST, (const T*)x, (const T*)dy, w, (T*)dx, dw, db, rows, C));
+    const int blocks = cls_head_bwd_blocks(dtype, rows, C);
+    DISPATCH_T(dtype, "lavt_cls_head_bwd", hipLaunchKernelGGL((cls_head_bwd_kernel<T, false>), dim3(blocks), dim3(256), 0, ST, (const T*)x, (const T*)dy, w, (T*)dx, dw, db, rows, C));
     LAVT_CHECK_LAUNCH("lavt_cls_head_bwd");
+    return LAVT_OK;
+}
+extern "C" int lavt_cls_head_bwd_partial(int dtype, const void* x, const void* dy, const float* w, void* dx, float* pw, float* pb,
+                                         int64_t rows, int C, void* stream) {
+    const int cpr = C / EPC_OF(dtype);
+    LAVT_CHECK_ARG(x && dy && w && dx && pw && pb && rows > 0 && C % EPC_OF(dtype) == 0 && cpr <= 256 && C <= 2048, "lavt_cls_head_bwd_partial: bad arguments");
+    const int blocks = cls_head_bwd_blocks(dtype, rows, C);
+    DISPATCH_T(dtype, "lavt_cls_head_bwd_partial", hipLaunchKernelGGL((cls_head_bwd_kernel<T, true>), dim3(blocks), dim3(256), 0, ST, (const T*)x, (const T*)dy, w, (T*)dx, pw, pb, rows, C));
+    LAVT_CHECK_LAUNCH("lavt_cls_head_bwd_partial");
     return LAVT_OK;
 }
 extern "C" int lavt_im2col4(int dtype, const float* img, void* cols, int B, int H, int W, void* stream) {

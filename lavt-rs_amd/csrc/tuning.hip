@@ -49,6 +49,7 @@ void read_tuning(lavt_tuning_t& t) {
     t.gemm_pipe = env_int("LAVT_GEMM_PIPE", 2);                  // gemm_nt_pipe.hip: 0 off, 1 the 256x256 tile, 2 + 128x128 tiles with K >= 1024, 3 + every 128x128 problem
     t.conv_tail_off = env_is("LAVT_CONV_TAIL", '0');             // 480-channel concat convolution (Swin-T) on the general decode instead of the partial-block tap walk (A/B switch)
     t.side_pre_off = env_is("LAVT_SIDE_PRE", '0');               // epilogue side inputs (residual, activation-gradient operand, multiplier) loaded at the head of the epilogue instead of before the K loop
+    t.upce_tile_off = env_is("LAVT_UPCE_TILE", '0');             // fused upsample + cross-entropy backward: the wave-per-low-resolution-pixel form instead of the tiled one
     t.tn_pipe = env_int("LAVT_TN_PIPE", 2);                      // gemm_tn_pipe.hip: grouped weight gradients on 128x128 pipelined tiles -- 0: never (gemm_tn_v2.hip's 64x64 launch), 1: uncut groups only, 2: + long reductions cut into K pieces
     t.tn_pipe_min_tiles = env_int("LAVT_TN_PIPE_MIN_TILES", 128);
     t.tn_pipe_stages = env_int("LAVT_TN_PIPE_STAGES", 4);

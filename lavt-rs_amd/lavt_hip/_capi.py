@@ -223,6 +223,8 @@ _PROTOTYPES = {
     "lavt_fp8_quantize_current": [i32, vp, vp, i64, vp, vp],
     "lavt_cls_head_fwd": [i32, vp, vp, vp, vp, i64, i32, vp],
     "lavt_cls_head_bwd": [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "lavt_cls_head_bwd_partial": [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "lavt_cls_head_bwd_blocks": [i32, i64, i32],
     "lavt_im2col4": [i32, vp, vp, i32, i32, i32, vp],
     "lavt_col2im4": [i32, vp, vp, i32, i32, i32, vp],
     "lavt_cast": [i32, vp, i32, vp, i64, vp],

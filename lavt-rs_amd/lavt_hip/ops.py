@@ -2620,6 +2620,15 @@ class _ClsHead(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw, wsink = sinks.buf(weight, (2, Cc))
         db, bsink = sinks.buf(bias, (2,))
+        if wsink and bsink and ln_deferred.active():
+            # under the step harness the per-workgroup sums ride in the end-of-backward reduction of the LayerNorm partial sums (no global atomics)
+            nblk = int(K.lib.lavt_cls_head_bwd_blocks(K.dt(x.dtype), R, Cc))
+            pw, pb = ln_deferred.alloc(nblk * 2 * Cc, x.device), ln_deferred.alloc(nblk * 2, x.device)
+            if pw is not None and pb is not None:
+                K.check(K.lib.lavt_cls_head_bwd_partial(K.dt(x.dtype), K.ptr(x), K.ptr(dy), K.ptr(_f32(weight)), K.ptr(dx), K.ptr(pw), K.ptr(pb), R, Cc, K.stream()))
+                ln_deferred.add(pw, nblk, Cc, dw[0], dw[1], (weight,))
+                ln_deferred.add(pb, nblk, 1, db[0:1], db[1:2], (bias,))
+                return dx, None, None
         K.check(K.lib.lavt_cls_head_bwd(K.dt(x.dtype), K.ptr(x), K.ptr(dy), K.ptr(_f32(weight)), K.ptr(dx), K.ptr(dw), K.ptr(db), R, Cc, K.stream()))
         return dx, sinks.done(weight, dw, wsink), sinks.done(bias, db, bsink)
 
