@@ -349,7 +349,8 @@ int lavt_layernorm_bwd_partial_xn(int dtype, const void* dy, const void* x, cons
                                   void* dx, void* xn, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream);
 int lavt_layernorm_bwd_xn(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                           void* dx, void* xn, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream);
-int lavt_reduce_partials_multi(const int64_t* desc, int n, int total_column_blocks, void* stream); /* total_column_blocks = sum over the sets of ceil(2 C / 32) (ABI v6; <= 0: unknown) */
+int lavt_reduce_partials_multi(const int64_t* desc, int n, int total_column_blocks, void* stream); /* total_column_blocks = sum over the sets of lavt_reduce_partials_column_blocks(C) (<= 0: unknown; a larger number -- e.g. the ceil(2 C / 32) of the first ABI v6 builds -- only starts idle workgroups) */
+int lavt_reduce_partials_column_blocks(int C);
 /* dres (optional, [rows][C], not with gather): gradient of the residual stream that bypassed the LayerNorm (x -> LN(x) and x -> + ...):
  * dx = LN'(dy) + dres in the same pass, instead of a separate element-wise add of the two gradients of x */
 

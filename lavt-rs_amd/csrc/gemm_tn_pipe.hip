@@ -46,6 +46,7 @@ __host__ __device__ inline void tnp_dma16(tnp_rsrc_t, void*, unsigned) {}
 typedef int tnp_i32x8 __attribute__((ext_vector_type(8)));
 typedef tnp_i32x8 __attribute__((aligned(4))) tnp_i32x8_u;          // (row maps are 4-byte aligned: s_load_dwordx8 needs no more)
 typedef __attribute__((address_space(4))) const tnp_i32x8_u* tnp_cptr8;
+typedef __attribute__((address_space(4))) const int* tnp_cptr1;
 
 // transposing reads of NF fragments of one k-step (two reads per fragment: K rows r and r + 4 of the lane's 8-row block), issued only
 template <int NF, int HO, int KOFF> __device__ __forceinline__ void tnp_issue_tr(const unsigned (&a)[NF], u64 (&l)[NF], u64 (&h)[NF]) {
@@ -108,7 +109,7 @@ constexpr unsigned TNP_OOB = 0x80000000u;
 
 // One 128x128 output tile of member m.  MAPS: the member has a row map or a row mask (per-K-tile offset arithmetic); else the K rows are
 // consecutive and a lane's offsets just advance.
-template <int STAGES, bool MAPS>
+template <int STAGES, int MAPS>          // MAPS 0: plain rows; 1: row maps / row mask; 2: + a mapped reduction whose length is not a multiple of 8
 __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int local, char* smem) {
     constexpr int BT = 128, BK = 64, CH = BT / 8, L = 4;
     constexpr int TILE_BYTES = BK * BT * 2, STAGE_BYTES = 2 * TILE_BYTES;
@@ -178,6 +179,20 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int local, ch
         if constexpr (MAPS) {
             int e = k_first + t * BK + wave * 8;
             e = e < Kd ? e : 0;
+            if constexpr (MAPS == 2) {
+                // (round 5: the last stage's 450 tokens, batch 4's 900) the map ends inside this wave's eight entries: read them one by one, clamped to the
+                // last entry -- one wide load would read up to 28 bytes past the caller's map; the rows at and beyond K are masked by k < Kd below
+                if (e + 8 > m.K) {
+                    const int last = m.K - 1;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int idx = min(e + j, last);
+                        if (map_a) sa[j] = *reinterpret_cast<tnp_cptr1>(reinterpret_cast<uintptr_t>(map_a + idx));
+                        if (map_b) sb[j] = *reinterpret_cast<tnp_cptr1>(reinterpret_cast<uintptr_t>(map_b + idx));
+                    }
+                    return;
+                }
+            }
             if (map_a) sa = *reinterpret_cast<tnp_cptr8>(reinterpret_cast<uintptr_t>(map_a + e));
             if (map_b) sb = *reinterpret_cast<tnp_cptr8>(reinterpret_cast<uintptr_t>(map_b + e));
         }
@@ -428,8 +443,9 @@ __global__ __launch_bounds__(512) void gemm_tn_pipe_kernel(const TnpGroup g, con
     while (k + 1 < g.n && t >= g.m[k].tile_end) ++k;
     const TnpMember& m = g.m[k];
     const int local = t - (k ? g.m[k - 1].tile_end : 0);
-    if (m.a_map || m.b_map || m.a_rs) tnp_tile<STAGES, true>(m, local, smem);
-    else tnp_tile<STAGES, false>(m, local, smem);
+    if ((m.a_map || m.b_map) && (m.K & 7)) tnp_tile<STAGES, 2>(m, local, smem);
+    else if (m.a_map || m.b_map || m.a_rs) tnp_tile<STAGES, 1>(m, local, smem);
+    else tnp_tile<STAGES, 0>(m, local, smem);
 }
 
 // second stage of the K pieces: C[i][j] += sum_s part[s][i][j], colsum[i] += sum_s part[pieces][s][i] (fixed order: run-to-run identical; a member whose bias
@@ -545,7 +561,6 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
         if (p.I % 8 || p.J % 4 || p.lda % 8 || p.ldb % 8 || p.K < 8) return 1;
         if ((int64_t)(p.K + 1024) * p.lda * 2 >= (1LL << 30) || (int64_t)(p.K + 1024) * p.ldb * 2 >= (1LL << 30)) return 1;          // 32-bit byte offsets inside a 2 GB descriptor, with room for the source rows of a mapped operand and the tiles issued beyond K
         if (p.a_rowscale && (!p.a_rowscale_binary || p.a_rowscale_div < 64 || (p.K + p.a_rowscale_div - 1) / p.a_rowscale_div > 64)) return 1;
-        if ((p.a_rowmap || p.b_rowmap) && p.K % 8) return 1;     // a wave's eight K rows come from one aligned scalar load inside the map
         if (no_b && !p.colsum) return 1;
         if (!no_b && p.J % 8) return 1;
         TnpMember& m = g.m[i];
@@ -570,6 +585,9 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
     bool any_pieces = false, drop_rider = false;
     int64_t max_total = 0;
     if (base_tiles >= tun.tn_pipe_min_tiles) {
+        // (short reductions stay on the 64x64 launch: at 8 K tiles -- the last stage's 450 tokens, 792 tiles -- a workgroup that holds a CU alone spends more
+        // on its ring prologue and its 64 KB epilogue than on its K loop, and nothing else runs on the CU meanwhile: 54 us against 49)
+        if (work < (long)base_tiles * tun.tn_pipe_min_ktiles) return 1;
         for (int i = 0; i < n; ++i) {
             if (cdiv(probs[i].K, 64) > 128) return 1;
             tiles += g.m[i].tiles;

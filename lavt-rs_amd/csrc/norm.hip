@@ -88,12 +88,20 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int w = blockIdx.x * 32 + col;
     const int per = (nblk + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * per, k1 = min(nblk, k0 + per);
-    float a = 0.f;
-    if (w < W)
-        for (int k = k0 + slice; k < k1; k += 8) a += partials[(int64_t)k * W + w];
-    red[slice][col] = a;
+    float a = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (w < W) {
+        // (four rows in flight per thread and up to 16 row pieces: one row at a time in 4 pieces, the 900 x 1024 partial sums of a 512-channel BatchNorm
+        // backward -- 3.7 MB -- took 10.6 us)
+        int k = k0 + slice;
+        for (; k + 24 < k1; k += 32) {
+            a += partials[(int64_t)k * W + w]; a1 += partials[(int64_t)(k + 8) * W + w];
+            a2 += partials[(int64_t)(k + 16) * W + w]; a3 += partials[(int64_t)(k + 24) * W + w];
+        }
+        for (; k < k1; k += 8) a += partials[(int64_t)k * W + w];
+    }
+    red[slice][col] = (a + a1) + (a2 + a3);
     __syncthreads();
-    if (slice == 0 && w < W) {
+    if (slice == 0 && w < W && k0 < k1) {
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][col];
@@ -107,6 +115,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // desc[s] = {partials, nblk, C, o1, o2}; partials [nblk][2][C]; the row slices of a set meet through atomics.
 // COMPACT: blockIdx.x runs over the column blocks of ALL sets (the host passes their total): the (128 column blocks, 8 slices, sets) grid of the first
 // version started 57 344 workgroups for Swin-B's 56 sets, two thirds of which found no columns (34 us for ~80 MB of partial sums).
+// (round 5) a workgroup covers 128 columns (a float4 per lane, 32 lanes) x 8 row slices, four rows in flight per thread: as 32 scalar columns per
+// workgroup the 75 MB of Swin-B's partial sums were read at 2.2 TB/s (33.6 us, the last launch of every backward pass).
+constexpr int RPM_COLS = 128;
 template <bool COMPACT>
 __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(const int64_t* __restrict__ desc, int nsets) {
     int set = blockIdx.z, cb = blockIdx.x;
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(const int64_
         // the first lane whose sum exceeds blockIdx.x names the set -- one round trip (as a serial scan over the descriptors every workgroup paid
         // up to 56 dependent loads: slower than the empty workgroups it was meant to save)
         const int ln = threadIdx.x & 63;
-        int nb = ln < nsets ? (2 * (int)desc[(int64_t)ln * 5 + 2] + 31) / 32 : 0;
+        int nb = ln < nsets ? (2 * (int)desc[(int64_t)ln * 5 + 2] + RPM_COLS - 1) / RPM_COLS : 0;
         int pre = nb;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -132,27 +143,45 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(const int64_
     const int nblk = (int)d[1], C = (int)d[2], W = 2 * C;
     float* o1 = reinterpret_cast<float*>(d[3]);
     float* o2 = reinterpret_cast<float*>(d[4]);
-    if (cb * 32 >= W) return;
-    __shared__ float red[8][33];
+    if (cb * RPM_COLS >= W) return;
+    __shared__ float4 red[8][33];
     const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    const int w = cb * 32 + col;
+    const int w = cb * RPM_COLS + 4 * col;
     const int per = (nblk + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * per, k1 = min(nblk, k0 + per);
-    float a = 0.f, b = 0.f;
-    if (w < W) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, e = a;
+    if (w + 3 < W && (W & 3) == 0) {
         int k = k0 + slice;
-        for (; k + 8 < k1; k += 16) { a += partials[(int64_t)k * W + w]; b += partials[(int64_t)(k + 8) * W + w]; }
-        for (; k < k1; k += 8) a += partials[(int64_t)k * W + w];
+        for (; k + 24 < k1; k += 32) {
+            const float4 v0 = *reinterpret_cast<const float4*>(partials + (int64_t)k * W + w), v1 = *reinterpret_cast<const float4*>(partials + (int64_t)(k + 8) * W + w);
+            const float4 v2 = *reinterpret_cast<const float4*>(partials + (int64_t)(k + 16) * W + w), v3 = *reinterpret_cast<const float4*>(partials + (int64_t)(k + 24) * W + w);
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w; b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
+            c.x += v2.x; c.y += v2.y; c.z += v2.z; c.w += v2.w; e.x += v3.x; e.y += v3.y; e.z += v3.z; e.w += v3.w;
+        }
+        for (; k < k1; k += 8) {
+            const float4 v0 = *reinterpret_cast<const float4*>(partials + (int64_t)k * W + w);
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+        }
+    } else if (w < W) {          // (a width that is not a multiple of 4: the classifier head's 2-column bias set)
+        for (int k = k0 + slice; k < k1; k += 8) {
+            a.x += partials[(int64_t)k * W + w];
+            if (w + 1 < W) a.y += partials[(int64_t)k * W + w + 1];
+            if (w + 2 < W) a.z += partials[(int64_t)k * W + w + 2];
+            if (w + 3 < W) a.w += partials[(int64_t)k * W + w + 3];
+        }
     }
-    red[slice][col] = a + b;
+    red[slice][col] = make_float4((a.x + b.x) + (c.x + e.x), (a.y + b.y) + (c.y + e.y), (a.z + b.z) + (c.z + e.z), (a.w + b.w) + (c.w + e.w));
     __syncthreads();
     if (slice == 0 && w < W && k0 < k1) {
-        float t = 0.f;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][col];
-        atomicAdd((w >= C ? o2 : o1) + (w >= C ? w - C : w), t);
+        for (int k = 0; k < 8; ++k) { const float4 v = red[k][col]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (w + i < W) atomicAdd((w + i >= C ? o2 : o1) + (w + i >= C ? w + i - C : w + i), tv[i]);
     }
 }
-static inline dim3 reduce_partials_grid(int nblk, int W) { return dim3(cdiv(W, 32), nblk >= 128 ? 4 : (nblk >= 48 ? 2 : 1)); }
+static inline dim3 reduce_partials_grid(int nblk, int W) { return dim3(cdiv(W, 32), nblk >= 768 ? 16 : nblk >= 384 ? 8 : nblk >= 128 ? 4 : (nblk >= 48 ? 2 : 1)); }
 
 // ---------------------------------------------------------------------------------------------- column statistics
 // grid: (row blocks, groups).  Thread t owns chunk column t % cpr and walks rows t / cpr, + 256/cpr, ...
@@ -570,12 +599,14 @@ extern "C" int lavt_layernorm_bwd_xn(int dtype, const void* dy, const void* x, c
     LAVT_CHECK_ARG(xn && beta, "lavt_layernorm_bwd_xn: xn and beta required");
     return layernorm_bwd_impl(dtype, dy, x, nullptr, gamma, mean, rstd, dx, dgamma, dbeta, ws, ws_floats, dres, rows, C, stream, false, xn, beta);
 }
+// column blocks of a set of width C in the compact grid of lavt_reduce_partials_multi (the caller passes their sum over the sets)
+extern "C" int lavt_reduce_partials_column_blocks(int C) { return (2 * C + RPM_COLS - 1) / RPM_COLS; }
 extern "C" int lavt_reduce_partials_multi(const int64_t* desc, int n, int total_column_blocks, void* stream) {
     LAVT_CHECK_ARG(desc && n > 0, "lavt_reduce_partials_multi: bad arguments");
-    if (total_column_blocks > 0 && n <= 64)          // sum over the sets of ceil(2 C / 32): one workgroup column per 32 columns that exist
+    if (total_column_blocks > 0 && n <= 64)          // sum over the sets of lavt_reduce_partials_column_blocks(C): one workgroup column per 128 columns that exist
         hipLaunchKernelGGL(reduce_partials_multi_kernel<true>, dim3(total_column_blocks, 8, 1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, n);
-    else          // (the caller does not know the widths: widest supported set C = 2048 -> 128 column blocks per set)
-        hipLaunchKernelGGL(reduce_partials_multi_kernel<false>, dim3(128, 8, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, n);
+    else          // (the caller does not know the widths: widest supported set C = 2048 -> 32 column blocks per set)
+        hipLaunchKernelGGL(reduce_partials_multi_kernel<false>, dim3(4096 / RPM_COLS, 8, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, n);
     LAVT_CHECK_LAUNCH("lavt_reduce_partials_multi");
     return LAVT_OK;
 }

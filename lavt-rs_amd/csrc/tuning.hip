@@ -52,6 +52,7 @@ void read_tuning(lavt_tuning_t& t) {
     t.upce_tile_off = env_is("LAVT_UPCE_TILE", '0');             // fused upsample + cross-entropy backward: the wave-per-low-resolution-pixel form instead of the tiled one
     t.tn_pipe = env_int("LAVT_TN_PIPE", 2);                      // gemm_tn_pipe.hip: grouped weight gradients on 128x128 pipelined tiles -- 0: never (gemm_tn_v2.hip's 64x64 launch), 1: uncut groups only, 2: + long reductions cut into K pieces
     t.tn_pipe_min_tiles = env_int("LAVT_TN_PIPE_MIN_TILES", 128);
+    t.tn_pipe_min_ktiles = env_int("LAVT_TN_PIPE_MIN_KTILES", 12);   // uncut groups: average K tiles per output tile below which the group stays on the 64x64 launch
     t.tn_pipe_stages = env_int("LAVT_TN_PIPE_STAGES", 4);
     for (int i = 0; i < 8; ++i) t.probe[i] = 0;
     if (const char* c = getenv("LAVT_PROBE")) sscanf(c, "%d,%d,%d,%d,%d,%d,%d,%d", &t.probe[0], &t.probe[1], &t.probe[2], &t.probe[3], &t.probe[4], &t.probe[5], &t.probe[6], &t.probe[7]);

@@ -178,6 +178,7 @@ _PROTOTYPES = {
     "lavt_layernorm_bwd_partial_xn": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
     "lavt_layernorm_bwd_xn": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
     "lavt_reduce_partials_multi": [vp, i32, i32, vp],
+    "lavt_reduce_partials_column_blocks": [i32],
     "lavt_colstats": [i32, vp, vp, vp, vp, i64, i32, i32, i32, vp],
     "lavt_syncbn_combine": [vp, i32, f32, f32, vp, vp, vp, vp, f32, i32, vp],
     "lavt_colstats_meanrstd": [i32, vp, vp, vp, vp, i64, i32, i32, i32, f32, vp, vp, f32, vp],
@@ -246,7 +247,7 @@ _cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
 _cdll.lavt_conv3x3_wgrad_ws.restype = C.c_int64
 _cdll.lavt_gemm_tn_grouped_sk_ws.restype = C.c_int64
 _cdll.lavt_last_error.argtypes = []
-for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts", "lavt_adamw_chunk_elems", "lavt_tuning_reload", "lavt_conv3x3_wgrad_ws", "lavt_gemm_tn_grouped_sk_ws", "lavt_gemm_nt_colstats_plan"):      # queries, not launches: never timed
+for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts", "lavt_adamw_chunk_elems", "lavt_tuning_reload", "lavt_conv3x3_wgrad_ws", "lavt_gemm_tn_grouped_sk_ws", "lavt_gemm_nt_colstats_plan", "lavt_cls_head_bwd_blocks", "lavt_reduce_partials_column_blocks"):      # queries, not launches: never timed
     setattr(lib, _name, getattr(_cdll, _name))
 
 EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)

@@ -767,7 +767,7 @@ class _LnDeferred:
                     raise RuntimeError("deferred LayerNorm reductions: the step being captured differs from the warm-up steps (descriptor table would need a host copy)")
                 self.desc = torch.tensor(self.items, dtype=torch.int64).to(self.arena.device)
                 self.desc_key = key
-            K.check(K.lib.lavt_reduce_partials_multi(K.ptr(self.desc), len(self.items), sum((2 * it[2] + 31) // 32 for it in self.items) if _LN_REDUCE_COMPACT else 0, K.stream()))
+            K.check(K.lib.lavt_reduce_partials_multi(K.ptr(self.desc), len(self.items), sum(int(K.lib.lavt_reduce_partials_column_blocks(it[2])) for it in self.items) if _LN_REDUCE_COMPACT else 0, K.stream()))
         params = self.params
         self.items, self.params, self.off = [], [], 0
         for p in params:

@@ -827,12 +827,13 @@ def test_gemm_tn_grouped_matches_individual():
 
 
 @pytest.mark.parametrize("stages,Kd,min_tiles", [("4", 1800, "8"), ("4", 7200, "8"), ("4", 456, "8"), ("3", 1800, "8"), ("3", 7200, "8"),
-                                                  ("4", 7200, "4096"), ("4", 28800, "4096")])
+                                                  ("4", 7200, "4096"), ("4", 28800, "4096"), ("4", 450, "8"), ("4", 900, "8"), ("4", 900, "4096")])
 def test_gemm_tn_grouped_pipelined_tiles(Kd, stages, min_tiles, monkeypatch, request):
     """csrc/gemm_tn_pipe.hip (round 5: the grouped weight-gradient launch on 128x128 software-pipelined tiles -- buffer-descriptor LDS-DMA of two
     k-major operand tiles, transposing fragment reads one MFMA group ahead, row maps through scalar loads, the DropPath mask as a keep bit per
     sample, column sums on the matrix cores) against fp32 torch and against gemm_tn_v2.hip's 64x64 launch (LAVT_TN_PIPE=0): six members with
-    every feature at once -- tiles that overhang I and J (I = 192, J = 328), a K tail of 8 rows (1800 = 28 x 64 + 8; 456 = 7 x 64 + 8), a long chain
+    every feature at once -- tiles that overhang I and J (I = 192, J = 328), a K tail of 8 rows (1800 = 28 x 64 + 8; 456 = 7 x 64 + 8), gathered
+    reductions whose length is not a multiple of 8 (450 = the last stage's tokens, 900 = batch 4's: the row maps end inside a wave's eight entries), a long chain
     (7200 = 113 K tiles), gathered A rows with masked (-1) entries, gathered B rows, a row mask folded into alpha, accumulate into a non-zero C,
     a column-sum-only member adding atomically into a bias gradient it shares with a second member, an unaligned C (4-byte stores) -- in both ring depths.
     min_tiles = 4096: the same group CUT INTO K PIECES (the form long reductions on few output tiles take: every member through its partials scratch,
@@ -840,7 +841,8 @@ def test_gemm_tn_grouped_pipelined_tiles(Kd, stages, min_tiles, monkeypatch, req
     from lavt_hip import _capi as K, ops
     monkeypatch.setenv("LAVT_TN_PIPE_STAGES", stages)
     monkeypatch.setenv("LAVT_TN_PIPE_MIN_TILES", min_tiles)
-    request.addfinalizer(lambda: ([os.environ.pop(k, None) for k in ("LAVT_TN_PIPE", "LAVT_TN_PIPE_STAGES", "LAVT_TN_PIPE_MIN_TILES")], K.lib.lavt_tuning_reload()))
+    monkeypatch.setenv("LAVT_TN_PIPE_MIN_KTILES", "1")          # (the planner keeps uncut groups of < 12 K tiles per tile on the 64x64 launch: here they take the pipelined one)
+    request.addfinalizer(lambda: ([os.environ.pop(k, None) for k in ("LAVT_TN_PIPE", "LAVT_TN_PIPE_STAGES", "LAVT_TN_PIPE_MIN_TILES", "LAVT_TN_PIPE_MIN_KTILES")], K.lib.lavt_tuning_reload()))
     g = torch.Generator().manual_seed(77)
     bf = torch.bfloat16
     Ms = Kd + 640                                                               # rows of the gathered sources

@@ -9,15 +9,15 @@ import sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").replace("_ZN12_GLOBAL__N_1", "")[:110]
 fin = [i for i, r in enumerate(rows) if "upsample_ce_finish_kernel" in r["Kernel_Name"]]
-# the last occurrence is bench.py's eager loss check; a replay runs from the launch after loss k - 1's backward to the end of loss k's backward.  The first
-# launch of a replay is the one that follows the longest idle gap between two losses (the host's replay call).
+# the last occurrence is bench.py's eager loss check.  A replay starts at the launch that follows the longest idle gap between two losses (the host's
+# replay call) and ends where the kernel name of its first launch comes round again behind a gap (the next replay's first launch).
 a, b = fin[-4], fin[-3]
 seg = rows[a:b + 1]
 gaps = [(int(seg[i + 1]["Start_Timestamp"]) - int(seg[i]["End_Timestamp"]), i + 1) for i in range(len(seg) - 1)]
 first = a + max(gaps)[1]
-seg2 = rows[fin[-3]:fin[-2] + 1]
-gaps2 = [(int(seg2[i + 1]["Start_Timestamp"]) - int(seg2[i]["End_Timestamp"]), i + 1) for i in range(len(seg2) - 1)]
-last = fin[-3] + max(gaps2)[1]
+last = first + 1
+while last < len(rows) and not (rows[last]["Kernel_Name"] == rows[first]["Kernel_Name"] and rows[last - 1]["Kernel_Name"] != rows[first]["Kernel_Name"] and last > fin[-3]):
+    last += 1
 step = rows[first:last]
 t0 = int(step[0]["Start_Timestamp"])
 span = (int(step[-1]["End_Timestamp"]) - t0) / 1e3
