@@ -403,6 +403,9 @@ int lavt_act_bwd(int dtype, int act, const void* dy, const void* pre, void* dx, 
  * (timm drop_path, the reference's DropPath: lib/backbone.py:6, 240-245) from one uniform draw u. */
 int lavt_lang_mask(const void* l_mask, int is_int64, float* mask_rows, float* maskbias, int B, int n_l, int ld, void* stream);
 int lavt_droppath_factors(const float* u, const float* keep, float* f, int n, int B, void* stream);
+/* the same factors with the uniform draw made on the device: u[e] = (Philox4x32-10(key = state[0], counter = (state[1], e, 0))[0] >> 8) * 2^-24; the
+ *   kernel advances state[1] (two uint64 in device memory: seed, draw counter), so a captured step draws fresh factors on every replay */
+int lavt_droppath_draw(void* state, const float* keep, float* f, int n, int B, void* stream);
 int lavt_gate_fwd(int dtype, const void* x, const void* gpre, const void* r, void* xo, int64_t n, void* stream);
 int lavt_gate_bwd(int dtype, const void* dxo, const void* gpre, const void* r, const void* dr_add, void* dgpre, void* dr, int64_t n, void* stream); /* dr = dxo * tanh(gpre) (+ dr_add) */
 

@@ -725,6 +725,40 @@ extern "C" int lavt_droppath_factors(const float* u, const float* keep, float* f
     return LAVT_OK;
 }
 
+// DropPath factors with the uniform draw made here (round 5): Philox4x32-10 keyed by state[0] (seed), counter = (state[1], element index); the kernel
+// advances state[1] itself, so a hipGraph replay draws fresh numbers with no host involvement.  (torch.rand under capture costs two bookkeeping fills per
+// replay -- the graph's seed / offset tensors -- besides its own launch: 3 x 4.7 us at the head of every step.)  One workgroup: every thread has read
+// the counter before thread 0 writes it.
+__device__ __forceinline__ uint32_t philox_u32(uint32_t seed_lo, uint32_t seed_hi, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+__global__ __launch_bounds__(256) void droppath_draw_kernel(unsigned long long* __restrict__ state, const float* __restrict__ keep, float* __restrict__ f, int n, int B) {
+    const unsigned long long seed = state[0], ctr = state[1];
+    for (int e = threadIdx.x; e < n * B; e += 256) {
+        const uint32_t x = philox_u32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)e, 0u);
+        const float u = (float)(x >> 8) * (1.0f / 16777216.0f);          // 24 bits: [0, 1)
+        const float k = keep[e / B];
+        f[e] = floorf(k + u) / k;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) state[1] = ctr + 1ull;
+}
+extern "C" int lavt_droppath_draw(void* state, const float* keep, float* f, int n, int B, void* stream) {
+    LAVT_CHECK_ARG(state && keep && f && n > 0 && B > 0, "lavt_droppath_draw: bad arguments");
+    hipLaunchKernelGGL(droppath_draw_kernel, dim3(1), dim3(256), 0, ST, (unsigned long long*)state, keep, f, n, B);
+    LAVT_CHECK_LAUNCH("lavt_droppath_draw");
+    return LAVT_OK;
+}
+
 extern "C" int lavt_gate_fwd(int dtype, const void* x, const void* gpre, const void* r, void* xo, int64_t n, void* stream) {
     LAVT_CHECK_ARG(x && gpre && r && xo && n > 0 && n % EPC_OF(dtype) == 0, "lavt_gate_fwd: bad arguments");
     const int64_t nc = n / EPC_OF(dtype);

@@ -150,6 +150,7 @@ _PROTOTYPES = {
     "lavt_attn_dtable_run": [C.POINTER(DtableJob), vp],
     "lavt_lang_mask": [vp, i32, vp, vp, i32, i32, i32, vp],
     "lavt_droppath_factors": [vp, vp, vp, i32, i32, vp],
+    "lavt_droppath_draw": [vp, vp, vp, i32, i32, vp],
     "lavt_conv3x3_wgrad_ws": [i32, i32, i32, i32, i32, i32],
     "lavt_gemm_tn_grouped_ln": [C.POINTER(GemmTN), i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
     "lavt_gemm_tn_grouped_sk_ws": [C.POINTER(GemmTN), i32],

@@ -169,7 +169,7 @@ class GradBuckets:
         return sum(4 * (e - s) for b, (s, e) in enumerate(self.buckets) if b != self.late_bucket)
 
     # ---- step protocol: zero() -> forward/backward -> finish() -------------------------------------------------
-    def zero(self, defer_fill=False):
+    def zero(self, defer_fill=False, also_zero=None):
         """defer_fill (step harness): the zero fill of the flat buffer is handed to lavt_hip.ops.fill_riders -- forward launches zero it slice by slice
         with rider workgroups, and the harness calls ops.fill_riders.finish() before backward starts"""
         if self._relayout:          # learnt in the first step: parameters nothing reports during backward join the late bucket
@@ -186,9 +186,14 @@ class GradBuckets:
             taken = ops.fill_riders.begin(self.flat)
         if not taken:
             if self._zero_views is not None:
-                torch._foreach_zero_(self._zero_views)          # everything but the parameters whose gradient launch overwrites its buffer (set_zero_skip)
+                # everything but the parameters whose gradient launch overwrites its buffer (set_zero_skip); `also_zero`: a float32 tensor of the caller's
+                # (the step harness's arena of small zero-initialised buffers) cleared by the same multi-tensor launch
+                torch._foreach_zero_(self._zero_views + [also_zero] if also_zero is not None else self._zero_views)
+                also_zero = None
             else:
                 self.flat.zero_()
+        if also_zero is not None:
+            also_zero.zero_()
         lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * 4
         for p in self.params:                      # an optimizer / user may have detached .grad; re-point it
             if p.grad is None or p.grad.data_ptr() != lo + 4 * self.offset_of[id(p)]:

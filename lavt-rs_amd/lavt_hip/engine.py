@@ -64,8 +64,8 @@ class TrainStep:
     def _body(self):
         if self.refresh_in_step:
             ops.weights.refresh_all()            # re-cast weights inside the step (for optimizers that do not maintain the compute copies)
-        self.buckets.zero(defer_fill=True)       # the 475 MB zero fill rides on forward launches (ops.fill_riders); the rest is filled before backward
-        ops.zero_arena.begin_step(self.x.device)          # one fill for every small zero-initialised buffer of the step
+        arena = ops.zero_arena.begin_step(self.x.device, defer=True)          # one fill for every small zero-initialised buffer of the step ...
+        self.buckets.zero(defer_fill=True, also_zero=arena)                    # ... shared with the gradient buffer's (the 475 MB fill of an unskipped buffer rides on forward launches: ops.fill_riders)
         ops.dtable_chain.job, ops.dtable_chain.keep = None, None          # (a backward that raised mid-way must not leave its binning job to the next step)
         if fp8_enabled():
             ops.fp8.advance()                    # delayed scaling: last step's |max| values become this step's quantisation scales

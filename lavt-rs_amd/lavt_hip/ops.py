@@ -138,6 +138,22 @@ class _WeightCache:
             self.get(p, dtype, "lin")
         return ent[0]
 
+    def get_bias_cat(self, bs) -> torch.Tensor:
+        """fp32 biases of several Linear layers stacked into ONE persistent vector (the stacked-weight GEMMs' bias operand): rebuilt when a bias changes
+        (version / address / refresh_all's epoch -- the optimizer's refresh), not by a torch.cat inside every step."""
+        key = (tuple(id(b) for b in bs), "f32", "bcat")
+        ent = self.store.get(key)
+        if ent is not None and any(r() is not b for r, b in zip(ent[1][1], bs)):
+            ent = None
+        stamp = (tuple(b._version for b in bs), tuple(b.data_ptr() for b in bs), self.epoch)
+        if ent is not None and ent[0] == stamp:
+            return ent[1][0]
+        n = sum(b.numel() for b in bs)
+        out = ent[1][0] if ent is not None and ent[1][0].numel() == n else torch.empty(n, dtype=torch.float32, device=bs[0].device)
+        torch.cat([b.detach().float().reshape(-1) for b in bs], out=out)
+        self.store[key] = (stamp, (out, [weakref.ref(b) for b in bs]), weakref.ref(bs[0]))
+        return out
+
     # ---- one-launch refresh of every cached 'lin' copy (the per-parameter casts are ~140 tiny launches per step) ----
     def build_multicast(self, dtype):
         """Call after a warm-up step: collects every live (param, 'lin') entry of `dtype` into a device descriptor table."""
@@ -181,6 +197,12 @@ class _WeightCache:
                 del self.store[k]
             elif k[1] == "fp8":
                 self.get_fp8(p, k[2])
+            elif k[2] == "bcat":
+                bs = [r() for r in out[1]]
+                if all(b is not None for b in bs):
+                    self.get_bias_cat(bs)
+                else:
+                    del self.store[k]
             elif k[1] == "lnfold":
                 others = [r() for r in out[3]]
                 if all(o is not None for o in others):
@@ -419,16 +441,23 @@ class _ZeroArena:
     def __init__(self):
         self.buf, self.off, self.hw, self.zeroed, self.active = None, 0, 0, 0, False
 
-    def begin_step(self, device):
+    def begin_step(self, device, defer=False):
+        """defer: the used prefix is returned (as a float32 view) for the caller to zero with its own fill -- the step harness hands it to the gradient
+        buffer's multi-tensor zero, one launch for both"""
         if os.environ.get("LAVT_ZERO_ARENA", "1") == "0":
-            return
+            return None
         if self.buf is None or self.buf.device != device:
             self.buf = torch.empty(self.BYTES, dtype=torch.uint8, device=device)
             self.hw = 0
         self.zeroed = min(self.hw, self.BYTES)
+        view = None
         if self.zeroed:
-            self.buf[:self.zeroed].zero_()
+            if defer:
+                view = self.buf[:self.zeroed].view(torch.float32)          # (requests are rounded to 256 bytes)
+            else:
+                self.buf[:self.zeroed].zero_()
         self.off, self.hw, self.active = 0, 0, True
+        return view
 
     def end_step(self):
         self.active = False
@@ -823,6 +852,30 @@ def droppath_factors(u, keep):
     return f
 
 
+_dp_state = {}
+
+
+def droppath_draw(keep, B):
+    """floor(keep + u) / keep [n, B] with u drawn on the device (Philox4x32-10; csrc/elementwise.hip): the generator state -- (seed, draw counter), seeded
+    from torch's default generator when first used on a device -- lives in device memory and is advanced by the kernel, so a captured step draws fresh
+    factors on every replay without torch.rand's two bookkeeping fills.  LAVT_DROPPATH_RNG=torch keeps torch.rand."""
+    dev = keep.device
+    st = _dp_state.get(dev)
+    if st is None:
+        st = torch.tensor([torch.initial_seed() & 0x7fffffffffffffff, 0], dtype=torch.int64).to(dev)
+        _dp_state[dev] = st
+    f = torch.empty(keep.shape[0], B, dtype=torch.float32, device=dev)
+    K.check(K.lib.lavt_droppath_draw(K.ptr(st), K.ptr(keep.contiguous()), K.ptr(f), keep.shape[0], B, K.stream()))
+    return f
+
+
+def droppath_reseed(seed, device=None):
+    """restart the device DropPath generator (all devices, or one) from `seed`"""
+    for dev, st in _dp_state.items():
+        if device is None or torch.device(device) == dev:
+            st.copy_(torch.tensor([int(seed) & 0x7fffffffffffffff, 0], dtype=torch.int64))
+
+
 def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     if x.dtype == dtype:
         return x
@@ -955,7 +1008,7 @@ class _LinearCat(torch.autograd.Function):
         Nt, Kd = Wc.shape
         M = x.shape[0]
         y = torch.empty(M, Nt, dtype=dtype, device=x.device)
-        bias = torch.cat([_f32(b) for b in bs]) if all(b is not None for b in bs) else None
+        bias = weights.get_bias_cat(bs) if all(b is not None for b in bs) else None
         gemm_nt(dtype, M, Nt, Kd, x, Kd, Wc, Kd, y, Nt, bias=bias)
         ctx.save_for_backward(x, *wb)
         return y
@@ -2092,7 +2145,7 @@ class _KvAll(torch.autograd.Function):
         M = lt.shape[0]
         rows = ctx_kv.B * KV_LD
         big = zero_arena.take((rows, Nt), dtype, lt.device)
-        bias = torch.cat([_f32(b) for b in bs])
+        bias = weights.get_bias_cat(bs)
         gemm_nt(dtype, M, Nt, Kd, lt, Kd, Wc, Kd, big, Nt, bias=bias, row_scale=ctx_kv.mask_rows, c_rowmap=ctx_kv.kv_map)
         ctx.save_for_backward(lt, *wb)
         ctx.ctx_kv = ctx_kv
@@ -2679,16 +2732,20 @@ class _UpsampleCE(torch.autograd.Function):
         ws = _scratch(4 * 2048, x.device)
         K.check(K.lib.lavt_upsample_ce_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(target), float(w0), float(w1), K.ptr(ws), ws.numel(), K.ptr(out4),
                                            B, Hi, Wi, Ho, Wo, K.stream()))
-        ctx.save_for_backward(x, target, out4)
+        stats = out4[:]                          # (a second view: the loss below is element 0 of the same four floats -- no copy kernel per step)
+        ctx.save_for_backward(x, target, stats)
         ctx.dims = (B, Hi, Wi, Ho, Wo, float(w0), float(w1))
-        ctx.mark_non_differentiable(out4)
-        return out4[0].clone(), out4
+        ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)         # (the statistics receive no gradient: None instead of a zero fill per step)
+        return out4[0], stats
 
     @staticmethod
     def backward(ctx, dloss, _dstats):
         x, target, out4 = ctx.saved_tensors
         B, Hi, Wi, Ho, Wo, w0, w1 = ctx.dims
         dx = torch.empty_like(x)
+        if dloss is None:                        # (nothing downstream of the loss)
+            return None, None, None, None, None, None, None, None, None
         dl = dloss.contiguous().float().reshape(1)
         K.check(K.lib.lavt_upsample_ce_bwd(K.dt(x.dtype), K.ptr(x), K.ptr(target), w0, w1, K.ptr(out4), K.ptr(dl), K.ptr(dx), B, Hi, Wi, Ho, Wo, K.stream()))
         return dx, None, None, None, None, None, None, None, None
@@ -2722,6 +2779,8 @@ class _UpsampleDice(torch.autograd.Function):
         x, target, stats = ctx.saved_tensors
         B, Hi, Wi, Ho, Wo = ctx.dims
         dx = torch.empty_like(x)
+        if dloss is None:                        # (nothing downstream of the loss)
+            return None, None, None, None, None, None, None, None, None
         dl = dloss.contiguous().float().reshape(1)
         K.check(K.lib.lavt_upsample_dice_bwd(K.dt(x.dtype), K.ptr(x), K.ptr(target), K.ptr(stats), K.ptr(dl), K.ptr(dx), B, Hi, Wi, Ho, Wo, K.stream()))
         return dx, None, None, None, None, None, None

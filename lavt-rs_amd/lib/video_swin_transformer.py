@@ -16,6 +16,8 @@ In scope: the default per-stage PWAM and the READM
 The other fusion ablations (TSPWAM, TPWAM, TPWAMComp, SepTPWAMInner, SeqTPWAM, SepSeqTPWAM*, LangProject) raise
 NotImplementedError.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -363,7 +365,10 @@ class MultiModalSwinTransformer3D(nn.Module):
         if keep is None or keep.device != device or keep.shape[0] != 2 * len(live):
             keep = torch.tensor([1.0 - d.drop_prob for d in live for _ in (0, 1)], dtype=torch.float32, device=device)[:, None]
             self._dp_keep = keep
-        f = ops.droppath_factors(torch.rand(2 * len(live), B, device=device, dtype=torch.float32), keep)      # floor(keep + u) / keep, one launch
+        if os.environ.get("LAVT_DROPPATH_RNG", "device") == "torch":
+            f = ops.droppath_factors(torch.rand(2 * len(live), B, device=device, dtype=torch.float32), keep)      # floor(keep + u) / keep, one launch
+        else:
+            f = ops.droppath_draw(keep, B)                                                                         # the same with the draw made in the kernel
         for i, d in enumerate(live):
             d._batched = [f[2 * i], f[2 * i + 1]]
 

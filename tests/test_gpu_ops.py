@@ -1454,3 +1454,51 @@ def test_forward_glue_kernels():
     keep = (1.0 - torch.linspace(0.0125, 0.3, 48))[:, None]
     f = ops.droppath_factors(u.to(dev()), keep.to(dev()))
     assert torch.equal(f.cpu(), torch.floor(keep + u) / keep)
+
+
+def _philox4x32_10_first(seed, ctr, n):
+    """numpy restatement of the generator of lavt_droppath_draw (Philox4x32-10, Salmon et al. 2011; key = seed, counter = (ctr lo, ctr hi, e, 0)): word 0"""
+    import numpy as np
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    c0 = np.full(n, ctr & 0xffffffff, dtype=np.uint64); c1 = np.full(n, ctr >> 32, dtype=np.uint64)
+    c2 = np.arange(n, dtype=np.uint64); c3 = np.zeros(n, dtype=np.uint64)
+    k0, k1 = seed & 0xffffffff, (seed >> 32) & 0xffffffff
+    mask = np.uint64(0xffffffff)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = hi1 ^ c1 ^ np.uint64(k0), lo1, hi0 ^ c3 ^ np.uint64(k1), lo0
+        k0, k1 = (k0 + W0) & 0xffffffff, (k1 + W1) & 0xffffffff
+    return c0.astype(np.uint32)
+
+
+def test_droppath_draw_on_device():
+    """lavt_droppath_draw: the DropPath factors of a forward with the uniform draw made in the kernel (no torch.rand under capture) -- bit-identical to a
+    numpy restatement of Philox4x32-10 for three consecutive draws (the kernel advances its own counter), reseedable, and the drop rate is what
+    timm's drop_path gives (reference lib/backbone.py:240-245)."""
+    import numpy as np
+    from lavt_hip import ops
+    keep = (1.0 - torch.linspace(0.0125, 0.3, 48))[:, None].to(dev())
+    B = 2
+    ops.droppath_draw(keep, B)                                   # (creates the state)
+    ops.droppath_reseed(1234567890123)
+    kf = keep.cpu().numpy()
+    for ctr in range(3):
+        f = ops.droppath_draw(keep, B).cpu().numpy()
+        x = _philox4x32_10_first(1234567890123, ctr, 48 * B)
+        u = ((x >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)).reshape(48, B)
+        assert np.array_equal(f, np.floor(kf + u) / kf), ctr
+    keep2 = torch.full((64, 1), 0.7, device=dev())
+    drops = sum(float((ops.droppath_draw(keep2, 64) == 0).float().mean()) for _ in range(20)) / 20
+    assert abs(drops - 0.3) < 0.02, drops
+    g = torch.cuda.CUDAGraph()
+    out = []
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            fg = ops.droppath_draw(keep2, 64)
+    for _ in range(2):
+        g.replay()
+        torch.cuda.synchronize()
+        out.append(fg.clone())
+    assert not torch.equal(out[0], out[1]), "a replay must draw fresh factors"
