@@ -303,6 +303,8 @@ int lavt_attn_uses_table(int dtype, int N);
  * desc = device int64 [n][5] rows {parts, pieces, heads, R, dtable}; max_R / max_heads size the grid. */
 int lavt_window_attn_bwd_pieces(int dtype, int nwin, int N, int heads, int bias_ld);
 int lavt_attn_dtable_finish_multi(const int64_t* desc, int n, int max_R, int max_heads, void* stream);
+/* the same launch sized for the (layer, head) pairs that exist: total_heads = sum over the n <= 64 layers of their head counts */
+int lavt_attn_dtable_finish_multi_compact(const int64_t* desc, int n, int max_R, int total_heads, void* stream);
 /* floats of scratch (`ws`) lavt_window_attn_bwd wants for these shapes: dS slabs + per-workgroup table histograms (0 for the exact-fp32 kernel) */
 int64_t lavt_window_attn_bwd_ws(int dtype, int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww);
 

@@ -393,7 +393,7 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
                               const float* lse, void* dqkv, float* dtable, int bias_ld, float* ws, float* parts, int wd, int wh, int ww, int nwin, int N,
                               int heads, float scale, hipStream_t st, const lavt_dtable_job_t* prev, lavt_dtable_job_t* mine);
 int lavt_attn_dtable_run_mfma(const lavt_dtable_job_t* jb, hipStream_t st);
-int lavt_attn_dtable_finish_multi_impl(const int64_t* desc, int n, int max_R, int max_heads, hipStream_t st);
+int lavt_attn_dtable_finish_multi_impl(const int64_t* desc, int n, int max_R, int max_heads, int total_heads, hipStream_t st);
 int lavt_window_attn_bwd_pieces_mfma(int nwin, int N, int heads);
 int64_t lavt_window_attn_bwd_ws_mfma(int nwin, int N, int heads, int bias_ld, int wd, int wh, int ww);
 // LAVT_ATTN_SIMPLE=1 forces the VALU formulation for bf16 too (A/B tests of the MFMA kernels)
@@ -463,7 +463,12 @@ extern "C" int lavt_window_attn_bwd_pieces(int dtype, int nwin, int N, int heads
 }
 extern "C" int lavt_attn_dtable_finish_multi(const int64_t* desc, int n, int max_R, int max_heads, void* stream) {
     LAVT_CHECK_ARG(desc && n > 0 && max_R > 0 && max_heads > 0, "lavt_attn_dtable_finish_multi: bad arguments");
-    return lavt_attn_dtable_finish_multi_impl(desc, n, max_R, max_heads, reinterpret_cast<hipStream_t>(stream));
+    return lavt_attn_dtable_finish_multi_impl(desc, n, max_R, max_heads, 0, reinterpret_cast<hipStream_t>(stream));
+}
+/* the same with the launch sized for the (layer, head) pairs that exist: total_heads = sum over the layers of their head counts (n <= 64) */
+extern "C" int lavt_attn_dtable_finish_multi_compact(const int64_t* desc, int n, int max_R, int total_heads, void* stream) {
+    LAVT_CHECK_ARG(desc && n > 0 && n <= 64 && max_R > 0 && total_heads > 0, "lavt_attn_dtable_finish_multi_compact: bad arguments (n <= 64)");
+    return lavt_attn_dtable_finish_multi_impl(desc, n, max_R, 0, total_heads, reinterpret_cast<hipStream_t>(stream));
 }
 extern "C" int lavt_attn_uses_table(int dtype, int N) { return use_mfma(dtype, N, N <= 64 ? 64 : N <= 160 ? 160 : 416) ? 1 : 0; }
 

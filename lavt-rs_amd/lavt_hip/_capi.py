@@ -165,6 +165,7 @@ _PROTOTYPES = {
     "lavt_window_attn_bwd": [i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "lavt_window_attn_bwd_pieces": [i32, i32, i32, i32, i32],
     "lavt_attn_dtable_finish_multi": [vp, i32, i32, i32, vp],
+    "lavt_attn_dtable_finish_multi_compact": [vp, i32, i32, i32, vp],
     "lavt_attn_uses_table": [i32, i32],
     "lavt_window_attn_bwd_ws": [i32, i32, i32, i32, i32, i32, i32, i32],
     "lavt_relpos_expand": [vp, vp, i32, i32, i32, i32, i32, i32, vp],

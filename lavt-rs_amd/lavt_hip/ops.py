@@ -787,7 +787,10 @@ class _LnDeferred:
                     raise RuntimeError("deferred table gradients: the step being captured differs from the warm-up steps")
                 self.tdesc = torch.tensor(self.tables, dtype=torch.int64).to(self.arena.device)
                 self.tdesc_key = key
-            K.check(K.lib.lavt_attn_dtable_finish_multi(K.ptr(self.tdesc), len(self.tables), max(t[3] for t in self.tables), max(t[2] for t in self.tables), K.stream()))
+            if len(self.tables) <= 64 and _LN_REDUCE_COMPACT:
+                K.check(K.lib.lavt_attn_dtable_finish_multi_compact(K.ptr(self.tdesc), len(self.tables), max(t[3] for t in self.tables), sum(t[2] for t in self.tables), K.stream()))
+            else:
+                K.check(K.lib.lavt_attn_dtable_finish_multi(K.ptr(self.tdesc), len(self.tables), max(t[3] for t in self.tables), max(t[2] for t in self.tables), K.stream()))
             self.tables = []
         if self.items:
             key = tuple(self.items)
