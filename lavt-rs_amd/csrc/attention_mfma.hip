@@ -618,6 +618,13 @@ __global__ __launch_bounds__(256) void wattn_dtable_finish_multi(const int64_t* 
     if (e < R) {
         const float* q = part + (int64_t)h * R + e;
         int k = pl;
+        for (; k + 120 < pieces; k += 128) {          // (sixteen pieces in flight per thread: a stage-0 layer's 252 pieces were 8 dependent rounds of 4 -- the launch is latency)
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = q[(int64_t)(k + 8 * u) * st];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u & 3] += v[u];
+        }
         for (; k + 24 < pieces; k += 32)
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[u] += q[(int64_t)(k + 8 * u) * st];

@@ -18,6 +18,7 @@ f=$(ls $O/eager/*/*kernel_trace.csv | head -1); python3 tools/trace_by_shape.py 
 rm -rf $O/eager
 rocprofv3 --kernel-trace --output-format csv -d $O/graph -- python3 bench.py --steps 40 --warmup 2 --no-cpu-baseline --no-profile --no-optimizer > $O/graph.log 2>&1
 f=$(ls $O/graph/*/*kernel_trace.csv | head -1); python3 tools/trace_by_shape.py $f auto 400 > $O/${RND}_z_by_shape_graph_replay.txt
+python3 tools/step_timeline.py $f > $O/${RND}_z_step_timeline.txt          # one replay as an ordered launch list
 rm -rf $O/graph
 # by-shape tables (hipGraph replay) of the non-headline workloads, next to their bench lines
 for w in swin_t_w7_480_b8 video_swin_b_t8_384 swin_b_w12_480_b4 swin_b_w12_480_b4_fp8; do

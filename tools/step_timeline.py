@@ -9,15 +9,12 @@ import sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").replace("_ZN12_GLOBAL__N_1", "")[:110]
 fin = [i for i, r in enumerate(rows) if "upsample_ce_finish_kernel" in r["Kernel_Name"]]
-# the last occurrence is bench.py's eager loss check.  A replay starts at the launch that follows the longest idle gap between two losses (the host's
-# replay call) and ends where the kernel name of its first launch comes round again behind a gap (the next replay's first launch).
-a, b = fin[-4], fin[-3]
-seg = rows[a:b + 1]
-gaps = [(int(seg[i + 1]["Start_Timestamp"]) - int(seg[i]["End_Timestamp"]), i + 1) for i in range(len(seg) - 1)]
-first = a + max(gaps)[1]
-last = first + 1
-while last < len(rows) and not (rows[last]["Kernel_Name"] == rows[first]["Kernel_Name"] and rows[last - 1]["Kernel_Name"] != rows[first]["Kernel_Name"] and last > fin[-3]):
-    last += 1
+# the last occurrence is bench.py's eager loss check.  Replays are separated by the host's replay call: cut the trace at every idle gap > 6 us in front of
+# a launch and take the last piece that holds exactly one loss and at least 100 launches.
+cuts = [0] + [i + 1 for i in range(len(rows) - 1) if int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) > 6000] + [len(rows)]
+pieces = [(cuts[j], cuts[j + 1]) for j in range(len(cuts) - 1)]
+good = [(a, b) for a, b in pieces if b - a >= 100 and sum(a <= f < b for f in fin) == 1 and b <= fin[-1]]
+first, last = good[-1]
 step = rows[first:last]
 t0 = int(step[0]["Start_Timestamp"])
 span = (int(step[-1]["End_Timestamp"]) - t0) / 1e3
