@@ -758,7 +758,10 @@ int lavt_gemm_nt_pipe_tile(const lavt_gemm_nt_t& p, int* stages_out) {
     if (wide) return 0;
     const long tiles256x = (long)cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch;
     const long rounds = (tiles256x + 255) / 256;
-    const bool huge = force ? force == 512 : (p.N % 256 == 0 && p.K >= 1024 && tiles256x >= 128 && tiles256x * 10 >= rounds * 256 * 8);
+    // (round 5: N within 1/16 of a multiple of 256 also takes the large tile -- Swin-T's 480-column data gradient of the concat convolution ran 439 us on 3600
+    // 128x128 tiles at 0.35 of peak; the columns beyond N are out-of-range offsets in the weight descriptor and masked stores)
+    const bool n_fits = p.N % 256 == 0 || (p.N % 8 == 0 && (long)p.N * 16 >= (long)cdiv(p.N, 256) * 256 * 15);
+    const bool huge = force ? force == 512 : (n_fits && p.K >= 1024 && tiles256x >= 128 && tiles256x * 10 >= rounds * 256 * 8);
     if (huge) { *stages_out = 2; return 256; }
     if (big && tun.gemm_waves == 8 && (pipe >= 3 || (pipe == 2 && p.K >= 1024))) { *stages_out = stages == 2 ? 2 : 4; return 128; }
     return 0;
