@@ -2782,8 +2782,6 @@ class _UpsampleDice(torch.autograd.Function):
         x, target, stats = ctx.saved_tensors
         B, Hi, Wi, Ho, Wo = ctx.dims
         dx = torch.empty_like(x)
-        if dloss is None:                        # (nothing downstream of the loss)
-            return None, None, None, None, None, None, None, None, None
         dl = dloss.contiguous().float().reshape(1)
         K.check(K.lib.lavt_upsample_dice_bwd(K.dt(x.dtype), K.ptr(x), K.ptr(target), K.ptr(stats), K.ptr(dl), K.ptr(dx), B, Hi, Wi, Ho, Wo, K.stream()))
         return dx, None, None, None, None, None, None
