@@ -258,6 +258,14 @@ int lavt_gemm_tn_grouped_sk(const lavt_gemm_tn_t* probs, int n, float* scratch, 
 int64_t lavt_conv3x3_wgrad_ws(int B, int H, int W, int Cout, int Cin, int c1);
 int lavt_conv3x3_wgrad(const void* dy, int64_t ldy, const void* x1, int64_t ldx1, const void* x2, int64_t ldx2, int c1, int B, int H, int W, int Cout,
                        int Cin, float* parts, int64_t parts_floats, float* dW, int accumulate, const void* zeros, void* stream);
+/* The same gradient from OCP e4m3 operands on the fp8 MFMA (round 5; BASELINE.json configs[4]): dy, x1, x2 hold bytes q = value * 448 / |max|
+ * ([pixels][channels]; leading dimensions in bytes, multiples of 16) -- the copies lavt_fp8_quantize / lavt_fp8_quantize_current wrote for the forward
+ * convolution and the data gradient --, amax_dy / amax_x point at the |max| each was quantised against (x1 and x2 share one scale: they feed one
+ * contraction); dW receives the de-quantised fp32 gradient.  Scratch as lavt_conv3x3_wgrad_ws.  lavt_conv3x3_wgrad_f8_ok returns 0 for shapes the
+ * kernel does not cover (32 < W <= 128, Cout % 128, Cin % 16, c1 % 64, H even when W <= 64): use the bf16 entry then. */
+int lavt_conv3x3_wgrad_f8_ok(int B, int H, int W, int Cout, int Cin, int c1);
+int lavt_conv3x3_wgrad_f8(const void* dy, int64_t ldy, const float* amax_dy, const void* x1, int64_t ldx1, const void* x2, int64_t ldx2, const float* amax_x, int c1,
+                          int B, int H, int W, int Cout, int Cin, float* parts, int64_t parts_floats, float* dW, int accumulate, const void* zeros, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Shifted-window attention core (WindowAttention.forward, lib/backbone.py:123-140; mask :634-652).

@@ -156,6 +156,8 @@ _PROTOTYPES = {
     "lavt_gemm_tn_grouped_sk_ws": [C.POINTER(GemmTN), i32],
     "lavt_gemm_tn_grouped_sk": [C.POINTER(GemmTN), i32, vp, i64, vp],
     "lavt_conv3x3_wgrad": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp, i32, vp, vp],
+    "lavt_conv3x3_wgrad_f8_ok": [i32, i32, i32, i32, i32, i32],
+    "lavt_conv3x3_wgrad_f8": [vp, i64, vp, vp, i64, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, i32, vp, vp],
     "lavt_gemm_nt": [C.POINTER(GemmNT), vp],
     "lavt_gemm_tn": [C.POINTER(GemmTN), vp],
     "lavt_splitk_reduce": [i32, vp, i32, i64, i32, vp, i64, vp],
@@ -249,7 +251,7 @@ _cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
 _cdll.lavt_conv3x3_wgrad_ws.restype = C.c_int64
 _cdll.lavt_gemm_tn_grouped_sk_ws.restype = C.c_int64
 _cdll.lavt_last_error.argtypes = []
-for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts", "lavt_adamw_chunk_elems", "lavt_tuning_reload", "lavt_conv3x3_wgrad_ws", "lavt_gemm_tn_grouped_sk_ws", "lavt_gemm_nt_colstats_plan", "lavt_cls_head_bwd_blocks", "lavt_reduce_partials_column_blocks"):      # queries, not launches: never timed
+for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts", "lavt_adamw_chunk_elems", "lavt_tuning_reload", "lavt_conv3x3_wgrad_ws", "lavt_conv3x3_wgrad_f8_ok", "lavt_gemm_tn_grouped_sk_ws", "lavt_gemm_nt_colstats_plan", "lavt_cls_head_bwd_blocks", "lavt_reduce_partials_column_blocks"):      # queries, not launches: never timed
     setattr(lib, _name, getattr(_cdll, _name))
 
 EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)

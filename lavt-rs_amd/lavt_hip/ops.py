@@ -292,6 +292,9 @@ _FP8_LINEAR_MIN_ROWS = int(os.environ.get("LAVT_FP8_LINEAR_MIN_ROWS", str(1 << 3
 _FP8_CONV_MIN_TILES = int(os.environ.get("LAVT_FP8_CONV_MIN_TILES", "200"))
 
 
+_FP8_WGRAD = os.environ.get("LAVT_FP8_WGRAD", "1") != "0"          # e4m3 weight gradients of the fp8 convolutions (0: the bf16 fused-tap kernel)
+
+
 def _fp8_conv_fills(M, N):
     return -(-M // 128) * -(-N // 128) >= _FP8_CONV_MIN_TILES
 
@@ -2464,6 +2467,8 @@ class _ConvTaps(torch.autograd.Function):
         M = B * D * H * W
         y = torch.empty(M, Cout, dtype=dtype, device=x1.device)
         pre = torch.empty_like(y) if act != K.ACT_NONE else None
+        x1q = x2q = None
+        ctx.fp8_x_amax = 0
         if dtype == torch.bfloat16 and fp8_enabled() and C1 % 16 == 0 and C2 % 16 == 0 and _fp8_conv_fills(M, Cout):
             # configs[4]: e4m3 activations (both concat sources against ONE scale: they feed one contraction) x e4m3 weights on the fp8 MFMA;
             # the bf16 tensors stay saved for the (bf16) backward
@@ -2475,6 +2480,10 @@ class _ConvTaps(torch.autograd.Function):
                          want_colstats=_CONV_STATS and stats and bias is None and act == K.ACT_NONE)
             if st is not None:          # (the pipelined e4m3 kernel has the statistics epilogue of the bf16 one)
                 conv_stats.put(y, st)
+            if _FP8_WGRAD and (kd, kh, kw) == (1, 3, 3) and bias is None and D == 1 and K.lib.lavt_conv3x3_wgrad_f8_ok(B, H, W, Cout, Cin, C1 if x2 is not None else Cin):
+                ctx.fp8_x_amax = a_ptr          # the e4m3 copies stay alive for the weight gradient (half the bytes of the bf16 tensors beside them)
+            else:
+                x1q = x2q = None
         elif _conv_split(dtype, M, Cout, Cin, C1, C2, taps, bias, act)[0]:
             # few pixels, long reduction (decoder level 4: 1 800 rows x K = 13 824 = 60-232 tiles walking 72-216 K tiles each): the reduction is cut
             # at tap boundaries over the batch index into fp32 partial outputs, a second small kernel adds them
@@ -2493,15 +2502,16 @@ class _ConvTaps(torch.autograd.Function):
                          want_colstats=_CONV_STATS and stats and bias is None and act == K.ACT_NONE)
             if st is not None:
                 conv_stats.put(y, st)
-        ctx.save_for_backward(x1, x2, weight, bias, pre)
+        ctx.save_for_backward(x1, x2, weight, bias, pre, x1q if ctx.fp8_x_amax else None, x2q if ctx.fp8_x_amax else None)
         ctx.dims = (B, D, H, W, C1, C2, Cout, kd, kh, kw, act)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x1, x2, weight, bias, pre = ctx.saved_tensors
+        x1, x2, weight, bias, pre, x1q, x2q = ctx.saved_tensors
         B, D, H, W, C1, C2, Cout, kd, kh, kw, act = ctx.dims
         dtype = x1.dtype
+        dyq = dy_amax = None
         Cin = C1 + C2
         taps = kd * kh * kw
         M = B * D * H * W
@@ -2520,6 +2530,7 @@ class _ConvTaps(torch.autograd.Function):
                 # convolution runs as one launch per source (row blocks of the transposed weight), like the bf16 split below
                 WqT, w_amax = weights.get_fp8(weight, "conv3t")
                 dyq, a_ptr = fp8.quantize_current(dy, (id(weight), "dy"))
+                dy_amax = a_ptr
                 for dxo, Cn, roff in ((dx1, C1, 0),) + (((dx2, C2, C1),) if x2 is not None else ()):
                     gemm_nt(torch.uint8, M, Cn, taps * Cout, dyq, Cout, WqT, taps * Cout, dxo, Cn, conv=(H, W, Cout, 1, D, kd, kh, kw),
                             b_off=roff * taps * Cout, deq=(a_ptr, w_amax.data_ptr()))
@@ -2561,6 +2572,19 @@ class _ConvTaps(torch.autograd.Function):
         # the GEMM writes [Cout][taps][Cin] (contiguous split-K atomics), a small kernel adds it into the [Cout][Cin][taps] gradient
         def _wgrad():
             ws = 0
+            if x1q is not None:
+                # configs[4]: e4m3 dY x e4m3 X on the fp8 MFMA (csrc/conv_wgrad.hip, conv_wgrad3x3_f8_kernel): the operands are the copies the forward convolution
+                # and the data gradient contracted -- no quantiser launch of its own unless the data gradient stayed in bf16
+                ws = int(K.lib.lavt_conv3x3_wgrad_ws(B, H, W, Cout, Cin, C1 if x2 is not None else Cin))
+                q, amax = (dyq, dy_amax) if dyq is not None else fp8.quantize_current(dy, (id(weight), "dy"))
+                scr = _tn_parts(ws, dy.device)
+                if K.prof.enabled:
+                    K.prof.note = {"flops": 2.0 * Cout * taps * Cin * M, "shape": f"conv-wgrad-f8 {Cout}x{taps * Cin}x{M}"}
+                K.check(K.lib.lavt_conv3x3_wgrad_f8(K.ptr(q), Cout, amax, K.ptr(x1q), C1, K.ptr(x2q), C2, ctx.fp8_x_amax, C1, B, H, W, Cout, Cin, K.ptr(scr), scr.numel(),
+                                                    K.ptr(dW), 0, _zero_page(dy.device), K.stream()))
+                if wsink:
+                    sinks.mark_assigned_ptr(dW.data_ptr())
+                return
             if dtype == torch.bfloat16 and (kd, kh, kw) == (1, 3, 3) and bias is None and D == 1 and os.environ.get("LAVT_CONV_WGRAD_TAPS", "1") != "0":
                 ws = int(K.lib.lavt_conv3x3_wgrad_ws(B, H, W, Cout, Cin, C1 if x2 is not None else Cin))
             if ws:

@@ -43,3 +43,10 @@ def conv3x3_fp8_dgrad(dy_nchw, w, amax_dy, amax_w):
     F.conv2d(padding=1); reference lib/mask_predictor.py:60-97 backward)"""
     return F.conv_transpose2d(dequantize(dy_nchw, amax_dy), dequantize(w, amax_w), padding=1)
 
+
+
+def conv3x3_fp8_wgrad(x_nchw, dy_nchw, amax_x, amax_dy):
+    """weight gradient of the 3x3 convolution on quantise-dequantised X and dY (what autograd computes for nn.Conv2d(3x3, padding=1, bias=False);
+    reference lib/mask_predictor.py:60-97 backward): dW[co][ci][ky][kx] = sum_p dY[p][co] X[p + (ky - 1, kx - 1)][ci], zero outside the image"""
+    xq, dq = dequantize(x_nchw, amax_x), dequantize(dy_nchw, amax_dy)
+    return torch.nn.grad.conv2d_weight(xq, (dq.shape[1], xq.shape[1], 3, 3), dq, padding=1)
