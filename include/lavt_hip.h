@@ -478,6 +478,16 @@ int lavt_rowsoftmax_fwd(int dtype, const void* s, void* p, int64_t rows, int n_l
 int lavt_rowsoftmax_bwd(int dtype, const void* p, const void* dp, void* ds, int64_t rows, int n_l, int ld, void* stream);
 /* bilinear resize, align_corners=True, NHWC (F.interpolate in lib/mask_predictor.py:59,69,80) */
 int lavt_bilinear_fwd(int dtype, const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
+/* Producers that write the e4m3 twin of their bf16 output (round 5; BASELINE.json configs[4]): q = e4m3(bf16(y) * 448 / *amax_prev) (scale 1 while
+ * *amax_prev <= 0) -- exactly the bytes lavt_fp8_quantize(y) would write -- and |max| of y recorded into *amax_cur by atomic max (delayed scaling):
+ * the quantiser launch in front of the consuming fp8 convolution disappears.  lavt_norm_bwd_apply_amax records |max| of the stored dx into *amax
+ * (zeroed by the caller once per step, lavt_fp8_advance does): the |max| pass of lavt_fp8_quantize_current disappears. */
+int lavt_bilinear_fwd_q8(const void* x, void* y, void* q, const float* amax_prev, float* amax_cur, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
+int lavt_norm_apply_q8(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const void* mul, int relu, void* y,
+                       void* q, const float* amax_prev, float* amax_cur, int groups, int rows, int C, void* stream);
+int lavt_norm_bwd_apply_amax(const void* dy, const void* x, const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                             const void* mul, int relu, const float* s1, const float* s2, float count, void* dx, void* dmul, float* amax, int groups, int rows,
+                             int C, void* stream);
 int lavt_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
 /* final logits: NHWC [B,Hi,Wi,2] (dtype) -> NCHW fp32 [B,2,Ho,Wo] (lib/_utils.py:21) and its gradient */
 int lavt_logits_up_fwd(int dtype, const void* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, void* stream);

@@ -3,6 +3,7 @@
 #include <stdio.h>
 
 #include "common.h"
+#include "fp8_pack.h"
 
 // ---- error string (the only global state of the library) ----------------------------------------
 static thread_local char g_err[512] = "";
@@ -120,8 +121,13 @@ __device__ __forceinline__ void bl_coord(int o, float scale, int n_in, int& i0, 
 }
 __host__ __device__ inline float bl_scale(int n_in, int n_out) { return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f; }
 
-template <typename T> __global__ void bilinear_fwd_kernel(const T* x, T* y, int B, int Hi, int Wi, int Ho, int Wo, int C, float sh, float sw) {
+// Q8 (bf16; configs[4]): also writes the e4m3 twin of the output (the bytes of lavt_fp8_quantize(y)) and records its |max| (delayed scaling)
+template <typename T, bool Q8 = false>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* x, T* y, int B, int Hi, int Wi, int Ho, int Wo, int C, float sh, float sw, unsigned char* q = nullptr,
+                                                           const float* amax_prev = nullptr, float* amax_cur = nullptr) {
     constexpr int EPC = Chunk<T>::N;
+    float q_s = 1.f, q_m = 0.f;
+    if constexpr (Q8) q_s = q8_scale(amax_prev);
     const int cpr = C / EPC;
     const int64_t n = (int64_t)B * Ho * Wo * cpr;
     GRID_STRIDE(i, n) {
@@ -139,8 +145,14 @@ template <typename T> __global__ void bilinear_fwd_kernel(const T* x, T* y, int 
 #pragma unroll
         for (int e = 0; e < EPC; ++e)
             o[e] = (1.f - ly) * ((1.f - lx) * f00[e] + lx * f01[e]) + ly * ((1.f - lx) * f10[e] + lx * f11[e]);
-        *reinterpret_cast<uint4*>(y + i * EPC) = f_to_chunk<T>(o);
+        const uint4 out = f_to_chunk<T>(o);
+        *reinterpret_cast<uint4*>(y + i * EPC) = out;
+        if constexpr (Q8) {
+            chunk_to_f<T>(out, o);
+            *reinterpret_cast<uint2*>(q + i * EPC) = q8_chunk8(o, q_s, q_m);
+        }
     }
+    if constexpr (Q8) q8_block_amax(q_m, amax_cur);
 }
 // gather form of the transpose: every input pixel sums the output pixels that sampled it (deterministic, no atomics)
 __device__ __forceinline__ void bl_range(int i, float scale, int n_in, int n_out, int& lo, int& hi) {
@@ -792,6 +804,16 @@ extern "C" int lavt_bilinear_fwd(int dtype, const void* x, void* y, int B, int H
     LAVT_CHECK_LAUNCH("lavt_bilinear_fwd");
     return LAVT_OK;
 }
+/* lavt_bilinear_fwd (bf16) with an e4m3 twin of the output: see lavt_norm_apply_q8 */
+extern "C" int lavt_bilinear_fwd_q8(const void* x, void* y, void* q, const float* amax_prev, float* amax_cur, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream) {
+    LAVT_CHECK_ARG(x && y && q && amax_cur && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % 8 == 0, "lavt_bilinear_fwd_q8: bad arguments");
+    const int64_t nc = (int64_t)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL((bilinear_fwd_kernel<bf16, true>), dim3(ew_grid(nc)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, B, Hi, Wi, Ho, Wo, C, bl_scale(Hi, Ho), bl_scale(Wi, Wo),
+                       (unsigned char*)q, amax_prev, amax_cur);
+    LAVT_CHECK_LAUNCH("lavt_bilinear_fwd_q8");
+    return LAVT_OK;
+}
+
 extern "C" int lavt_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream) {
     LAVT_CHECK_ARG(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % EPC_OF(dtype) == 0, "lavt_bilinear_bwd: bad arguments");
     const int64_t nc = (int64_t)B * Hi * Wi * (C / EPC_OF(dtype));

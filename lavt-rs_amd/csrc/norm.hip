@@ -2,6 +2,7 @@
 // normalisation kernels behind InstanceNorm1d (PWAM) and BatchNorm2d(+ReLU) (decoder).  All HBM-bound:
 // 16-byte accesses, one wave per LayerNorm row (row kept in registers, fp32 math), wave-shuffle reductions.
 #include "common.h"
+#include "fp8_pack.h"
 #include "ln_bwd_body.h"
 
 namespace {
@@ -396,11 +397,17 @@ __global__ void stats_finalize_kernel(const float* sum, const float* m2, float c
 // Apply kernels: a thread owns one 16-byte channel chunk of a group and walks rows, so the per-channel constants (mean, rstd, gamma, beta,
 // backward sums) sit in registers instead of being re-fetched for every element (the element-indexed form ran at ~0.9 TB/s on the
 // 28 800 x 512 decoder maps).  grid = (row blocks, groups); columns beyond 256 chunks are walked in slabs.
-template <typename T>
+// Q8 (bf16 only; BASELINE.json configs[4]): the kernel also writes the e4m3 twin of its output -- q = e4m3(bf16(y) * 448 / *amax_prev), the bytes
+// lavt_fp8_quantize would produce from y -- and records |max| of y into *amax_cur (delayed scaling): the consuming convolution's quantiser launch disappears.
+template <typename T, bool Q8 = false>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const T* __restrict__ mul, int relu, T* __restrict__ y, int rows, int C, int rows_per_block) {
+                                                         const T* __restrict__ mul, int relu, T* __restrict__ y, int rows, int C, int rows_per_block,
+                                                         unsigned char* __restrict__ q = nullptr, const float* __restrict__ amax_prev = nullptr,
+                                                         float* __restrict__ amax_cur = nullptr) {
     constexpr int EPC = Chunk<T>::N;
+    float q_s = 1.f, q_m = 0.f;
+    if constexpr (Q8) q_s = q8_scale(amax_prev);
     const int cpr = C / EPC, g = blockIdx.y;
     const int r_begin = blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
     for (int cbase = 0; cbase < cpr; cbase += 256) {
@@ -435,19 +442,28 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
                 if (relu) v = fmaxf(v, 0.f);
                 f[e] = v;
             }
-            *reinterpret_cast<uint4*>(y + off) = f_to_chunk<T>(f);
+            const uint4 out = f_to_chunk<T>(f);
+            *reinterpret_cast<uint4*>(y + off) = out;
+            if constexpr (Q8) {
+                chunk_to_f<T>(out, f);
+                *reinterpret_cast<uint2*>(q + off) = q8_chunk8(f, q_s, q_m);
+            }
         }
     }
+    if constexpr (Q8) q8_block_amax(q_m, amax_cur);
 }
 
-template <typename T>
+// AMAX (bf16; configs[4]): |max| of the stored dx is recorded into *amax (zeroed by the caller's bookkeeping once per step): the |max| pass in front of a
+// CURRENT-scaling quantisation of this gradient disappears.
+template <typename T, bool AMAX = false>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yout,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const T* __restrict__ mul, int relu, const float* __restrict__ s1,
                                                              const float* __restrict__ s2, float inv_count, T* __restrict__ dx,
-                                                             T* __restrict__ dmul, int rows, int C, int rows_per_block) {
+                                                             T* __restrict__ dmul, int rows, int C, int rows_per_block, float* __restrict__ amax = nullptr) {
     constexpr int EPC = Chunk<T>::N;
+    float q_m = 0.f;
     const int cpr = C / EPC, g = blockIdx.y;
     const int r_begin = blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
     for (int cbase = 0; cbase < cpr; cbase += 256) {
@@ -486,10 +502,17 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                 else if (relu && !(fy[e] > 0.f)) gg = 0.f;
                 fg[e] = ga[e] * rs[e] * (gg - a1[e] - xh * a2[e]);
             }
-            *reinterpret_cast<uint4*>(dx + off) = f_to_chunk<T>(fg);
+            const uint4 out = f_to_chunk<T>(fg);
+            *reinterpret_cast<uint4*>(dx + off) = out;
+            if constexpr (AMAX) {
+                chunk_to_f<T>(out, fg);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) q_m = fmaxf(q_m, fabsf(fg[e]));
+            }
             if (mul && dmul) *reinterpret_cast<uint4*>(dmul + off) = f_to_chunk<T>(fdm);
         }
     }
+    if constexpr (AMAX) q8_block_amax(q_m, amax);
 }
 
 // rows per workgroup for the apply kernels: ~2k workgroups in total, at least one full pass of the 256 threads over their rows
@@ -755,5 +778,31 @@ extern "C" int lavt_norm_bwd_apply(int dtype, const void* dy, const void* x, con
                hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(cdiv(rows, rpb), groups), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y, mean, rstd, gamma, beta,
                                   (const T*)mul, relu, s1, s2, 1.f / count, (T*)dx, (T*)dmul, rows, C, rpb));
     LAVT_CHECK_LAUNCH("lavt_norm_bwd_apply");
+    return LAVT_OK;
+}
+
+/* lavt_norm_apply with an e4m3 twin of the output (bf16; BASELINE.json configs[4]): q[rows][C] = e4m3(bf16(y) * 448 / *amax_prev) (scale 1 while *amax_prev
+ * <= 0), |max| of y recorded into *amax_cur -- the bytes and the bookkeeping of lavt_fp8_quantize(y), without its launch. */
+extern "C" int lavt_norm_apply_q8(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const void* mul, int relu, void* y,
+                                  void* q, const float* amax_prev, float* amax_cur, int groups, int rows, int C, void* stream) {
+    LAVT_CHECK_ARG(x && mean && rstd && y && q && amax_cur && groups > 0 && rows > 0 && C % 8 == 0 && (!gamma == !beta), "lavt_norm_apply_q8: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rpb = apply_rows_per_block(rows, groups, C, 8);
+    hipLaunchKernelGGL((norm_apply_kernel<bf16, true>), dim3(cdiv(rows, rpb), groups), dim3(256), 0, st, (const bf16*)x, mean, rstd, gamma, beta, (const bf16*)mul, relu,
+                       (bf16*)y, rows, C, rpb, (unsigned char*)q, amax_prev, amax_cur);
+    LAVT_CHECK_LAUNCH("lavt_norm_apply_q8");
+    return LAVT_OK;
+}
+
+/* lavt_norm_bwd_apply (bf16) that also records |max| of the stored dx into *amax by atomic max (the caller zeroes it once per step). */
+extern "C" int lavt_norm_bwd_apply_amax(const void* dy, const void* x, const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                        const void* mul, int relu, const float* s1, const float* s2, float count, void* dx, void* dmul, float* amax, int groups, int rows,
+                                        int C, void* stream) {
+    LAVT_CHECK_ARG(dy && x && mean && rstd && s1 && s2 && dx && amax && (!relu || y) && count > 0 && C % 8 == 0, "lavt_norm_bwd_apply_amax: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rpb = apply_rows_per_block(rows, groups, C, 8);
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16, true>), dim3(cdiv(rows, rpb), groups), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, rstd,
+                       gamma, beta, (const bf16*)mul, relu, s1, s2, 1.f / count, (bf16*)dx, (bf16*)dmul, rows, C, rpb, amax);
+    LAVT_CHECK_LAUNCH("lavt_norm_bwd_apply_amax");
     return LAVT_OK;
 }

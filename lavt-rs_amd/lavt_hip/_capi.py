@@ -209,6 +209,9 @@ _PROTOTYPES = {
     "lavt_rowsoftmax_fwd": [i32, vp, vp, i64, i32, i32, vp],
     "lavt_rowsoftmax_bwd": [i32, vp, vp, vp, i64, i32, i32, vp],
     "lavt_bilinear_fwd": [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "lavt_bilinear_fwd_q8": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "lavt_norm_apply_q8": [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp],
+    "lavt_norm_bwd_apply_amax": [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, f32, vp, vp, vp, i32, i32, i32, vp],
     "lavt_bilinear_bwd": [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lavt_logits_up_fwd": [i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "lavt_logits_up_bwd": [i32, vp, vp, i32, i32, i32, i32, i32, vp],

@@ -241,6 +241,8 @@ class _Fp8State:
     def __init__(self):
         self.prev = self.cur = None
         self.slots = {}
+        self.twins = {}          # (data_ptr, numel) of a bf16 tensor -> (its e4m3 twin written by the producing kernel, pointer of the |max| it was scaled by)
+        self.dy_amax = {}        # (data_ptr, numel) of a gradient tensor -> pointer of its |max|, recorded by the producing kernel
 
     def _ensure(self, device):
         if self.prev is None or self.prev.device != device:
@@ -258,13 +260,29 @@ class _Fp8State:
         return i
 
     def advance(self):
+        self.twins.clear()
+        self.dy_amax.clear()
         if self.prev is not None and self.slots:
             K.check(K.lib.lavt_fp8_advance(K.ptr(self.prev), K.ptr(self.cur), len(self.slots), K.stream()))
+
+    def site_ptrs(self, key, device):
+        """(pointer of the |max| this step quantises against, pointer of the |max| this step records) of a delayed-scaling site"""
+        i = self.slot(key, device)
+        return self.prev.data_ptr() + 4 * i, self.cur.data_ptr() + 4 * i
+
+    def put_twin(self, y, q, a_ptr):
+        self.twins[(y.data_ptr(), y.numel())] = (q, a_ptr)
+
+    def put_dy_amax(self, dx, a_ptr):
+        self.dy_amax[(dx.data_ptr(), dx.numel())] = a_ptr
 
     def quantize(self, x, key):
         """bf16 activation rows -> (uint8 e4m3 tensor of the same shape, pointer of the amax float it was scaled by)"""
         i = self.slot(key, x.device)
         x = x.contiguous()
+        tw = self.twins.pop((x.data_ptr(), x.numel()), None)
+        if tw is not None and tw[1] == self.prev.data_ptr() + 4 * i and tw[0].shape == x.shape:
+            return tw          # the producing kernel wrote the twin against this site's scale (lavt_norm_apply_q8 / lavt_bilinear_fwd_q8): no launch
         q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
         K.check(K.lib.lavt_fp8_quantize(K.dt(x.dtype), K.ptr(x), K.ptr(q), x.numel(), self.prev.data_ptr() + 4 * i, self.cur.data_ptr() + 4 * i, K.stream()))
         return q, self.prev.data_ptr() + 4 * i
@@ -276,6 +294,11 @@ class _Fp8State:
         i = self.slot(key, x.device)
         x = x.contiguous()
         q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        a_ptr = self.dy_amax.pop((x.data_ptr(), x.numel()), None)
+        if a_ptr is not None:
+            # the kernel that produced x recorded its |max| (lavt_norm_bwd_apply_amax, into the site's `cur` slot: advance() zeroes it): one pass instead of two
+            K.check(K.lib.lavt_fp8_quantize(K.dt(x.dtype), K.ptr(x), K.ptr(q), x.numel(), a_ptr, None, K.stream()))
+            return q, a_ptr
         K.check(K.lib.lavt_fp8_quantize_current(K.dt(x.dtype), K.ptr(x), K.ptr(q), x.numel(), self.prev.data_ptr() + 4 * i, K.stream()))
         return q, self.prev.data_ptr() + 4 * i
 
@@ -297,6 +320,24 @@ _FP8_WGRAD = os.environ.get("LAVT_FP8_WGRAD", "1") != "0"          # e4m3 weight
 
 def _fp8_conv_fills(M, N):
     return -(-M // 128) * -(-N // 128) >= _FP8_CONV_MIN_TILES
+
+
+_FP8_TWINS = os.environ.get("LAVT_FP8_TWINS", "1") != "0"          # producers write the e4m3 twin / record the gradient |max| (0: separate quantiser launches)
+
+
+def fp8_act_site(weight, M, C1, C2=0):
+    """the quantisation site of the activations a 3x3 convolution with `weight` contracts in e4m3, or None when that convolution stays in bf16: what a
+    producer of its first input passes to `bilinear(..., fp8_site=)` / `batch_norm_relu(..., fp8_site=)` to write the e4m3 twin itself"""
+    if not (_FP8_TWINS and fp8_enabled() and C1 % 16 == 0 and C2 % 16 == 0 and _fp8_conv_fills(M, weight.shape[0])):
+        return None
+    return id(weight)
+
+
+def fp8_dy_site(weight, M, C1):
+    """the site of the output gradient of the convolution with `weight` when its backward quantises it (e4m3 data gradient), else None"""
+    if not (_FP8_TWINS and fp8_enabled() and _FP8_DGRAD and weight.shape[0] % 16 == 0 and _fp8_conv_fills(M, C1)):
+        return None
+    return (id(weight), "dy")
 
 
 # data gradients of the decoder's convolutions in e4m3 as well (dY quantised with current scaling against its own |max|); 0 = bf16 data gradients
@@ -1745,8 +1786,15 @@ class _HipBnKernels:
         return mean, rstd
 
     @staticmethod
-    def apply(x, mean, rstd, gamma, beta):
+    def apply(x, mean, rstd, gamma, beta, fp8_site=None):
         y = torch.empty_like(x)
+        if fp8_site is not None and x.dtype == torch.bfloat16 and fp8_enabled():
+            q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+            a_prev, a_cur = fp8.site_ptrs(fp8_site, x.device)
+            K.check(K.lib.lavt_norm_apply_q8(K.ptr(x), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), None, 1, K.ptr(y), K.ptr(q), a_prev, a_cur,
+                                             1, x.shape[0], x.shape[1], K.stream()))
+            fp8.put_twin(y, q, a_prev)
+            return y
         K.check(K.lib.lavt_norm_apply(K.dt(x.dtype), K.ptr(x), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), None, 1,
                                       K.ptr(y), 1, x.shape[0], x.shape[1], K.stream()))
         return y
@@ -1764,9 +1812,15 @@ class _HipBnKernels:
         return out
 
     @staticmethod
-    def bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count):
+    def bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count, fp8_dy_site=None):
         R, Cc = x.shape
         dx = torch.empty_like(x)
+        if fp8_dy_site is not None and x.dtype == torch.bfloat16 and fp8_enabled():
+            a_cur = fp8.site_ptrs(fp8_dy_site, x.device)[1]
+            K.check(K.lib.lavt_norm_bwd_apply_amax(K.ptr(dy), K.ptr(x), K.ptr(y), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)),
+                                                   None, 1, K.ptr(s[0]), K.ptr(s[1]), count, K.ptr(dx), None, a_cur, 1, R, Cc, K.stream()))
+            fp8.put_dy_amax(dx, a_cur)
+            return dx
         K.check(K.lib.lavt_norm_bwd_apply(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(y), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)),
                                           None, 1, K.ptr(s[0]), K.ptr(s[1]), count, K.ptr(dx), None, 1, R, Cc, K.stream()))
         return dx
@@ -1778,7 +1832,7 @@ class _BatchNormRelu(torch.autograd.Function):
     SyncBatchNorm semantics, train.py:589), running stats updated in place; eval: running statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, group, kern):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, group, kern, fp8_site=None, fp8_dy_site=None):
         x = x.contiguous()
         R, Cc = x.shape
         count = float(R)
@@ -1798,9 +1852,10 @@ class _BatchNormRelu(torch.autograd.Function):
         else:
             # eval: mean = running_mean, var = running_var  (sum = mean, m2 = var, count = 1)
             mean, rstd = kern.finalize(torch.stack([running_mean, running_var]), 1.0, eps, None, None, 0.0)
-        y = kern.apply(x, mean, rstd, gamma, beta)
+        y = kern.apply(x, mean, rstd, gamma, beta, fp8_site) if fp8_site is not None else kern.apply(x, mean, rstd, gamma, beta)
         ctx.save_for_backward(x, y, gamma, beta, mean, rstd)
         ctx.cfg = (training, count, group, kern)
+        ctx.fp8_dy_site = fp8_dy_site
         return y
 
     @staticmethod
@@ -1818,8 +1873,9 @@ class _BatchNormRelu(torch.autograd.Function):
             s = kern.bwd_stats(dy, x, y, mean, rstd, gamma, beta, out=(bbuf, gbuf))
             if group is not None:
                 s = syncbn_exchange_backward(torch.stack([bbuf, gbuf]), group)
-            dx = kern.bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count)
-            return dx, sinks.done(gamma, gbuf, gsink), sinks.done(beta, bbuf, bsink), None, None, None, None, None, None, None
+            dx = (kern.bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count, ctx.fp8_dy_site) if ctx.fp8_dy_site is not None
+                  else kern.bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count))
+            return dx, sinks.done(gamma, gbuf, gsink), sinks.done(beta, bbuf, bsink), None, None, None, None, None, None, None, None, None
         s0, s1 = kern.bwd_stats(dy, x, y, mean, rstd, gamma, beta)
         s = torch.stack([s0, s1])
         dgamma, dbeta = s[1].clone(), s[0].clone()          # local sums: DDP averages parameter grads later
@@ -1827,14 +1883,17 @@ class _BatchNormRelu(torch.autograd.Function):
             s.zero_()                                       # running statistics are constants: no batch terms
         elif group is not None:
             syncbn_exchange_backward(s, group)
-        dx = kern.bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        dx = (kern.bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count, ctx.fp8_dy_site) if ctx.fp8_dy_site is not None
+              else kern.bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count))
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-def batch_norm_relu(x, bn: torch.nn.modules.batchnorm._BatchNorm, track=True):
+def batch_norm_relu(x, bn: torch.nn.modules.batchnorm._BatchNorm, track=True, fp8_site=None, fp8_dy_site=None):
     """`bn` is the module holding the parameters/buffers (nn.BatchNorm2d, or nn.SyncBatchNorm after
     convert_sync_batchnorm -> statistics are all-reduced over its process group).
-    track=False: the caller counts the batch itself (bn_count_batches: one launch for all its layers instead of one `add_` each)."""
+    track=False: the caller counts the batch itself (bn_count_batches: one launch for all its layers instead of one `add_` each).
+    fp8_site / fp8_dy_site (fp8_act_site / fp8_dy_site of the consuming / producing convolution; configs[4]): the apply pass writes the e4m3 twin of the
+    output, the backward apply pass records |max| of the input gradient -- the quantiser / |max| launches of those convolutions disappear."""
     import torch.distributed as dist
     group = None
     if isinstance(bn, torch.nn.SyncBatchNorm) and bn.training and dist.is_available() and dist.is_initialized():
@@ -1846,7 +1905,7 @@ def batch_norm_relu(x, bn: torch.nn.modules.batchnorm._BatchNorm, track=True):
     if track and training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return _BatchNormRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                                bn.momentum if bn.momentum is not None else 0.1, bn.eps, group, _HipBnKernels)
+                                bn.momentum if bn.momentum is not None else 0.1, bn.eps, group, _HipBnKernels, fp8_site, fp8_dy_site)
 
 
 def bn_count_batches(bns):
@@ -2660,12 +2719,18 @@ def conv3d(x, weight, bias, B, D, H, W, act=K.ACT_NONE):
 @K.scoped
 class _Bilinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, B, Hi, Wi, Ho, Wo):
+    def forward(ctx, x, B, Hi, Wi, Ho, Wo, fp8_site=None):
         x = x.contiguous()
         Cc = x.shape[1]
         y = torch.empty(B * Ho * Wo, Cc, dtype=x.dtype, device=x.device)
-        K.check(K.lib.lavt_bilinear_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(y), B, Hi, Wi, Ho, Wo, Cc, K.stream()))
         ctx.dims = (B, Hi, Wi, Ho, Wo, Cc)
+        if fp8_site is not None and x.dtype == torch.bfloat16 and fp8_enabled():
+            q = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+            a_prev, a_cur = fp8.site_ptrs(fp8_site, x.device)
+            K.check(K.lib.lavt_bilinear_fwd_q8(K.ptr(x), K.ptr(y), K.ptr(q), a_prev, a_cur, B, Hi, Wi, Ho, Wo, Cc, K.stream()))
+            fp8.put_twin(y, q, a_prev)
+            return y
+        K.check(K.lib.lavt_bilinear_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(y), B, Hi, Wi, Ho, Wo, Cc, K.stream()))
         return y
 
     @staticmethod
@@ -2674,11 +2739,12 @@ class _Bilinear(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty(B * Hi * Wi, Cc, dtype=dy.dtype, device=dy.device)
         K.check(K.lib.lavt_bilinear_bwd(K.dt(dy.dtype), K.ptr(dy), K.ptr(dx), B, Hi, Wi, Ho, Wo, Cc, K.stream()))
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
-def bilinear(x, B, Hi, Wi, Ho, Wo):
-    return _Bilinear.apply(x, B, Hi, Wi, Ho, Wo)
+def bilinear(x, B, Hi, Wi, Ho, Wo, fp8_site=None):
+    """fp8_site: fp8_act_site of the convolution that consumes the output (configs[4]): the kernel writes the e4m3 twin itself"""
+    return _Bilinear.apply(x, B, Hi, Wi, Ho, Wo, fp8_site)
 
 
 @K.scoped

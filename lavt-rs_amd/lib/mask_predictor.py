@@ -50,14 +50,19 @@ class SimpleDecoding(nn.Module):
     def _level(self, tag, x, xhw, skip, B, dtype):
         """x: rows at resolution xhw; skip: NCHW-shaped feature.  Returns rows at the skip's resolution."""
         H, W = skip.shape[-2:]
+        w1, w2 = getattr(self, f"conv1_{tag}").weight, getattr(self, f"conv2_{tag}").weight
+        # fp8 (configs[4]): the producers of the convolutions' inputs write the e4m3 twins / record the gradient |max| themselves (None = that convolution is bf16)
+        M, C1, hid = B * H * W, x.shape[1], w2.shape[0]
+        s1, s2 = ops.fp8_act_site(w1, M, C1, skip.shape[1]), ops.fp8_act_site(w2, M, hid)
+        d1, d2 = ops.fp8_dy_site(w1, M, C1), ops.fp8_dy_site(w2, M, hid)
         if xhw[0] < H or xhw[1] < W:
-            x = ops.bilinear(x, B, xhw[0], xhw[1], H, W)
+            x = ops.bilinear(x, B, xhw[0], xhw[1], H, W, fp8_site=s1)
         elif xhw != (H, W):
             raise ValueError("decoder: top-down map larger than the skip feature")
-        x = ops.conv3x3(x, nchw_rows(skip, dtype), getattr(self, f"conv1_{tag}").weight, B, H, W)
-        x = ops.batch_norm_relu(x, getattr(self, f"bn1_{tag}"), track=False)          # (num_batches_tracked: one launch for all layers, _run_scoped)
-        x = ops.conv3x3(x, None, getattr(self, f"conv2_{tag}").weight, B, H, W)
-        x = ops.batch_norm_relu(x, getattr(self, f"bn2_{tag}"), track=False)
+        x = ops.conv3x3(x, nchw_rows(skip, dtype), w1, B, H, W)
+        x = ops.batch_norm_relu(x, getattr(self, f"bn1_{tag}"), track=False, fp8_site=s2, fp8_dy_site=d1)          # (num_batches_tracked: one launch for all layers, _run_scoped)
+        x = ops.conv3x3(x, None, w2, B, H, W)
+        x = ops.batch_norm_relu(x, getattr(self, f"bn2_{tag}"), track=False, fp8_dy_site=d2)
         return x, (H, W)
 
     def _run(self, x_c4, x_c3, x_c2, x_c1):

@@ -1303,6 +1303,57 @@ def test_fp8_quantizer_bit_exact_and_delayed_scaling():
     assert torch.equal(q1.cpu(), F8.quantize_bytes(x, amax))
 
 
+def test_fp8_twins_written_by_producers_equal_the_quantiser(monkeypatch):
+    """configs[4]: BatchNorm + ReLU (lavt_norm_apply_q8) and the bilinear upsample (lavt_bilinear_fwd_q8) write the e4m3 twin of their bf16 output themselves,
+    the BatchNorm backward apply pass (lavt_norm_bwd_apply_amax) records |max| of the gradient it stores: the bytes must be the ones lavt_fp8_quantize /
+    lavt_fp8_quantize_current produce from the same bf16 tensors (oracle: fp8_oracle.quantize_bytes), the |max| bookkeeping the same, and the consuming
+    convolution must pick the twin up instead of launching a quantiser."""
+    import lavt_hip
+    from lavt_hip import ops
+    from oracle import fp8_oracle as F8
+    monkeypatch.setattr(ops, "_FP8_CONV_MIN_TILES", 0)
+    B, Hi, H, C = 2, 12, 24, 128
+    x = rnd(B * Hi * Hi, C, seed=1).to(torch.bfloat16)
+    w = torch.nn.Parameter((rnd(C, C, 3, 3, seed=2) * (9 * C) ** -0.5).to(dev()))
+    bn = torch.nn.BatchNorm2d(C).to(dev())
+    with torch.no_grad():
+        bn.weight.copy_(1.0 + 0.2 * rnd(C, seed=3)); bn.bias.copy_(0.3 * rnd(C, seed=4))
+    ops.fp8.__init__()
+    with lavt_hip.use_dtype("fp8"):
+        site = ops.fp8_act_site(w, B * H * H, C)
+        assert site == id(w)
+        for it in range(2):                                                  # second pass: calibrated scale
+            ops.fp8.advance()
+            up = ops.bilinear(x.to(dev()), B, Hi, Hi, H, H, fp8_site=site)
+            q_up, a_up = ops.fp8.twins[(up.data_ptr(), up.numel())]
+            got = ops.fp8.quantize(up, site)
+            assert got[0] is q_up and not ops.fp8.twins                     # picked up, no second quantisation
+        amax_up = float(up.float().abs().max())
+        assert torch.equal(q_up.cpu(), F8.quantize_bytes(up.cpu(), amax_up))   # (the same tensor both passes: the delayed scale is its own |max|)
+        assert float(ops.fp8.cur[ops.fp8.slots[site]]) == amax_up
+        # BatchNorm + ReLU twin, and the gradient |max| of its backward
+        ops.fp8.__init__()
+        dsite = ops.fp8_dy_site(w, B * H * H, C)
+        for it in range(2):
+            ops.fp8.advance()
+            xin = up.detach().clone().requires_grad_(True)
+            y = ops.batch_norm_relu(xin, bn, fp8_site=site, fp8_dy_site=dsite)
+            q_y, _ = ops.fp8.twins.pop((y.data_ptr(), y.numel()))
+            dy = (rnd(B * H * H, C, seed=9) * 1e-3).to(torch.bfloat16).to(dev())
+            dx, = torch.autograd.grad(y, xin, dy)
+        assert torch.equal(q_y.cpu(), F8.quantize_bytes(y.detach().cpu(), float(y.detach().float().abs().max())))
+        a_ptr = ops.fp8.dy_amax[(dx.data_ptr(), dx.numel())]
+        i = ops.fp8.slots[dsite]
+        assert a_ptr == ops.fp8.cur.data_ptr() + 4 * i
+        assert float(ops.fp8.cur[i]) == float(dx.float().abs().max())
+        qd, ap = ops.fp8.quantize_current(dx, dsite)
+        assert ap == a_ptr and torch.equal(qd.cpu(), F8.quantize_bytes(dx.cpu(), float(dx.float().abs().max())))
+        # without fp8 sites nothing is registered
+        ops.fp8.advance()
+        ops.batch_norm_relu(up.detach(), bn)
+        assert not ops.fp8.twins and not ops.fp8.dy_amax
+
+
 @pytest.mark.parametrize("cat", [False, True])
 def test_fp8_conv3x3_matches_quantised_oracle(cat, monkeypatch):
     """decoder 3x3 convolution on e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales): both concat sources against one scale,
