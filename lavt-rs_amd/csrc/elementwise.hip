@@ -808,7 +808,9 @@ extern "C" int lavt_bilinear_fwd(int dtype, const void* x, void* y, int B, int H
 extern "C" int lavt_bilinear_fwd_q8(const void* x, void* y, void* q, const float* amax_prev, float* amax_cur, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream) {
     LAVT_CHECK_ARG(x && y && q && amax_cur && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % 8 == 0, "lavt_bilinear_fwd_q8: bad arguments");
     const int64_t nc = (int64_t)B * Ho * Wo * (C / 8);
-    hipLaunchKernelGGL((bilinear_fwd_kernel<bf16, true>), dim3(ew_grid(nc)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, B, Hi, Wi, Ho, Wo, C, bl_scale(Hi, Ho), bl_scale(Wi, Wo),
+    // at most 1024 workgroups: each ends with one same-address atomic (|max|), and those serialise at ~20 ns apiece (3600 of them made the 60x60 launch 55 us)
+    const int grid = ew_grid(nc) < 1024 ? ew_grid(nc) : 1024;
+    hipLaunchKernelGGL((bilinear_fwd_kernel<bf16, true>), dim3(grid), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, B, Hi, Wi, Ho, Wo, C, bl_scale(Hi, Ho), bl_scale(Wi, Wo),
                        (unsigned char*)q, amax_prev, amax_cur);
     LAVT_CHECK_LAUNCH("lavt_bilinear_fwd_q8");
     return LAVT_OK;
