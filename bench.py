@@ -137,7 +137,7 @@ def measure_conv_kernel(device, iters=20):
             tsrc = "profiles/r04_pmc_conv_fp8.json (recorded)"
         except Exception:  # noqa: BLE001
             pass
-    return {"bound": "mfma", "kernel": "implicit-GEMM conv3x3 512->512 @120x120, batch 2 (decoder conv2_2), timed alone" + (" [fp8: the e4m3 contraction; the activation quantiser is a launch of its own]" if f8 else ""),
+    return {"bound": "mfma", "kernel": "implicit-GEMM conv3x3 512->512 @120x120, batch 2 (decoder conv2_2), timed alone" + (" [fp8: the e4m3 contraction; in the step its activation operand is the twin the producing BatchNorm + ReLU / bilinear kernel wrote]" if f8 else ""),
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "avg_launch_us": round(ms * 1e3, 2), "flops_per_launch": flops, "traffic": traffic, "traffic_source": tsrc}
 
