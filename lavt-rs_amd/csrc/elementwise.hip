@@ -128,11 +128,14 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* x, T* y, int
     constexpr int EPC = Chunk<T>::N;
     float q_s = 1.f, q_m = 0.f;
     if constexpr (Q8) q_s = q8_scale(amax_prev);
-    const int cpr = C / EPC;
-    const int64_t n = (int64_t)B * Ho * Wo * cpr;
-    GRID_STRIDE(i, n) {
-        const int c = (int)(i % cpr) * EPC;
-        const int xo = (int)((i / cpr) % Wo), yo = (int)((i / cpr / Wo) % Ho), b = (int)(i / cpr / Wo / Ho);
+    const unsigned cpr = C / EPC;
+    // 32-bit index arithmetic (the entry points refuse more than 2^31 chunks): with int64 indices the three divisions of the decode were ~300 vector
+    // instructions per 16-byte chunk and the kernel ran at 2.5 TB/s, VALU-bound (28.3 us for the 4 x 60 x 60 -> 120 x 120 x 512 map)
+    const unsigned n = (unsigned)B * Ho * Wo * cpr;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned pix = i / cpr, rowo = pix / (unsigned)Wo;
+        const int c = (int)(i - pix * cpr) * EPC;
+        const int xo = (int)(pix - rowo * Wo), b = (int)(rowo / (unsigned)Ho), yo = (int)(rowo - (unsigned)b * Ho);
         int y0, y1, x0, x1; float ly, lx;
         bl_coord(yo, sh, Hi, y0, y1, ly);
         bl_coord(xo, sw, Wi, x0, x1, lx);
@@ -146,10 +149,10 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* x, T* y, int
         for (int e = 0; e < EPC; ++e)
             o[e] = (1.f - ly) * ((1.f - lx) * f00[e] + lx * f01[e]) + ly * ((1.f - lx) * f10[e] + lx * f11[e]);
         const uint4 out = f_to_chunk<T>(o);
-        *reinterpret_cast<uint4*>(y + i * EPC) = out;
+        *reinterpret_cast<uint4*>(y + (int64_t)i * EPC) = out;
         if constexpr (Q8) {
             chunk_to_f<T>(out, o);
-            *reinterpret_cast<uint2*>(q + i * EPC) = q8_chunk8(o, q_s, q_m);
+            *reinterpret_cast<uint2*>(q + (int64_t)i * EPC) = q8_chunk8(o, q_s, q_m);
         }
     }
     if constexpr (Q8) q8_block_amax(q_m, amax_cur);
@@ -162,11 +165,12 @@ __device__ __forceinline__ void bl_range(int i, float scale, int n_in, int n_out
 }
 template <typename T> __global__ void bilinear_bwd_kernel(const T* dy, T* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, float sh, float sw) {
     constexpr int EPC = Chunk<T>::N;
-    const int cpr = C / EPC;
-    const int64_t n = (int64_t)B * Hi * Wi * cpr;
-    GRID_STRIDE(i, n) {
-        const int c = (int)(i % cpr) * EPC;
-        const int xi = (int)((i / cpr) % Wi), yi = (int)((i / cpr / Wi) % Hi), b = (int)(i / cpr / Wi / Hi);
+    const unsigned cpr = C / EPC;
+    const unsigned n = (unsigned)B * Hi * Wi * cpr;          // (32-bit index arithmetic: see bilinear_fwd_kernel)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned pix = i / cpr, rowi = pix / (unsigned)Wi;
+        const int c = (int)(i - pix * cpr) * EPC;
+        const int xi = (int)(pix - rowi * Wi), b = (int)(rowi / (unsigned)Hi), yi = (int)(rowi - (unsigned)b * Hi);
         int ylo, yhi, xlo, xhi;
         bl_range(yi, sh, Hi, Ho, ylo, yhi);
         bl_range(xi, sw, Wi, Wo, xlo, xhi);
@@ -189,7 +193,7 @@ template <typename T> __global__ void bilinear_bwd_kernel(const T* dy, T* dx, in
                 for (int e = 0; e < EPC; ++e) acc[e] += wy * wx * g[e];
             }
         }
-        *reinterpret_cast<uint4*>(dx + i * EPC) = f_to_chunk<T>(acc);
+        *reinterpret_cast<uint4*>(dx + (int64_t)i * EPC) = f_to_chunk<T>(acc);
     }
 }
 // logits: NHWC [B,Hi,Wi,2] (T) -> NCHW fp32 [B,2,Ho,Wo]
@@ -799,6 +803,7 @@ extern "C" int lavt_rowsoftmax_bwd(int dtype, const void* p, const void* dp, voi
 }
 extern "C" int lavt_bilinear_fwd(int dtype, const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream) {
     LAVT_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % EPC_OF(dtype) == 0, "lavt_bilinear_fwd: bad arguments");
+    LAVT_CHECK_ARG((int64_t)B * Ho * Wo * (C / EPC_OF(dtype)) < (1LL << 31) - (1LL << 21), "lavt_bilinear_fwd: more than 2^31 output chunks");
     const int64_t nc = (int64_t)B * Ho * Wo * (C / EPC_OF(dtype));
     DISPATCH_T(dtype, "lavt_bilinear_fwd", hipLaunchKernelGGL(bilinear_fwd_kernel<T>, dim3(ew_grid(nc)), dim3(256), 0, ST, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
     LAVT_CHECK_LAUNCH("lavt_bilinear_fwd");
@@ -808,6 +813,7 @@ extern "C" int lavt_bilinear_fwd(int dtype, const void* x, void* y, int B, int H
 extern "C" int lavt_bilinear_fwd_q8(const void* x, void* y, void* q, const float* amax_prev, float* amax_cur, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream) {
     LAVT_CHECK_ARG(x && y && q && amax_cur && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % 8 == 0, "lavt_bilinear_fwd_q8: bad arguments");
     const int64_t nc = (int64_t)B * Ho * Wo * (C / 8);
+    LAVT_CHECK_ARG(nc < (1LL << 31) - (1LL << 21), "lavt_bilinear_fwd_q8: more than 2^31 output chunks");
     // at most 1024 workgroups: each ends with one same-address atomic (|max|), and those serialise at ~20 ns apiece (3600 of them made the 60x60 launch 55 us)
     const int grid = ew_grid(nc) < 1024 ? ew_grid(nc) : 1024;
     hipLaunchKernelGGL((bilinear_fwd_kernel<bf16, true>), dim3(grid), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, B, Hi, Wi, Ho, Wo, C, bl_scale(Hi, Ho), bl_scale(Wi, Wo),
@@ -818,6 +824,7 @@ extern "C" int lavt_bilinear_fwd_q8(const void* x, void* y, void* q, const float
 
 extern "C" int lavt_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, void* stream) {
     LAVT_CHECK_ARG(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % EPC_OF(dtype) == 0, "lavt_bilinear_bwd: bad arguments");
+    LAVT_CHECK_ARG((int64_t)B * Hi * Wi * (C / EPC_OF(dtype)) < (1LL << 31) - (1LL << 21), "lavt_bilinear_bwd: more than 2^31 input chunks");
     const int64_t nc = (int64_t)B * Hi * Wi * (C / EPC_OF(dtype));
     DISPATCH_T(dtype, "lavt_bilinear_bwd", hipLaunchKernelGGL(bilinear_bwd_kernel<T>, dim3(ew_grid(nc)), dim3(256), 0, ST, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
     LAVT_CHECK_LAUNCH("lavt_bilinear_bwd");
