@@ -173,6 +173,8 @@ __device__ __forceinline__ uint2 xchg16(uint2 v) { return make_uint2((unsigned)_
 // them as not-taken uniform branches costs every plain GEMM of the step (tools/ab_lib.sh: -0.2 ms per step with all of them compiled out, of which
 // about half is the launches that do use them).
 // LEAN = 2 (data gradients, convolutions without bias): additionally no bias / residual / row scale / output row map -- a plain store.
+// LEAN = 3 (round 5): LEAN 2 with the split output kept -- the data gradient of a concat convolution in ONE launch (Swin-T's conv1_2: 384 + 96 columns;
+// on the full epilogue that launch ran at 0.36 of peak where its lean siblings reach 0.45).
 // Side inputs of the wide epilogue (pre-activation of the activation gradient, residual, multiplier) for a wave tile of <= 8 fragments.  Loaded at the
 // head of the epilogue they are one exposed round trip to L2 / HBM behind the K loop of a launch whose K loop lasts 3-10 us (proj forward 1800 x 512 x
 // 512: 5.2 us as a plain GEMM, ~10 with residual + DropPath scale); `nt_side_load` issues the same loads BEFORE the K loop (round 5) -- they are the
@@ -231,7 +233,8 @@ __device__ __forceinline__ void nt_epilogue_wide(const lavt_gemm_nt_t& p_in, f32
     if constexpr (GD && !DACT) {         // fc1 of the LayerNorm-folded MLP node: folded bias, GELU + its derivative as second output, nothing else
         p.mul = nullptr; p.C2 = nullptr; p.R = nullptr; p.row_scale = nullptr; p.c_rowmap = nullptr;
     }
-    if constexpr (LEAN >= 1) { p.act = 0; p.mul = nullptr; p.Cpre = nullptr; p.C2 = nullptr; }
+    if constexpr (LEAN >= 1) { p.act = 0; p.mul = nullptr; p.Cpre = nullptr; }
+    if constexpr (LEAN == 1 || LEAN == 2) p.C2 = nullptr;
     if constexpr (LEAN >= 2) { p.bias = nullptr; p.R = nullptr; p.row_scale = nullptr; p.c_rowmap = nullptr; }
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
     const float* rscale = p.row_scale ? p.row_scale + (int64_t)bz * p.strideRowScale : nullptr;

@@ -680,6 +680,10 @@ template <int BM, int BN, bool BKM, int STAGES, int MODE, int LEAN, bool F8 = fa
     return LAVT_OK;
 }
 template <int BM, int BN, bool BKM, int STAGES, int MODE> int launch_pipe_lean(const lavt_gemm_nt_t& p, hipStream_t st) {
+    if constexpr (BM == 256 && BKM && MODE == 2) {          // split-output data gradient of a concat convolution: the plain store with the second output kept (LEAN 3)
+        if (p.C2 && p.act == 0 && !p.mul && !p.Cpre && !p.bias && !p.R && !p.row_scale && !p.c_rowmap && !lavt_tuning().probe[7])
+            return launch_pipe_<BM, BN, BKM, STAGES, MODE, 3>(p, st);
+    }
     if (MODE != 0 && p.act == 0 && !p.mul && !p.Cpre && !p.C2) {      // epilogue instantiations without the features a launch does not use (gemm_common.h)
         if (!p.bias && !p.R && !p.row_scale && !p.c_rowmap) return launch_pipe_<BM, BN, BKM, STAGES, MODE, 2>(p, st);
         return launch_pipe_<BM, BN, BKM, STAGES, MODE, 1>(p, st);
