@@ -157,6 +157,75 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* x, T* y, int
     }
     if constexpr (Q8) q8_block_amax(q_m, amax_cur);
 }
+// Row-staged form (bf16, round 5): the element-indexed kernel above reads every input byte 16 times through register loads -- 43 GB/s per CU of L1 / L2
+// traffic, the rate that path reaches (tools/probes/ingest_paths.hip: 32 GB/s per CU for register loads from L2, 71 for LDS-DMA) -- and ran the decoder's
+// 60 -> 120 upsample at 2.6 TB/s.  Here a workgroup owns ONE input row interval (rows y0, y0 + 1) of one image and one block of channels: the two rows
+// arrive in LDS by LDS-DMA (every input byte fetched twice, lane-linear image [row][pixel][16-byte chunk]), then every output row that samples the
+// interval is formed from LDS with the element-indexed kernel's own expression (bit-identical results) and stored.  grid (Hi, B, C / cblk).
+typedef __attribute__((address_space(3))) void ew_lds_void;
+typedef __attribute__((address_space(1))) const void ew_gbl_void;
+template <bool Q8>
+__global__ __launch_bounds__(256) void bilinear_rows_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int Hi, int Wi, int Ho, int Wo, int C, int cblk, float sh, float sw,
+                                                                unsigned char* __restrict__ q, const float* __restrict__ amax_prev, float* __restrict__ amax_cur) {
+    extern __shared__ __attribute__((aligned(16))) char ew_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int y0b = blockIdx.x, b = blockIdx.y, c0 = blockIdx.z * cblk, cpp = cblk >> 3;          // cpp: 16-byte chunks per pixel of this channel block (divides 256)
+    const int y1b = min(y0b + 1, Hi - 1);
+    const int row_chunks = Wi * cpp, total = 2 * row_chunks;
+    float q_s = 1.f, q_m = 0.f;
+    if constexpr (Q8) q_s = q8_scale(amax_prev);
+    for (int q0 = wave * 64; q0 < total; q0 += 256) {          // one 1 KiB LDS-DMA per wave and trip; chunks beyond the image re-load the last one (the LDS image is rounded up)
+        const int qq = min(q0 + lane, total - 1);
+        const int r = qq >= row_chunks ? 1 : 0, e = qq - r * row_chunks, xi = e / cpp, cc = e - xi * cpp;
+        const bf16* src = x + (((int64_t)b * Hi + (r ? y1b : y0b)) * Wi + xi) * C + c0 + cc * 8;
+        __builtin_amdgcn_global_load_lds((ew_gbl_void*)src, (ew_lds_void*)(ew_smem + (size_t)q0 * 16), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint4* r0 = reinterpret_cast<const uint4*>(ew_smem);
+    const uint4* r1 = r0 + row_chunks;
+    const int cc = tid % cpp, xstep = 256 / cpp;
+    // output rows that sample this interval: floor(sh * yo) == y0b (bl_coord's own arithmetic decides; the candidate range is generous)
+    const int lo = sh > 0.f ? max(0, (int)floorf((float)y0b / sh) - 1) : 0, hi = sh > 0.f ? min(Ho - 1, (int)ceilf((float)(y0b + 1) / sh) + 1) : Ho - 1;
+    for (int yo = lo; yo <= hi; ++yo) {
+        int yy0, yy1; float ly;
+        bl_coord(yo, sh, Hi, yy0, yy1, ly);
+        if (yy0 != y0b) continue;
+        for (int xo = tid / cpp; xo < Wo; xo += xstep) {
+            int x0, x1; float lx;
+            bl_coord(xo, sw, Wi, x0, x1, lx);
+            float f00[8], f01[8], f10[8], f11[8], o[8];
+            chunk_to_f<bf16>(r0[x0 * cpp + cc], f00);
+            chunk_to_f<bf16>(r0[x1 * cpp + cc], f01);
+            chunk_to_f<bf16>(r1[x0 * cpp + cc], f10);
+            chunk_to_f<bf16>(r1[x1 * cpp + cc], f11);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                o[e] = (1.f - ly) * ((1.f - lx) * f00[e] + lx * f01[e]) + ly * ((1.f - lx) * f10[e] + lx * f11[e]);
+            const uint4 out = f_to_chunk<bf16>(o);
+            const int64_t off = (((int64_t)b * Ho + yo) * Wo + xo) * C + c0 + cc * 8;
+            *reinterpret_cast<uint4*>(y + off) = out;
+            if constexpr (Q8) {
+                chunk_to_f<bf16>(out, o);
+                *reinterpret_cast<uint2*>(q + off) = q8_chunk8(o, q_s, q_m);
+            }
+        }
+    }
+    if constexpr (Q8) q8_block_amax(q_m, amax_cur);
+}
+// channel block of the row-staged form: the widest of 512 / 256 / 128 / 64 channels that divides C, keeps two input rows within 64 KB of LDS and leaves
+// at least ~256 workgroups; 0 = the shape stays on the element-indexed kernel
+static int bl_rows_cblk(int B, int Hi, int Wi, int C) {
+    for (int cb = 512; cb >= 64; cb >>= 1) {
+        if (C % cb) continue;
+        const long lds = 2L * Wi * cb * 2;
+        const long blocks = (long)Hi * B * (C / cb);
+        if (lds <= 64 * 1024 && (blocks >= 256 || cb == 64)) return cb;
+    }
+    return 0;
+}
+static inline size_t bl_rows_lds(int Wi, int cblk) { return ((size_t)2 * Wi * cblk * 2 + 1023) / 1024 * 1024; }
+
 // gather form of the transpose: every input pixel sums the output pixels that sampled it (deterministic, no atomics)
 __device__ __forceinline__ void bl_range(int i, float scale, int n_in, int n_out, int& lo, int& hi) {
     if (scale <= 0.f) { lo = 0; hi = n_out - 1; return; }
@@ -805,6 +874,15 @@ extern "C" int lavt_bilinear_fwd(int dtype, const void* x, void* y, int B, int H
     LAVT_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % EPC_OF(dtype) == 0, "lavt_bilinear_fwd: bad arguments");
     LAVT_CHECK_ARG((int64_t)B * Ho * Wo * (C / EPC_OF(dtype)) < (1LL << 31) - (1LL << 21), "lavt_bilinear_fwd: more than 2^31 output chunks");
     const int64_t nc = (int64_t)B * Ho * Wo * (C / EPC_OF(dtype));
+    if (dtype == LAVT_BF16 && !lavt_tuning().probe[7]) {          // row-staged form (LDS-DMA): every decoder shape
+        const int cblk = bl_rows_cblk(B, Hi, Wi, C);
+        if (cblk) {
+            hipLaunchKernelGGL((bilinear_rows_fwd_kernel<false>), dim3(Hi, B, C / cblk), dim3(256), bl_rows_lds(Wi, cblk), ST, (const bf16*)x, (bf16*)y, Hi, Wi, Ho, Wo, C, cblk,
+                               bl_scale(Hi, Ho), bl_scale(Wi, Wo), (unsigned char*)nullptr, (const float*)nullptr, (float*)nullptr);
+            LAVT_CHECK_LAUNCH("lavt_bilinear_fwd");
+            return LAVT_OK;
+        }
+    }
     DISPATCH_T(dtype, "lavt_bilinear_fwd", hipLaunchKernelGGL(bilinear_fwd_kernel<T>, dim3(ew_grid(nc)), dim3(256), 0, ST, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, bl_scale(Hi, Ho), bl_scale(Wi, Wo)));
     LAVT_CHECK_LAUNCH("lavt_bilinear_fwd");
     return LAVT_OK;
@@ -814,6 +892,15 @@ extern "C" int lavt_bilinear_fwd_q8(const void* x, void* y, void* q, const float
     LAVT_CHECK_ARG(x && y && q && amax_cur && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % 8 == 0, "lavt_bilinear_fwd_q8: bad arguments");
     const int64_t nc = (int64_t)B * Ho * Wo * (C / 8);
     LAVT_CHECK_ARG(nc < (1LL << 31) - (1LL << 21), "lavt_bilinear_fwd_q8: more than 2^31 output chunks");
+    if (!lavt_tuning().probe[7]) {
+        const int cblk = bl_rows_cblk(B, Hi, Wi, C);
+        if (cblk && (long)Hi * B * (C / cblk) <= 1024) {          // (one same-address |max| atomic per workgroup: keep them few)
+            hipLaunchKernelGGL((bilinear_rows_fwd_kernel<true>), dim3(Hi, B, C / cblk), dim3(256), bl_rows_lds(Wi, cblk), ST, (const bf16*)x, (bf16*)y, Hi, Wi, Ho, Wo, C, cblk,
+                               bl_scale(Hi, Ho), bl_scale(Wi, Wo), (unsigned char*)q, amax_prev, amax_cur);
+            LAVT_CHECK_LAUNCH("lavt_bilinear_fwd_q8");
+            return LAVT_OK;
+        }
+    }
     // at most 1024 workgroups: each ends with one same-address atomic (|max|), and those serialise at ~20 ns apiece (3600 of them made the 60x60 launch 55 us)
     const int grid = ew_grid(nc) < 1024 ? ew_grid(nc) : 1024;
     hipLaunchKernelGGL((bilinear_fwd_kernel<bf16, true>), dim3(grid), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, B, Hi, Wi, Ho, Wo, C, bl_scale(Hi, Ho), bl_scale(Wi, Wo),

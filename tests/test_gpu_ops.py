@@ -583,6 +583,32 @@ def test_bilinear(dtype, Hi, Wi, Ho, Wo):
     run_pair(lambda x: ops.bilinear(x, B, Hi, Wi, Ho, Wo), ref, {"x": (rnd(B * Hi * Wi, C, seed=1), "act")}, dtype, name="bilinear")
 
 
+@pytest.mark.parametrize("B,C,Hi,Wi,Ho,Wo", [(2, 512, 60, 60, 120, 120), (3, 192, 15, 15, 30, 30), (1, 128, 7, 5, 14, 9), (2, 64, 3, 3, 3, 7), (2, 1024, 15, 15, 30, 30),
+                                              (1, 256, 9, 11, 9, 40), (2, 128, 6, 6, 1, 1), (1, 64, 1, 8, 5, 8)])
+def test_bilinear_row_staged_equals_element_indexed(B, C, Hi, Wi, Ho, Wo, monkeypatch, request):
+    """the row-staged bf16 upsample (input row pairs through LDS-DMA, csrc/elementwise.hip bilinear_rows_fwd_kernel) against the element-indexed kernel it
+    replaces -- the same expression, so at most one bf16 rounding step apart where hipcc contracts the two kernels' multiply-adds differently (0.1 % of the
+    elements) -- and against F.interpolate(align_corners=True) with the same error as the old kernel; decoder shapes, odd ratios, a single output row /
+    column, a single input row"""
+    from lavt_hip import ops, _capi as K
+    x = rnd(B * Hi * Wi, C, seed=1).to(torch.bfloat16).to(dev())
+
+    def run(probe):
+        monkeypatch.setenv("LAVT_PROBE", probe)
+        K.lib.lavt_tuning_reload()
+        y = torch.empty(B * Ho * Wo, C, dtype=torch.bfloat16, device=dev())
+        K.check(K.lib.lavt_bilinear_fwd(K.BF16, K.ptr(x), K.ptr(y), B, Hi, Wi, Ho, Wo, C, K.stream()))
+        torch.cuda.synchronize()
+        return y.cpu()
+    request.addfinalizer(lambda: (os.environ.pop("LAVT_PROBE", None), K.lib.lavt_tuning_reload()))
+    new, old = run("0,0,0,0,0,0,0,0"), run("0,0,0,0,0,0,0,1")
+    d = (new.float() - old.float()).abs()
+    assert float((d / old.float().abs().clamp_min(1e-3)).max()) <= 2.0 ** -7 and float((d > 0).float().mean()) < 0.01
+    ref = F.interpolate(x.float().cpu().view(B, Hi, Wi, C).permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).reshape(B * Ho * Wo, C)
+    assert float((new.float() - ref).abs().max()) <= 1.05 * float((old.float() - ref).abs().max()) + 1e-6
+    assert float((new.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_cls_head_and_logits_up(dtype):
     from lavt_hip import ops
