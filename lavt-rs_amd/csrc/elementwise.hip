@@ -874,7 +874,7 @@ extern "C" int lavt_bilinear_fwd(int dtype, const void* x, void* y, int B, int H
     LAVT_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % EPC_OF(dtype) == 0, "lavt_bilinear_fwd: bad arguments");
     LAVT_CHECK_ARG((int64_t)B * Ho * Wo * (C / EPC_OF(dtype)) < (1LL << 31) - (1LL << 21), "lavt_bilinear_fwd: more than 2^31 output chunks");
     const int64_t nc = (int64_t)B * Ho * Wo * (C / EPC_OF(dtype));
-    if (dtype == LAVT_BF16 && !lavt_tuning().probe[7]) {          // row-staged form (LDS-DMA): every decoder shape
+    if (dtype == LAVT_BF16 && lavt_tuning().probe[7] != 1) {          // row-staged form (LDS-DMA): every decoder shape
         const int cblk = bl_rows_cblk(B, Hi, Wi, C);
         if (cblk) {
             hipLaunchKernelGGL((bilinear_rows_fwd_kernel<false>), dim3(Hi, B, C / cblk), dim3(256), bl_rows_lds(Wi, cblk), ST, (const bf16*)x, (bf16*)y, Hi, Wi, Ho, Wo, C, cblk,
@@ -892,7 +892,7 @@ extern "C" int lavt_bilinear_fwd_q8(const void* x, void* y, void* q, const float
     LAVT_CHECK_ARG(x && y && q && amax_cur && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % 8 == 0, "lavt_bilinear_fwd_q8: bad arguments");
     const int64_t nc = (int64_t)B * Ho * Wo * (C / 8);
     LAVT_CHECK_ARG(nc < (1LL << 31) - (1LL << 21), "lavt_bilinear_fwd_q8: more than 2^31 output chunks");
-    if (!lavt_tuning().probe[7]) {
+    if (lavt_tuning().probe[7] != 1) {
         const int cblk = bl_rows_cblk(B, Hi, Wi, C);
         if (cblk && (long)Hi * B * (C / cblk) <= 1024) {          // (one same-address |max| atomic per workgroup: keep them few)
             hipLaunchKernelGGL((bilinear_rows_fwd_kernel<true>), dim3(Hi, B, C / cblk), dim3(256), bl_rows_lds(Wi, cblk), ST, (const bf16*)x, (bf16*)y, Hi, Wi, Ho, Wo, C, cblk,

@@ -29,6 +29,9 @@
 #include "gemm_v2_helpers.h"
 
 namespace {
+// workgroups of the 128x128 tile from which the 2-stage ring (two workgroups per CU) replaces the 4-stage one (LAVT_PROBE slot 7 >= 100 overrides: experiments)
+static inline long s2_min128() { const int v = lavt_tuning().probe[7]; return v >= 100 ? v : 257; }
+
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((__vector_size__(8 * sizeof(int)))) int i32x8;
@@ -681,7 +684,7 @@ template <int BM, int BN, bool BKM, int STAGES, int MODE, int LEAN, bool F8 = fa
 }
 template <int BM, int BN, bool BKM, int STAGES, int MODE> int launch_pipe_lean(const lavt_gemm_nt_t& p, hipStream_t st) {
     if constexpr (BM == 256 && BKM && MODE == 2) {          // split-output data gradient of a concat convolution: the plain store with the second output kept (LEAN 3)
-        if (p.C2 && p.act == 0 && !p.mul && !p.Cpre && !p.bias && !p.R && !p.row_scale && !p.c_rowmap && !lavt_tuning().probe[7])
+        if (p.C2 && p.act == 0 && !p.mul && !p.Cpre && !p.bias && !p.R && !p.row_scale && !p.c_rowmap && lavt_tuning().probe[7] != 1)
             return launch_pipe_<BM, BN, BKM, STAGES, MODE, 3>(p, st);
     }
     if (MODE != 0 && p.act == 0 && !p.mul && !p.Cpre && !p.C2) {      // epilogue instantiations without the features a launch does not use (gemm_common.h)
@@ -756,7 +759,7 @@ int lavt_gemm_nt_pipe_tile(const lavt_gemm_nt_t& p, int* stages_out) {
     const int big_long = tun.gemm_big_long;
     const bool big = force ? force == 128 : ((tiles128 >= 200 || (big_long > 0 && p.K >= 64 * 64 && tiles128 >= big_long)) && p.N >= 128);
     const long wgs = big ? tiles128 : tiles64;
-    const int stages = tun.gemm_stages ? tun.gemm_stages : (wgs >= 600 ? 2 : 4);
+    const int stages = tun.gemm_stages ? tun.gemm_stages : (wgs >= (big ? s2_min128() : 512) ? 2 : 4);
     const long tiles256 = (long)cdiv(p.M, 128) * cdiv(p.N, 256) * p.batch;
     const bool wide = force ? force == 256 : (tun.gemm_wide && tiles256 >= 256 && p.N % 256 == 0 && p.K >= 1024);
     if (wide) return 0;

@@ -20,6 +20,9 @@
 #include "gemm_v2_helpers.h"
 
 namespace {
+// workgroups of the 128x128 tile from which the 2-stage ring (two workgroups per CU) replaces the 4-stage one (LAVT_PROBE slot 7 >= 100 overrides: experiments)
+static inline long s2_min128() { const int v = lavt_tuning().probe[7]; return v >= 100 ? v : 257; }
+
 
 // SIMPLE = no conv taps, no concat source, K % 64 == 0: every lane's DMA source is a fixed pointer that advances by a constant per K tile,
 // so the K loop carries ~3 instructions per DMA instead of the general path's address arithmetic (which made small GEMMs issue-bound:
@@ -449,11 +452,11 @@ int launch_nt_v2_lna(const lavt_gemm_nt_t& p, hipStream_t st) {
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128), tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
     // (LAVT_ACT_GELU_D is its own instantiation: with the branch on p.act inside one kernel, the classic form ran 3 us per launch slower)
     if (p.act == LAVT_ACT_GELU_D && !p.mul && !p.C2 && !p.R && !p.row_scale && !p.c_rowmap) {
-        if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_<128, 128, false, 2, 8, 1, false, false, true, true>(p, st) : launch_nt_v2_<128, 128, false, 4, 8, 1, false, false, true, true>(p, st);
-        return tiles64 >= 600 ? launch_nt_v2_<64, 64, false, 2, 4, 1, false, false, true, true>(p, st) : launch_nt_v2_<64, 64, false, 4, 4, 1, false, false, true, true>(p, st);
+        if (tiles128 >= 200 && p.N >= 128) return tiles128 >= s2_min128() ? launch_nt_v2_<128, 128, false, 2, 8, 1, false, false, true, true>(p, st) : launch_nt_v2_<128, 128, false, 4, 8, 1, false, false, true, true>(p, st);
+        return tiles64 >= 512 ? launch_nt_v2_<64, 64, false, 2, 4, 1, false, false, true, true>(p, st) : launch_nt_v2_<64, 64, false, 4, 4, 1, false, false, true, true>(p, st);
     }
-    if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_<128, 128, false, 2, 8, 1, false, false, true>(p, st) : launch_nt_v2_<128, 128, false, 4, 8, 1, false, false, true>(p, st);
-    return tiles64 >= 600 ? launch_nt_v2_<64, 64, false, 2, 4, 1, false, false, true>(p, st) : launch_nt_v2_<64, 64, false, 4, 4, 1, false, false, true>(p, st);
+    if (tiles128 >= 200 && p.N >= 128) return tiles128 >= s2_min128() ? launch_nt_v2_<128, 128, false, 2, 8, 1, false, false, true>(p, st) : launch_nt_v2_<128, 128, false, 4, 8, 1, false, false, true>(p, st);
+    return tiles64 >= 512 ? launch_nt_v2_<64, 64, false, 2, 4, 1, false, false, true>(p, st) : launch_nt_v2_<64, 64, false, 4, 4, 1, false, false, true>(p, st);
 }
 // fp8 operands (LAVT_FP8): k-contiguous A and B, 128-element K tiles; 128x128 / 8 waves when that fills the chip, else 64x64 / 4 waves
 template <int BM, int BN, int STAGES, int WAVES> int launch_nt_v2_f8(const lavt_gemm_nt_t& p, hipStream_t st) {
@@ -469,8 +472,8 @@ int launch_nt_v2_fp8(const lavt_gemm_nt_t& p, hipStream_t st) {
         return LAVT_ERR_INVALID;
     }
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch, tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;
-    if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_f8<128, 128, 2, 8>(p, st) : launch_nt_v2_f8<128, 128, 4, 8>(p, st);
-    return tiles64 >= 600 ? launch_nt_v2_f8<64, 64, 2, 4>(p, st) : launch_nt_v2_f8<64, 64, 4, 4>(p, st);
+    if (tiles128 >= 200 && p.N >= 128) return tiles128 >= s2_min128() ? launch_nt_v2_f8<128, 128, 2, 8>(p, st) : launch_nt_v2_f8<128, 128, 4, 8>(p, st);
+    return tiles64 >= 512 ? launch_nt_v2_f8<64, 64, 2, 4>(p, st) : launch_nt_v2_f8<64, 64, 4, 4>(p, st);
 }
 // Fused activation-gradient epilogue (dact_pre): data gradients only (k-major B, plain K walk); the flag is a template parameter so that no
 // other instantiation pays its registers (as a run-time branch in every kernel it cost 12 VGPRs and 0.25 ms per step in round 1).
@@ -482,11 +485,11 @@ int launch_nt_v2_dact(const lavt_gemm_nt_t& p, hipStream_t st) {
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch, tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64) * p.batch;
     // the stored-derivative form (dact = LAVT_ACT_STORED, no residual) is its own instantiation (GD): a multiply, none of the transcendental forms
     if (p.dact == LAVT_ACT_STORED && !p.R && !p.bias && !p.c_rowmap && !p.act && !p.mul && !p.Cpre && !p.C2) {      // (its wide epilogue has none of these: any of them takes the general instantiation)
-        if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_<128, 128, true, 2, 8, 1, true, false, false, true>(p, st) : launch_nt_v2_<128, 128, true, 4, 8, 1, true, false, false, true>(p, st);
-        return tiles64 >= 600 ? launch_nt_v2_<64, 64, true, 2, 4, 1, true, false, false, true>(p, st) : launch_nt_v2_<64, 64, true, 4, 4, 1, true, false, false, true>(p, st);
+        if (tiles128 >= 200 && p.N >= 128) return tiles128 >= s2_min128() ? launch_nt_v2_<128, 128, true, 2, 8, 1, true, false, false, true>(p, st) : launch_nt_v2_<128, 128, true, 4, 8, 1, true, false, false, true>(p, st);
+        return tiles64 >= 512 ? launch_nt_v2_<64, 64, true, 2, 4, 1, true, false, false, true>(p, st) : launch_nt_v2_<64, 64, true, 4, 4, 1, true, false, false, true>(p, st);
     }
-    if (tiles128 >= 200 && p.N >= 128) return tiles128 >= 600 ? launch_nt_v2_<128, 128, true, 2, 8, 1, true>(p, st) : launch_nt_v2_<128, 128, true, 4, 8, 1, true>(p, st);
-    return tiles64 >= 600 ? launch_nt_v2_<64, 64, true, 2, 4, 1, true>(p, st) : launch_nt_v2_<64, 64, true, 4, 4, 1, true>(p, st);
+    if (tiles128 >= 200 && p.N >= 128) return tiles128 >= s2_min128() ? launch_nt_v2_<128, 128, true, 2, 8, 1, true>(p, st) : launch_nt_v2_<128, 128, true, 4, 8, 1, true>(p, st);
+    return tiles64 >= 512 ? launch_nt_v2_<64, 64, true, 2, 4, 1, true>(p, st) : launch_nt_v2_<64, 64, true, 4, 4, 1, true>(p, st);
 }
 template <int BM, int BN, bool BKM, int STAGES, int WAVES> int launch_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     const bool general_only = lavt_tuning().gemm_general;
@@ -523,8 +526,12 @@ int lavt_gemm_nt_v2(const lavt_gemm_nt_t& p, hipStream_t st) {
     // Ring depth.  In isolation (operands L2-resident) 2 stages win everywhere; inside the training step the operands of the small
     // GEMMs arrive cold from HBM / Infinity Cache and a 4-deep ring is worth 0.8 ms per step.  The many-tile long-K problems (decoder
     // convolutions: every CU holds 2 workgroups and streams from L2) stay at 2 stages, which keeps two workgroups per CU resident.
+    // Round 5 (second session): for the 128x128 / 8-wave tile the 4-deep ring is 128 KB -- ONE workgroup per CU -- so a launch of 257-600 such workgroups ran in
+    // two or three rounds of single workgroups; from 257 workgroups up (more workgroups than CUs) the 2-deep ring (64 KB, two co-resident workgroups whose
+    // barrier stalls overlap) wins: batch 4 11.70 -> 11.39 ms, Video-Swin-B 19.55 -> 18.77, Swin-T batch 8 10.89 -> 10.73, headline 7.61 -> 7.58
+    // (profiles/r05_zz_ring_depth_threshold_sweep.txt, ..._rule_ab.txt).  Up to 256 workgroups (the M = 1800 GEMMs of batch 2) the 4-deep ring stays.
     const long wgs = big ? tiles128 : tiles64;
-    const int stages = tun.gemm_stages ? tun.gemm_stages : (wgs >= 600 ? 2 : 4);
+    const int stages = tun.gemm_stages ? tun.gemm_stages : (wgs >= (big ? s2_min128() : 512) ? 2 : 4);
     const int waves = tun.gemm_waves;
 #define GO(BM_, BN_, KM_, ST_, WV_) return launch_nt_v2<BM_, BN_, KM_, ST_, WV_>(p, st)
     // 128x256 tile, 8 waves of 64x64: fewer LDS bytes (DMA fill and fragment reads) per MFMA than 128x128; for the long-K, many-tile problems
