@@ -2668,14 +2668,16 @@ class _ConvTaps(torch.autograd.Function):
                 None, None, None, None, None, None)
 
 
-_CONV_SPLIT_MAX_ROWS = int(os.environ.get("LAVT_CONV_SPLIT_ROWS", "2048"))
+# (round 5: 4096 -- decoder level 4 at batch 4 has 3600 rows: 11.37 -> 11.32 ms; 2048 was sized on batch 2; tools/r05_knob_sweep2.sh)
+_CONV_SPLIT_MAX_ROWS = int(os.environ.get("LAVT_CONV_SPLIT_ROWS", "4096"))
 
 
 def _conv_split(dtype, M, N, Kc, C1, C2, taps, bias, act):
     """-> (pieces, over_channels): the number of pieces a convolution's reduction is cut into (0 = not split) and whether they are channel blocks
     (lavt_gemm_nt_t.conv_kc_split) or tap groups (conv_tap_split): bf16 tap-walking problems (channels % 64 == 0) without a fused epilogue, few rows
     (<= 2048: the fp32 partials are M x N x pieces x 4 bytes written and re-read) and a long reduction"""
-    if dtype != torch.bfloat16 or bias is not None or act != K.ACT_NONE or fp8_enabled() or M > _CONV_SPLIT_MAX_ROWS or taps % 3 or taps > 27:
+    # (callers ask only for convolutions that stay bf16: in fp8 mode the e4m3 branches are tried first, and the maps they leave in bf16 -- decoder level 4 -- split like in bf16 mode)
+    if dtype != torch.bfloat16 or bias is not None or act != K.ACT_NONE or M > _CONV_SPLIT_MAX_ROWS or taps % 3 or taps > 27:
         return 0, False
     if Kc % 64 or C1 % 64 or C2 % 64 or N % 8 or taps * Kc < 4096:
         return 0, False
