@@ -173,7 +173,7 @@ def replay_trace_launch_us(kernel_substr, grid):
     tools/trace_by_shape.py): a recorded figure, quoted next to the eager-timed one of this run"""
     import glob
     import re
-    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_z_by_shape_graph_replay.txt")), reverse=True):
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_z*_by_shape_graph_replay.txt")), reverse=True):          # (r05_zzz_... = the second session's table sorts in front of r05_z_...)
         for line in open(fn):
             if kernel_substr in line and (grid is None or f"grid {grid}x" in line):          # (tables are sorted by us/step: the first match is the heaviest launch of that kernel)
                 m_ = re.search(r"x\s+([0-9.]+) us\s+grid", line)
