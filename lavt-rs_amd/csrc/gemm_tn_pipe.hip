@@ -114,7 +114,7 @@ __device__ __forceinline__ void tnp_tile(const TnpMember& m, const int local, ch
     constexpr int BT = 128, BK = 64, CH = BT / 8, L = 4;
     constexpr int TILE_BYTES = BK * BT * 2, STAGE_BYTES = 2 * TILE_BYTES;
     constexpr int HO = 4 * BT * 2, KOFF = 32 * BT * 2;
-    static_assert(STAGES >= 3 && STAGES <= 5, "ring depth (5 x 32 KB = the whole 160 KB of a CU)");
+    static_assert(STAGES >= 2 && STAGES <= 5, "ring depth (5 x 32 KB = the whole 160 KB of a CU; 2 x 32 KB lets two workgroups share a CU)");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 2, wj = wave & 3;                       // 2 (i) x 4 (j) waves: wave tile 64 x 32
     const int l15 = lane & 15, g4 = lane >> 4;
@@ -650,7 +650,7 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
             rider_wgs = (blocks + 1) / 2;
         } else lpr = 0;
     }
-    const int stages = tun.tn_pipe_stages == 3 ? 3 : tun.tn_pipe_stages == 5 ? 5 : 4;
+    const int stages = tun.tn_pipe_stages == 3 ? 3 : tun.tn_pipe_stages == 5 ? 5 : tun.tn_pipe_stages == 2 ? 2 : 4;
 #define TNP_GO(S_)                                                                  \
     do {                                                                            \
         if (lpr == 64) tnp_launch<S_, 64>(g, r, rider_wgs, st);                     \
@@ -658,7 +658,7 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
         else if (lpr == 16) tnp_launch<S_, 16>(g, r, rider_wgs, st);                \
         else tnp_launch<S_, 0>(g, r, 0, st);                                        \
     } while (0)
-    if (stages == 3) TNP_GO(3); else if (stages == 5) TNP_GO(5); else TNP_GO(4);
+    if (stages == 3) TNP_GO(3); else if (stages == 5) TNP_GO(5); else if (stages == 2) TNP_GO(2); else TNP_GO(4);
 #undef TNP_GO
     if (any_pieces) {
         int max_ns = 1;
