@@ -76,7 +76,20 @@ SHAPES = [
 ]
 
 
+# the same layer shapes at batch 4 (3600 rows) and in the video workload's stage 2 (4608 rows): the rows the ring-depth rule of the second session of round 5 changed
+# (`python tools/gemm_yardstick.py b4`; LAVT_PROBE=0,0,0,0,0,0,0,600 gives the old rule)
+SHAPES_B4 = [
+    ("fc1 s2 fwd b4", "nt", 3600, 2048, 512, 18), ("fc2 s2 fwd b4", "nt", 3600, 512, 2048, 18), ("proj s2 fwd b4", "nt", 3600, 512, 512, 18),
+    ("d-fc2 s2 b4", "ntk", 3600, 2048, 512, 18), ("d-fc1 s2 b4", "ntk", 3600, 512, 2048, 18), ("d-qkv s2 b4", "ntk", 3600, 512, 1536, 18),
+    ("fc1 s2 fwd video", "nt", 4608, 2048, 512, 18), ("fc2 s2 fwd video", "nt", 4608, 512, 2048, 18), ("d-fc2 s2 video", "ntk", 4608, 2048, 512, 18), ("qkv s2 video (unfused)", "nt", 6272, 1536, 512, 18),
+    ("fc1 s1 fwd b4", "nt", 14400, 1024, 256, 2), ("fc1 s0 fwd b4", "nt", 57600, 512, 128, 2),
+]
+
+
 def main():
+    global SHAPES
+    if len(sys.argv) > 1 and sys.argv[1] == "b4":
+        SHAPES = SHAPES_B4
     print(f"# {torch.cuda.get_device_name(0)}; torch {torch.__version__}; nominal bf16 dense peak {PEAK:.0f} TFLOP/s")
     print(f"# {'shape':32s} {'kind':4s} {'M/I':>6s} {'N/J':>6s} {'K':>6s} | {'own us':>8s} {'TF/s':>7s} {'of peak':>7s} | {'vendor us':>9s} {'TF/s':>7s} {'of peak':>7s} | own/vendor time")
     tot_own = tot_ven = 0.0
