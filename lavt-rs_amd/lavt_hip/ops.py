@@ -270,11 +270,12 @@ class _Fp8State:
         i = self.slot(key, device)
         return self.prev.data_ptr() + 4 * i, self.cur.data_ptr() + 4 * i
 
+    # (an entry holds its tensor: the address cannot be handed to another tensor while the entry lives -- until it is picked up, or advance() at the next step)
     def put_twin(self, y, q, a_ptr):
-        self.twins[(y.data_ptr(), y.numel())] = (q, a_ptr)
+        self.twins[(y.data_ptr(), y.numel())] = (q, a_ptr, y)
 
     def put_dy_amax(self, dx, a_ptr):
-        self.dy_amax[(dx.data_ptr(), dx.numel())] = a_ptr
+        self.dy_amax[(dx.data_ptr(), dx.numel())] = (a_ptr, dx)
 
     def quantize(self, x, key):
         """bf16 activation rows -> (uint8 e4m3 tensor of the same shape, pointer of the amax float it was scaled by)"""
@@ -282,7 +283,7 @@ class _Fp8State:
         x = x.contiguous()
         tw = self.twins.pop((x.data_ptr(), x.numel()), None)
         if tw is not None and tw[1] == self.prev.data_ptr() + 4 * i and tw[0].shape == x.shape:
-            return tw          # the producing kernel wrote the twin against this site's scale (lavt_norm_apply_q8 / lavt_bilinear_fwd_q8): no launch
+            return tw[0], tw[1]          # the producing kernel wrote the twin against this site's scale (lavt_norm_apply_q8 / lavt_bilinear_fwd_q8): no launch
         q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
         K.check(K.lib.lavt_fp8_quantize(K.dt(x.dtype), K.ptr(x), K.ptr(q), x.numel(), self.prev.data_ptr() + 4 * i, self.cur.data_ptr() + 4 * i, K.stream()))
         return q, self.prev.data_ptr() + 4 * i
@@ -294,7 +295,8 @@ class _Fp8State:
         i = self.slot(key, x.device)
         x = x.contiguous()
         q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-        a_ptr = self.dy_amax.pop((x.data_ptr(), x.numel()), None)
+        ent = self.dy_amax.pop((x.data_ptr(), x.numel()), None)
+        a_ptr = ent[0] if ent is not None else None
         if a_ptr is not None:
             # the kernel that produced x recorded its |max| (lavt_norm_bwd_apply_amax, into the site's `cur` slot: advance() zeroes it): one pass instead of two
             K.check(K.lib.lavt_fp8_quantize(K.dt(x.dtype), K.ptr(x), K.ptr(q), x.numel(), a_ptr, None, K.stream()))

@@ -1351,7 +1351,7 @@ def test_fp8_twins_written_by_producers_equal_the_quantiser(monkeypatch):
         for it in range(2):                                                  # second pass: calibrated scale
             ops.fp8.advance()
             up = ops.bilinear(x.to(dev()), B, Hi, Hi, H, H, fp8_site=site)
-            q_up, a_up = ops.fp8.twins[(up.data_ptr(), up.numel())]
+            q_up, a_up = ops.fp8.twins[(up.data_ptr(), up.numel())][:2]
             got = ops.fp8.quantize(up, site)
             assert got[0] is q_up and not ops.fp8.twins                     # picked up, no second quantisation
         amax_up = float(up.float().abs().max())
@@ -1364,11 +1364,11 @@ def test_fp8_twins_written_by_producers_equal_the_quantiser(monkeypatch):
             ops.fp8.advance()
             xin = up.detach().clone().requires_grad_(True)
             y = ops.batch_norm_relu(xin, bn, fp8_site=site, fp8_dy_site=dsite)
-            q_y, _ = ops.fp8.twins.pop((y.data_ptr(), y.numel()))
+            q_y = ops.fp8.twins.pop((y.data_ptr(), y.numel()))[0]
             dy = (rnd(B * H * H, C, seed=9) * 1e-3).to(torch.bfloat16).to(dev())
             dx, = torch.autograd.grad(y, xin, dy)
         assert torch.equal(q_y.cpu(), F8.quantize_bytes(y.detach().cpu(), float(y.detach().float().abs().max())))
-        a_ptr = ops.fp8.dy_amax[(dx.data_ptr(), dx.numel())]
+        a_ptr = ops.fp8.dy_amax[(dx.data_ptr(), dx.numel())][0]
         i = ops.fp8.slots[dsite]
         assert a_ptr == ops.fp8.cur.data_ptr() + 4 * i
         assert float(ops.fp8.cur[i]) == float(dx.float().abs().max())
