@@ -4,7 +4,7 @@ usage: pmc_summary.py <gpurun_out/r02_pmc> <out.json>"""
 import csv, glob, json, os, sys
 root, out = sys.argv[1], sys.argv[2]
 TARGET = {"conv_one": ["gemm_nt_pipe_kernel<256, 256, false, 2, 2, 2"], "wgrad_group_one": ["gemm_tn_pipe_kernel", "gemm_tn_v2_grouped"],
-          "attn_one": ["wattn_bwd_mfma", "wattn_fwd_mfma"], "wmsa_one": ["wmsa_fwd_fused_kernel"], "conv_wgrad_one": ["conv_wgrad3x3_kernel"], "conv_wgrad_f8_one": ["conv_wgrad3x3_f8_kernel"],
+          "attn_one": ["wattn_bwd_mfma", "wattn_fwd_mfma"], "wmsa_one": ["wmsa_fwd_fused_kernel"], "conv_wgrad_one": ["conv_wgrad3x3_kernel"], "conv_wgrad_f8_one": ["conv_wgrad3x3_f8_kernel"], "gemm_b4_one": ["gemm_nt_v2_kernel<128, 128"],
           "conv_fp8_one": ["gemm_nt_pipe_kernel<256, 256, false, 2, 2, 2, true"]}
 
 
