@@ -427,3 +427,37 @@ def test_image_transforms():
     assert torch.allclose(x, (ref - mean) / std, atol=1e-6)
     same, _ = T.Resize(37, 53)(img, None)
     assert np.array_equal(np.asarray(same), np.asarray(img))
+
+
+def test_fp8_twin_registry_and_sites_host_logic():
+    """configs[4] host bookkeeping (lavt_hip/ops.py, no kernel launch): which convolutions get a quantisation site (fp8_act_site / fp8_dy_site follow the
+    convolution's own fp8 conditions), a producer-written twin is picked up exactly once by the site it was written for, a twin of another site or shape is
+    not, entries keep their tensor alive (no address re-use while they live), advance() forgets them, and in bf16 mode nothing asks for a site."""
+    import lavt_hip
+    from lavt_hip import ops
+    w = torch.nn.Parameter(torch.zeros(512, 640, 3, 3))
+    assert ops.fp8_act_site(w, 57600, 512, 128) is None and ops.fp8_dy_site(w, 57600, 512) is None          # bf16 mode
+    st = ops._Fp8State()
+    with lavt_hip.use_dtype("fp8"):
+        assert ops.fp8_act_site(w, 57600, 512, 128) == id(w)                       # 450 x 4 tiles: fills the chip
+        assert ops.fp8_act_site(w, 3600, 512, 128) is None                         # decoder level 4: 29 x 4 tiles stay bf16
+        assert ops.fp8_act_site(w, 57600, 520, 128) is None                        # channels % 16
+        assert ops.fp8_dy_site(w, 57600, 512) == (id(w), "dy") and ops.fp8_dy_site(w, 1800, 512) is None
+        y = torch.zeros(64, 32, dtype=torch.bfloat16)
+        q = torch.zeros(64, 32, dtype=torch.uint8)
+        a_prev, a_cur = st.site_ptrs("site", y.device)
+        assert a_cur != a_prev and st.site_ptrs("site", y.device) == (a_prev, a_cur)
+        st.put_twin(y, q, a_prev)
+        assert st.twins[(y.data_ptr(), y.numel())][2] is y                          # the entry holds the tensor
+        got = st.quantize(y, "site")
+        assert got[0] is q and got[1] == a_prev and not st.twins                    # picked up: no launch (a launch on CPU tensors would raise)
+        st.put_twin(y, q, a_prev)
+        with pytest.raises(RuntimeError):                                           # another site's scale: the twin is dropped and the quantiser must run -> refuses CPU memory
+            st.quantize(y, "other site")
+        assert not st.twins
+        st.put_twin(y, q, a_prev)
+        st.put_dy_amax(y, a_cur)
+        assert st.twins and st.dy_amax
+        st.slots.clear()                                                            # (no sites: advance() then launches nothing -- the roll-over kernel itself is a GPU test)
+        st.advance()
+        assert not st.twins and not st.dy_amax
