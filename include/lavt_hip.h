@@ -461,6 +461,13 @@ int lavt_wmsa_fwd_rider(const void* x, const int32_t* wmap, const void* Wg, cons
  * ------------------------------------------------------------------------------------------- */
 int lavt_pwam_words_fwd(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
                         void* P, int B, int T, int C, int n_l, float alpha, void* stream);
+/* ABI v7: the same launch also leaves the second moments of the word probabilities -- rec [B][lavt_pwam_words_records(B, T, C)][1056] floats of
+ * scratch, counters [B] (unsigned, zero before the first launch, left zero), cov [B][32][32] = Cov_T(P), pbar [B][32] = mean_T(P) -- summed over the
+ * workgroups' records in a fixed order by the last workgroup of a sample to finish (csrc/arrive.h): replaces the P^T P launch, its reduction and the
+ * statistics half of lavt_pwam_lang_fwd.  rec == NULL: as lavt_pwam_words_fwd. */
+int lavt_pwam_words_fwd_moments(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
+                                void* P, float* rec, unsigned* counters, float* cov, float* pbar, int B, int T, int C, int n_l, float alpha, void* stream);
+int lavt_pwam_words_records(int B, int T, int C);
 int lavt_pwam_words_bwd(const void* dwhat, int64_t ldx, const void* VWw, const float* Qp, const float* pbar, const void* P,
                         void* dS, int B, int T, int C, void* stream);
 int lavt_pwam_q_parts(int C); /* records per sample in Qp: [B][records][1024 Q | 32 u] floats, written by lavt_pwam_lang_bwd1, summed in fixed order by lavt_pwam_words_bwd */

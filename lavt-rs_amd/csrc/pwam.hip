@@ -16,6 +16,7 @@
 // and three tiny language-side kernels on [32 x C] / [32 x 32] matrices.  tools/pwam_algebra_check.py proves the algebra against autograd.
 #include <stdlib.h>
 
+#include "arrive.h"
 #include "common.h"
 
 namespace {
@@ -27,6 +28,7 @@ __device__ __forceinline__ bf16x8 lds8(const bf16* p) { return *reinterpret_cast
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
 __device__ __forceinline__ float bf16_round(float v) { return (float)(bf16)v; }
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p; }
 
 // A lane of a C^T accumulator pair holds, for ONE row, elements 4g .. 4g+3 of a 16-wide tile (p0) and the same of the next tile (p1), g = lane / 16.
 // Lanes g and g ^ 1 swap one packed quadruple so that every lane moves 16 contiguous bytes (64 contiguous bytes per row and wave-instruction).
@@ -68,17 +70,28 @@ struct WordsArgs {
     bf16* out;            // [B*T][32]
     int T, C, n_l;
     float alpha;
+    // forward by-product (rec != null): the second moments of the word probabilities.  Every workgroup leaves [1024 P^T P | 32 colsum(P)] of ITS rows in
+    // rec[B][gridDim.x][1056]; the last workgroup of a sample to arrive (arrive.h) adds the records in index order and writes Cov_T(P), Pbar.
+    float* rec;
+    unsigned* counters;   // [B], zero between launches
+    float* cov_out;       // [B][32][32]
+    float* pbar_out;      // [B][32]
 };
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+typedef unsigned long long u64_t;
 
-template <bool BWD>
-__global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
+template <bool BWD, int NT, int PRE>
+__global__ __launch_bounds__(NT) void pwam_words_kernel(const WordsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NW = NT / 64;
     const int C = a.C, LDW = C + 8;
-    bf16* Wm = reinterpret_cast<bf16*>(smem_raw);                   // [32][LDW]
+    int* const s_flag = reinterpret_cast<int*>(smem_raw);           // (16 bytes in front of everything: never aliased by the reduction scratch)
+    bf16* Wm = reinterpret_cast<bf16*>(smem_raw + 16);              // [32][LDW]
     float* vec = reinterpret_cast<float*>(Wm + 32 * LDW);           // [32]
     bf16* Qn = reinterpret_cast<bf16*>(vec + 32);                   // backward: -Q as bf16 [32][40]
     float* meanS = reinterpret_cast<float*>(Qn + 32 * 40);          // forward: mu_q of this sample [C]
     float* rstdS = meanS + C;                                       // forward: rstd_q of this sample [C]
+    bf16* Pt = reinterpret_cast<bf16*>(rstdS + C);                  // forward by-product: [NW][16 rows][32 words], a wave's P tile for the transposing reads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int b = blockIdx.y;
 
@@ -88,12 +101,11 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
     // ones of the same shape, the 8-workgroup launch of the last stage 20 us for 2 us of rows).
     const int ntiles = (a.T + 15) >> 4;
     const int ksteps = C >> 5;
-    constexpr int PRE = 16;
     bf16x8 xpre[PRE] = {};
     bf16x8 pf_pre = {};
     uint2 p0_pre = make_uint2(0u, 0u), p1_pre = make_uint2(0u, 0u);
     {
-        const int tile = min((int)blockIdx.x * 4 + wave, ntiles - 1);
+        const int tile = min((int)blockIdx.x * NW + wave, ntiles - 1);
         const int64_t row = (int64_t)b * a.T + min(tile * 16 + c16, a.T - 1);
         const bf16* xp = a.X + row * a.ldx + 8 * g;
 #pragma unroll
@@ -108,12 +120,12 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
     float uj_pre = 0.f, pb_pre[4] = {0.f, 0.f, 0.f, 0.f}, mb_pre = 0.f;
     float4 mean_pre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, rstd_pre[2] = {mean_pre[0], mean_pre[0]};
     if constexpr (!BWD) {
-        mb_pre = a.vec[b * 32 + (tid >> 3)];
+        mb_pre = a.vec[b * 32 + ((tid & 255) >> 3)];
 #pragma unroll
         for (int i = 0; i < 2; ++i)          // (C <= 2048: two float4 per thread)
-            if (tid + 256 * i < (C >> 2)) {
-                mean_pre[i] = *reinterpret_cast<const float4*>(a.mean + (int64_t)b * C + 4 * (tid + 256 * i));
-                rstd_pre[i] = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + 4 * (tid + 256 * i));
+            if (tid + NT * i < (C >> 2)) {
+                mean_pre[i] = *reinterpret_cast<const float4*>(a.mean + (int64_t)b * C + 4 * (tid + NT * i));
+                rstd_pre[i] = *reinterpret_cast<const float4*>(a.rstd + (int64_t)b * C + 4 * (tid + NT * i));
             }
     } else {
         const int j = tid >> 3, part = tid & 7;
@@ -141,15 +153,15 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
     // (sixteen chunks per thread per pass = one pass at C = 1024, every load issued before the first use: as a one-chunk loop the 32 x 1024 matrix of
     // the last stage was a chain of 16 exposed round trips per thread -- 22 us for a launch whose rows take 2.  Forward: rstd_q and mu_q travel with
     // the first pass in registers, are parked in LDS, and the chunks are scaled behind ONE barrier -- as global loads per chunk they halved the pass.)
-    constexpr int UW = 16;
-    for (int base = 0; base < 32 * nch; base += 256 * UW) {          // (uniform trip count: the forward pass holds a barrier)
+    constexpr int UW = NT == 256 ? 16 : 2;          // (the 1024-thread form serves C <= 256: 1024 chunks)
+    for (int base = 0; base < 32 * nch; base += NT * UW) {          // (uniform trip count: the forward pass holds a barrier)
         const int e0 = base + tid;
         uint4 raw[UW];
         // (loads unconditional on a clamped chunk index, only the LDS store below is predicated: with the loads under `if (e < ...)` hipcc kept raw[] in
         // scratch -- 144 bytes per lane, eight scratch round trips at the head of the kernel)
 #pragma unroll
         for (int u = 0; u < UW; ++u) {
-            const int e = min(e0 + 256 * u, 32 * nch - 1);
+            const int e = min(e0 + NT * u, 32 * nch - 1);
             const int j = e / nch, cc = e - j * nch;
             raw[u] = *reinterpret_cast<const uint4*>(a.Wsrc + ((int64_t)b * 32 + j) * a.ldw + cc * 8);
         }
@@ -157,16 +169,16 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
             if (base == 0) {                          // (first pass, every thread)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    if (tid + 256 * i < (C >> 2)) {
-                        *reinterpret_cast<float4*>(meanS + 4 * (tid + 256 * i)) = mean_pre[i];
-                        *reinterpret_cast<float4*>(rstdS + 4 * (tid + 256 * i)) = rstd_pre[i];
+                    if (tid + NT * i < (C >> 2)) {
+                        *reinterpret_cast<float4*>(meanS + 4 * (tid + NT * i)) = mean_pre[i];
+                        *reinterpret_cast<float4*>(rstdS + 4 * (tid + NT * i)) = rstd_pre[i];
                     }
                 __syncthreads();
             }
         }
 #pragma unroll
         for (int u = 0; u < UW; ++u) {
-            const int e = e0 + 256 * u;
+            const int e = e0 + NT * u;
             uint4 val = raw[u];
             if (e < 32 * nch) {
                 const int j = e / nch, cc = e - j * nch;
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
         }
     }
     __syncthreads();
-    {
+    if (NT == 256 || tid < 256) {
         const int j = tid >> 3, part = tid & 7;
         float s = 0.f;
         if constexpr (!BWD) {
@@ -220,8 +232,12 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
     }
     __syncthreads();
 
+    // forward by-product accumulators: P^T P as 2 x 2 tiles of 16 x 16 words (D layout: row = word 4g + r, column = word c16) and colsum(P) (P^T 1)
+    f32x4 pp[2][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
+    f32x4 ps[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const bool moments = !BWD && a.rec != nullptr;
     bool first = true;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    for (int tile = blockIdx.x * NW + wave; tile < ntiles; tile += gridDim.x * NW) {
         const int t = tile * 16 + c16;
         const bool vr = t < a.T;
         const int64_t row = (int64_t)b * a.T + (vr ? t : a.T - 1);
@@ -315,6 +331,64 @@ __global__ __launch_bounds__(256) void pwam_words_kernel(const WordsArgs a) {
             for (int r = 0; r < 4; ++r) { o0[r] = p0[r] * (o0[r] - dot); o1[r] = p1[r] * (o1[r] - dot); }
         }
         store_pair16(a.out + row * 32, g, pack4(o0), pack4(o1), vr);
+        if constexpr (!BWD) {
+            if (moments) {          // (wave-uniform: the transposing reads need every lane)
+                // P^T P sums over the ROWS, which sit on the lanes of the S^T accumulators: one transpose through a 1 KB LDS image per wave.  The
+                // image holds the bf16 values that were stored (rows beyond T as zeros); lane 4q + p of a 16-lane group addresses row 4g + q,
+                // words 4p .. 4p + 3 of a word tile and receives word c16 of rows 4g .. 4g + 3: the A and the B fragment of v_mfma_f32_16x16x16_bf16.
+                bf16* pt = Pt + wave * 512;
+                const uint2 q0 = vr ? pack4(o0) : make_uint2(0u, 0u), q1 = vr ? pack4(o1) : make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(pt + c16 * 32 + 4 * g) = q0;
+                *reinterpret_cast<uint2*>(pt + c16 * 32 + 16 + 4 * g) = q1;
+                const unsigned ad = lds_addr(pt + (4 * g + (c16 >> 2)) * 32 + 4 * (c16 & 3));
+                u64_t t0, t1;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(t0), "=&v"(t1) : "v"(ad) : "memory");
+                const s16x4 f0 = __builtin_bit_cast(s16x4, t0), f1 = __builtin_bit_cast(s16x4, t1);
+                const s16x4 one4 = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
+                pp[0][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f0, f0, pp[0][0], 0, 0, 0);
+                pp[0][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f0, f1, pp[0][1], 0, 0, 0);
+                pp[1][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f1, f0, pp[1][0], 0, 0, 0);
+                pp[1][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f1, f1, pp[1][1], 0, 0, 0);
+                ps[0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f0, one4, ps[0], 0, 0, 0);
+                ps[1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f1, one4, ps[1], 0, 0, 0);
+            }
+        }
+    }
+    if constexpr (!BWD) {
+        if (moments) {
+            // this workgroup's record: waves in LDS (the word matrix is dead), summed in wave order, stored plainly
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem_raw + 16);          // [NW][1056]
+            float* mine = red + wave * 1056;
+#pragma unroll
+            for (int wa = 0; wa < 2; ++wa)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * wa + 4 * g + r;
+                    mine[m * 32 + c16] = pp[wa][0][r];
+                    mine[m * 32 + 16 + c16] = pp[wa][1][r];
+                    if (c16 == 0) mine[1024 + m] = ps[wa][r];
+                }
+            __syncthreads();
+            float* recp = a.rec + ((int64_t)b * gridDim.x + blockIdx.x) * 1056;
+            for (int e = tid; e < 1056; e += NT) {
+                float s = red[e];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) s += red[w * 1056 + e];
+                recp[e] = s;
+            }
+            if (arrive_last(a.counters + b, gridDim.x, s_flag)) {
+                float4* red4 = reinterpret_cast<float4*>(smem_raw + 16);
+                float4* out4 = red4 + (NT / 256) * 264;
+                sum_records<NT, 2>(a.rec + (int64_t)b * gridDim.x * 1056, (int)gridDim.x, 1056, 264, red4, out4);
+                const float* tot = reinterpret_cast<const float*>(out4);
+                const float invT = 1.0f / (float)a.T;
+                for (int e = tid; e < 1024; e += NT)
+                    a.cov_out[(int64_t)b * 1024 + e] = tot[e] * invT - (tot[1024 + (e >> 5)] * invT) * (tot[1024 + (e & 31)] * invT);
+                if (tid < 32) a.pbar_out[b * 32 + tid] = tot[1024 + tid] * invT;
+            }
+        }
     }
 }
 
@@ -465,20 +539,26 @@ __global__ __launch_bounds__(256) void pwam_lang_fwd_kernel(const bf16* __restri
         wf[u] = ldg8(wp + 32 * ks); a0[u] = ldg8(vp0 + 32 * ks); a1[u] = ldg8(vp1 + 32 * ks);
     }
     // second-moment matrix and word means: 4 + 5 independent loads per thread, no LDS hop in between
-    float ppv[4], sj[4];
+    if (PP) {
+        float ppv[4], sj[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ppv[i] = PP[(int64_t)b * 1024 + tid + 256 * i]; sj[i] = sumP[b * 32 + (tid >> 5) + 8 * i]; }
-    const float sk = sumP[b * 32 + (tid & 31)];
+        for (int i = 0; i < 4; ++i) { ppv[i] = PP[(int64_t)b * 1024 + tid + 256 * i]; sj[i] = sumP[b * 32 + (tid >> 5) + 8 * i]; }
+        const float sk = sumP[b * 32 + (tid & 31)];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = tid + 256 * i;
-        const float cv = ppv[i] * invT - (sj[i] * invT) * (sk * invT);
-        cov[e >> 5][e & 31] = cv;
-        if (blockIdx.x == 0) cov_out[(int64_t)b * 1024 + e] = cv;
-    }
-    if (tid < 32) {
-        pb[tid] = sk * invT;
-        if (blockIdx.x == 0) pbar_out[b * 32 + tid] = sk * invT;
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            const float cv = ppv[i] * invT - (sj[i] * invT) * (sk * invT);
+            cov[e >> 5][e & 31] = cv;
+            if (blockIdx.x == 0) cov_out[(int64_t)b * 1024 + e] = cv;
+        }
+        if (tid < 32) {
+            pb[tid] = sk * invT;
+            if (blockIdx.x == 0) pbar_out[b * 32 + tid] = sk * invT;
+        }
+    } else {          // (ABI v7) Cov and Pbar were left by lavt_pwam_words_fwd_moments
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int e = tid + 256 * i; cov[e >> 5][e & 31] = cov_out[(int64_t)b * 1024 + e]; }
+        if (tid < 32) pb[tid] = pbar_out[b * 32 + tid];
     }
 #pragma unroll
     for (int u = 0; u < LF_MAXK; ++u)
@@ -621,8 +701,8 @@ __global__ __launch_bounds__(256) void pwam_lang_bwd2_kernel(const float* __rest
     for (int j = 0; j < 32; j += 8) *reinterpret_cast<uint4*>(dst + j) = f_to_chunk<bf16>(k2 + j);
 }
 
-int rows_grid(int tiles_per_sample, int B) {
-    int gx = (tiles_per_sample + 3) / 4;            // 4 waves, one tile each per pass
+int rows_grid(int tiles_per_sample, int B, int waves) {
+    int gx = (tiles_per_sample + waves - 1) / waves;            // one tile per wave per pass
     const int cap = 1024 / (B > 0 ? B : 1);
     if (gx > cap) gx = cap;
     return gx < 1 ? 1 : gx;
@@ -637,20 +717,48 @@ int rows_grid(int tiles_per_sample, int B) {
 // trips each instead of eight -- every trip is a barrier-separated round of loads -- and the consumer sums the records eight at a time)
 extern "C" int lavt_pwam_q_parts(int C) { const int n = C / 16; return n < 16 ? (n < 1 ? 1 : n) : 16; }
 
-extern "C" int lavt_pwam_words_fwd(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
-                                   void* P, int B, int T, int C, int n_l, float alpha, void* stream) {
-    LAVT_CHECK_ARG(q && K && mean && rstd && maskbias && P && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && C <= 2048 && n_l > 0 && n_l <= 32 && ldq % 8 == 0 && ldk % 8 == 0,
-                   "lavt_pwam_words_fwd: bad arguments (C %% 32 == 0, C <= 2048, 1 <= n_l <= 32, 16-byte aligned rows)");
-    WordsArgs a{};
-    a.X = (const bf16*)q; a.ldx = ldq; a.Wsrc = (const bf16*)K; a.ldw = ldk; a.mean = mean; a.rstd = rstd; a.vec = maskbias; a.out = (bf16*)P;
-    a.T = T; a.C = C; a.n_l = n_l; a.alpha = alpha;
-    const size_t lds = (size_t)32 * (C + 8) * 2 + 128 + 32 * 40 * 2 + (size_t)C * 8;
+// LDS of the words kernels: 16 (arrival flag) + word matrix + per-word constants + -Q + the q statistics + a 1 KB transposition image per wave; the
+// forward's reduction scratch ([waves][1056] floats, then the record sums) aliases it from byte 16 on
+static size_t words_lds(int C, int nt, bool moments) {
+    const size_t base = 16 + (size_t)32 * (C + 8) * 2 + 128 + 32 * 40 * 2 + (size_t)C * 8 + (size_t)(nt / 64) * 1024;
+    const size_t red = 16 + (size_t)(nt / 64) * 1056 * 4 + 64;
+    return moments && red > base ? red : base;
+}
+template <int NT, int PRE> static int launch_words_fwd(const WordsArgs& a, int B, size_t lds, hipStream_t st) {
     static size_t reserved = 0;
     if (lds > 65536 && lds > reserved) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pwam_words_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { lavt_set_error("lavt_pwam_words_fwd: cannot reserve LDS"); return LAVT_ERR_LAUNCH; }
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pwam_words_kernel<false, NT, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { lavt_set_error("lavt_pwam_words_fwd: cannot reserve LDS"); return LAVT_ERR_LAUNCH; }
         reserved = lds;
     }
-    hipLaunchKernelGGL(pwam_words_kernel<false>, dim3(rows_grid((T + 15) / 16, B), B), dim3(256), lds, ST, a);
+    int gx = rows_grid((a.T + 15) / 16, B, NT / 64);
+    if (a.rec && gx > 64) gx = 64;                    // (records per sample the last arriver adds: the waves walk further instead)
+    hipLaunchKernelGGL((pwam_words_kernel<false, NT, PRE>), dim3(gx, B), dim3(NT), lds, st, a);
+    return LAVT_OK;
+}
+// 1024-thread workgroups where 256-thread ones would leave more than 64 records per sample for the last arriver (C <= 256: registers, one pass of the word matrix)
+static int words_fwd_threads(int T, int C, int B) { return (C <= 256 && rows_grid((T + 15) / 16, B, 4) > 64) ? 1024 : 256; }
+extern "C" int lavt_pwam_words_records(int B, int T, int C) {
+    const int gx = rows_grid((T + 15) / 16, B, words_fwd_threads(T, C, B) / 64);
+    return gx > 64 ? 64 : gx;
+}
+
+extern "C" int lavt_pwam_words_fwd(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
+                                   void* P, int B, int T, int C, int n_l, float alpha, void* stream) {
+    return lavt_pwam_words_fwd_moments(q, ldq, K, ldk, mean, rstd, maskbias, P, nullptr, nullptr, nullptr, nullptr, B, T, C, n_l, alpha, stream);
+}
+
+extern "C" int lavt_pwam_words_fwd_moments(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
+                                           void* P, float* rec, unsigned* counters, float* cov, float* pbar, int B, int T, int C, int n_l, float alpha, void* stream) {
+    LAVT_CHECK_ARG(q && K && mean && rstd && maskbias && P && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && C <= 2048 && n_l > 0 && n_l <= 32 && ldq % 8 == 0 && ldk % 8 == 0,
+                   "lavt_pwam_words_fwd: bad arguments (C %% 32 == 0, C <= 2048, 1 <= n_l <= 32, 16-byte aligned rows)");
+    LAVT_CHECK_ARG(!rec || (counters && cov && pbar), "lavt_pwam_words_fwd_moments: records need counters, cov and pbar");
+    WordsArgs a{};
+    a.X = (const bf16*)q; a.ldx = ldq; a.Wsrc = (const bf16*)K; a.ldw = ldk; a.mean = mean; a.rstd = rstd; a.vec = maskbias; a.out = (bf16*)P;
+    a.T = T; a.C = C; a.n_l = n_l; a.alpha = alpha; a.rec = rec; a.counters = counters; a.cov_out = cov; a.pbar_out = pbar;
+    const int nt = rec ? words_fwd_threads(T, C, B) : 256;
+    const size_t lds = words_lds(C, nt, rec != nullptr);
+    const int rc = nt == 1024 ? launch_words_fwd<1024, 8>(a, B, lds, ST) : launch_words_fwd<256, 16>(a, B, lds, ST);
+    if (rc != LAVT_OK) return rc;
     LAVT_CHECK_LAUNCH("lavt_pwam_words_fwd");
     return LAVT_OK;
 }
@@ -661,13 +769,13 @@ extern "C" int lavt_pwam_words_bwd(const void* dwhat, int64_t ldx, const void* V
     WordsArgs a{};
     a.X = (const bf16*)dwhat; a.ldx = ldx; a.Wsrc = (const bf16*)VWw; a.ldw = C; a.Qf = Qp; a.pbar = pbar; a.P = (const bf16*)P; a.out = (bf16*)dS;
     a.T = T; a.C = C; a.n_l = lavt_pwam_q_parts(C); a.alpha = 1.f;
-    const size_t lds = (size_t)32 * (C + 8) * 2 + 128 + 32 * 40 * 2 + (size_t)C * 8;
+    const size_t lds = words_lds(C, 256, false);
     static size_t reserved = 0;
     if (lds > 65536 && lds > reserved) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pwam_words_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { lavt_set_error("lavt_pwam_words_bwd: cannot reserve LDS"); return LAVT_ERR_LAUNCH; }
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pwam_words_kernel<true, 256, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { lavt_set_error("lavt_pwam_words_bwd: cannot reserve LDS"); return LAVT_ERR_LAUNCH; }
         reserved = lds;
     }
-    hipLaunchKernelGGL(pwam_words_kernel<true>, dim3(rows_grid((T + 15) / 16, B), B), dim3(256), lds, ST, a);
+    hipLaunchKernelGGL((pwam_words_kernel<true, 256, 16>), dim3(rows_grid((T + 15) / 16, B, 4), B), dim3(256), lds, ST, a);
     LAVT_CHECK_LAUNCH("lavt_pwam_words_bwd");
     return LAVT_OK;
 }
@@ -690,7 +798,7 @@ extern "C" int lavt_pwam_mix(int mode, const void* Wd, const void* Wc, const flo
 
 extern "C" int lavt_pwam_lang_fwd(const void* V, int64_t ldv, const void* Wo, const float* PP, const float* sumP, void* VWc, void* VWw, float* beta, float* rw,
                                   float* pbar, float* cov, int B, int T, int C, float eps, void* stream) {
-    LAVT_CHECK_ARG(V && Wo && PP && sumP && VWc && VWw && beta && rw && pbar && cov && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && ldv % 8 == 0, "lavt_pwam_lang_fwd: bad arguments");
+    LAVT_CHECK_ARG(V && Wo && (PP == nullptr || sumP) && VWc && VWw && beta && rw && pbar && cov && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && ldv % 8 == 0, "lavt_pwam_lang_fwd: bad arguments");
     hipLaunchKernelGGL(pwam_lang_fwd_kernel, dim3(cdiv(C, 16), B), dim3(256), 0, ST, (const bf16*)V, ldv, (const bf16*)Wo, PP, sumP, (bf16*)VWc, (bf16*)VWw, beta, rw, pbar, cov, T, C, eps);
     LAVT_CHECK_LAUNCH("lavt_pwam_lang_fwd");
     return LAVT_OK;

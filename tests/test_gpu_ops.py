@@ -1627,3 +1627,60 @@ def test_droppath_draw_on_device():
         torch.cuda.synchronize()
         out.append(fg.clone())
     assert not torch.equal(out[0], out[1]), "a replay must draw fresh factors"
+
+
+# ------------------------------------------------------------------------------------------ PWAM in-launch hand-overs (round 6, csrc/arrive.h)
+def _pwam_words_ref(q, k, mean, rstd, maskbias, n_l, alpha):
+    """fp32 statement of lavt_pwam_words_fwd on the bf16 operands: softmax_{j < n_l}(alpha * IN(q) K^T + maskbias), lib/backbone.py:1349-1361"""
+    B, T, C = q.shape
+    qn = (q.float() - mean[:, None, :]) * rstd[:, None, :]
+    s = alpha * torch.einsum("btc,bjc->btj", qn, k.float()) + maskbias[:, None, :]
+    s[:, :, n_l:] = -float("inf")
+    return torch.softmax(s, dim=-1)
+
+
+@pytest.mark.parametrize("B,T,C,n_l", [(2, 14400, 128, 20), (2, 3600, 256, 13), (2, 900, 512, 20), (3, 225, 1024, 7), (2, 50, 64, 32), (4, 14400, 96, 20), (1, 40000, 128, 20)])
+def test_pwam_words_moments_by_product(B, T, C, n_l):
+    """lavt_pwam_words_fwd_moments: P as lavt_pwam_words_fwd writes it, and Cov_T(P) / Pbar equal to the fp32 moments of THAT bf16 P -- records of
+    1 .. 64 workgroups per sample, both workgroup sizes, rows that are no multiple of a tile; run-to-run identical, counters left at zero."""
+    from lavt_hip import _capi as K
+    d = dev()
+    bf = torch.bfloat16
+    q = (rnd(B, T, C, seed=1) * 1.5 + 0.3).to(bf).to(d)
+    k = torch.zeros(B, 32, C)
+    k[:, :n_l] = rnd(B, n_l, C, seed=2)
+    k = k.to(bf).to(d)
+    mean = q.float().mean(1)
+    rstd = (q.float().var(1, unbiased=False) + 1e-5).rsqrt()
+    mb = torch.zeros(B, 32)
+    mb[:, n_l:] = -1e4
+    mb[0, max(n_l - 3, 1):n_l] = -1e4              # masked words inside n_l: probability exactly zero rows / columns of the moments
+    mb = mb.to(d)
+    alpha = C ** -0.5
+    P0 = torch.empty(B * T, 32, dtype=bf, device=d)
+    K.check(K.lib.lavt_pwam_words_fwd(K.ptr(q), C, K.ptr(k), C, K.ptr(mean), K.ptr(rstd), K.ptr(mb), K.ptr(P0), B, T, C, n_l, alpha, K.stream()))
+    R = int(K.lib.lavt_pwam_words_records(B, T, C))
+    assert 1 <= R <= 64
+    counters = torch.zeros(64, dtype=torch.int32, device=d)
+    outs = []
+    for _ in range(3):
+        P = torch.empty_like(P0)
+        rec = torch.full((B * R * 1056,), float("nan"), device=d)
+        cov = torch.full((B, 32, 32), float("nan"), device=d)
+        pbar = torch.full((B, 32), float("nan"), device=d)
+        K.check(K.lib.lavt_pwam_words_fwd_moments(K.ptr(q), C, K.ptr(k), C, K.ptr(mean), K.ptr(rstd), K.ptr(mb), K.ptr(P), K.ptr(rec), K.ptr(counters),
+                                                  K.ptr(cov), K.ptr(pbar), B, T, C, n_l, alpha, K.stream()))
+        torch.cuda.synchronize()
+        assert int(counters.abs().sum()) == 0, "the last arriver leaves the counters at zero"
+        outs.append((P, cov, pbar))
+    P, cov, pbar = outs[0]
+    assert torch.equal(P, P0), "the by-product does not change P"
+    ref = _pwam_words_ref(q.cpu(), k.cpu(), mean.cpu(), rstd.cpu(), mb.cpu(), n_l, alpha)
+    assert_close(P.reshape(B, T, 32), ref, bf, "P", bf16=2e-2)
+    Pd = P.reshape(B, T, 32).double()
+    pb_ref = Pd.mean(1)
+    cov_ref = torch.einsum("btj,btk->bjk", Pd, Pd) / T - pb_ref[:, :, None] * pb_ref[:, None, :]
+    assert float((pbar.double() - pb_ref).abs().max()) <= 2e-6, "Pbar"
+    assert float((cov.double() - cov_ref).abs().max()) <= 3e-6 * max(1.0, float(cov_ref.abs().max()) * 1e3), f"Cov: {float((cov.double() - cov_ref).abs().max()):.3e}"
+    for P2, cov2, pbar2 in outs[1:]:
+        assert torch.equal(cov2, cov) and torch.equal(pbar2, pbar) and torch.equal(P2, P), "run-to-run identical (fixed summation order)"
