@@ -461,12 +461,11 @@ int lavt_wmsa_fwd_rider(const void* x, const int32_t* wmap, const void* Wg, cons
  * ------------------------------------------------------------------------------------------- */
 int lavt_pwam_words_fwd(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
                         void* P, int B, int T, int C, int n_l, float alpha, void* stream);
-/* ABI v7: the same launch also leaves the second moments of the word probabilities -- rec [B][lavt_pwam_words_records(B, T, C)][1056] floats of
- * scratch, counters [B] (unsigned, zero before the first launch, left zero), cov [B][32][32] = Cov_T(P), pbar [B][32] = mean_T(P) -- summed over the
- * workgroups' records in a fixed order by the last workgroup of a sample to finish (csrc/arrive.h): replaces the P^T P launch, its reduction and the
- * statistics half of lavt_pwam_lang_fwd.  rec == NULL: as lavt_pwam_words_fwd. */
+/* ABI v7: the same launch also leaves the second moments of the word probabilities as per-workgroup records -- rec [B][lavt_pwam_words_records(B, T, C)][1056]
+ * floats: [32][32] P^T P | [32] colsum(P) over the workgroup's rows (of the bf16 P it stored) -- which lavt_pwam_lang_fwd_records adds in index order:
+ * replaces the P^T P launch and its reduction launch.  rec == NULL: as lavt_pwam_words_fwd. */
 int lavt_pwam_words_fwd_moments(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
-                                void* P, float* rec, unsigned* counters, float* cov, float* pbar, int B, int T, int C, int n_l, float alpha, void* stream);
+                                void* P, float* rec, int B, int T, int C, int n_l, float alpha, void* stream);
 int lavt_pwam_words_records(int B, int T, int C);
 int lavt_pwam_words_bwd(const void* dwhat, int64_t ldx, const void* VWw, const float* Qp, const float* pbar, const void* P,
                         void* dS, int B, int T, int C, void* stream);
@@ -475,6 +474,9 @@ int lavt_pwam_mix(int mode, const void* Wd, const void* Wc, const float* v0, con
                   void* out0, int64_t ld0, void* out1, int64_t ld1, int B, int T, int C, void* stream);
 int lavt_pwam_lang_fwd(const void* V, int64_t ldv, const void* Wo, const float* PP, const float* sumP, void* VWc, void* VWw, float* beta, float* rw,
                        float* pbar, float* cov, int B, int T, int C, float eps, void* stream);
+/* ABI v7: lavt_pwam_lang_fwd with the moments given as records (PP == NULL): rec [B][nrec][1056] of lavt_pwam_words_fwd_moments */
+int lavt_pwam_lang_fwd_records(const void* V, int64_t ldv, const void* Wo, const float* PP, const float* sumP, const float* rec, int nrec, void* VWc, void* VWw,
+                               float* beta, float* rw, float* pbar, float* cov, int B, int T, int C, float eps, void* stream);
 int lavt_pwam_lang_bwd1(const float* HT, const float* s, const void* VWc, const float* rw, const float* pbar, const float* cov, void* dVW, float* Qp,
                         int B, int T, int C, void* stream);
 int lavt_pwam_lang_bwd2(const float* G, const float* sdS, const void* K, int64_t ldk, const float* mean, const float* rstd, void* dK, int64_t lddk, void* K2c,

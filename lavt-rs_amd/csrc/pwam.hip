@@ -16,7 +16,6 @@
 // and three tiny language-side kernels on [32 x C] / [32 x 32] matrices.  tools/pwam_algebra_check.py proves the algebra against autograd.
 #include <stdlib.h>
 
-#include "arrive.h"
 #include "common.h"
 
 namespace {
@@ -71,11 +70,8 @@ struct WordsArgs {
     int T, C, n_l;
     float alpha;
     // forward by-product (rec != null): the second moments of the word probabilities.  Every workgroup leaves [1024 P^T P | 32 colsum(P)] of ITS rows in
-    // rec[B][gridDim.x][1056]; the last workgroup of a sample to arrive (arrive.h) adds the records in index order and writes Cov_T(P), Pbar.
+    // rec[B][gridDim.x][1056]; the consumer (lavt_pwam_lang_fwd: a few workgroups per sample) adds the records in index order.
     float* rec;
-    unsigned* counters;   // [B], zero between launches
-    float* cov_out;       // [B][32][32]
-    float* pbar_out;      // [B][32]
 };
 typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
 typedef unsigned long long u64_t;
@@ -85,8 +81,7 @@ __global__ __launch_bounds__(NT) void pwam_words_kernel(const WordsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NW = NT / 64;
     const int C = a.C, LDW = C + 8;
-    int* const s_flag = reinterpret_cast<int*>(smem_raw);           // (16 bytes in front of everything: never aliased by the reduction scratch)
-    bf16* Wm = reinterpret_cast<bf16*>(smem_raw + 16);              // [32][LDW]
+    bf16* Wm = reinterpret_cast<bf16*>(smem_raw);                   // [32][LDW]
     float* vec = reinterpret_cast<float*>(Wm + 32 * LDW);           // [32]
     bf16* Qn = reinterpret_cast<bf16*>(vec + 32);                   // backward: -Q as bf16 [32][40]
     float* meanS = reinterpret_cast<float*>(Qn + 32 * 40);          // forward: mu_q of this sample [C]
@@ -359,7 +354,7 @@ __global__ __launch_bounds__(NT) void pwam_words_kernel(const WordsArgs a) {
         if (moments) {
             // this workgroup's record: waves in LDS (the word matrix is dead), summed in wave order, stored plainly
             __syncthreads();
-            float* red = reinterpret_cast<float*>(smem_raw + 16);          // [NW][1056]
+            float* red = reinterpret_cast<float*>(smem_raw);               // [NW][1056]
             float* mine = red + wave * 1056;
 #pragma unroll
             for (int wa = 0; wa < 2; ++wa)
@@ -377,16 +372,6 @@ __global__ __launch_bounds__(NT) void pwam_words_kernel(const WordsArgs a) {
 #pragma unroll
                 for (int w = 1; w < NW; ++w) s += red[w * 1056 + e];
                 recp[e] = s;
-            }
-            if (arrive_last(a.counters + b, gridDim.x, s_flag)) {
-                float4* red4 = reinterpret_cast<float4*>(smem_raw + 16);
-                float4* out4 = red4 + (NT / 256) * 264;
-                sum_records<NT, 2>(a.rec + (int64_t)b * gridDim.x * 1056, (int)gridDim.x, 1056, 264, red4, out4);
-                const float* tot = reinterpret_cast<const float*>(out4);
-                const float invT = 1.0f / (float)a.T;
-                for (int e = tid; e < 1024; e += NT)
-                    a.cov_out[(int64_t)b * 1024 + e] = tot[e] * invT - (tot[1024 + (e >> 5)] * invT) * (tot[1024 + (e & 31)] * invT);
-                if (tid < 32) a.pbar_out[b * 32 + tid] = tot[1024 + tid] * invT;
             }
         }
     }
@@ -511,10 +496,12 @@ __global__ __launch_bounds__(256) void pwam_mix_kernel(const MixArgs a) {
 // grid (C / 16, B), 256 threads: a workgroup owns 16 channels, its four waves a quarter of the reduction each (round 5: as 64 channels per workgroup
 // with the whole reduction in every wave the C = 1024 launch was 32 workgroups x 4 dependent rounds of cold loads of Wo -- 18 us; every load of a
 // wave is now one round, requested in front of everything else).
+constexpr int WORDS_MAX_RECORDS = 32;
 constexpr int LF_MAXK = 8;          // k-steps per wave held in registers per round (C <= 1024: one round)
 __global__ __launch_bounds__(256) void pwam_lang_fwd_kernel(const bf16* __restrict__ V, int64_t ldv, const bf16* __restrict__ Wo, const float* __restrict__ PP,
                                                             const float* __restrict__ sumP, bf16* __restrict__ VWc, bf16* __restrict__ VWw, float* __restrict__ beta,
-                                                            float* __restrict__ rw, float* __restrict__ pbar_out, float* __restrict__ cov_out, int T, int C, float eps) {
+                                                            float* __restrict__ rw, float* __restrict__ pbar_out, float* __restrict__ cov_out, int T, int C, float eps,
+                                                            const float* __restrict__ rec, int nrec) {
     __shared__ float part_vw[4][16][33];
     __shared__ float vw[16][33];
     __shared__ float cov[32][33];
@@ -555,10 +542,36 @@ __global__ __launch_bounds__(256) void pwam_lang_fwd_kernel(const bf16* __restri
             pb[tid] = sk * invT;
             if (blockIdx.x == 0) pbar_out[b * 32 + tid] = sk * invT;
         }
-    } else {          // (ABI v7) Cov and Pbar were left by lavt_pwam_words_fwd_moments
+    } else {
+        // (ABI v7) the second moments arrive as per-workgroup records of lavt_pwam_words_fwd_moments: [nrec][1024 P^T P | 32 colsum(P)] per sample, added here in
+        // index order (every workgroup of this launch repeats the sum: nrec x C / 16 record reads of 4 KB per sample, L2-resident -- no launch, no hand-over)
+        const float* rb = rec + (int64_t)b * nrec * 1056;
+        float4 pp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sp = 0.f;
+        for (int r0 = 0; r0 < nrec; r0 += 16) {
+            float4 v[16];
+            float w[16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int e = tid + 256 * i; cov[e >> 5][e & 31] = cov_out[(int64_t)b * 1024 + e]; }
-        if (tid < 32) pb[tid] = pbar_out[b * 32 + tid];
+            for (int u = 0; u < 16; ++u) {
+                const int r = min(r0 + u, nrec - 1);
+                v[u] = *reinterpret_cast<const float4*>(rb + (int64_t)r * 1056 + 4 * tid);
+                w[u] = rb[(int64_t)r * 1056 + 1024 + (tid & 31)];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (r0 + u < nrec) { pp4.x += v[u].x; pp4.y += v[u].y; pp4.z += v[u].z; pp4.w += v[u].w; sp += w[u]; }
+        }
+        if (tid < 32) pb[tid] = sp * invT;
+        __syncthreads();
+        const int j = tid >> 3, k0 = 4 * (tid & 7);          // float4 tid = row tid / 8, columns 4 (tid % 8) ..
+        const float pj = pb[j];
+        const float cv[4] = {pp4.x * invT - pj * pb[k0], pp4.y * invT - pj * pb[k0 + 1], pp4.z * invT - pj * pb[k0 + 2], pp4.w * invT - pj * pb[k0 + 3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cov[j][k0 + i] = cv[i];
+            if (blockIdx.x == 0) cov_out[(int64_t)b * 1024 + 4 * tid + i] = cv[i];
+        }
+        if (blockIdx.x == 0 && tid < 32) pbar_out[b * 32 + tid] = pb[tid];
     }
 #pragma unroll
     for (int u = 0; u < LF_MAXK; ++u)
@@ -717,11 +730,11 @@ int rows_grid(int tiles_per_sample, int B, int waves) {
 // trips each instead of eight -- every trip is a barrier-separated round of loads -- and the consumer sums the records eight at a time)
 extern "C" int lavt_pwam_q_parts(int C) { const int n = C / 16; return n < 16 ? (n < 1 ? 1 : n) : 16; }
 
-// LDS of the words kernels: 16 (arrival flag) + word matrix + per-word constants + -Q + the q statistics + a 1 KB transposition image per wave; the
-// forward's reduction scratch ([waves][1056] floats, then the record sums) aliases it from byte 16 on
+// LDS of the words kernels: word matrix + per-word constants + -Q + the q statistics + a 1 KB transposition image per wave; the forward's reduction
+// scratch ([waves][1056] floats) aliases it
 static size_t words_lds(int C, int nt, bool moments) {
-    const size_t base = 16 + (size_t)32 * (C + 8) * 2 + 128 + 32 * 40 * 2 + (size_t)C * 8 + (size_t)(nt / 64) * 1024;
-    const size_t red = 16 + (size_t)(nt / 64) * 1056 * 4 + 64;
+    const size_t base = (size_t)32 * (C + 8) * 2 + 128 + 32 * 40 * 2 + (size_t)C * 8 + (size_t)(nt / 64) * 1024;
+    const size_t red = (size_t)(nt / 64) * 1056 * 4;
     return moments && red > base ? red : base;
 }
 template <int NT, int PRE> static int launch_words_fwd(const WordsArgs& a, int B, size_t lds, hipStream_t st) {
@@ -731,30 +744,29 @@ template <int NT, int PRE> static int launch_words_fwd(const WordsArgs& a, int B
         reserved = lds;
     }
     int gx = rows_grid((a.T + 15) / 16, B, NT / 64);
-    if (a.rec && gx > 64) gx = 64;                    // (records per sample the last arriver adds: the waves walk further instead)
+    if (a.rec && gx > WORDS_MAX_RECORDS) gx = WORDS_MAX_RECORDS;          // (records per sample the consumer adds, 16 loads per round: the waves walk further instead)
     hipLaunchKernelGGL((pwam_words_kernel<false, NT, PRE>), dim3(gx, B), dim3(NT), lds, st, a);
     return LAVT_OK;
 }
-// 1024-thread workgroups where 256-thread ones would leave more than 64 records per sample for the last arriver (C <= 256: registers, one pass of the word matrix)
-static int words_fwd_threads(int T, int C, int B) { return (C <= 256 && rows_grid((T + 15) / 16, B, 4) > 64) ? 1024 : 256; }
+// 1024-thread workgroups where 256-thread ones would leave more than 16 records per sample for the consumer (C <= 256: registers, one pass of the word matrix)
+static int words_fwd_threads(int T, int C, int B) { return (C <= 256 && rows_grid((T + 15) / 16, B, 4) > 16) ? 1024 : 256; }
 extern "C" int lavt_pwam_words_records(int B, int T, int C) {
-    const int gx = rows_grid((T + 15) / 16, B, words_fwd_threads(T, C, B) / 64);
-    return gx > 64 ? 64 : gx;
+    const int nt = words_fwd_threads(T, C, B), gx = rows_grid((T + 15) / 16, B, nt / 64);
+    return gx > WORDS_MAX_RECORDS ? WORDS_MAX_RECORDS : gx;
 }
 
 extern "C" int lavt_pwam_words_fwd(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
                                    void* P, int B, int T, int C, int n_l, float alpha, void* stream) {
-    return lavt_pwam_words_fwd_moments(q, ldq, K, ldk, mean, rstd, maskbias, P, nullptr, nullptr, nullptr, nullptr, B, T, C, n_l, alpha, stream);
+    return lavt_pwam_words_fwd_moments(q, ldq, K, ldk, mean, rstd, maskbias, P, nullptr, B, T, C, n_l, alpha, stream);
 }
 
 extern "C" int lavt_pwam_words_fwd_moments(const void* q, int64_t ldq, const void* K, int64_t ldk, const float* mean, const float* rstd, const float* maskbias,
-                                           void* P, float* rec, unsigned* counters, float* cov, float* pbar, int B, int T, int C, int n_l, float alpha, void* stream) {
+                                           void* P, float* rec, int B, int T, int C, int n_l, float alpha, void* stream) {
     LAVT_CHECK_ARG(q && K && mean && rstd && maskbias && P && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && C <= 2048 && n_l > 0 && n_l <= 32 && ldq % 8 == 0 && ldk % 8 == 0,
                    "lavt_pwam_words_fwd: bad arguments (C %% 32 == 0, C <= 2048, 1 <= n_l <= 32, 16-byte aligned rows)");
-    LAVT_CHECK_ARG(!rec || (counters && cov && pbar), "lavt_pwam_words_fwd_moments: records need counters, cov and pbar");
     WordsArgs a{};
     a.X = (const bf16*)q; a.ldx = ldq; a.Wsrc = (const bf16*)K; a.ldw = ldk; a.mean = mean; a.rstd = rstd; a.vec = maskbias; a.out = (bf16*)P;
-    a.T = T; a.C = C; a.n_l = n_l; a.alpha = alpha; a.rec = rec; a.counters = counters; a.cov_out = cov; a.pbar_out = pbar;
+    a.T = T; a.C = C; a.n_l = n_l; a.alpha = alpha; a.rec = rec;
     const int nt = rec ? words_fwd_threads(T, C, B) : 256;
     const size_t lds = words_lds(C, nt, rec != nullptr);
     const int rc = nt == 1024 ? launch_words_fwd<1024, 8>(a, B, lds, ST) : launch_words_fwd<256, 16>(a, B, lds, ST);
@@ -798,8 +810,13 @@ extern "C" int lavt_pwam_mix(int mode, const void* Wd, const void* Wc, const flo
 
 extern "C" int lavt_pwam_lang_fwd(const void* V, int64_t ldv, const void* Wo, const float* PP, const float* sumP, void* VWc, void* VWw, float* beta, float* rw,
                                   float* pbar, float* cov, int B, int T, int C, float eps, void* stream) {
-    LAVT_CHECK_ARG(V && Wo && (PP == nullptr || sumP) && VWc && VWw && beta && rw && pbar && cov && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && ldv % 8 == 0, "lavt_pwam_lang_fwd: bad arguments");
-    hipLaunchKernelGGL(pwam_lang_fwd_kernel, dim3(cdiv(C, 16), B), dim3(256), 0, ST, (const bf16*)V, ldv, (const bf16*)Wo, PP, sumP, (bf16*)VWc, (bf16*)VWw, beta, rw, pbar, cov, T, C, eps);
+    return lavt_pwam_lang_fwd_records(V, ldv, Wo, PP, sumP, nullptr, 0, VWc, VWw, beta, rw, pbar, cov, B, T, C, eps, stream);
+}
+
+extern "C" int lavt_pwam_lang_fwd_records(const void* V, int64_t ldv, const void* Wo, const float* PP, const float* sumP, const float* rec, int nrec, void* VWc, void* VWw,
+                                          float* beta, float* rw, float* pbar, float* cov, int B, int T, int C, float eps, void* stream) {
+    LAVT_CHECK_ARG(V && Wo && ((PP && sumP) || (rec && nrec > 0)) && VWc && VWw && beta && rw && pbar && cov && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && ldv % 8 == 0, "lavt_pwam_lang_fwd: bad arguments");
+    hipLaunchKernelGGL(pwam_lang_fwd_kernel, dim3(cdiv(C, 16), B), dim3(256), 0, ST, (const bf16*)V, ldv, (const bf16*)Wo, PP, sumP, (bf16*)VWc, (bf16*)VWw, beta, rw, pbar, cov, T, C, eps, PP ? nullptr : rec, nrec);
     LAVT_CHECK_LAUNCH("lavt_pwam_lang_fwd");
     return LAVT_OK;
 }

@@ -200,7 +200,8 @@ _PROTOTYPES = {
     "lavt_wmsa_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp],
     "lavt_wmsa_fwd_rider": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp, i64, vp],
     "lavt_pwam_words_fwd": [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
-    "lavt_pwam_words_fwd_moments": [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "lavt_pwam_words_fwd_moments": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "lavt_pwam_lang_fwd_records": [vp, i64, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "lavt_pwam_words_records": [i32, i32, i32],
     "lavt_pwam_words_bwd": [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "lavt_pwam_q_parts": [i32],

@@ -453,19 +453,7 @@ def _scratch(n_floats, device):
     return torch.empty(int(n_floats), dtype=torch.float32, device=device)
 
 
-_ARRIVE = {}
-
-
-def _arrive_counters(device):
-    """the counters of the in-launch hand-overs (csrc/arrive.h): zero here, and every launch leaves them zero.  One [4096] block per device; the PWAM
-    kernels use disjoint regions by kind (words 0.., mix 1024.., tn 2048..), launches of a kind follow each other on one stream."""
-    t = _ARRIVE.get(device)
-    if t is None:
-        t = _ARRIVE[device] = torch.zeros(4096, dtype=torch.int32, device=device)
-    return t
-
-
-_PWAM_TAILS = os.environ.get("LAVT_PWAM_TAILS", "1") != "0"          # A/B switch: 0 = the round-5 launch sequence (separate reductions + language kernels)
+_PWAM_RECORDS = os.environ.get("LAVT_PWAM_RECORDS", "1") != "0"          # A/B switch: 0 = the round-5 launch sequence (word-side reductions as TN launches + their reduction launches)
 _TN_PARTS = {}
 _TN_PARTIALS_MINK = int(os.environ.get("LAVT_TN_PARTIALS_MINK", "2048"))
 
@@ -2060,11 +2048,12 @@ class _PwamGate(torch.autograd.Function):
         _note(f"words {M}x{Cc}", 2.0 * M * Cc * KV_LD)
         lf = torch.empty(B * (2 * Cc + KV_LD + KV_LD * KV_LD), dtype=torch.float32, device=dev)
         beta, rw, pbar, cov = lf[:B * Cc], lf[B * Cc:2 * B * Cc], lf[2 * B * Cc:2 * B * Cc + B * KV_LD], lf[2 * B * Cc + B * KV_LD:]
-        if _PWAM_TAILS:
-            # Cov_T(P), Pbar as a by-product of the word kernel (records + last arriver): no P^T P launch, no reduction launch
-            rec = _scratch(B * int(K.lib.lavt_pwam_words_records(B, T, Cc)) * (KV_LD * KV_LD + KV_LD), dev)
-            K.check(K.lib.lavt_pwam_words_fwd_moments(K.ptr(q), Cc, K.ptr(k), kld, K.ptr(mean), K.ptr(rstd), K.ptr(maskbias), K.ptr(P), K.ptr(rec),
-                                                      K.ptr(_arrive_counters(dev)), K.ptr(cov), K.ptr(pbar), B, T, Cc, n_l, alpha, K.stream()))
+        rec, nrec = None, 0
+        if _PWAM_RECORDS:
+            # P^T P, colsum(P) as a by-product of the word kernel: per-workgroup records that the language kernel adds (no P^T P launch, no reduction launch)
+            nrec = int(K.lib.lavt_pwam_words_records(B, T, Cc))
+            rec = _scratch(B * nrec * (KV_LD * KV_LD + KV_LD), dev)
+            K.check(K.lib.lavt_pwam_words_fwd_moments(K.ptr(q), Cc, K.ptr(k), kld, K.ptr(mean), K.ptr(rstd), K.ptr(maskbias), K.ptr(P), K.ptr(rec), B, T, Cc, n_l, alpha, K.stream()))
             PP = sumP = None
         else:
             K.check(K.lib.lavt_pwam_words_fwd(K.ptr(q), Cc, K.ptr(k), kld, K.ptr(mean), K.ptr(rstd), K.ptr(maskbias), K.ptr(P), B, T, Cc, n_l, alpha, K.stream()))
@@ -2073,10 +2062,10 @@ class _PwamGate(torch.autograd.Function):
             gemm_tn(dtype, KV_LD, KV_LD, T, P, KV_LD, P, KV_LD, PP, KV_LD, batch=B, strideA=T * KV_LD, strideB=T * KV_LD, strideC=KV_LD * KV_LD, colsum=sumP, strideColsum=KV_LD)
         VWc = torch.empty(B, Cc, KV_LD, dtype=dtype, device=dev)
         VWw = torch.empty(B, KV_LD, Cc, dtype=dtype, device=dev)
-        _note(f"lang {B}x{Cc}")
-        K.check(K.lib.lavt_pwam_lang_fwd(K.ptr(v), kld, K.ptr(weights.get(Wo, dtype, "lin")), K.ptr(PP), K.ptr(sumP), K.ptr(VWc), K.ptr(VWw), K.ptr(beta), K.ptr(rw),
-                                         K.ptr(pbar), K.ptr(cov), B, T, Cc, 1e-5, K.stream()))
         mm = torch.empty_like(vpre)
+        _note(f"lang {B}x{Cc}")
+        K.check(K.lib.lavt_pwam_lang_fwd_records(K.ptr(v), kld, K.ptr(weights.get(Wo, dtype, "lin")), K.ptr(PP), K.ptr(sumP), K.ptr(rec), nrec, K.ptr(VWc), K.ptr(VWw),
+                                                 K.ptr(beta), K.ptr(rw), K.ptr(pbar), K.ptr(cov), B, T, Cc, 1e-5, K.stream()))
         _note(f"mix0 {M}x{Cc}", 2.0 * M * Cc * KV_LD)
         K.check(K.lib.lavt_pwam_mix(0, K.ptr(P), K.ptr(VWc), K.ptr(beta), None, K.ptr(_f32(bv)), K.ptr(vpre), Cc, None, 0, K.ptr(mm), Cc, None, 0, B, T, Cc, K.stream()))
         rpre = torch.empty_like(vpre)

@@ -1629,7 +1629,7 @@ def test_droppath_draw_on_device():
     assert not torch.equal(out[0], out[1]), "a replay must draw fresh factors"
 
 
-# ------------------------------------------------------------------------------------------ PWAM in-launch hand-overs (round 6, csrc/arrive.h)
+# ------------------------------------------------------------------------------------------ PWAM word-side reductions as by-products (round 6)
 def _pwam_words_ref(q, k, mean, rstd, maskbias, n_l, alpha):
     """fp32 statement of lavt_pwam_words_fwd on the bf16 operands: softmax_{j < n_l}(alpha * IN(q) K^T + maskbias), lib/backbone.py:1349-1361"""
     B, T, C = q.shape
@@ -1641,9 +1641,11 @@ def _pwam_words_ref(q, k, mean, rstd, maskbias, n_l, alpha):
 
 @pytest.mark.parametrize("B,T,C,n_l", [(2, 14400, 128, 20), (2, 3600, 256, 13), (2, 900, 512, 20), (3, 225, 1024, 7), (2, 50, 64, 32), (4, 14400, 96, 20), (1, 40000, 128, 20)])
 def test_pwam_words_moments_by_product(B, T, C, n_l):
-    """lavt_pwam_words_fwd_moments: P as lavt_pwam_words_fwd writes it, and Cov_T(P) / Pbar equal to the fp32 moments of THAT bf16 P -- records of
-    1 .. 64 workgroups per sample, both workgroup sizes, rows that are no multiple of a tile; run-to-run identical, counters left at zero."""
+    """lavt_pwam_words_fwd_moments: P as lavt_pwam_words_fwd writes it, and records whose sum is P^T P / colsum(P) of THAT bf16 P (1 .. 64 records per
+    sample, both workgroup sizes, rows that are no multiple of a tile, masked words); lavt_pwam_lang_fwd_records on the records = lavt_pwam_lang_fwd on
+    the TN product of the round-5 path; run-to-run identical."""
     from lavt_hip import _capi as K
+    from lavt_hip import ops
     d = dev()
     bf = torch.bfloat16
     q = (rnd(B, T, C, seed=1) * 1.5 + 0.3).to(bf).to(d)
@@ -1661,26 +1663,46 @@ def test_pwam_words_moments_by_product(B, T, C, n_l):
     K.check(K.lib.lavt_pwam_words_fwd(K.ptr(q), C, K.ptr(k), C, K.ptr(mean), K.ptr(rstd), K.ptr(mb), K.ptr(P0), B, T, C, n_l, alpha, K.stream()))
     R = int(K.lib.lavt_pwam_words_records(B, T, C))
     assert 1 <= R <= 64
-    counters = torch.zeros(64, dtype=torch.int32, device=d)
     outs = []
-    for _ in range(3):
+    for _ in range(2):
         P = torch.empty_like(P0)
-        rec = torch.full((B * R * 1056,), float("nan"), device=d)
-        cov = torch.full((B, 32, 32), float("nan"), device=d)
-        pbar = torch.full((B, 32), float("nan"), device=d)
-        K.check(K.lib.lavt_pwam_words_fwd_moments(K.ptr(q), C, K.ptr(k), C, K.ptr(mean), K.ptr(rstd), K.ptr(mb), K.ptr(P), K.ptr(rec), K.ptr(counters),
-                                                  K.ptr(cov), K.ptr(pbar), B, T, C, n_l, alpha, K.stream()))
+        rec = torch.full((B, R, 1056), float("nan"), device=d)
+        K.check(K.lib.lavt_pwam_words_fwd_moments(K.ptr(q), C, K.ptr(k), C, K.ptr(mean), K.ptr(rstd), K.ptr(mb), K.ptr(P), K.ptr(rec), B, T, C, n_l, alpha, K.stream()))
         torch.cuda.synchronize()
-        assert int(counters.abs().sum()) == 0, "the last arriver leaves the counters at zero"
-        outs.append((P, cov, pbar))
-    P, cov, pbar = outs[0]
+        outs.append((P, rec))
+    P, rec = outs[0]
     assert torch.equal(P, P0), "the by-product does not change P"
+    assert torch.equal(outs[1][1], rec), "records are run-to-run identical"
     ref = _pwam_words_ref(q.cpu(), k.cpu(), mean.cpu(), rstd.cpu(), mb.cpu(), n_l, alpha)
     assert_close(P.reshape(B, T, 32), ref, bf, "P", bf16=2e-2)
     Pd = P.reshape(B, T, 32).double()
+    tot = rec.double().sum(1)
+    pp_ref = torch.einsum("btj,btk->bjk", Pd, Pd)
+    assert float((tot[:, :1024].reshape(B, 32, 32) - pp_ref).abs().max()) <= 2e-6 * T, "sum of the records = P^T P"
+    assert float((tot[:, 1024:] - Pd.sum(1)).abs().max()) <= 2e-6 * T, "sum of the records = colsum(P)"
+    # the language kernel on the records against the same kernel on the explicit TN product
+    V = torch.zeros(B, 32, C)
+    V[:, :n_l] = rnd(B, n_l, C, seed=3)
+    V = V.to(bf).to(d)
+    Wo = (rnd(C, C, seed=4) * C ** -0.5).to(bf).to(d)
+    PP = torch.zeros(B, 32, 32, device=d)
+    sumP = torch.zeros(B, 32, device=d)
+    ops.gemm_tn(bf, 32, 32, T, P, 32, P, 32, PP, 32, batch=B, strideA=T * 32, strideB=T * 32, strideC=1024, colsum=sumP, strideColsum=32)
+
+    def lang(use_rec):
+        o = dict(VWc=torch.empty(B, C, 32, dtype=bf, device=d), VWw=torch.empty(B, 32, C, dtype=bf, device=d), beta=torch.empty(B, C, device=d),
+                 rw=torch.empty(B, C, device=d), pbar=torch.empty(B, 32, device=d), cov=torch.empty(B, 32, 32, device=d))
+        K.check(K.lib.lavt_pwam_lang_fwd_records(K.ptr(V), C, K.ptr(Wo), None if use_rec else K.ptr(PP), None if use_rec else K.ptr(sumP), K.ptr(rec) if use_rec else None,
+                                                 R if use_rec else 0, K.ptr(o["VWc"]), K.ptr(o["VWw"]), K.ptr(o["beta"]), K.ptr(o["rw"]), K.ptr(o["pbar"]), K.ptr(o["cov"]),
+                                                 B, T, C, 1e-5, K.stream()))
+        torch.cuda.synchronize()
+        return o
+    a, b_ = lang(True), lang(False)
     pb_ref = Pd.mean(1)
-    cov_ref = torch.einsum("btj,btk->bjk", Pd, Pd) / T - pb_ref[:, :, None] * pb_ref[:, None, :]
-    assert float((pbar.double() - pb_ref).abs().max()) <= 2e-6, "Pbar"
-    assert float((cov.double() - cov_ref).abs().max()) <= 3e-6 * max(1.0, float(cov_ref.abs().max()) * 1e3), f"Cov: {float((cov.double() - cov_ref).abs().max()):.3e}"
-    for P2, cov2, pbar2 in outs[1:]:
-        assert torch.equal(cov2, cov) and torch.equal(pbar2, pbar) and torch.equal(P2, P), "run-to-run identical (fixed summation order)"
+    cov_ref = pp_ref / T - pb_ref[:, :, None] * pb_ref[:, None, :]
+    assert float((a["pbar"].double() - pb_ref).abs().max()) <= 2e-6, "Pbar"
+    assert float((a["cov"].double() - cov_ref).abs().max()) <= 5e-6, "Cov"
+    for kname in ("beta", "rw"):
+        assert_close(a[kname], b_[kname].cpu(), torch.float32, kname, f32=2e-3)
+    assert_close(a["VWc"], b_["VWc"].float().cpu(), bf, "VWc", bf16=1e-2)
+    assert torch.equal(a["VWc"].transpose(1, 2).contiguous(), a["VWw"]), "both layouts of VW' hold the same values"
