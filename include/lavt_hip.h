@@ -222,6 +222,9 @@ typedef struct lavt_gemm_tn {
                                 * a windowed qkv weight gradient taken over the REAL tokens only (token order: the zero rows of padded window
                                 * positions are skipped, K = tokens instead of window rows) + a side problem over the padded rows alone, whose
                                 * dq / dk / dv still belong to the bias gradient (the reference pads after norm1: lib/backbone.py:205-209) */
+    int64_t a_src_rows, b_src_rows; /* ABI v7: rows of the tensors that a_rowmap / b_rowmap index (0 = unknown: at most K).  The pipelined grouped kernel addresses a
+                                * mapped operand through ONE 2 GB buffer descriptor with 32-bit byte offsets row * ld * 2: a problem whose mapped source
+                                * reaches beyond that falls back to the 64x64 launch instead of reading zeros from beyond the descriptor's range */
 } lavt_gemm_tn_t;
 
 int lavt_gemm_tn(const lavt_gemm_tn_t* p, void* stream);

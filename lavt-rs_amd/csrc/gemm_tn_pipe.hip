@@ -559,7 +559,11 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
         const bool no_b = p.ldb == 0;                             // (the column-sum-only side member: B = the zero page)
         if (p.dtype != LAVT_BF16 || p.batch != 1 || p.conv_kc > 0 || p.B2 || p.c_conv_permute) return 1;
         if (p.I % 8 || p.J % 4 || p.lda % 8 || p.ldb % 8 || p.K < 8) return 1;
-        if ((int64_t)(p.K + 1024) * p.lda * 2 >= (1LL << 30) || (int64_t)(p.K + 1024) * p.ldb * 2 >= (1LL << 30)) return 1;          // 32-bit byte offsets inside a 2 GB descriptor, with room for the source rows of a mapped operand and the tiles issued beyond K
+        if ((int64_t)(p.K + 1024) * p.lda * 2 >= (1LL << 30) || (int64_t)(p.K + 1024) * p.ldb * 2 >= (1LL << 30)) return 1;          // 32-bit byte offsets inside a 2 GB descriptor, with room for the tiles issued beyond K
+        // a MAPPED operand is addressed by source row: the rows its map may name must stay inside the descriptor as well (unknown extent: the K + 1024 rows
+        // bounded above; a padded-window source or a large clip can be several times the reduction length -- beyond 2^31 bytes the hardware returns zeros)
+        if (p.a_rowmap && p.a_src_rows > 0 && (p.a_src_rows + 1) * p.lda * 2 + 256 >= (1LL << 31)) return 1;
+        if (p.b_rowmap && p.b_src_rows > 0 && (p.b_src_rows + 1) * p.ldb * 2 + 256 >= (1LL << 31)) return 1;
         if (p.a_rowscale && (!p.a_rowscale_binary || p.a_rowscale_div < 64 || (p.K + p.a_rowscale_div - 1) / p.a_rowscale_div > 64)) return 1;
         if (no_b && !p.colsum) return 1;
         if (!no_b && p.J % 8) return 1;

@@ -136,7 +136,7 @@ class GemmTN(C.Structure):
         ("alpha", f32), ("C", vp), ("ldc", i64), ("strideC", i64), ("c_conv_permute", i32), ("split_k", i32),
         ("colsum", vp), ("strideColsum", i64), ("zeros", vp), ("a_rowscale_binary", i32), ("accumulate", i32),
         ("conv_d", i32), ("conv_kd", i32), ("conv_kh", i32), ("conv_kw", i32),
-        ("partials", vp), ("partials_floats", i64), ("colsum_atomic", i32),
+        ("partials", vp), ("partials_floats", i64), ("colsum_atomic", i32), ("a_src_rows", i64), ("b_src_rows", i64),
     ]
 
 

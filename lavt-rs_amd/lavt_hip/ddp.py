@@ -17,7 +17,7 @@ Replaces `torch.nn.parallel.DistributedDataParallel(model, find_unused_parameter
   identical on every rank by construction (SyncBN semantics in lavt_hip.ops.batch_norm_relu).
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of 475 MB fp32 (Swin-B) is ~5 ms, comparable
-to the backward itself at batch 2/GPU, hence large buckets (default 64 MiB: few, large collectives) and overlap.
+to the backward itself at batch 2/GPU, hence large buckets (default 32 MiB, `engine.TrainStep(bucket_mib=...)` / LAVT_BUCKET_MIB: few, large collectives) and overlap.
 """
 import os
 import sys
@@ -242,11 +242,6 @@ class GradBuckets:
                 dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
         elif self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
-            if self.fused:
-                from . import ops
-                for lst in ops.side.streams.values():       # fused wgrad kernels write the bucket from side streams
-                    for st in lst:
-                        self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
                 if self.bf16:                           # (always stream-ordered on the communication stream, whatever LAVT_DDP_MODE says)
                     half = chunk.to(torch.bfloat16)

@@ -27,8 +27,27 @@ from .ddp import GradBuckets
 from .runtime import compute_dtype, fp8_enabled
 
 
+def _in_context(fn):
+    """run a TrainStep method inside the step's own ops.StepContext"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        with ops.use_context(self.context):
+            return fn(self, *a, **kw)
+    return wrapped
+
+
 class TrainStep:
-    def __init__(self, model, image, l_feats, l_mask, target, world=1, use_graph=True, bucket_mib=32.0, fused_loss=True, refresh_weights_in_step=False):
+    def __init__(self, model, image, l_feats, l_mask, target, world=1, use_graph=True, bucket_mib=32.0, fused_loss=True, refresh_weights_in_step=False, context=None):
+        """context: the ops.StepContext this harness keeps its state in (gradient sinks, deferred-launch queues, weight copies, scratch).  None = the
+        process-wide default context -- what the drop-in path and a single harness use.  Give every further model in the process its own
+        `ops.StepContext()` (and its optimizer the same one: FusedAdamW(..., context=)): their steps can then alternate freely."""
+        self.context = context if context is not None else ops.default_context()
+        with ops.use_context(self.context):
+            self._init(model, image, l_feats, l_mask, target, world, use_graph, bucket_mib, fused_loss, refresh_weights_in_step)
+
+    def _init(self, model, image, l_feats, l_mask, target, world, use_graph, bucket_mib, fused_loss, refresh_weights_in_step):
         self.model = model
         dev = image.device
         self.x, self.l, self.m, self.t = image, l_feats, l_mask, target
@@ -61,6 +80,7 @@ class TrainStep:
     def _param_stamp(self):
         return sum(p._version for p in self._params), sum(p.data_ptr() for p in self._params)
 
+    @_in_context
     def _body(self):
         if self.refresh_in_step:
             ops.weights.refresh_all()            # re-cast weights inside the step (for optimizers that do not maintain the compute copies)
@@ -81,11 +101,12 @@ class TrainStep:
         loss.backward(self._one)                 # one more 4.5 us launch on the captured chain
         ops.wgrads.flush()                       # weight-gradient GEMMs still queued for a grouped launch
         ops.ln_deferred.flush()                  # all LayerNorm weight / bias partial sums of this backward: one reduction launch
-        ops.side.join()                          # wgrad GEMMs ran on side streams: join before the step (or the graph capture) ends
         self.buckets.finish()                    # stragglers (never-used parameters) + join of the communication stream
         ops.zero_arena.end_step()
+        ops.fp8.end_step()
         return loss.detach()
 
+    @_in_context
     def warmup_and_capture(self, eager_iters=3):
         """Side effects beyond `eager_iters` steps: one more eager step when the bucket layout is still to settle (eager_iters = 1), and the zero-fill-skip validation below replays the captured step up to three more times on
         NaN-poisoned gradient buffers.  Each of those replays is a real training step of the forward pass -- BatchNorm running statistics and
@@ -169,6 +190,7 @@ class TrainStep:
             self.graph = None
             torch.cuda.synchronize()
 
+    @_in_context
     def step(self):
         if not self.refresh_in_step:
             stamp = self._param_stamp()

@@ -24,6 +24,31 @@ from .runtime import fp8_enabled
 KV_LD = 32          # padded word axis of PWAM keys/values (N_l <= 32)
 
 
+# ------------------------------------------------------------------------------------------ step context
+# Everything the ops keep BETWEEN calls -- compute-dtype weight copies, gradient sinks, the queues of deferred launches, zero arenas, fp8 scale history,
+# per-device scratch, the DropPath generator -- lives in ONE StepContext (defined below, after the classes it bundles).  The module-level names
+# (`weights`, `sinks`, `wgrads`, ...) are proxies onto the CURRENT context: the drop-in path (the reference's train.py / test.py loop) runs in the default
+# context and never sees the difference; a harness that owns a private context (engine.TrainStep(context=StepContext())) runs its forward, backward and
+# optimizer inside `with use_context(ctx):`, so two models -- or a train + eval pair -- in one process cannot share sinks, queues or scratch.
+_ctx = None
+
+
+class _Proxy:
+    """module-level stand-in for one member of the current StepContext: attribute reads / writes go to `getattr(_ctx, name)`"""
+
+    def __init__(self, name=None):
+        if name is None:                          # `ops.fp8.__init__()` in a test: re-initialise the member it stands for
+            getattr(_ctx, object.__getattribute__(self, "_n")).__init__()
+            return
+        object.__setattr__(self, "_n", name)
+
+    def __getattr__(self, a):
+        return getattr(getattr(_ctx, object.__getattribute__(self, "_n")), a)
+
+    def __setattr__(self, a, v):
+        setattr(getattr(_ctx, object.__getattribute__(self, "_n")), a, v)
+
+
 # ------------------------------------------------------------------------------------------ weights
 class _WeightCache:
     """compute-dtype copies of fp32 parameters: 'lin' = [N,K] matrix view, 'conv3' = [Cout][9][Cin]."""
@@ -229,16 +254,22 @@ class _WeightCache:
             self.store[k] = ((tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps), self.epoch), out, self.store[k][2])
 
 
-weights = _WeightCache()
+weights = _Proxy("weights")
 
 
 class _Fp8State:
     """Delayed-scaling bookkeeping of the fp8 path: one |max| slot per quantisation site (keyed by the consuming weight), two device arrays
     (`prev` = what this step quantises against, `cur` = what this step observes).  `advance()` rolls them over at the start of a step -- a
-    kernel, so it is part of the captured graph."""
+    kernel, so it is part of the captured graph.
+
+    The producer-side shortcuts (an e4m3 twin written by the kernel that produces an activation, a gradient |max| recorded by the kernel that produces the
+    gradient into the site's `cur` slot) rely on advance() -- it zeroes `cur` and forgets unclaimed twins -- so they are taken only between advance()
+    and end_step() (`step_active`: the step harness, engine.TrainStep).  Any other loop (the reference's eager train.py sequence, several backward passes
+    per optimizer step) quantises with the self-contained launches lavt_fp8_quantize / lavt_fp8_quantize_current and pins nothing."""
     SLOTS = 1024
 
     def __init__(self):
+        self.step_active = False
         self.prev = self.cur = None
         self.slots = {}
         self.twins = {}          # (data_ptr, numel) of a bf16 tensor -> (its e4m3 twin written by the producing kernel, pointer of the |max| it was scaled by)
@@ -262,8 +293,15 @@ class _Fp8State:
     def advance(self):
         self.twins.clear()
         self.dy_amax.clear()
+        self.step_active = True
         if self.prev is not None and self.slots:
             K.check(K.lib.lavt_fp8_advance(K.ptr(self.prev), K.ptr(self.cur), len(self.slots), K.stream()))
+
+    def end_step(self):
+        """the harness' step is over: unclaimed twins / gradient maxima are dropped (they would pin full-size activations), producers stop writing them"""
+        self.twins.clear()
+        self.dy_amax.clear()
+        self.step_active = False
 
     def site_ptrs(self, key, device):
         """(pointer of the |max| this step quantises against, pointer of the |max| this step records) of a delayed-scaling site"""
@@ -305,7 +343,7 @@ class _Fp8State:
         return q, self.prev.data_ptr() + 4 * i
 
 
-fp8 = _Fp8State()
+fp8 = _Proxy("fp8")
 # Linear layers take the fp8 path from this many GEMM rows up; by default NONE does (the decoder's 3x3 convolutions, 54 % of the FLOPs, are the
 # fp8 contractions).  Measured on MI355X, Swin-B 4x480x480 against the reference's fp32 run: convolutions only -- pixel agreement 0.974, mask IoU on
 # decisive pixels 0.984, 18.73 ms/step (bf16 18.83); plus every Linear with >= 4096 rows (stages 0-1, qkv of stage 2) -- agreement 0.930, IoU on
@@ -406,29 +444,7 @@ class _GradSinks:
         return None
 
 
-sinks = _GradSinks()
-
-
-class _SideStreams:
-    """Rounds 1-4 could send the weight-gradient GEMMs to side HIP streams (LAVT_SIDE_STREAMS=1: forked from / joined into the main stream, so that
-    they would fill the CUs the latency-bound data-gradient chain leaves idle).  REMOVED in round 5: it never paid (21.4 vs 20.9 ms per step in round
-    1, 9.88 vs 9.77 in round 2, 12.43-13.0 vs 12.46 in round 3: a hipGraph that is not a single chain costs ~0.5 us per kernel node on this runtime)
-    and it was not safe -- the per-device partial-tile scratch and the persistent arenas of the step are single-stream by construction (the round-4
-    advisor found the fused-tap convolution gradient racing on the scratch; a GPU run of the harness test with the switch on then showed 1e-3 of
-    drift in the data-gradient chain as well).  The object stays as the pass-through the call sites use: run() calls fn at once on the current
-    stream, join() has nothing to wait for."""
-
-    enabled = False
-    streams = {}
-
-    def run(self, fn, tensors, active):
-        fn()
-
-    def join(self):
-        return
-
-
-side = _SideStreams()
+sinks = _Proxy("sinks")
 
 
 def _note(shape, flops=0.0, nbytes=0.0):
@@ -454,27 +470,25 @@ def _scratch(n_floats, device):
 
 
 _PWAM_RECORDS = os.environ.get("LAVT_PWAM_RECORDS", "1") != "0"          # A/B switch: 0 = the round-5 launch sequence (word-side reductions as TN launches + their reduction launches)
-_TN_PARTS = {}
 _TN_PARTIALS_MINK = int(os.environ.get("LAVT_TN_PARTIALS_MINK", "2048"))
 
 
 def _tn_parts(n_floats, device):
     """One persistent fp32 buffer per device for the partial tiles of split weight-gradient reductions: a launch's pieces are consumed by its own
     reduction kernel before the next launch of the stream writes them again (stream order), so consecutive launches share it."""
-    t = _TN_PARTS.get(device)
+    t = _ctx.tn_parts.get(device)
     if t is None or t.numel() < n_floats:
-        t = _TN_PARTS[device] = torch.empty(max(int(n_floats), 4 << 20), dtype=torch.float32, device=device)
+        t = _ctx.tn_parts[device] = torch.empty(max(int(n_floats), 4 << 20), dtype=torch.float32, device=device)
     return t
 
 
-_SINK_OUT = {}
 
 
 def _discard_out(n_floats, device):
     """an output nobody reads (the C of a column-sum-only weight-gradient member); its own buffer: the shared scratch may hold partial sums"""
-    b = _SINK_OUT.get(device)
+    b = _ctx.sink_out.get(device)
     if b is None or b.numel() < n_floats:
-        b = _SINK_OUT[device] = torch.empty(n_floats, dtype=torch.float32, device=device)
+        b = _ctx.sink_out[device] = torch.empty(n_floats, dtype=torch.float32, device=device)
     return b
 
 
@@ -523,7 +537,7 @@ class _ZeroArena:
         return torch.zeros(shape, dtype=dtype, device=device)
 
 
-zero_arena = _ZeroArena()
+zero_arena = _Proxy("zero_arena")
 
 
 class _FillRiders:
@@ -564,7 +578,7 @@ class _FillRiders:
             self.buf, self.off = None, 0
 
 
-fill_riders = _FillRiders()
+fill_riders = _Proxy("fill_riders")
 
 
 def _zero_page_tensor(device):
@@ -649,8 +663,11 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     p.alpha, p.C, p.ldc, p.strideC = alpha, K.ptr(Cout) + c_off * 4, ldc, strideC
     p.c_conv_permute, p.split_k = int(c_conv_permute), (-1 if defer is not None else 0)     # deferred = into the zeroed flat gradient buffer: a grouped launch may split K
     p.colsum, p.strideColsum, p.colsum_atomic = K.ptr(colsum), strideColsum, int(colsum_atomic)
+    # rows a row map may name (the pipelined grouped kernel bounds its 32-bit descriptor offsets with them)
+    p.a_src_rows = (A.shape[0] if A.dim() >= 2 else A.numel() // max(lda, 1)) if a_rowmap is not None else 0
+    p.b_src_rows = (B.shape[0] if B.dim() >= 2 else B.numel() // max(ldb, 1)) if b_rowmap is not None else 0
     p.zeros = _zero_page(A.device)
-    if dtype == torch.bfloat16 and conv is None and (batch == 1 or defer is None) and Kd >= (_TN_PARTIALS_MINK if batch == 1 else 128) and not side.enabled and os.environ.get("LAVT_TN_PARTIALS", "1") != "0":      # (one scratch per device: single-stream order only)
+    if dtype == torch.bfloat16 and conv is None and (batch == 1 or defer is None) and Kd >= (_TN_PARTIALS_MINK if batch == 1 else 128) and os.environ.get("LAVT_TN_PARTIALS", "1") != "0":      # (one scratch per device: every launch of a step is on ONE stream)
         # scratch for split reductions through partial tiles (long-K weight gradients on few output tiles: PWAM's 1x1 convolutions over 28 800 rows;
         # batched: the per-sample word-side matrices of the fused PWAM node -- plain stores + a fixed-order sum, so the result is run-to-run identical)
         need = batch * int(K.lib.lavt_gemm_tn_pieces(C.byref(p))) * (I * J + I)
@@ -688,7 +705,6 @@ def _launch_ln_partial(rider):
                                              K.ptr(dres_), rows_, C_, K.stream()))
 
 
-_SK_SCRATCH = {}
 # measured (round 4, tools/wgrad_sk_time.py): 70-78 us against 39.6 us for the 64x64-tile launch of the stage-2 block -- contiguous runs lose the L2 / MALL sharing
 # of operand panels between workgroups that sweep K together.  Off by default; the launch stays reachable for experiments.
 _STREAMK = os.environ.get("LAVT_WGRAD_STREAMK", "0") == "1"
@@ -753,23 +769,21 @@ class _WgradQueue:
             if sk:
                 # stream-K form (csrc/gemm_tn_v2.hip): 128x128 tiles, equal runs of K-tile iterations per persistent workgroup, split tiles through a scratch
                 dev = tensors[0].device
-                scr = _SK_SCRATCH.get(dev)
+                scr = _ctx.sk_scratch.get(dev)
                 if scr is None or scr.numel() < sk:
-                    scr = _SK_SCRATCH[dev] = torch.empty(sk, dtype=torch.float32, device=dev)
-                side.run(lambda: K.check(K.lib.lavt_gemm_tn_grouped_sk(arr, n_items, K.ptr(scr), scr.numel(), K.stream())), tensors, True)
+                    scr = _ctx.sk_scratch[dev] = torch.empty(sk, dtype=torch.float32, device=dev)
+                K.check(K.lib.lavt_gemm_tn_grouped_sk(arr, n_items, K.ptr(scr), scr.numel(), K.stream()))
                 if rider is not None:
                     _launch_ln_partial(rider)
                 self._after_flush()
                 return
-            if rider is not None and not side.enabled and _LN_RIDER:
+            if rider is not None and _LN_RIDER:
                 dy_, x_, g_, mean_, rstd_, dx_, ws_, dres_, rows_, C_ = rider
                 K.check(K.lib.lavt_gemm_tn_grouped_ln(arr, n_items, K.ptr(dy_), K.ptr(x_), K.ptr(g_), K.ptr(mean_), K.ptr(rstd_), K.ptr(dx_), K.ptr(ws_), ws_.numel(),
                                                       K.ptr(dres_), rows_, C_, K.stream()))
                 self._after_flush()
                 return
-            # the grouped launch is off the critical path of backward (only the optimizer / all-reduce consumes it): on a side stream it overlaps
-            # the latency-bound data-gradient chain of the next block (LAVT_SIDE_STREAMS=1)
-            side.run(lambda: K.check(K.lib.lavt_gemm_tn_grouped(arr, n_items, K.stream())), tensors, True)
+            K.check(K.lib.lavt_gemm_tn_grouped(arr, n_items, K.stream()))
             if rider is not None:
                 _launch_ln_partial(rider)
         self._after_flush()
@@ -783,7 +797,7 @@ class _WgradQueue:
                 sinks.on_ready(prm)
 
 
-wgrads = _WgradQueue()
+wgrads = _Proxy("wgrads")
 
 
 _LN_REDUCE_COMPACT = os.environ.get("LAVT_LN_REDUCE_COMPACT", "1") != "0"          # A/B switch: 0 = the (128 column blocks x sets) grid of round 3
@@ -855,7 +869,7 @@ class _LnDeferred:
                 sinks.on_ready(p)
 
 
-ln_deferred = _LnDeferred()
+ln_deferred = _Proxy("ln_deferred")
 
 
 class _DtableChain:
@@ -880,7 +894,7 @@ class _DtableChain:
             self.job, self.keep = None, None
 
 
-dtable_chain = _DtableChain()
+dtable_chain = _Proxy("dtable_chain")
 
 
 def lang_mask(l_mask, B, n_l):
@@ -902,7 +916,6 @@ def droppath_factors(u, keep):
     return f
 
 
-_dp_state = {}
 
 
 def droppath_draw(keep, B):
@@ -910,20 +923,38 @@ def droppath_draw(keep, B):
     from torch's default generator when first used on a device -- lives in device memory and is advanced by the kernel, so a captured step draws fresh
     factors on every replay without torch.rand's two bookkeeping fills.  LAVT_DROPPATH_RNG=torch keeps torch.rand."""
     dev = keep.device
-    st = _dp_state.get(dev)
+    st = _ctx.dp_state.get(dev)
     if st is None:
         st = torch.tensor([torch.initial_seed() & 0x7fffffffffffffff, 0], dtype=torch.int64).to(dev)
-        _dp_state[dev] = st
+        _ctx.dp_state[dev] = st
     f = torch.empty(keep.shape[0], B, dtype=torch.float32, device=dev)
     K.check(K.lib.lavt_droppath_draw(K.ptr(st), K.ptr(keep.contiguous()), K.ptr(f), keep.shape[0], B, K.stream()))
     return f
 
 
 def droppath_reseed(seed, device=None):
-    """restart the device DropPath generator (all devices, or one) from `seed`"""
-    for dev, st in _dp_state.items():
+    """restart the device DropPath generator (all devices, or one) from `seed`.  The generator is seeded from torch.initial_seed() when FIRST used on a
+    device: a later torch.manual_seed() does not reach it -- call this after seeding (every DDP rank with the same seed draws the same masks, as
+    torch.rand under a common seed does)."""
+    for dev, st in _ctx.dp_state.items():
         if device is None or torch.device(device) == dev:
             st.copy_(torch.tensor([int(seed) & 0x7fffffffffffffff, 0], dtype=torch.int64))
+
+
+def droppath_state_dict():
+    """{device string: (seed, draw counter)} of the device DropPath generators: put it into a checkpoint next to the optimizer state (the reference's
+    torch.rand masks resume from the torch generator state; this generator lives outside it) and hand it to droppath_load_state_dict on resume"""
+    return {str(dev): tuple(int(v) for v in st.cpu()) for dev, st in _ctx.dp_state.items()}
+
+
+def droppath_load_state_dict(state):
+    for dev, (seed, counter) in state.items():
+        d = torch.device(dev)
+        t = torch.tensor([int(seed), int(counter)], dtype=torch.int64)
+        if d in _ctx.dp_state:
+            _ctx.dp_state[d].copy_(t)
+        else:
+            _ctx.dp_state[d] = t.to(d)
 
 
 def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -1033,10 +1064,8 @@ class _Linear(torch.autograd.Function):
                     wgrads.notify(bias)
                 dW = db = None
             else:
-                side.run(lambda: gemm_tn(dtype, N, Kd, M, g, N, x, Kd, wbuf, Kd, a_rowmap=o.out_map, a_rowscale=o.row_scale,
-                                         a_rowscale_div=o.row_scale_div, a_rowscale_binary=binary,
-                                         alpha=o.row_scale_value if binary else 1.0, b_rowmap=o.in_map, colsum=bbuf),
-                         (g, x), wsink and (bbuf is None or bsink))
+                gemm_tn(dtype, N, Kd, M, g, N, x, Kd, wbuf, Kd, a_rowmap=o.out_map, a_rowscale=o.row_scale, a_rowscale_div=o.row_scale_div, a_rowscale_binary=binary,
+                        alpha=o.row_scale_value if binary else 1.0, b_rowmap=o.in_map, colsum=bbuf)
                 dW = sinks.done(weight, wbuf, wsink)
                 if bbuf is not None:
                     db = sinks.done(bias, bbuf, bsink)
@@ -1171,7 +1200,7 @@ class _Mlp(torch.autograd.Function):
                     wgrads.notify(b)
                 grads += [None, None]
             else:
-                side.run(lambda: gemm_tn(dtype, n, kd, M, g, n, inp, kd, wbuf, kd, colsum=bbuf, **kw), (g, inp), wsink and bsink)
+                gemm_tn(dtype, n, kd, M, g, n, inp, kd, wbuf, kd, colsum=bbuf, **kw)
                 grads += [sinks.done(w, wbuf, wsink), sinks.done(b, bbuf, bsink) if b is not None else None]
         dw2, db2, dw1, db1 = grads
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res and ctx.needs_input_grad[5] else None), None
@@ -1734,7 +1763,53 @@ class _ConvStats:
         return None
 
 
-conv_stats = _ConvStats()
+conv_stats = _Proxy("conv_stats")
+
+
+class StepContext:
+    """the state the ops keep between calls (see the note at the top of this module).  `with use_context(ctx):` makes it current."""
+
+    def __init__(self):
+        self.weights = _WeightCache()
+        self.fp8 = _Fp8State()
+        self.sinks = _GradSinks()
+        self.zero_arena = _ZeroArena()
+        self.fill_riders = _FillRiders()
+        self.wgrads = _WgradQueue()
+        self.ln_deferred = _LnDeferred()
+        self.dtable_chain = _DtableChain()
+        self.conv_stats = _ConvStats()
+        self.tn_parts, self.sink_out, self.sk_scratch = {}, {}, {}          # per-device scratch of the split reductions (single-stream order within a context)
+        self.dp_state = {}                                                   # per-device DropPath generator (seed, draw counter)
+
+    def __enter__(self):
+        global _ctx
+        self._prev = getattr(self, "_prev", [])
+        self._prev.append(_ctx)
+        _ctx = self
+        return self
+
+    def __exit__(self, *exc):
+        global _ctx
+        _ctx = self._prev.pop()
+        return False
+
+
+_default_ctx = StepContext()
+_ctx = _default_ctx
+
+
+def default_context():
+    return _default_ctx
+
+
+def current_context():
+    return _ctx
+
+
+def use_context(ctx):
+    """`with use_context(ctx):` -- ops called inside (forward, the autograd backward started inside, optimizer refreshes) use ctx's state"""
+    return ctx if ctx is not None else _default_ctx
 
 
 class _HipBnKernels:
@@ -1791,7 +1866,7 @@ class _HipBnKernels:
     @staticmethod
     def apply(x, mean, rstd, gamma, beta, fp8_site=None):
         y = torch.empty_like(x)
-        if fp8_site is not None and x.dtype == torch.bfloat16 and fp8_enabled():
+        if fp8_site is not None and x.dtype == torch.bfloat16 and fp8_enabled() and fp8.step_active:
             q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
             a_prev, a_cur = fp8.site_ptrs(fp8_site, x.device)
             K.check(K.lib.lavt_norm_apply_q8(K.ptr(x), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), None, 1, K.ptr(y), K.ptr(q), a_prev, a_cur,
@@ -1818,7 +1893,7 @@ class _HipBnKernels:
     def bwd_apply(dy, x, y, mean, rstd, gamma, beta, s, count, fp8_dy_site=None):
         R, Cc = x.shape
         dx = torch.empty_like(x)
-        if fp8_dy_site is not None and x.dtype == torch.bfloat16 and fp8_enabled():
+        if fp8_dy_site is not None and x.dtype == torch.bfloat16 and fp8_enabled() and fp8.step_active:
             a_cur = fp8.site_ptrs(fp8_dy_site, x.device)[1]
             K.check(K.lib.lavt_norm_bwd_apply_amax(K.ptr(dy), K.ptr(x), K.ptr(y), K.ptr(mean), K.ptr(rstd), K.ptr(_f32(gamma)), K.ptr(_f32(beta)),
                                                    None, 1, K.ptr(s[0]), K.ptr(s[1]), count, K.ptr(dx), None, a_cur, 1, R, Cc, K.stream()))
@@ -2660,7 +2735,7 @@ class _ConvTaps(torch.autograd.Function):
             if ws:
                 # nine taps fused (csrc/conv_wgrad.hip): X rows in a rolling LDS window, partial tiles through the lent scratch, the reduction kernel
                 # accumulates straight into the [Cout][Cin][3][3] gradient -- no packed buffer, no zero fill, no unpack launch
-                scr = _tn_parts(ws, dy.device)          # (single-stream scratch: every launch of the step is on the one launch stream, see _SideStreams)
+                scr = _tn_parts(ws, dy.device)          # (single-stream scratch: every launch of the step is on the one launch stream)
                 if K.prof.enabled:
                     K.prof.note = {"flops": 2.0 * Cout * taps * Cin * M, "shape": f"conv-wgrad {Cout}x{taps * Cin}x{M}"}
                 # dW is either the parameter's slice of the zeroed flat gradient buffer (one weight gradient per parameter per step: sinks.buf refuses a
@@ -2674,7 +2749,7 @@ class _ConvTaps(torch.autograd.Function):
             gemm_tn(dtype, Cout, taps * Cin, M, dy, Cout, x1, C1, packed, taps * Cin, B2=x2, ldb2=C2, b_split=C1,
                     conv=(H, W, Cin, D, kd, kh, kw), colsum=db)
             K.check(K.lib.lavt_unpack_conv_grad(K.ptr(packed), K.ptr(dW), Cout, Cin, taps, K.stream()))
-        side.run(_wgrad, (dy, x1, x2), wsink and (db is None or bsink))
+        _wgrad()
         return (dx1, dx2, sinks.done(weight, dW, wsink), sinks.done(bias, db, bsink) if bias is not None else None,
                 None, None, None, None, None, None)
 
@@ -2737,7 +2812,7 @@ class _Bilinear(torch.autograd.Function):
         Cc = x.shape[1]
         y = torch.empty(B * Ho * Wo, Cc, dtype=x.dtype, device=x.device)
         ctx.dims = (B, Hi, Wi, Ho, Wo, Cc)
-        if fp8_site is not None and x.dtype == torch.bfloat16 and fp8_enabled():
+        if fp8_site is not None and x.dtype == torch.bfloat16 and fp8_enabled() and fp8.step_active:
             q = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
             a_prev, a_cur = fp8.site_ptrs(fp8_site, x.device)
             K.check(K.lib.lavt_bilinear_fwd_q8(K.ptr(x), K.ptr(y), K.ptr(q), a_prev, a_cur, B, Hi, Wi, Ho, Wo, Cc, K.stream()))
@@ -2838,12 +2913,21 @@ class _UpsampleCE(torch.autograd.Function):
         ws = _scratch(4 * 2048, x.device)
         K.check(K.lib.lavt_upsample_ce_fwd(K.dt(x.dtype), K.ptr(x), K.ptr(target), float(w0), float(w1), K.ptr(ws), ws.numel(), K.ptr(out4),
                                            B, Hi, Wi, Ho, Wo, K.stream()))
-        stats = out4[:]                          # (a second view: the loss below is element 0 of the same four floats -- no copy kernel per step)
-        ctx.save_for_backward(x, target, stats)
         ctx.dims = (B, Hi, Wi, Ho, Wo, float(w0), float(w1))
-        ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)         # (the statistics receive no gradient: None instead of a zero fill per step)
-        return out4[0], stats
+        if wgrads.active():
+            # inside the step harness the loss is consumed at once (engine.TrainStep): loss and statistics are views of the four floats that backward
+            # reads -- no copy kernel on the captured chain
+            stats = out4[:]
+            ctx.save_for_backward(x, target, stats)
+            ctx.mark_non_differentiable(stats)
+            return out4[0], stats
+        # public entry (lib._utils.fused_loss in a caller's own loop): the caller may scale the loss in place (`loss /= accum_steps`, a GradScaler) --
+        # backward keeps its own four floats, the caller gets copies
+        stats = out4.clone()
+        ctx.save_for_backward(x, target, out4)
+        ctx.mark_non_differentiable(stats)
+        return out4[0].clone(), stats
 
     @staticmethod
     def backward(ctx, dloss, _dstats):

@@ -40,7 +40,11 @@ def ops_generation():
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params: Iterable, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, total_steps=0, power=0.9):
+    def __init__(self, params: Iterable, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, total_steps=0, power=0.9, context=None):
+        """context: the ops.StepContext whose compute-dtype weight copies this optimizer maintains (None = the process-wide default; pass the one given to
+        engine.TrainStep when the model runs in a private context)"""
+        from . import ops
+        self.context = context if context is not None else ops.default_context()
         if amsgrad:
             raise NotImplementedError("FusedAdamW: amsgrad is not implemented (the reference's default is off)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
@@ -92,8 +96,9 @@ class FusedAdamW(torch.optim.Optimizer):
             hyper.append([g["lr"], g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"]])
         # (the copies' addresses are baked into the table: ops.weights.generation moves whenever one of them gets a new buffer)
         key = tuple(d[1] for d in desc) + tuple(tuple(h) for h in hyper) + (ops_generation(),)
-        # (first / middle / last described parameter: an O(1) probe of the gradient addresses for step(check_tables=False))
-        self._probe = [(p, p.grad.data_ptr()) for _, p in (ps[0], ps[len(ps) // 2], ps[-1]) if p.grad is not None]
+        # (every described parameter with the gradient address the table holds: step(check_tables=False) compares them all -- integer work on the host,
+        # no device synchronisation; three probed addresses missed a single re-created .grad)
+        self._probe = [(p, p.grad.data_ptr()) for _, p in ps if p.grad is not None]
         self._tables = (key, torch.tensor(desc, dtype=torch.int64).to(dev), torch.tensor(hyper, dtype=torch.float32).to(dev), len(desc),
                         torch.tensor(chunks, dtype=torch.int32).to(dev), len(chunks), dict(fused))
 
@@ -109,6 +114,11 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, check_tables=True):
+        from . import ops
+        with ops.use_context(self.context):
+            return self._step_in_context(closure, check_tables)
+
+    def _step_in_context(self, closure=None, check_tables=True):
         """check_tables=False skips the (host-side) scan for re-allocated gradients / edited hyper-parameters: use it when the gradients
         live in a fixed flat buffer (lavt_hip.ddp.GradBuckets) and the call is being captured into a hipGraph."""
         loss = closure() if closure is not None else None

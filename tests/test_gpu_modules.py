@@ -505,7 +505,7 @@ def test_train_step_gradients_match_plain_autograd(fused_loss):
     kernel the loss gradient differs in a few bf16 roundings (relative L2 1.7e-5 at the decoder output), which this small random network amplifies
     -- train-mode BatchNorm / LayerNorm backward remove the dominant components of the gradient (tools/harness_diff2.py: 1e-3 behind the decoder,
     1.5e-2 at the first block): stated gate there = relative L2 <= 3 % per parameter, no element further than 6 % of the parameter's scale.
-    (Every launch of the step is on ONE stream: the LAVT_SIDE_STREAMS experiment of rounds 1-4 is gone, see lavt_hip.ops._SideStreams.)"""
+    (Every launch of the step is on ONE stream: the LAVT_SIDE_STREAMS experiment of rounds 1-4 is gone; forked graph branches were measured again in round 6, profiles/r06_d_graph_fork_overlap_negative.txt.)"""
     import lavt_hip
     from lavt_hip import ops
     from lavt_hip.engine import TrainStep
@@ -551,6 +551,74 @@ def test_train_step_gradients_match_plain_autograd(fused_loss):
     finally:
         ops.sinks.clear()
         ops.wgrads.enabled = False
+        lavt_hip.set_compute_dtype(torch.float32)
+
+
+def test_two_train_steps_in_private_contexts_alternate():
+    """Two models in one process (a train + a second model, or train + eval), each with its own ops.StepContext -- gradient sinks, deferred-launch queues,
+    compute-dtype weight copies, scratch and the DropPath generator are per context -- stepping ALTERNATELY, captured and with FusedAdamW updates between
+    the steps (lr 0: Adam's sign-like first updates would amplify the last-bit noise of the few atomically accumulated sums into 1e-4 weight
+    differences): every model must end with the gradients it reaches when it runs alone -- 2e-4 of each gradient's scale (fp32 atomics in the table /
+    LayerNorm parameter reductions make two runs of ONE harness differ in the last bits; a shared sink, queue or DropPath generator shows as O(1))."""
+    import lavt_hip
+    from lavt_hip import ops
+    from lavt_hip.engine import TrainStep
+    from lavt_hip.optim import FusedAdamW, lavt_param_groups
+    from lib import segmentation
+    lavt_hip.set_compute_dtype(torch.bfloat16)
+
+    def make(seed):
+        x, l, m, t = det_inputs(2, 96, 20, seed=seed)
+        model = segmentation.lavt("", SimpleNamespace(swin_type="tiny", drop_path_rate=0.1))
+        fill_state_dict_(model)
+        model.to(DEV).train()
+        return model, (x.to(DEV), l.to(DEV), m.to(DEV), t.to(DEV))
+
+    def harness(seed):
+        model, inp = make(seed)
+        ctx = ops.StepContext()
+        step = TrainStep(model, *inp, context=ctx)
+        step.warmup_and_capture(eager_iters=1)
+        assert step.captured
+        opt = FusedAdamW(lavt_param_groups(model), lr=0.0, weight_decay=1e-2, total_steps=100, context=ctx)
+        with ops.use_context(ctx):
+            ops.droppath_reseed(1234 + seed)
+        return model, step, opt
+
+    def snapshot(model):
+        return {n: (p.detach().clone(), p.grad.detach().clone()) for n, p in model.named_parameters() if p.grad is not None}
+
+    try:
+        # each alone: three optimizer steps
+        alone = []
+        for seed in (3, 7):
+            model, step, opt = harness(seed)
+            for _ in range(3):
+                step.step()
+                opt.step()
+            torch.cuda.synchronize()
+            alone.append(snapshot(model))
+            del model, step, opt
+        # both alive, steps interleaved
+        a, b = harness(3), harness(7)
+        for _ in range(3):
+            for model, step, opt in (a, b):
+                step.step()
+                opt.step()
+        torch.cuda.synchronize()
+        assert not ops.default_context().wgrads.enabled, "the private harnesses left the default context alone"
+        for (model, _, _), ref in zip((a, b), alone):
+            got = snapshot(model)
+            assert got.keys() == ref.keys()
+            worst = (0.0, "")
+            for n in ref:
+                assert torch.equal(got[n][0], ref[n][0]), f"weights of {n} differ between the interleaved and the lone run (lr = 0)"
+                scale = float(ref[n][1].abs().max())
+                err = float((got[n][1] - ref[n][1]).abs().max())
+                worst = max(worst, (err / max(scale, 1e-12), n))
+            print(f"\n[two contexts] worst gradient difference interleaved vs alone (fraction of the gradient's scale, name): {worst}")
+            assert worst[0] <= 2e-4, worst
+    finally:
         lavt_hip.set_compute_dtype(torch.float32)
 
 

@@ -1378,6 +1378,17 @@ def test_fp8_twins_written_by_producers_equal_the_quantiser(monkeypatch):
         ops.fp8.advance()
         ops.batch_norm_relu(up.detach(), bn)
         assert not ops.fp8.twins and not ops.fp8.dy_amax
+        # outside the step harness (no advance() per step: the reference's eager loop, several backward passes per optimizer step) the producers register
+        # nothing and the gradient is quantised against ITS OWN |max| on every call -- shrinking gradients are not flushed by a stale running maximum
+        ops.fp8.end_step()
+        for k, scale in enumerate((1e-3, 1e-6)):
+            xin = up.detach().clone().requires_grad_(True)
+            y = ops.batch_norm_relu(xin, bn, fp8_site=site, fp8_dy_site=dsite)
+            dy = (rnd(B * H * H, C, seed=9) * scale).to(torch.bfloat16).to(dev())
+            dx, = torch.autograd.grad(y, xin, dy)
+            assert not ops.fp8.twins and not ops.fp8.dy_amax
+            qd, ap = ops.fp8.quantize_current(dx, dsite)
+            assert torch.equal(qd.cpu(), F8.quantize_bytes(dx.cpu(), float(dx.float().abs().max()))), f"pass {k}: current scaling outside the harness"
 
 
 @pytest.mark.parametrize("cat", [False, True])

@@ -61,7 +61,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_capi.EXPORTED), declared ^ set(_capi.EXPORTED)
     for name in declared:
         assert hasattr(_capi.lib, name), f"liblavt_hip.so does not export {name}"
-    assert _capi.lib.lavt_abi_version() == 6
+    assert _capi.lib.lavt_abi_version() == _capi.EXPECTED_ABI == 7
 
 
 def test_struct_layout_matches_header():
@@ -461,3 +461,11 @@ def test_fp8_twin_registry_and_sites_host_logic():
         st.slots.clear()                                                            # (no sites: advance() then launches nothing -- the roll-over kernel itself is a GPU test)
         st.advance()
         assert not st.twins and not st.dy_amax
+        # the producer shortcuts exist only between advance() and end_step() (round-5 advisor: outside the step harness nothing zeroes the `cur` slot a
+        # gradient |max| is max-ed into, and nothing drops unclaimed twins)
+        assert st.step_active
+        st.put_twin(y, q, a_prev)
+        st.put_dy_amax(y, a_cur)
+        st.end_step()
+        assert not st.step_active and not st.twins and not st.dy_amax
+    assert not ops._Fp8State().step_active, "a fresh state (an eager loop without the harness) never takes the producer path"
