@@ -360,6 +360,10 @@ int lavt_layernorm_bwd_partial(int dtype, const void* dy, const void* x, const i
  * (lavt_gemm_nt.ln_wsum) and never materialised it; the consumer's weight gradient reads xn.  _partial_xn = the deferred-reduction form. */
 int lavt_layernorm_bwd_partial_xn(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                                   void* dx, void* xn, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream);
+/* ABI v7: the same launch + the table-gradient binning job of an earlier lavt_window_attn_bwd_chained launch as rider workgroups (`job` as that call
+ * returned it in *mine).  Returns 1 and launches NOTHING when this LayerNorm geometry has no rider form: issue the two launches separately. */
+int lavt_layernorm_bwd_partial_xn_dtable(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                         void* dx, void* xn, float* ws, int64_t ws_floats, const void* dres, int rows, int C, const lavt_dtable_job_t* job, void* stream);
 int lavt_layernorm_bwd_xn(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                           void* dx, void* xn, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream);
 int lavt_reduce_partials_multi(const int64_t* desc, int n, int total_column_blocks, void* stream); /* total_column_blocks = sum over the sets of lavt_reduce_partials_column_blocks(C) (<= 0: unknown; a larger number -- e.g. the ceil(2 C / 32) of the first ABI v6 builds -- only starts idle workgroups) */

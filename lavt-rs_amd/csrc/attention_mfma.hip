@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "dtable_body.h"
 
 namespace {
 
@@ -216,8 +217,6 @@ struct DtableJob {
     float* part;
     int slab_ld, wd, wh, ww, nwin, N, heads, rows_per_block, win_per_group, gx, gz;      // gx, gz: the binning grid (gy = heads)
 };
-__device__ void dtable_block(const bf16* __restrict__ slab, float* __restrict__ part, int slab_ld, int wd, int wh, int ww, int nwin, int N, int heads,
-                             int rows_per_block, int win_per_group, int bx, int h, int bz, int gx, int tid, char* smem_raw);
 
 template <int NT, int WAVES, bool REGION, bool FULL>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void wattn_bwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
                                                       const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                       bf16* __restrict__ dqkv, bf16* __restrict__ slab, int slab_ld,
                                                       int wd, int wh, int ww, int nwin, int N, int heads, float scale, int win_per_block,
-                                                      int attn_blocks, const DtableJob job) {
+                                                      int attn_blocks, const DtableJob job, const int split_from, const int split_pieces) {
     constexpr int KS = (NT + 1) / 2, NP = KS * 32;         // tiles are consumed in pairs (k = 32)
     constexpr int NTHR = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -253,9 +252,19 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
     float* tab = reinterpret_cast<float*>(Rs + NP);        // this head's column of the bias table * log2 e, [(2wd-1)(2wh-1)(2ww-1)]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-    const int h = blockIdx.x % heads, chunk = blockIdx.x / heads;
-    const int C = heads * HD;
     const int QT = (N + 15) / 16;
+    // Units beyond a whole number of rounds of the chip (18 windows x 16 heads = 288 on 256 CUs: the 32 CUs that hold two took 21.1 us where one unit per
+    // CU takes 14.9) are cut into `split_pieces` workgroups, each with a contiguous run of the unit's 2 QT tasks (a task = one key tile of pass 1 or one query
+    // tile of pass 2: whole output rows, nothing to add up): every CU then carries one unit + one small piece.  A piece stages the unit's tensors like a whole unit.
+    int unit = blockIdx.x, t_lo = 0, t_hi = 2 * QT;
+    if (split_pieces > 1 && (int)blockIdx.x >= split_from) {
+        const int k = (int)blockIdx.x - split_from, piece = k % split_pieces;
+        unit = split_from + k / split_pieces;
+        t_lo = piece * 2 * QT / split_pieces;
+        t_hi = (piece + 1) * 2 * QT / split_pieces;
+    }
+    const int h = unit % heads, chunk = unit / heads;
+    const int C = heads * HD;
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
     const int centre = ((wd - 1) * (2 * wh - 1) + (wh - 1)) * (2 * ww - 1) + (ww - 1);
     const float sc2 = scale * LOG2E;
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
     // so workgroups that are likely to share a CU (the grid's second round of 256) start the list two slots later: the heavy SIMDs differ.
     // (9 waves of exactly one pass-1 and one pass-2 task -- 96 VGPRs for two workgroups per CU, 34 spills in the shifted variant -- measured
     // slower: 36.7 vs 34.1 us with the table kernels for the stage-2 launch, 10.77 vs 10.50 ms per step.)
-    const int slot = (wave + 2 * ((blockIdx.x >> 8) & 1)) % WAVES;
+    const int slot = (wave + 2 * ((unit >> 8) & 1)) % WAVES;
 
     const int w_end = min(nwin, (chunk + 1) * win_per_block);
     for (int w = chunk * win_per_block; w < w_end; ++w) {
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
         __syncthreads();
 
 #pragma unroll 1
-        for (int t = slot; t < 2 * QT; t += WAVES) {
+        for (int t = t_lo + slot; t < t_hi; t += WAVES) {
           if (t < QT) {
             // ---- pass 1: dV, dK of key tile jt ----------------------------------------------------------------------------
             const int jt = t;
@@ -444,65 +453,6 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
     }
 }
 
-// Table gradient straight from the per-(window, head) dS slabs: dtable[idx][h] += sum_w sum_{(i,j): idx(i,j) = idx} slab[w][h][i][j].
-// grid = (row chunks, heads, window groups).  A wave walks rows i of its chunk, lanes cover the keys j (coalesced row reads), the sum over
-// the group's windows stays in registers; the (i, j) -> table-index binning then costs one LDS atomic per (i, j) per workgroup (not per
-// window), and one global atomic per touched table entry per workgroup.
-__device__ void dtable_block(const bf16* __restrict__ slab, float* __restrict__ part, int slab_ld, int wd, int wh, int ww, int nwin, int N, int heads,
-                             int rows_per_block, int win_per_group, int bx, int h, int bz, int gx, int tid, char* smem_raw) {
-    const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
-    const int centre = ((wd - 1) * (2 * wh - 1) + (wh - 1)) * (2 * ww - 1) + (ww - 1);
-    float* hist = reinterpret_cast<float*>(smem_raw);
-    int* bs = reinterpret_cast<int*>(hist + R);
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < R; e += 256) hist[e] = 0.f;
-    for (int e = tid; e < N; e += 256) {
-        const int dz = e / (wh * ww), hy = (e / ww) % wh, wx = e % ww;
-        bs[e] = (dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx;
-    }
-    __syncthreads();
-    const int r0 = bx * rows_per_block, r1 = min(N, r0 + rows_per_block);
-    const int w0 = bz * win_per_group, w1 = min(nwin, w0 + win_per_group);
-    const int64_t wstride = (int64_t)heads * N * slab_ld;
-    for (int i = r0 + wave; i < r1; i += 4) {
-        const bf16* row = slab + ((int64_t)w0 * heads + h) * N * slab_ld + (int64_t)i * slab_ld;
-        const int bi = bs[i] + centre;
-        // a lane owns a QUAD of keys (one 8-byte load: 36 lanes cover a 144-token row in one pass); sixteen windows at a time, then ONE predicated
-        // round for the rest: the kernel is a chain of dependent-latency rounds (18 windows were 2 passes x 3 rounds with key pairs and 8-window steps)
-        for (int j = 4 * lane; j < N; j += 256) {
-            const bf16* q = row + j;
-            float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-            auto add = [&](float (&t)[4], uint2 v) {
-                t[0] += __uint_as_float(v.x << 16); t[1] += __uint_as_float(v.x & 0xFFFF0000u);
-                t[2] += __uint_as_float(v.y << 16); t[3] += __uint_as_float(v.y & 0xFFFF0000u);
-            };
-            int w = w0;
-            for (; w + 15 < w1; w += 16, q += 16 * wstride) {
-                uint2 v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const uint2*>(q + u * wstride);
-#pragma unroll
-                for (int u = 0; u < 16; u += 2) { add(a, v[u]); add(b, v[u + 1]); }
-            }
-            if (w < w1) {
-                uint2 v[15];
-#pragma unroll
-                for (int u = 0; u < 15; ++u) v[u] = (w + u < w1) ? *reinterpret_cast<const uint2*>(q + u * wstride) : make_uint2(0u, 0u);
-#pragma unroll
-                for (int u = 0; u < 15; ++u) add((u & 1) ? b : a, v[u]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (j + r < N) atomicAdd(hist + (bi - bs[j + r]), a[r] + b[r]);
-        }
-    }
-    __syncthreads();
-    // this workgroup's histogram -> part[(z * chunks + chunk) * heads + h][R] (contiguous, plain stores); wattn_dtable_finish adds the pieces up.
-    // (Flushing with atomics straight into dtable[R][heads] puts every lane in a different 64-byte segment: ~17x below the atomic rate.)
-    if (part == nullptr) return;                           // (a rider half without a unit)
-    float* dst = part + (((int64_t)bz * gx + bx) * heads + h) * R;
-    for (int e = tid; e < R; e += 256) dst[e] = hist[e];
-}
 __global__ __launch_bounds__(256) void wattn_dtable_kernel(const bf16* __restrict__ slab, float* __restrict__ part, int slab_ld, int wd, int wh,
                                                            int ww, int nwin, int N, int heads, int rows_per_block, int win_per_group) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -570,7 +520,9 @@ int lavt_window_attn_fwd_mfma(const void* qkv, const float* table, const int8_t*
 }
 
 static void dtable_geometry(int nwin, int N, int heads, int* rpb, int* wgroups, int* wpg) {
-    *rpb = cdiv(N * heads, 1024);                             // rows per workgroup: ~1k (row chunk, head) workgroups
+    // rows per binning block: <= 512 (row chunk, head) blocks per window group -- as riders of an attention-backward launch they are <= 256 workgroups of two
+    // blocks, ONE round in the second workgroup slot of every CU (with 576 blocks = 288 riders the last 32 queued behind the others: round 6)
+    *rpb = cdiv(N * heads, 512);
     if (*rpb < 4) *rpb = 4;
     const int g = cdiv(nwin, 32);                             // <= 32 windows summed per workgroup
     *wpg = cdiv(nwin, g);
@@ -687,8 +639,17 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
             if (rc != LAVT_OK) return rc;
         }
     }
-    dim3 grid(chunks * heads + riders);
-    const int attn_blocks = chunks * heads;
+    // split the units beyond whole rounds of 256 (see the kernel): up to 128 of them, each into min(8, 256 / extra) pieces -- at most ONE piece per CU beside
+    // its whole units.  (More pieces than CUs queue behind the two resident workgroups of a CU: 400 units = 256 + 144 x 3 pieces measured 26.9 us against
+    // 21.0 unsplit, 480 units 28.5 against 23.1; 288 -> 16.4-16.7 against 20.3-20.7, 384 -> 19.7 against 20.9, 576 -> 29.6 against 30.3.)
+    const int units = chunks * heads, extra = units % 256;
+    int split_from = units, split_pieces = 1;
+    if (wpb == 1 && units > 256 && extra > 0 && extra <= 128 && lavt_tuning().probe[6] != 1) {
+        split_pieces = 256 / extra < 8 ? 256 / extra : 8;
+        split_from = units - extra;
+    }
+    const int attn_blocks = split_from + (units - split_from) * split_pieces;
+    dim3 grid(attn_blocks + riders);
 #define LAVT_BWD_K(NT_, WV_, RG_, FULL_)                                                                                                    \
     do {                                                                                                                                     \
         const size_t lds = bwd_lds_bytes<NT_>(R);                                                                                            \
@@ -701,7 +662,8 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
             reserved = lds;                                                                                                                  \
         }                                                                                                                                    \
         hipLaunchKernelGGL((wattn_bwd_mfma<NT_, WV_, RG_, FULL_>), grid, dim3(WV_ * 64), lds, st, (const bf16*)qkv, table, region, nw_img,   \
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, reinterpret_cast<bf16*>(ws), bias_ld, wd, wh, ww, nwin, N, heads, scale, wpb, attn_blocks, job); \
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, reinterpret_cast<bf16*>(ws), bias_ld, wd, wh, ww, nwin, N, heads, scale, wpb, attn_blocks, job, \
+                           split_from, split_pieces);                                                                                        \
     } while (0)
 #define LAVT_BWD(NT_, WV_, FULL_)                                                                                                            \
     do {                                                                                                                                     \

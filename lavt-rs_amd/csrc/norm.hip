@@ -1,9 +1,11 @@
 // LayerNorm (optionally fused with the PatchMerging 2x2 gather) and the per-channel statistics /
 // normalisation kernels behind InstanceNorm1d (PWAM) and BatchNorm2d(+ReLU) (decoder).  All HBM-bound:
 // 16-byte accesses, one wave per LayerNorm row (row kept in registers, fp32 math), wave-shuffle reductions.
+#include <string.h>
 #include "common.h"
 #include "fp8_pack.h"
 #include "ln_bwd_body.h"
+#include "dtable_body.h"
 
 namespace {
 
@@ -77,6 +79,32 @@ __global__ __launch_bounds__(WAVES * 64) void layernorm_bwd_kernel(const T* __re
     __shared__ float red[(WAVES - 1) * (LPR * CPL * Chunk<T>::N)];
     layernorm_bwd_body<T, LPR, CPL, WAVES, FLAGS>(dy, x, gather, gamma, mean, rstd, dx, dgamma, dbeta, partials, dres, rows, C, xn_out_, beta, blockIdx.x, gridDim.x,
                                                   threadIdx.x, red);
+}
+
+// The same launch carrying the table-gradient binning of an attention backward as RIDER workgroups (round 6): blocks >= ln_blocks run dtable_block on the dS
+// slabs of the attention launch issued a few launches earlier (still in the Infinity Cache).  As riders of the NEXT attention-backward launch (round 4) the
+// binning blocks took that launch's second workgroup slot per CU at its 55 KB of LDS -- the launch grew from 16.7-20.7 us to 24.5; a LayerNorm backward is
+// 256-thread workgroups without LDS pressure, eight to a CU, and waits on HBM for most of its 8 us.
+struct DtableRider {
+    const bf16* slab; float* part;
+    int slab_ld, wd, wh, ww, nwin, N, heads, rows_per_block, win_per_group, gx, gz;
+};
+template <typename T, int LPR, int CPL, int FLAGS>
+__global__ __launch_bounds__(256) void layernorm_bwd_dtable_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
+                                                                   float* __restrict__ partials, const T* __restrict__ dres, int rows, int C,
+                                                                   T* __restrict__ xn_out_, const float* __restrict__ beta, const int ln_blocks, const DtableRider job) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    __shared__ float red[3 * (LPR * CPL * Chunk<T>::N)];
+    if ((int)blockIdx.x >= ln_blocks) {
+        const int u = (int)blockIdx.x - ln_blocks;
+        const int bx = u % job.gx, hh = (u / job.gx) % job.heads, bz = u / (job.gx * job.heads);
+        dtable_block(job.slab, job.part, job.slab_ld, job.wd, job.wh, job.ww, job.nwin, job.N, job.heads, job.rows_per_block, job.win_per_group, bx, hh, bz, job.gx,
+                     threadIdx.x, dsm);
+        return;
+    }
+    layernorm_bwd_body<T, LPR, CPL, 4, FLAGS>(dy, x, nullptr, gamma, mean, rstd, dx, nullptr, nullptr, partials, dres, rows, C, xn_out_, beta, blockIdx.x, ln_blocks,
+                                              threadIdx.x, red);
 }
 
 // Second stage of the two-stage reductions: partials [nblk][W] (W = groups*2*C: per group first the C "sum-1" values, then the C
@@ -616,6 +644,28 @@ extern "C" int lavt_layernorm_bwd_partial_xn(int dtype, const void* dy, const vo
                                              void* dx, void* xn, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream) {
     LAVT_CHECK_ARG(xn && beta, "lavt_layernorm_bwd_partial_xn: xn and beta required");
     return layernorm_bwd_impl(dtype, dy, x, nullptr, gamma, mean, rstd, dx, nullptr, nullptr, ws, ws_floats, dres, rows, C, stream, true, xn, beta);
+}
+// lavt_layernorm_bwd_partial_xn + the binning job of an earlier attention-backward launch as rider workgroups.  Returns 1 WITHOUT launching anything when this
+// LayerNorm's geometry has no rider form (fp32, 8-wave or wide-row variants): the caller then issues the two launches on their own.
+extern "C" int lavt_layernorm_bwd_partial_xn_dtable(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                                    void* dx, void* xn, float* ws, int64_t ws_floats, const void* dres, int rows, int C, const lavt_dtable_job_t* job, void* stream) {
+    LAVT_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && xn && ws && job && rows > 0, "lavt_layernorm_bwd_partial_xn_dtable: bad arguments");
+    int lpr, cpl, waves;
+    const int blocks = ln_bwd_geometry(dtype, rows, C, &lpr, &cpl, &waves);
+    if (dtype != LAVT_BF16 || waves != 4 || cpl > 2 || C % 8 || ws_floats < (int64_t)blocks * 2 * C) return 1;
+    static_assert(sizeof(DtableRider) == sizeof(lavt_dtable_job_t), "lavt_dtable_job_t mirrors DtableRider");
+    DtableRider r;
+    memcpy(&r, job, sizeof(r));
+    const int R = (2 * r.wd - 1) * (2 * r.wh - 1) * (2 * r.ww - 1);
+    const size_t lds = (size_t)(R + r.N) * 4 + 16;
+    const int riders = r.gx * r.heads * r.gz;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    using T = bf16;
+#define LN_BWD_DT(LPR_, CPL_) hipLaunchKernelGGL((layernorm_bwd_dtable_kernel<T, LPR_, CPL_, 2>), dim3(blocks + riders), dim3(256), lds, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, ws, (const T*)dres, rows, C, (T*)xn, beta, blocks, r)
+    if (lpr == 16) LN_BWD_DT(16, 1); else if (lpr == 32) LN_BWD_DT(32, 1); else if (cpl == 1) LN_BWD_DT(64, 1); else LN_BWD_DT(64, 2);
+#undef LN_BWD_DT
+    LAVT_CHECK_LAUNCH("lavt_layernorm_bwd_partial_xn_dtable");
+    return LAVT_OK;
 }
 extern "C" int lavt_layernorm_bwd_xn(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                                      void* dx, void* xn, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream) {

@@ -180,6 +180,7 @@ _PROTOTYPES = {
     "lavt_layernorm_bwd_blocks": [i32, i32, i32],
     "lavt_layernorm_bwd_partial": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
     "lavt_layernorm_bwd_partial_xn": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
+    "lavt_layernorm_bwd_partial_xn_dtable": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, C.POINTER(DtableJob), vp],
     "lavt_layernorm_bwd_xn": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
     "lavt_reduce_partials_multi": [vp, i32, i32, vp],
     "lavt_reduce_partials_column_blocks": [i32],

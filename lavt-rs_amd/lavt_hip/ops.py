@@ -873,13 +873,22 @@ ln_deferred = _Proxy("ln_deferred")
 
 
 class _DtableChain:
-    """Chained table-gradient binning (lavt_window_attn_bwd_chained): an attention-backward launch leaves the binning of its dS slabs to the NEXT
-    attention-backward launch of the backward pass, which runs it as extra workgroups; the last job of a pass is launched on its own from
-    ln_deferred.flush().  The slabs (and the histogram scratch) of a pending job are kept alive here until it has run."""
+    """Chained table-gradient binning (lavt_window_attn_bwd_chained): an attention-backward launch leaves the binning of its dS slabs to a LATER launch
+    of the backward pass, which runs it as extra workgroups -- the next LayerNorm backward of an MLP (round 6: 256-thread workgroups without LDS
+    pressure; lavt_layernorm_bwd_partial_xn_dtable), else the next attention-backward launch (round 4); the last job of a pass is launched on its
+    own from ln_deferred.flush().  The slabs (and the histogram scratch) of a pending job are kept alive here until it has run."""
 
     def __init__(self):
         self.job, self.keep = None, None
         self.enabled = os.environ.get("LAVT_DTABLE_CHAIN", "1") != "0"
+        self.ln_host = os.environ.get("LAVT_DTABLE_LN_HOST", "1") != "0"          # A/B switch: 0 = riders only in attention-backward launches
+
+    def take_for_layernorm(self):
+        """the pending job for a LayerNorm-backward launch to carry (None: nothing pending / switched off); the caller reports back with done_by_layernorm()"""
+        return self.job if (self.job is not None and self.ln_host) else None
+
+    def done_by_layernorm(self):
+        self.job, self.keep = None, None
 
     def launch(self, dtype, qkv, ld, region, nw_img, out, dout, lse, dqkv, table, wsb, parts, wd, wh, ww, nwin, N, heads, hd, scale):
         mine = K.DtableJob()
@@ -1258,8 +1267,18 @@ class _LnMlp(torch.autograd.Function):
             nblk = int(K.lib.lavt_layernorm_bwd_blocks(K.dt(dtype), M, Cin))
             wsd = ln_deferred.alloc(nblk * 2 * Cin, dev)
             if wsd is not None:
-                K.check(K.lib.lavt_layernorm_bwd_partial_xn(K.dt(dtype), K.ptr(dxn), K.ptr(x), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), K.ptr(st[0]), K.ptr(st[1]), K.ptr(dx),
-                                                            K.ptr(xn), K.ptr(wsd), wsd.numel(), K.ptr(dy), M, Cin, K.stream()))
+                job = dtable_chain.take_for_layernorm()
+                rc = 1
+                if job is not None:          # the binning of the attention backward issued a few launches ago rides in this launch
+                    rc = K.lib.lavt_layernorm_bwd_partial_xn_dtable(K.dt(dtype), K.ptr(dxn), K.ptr(x), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), K.ptr(st[0]), K.ptr(st[1]),
+                                                                    K.ptr(dx), K.ptr(xn), K.ptr(wsd), wsd.numel(), K.ptr(dy), M, Cin, C.byref(job), K.stream())
+                    if rc == 0:
+                        dtable_chain.done_by_layernorm()
+                    elif rc != 1:
+                        K.check(rc)
+                if rc == 1:
+                    K.check(K.lib.lavt_layernorm_bwd_partial_xn(K.dt(dtype), K.ptr(dxn), K.ptr(x), K.ptr(_f32(gamma)), K.ptr(_f32(beta)), K.ptr(st[0]), K.ptr(st[1]), K.ptr(dx),
+                                                                K.ptr(xn), K.ptr(wsd), wsd.numel(), K.ptr(dy), M, Cin, K.stream()))
                 ln_deferred.add(wsd, nblk, Cin, dg, db, (gamma, beta))
                 g_g = g_be = None
                 done = True
