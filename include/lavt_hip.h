@@ -486,6 +486,14 @@ int lavt_pwam_lang_fwd_records(const void* V, int64_t ldv, const void* Wo, const
                                float* beta, float* rw, float* pbar, float* cov, int B, int T, int C, float eps, void* stream);
 int lavt_pwam_lang_bwd1(const float* HT, const float* s, const void* VWc, const float* rw, const float* pbar, const float* cov, void* dVW, float* Qp,
                         int B, int T, int C, void* stream);
+/* ABI v7: lavt_pwam_mix(1) on workgroups that own one 64-channel group, with H^T = dwhat^T P and colsum(dwhat) as a by-product when rec != NULL:
+ * rec [B][lavt_pwam_mix1_records(B, T, C)][C * 33] floats (per record C x 32 H^T, then C sums), added in record order by lavt_pwam_lang_bwd1_records
+ * (HT == NULL): replaces the H launch and its reduction launch. */
+int lavt_pwam_mix1(const void* P, const void* VWc, const float* beta, const float* xbias, const void* X, int64_t ldx, const void* D, int64_t ldd, void* dvpre,
+                   int64_t ld0, void* dwhat, int64_t ld1, float* rec, int B, int T, int C, void* stream);
+int lavt_pwam_mix1_records(int B, int T, int C);
+int lavt_pwam_lang_bwd1_records(const float* HT, const float* s, const float* rec, int nrec, const void* VWc, const float* rw, const float* pbar, const float* cov,
+                                void* dVW, float* Qp, int B, int T, int C, void* stream);
 int lavt_pwam_lang_bwd2(const float* G, const float* sdS, const void* K, int64_t ldk, const float* mean, const float* rstd, void* dK, int64_t lddk, void* K2c,
                         float* c0, float* c1, int B, int T, int C, float alpha, void* stream);
 /* masked softmax over the (padded) word axis of PWAM scores, lib/backbone.py:1358-1361.

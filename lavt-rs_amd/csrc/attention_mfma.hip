@@ -644,7 +644,7 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     // 21.0 unsplit, 480 units 28.5 against 23.1; 288 -> 16.4-16.7 against 20.3-20.7, 384 -> 19.7 against 20.9, 576 -> 29.6 against 30.3.)
     const int units = chunks * heads, extra = units % 256;
     int split_from = units, split_pieces = 1;
-    if (wpb == 1 && units > 256 && extra > 0 && extra <= 128 && lavt_tuning().probe[6] != 1) {
+    if (wpb == 1 && units > 256 && extra > 0 && extra <= 128 && !lavt_tuning().attn_bwd_split_off) {
         split_pieces = 256 / extra < 8 ? 256 / extra : 8;
         split_from = units - extra;
     }

@@ -35,7 +35,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- tuning / A-B switches (tuning.hip): the LAVT_* environment variables, read once per process (lavt_tuning_reload() re-reads) ---------
 struct lavt_tuning_t {
-    bool attn_simple, unpack_tiled, gemm_epi_lds, gemm_epi_narrow, gemm_v2_off, tn_big, gemm_general, gemm_wide, fp8_pipe_off, conv_tail_off, side_pre_off, upce_tile_off;
+    bool attn_simple, unpack_tiled, gemm_epi_lds, gemm_epi_narrow, gemm_v2_off, tn_big, gemm_general, gemm_wide, fp8_pipe_off, conv_tail_off, side_pre_off, upce_tile_off, attn_bwd_split_off;
     int attn_bwd_waves, gemm_tile, tn_split, tng_tile, tng_waves, tng_stages, tng_chain, tng_piece, tn_big_min, tn_target, gemm_big_long, gemm_stages,
         gemm_waves, ln_bwd_waves, tn_streamk, gemm_pipe, tn_pipe, tn_pipe_min_tiles, tn_pipe_stages, tn_pipe_min_ktiles;
     int probe[8];          // LAVT_PROBE=a,b,...: free integers for experiment builds (unused by the shipped dispatch)

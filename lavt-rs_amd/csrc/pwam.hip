@@ -491,6 +491,160 @@ __global__ __launch_bounds__(256) void pwam_mix_kernel(const MixArgs a) {
     }
 }
 
+// ---- backward mix A with the word-side reduction as a by-product (round 6).  grid (row chunks, 64-channel groups, B), 512 threads: a workgroup owns ONE
+// channel group (the VW' fragments, beta, bias live in registers for all its rows), its waves walk 16-row tiles:
+//     d what = dmm * GELU(vpre + bv),   d vpre = dmm * (P VW'^T + beta) * GELU'(vpre + bv)                 (as pwam_mix_kernel<1>)
+// and, when `rec` is given, H^T = d what^T P [64 x 32] and s = colsum(d what) [64] of ITS rows: the stored bf16 d what tile and the P tile go through a
+// 3 KB LDS image per wave, read back with the transposing read (lane: one channel / word, four consecutive rows) as the operands of
+// v_mfma_f32_16x16x16_bf16.  A workgroup leaves one record slab rec[b][chunk][C x 32 H^T | C s] (its channel group's part) that lavt_pwam_lang_bwd1 adds
+// in chunk order: no H launch, no reduction launch.
+struct Mix1Args {
+    const bf16* P;        // [B*T][32]
+    const bf16* Wc;       // VW' channel-major [B][C][32]
+    const float* beta;    // [B][C]
+    const float* xb;      // [C] or null
+    const bf16* X;        // vpre [B*T][ldx]
+    int64_t ldx;
+    const bf16* D;        // dmm [B*T][ldd]
+    int64_t ldd;
+    bf16* out0;           // d vpre
+    int64_t ld0;
+    bf16* out1;           // d what
+    int64_t ld1;
+    float* rec;           // [B][gridDim.x][C * 33] or null
+    int T, C;
+};
+constexpr int MIX1_WAVES = 8;
+__global__ __launch_bounds__(MIX1_WAVES * 64) void pwam_mix1_kernel(const Mix1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char msm[];          // per wave: d what image [16][64] + P image [16][32] (3 KB); then the waves' sums [8][2112] floats
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.z, C = a.C, c0 = 64 * blockIdx.y;
+    const int nch = min(64, C - c0);
+    const bool two = nch == 64, odd = g & 1;
+    const int poff = odd ? 16 + 4 * (g - 1) : 4 * g;
+    const int ntiles = (a.T + 15) >> 4;
+    const bf16* Wc = a.Wc + ((int64_t)b * C + c0) * 32;
+    const float* v0 = a.beta + (int64_t)b * C + c0;
+    bf16x8 wa[2][2];
+    float c0a[2][2][4], xba[2][2][4];
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cl = ((cp == 1 && !two) ? 0 : 32 * cp) + 16 * h;          // (a dead second span re-reads the first: result unused)
+            wa[cp][h] = ldg8(Wc + (int64_t)(cl + c16) * 32 + 8 * g);
+            const float4 bt = *reinterpret_cast<const float4*>(v0 + cl + 4 * g);
+            c0a[cp][h][0] = bt.x; c0a[cp][h][1] = bt.y; c0a[cp][h][2] = bt.z; c0a[cp][h][3] = bt.w;
+            float4 xb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.xb) xb = *reinterpret_cast<const float4*>(a.xb + c0 + cl + 4 * g);
+            xba[cp][h][0] = xb.x; xba[cp][h][1] = xb.y; xba[cp][h][2] = xb.z; xba[cp][h][3] = xb.w;
+        }
+    const bool moments = a.rec != nullptr;
+    bf16* Dt = reinterpret_cast<bf16*>(msm) + wave * 1536;          // [16][64]
+    bf16* Pt = Dt + 1024;                                            // [16][32]
+    f32x4 hacc[4][2], sacc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { hacc[ct][0] = hacc[ct][1] = sacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    auto xchg = [&](uint4 L, uint2& p0, uint2& p1) {
+        const uint2 send = odd ? make_uint2(L.x, L.y) : make_uint2(L.z, L.w);
+        const uint2 got = make_uint2((unsigned)__shfl_xor((int)send.x, 16, 64), (unsigned)__shfl_xor((int)send.y, 16, 64));
+        p0 = odd ? got : make_uint2(L.x, L.y);
+        p1 = odd ? make_uint2(L.z, L.w) : got;
+    };
+    // the loads of a tile are requested one tile ahead (a wave walks several tiles when the launch is capped at 32 row chunks)
+    auto request = [&](int tile, bf16x8& wd, uint4 (&xr)[2], uint4 (&dr)[2]) {
+        const int64_t row = (int64_t)b * a.T + min(tile * 16 + c16, a.T - 1);
+        wd = ldg8(a.P + row * 32 + 8 * g);
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const int ch = c0 + ((cp == 1 && !two) ? 0 : 32 * cp) + poff;
+            xr[cp] = *reinterpret_cast<const uint4*>(a.X + row * a.ldx + ch);
+            dr[cp] = *reinterpret_cast<const uint4*>(a.D + row * a.ldd + ch);
+        }
+    };
+    const int tstep = gridDim.x * MIX1_WAVES;
+    int tile = blockIdx.x * MIX1_WAVES + wave;
+    bf16x8 wd_n = {};
+    uint4 xr_n[2] = {}, dr_n[2] = {};
+    if (tile < ntiles) request(tile, wd_n, xr_n, dr_n);
+    for (; tile < ntiles; tile += tstep) {
+        const bf16x8 wd = wd_n;
+        const uint4 xr[2] = {xr_n[0], xr_n[1]}, dr[2] = {dr_n[0], dr_n[1]};
+        if (tile + tstep < ntiles) request(tile + tstep, wd_n, xr_n, dr_n);
+        const int t = tile * 16 + c16;
+        const bool vr = t < a.T;
+        const int64_t row = (int64_t)b * a.T + (vr ? t : a.T - 1);
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const bool live = vr && (cp == 0 || two);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cp][0], wd, z, 0, 0, 0);
+            const f32x4 e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cp][1], wd, z, 0, 0, 0);
+            uint2 xp0, xp1, dp0, dp1;
+            xchg(xr[cp], xp0, xp1);
+            xchg(dr[cp], dp0, dp1);
+            float x0[4], x1[4], d0[4], d1[4], r0[4], r1[4], w0[4], w1[4];
+            unpack4(xp0, x0); unpack4(xp1, x1); unpack4(dp0, d0); unpack4(dp1, d1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float g0, g1;
+                const float a0 = gelu_pair_fast(x0[r] + xba[cp][0][r], g0), a1 = gelu_pair_fast(x1[r] + xba[cp][1][r], g1);
+                r0[r] = d0[r] * (e0[r] + c0a[cp][0][r]) * g0; r1[r] = d1[r] * (e1[r] + c0a[cp][1][r]) * g1;
+                w0[r] = d0[r] * a0; w1[r] = d1[r] * a1;
+            }
+            const uint2 q0 = pack4(w0), q1 = pack4(w1);
+            store_pair16(a.out0 + row * a.ld0 + c0 + 32 * cp, g, pack4(r0), pack4(r1), live);
+            store_pair16(a.out1 + row * a.ld1 + c0 + 32 * cp, g, q0, q1, live);
+            if (moments) {
+                *reinterpret_cast<uint2*>(Dt + c16 * 64 + 32 * cp + 4 * g) = live ? q0 : make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(Dt + c16 * 64 + 32 * cp + 16 + 4 * g) = live ? q1 : make_uint2(0u, 0u);
+            }
+        }
+        if (moments) {          // (wave-uniform: the transposing reads need every lane)
+            *reinterpret_cast<bf16x8*>(Pt + c16 * 32 + 8 * g) = vr ? wd : bf16x8{};
+            const unsigned ad = lds_addr(Dt + (4 * g + (c16 >> 2)) * 64 + 4 * (c16 & 3));
+            const unsigned ap = lds_addr(Pt + (4 * g + (c16 >> 2)) * 32 + 4 * (c16 & 3));
+            u64_t fa0, fa1, fa2, fa3, fb0, fb1;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b64_tr_b16 %0, %6\n\tds_read_b64_tr_b16 %1, %6 offset:32\n\tds_read_b64_tr_b16 %2, %6 offset:64\n\t"
+                         "ds_read_b64_tr_b16 %3, %6 offset:96\n\tds_read_b64_tr_b16 %4, %7\n\tds_read_b64_tr_b16 %5, %7 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(fa0), "=&v"(fa1), "=&v"(fa2), "=&v"(fa3), "=&v"(fb0), "=&v"(fb1) : "v"(ad), "v"(ap) : "memory");
+            const s16x4 A[4] = {__builtin_bit_cast(s16x4, fa0), __builtin_bit_cast(s16x4, fa1), __builtin_bit_cast(s16x4, fa2), __builtin_bit_cast(s16x4, fa3)};
+            const s16x4 Bf[2] = {__builtin_bit_cast(s16x4, fb0), __builtin_bit_cast(s16x4, fb1)};
+            const s16x4 one4 = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                hacc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A[ct], Bf[0], hacc[ct][0], 0, 0, 0);
+                hacc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A[ct], Bf[1], hacc[ct][1], 0, 0, 0);
+                sacc[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A[ct], one4, sacc[ct], 0, 0, 0);
+            }
+        }
+    }
+    if (moments) {
+        // D layout: row = channel 16 ct + 4 g + r, column = word 16 wt + c16 (s: every column the same)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(msm);          // [waves][64 * 32 H^T | 64 s]
+        float* mine = red + wave * 2112;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 16 * ct + 4 * g + r;
+                mine[ch * 32 + c16] = hacc[ct][0][r];
+                mine[ch * 32 + 16 + c16] = hacc[ct][1][r];
+                if (c16 == 0) mine[2048 + ch] = sacc[ct][r];
+            }
+        __syncthreads();
+        float* slab = a.rec + ((int64_t)b * gridDim.x + blockIdx.x) * C * 33;
+        for (int e = tid; e < 2112; e += MIX1_WAVES * 64) {
+            float v = red[e];
+#pragma unroll
+            for (int w = 1; w < MIX1_WAVES; ++w) v += red[w * 2112 + e];
+            if (e < 2048) { if ((e >> 5) < nch) slab[(int64_t)(c0 + (e >> 5)) * 32 + (e & 31)] = v; }
+            else if (e - 2048 < nch) slab[(int64_t)C * 32 + c0 + e - 2048] = v;
+        }
+    }
+}
+
 // ================================================================================================ language side
 // forward: VW = V Wo^T on the matrix cores, Cov_T(P) from the second-moment matrix, var_w -> VW' in both layouts, beta = -Pbar VW'.
 // grid (C / 16, B), 256 threads: a workgroup owns 16 channels, its four waves a quarter of the reduction each (round 5: as 64 channels per workgroup
@@ -616,7 +770,7 @@ __global__ __launch_bounds__(256) void pwam_lang_fwd_kernel(const bf16* __restri
 // and this workgroup's share of the sums over channels Q = VW' diag(b) VW'^T [32][32], u = VW' a [32] (one record per workgroup, no atomics).
 __global__ __launch_bounds__(256) void pwam_lang_bwd1_kernel(const float* __restrict__ HT, const float* __restrict__ s, const bf16* __restrict__ VWc,
                                                              const float* __restrict__ rw, const float* __restrict__ pbar, const float* __restrict__ cov_in,
-                                                             bf16* __restrict__ dVW, float* __restrict__ Qf, int T, int C) {
+                                                             bf16* __restrict__ dVW, float* __restrict__ Qf, int T, int C, const float* __restrict__ rec, int nrec) {
     // grid (min(C / 16, 8), B): 16 channels per workgroup, thread (channel tid / 16, word pair tid % 16).  (64 channels per workgroup with 8 words per
     // thread ran 13 us at every size: ~1 300 dependent LDS operations per thread.)
     __shared__ float vw[16][33];
@@ -636,10 +790,33 @@ __global__ __launch_bounds__(256) void pwam_lang_bwd1_kernel(const float* __rest
         for (int i = 0; i < 2; ++i) {
             const int e = tid + 256 * i;
             n_vw[i] = (float)VWc[((int64_t)b * C + c0 + (e >> 5)) * 32 + (e & 31)];
-            n_h[i] = HT[((int64_t)b * C + c0 + (e >> 5)) * 32 + (e & 31)];
         }
-        n_sc = s[(int64_t)b * C + c0 + c];
         n_rs = rw[(int64_t)b * C + c0 + c];
+        if (rec == nullptr) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + 256 * i;
+                n_h[i] = HT[((int64_t)b * C + c0 + (e >> 5)) * 32 + (e & 31)];
+            }
+            n_sc = s[(int64_t)b * C + c0 + c];
+        } else {
+            // (ABI v7) H^T and s arrive as per-workgroup records of lavt_pwam_mix1: [nrec][C x 32 | C] per sample, added here in record order, sixteen in flight
+            const float* rb = rec + (int64_t)b * nrec * C * 33;
+            n_h[0] = n_h[1] = n_sc = 0.f;
+            for (int r0 = 0; r0 < nrec; r0 += 16) {
+                float v0[16], v1[16], v2[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float* q = rb + (int64_t)min(r0 + u, nrec - 1) * C * 33;
+                    v0[u] = q[(int64_t)(c0 + (tid >> 5)) * 32 + (tid & 31)];
+                    v1[u] = q[(int64_t)(c0 + 8 + (tid >> 5)) * 32 + (tid & 31)];
+                    v2[u] = q[(int64_t)C * 32 + c0 + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (r0 + u < nrec) { n_h[0] += v0[u]; n_h[1] += v1[u]; n_sc += v2[u]; }
+            }
+        }
     };
     request(min((int)blockIdx.x * 16, C - 16));
     if (tid < 32) pb[tid] = pbar[b * 32 + tid];
@@ -821,10 +998,38 @@ extern "C" int lavt_pwam_lang_fwd_records(const void* V, int64_t ldv, const void
     return LAVT_OK;
 }
 
+extern "C" int lavt_pwam_mix1(const void* P, const void* VWc, const float* beta, const float* xbias, const void* X, int64_t ldx, const void* D, int64_t ldd, void* dvpre,
+                              int64_t ld0, void* dwhat, int64_t ld1, float* rec, int B, int T, int C, void* stream) {
+    LAVT_CHECK_ARG(P && VWc && beta && X && D && dvpre && dwhat && B > 0 && T > 0 && C >= 32 && C % 32 == 0 && ldx % 8 == 0 && ldd % 8 == 0 && ld0 % 8 == 0 && ld1 % 8 == 0,
+                   "lavt_pwam_mix1: bad arguments");
+    Mix1Args a{};
+    a.P = (const bf16*)P; a.Wc = (const bf16*)VWc; a.beta = beta; a.xb = xbias; a.X = (const bf16*)X; a.ldx = ldx; a.D = (const bf16*)D; a.ldd = ldd;
+    a.out0 = (bf16*)dvpre; a.ld0 = ld0; a.out1 = (bf16*)dwhat; a.ld1 = ld1; a.rec = rec; a.T = T; a.C = C;
+    const size_t lds = (size_t)MIX1_WAVES * 2112 * 4;
+    static bool reserved = false;
+    if (!reserved) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pwam_mix1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { lavt_set_error("lavt_pwam_mix1: cannot reserve LDS"); return LAVT_ERR_LAUNCH; }
+        reserved = true;
+    }
+    hipLaunchKernelGGL(pwam_mix1_kernel, dim3(lavt_pwam_mix1_records(B, T, C), (C + 63) / 64, B), dim3(MIX1_WAVES * 64), lds, ST, a);
+    LAVT_CHECK_LAUNCH("lavt_pwam_mix1");
+    return LAVT_OK;
+}
+// row chunks of lavt_pwam_mix1 = records per sample that lavt_pwam_lang_bwd1_records adds: one 16-row tile per wave per pass, at most 32
+extern "C" int lavt_pwam_mix1_records(int B, int T, int C) {
+    (void)B; (void)C;
+    const int rc = ((T + 15) / 16 + MIX1_WAVES - 1) / MIX1_WAVES;
+    return rc > 32 ? 32 : (rc < 1 ? 1 : rc);
+}
+
 extern "C" int lavt_pwam_lang_bwd1(const float* HT, const float* s, const void* VWc, const float* rw, const float* pbar, const float* cov, void* dVW, float* Qp,
                                    int B, int T, int C, void* stream) {
-    LAVT_CHECK_ARG(HT && s && VWc && rw && pbar && cov && dVW && Qp && B > 0 && T > 0 && C >= 32 && C % 16 == 0, "lavt_pwam_lang_bwd1: bad arguments");
-    hipLaunchKernelGGL(pwam_lang_bwd1_kernel, dim3(lavt_pwam_q_parts(C), B), dim3(256), 0, ST, HT, s, (const bf16*)VWc, rw, pbar, cov, (bf16*)dVW, Qp, T, C);
+    return lavt_pwam_lang_bwd1_records(HT, s, nullptr, 0, VWc, rw, pbar, cov, dVW, Qp, B, T, C, stream);
+}
+extern "C" int lavt_pwam_lang_bwd1_records(const float* HT, const float* s, const float* rec, int nrec, const void* VWc, const float* rw, const float* pbar, const float* cov,
+                                           void* dVW, float* Qp, int B, int T, int C, void* stream) {
+    LAVT_CHECK_ARG(((HT && s) || (rec && nrec > 0)) && VWc && rw && pbar && cov && dVW && Qp && B > 0 && T > 0 && C >= 32 && C % 16 == 0, "lavt_pwam_lang_bwd1: bad arguments");
+    hipLaunchKernelGGL(pwam_lang_bwd1_kernel, dim3(lavt_pwam_q_parts(C), B), dim3(256), 0, ST, HT, s, (const bf16*)VWc, rw, pbar, cov, (bf16*)dVW, Qp, T, C, HT ? nullptr : rec, nrec);
     LAVT_CHECK_LAUNCH("lavt_pwam_lang_bwd1");
     return LAVT_OK;
 }

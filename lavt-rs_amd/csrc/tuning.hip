@@ -25,6 +25,7 @@ bool env_is(const char* name, char c) {
 void read_tuning(lavt_tuning_t& t) {
     t.attn_simple = env_is("LAVT_ATTN_SIMPLE", '1');             // VALU attention kernels for bf16 too
     t.attn_bwd_waves = env_int("LAVT_ATTN_BWD_WAVES", 0);        // 4: the 4-wave attention backward
+    t.attn_bwd_split_off = env_is("LAVT_ATTN_BWD_SPLIT", '0');   // A/B switch: the attention backward's surplus units (beyond whole rounds of 256) as whole workgroups, not task pieces
     t.unpack_tiled = !env_is("LAVT_UNPACK_TILED", '0');
     t.gemm_tile = env_int("LAVT_GEMM_TILE", 0);                  // 64 | 128 | 256 | 512: forced tile configuration (tests exercise them)
     t.tn_split = env_int("LAVT_TN_SPLIT", 0);

@@ -209,6 +209,9 @@ _PROTOTYPES = {
     "lavt_pwam_mix": [i32, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
     "lavt_pwam_lang_fwd": [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "lavt_pwam_lang_bwd1": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "lavt_pwam_mix1": [vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp],
+    "lavt_pwam_mix1_records": [i32, i32, i32],
+    "lavt_pwam_lang_bwd1_records": [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "lavt_pwam_lang_bwd2": [vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, vp],
     "lavt_rowsoftmax_fwd": [i32, vp, vp, i64, i32, i32, vp],
     "lavt_rowsoftmax_bwd": [i32, vp, vp, vp, i64, i32, i32, vp],
@@ -258,7 +261,7 @@ _cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
 _cdll.lavt_conv3x3_wgrad_ws.restype = C.c_int64
 _cdll.lavt_gemm_tn_grouped_sk_ws.restype = C.c_int64
 _cdll.lavt_last_error.argtypes = []
-for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts", "lavt_pwam_words_records", "lavt_adamw_chunk_elems", "lavt_tuning_reload", "lavt_conv3x3_wgrad_ws", "lavt_conv3x3_wgrad_f8_ok", "lavt_gemm_tn_grouped_sk_ws", "lavt_gemm_nt_colstats_plan", "lavt_cls_head_bwd_blocks", "lavt_reduce_partials_column_blocks"):      # queries, not launches: never timed
+for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts", "lavt_pwam_words_records", "lavt_pwam_mix1_records", "lavt_adamw_chunk_elems", "lavt_tuning_reload", "lavt_conv3x3_wgrad_ws", "lavt_conv3x3_wgrad_f8_ok", "lavt_gemm_tn_grouped_sk_ws", "lavt_gemm_nt_colstats_plan", "lavt_cls_head_bwd_blocks", "lavt_reduce_partials_column_blocks"):      # queries, not launches: never timed
     setattr(lib, _name, getattr(_cdll, _name))
 
 EXPORTED = tuple(_PROTOTYPES) + ("lavt_last_error",)

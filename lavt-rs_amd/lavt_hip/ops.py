@@ -2212,21 +2212,32 @@ class _PwamGate(torch.autograd.Function):
         g = torch.empty(M, 2 * Cc, dtype=dtype, device=dev)                 # [d vpre | dq]: the A operand of the stacked data / weight gradient
         dwh = torch.empty_like(x)
         _note(f"mix1 {M}x{Cc}", 2.0 * M * Cc * KV_LD)
-        K.check(K.lib.lavt_pwam_mix(1, K.ptr(P), K.ptr(VWc), K.ptr(beta), None, K.ptr(_f32(bv)), K.ptr(vpre), Cc, K.ptr(dmm), Cc, K.ptr(g), 2 * Cc, K.ptr(dwh), Cc,
-                                    B, T, Cc, K.stream()))
-        # one zeroed side buffer for the targets of the split reductions (partial tiles, then += the fixed-order sum): H^T, s, G, colsum(dS)
-        nz = B * (Cc * KV_LD + Cc + KV_LD * Cc + KV_LD)
-        z = zero_arena.take(nz, torch.float32, dev)
-        o = 0
-        HT = z[o:o + B * Cc * KV_LD]; o += B * Cc * KV_LD
-        s = z[o:o + B * Cc]; o += B * Cc
-        G = z[o:o + B * KV_LD * Cc]; o += B * KV_LD * Cc
-        sdS = z[o:o + B * KV_LD]
         Qp = torch.empty(B * int(K.lib.lavt_pwam_q_parts(Cc)) * (KV_LD * KV_LD + KV_LD), dtype=torch.float32, device=dev)      # partial records, written plainly
-        gemm_tn(dtype, Cc, KV_LD, T, dwh, Cc, P, KV_LD, HT, KV_LD, batch=B, strideA=T * Cc, strideB=T * KV_LD, strideC=Cc * KV_LD, colsum=s, strideColsum=Cc)
         dVW = torch.empty(B * KV_LD, Cc, dtype=dtype, device=dev)
-        _note(f"lang {B}x{Cc}")
-        K.check(K.lib.lavt_pwam_lang_bwd1(K.ptr(HT), K.ptr(s), K.ptr(VWc), K.ptr(rw), K.ptr(pbar), K.ptr(cov), K.ptr(dVW), K.ptr(Qp), B, T, Cc, K.stream()))
+        # one zeroed side buffer for the targets of the split reductions (partial tiles, then += the fixed-order sum): G, colsum(dS) (+ H^T, s on the round-5 path)
+        if _PWAM_RECORDS:
+            # H^T = dwhat^T P and colsum(dwhat) as a by-product of the mix kernel: per-workgroup records that the language kernel adds
+            nrec1 = int(K.lib.lavt_pwam_mix1_records(B, T, Cc))
+            rec1 = _scratch(B * nrec1 * Cc * (KV_LD + 1), dev)
+            K.check(K.lib.lavt_pwam_mix1(K.ptr(P), K.ptr(VWc), K.ptr(beta), K.ptr(_f32(bv)), K.ptr(vpre), Cc, K.ptr(dmm), Cc, K.ptr(g), 2 * Cc, K.ptr(dwh), Cc, K.ptr(rec1),
+                                         B, T, Cc, K.stream()))
+            z = zero_arena.take(B * (KV_LD * Cc + KV_LD), torch.float32, dev)
+            G, sdS = z[:B * KV_LD * Cc], z[B * KV_LD * Cc:]
+            _note(f"lang {B}x{Cc}")
+            K.check(K.lib.lavt_pwam_lang_bwd1_records(None, None, K.ptr(rec1), nrec1, K.ptr(VWc), K.ptr(rw), K.ptr(pbar), K.ptr(cov), K.ptr(dVW), K.ptr(Qp), B, T, Cc, K.stream()))
+        else:
+            K.check(K.lib.lavt_pwam_mix(1, K.ptr(P), K.ptr(VWc), K.ptr(beta), None, K.ptr(_f32(bv)), K.ptr(vpre), Cc, K.ptr(dmm), Cc, K.ptr(g), 2 * Cc, K.ptr(dwh), Cc,
+                                        B, T, Cc, K.stream()))
+            nz = B * (Cc * KV_LD + Cc + KV_LD * Cc + KV_LD)
+            z = zero_arena.take(nz, torch.float32, dev)
+            o = 0
+            HT = z[o:o + B * Cc * KV_LD]; o += B * Cc * KV_LD
+            s = z[o:o + B * Cc]; o += B * Cc
+            G = z[o:o + B * KV_LD * Cc]; o += B * KV_LD * Cc
+            sdS = z[o:o + B * KV_LD]
+            gemm_tn(dtype, Cc, KV_LD, T, dwh, Cc, P, KV_LD, HT, KV_LD, batch=B, strideA=T * Cc, strideB=T * KV_LD, strideC=Cc * KV_LD, colsum=s, strideColsum=Cc)
+            _note(f"lang {B}x{Cc}")
+            K.check(K.lib.lavt_pwam_lang_bwd1(K.ptr(HT), K.ptr(s), K.ptr(VWc), K.ptr(rw), K.ptr(pbar), K.ptr(cov), K.ptr(dVW), K.ptr(Qp), B, T, Cc, K.stream()))
         dS = torch.empty_like(P)
         _note(f"words {M}x{Cc}", 2.0 * M * (Cc + KV_LD) * KV_LD)
         K.check(K.lib.lavt_pwam_words_bwd(K.ptr(dwh), Cc, K.ptr(VWw), K.ptr(Qp), K.ptr(pbar), K.ptr(P), K.ptr(dS), B, T, Cc, K.stream()))

@@ -1717,3 +1717,71 @@ def test_pwam_words_moments_by_product(B, T, C, n_l):
         assert_close(a[kname], b_[kname].cpu(), torch.float32, kname, f32=2e-3)
     assert_close(a["VWc"], b_["VWc"].float().cpu(), bf, "VWc", bf16=1e-2)
     assert torch.equal(a["VWc"].transpose(1, 2).contiguous(), a["VWw"]), "both layouts of VW' hold the same values"
+
+
+@pytest.mark.parametrize("B,T,C", [(2, 14400, 128), (2, 3600, 256), (2, 900, 512), (3, 225, 1024), (2, 50, 96), (1, 5000, 64)])
+def test_pwam_mix1_word_reduction_by_product(B, T, C):
+    """lavt_pwam_mix1: d vpre / d what as lavt_pwam_mix(1) writes them, records whose sum is H^T = dwhat^T P and colsum(dwhat) of THAT bf16 d what
+    (1 .. 32 records per sample, a last channel group of 32, rows that are no multiple of a tile); lavt_pwam_lang_bwd1_records on the records =
+    lavt_pwam_lang_bwd1 on the explicit TN product; run-to-run identical."""
+    from lavt_hip import _capi as K
+    from lavt_hip import ops
+    d = dev()
+    bf = torch.bfloat16
+    P = torch.softmax(rnd(B * T, 32, seed=1) * 2.0, dim=-1)
+    P[:, 20:] = 0.0
+    P = (P / P.sum(-1, keepdim=True)).to(bf).to(d)
+    VWc = (rnd(B, C, 32, seed=2) * 0.7).to(bf).to(d)
+    beta = (rnd(B, C, seed=3) * 0.3).to(d)
+    bv = (rnd(C, seed=4) * 0.2).to(d)
+    vpre = rnd(B * T, C, seed=5).to(bf).to(d)
+    dmm = (rnd(B * T, C, seed=6) * 1e-2).to(bf).to(d)
+
+    def old():
+        g = torch.empty(B * T, 2 * C, dtype=bf, device=d)
+        dwh = torch.empty(B * T, C, dtype=bf, device=d)
+        K.check(K.lib.lavt_pwam_mix(1, K.ptr(P), K.ptr(VWc), K.ptr(beta), None, K.ptr(bv), K.ptr(vpre), C, K.ptr(dmm), C, K.ptr(g), 2 * C, K.ptr(dwh), C, B, T, C, K.stream()))
+        return g, dwh
+
+    R = int(K.lib.lavt_pwam_mix1_records(B, T, C))
+    assert 1 <= R <= 32
+
+    def new():
+        g = torch.empty(B * T, 2 * C, dtype=bf, device=d)
+        dwh = torch.empty(B * T, C, dtype=bf, device=d)
+        rec = torch.full((B, R, C * 33), float("nan"), device=d)
+        K.check(K.lib.lavt_pwam_mix1(K.ptr(P), K.ptr(VWc), K.ptr(beta), K.ptr(bv), K.ptr(vpre), C, K.ptr(dmm), C, K.ptr(g), 2 * C, K.ptr(dwh), C, K.ptr(rec), B, T, C, K.stream()))
+        torch.cuda.synchronize()
+        return g, dwh, rec
+    g0, w0 = old()
+    g1, w1, rec = new()
+    g2, w2, rec2 = new()
+    assert torch.equal(rec, rec2) and torch.equal(w1, w2), "run-to-run identical"
+    assert_close(w1, w0.float().cpu(), bf, "d what", bf16=1e-2)
+    assert_close(g1[:, :C], g0[:, :C].float().cpu(), bf, "d vpre", bf16=1e-2)
+    wd, Pd = w1.reshape(B, T, C).double(), P.reshape(B, T, 32).double()
+    tot = rec.double().sum(1)
+    H_ref = torch.einsum("btc,btj->bcj", wd, Pd)
+    scale = float(H_ref.abs().max())
+    assert float((tot[:, :C * 32].reshape(B, C, 32) - H_ref).abs().max()) <= 2e-5 * scale, "sum of the records = dwhat^T P"
+    assert float((tot[:, C * 32:] - wd.sum(1)).abs().max()) <= 2e-5 * float(wd.sum(1).abs().max()), "sum of the records = colsum(dwhat)"
+    # the language kernel on the records against the same kernel on the explicit product of the same d what
+    HT = torch.zeros(B, C, 32, device=d)
+    s = torch.zeros(B, C, device=d)
+    ops.gemm_tn(bf, C, 32, T, w1, C, P, 32, HT, 32, batch=B, strideA=T * C, strideB=T * 32, strideC=C * 32, colsum=s, strideColsum=C)
+    rw = (1.0 + 0.1 * rnd(B, C, seed=7).abs()).to(d)
+    pbar = P.reshape(B, T, 32).float().mean(1)
+    cov = torch.einsum("btj,btk->bjk", P.reshape(B, T, 32).float(), P.reshape(B, T, 32).float()) / T - pbar[:, :, None] * pbar[:, None, :]
+    nq = int(K.lib.lavt_pwam_q_parts(C))
+
+    def lang(use_rec):
+        dVW = torch.empty(B * 32, C, dtype=bf, device=d)
+        Qp = torch.empty(B * nq * 1056, device=d)
+        K.check(K.lib.lavt_pwam_lang_bwd1_records(None if use_rec else K.ptr(HT), None if use_rec else K.ptr(s), K.ptr(rec) if use_rec else None, R if use_rec else 0,
+                                                  K.ptr(VWc), K.ptr(rw), K.ptr(pbar), K.ptr(cov), K.ptr(dVW), K.ptr(Qp), B, T, C, K.stream()))
+        torch.cuda.synchronize()
+        return dVW, Qp.reshape(B, nq, 1056).sum(1)
+    dv_a, q_a = lang(True)
+    dv_b, q_b = lang(False)
+    assert_close(dv_a, dv_b.float().cpu(), bf, "dVW", bf16=1e-2)
+    assert_close(q_a, q_b.cpu(), torch.float32, "Q / u", f32=2e-3)
