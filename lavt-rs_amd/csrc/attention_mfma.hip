@@ -619,7 +619,10 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     if (N > 400 || !table || !(dtable || parts) || !ws || bias_ld % 4) { lavt_set_error("lavt_window_attn_bwd(mfma): N=%d (<= 400), table, dtable and scratch required", N); return LAVT_ERR_INVALID; }
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
     // >= 2 workgroups per CU when there is that much work
-    int wpb = (int)(((long)nwin * heads + 767) / 768);
+    // (round 6: one window per workgroup up to 2048 units -- 800 units as 400 two-window workgroups took 39.7 us against 36.7 as 800 + pieces, 1152 units 56.5
+    // against 49.8: more workgroups than resident slots cost less than a second window behind the first.  LAVT_ATTN_WPB_UNITS = 768 restores the round-5 rule.)
+    static const long wpb_units = getenv("LAVT_ATTN_WPB_UNITS") ? atol(getenv("LAVT_ATTN_WPB_UNITS")) : 2048;
+    int wpb = (int)(((long)nwin * heads + wpb_units - 1) / wpb_units);
     if (wpb < 1) wpb = 1;
     const int chunks = cdiv(nwin, wpb);
     const int force_waves = lavt_tuning().attn_bwd_waves;

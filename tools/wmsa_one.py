@@ -10,7 +10,7 @@ from lavt_hip import ops, rowmaps
 from lib.backbone import SwinTransformerBlock
 dev = "cuda:0"
 lavt_hip.set_compute_dtype(torch.bfloat16)
-C, H, ws, B = 512, 30, 12, 2
+C, H, ws, B = 512, int(os.environ.get("WMSA_H", 30)), 12, int(os.environ.get("WMSA_B", 2))
 blk = SwinTransformerBlock(C, C // 32, ws, shift_size=ws // 2).to(dev)
 x = torch.randn(B * H * H, C, device=dev).to(torch.bfloat16)
 wmap = rowmaps.window_map(B, H, H, ws, blk.shift_size, dev)
