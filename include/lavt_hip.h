@@ -361,7 +361,8 @@ int lavt_layernorm_bwd_partial(int dtype, const void* dy, const void* x, const i
 int lavt_layernorm_bwd_partial_xn(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                                   void* dx, void* xn, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream);
 /* ABI v7: the same launch + the table-gradient binning job of an earlier lavt_window_attn_bwd_chained launch as rider workgroups (`job` as that call
- * returned it in *mine).  Returns 1 and launches NOTHING when this LayerNorm geometry has no rider form: issue the two launches separately. */
+ * returned it in *mine).  xn == beta == NULL: the plain form (lavt_layernorm_bwd_partial without gather).  Returns 1 and launches NOTHING when this
+ * LayerNorm geometry has no rider form: issue the two launches separately. */
 int lavt_layernorm_bwd_partial_xn_dtable(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                                          void* dx, void* xn, float* ws, int64_t ws_floats, const void* dres, int rows, int C, const lavt_dtable_job_t* job, void* stream);
 int lavt_layernorm_bwd_xn(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,

@@ -649,7 +649,7 @@ extern "C" int lavt_layernorm_bwd_partial_xn(int dtype, const void* dy, const vo
 // LayerNorm's geometry has no rider form (fp32, 8-wave or wide-row variants): the caller then issues the two launches on their own.
 extern "C" int lavt_layernorm_bwd_partial_xn_dtable(int dtype, const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                                                     void* dx, void* xn, float* ws, int64_t ws_floats, const void* dres, int rows, int C, const lavt_dtable_job_t* job, void* stream) {
-    LAVT_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && xn && ws && job && rows > 0, "lavt_layernorm_bwd_partial_xn_dtable: bad arguments");
+    LAVT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && ws && job && rows > 0 && ((xn != nullptr) == (beta != nullptr)), "lavt_layernorm_bwd_partial_xn_dtable: bad arguments");
     int lpr, cpl, waves;
     const int blocks = ln_bwd_geometry(dtype, rows, C, &lpr, &cpl, &waves);
     if (dtype != LAVT_BF16 || waves != 4 || cpl > 2 || C % 8 || ws_floats < (int64_t)blocks * 2 * C) return 1;
@@ -661,9 +661,11 @@ extern "C" int lavt_layernorm_bwd_partial_xn_dtable(int dtype, const void* dy, c
     const int riders = r.gx * r.heads * r.gz;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     using T = bf16;
-#define LN_BWD_DT(LPR_, CPL_) hipLaunchKernelGGL((layernorm_bwd_dtable_kernel<T, LPR_, CPL_, 2>), dim3(blocks + riders), dim3(256), lds, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, ws, (const T*)dres, rows, C, (T*)xn, beta, blocks, r)
+#define LN_BWD_DT_F(LPR_, CPL_, F_) hipLaunchKernelGGL((layernorm_bwd_dtable_kernel<T, LPR_, CPL_, F_>), dim3(blocks + riders), dim3(256), lds, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, ws, (const T*)dres, rows, C, (T*)xn, beta, blocks, r)
+#define LN_BWD_DT(LPR_, CPL_) do { if (xn) LN_BWD_DT_F(LPR_, CPL_, 2); else LN_BWD_DT_F(LPR_, CPL_, 0); } while (0)          /* (xn == NULL: the plain LayerNorm backward) */
     if (lpr == 16) LN_BWD_DT(16, 1); else if (lpr == 32) LN_BWD_DT(32, 1); else if (cpl == 1) LN_BWD_DT(64, 1); else LN_BWD_DT(64, 2);
 #undef LN_BWD_DT
+#undef LN_BWD_DT_F
     LAVT_CHECK_LAUNCH("lavt_layernorm_bwd_partial_xn_dtable");
     return LAVT_OK;
 }

@@ -1365,8 +1365,18 @@ class _LayerNorm(torch.autograd.Function):
             wsd = ln_deferred.alloc(nblk * 2 * ctx.C, x.device)
             if wsd is not None:
                 _note(f"ln-bwd {ctx.rows}x{ctx.C}", nbytes=(4.0 if dres is not None else 3.0) * ctx.rows * ctx.C * x.element_size())
-                K.check(K.lib.lavt_layernorm_bwd_partial(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(gather), K.ptr(_f32(gamma)), K.ptr(mean), K.ptr(rstd),
-                                                         K.ptr(dx), K.ptr(wsd), wsd.numel(), K.ptr(dres), ctx.rows, ctx.C, K.stream()))
+                job = dtable_chain.take_for_layernorm() if gather is None else None
+                rc = 1
+                if job is not None:          # a pending table-gradient binning job rides in this launch (the last one of a backward pass: the patch embedding's norm)
+                    rc = K.lib.lavt_layernorm_bwd_partial_xn_dtable(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(_f32(gamma)), None, K.ptr(mean), K.ptr(rstd), K.ptr(dx), None,
+                                                                    K.ptr(wsd), wsd.numel(), K.ptr(dres), ctx.rows, ctx.C, C.byref(job), K.stream())
+                    if rc == 0:
+                        dtable_chain.done_by_layernorm()
+                    elif rc != 1:
+                        K.check(rc)
+                if rc == 1:
+                    K.check(K.lib.lavt_layernorm_bwd_partial(K.dt(x.dtype), K.ptr(dy), K.ptr(x), K.ptr(gather), K.ptr(_f32(gamma)), K.ptr(mean), K.ptr(rstd),
+                                                             K.ptr(dx), K.ptr(wsd), wsd.numel(), K.ptr(dres), ctx.rows, ctx.C, K.stream()))
                 ln_deferred.add(wsd, nblk, ctx.C, dg, db, (gamma, beta))
                 return dx, None, None, None, None, None, None, None
         ws = _scratch(int(K.lib.lavt_layernorm_bwd_blocks(K.dt(x.dtype), ctx.rows, ctx.C)) * 2 * ctx.C, x.device)     # (without it the kernel falls back to same-address atomics)
