@@ -118,7 +118,7 @@ def measure_conv_kernel(device, iters=20):
     achieved = flops / (ms * 1e-3) / 1e12
     traffic, tsrc = None, None          # fabric-side bytes per launch from the committed rocprofv3 --pmc passes of this kernel: a recorded constant, not measured by this run
     try:
-        for fn in ("r05_pmc.json", "r04_pmc.json", "r02_pmc_conv_and_grouped_wgrad.json"):          # the newest committed pass of this kernel (tools/pmc_passes.sh conv_one)
+        for fn in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r02_pmc_conv_and_grouped_wgrad.json"):          # the newest committed pass of this kernel (tools/pmc_passes.sh conv_one)
             if os.path.exists(os.path.join(ROOT, "profiles", fn)):
                 traffic = int(json.load(open(os.path.join(ROOT, "profiles", fn)))["conv_one"]["derived"]["fabric_bytes (FETCH_SIZE KB x2 gfx950 correction + WRITE_SIZE KB)"])
                 tsrc = f"profiles/{fn} (recorded)"
@@ -247,7 +247,7 @@ def profile_step(step, cfg, device, reps=3):
         # fabric-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE on
         # tools/wgrad_group_one.py, the same five problems in token order): a recorded constant, not a measurement of this run
         try:
-            fn = next(f for f in ("r05_pmc.json", "r04_pmc.json", "r03_pmc_grouped_wgrad_and_wmsa.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            fn = next(f for f in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc_grouped_wgrad_and_wmsa.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pm = json.load(open(os.path.join(ROOT, "profiles", fn)))["wgrad_group_one"]["derived"]
             roof["traffic"] = int(pm["fabric_bytes (FETCH_SIZE KB x2 gfx950 correction + WRITE_SIZE KB)"])
             roof["traffic_source"] = f"profiles/{fn} (recorded)"
