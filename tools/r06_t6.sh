@@ -1,6 +1,7 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-timeout 900 python3 -m pytest tests/test_gpu_ops.py -q -x -k "layernorm or layer_norm or attention or attn or reduce" 2>&1 | tail -2
-timeout 1200 python3 -m pytest tests/test_gpu_modules.py -q -x -k "harness or train_step or block" 2>&1 | tail -2
-TL_TAG=lnhost3 bash tools/r06_timeline.sh
-tail -4 gpurun_out/r06_step_timeline_lnhost3.txt | cut -c1-150
+CFG="records_off LAVT_PWAM_RECORDS=0
+records_on LAVT_X=1"
+AB_ARGS="--workload swin_t_w7_480_b8" AB_CONFIGS="$CFG" AB_OUT=r06_l_pwam_records_ab_swint.txt bash tools/r06_ab.sh
+AB_ARGS="--workload swin_b_w12_480_b4" AB_CONFIGS="$CFG" AB_OUT=r06_l_pwam_records_ab_b4.txt bash tools/r06_ab.sh
+AB_ARGS="--workload video_swin_b_t8_384" AB_CONFIGS="$CFG" AB_OUT=r06_l_pwam_records_ab_video.txt bash tools/r06_ab.sh
