@@ -7,16 +7,17 @@ sys.path.insert(0, os.path.join(ROOT, "lavt-rs_amd"))
 import torch
 from lavt_hip import _capi as K
 dev, bf = "cuda:0", torch.bfloat16
-nwin, heads, ws = int(os.environ.get("ATTN_NWIN", 18)), int(os.environ.get("ATTN_HEADS", 16)), 12
-N, C = ws * ws, heads * 32
+nwin, heads, ws, wd = int(os.environ.get("ATTN_NWIN", 18)), int(os.environ.get("ATTN_HEADS", 16)), int(os.environ.get("ATTN_WS", 12)), int(os.environ.get("ATTN_WD", 1))
+N, C = wd * ws * ws, heads * 32          # ATTN_WD=8 ATTN_WS=7: the 392-token window of Video-Swin
 ld = -(-N // 32) * 32
 qkv = torch.randn(nwin * N, 3 * C, device=dev).to(bf)
 out = torch.empty(nwin * N, C, device=dev, dtype=bf); lse = torch.empty(nwin, heads, N, device=dev)
 dout = torch.randn_like(out); dqkv = torch.empty_like(qkv)
-dtable = torch.zeros((2 * ws - 1) ** 2, heads, device=dev)
-wsb = torch.empty(int(K.lib.lavt_window_attn_bwd_ws(K.dt(bf), nwin, N, heads, ld, 1, ws, ws)), device=dev)
-table = torch.randn((2 * ws - 1) ** 2, heads, device=dev) * 0.1
+R = (2 * wd - 1) * (2 * ws - 1) ** 2
+dtable = torch.zeros(R, heads, device=dev)
+wsb = torch.empty(int(K.lib.lavt_window_attn_bwd_ws(K.dt(bf), nwin, N, heads, ld, wd, ws, ws)), device=dev)
+table = torch.randn(R, heads, device=dev) * 0.1
 for _ in range(6):
-    K.check(K.lib.lavt_window_attn_fwd(K.dt(bf), K.ptr(qkv), None, ld, None, 0, K.ptr(out), K.ptr(lse), K.ptr(table), 1, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
-    K.check(K.lib.lavt_window_attn_bwd(K.dt(bf), K.ptr(qkv), None, ld, None, 0, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(table), K.ptr(dtable), K.ptr(wsb), wsb.numel(), None, 1, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
+    K.check(K.lib.lavt_window_attn_fwd(K.dt(bf), K.ptr(qkv), None, ld, None, 0, K.ptr(out), K.ptr(lse), K.ptr(table), wd, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
+    K.check(K.lib.lavt_window_attn_bwd(K.dt(bf), K.ptr(qkv), None, ld, None, 0, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(table), K.ptr(dtable), K.ptr(wsb), wsb.numel(), None, wd, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
 torch.cuda.synchronize()
