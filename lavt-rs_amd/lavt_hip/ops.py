@@ -1796,7 +1796,11 @@ conv_stats = _Proxy("conv_stats")
 
 
 class StepContext:
-    """the state the ops keep between calls (see the note at the top of this module).  `with use_context(ctx):` makes it current."""
+    """the state the ops keep between calls (see the note at the top of this module).  `with use_context(ctx):` makes it current.
+
+    The current context is ONE pointer per process, not per thread, on purpose: autograd runs the backward of GPU ops on its own worker thread, which has to
+    see the context of the thread that called `backward()` inside the `with` block (and that thread is blocked meanwhile).  Harnesses in private contexts
+    can therefore alternate freely, but two host threads must not run forward / backward passes at the same time."""
 
     def __init__(self):
         self.weights = _WeightCache()
