@@ -538,10 +538,12 @@ int64_t lavt_window_attn_bwd_ws_mfma(int nwin, int N, int heads, int bias_ld, in
 // several layers' per-workgroup table histograms -> their table gradients in ONE launch (deferred form): desc[s] = {part, pieces, heads, R, dtable}
 // COMPACT (round 5): blockIdx.y runs over the (layer, head) pairs that exist (the host passes their number) instead of (max heads) x (layers): Swin-B's
 // 24 layers have 4 / 8 / 16 / 32 heads, so the (17, 32, 24) grid started 13 056 workgroups of which 6 664 found no head -- an 18 us launch for ~10 MB.
+constexpr int DF_ENT = 128, DF_PL = 256 / DF_ENT;
 template <bool COMPACT>
 __global__ __launch_bounds__(256) void wattn_dtable_finish_multi(const int64_t* __restrict__ desc, int nsets) {
-    // 32 table entries x 8 piece lanes per workgroup (one thread per entry walking all pieces -- 252 for a stage-0 layer -- was a 38 us launch)
-    __shared__ float red[8][32];
+    // DF_ENT table entries x DF_PL piece lanes per workgroup (one thread per entry walking all pieces -- 252 for a stage-0 layer -- was a 38 us launch; 32 x 8: 6 392
+    // workgroups for Swin-B, 23 us -- the launch is bound by their number)
+    __shared__ float red[DF_PL][DF_ENT];
     int set = blockIdx.z, h = blockIdx.y;
     if constexpr (COMPACT) {
         // lane s reads the head count of set s (nsets <= 64); an inclusive prefix sum over the lanes; the first lane whose sum exceeds blockIdx.y names the set
@@ -562,38 +564,38 @@ __global__ __launch_bounds__(256) void wattn_dtable_finish_multi(const int64_t* 
     const float* part = reinterpret_cast<const float*>(d[0]);
     const int pieces = (int)d[1], heads = (int)d[2], R = (int)d[3];
     float* dtable = reinterpret_cast<float*>(d[4]);
-    const int el = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + el;
-    if (h >= heads || blockIdx.x * 32 >= R) return;          // uniform per workgroup
+    const int el = threadIdx.x % DF_ENT, pl = threadIdx.x / DF_ENT;
+    const int e = blockIdx.x * DF_ENT + el;
+    if (h >= heads || blockIdx.x * DF_ENT >= R) return;          // uniform per workgroup
     const int64_t st = (int64_t)heads * R;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (e < R) {
         const float* q = part + (int64_t)h * R + e;
         int k = pl;
-        for (; k + 120 < pieces; k += 128) {          // (sixteen pieces in flight per thread: a stage-0 layer's 252 pieces were 8 dependent rounds of 4 -- the launch is latency)
+        for (; k + 15 * DF_PL < pieces; k += 16 * DF_PL) {          // (sixteen pieces in flight per thread: a stage-0 layer's 252 pieces were 8 dependent rounds of 4 -- the launch is latency)
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = q[(int64_t)(k + 8 * u) * st];
+            for (int u = 0; u < 16; ++u) v[u] = q[(int64_t)(k + DF_PL * u) * st];
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc[u & 3] += v[u];
         }
-        for (; k + 24 < pieces; k += 32)
+        for (; k + 3 * DF_PL < pieces; k += 4 * DF_PL)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] += q[(int64_t)(k + 8 * u) * st];
-        for (; k < pieces; k += 8) acc[0] += q[(int64_t)k * st];
+            for (int u = 0; u < 4; ++u) acc[u] += q[(int64_t)(k + DF_PL * u) * st];
+        for (; k < pieces; k += DF_PL) acc[0] += q[(int64_t)k * st];
     }
     red[pl][el] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
     if (pl == 0 && e < R) {
         float a = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a += red[k][el];
+        for (int k = 0; k < DF_PL; ++k) a += red[k][el];
         dtable[(int64_t)e * heads + h] += a;                 // one writer per entry: the zeroed gradient buffer
     }
 }
 int lavt_attn_dtable_finish_multi_impl(const int64_t* desc, int n, int max_R, int max_heads, int total_heads, hipStream_t st) {
-    if (total_heads > 0 && n <= 64) hipLaunchKernelGGL(wattn_dtable_finish_multi<true>, dim3(cdiv(max_R, 32), total_heads, 1), dim3(256), 0, st, desc, n);
-    else hipLaunchKernelGGL(wattn_dtable_finish_multi<false>, dim3(cdiv(max_R, 32), max_heads, n), dim3(256), 0, st, desc, n);
+    if (total_heads > 0 && n <= 64) hipLaunchKernelGGL(wattn_dtable_finish_multi<true>, dim3(cdiv(max_R, DF_ENT), total_heads, 1), dim3(256), 0, st, desc, n);
+    else hipLaunchKernelGGL(wattn_dtable_finish_multi<false>, dim3(cdiv(max_R, DF_ENT), max_heads, n), dim3(256), 0, st, desc, n);
     LAVT_CHECK_LAUNCH("lavt_attn_dtable_finish_multi");
     return LAVT_OK;
 }
