@@ -246,6 +246,15 @@ __global__ __launch_bounds__(512, 4) void wmsa_fwd_fused_kernel(const WmsaArgs a
     }
     __syncthreads();
 
+    // (round 6) the raw rows of this head's 32-column slice for the LayerNorm-output tail below: requested here, used after the attention phase
+    constexpr int XS = (NP * 4 + NTHR - 1) / NTHR;
+    uint4 xs[XS];
+#pragma unroll
+    for (int k = 0; k < XS; ++k) {
+        const int e = tid + k * NTHR, row = min(e >> 2, N - 1), c = e & 3;
+        const int src = srcs[row];
+        xs[k] = *reinterpret_cast<const uint4*>(a.x + (int64_t)(src >= 0 ? src : 0) * C + h * HD + c * 8);
+    }
     // ---- phase 2: attention core on the LDS copies (as wattn_fwd_mfma, attention_mfma.hip; a wave owns at most two query tiles, so the K / V^T
     // fragments are read per tile instead of being kept in registers) ---------------------------------------------------------------------------
     const float sc2 = a.scale * LOG2E;
@@ -309,19 +318,23 @@ __global__ __launch_bounds__(512, 4) void wmsa_fwd_fused_kernel(const WmsaArgs a
                          make_uint2(pack_bf16x2(o[0][0] * inv, o[0][1] * inv), pack_bf16x2(o[0][2] * inv, o[0][3] * inv)),
                          make_uint2(pack_bf16x2(o[1][0] * inv, o[1][1] * inv), pack_bf16x2(o[1][2] * inv, o[1][3] * inv)), vi);
     }
-    // this head's 32-column slice of the LayerNorm output (operand of the qkv weight gradient) + the row statistics (LayerNorm backward)
-    for (int e = tid; e < N * 4; e += NTHR) {          // (last: off the critical path of the attention phase; mu / rsd / srcs live outside the aliased ring)
+    // this head's 32-column slice of the LayerNorm output (operand of the qkv weight gradient) + the row statistics (LayerNorm backward): the raw rows were
+    // requested in front of the attention phase (xs), so only the arithmetic and the store are left here
+#pragma unroll
+    for (int k = 0; k < XS; ++k) {
+        const int e = tid + k * NTHR;
+        if (e >= N * 4) continue;
         const int row = e >> 2, c = e & 3;
         const int src = srcs[row];
         if (src < 0) continue;
         float f[8];
-        chunk_to_f<bf16>(*reinterpret_cast<const uint4*>(a.x + (int64_t)src * C + h * HD + c * 8), f);
+        chunk_to_f<bf16>(xs[k], f);
         const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + h * HD + c * 8), g1 = *reinterpret_cast<const float4*>(a.gamma + h * HD + c * 8 + 4);
         const float4 e0 = *reinterpret_cast<const float4*>(a.beta + h * HD + c * 8), e1 = *reinterpret_cast<const float4*>(a.beta + h * HD + c * 8 + 4);
         const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
         const float mr = mu[row], rr = rsd[row];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) f[k] = (f[k] - mr) * rr * gm[k] + bt[k];
+        for (int q = 0; q < 8; ++q) f[q] = (f[q] - mr) * rr * gm[q] + bt[q];
         *reinterpret_cast<uint4*>(a.xn + (int64_t)src * C + h * HD + c * 8) = f_to_chunk<bf16>(f);
         if (h == 0 && c == 0) { a.mean[src] = mr; a.rstd[src] = rr; }
     }
