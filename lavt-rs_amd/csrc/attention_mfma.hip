@@ -58,33 +58,44 @@ __device__ __forceinline__ void store_head_row16(bf16* row_head, int g, uint2 p0
 }
 
 // ================================================================================================ forward
-// One workgroup (4 waves) per (window, head).  Q, K, V are staged once into LDS by all 256 threads (one round of 16-byte loads in
+// One workgroup (4 waves; 8 for the 25-tile windows) per (window, head).  Q, K, V are staged once into LDS by all threads (one round of 16-byte loads in
 // flight instead of the per-wave, per-row latency chain of a one-wave-per-pair kernel: measured 25 us per layer whatever the size);
 // the head's column of the relative-position table sits in LDS too (bias[i][j] = tab[base[i] - base[j] + centre]), so the query-tile loop
-// touches no global memory except its stores.  A wave owns query tiles it = wave, wave + 4, ...; it keeps the K fragments (A operand of
+// touches no global memory except its stores.  A wave owns query tiles it = wave, wave + WAVES, ...; it keeps the K fragments (A operand of
 // S^T = K Q^T) and the V^T fragments (A operand of O^T = V^T P^T, transposing LDS read) in registers for all its tiles.
 // S^T puts one query per lane column: softmax reductions are in-register + two shuffles, and the un-normalised P^T accumulators of two
 // key tiles are directly the B operand of the second MFMA (no LDS round trip for P).
 constexpr int F_LD = 40;        // bf16 elements per LDS row of Q / K / V (80 B)
 
-// Arithmetic diet (the kernels are VALU-issue bound: rocprofv3 counters, profiles/r02_pmc_attention.json): scores live in the log2 domain
-// (table column and scale pre-multiplied by log2 e when staged, so the exponential is the bare v_exp_f32), the shift-mask compare is compiled
-// out for unshifted blocks (REGION), and with FULL (N == 16 NT: no padded key / query inside a real tile) the bounds selects and the whole
-// padding tile of an odd tile count disappear.
+// Arithmetic diet (the 392-token kernels are VALU-issue bound: rocprofv3 counters, profiles/r02_pmc_attention.json, r06_pmc_attn_392_tokens.json): scores live
+// in the log2 domain (table column and scale pre-multiplied by log2 e when staged, so the exponential is the bare v_exp_f32), the shift-mask compare is compiled
+// out for unshifted blocks (REGION), the padding tile of an odd tile count costs no arithmetic, and padded tokens need no bounds select in any tile: the
+// staged constants make their terms vanish (round 6, below).
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
-template <int NT, bool REGION, bool FULL>
-__global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lds_f32_at(uint32_t addr) { return *reinterpret_cast<lds_f32*>(addr); }
+
+// Round 6: the instruction diet of the backward below applied to the forward (before: 26 VALU instructions per MFMA in the 392-token launch, and ONE wave per
+// SIMD -- 112 KB of LDS, one 4-wave workgroup per CU; 39.8 -> 27.9 us for 16 x 16 units of 392 tokens, shifted 48.4 -> 31.7; 144- and 49-token windows +-1 us):
+//   * WAVES = 8 for the 25-tile windows: two waves per SIMD (the K / V tiles are staged once per workgroup either way; 25 query tiles on 8 waves);
+//   * table gather with byte offsets (one subtraction per element); a padded KEY carries an offset that lands every query in a run of -1e30 entries behind
+//     the table (its probability is exp2(-1e30 - max) = 0): no bounds select in any tile;
+//   * shift mask as one AND + compare + select + add per element on the XOR of the packed region ids; row sum as packed adds.
+template <int NT, int WAVES, bool REGION>
+__global__ __launch_bounds__(WAVES * 64) void wattn_fwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                       const int8_t* __restrict__ region, int nw_img, bf16* __restrict__ out,
                                                       float* __restrict__ lse, int wd, int wh, int ww, int nwin, int N, int heads, float scale) {
-    constexpr int KS = (NT + 1) / 2, NP = KS * 32;
+    constexpr int KS = (NT + 1) / 2, NP = KS * 32, NTHR = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16* Qs = reinterpret_cast<bf16*>(smem_raw);
     bf16* Ks = Qs + NP * F_LD;
     bf16* Vs = Ks + NP * F_LD;
     int* bs = reinterpret_cast<int*>(Vs + NP * F_LD);
     uint8_t* Rs = reinterpret_cast<uint8_t*>(bs + NP);
-    float* tab = reinterpret_cast<float*>(Rs + NP);
+    float* tab = reinterpret_cast<float*>(Rs + NP);        // [R] table column * log2 e, then [centre + 1] x -1e30
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int w = blockIdx.x / heads, h = blockIdx.x % heads;
     const int C = heads * HD;
@@ -92,7 +103,7 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
     const int centre = ((wd - 1) * (2 * wh - 1) + (wh - 1)) * (2 * ww - 1) + (ww - 1);
     const bf16* base = qkv + (int64_t)w * N * 3 * C + h * HD;
 
-    for (int e = tid; e < NP * 4; e += 256) {
+    for (int e = tid; e < NP * 4; e += NTHR) {
         const int row = e >> 2, c = e & 3;
         uint4 q = make_uint4(0, 0, 0, 0), k = q, v = q;
         if (row < N) {
@@ -105,25 +116,25 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
         *reinterpret_cast<uint4*>(Ks + row * F_LD + c * 8) = k;
         *reinterpret_cast<uint4*>(Vs + row * F_LD + c * 8) = v;
     }
-    for (int e = tid; e < NP; e += 256) {
+    for (int e = tid; e < NP; e += NTHR) {
         const int dz = e / (wh * ww), hy = (e / ww) % wh, wx = e % ww;
-        bs[e] = (dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx;
+        // byte offsets; a padded token: idx_i - idx_j + centre = R + idx_i for every query i, i.e. the -1e30 run behind the table (idx_i <= centre)
+        bs[e] = e < N ? 4 * ((dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx) : -4 * (R - centre);
         Rs[e] = (region && e < N) ? (uint8_t)region[(int64_t)(w % nw_img) * N + e] : 0;
     }
-    for (int e = tid; e < R; e += 256) tab[e] = table[(int64_t)e * heads + h] * LOG2E;
+    for (int e = tid; e < R + centre + 1; e += NTHR) tab[e] = e < R ? table[(int64_t)e * heads + h] * LOG2E : -1e30f;
     __syncthreads();
 
     const int QT = (N + 15) / 16;
     if (wave >= QT) return;
     const float sc2 = scale * LOG2E;
-    // Up to 10 key tiles (12x12 windows) the K and V^T fragments stay in registers for all query tiles of the wave; the 25-tile windows of
-    // Video-Swin (8x7x7 = 392 tokens) re-read them from LDS per query tile (their score block alone is 104 registers).
+    const f32x4 sc4 = {sc2, sc2, sc2, sc2};
+    const uint32_t tab_c = (uint32_t)reinterpret_cast<uintptr_t>((lds_f32*)tab) + 4u * (uint32_t)centre;
     constexpr bool CACHE = NT <= 10;
     constexpr int NC = CACHE ? NT : 1, KC = CACHE ? KS : 1;
     bf16x8 kf[NC], vf[2][KC];
     auto k_frag = [&](int t) { return lds_row8(Ks, F_LD, 16 * t + c16, 8 * g); };
     auto v_frag = [&](int u, int ks) {
-        // k-slot (g, jj) <-> key j = 32 ks + 16 (jj >> 2) + 4 g + (jj & 3): matches the accumulator rows of tiles 2ks, 2ks+1
         const bf16* p = Vs + (32 * ks + 4 * g + (c16 >> 2)) * F_LD + 16 * u + 4 * (c16 & 3);
         return join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p), __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * F_LD)));
     };
@@ -136,52 +147,57 @@ __global__ __launch_bounds__(256) void wattn_fwd_mfma(const bf16* __restrict__ q
             for (int ks = 0; ks < KS; ++ks) vf[u][ks] = v_frag(u, ks);
     }
 
-    for (int it = wave; it < QT; it += 4) {
+    for (int it = wave; it < QT; it += WAVES) {
         const int i = 16 * it + c16;
         const bool vi = i < N;
         const bf16x8 qf = lds_row8(Qs, F_LD, i, 8 * g);
-        const int rid_i = Rs[i], bi = bs[i] + centre;
+        const uint32_t ri4 = REGION ? 0x01010101u * Rs[i] : 0u;
+        const uint32_t bi = tab_c + (uint32_t)bs[i];           // (a padded query lane gathers from wherever: its column is discarded)
         f32x4 s[2 * KS];
         float mx = -1e30f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CACHE ? kf[CACHE ? t : 0] : k_frag(t), qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             const int j0 = 16 * t + 4 * g;
-            const int4 bj = *reinterpret_cast<const int4*>(bs + j0);
-            const f32x4 bb = {tab[bi - bj.x], tab[bi - bj.y], tab[bi - bj.z], tab[bi - bj.w]};
-            f32x4 v = acc * sc2 + bb;
+            const u32x4 bj = *reinterpret_cast<const u32x4*>(bs + j0);
+            const f32x4 bb = {lds_f32_at(bi - bj[0]), lds_f32_at(bi - bj[1]), lds_f32_at(bi - bj[2]), lds_f32_at(bi - bj[3])};
+            f32x4 v = __builtin_elementwise_fma(acc, sc4, bb);
             if constexpr (REGION) {
-                const uint32_t rj = *reinterpret_cast<const uint32_t*>(Rs + j0);
+                const uint32_t x = *reinterpret_cast<const uint32_t*>(Rs + j0) ^ ri4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += ((int)((rj >> (8 * r)) & 0xFF) != rid_i) ? -100.0f * LOG2E : 0.f;
-            }
-            if constexpr (!FULL) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (j0 + r < N) ? v[r] : -1e30f;
+                for (int r = 0; r < 4; ++r) v[r] += (x & (0xFFu << (8 * r))) ? -100.0f * LOG2E : 0.f;
             }
             s[t] = v;
             mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+            // (25 tiles: left alone the scheduler hoists every tile's LDS reads to the top -- 434 registers; at the 256 of two waves per SIMD that spilt 76)
+            if constexpr (!CACHE) { if (t % 2 == 1) __builtin_amdgcn_sched_barrier(0); }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
+        const float nmx = -mx;
+        f32x4 sum4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 2 * KS; ++t) {
             if (t < NT) {
-                const f32x4 d = s[t] - mx;
+                const f32x4 d = s[t] + nmx;
+                f32x4 p;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(d[r]); s[t][r] = p; sum += p; }
-            } else s[t] = f32x4{0.f, 0.f, 0.f, 0.f};          // padding tile of an odd tile count: zero probabilities, no arithmetic
+                for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(d[r]);
+                s[t] = p;
+                sum4 += p;
+            } else s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         if (vi && g == 0) lse[((int64_t)w * heads + h) * N + i] = (mx + __log2f(sum)) * LN2;
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 pf;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16)s[2 * ks + (jj >> 2)][jj & 3];
+            u32x4 pw;
+            pw[0] = pack_bf16x2(s[2 * ks][0], s[2 * ks][1]); pw[1] = pack_bf16x2(s[2 * ks][2], s[2 * ks][3]);
+            pw[2] = pack_bf16x2(s[2 * ks + 1][0], s[2 * ks + 1][1]); pw[3] = pack_bf16x2(s[2 * ks + 1][2], s[2 * ks + 1][3]);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
             o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CACHE ? vf[0][CACHE ? ks : 0] : v_frag(0, ks), pf, o[0], 0, 0, 0);
             o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CACHE ? vf[1][CACHE ? ks : 0] : v_frag(1, ks), pf, o[1], 0, 0, 0);
         }
@@ -218,21 +234,33 @@ struct DtableJob {
     int slab_ld, wd, wh, ww, nwin, N, heads, rows_per_block, win_per_group, gx, gz;      // gx, gz: the binning grid (gy = heads)
 };
 
-template <int NT, int WAVES, bool REGION, bool FULL>
+// Round 6: the instruction diet (before: 16.5 VALU instructions per MFMA in the 392-token launch, SGPR pairs of the per-tile select masks spilt into VGPR
+// lanes; 69.4 -> 57.2 us for 16 x 16 units of 392 tokens, shifted 81.3 -> 62.4; the 144-token launches are latency-bound and did not move: 17.3 us either way):
+//   * table gather: bs[] holds BYTE offsets (4 x index) and the per-task constant carries the table's LDS address and the centre, so an element's address is
+//     ONE subtraction (was: subtract, shift-add);
+//   * lse and delta are staged NEGATED: bias + (-lse) and dP + (-delta) are packed adds (v_pk_add_f32: two per quadruple instead of four subtractions);
+//   * the shift mask is a select AFTER the exponential (masked probabilities are < 2^-144 x e^(s - lse): zero in bf16 either way) -- compare + select per
+//     element instead of extract, compare, select, add;
+//   * padding selects only in the one tile that has padding (compile-time tile index) and only for the operand that is not discarded with its lane;
+//   * the dS slab takes the two packed words the MFMA operand is made of (no second conversion, no re-pack), through a buffer descriptor over the
+//     (window, head) slab: a lane without a row carries an offset beyond the descriptor (the hardware drops the store) -- no branch, no 64-bit address per tile.
+
+template <int NT, int WAVES, bool REGION>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void wattn_bwd_mfma(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                       const int8_t* __restrict__ region, int nw_img, const bf16* __restrict__ out,
                                                       const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                       bf16* __restrict__ dqkv, bf16* __restrict__ slab, int slab_ld,
                                                       int wd, int wh, int ww, int nwin, int N, int heads, float scale, int win_per_block,
                                                       int attn_blocks, const DtableJob job, const int split_from, const int split_pieces) {
-    constexpr int KS = (NT + 1) / 2, NP = KS * 32;         // tiles are consumed in pairs (k = 32)
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KS = (NT + 1) / 2, NP = KS * 32;
     constexpr int NTHR = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if constexpr (WAVES == 8) {
         if ((int)blockIdx.x >= attn_blocks) {              // riders: the previous launch's binning, two 256-thread binning blocks per workgroup
+            // (both halves take the same barriers: a half without a unit runs on unit 0's geometry with its stores masked off)
             const int half = threadIdx.x >> 8, u = 2 * ((int)blockIdx.x - attn_blocks) + half;
             const int units = job.gx * job.heads * job.gz;
-            // (both halves take the same barriers: a half without a unit runs on unit 0's geometry with its stores masked off)
             const int uu = u < units ? u : 0;
             const int bx = uu % job.gx, hh = (uu / job.gx) % job.heads, bz = uu / (job.gx * job.heads);
             const int R = (2 * job.wd - 1) * (2 * job.wh - 1) * (2 * job.ww - 1);
@@ -245,11 +273,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
     bf16* Ks = Qs + NP * R_LD;
     bf16* Vs = Ks + NP * R_LD;
     bf16* Os = Vs + NP * R_LD;                             // dO
-    float* dl = reinterpret_cast<float*>(Os + NP * R_LD);  // delta_i = sum_d dO*O
-    float* ls = dl + NP;                                   // lse_i * log2 e
-    int* bs = reinterpret_cast<int*>(ls + NP);             // table-index base of token i
+    float* dl = reinterpret_cast<float*>(Os + NP * R_LD);  // -delta_i = -sum_d dO*O
+    float* ls = dl + NP;                                   // -lse_i * log2 e
+    int* bs = reinterpret_cast<int*>(ls + NP);             // 4 x table-index base of token i (a byte offset)
     uint8_t* Rs = reinterpret_cast<uint8_t*>(bs + NP);
-    float* tab = reinterpret_cast<float*>(Rs + NP);        // this head's column of the bias table * log2 e, [(2wd-1)(2wh-1)(2ww-1)]
+    float* tab = reinterpret_cast<float*>(Rs + NP);        // this head's column of the bias table * log2 e
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int QT = (N + 15) / 16;
@@ -268,14 +296,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
     const int centre = ((wd - 1) * (2 * wh - 1) + (wh - 1)) * (2 * ww - 1) + (ww - 1);
     const float sc2 = scale * LOG2E;
+    const f32x4 sc4 = {sc2, sc2, sc2, sc2};
+    const uint32_t tab_c = (uint32_t)reinterpret_cast<uintptr_t>((lds_f32*)tab) + 4u * (uint32_t)centre;       // LDS address of tab[centre]
     for (int e = tid; e < R; e += NTHR) tab[e] = table[(int64_t)e * heads + h] * LOG2E;
     for (int e = tid; e < NP; e += NTHR) {
         const int dz = e / (wh * ww), hy = (e / ww) % wh, wx = e % ww;
-        bs[e] = (dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx;
+        bs[e] = e < N ? 4 * ((dz * (2 * wh - 1) + hy) * (2 * ww - 1) + wx) : 0;          // (padded tokens: any index inside the table -- their bias must be FINITE, see below)
     }
     // Task list of a window: t < QT -> pass 1 of key tile t; QT <= t < 2 QT -> pass 2 of query tile t - QT.  A wave takes t = slot, slot + WAVES, ...
-    // (9 tiles on 8 waves: 3, 3, 2, ... tasks instead of one wave running 2 + 2).  The kernel is VALU-issue bound and waves w, w + 4 share a SIMD,
-    // so workgroups that are likely to share a CU (the grid's second round of 256) start the list two slots later: the heavy SIMDs differ.
+    // (9 tiles on 8 waves: 3, 3, 2, ... tasks instead of one wave running 2 + 2).  Waves w, w + 4 share a SIMD, so workgroups that are likely to share a
+    // CU (the grid's second round of 256) start the list two slots later: the heavy SIMDs differ.
     // (9 waves of exactly one pass-1 and one pass-2 task -- 96 VGPRs for two workgroups per CU, 34 spills in the shifted variant -- measured
     // slower: 36.7 vs 34.1 us with the table kernels for the stage-2 launch, 10.77 vs 10.50 ms per step.)
     const int slot = (wave + 2 * ((unit >> 8) & 1)) % WAVES;
@@ -283,7 +313,6 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
     const int w_end = min(nwin, (chunk + 1) * win_per_block);
     for (int w = chunk * win_per_block; w < w_end; ++w) {
         __syncthreads();
-        // ---- stage Q, K, V, dO (rows >= N are zero), delta_i, lse_i, region ids ------------------------------------
         const bf16* base = qkv + (int64_t)w * N * 3 * C + h * HD;
         for (int e = tid; e < NP * 4; e += NTHR) {
             const int row = e >> 2, c = e & 3;
@@ -308,11 +337,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
             for (int x = 0; x < 8; ++x) part += fd[x] * fo[x];
             part += __shfl_xor(part, 1, 64);
             part += __shfl_xor(part, 2, 64);
-            if (c == 0) { dl[row] = part; ls[row] = row < N ? lse[((int64_t)w * heads + h) * N + row] * LOG2E : 0.f; }
+            if (c == 0) { dl[row] = -part; ls[row] = row < N ? -lse[((int64_t)w * heads + h) * N + row] * LOG2E : -1e30f; }
         }
         if constexpr (REGION)
             for (int e = tid; e < NP; e += NTHR) Rs[e] = e < N ? (uint8_t)region[(int64_t)(w % nw_img) * N + e] : 0;
         __syncthreads();
+        // this (window, head)'s dS slab [N][slab_ld] behind a raw buffer descriptor (offsets at or beyond its size: the store is dropped)
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(slab + ((int64_t)w * heads + h) * N * slab_ld, 0, N * slab_ld * 2, 0x00020000);
 
 #pragma unroll 1
         for (int t = t_lo + slot; t < t_hi; t += WAVES) {
@@ -322,46 +353,43 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
             const int j = 16 * jt + c16;
             const bf16x8 kfr = lds_row8(Ks, R_LD, j, 8 * g);
             const bf16x8 vfr = lds_row8(Vs, R_LD, j, 8 * g);
-            const int rj = REGION ? Rs[j] : 0;
+            const uint32_t rj4 = REGION ? 0x01010101u * Rs[j] : 0u;
             f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dk[2] = {dv[0], dv[0]};
-            const int bj = bs[j] - centre;                 // bias[i][j] = tab[bs[i] - bs[j] + centre]
+            const uint32_t bj = tab_c - (uint32_t)bs[j];              // + bs[i]: the LDS address of tab[idx_i - idx_j + centre]
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 pp, dp8;
+                u32x4 ppw, dsw;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int it = 2 * ks + half;
-                    if (FULL && it >= NT) {                // the padding tile of an odd tile count: zero fragments, no arithmetic
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { pp[half * 4 + r] = (bf16)0.f; dp8[half * 4 + r] = (bf16)0.f; }
+                    if (it >= NT) {                        // the padding tile of an odd tile count: zero fragments, no arithmetic
+                        ppw[2 * half] = 0u; ppw[2 * half + 1] = 0u; dsw[2 * half] = 0u; dsw[2 * half + 1] = 0u;
                         continue;
                     }
                     const bf16x8 qf = lds_row8(Qs, R_LD, 16 * it + c16, 8 * g);
                     const bf16x8 of = lds_row8(Os, R_LD, 16 * it + c16, 8 * g);
                     const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kfr, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, vfr, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    // per-query constants of the 4 rows this lane holds: vector LDS reads (rows >= N hold lse = delta = 0)
                     const int i0 = 16 * it + 4 * g;
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + i0), d4 = *reinterpret_cast<const f32x4*>(dl + i0);
-                    const int4 bi4 = *reinterpret_cast<const int4*>(bs + i0);
-                    const f32x4 bb = {tab[bi4.x - bj], tab[bi4.y - bj], tab[bi4.z - bj], tab[bi4.w - bj]};
-                    f32x4 a = s * sc2 + (bb - l4);
-                    if constexpr (REGION) {
-                        const uint32_t ri4 = *reinterpret_cast<const uint32_t*>(Rs + i0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) a[r] += ((int)((ri4 >> (8 * r)) & 0xFF) != rj) ? -100.0f * LOG2E : 0.f;
-                    }
+                    const f32x4 nl4 = *reinterpret_cast<const f32x4*>(ls + i0), nd4 = *reinterpret_cast<const f32x4*>(dl + i0);
+                    const u32x4 bi4 = *reinterpret_cast<const u32x4*>(bs + i0);
+                    const f32x4 bb = {lds_f32_at(bj + bi4[0]), lds_f32_at(bj + bi4[1]), lds_f32_at(bj + bi4[2]), lds_f32_at(bj + bi4[3])};
+                    const f32x4 a = __builtin_elementwise_fma(s, sc4, bb + nl4);
                     f32x4 p;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        p[r] = __builtin_amdgcn_exp2f(a[r]);
-                        if constexpr (!FULL) p[r] = (i0 + r < N && j < N) ? p[r] : 0.f;      // branch-free: padded rows / columns contribute exactly zero
-                    }
-                    const f32x4 ds = p * (dp - d4);
+                    for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(a[r]);
+                    if constexpr (REGION) {
+                        const uint32_t x = *reinterpret_cast<const uint32_t*>(Rs + i0) ^ rj4;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { pp[half * 4 + r] = (bf16)p[r]; dp8[half * 4 + r] = (bf16)ds[r]; }
+                        for (int r = 0; r < 4; ++r) p[r] = (x & (0xFFu << (8 * r))) ? 0.f : p[r];
+                    }
+                    // No padding selects: a padded QUERY row carries -lse = -1e30 (P = exp2(-1e30) = 0, dS = 0 x finite); a padded KEY lane holds finite values
+                    // (zero K / V rows, a bias from inside the table) in the dV / dK columns that are discarded with it.
+                    const f32x4 ds = p * (dp + nd4);
+                    ppw[2 * half] = pack_bf16x2(p[0], p[1]); ppw[2 * half + 1] = pack_bf16x2(p[2], p[3]);
+                    dsw[2 * half] = pack_bf16x2(ds[0], ds[1]); dsw[2 * half + 1] = pack_bf16x2(ds[2], ds[3]);
                 }
-                // B operands [k = query i][n = d]: transposing reads of dO / Q, k-slot (g, jj) <-> i = 32 ks + 16 (jj >> 2) + 4 g + (jj & 3)
+                const bf16x8 pp = __builtin_bit_cast(bf16x8, ppw), dp8 = __builtin_bit_cast(bf16x8, dsw);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int off = (32 * ks + 4 * g + (c16 >> 2)) * R_LD + 16 * u + 4 * (c16 & 3);
@@ -369,13 +397,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
                                             __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Os + off + 16 * R_LD)));
                     const bf16x8 qt = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Qs + off)),
                                             __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Qs + off + 16 * R_LD)));
-                    // operands swapped (a B fragment of X is the A fragment of X^T): the accumulators hold dV^T / dK^T, i.e. a lane owns 4 consecutive
-                    // channels of ONE key row -- the layout of the dQ accumulators below -- instead of one channel of 4 keys (2-byte stores)
                     dv[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot, pp, dv[u], 0, 0, 0);
                     dk[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dp8, dk[u], 0, 0, 0);
                 }
             }
-            // C[m = d = 4g+r (+16u)][n = key c16]
             {
                 const bool vj = j < N;
                 bf16* row = dqkv + ((int64_t)w * N + (vj ? j : 0)) * 3 * C + h * HD;
@@ -391,51 +416,50 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
             const bool vi = i < N;
             const bf16x8 qfb = lds_row8(Qs, R_LD, i, 8 * g);
             const bf16x8 ofb = lds_row8(Os, R_LD, i, 8 * g);
-            const float li = ls[i], di = dl[i];
-            const int ri = REGION ? Rs[i] : 0, bi = bs[i] + centre;
-            bf16* srow = slab + (((int64_t)w * heads + h) * N + (vi ? i : 0)) * slab_ld;
+            const float nli = ls[i], ndi = dl[i];
+            const uint32_t ri4 = REGION ? 0x01010101u * Rs[i] : 0u;
+            const uint32_t bi = tab_c + (uint32_t)bs[i];
+            const uint32_t srow = vi ? (uint32_t)(i * slab_ld * 2 + 8 * g) : 0x80000000u;        // byte offset of (row i, column 4g) in the slab
             f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 ds8;
+                u32x4 dsw;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int jt = 2 * ks + half, j0 = 16 * jt + 4 * g;
-                    if (FULL && jt >= NT) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) ds8[half * 4 + r] = (bf16)0.f;          // (slab columns >= N are never read)
+                    if (jt >= NT) {
+                        dsw[2 * half] = 0u; dsw[2 * half + 1] = 0u;          // (slab columns >= N are never read)
                         continue;
                     }
                     const bf16x8 ka = lds_row8(Ks, R_LD, 16 * jt + c16, 8 * g);
                     const bf16x8 va = lds_row8(Vs, R_LD, 16 * jt + c16, 8 * g);
                     const f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qfb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     const f32x4 dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, ofb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    const int4 bj4 = *reinterpret_cast<const int4*>(bs + j0);
-                    const f32x4 bb = {tab[bi - bj4.x], tab[bi - bj4.y], tab[bi - bj4.z], tab[bi - bj4.w]};
-                    f32x4 a = st * sc2 + (bb - li);
-                    if constexpr (REGION) {
-                        const uint32_t rj4 = *reinterpret_cast<const uint32_t*>(Rs + j0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) a[r] += ((int)((rj4 >> (8 * r)) & 0xFF) != ri) ? -100.0f * LOG2E : 0.f;
-                    }
+                    const u32x4 bj4 = *reinterpret_cast<const u32x4*>(bs + j0);
+                    const f32x4 bb = {lds_f32_at(bi - bj4[0]), lds_f32_at(bi - bj4[1]), lds_f32_at(bi - bj4[2]), lds_f32_at(bi - bj4[3])};
+                    const f32x4 a = __builtin_elementwise_fma(st, sc4, bb + nli);
                     f32x4 p;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        p[r] = __builtin_amdgcn_exp2f(a[r]);
-                        if constexpr (!FULL) p[r] = (vi && j0 + r < N) ? p[r] : 0.f;
-                    }
-                    const f32x4 ds = p * (dpt - di);
+                    for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(a[r]);
+                    if constexpr (REGION) {
+                        const uint32_t x = *reinterpret_cast<const uint32_t*>(Rs + j0) ^ ri4;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ds8[half * 4 + r] = (bf16)ds[r];
+                        for (int r = 0; r < 4; ++r) p[r] = (x & (0xFFu << (8 * r))) ? 0.f : p[r];
+                    }
+                    // (a padded KEY column: P finite, dS = P x (0 - delta) finite, times its zero K row = 0 in dQ; its slab columns are never read.
+                    //  A padded query lane is discarded with its dQ row and its slab row.)
+                    const f32x4 ds = p * (dpt + ndi);
+                    const uint32_t w0 = pack_bf16x2(ds[0], ds[1]), w1 = pack_bf16x2(ds[2], ds[3]);
+                    dsw[2 * half] = w0; dsw[2 * half + 1] = w1;
                     // dS of this (window, head) goes to its own slab, in bf16 -- the values dQ / dK are computed from -- as plain 8-byte stores;
                     // wattn_dtable_kernel sums the slabs over windows in fp32 and bins them (fp32 slabs: twice the bytes written here and read
                     // there, 9.1 vs ~6 us for the binning kernel of a stage-2 block).
                     // (LDS float atomics for an in-kernel histogram -- ds_add_f32 per element, up to 4 lanes of a wave on one table entry -- were
                     // measured twice: 37 of 57 us per window-head in round 1, 72 vs 34 us for the stage-2 launch in round 2; global atomics as bad.)
-                    if (vi && j0 + 3 < slab_ld)
-                        *reinterpret_cast<uint2*>(srow + j0) = make_uint2(pack_bf16x2(ds[0], ds[1]), pack_bf16x2(ds[2], ds[3]));
+                    // (slab_ld >= 16 NT: checked by the host)
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{w0, w1}, srs, (int)(srow + 32u * jt), 0, 0);
                 }
-                // A operand [m = d][k = key j]: transposing read of K, k-slot (g, jj) <-> j = 32 ks + 16 (jj >> 2) + 4 g + (jj & 3)
+                const bf16x8 ds8 = __builtin_bit_cast(bf16x8, dsw);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int off = (32 * ks + 4 * g + (c16 >> 2)) * R_LD + 16 * u + 4 * (c16 & 3);
@@ -444,13 +468,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
                     dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, ds8, dq[u], 0, 0, 0);
                 }
             }
-            // C[m = d = 4g+r (+16u)][n = query c16]: 4 consecutive channels per lane
             store_head_row16(dqkv + ((int64_t)w * N + (vi ? i : 0)) * 3 * C + h * HD, g,
                              make_uint2(pack_bf16x2(dq[0][0] * scale, dq[0][1] * scale), pack_bf16x2(dq[0][2] * scale, dq[0][3] * scale)),
                              make_uint2(pack_bf16x2(dq[1][0] * scale, dq[1][1] * scale), pack_bf16x2(dq[1][2] * scale, dq[1][3] * scale)), vi);
           }
         }
     }
+#endif
 }
 
 __global__ __launch_bounds__(256) void wattn_dtable_kernel(const bf16* __restrict__ slab, float* __restrict__ part, int slab_ld, int wd, int wh,
@@ -490,30 +514,30 @@ int lavt_window_attn_fwd_mfma(const void* qkv, const float* table, const int8_t*
                               int wd, int wh, int ww, int nwin, int N, int heads, float scale, hipStream_t st) {
     if (N > 400 || !table) { lavt_set_error("lavt_window_attn_fwd(mfma): N=%d (<= 400) with the bias table required", N); return LAVT_ERR_INVALID; }
     const int R = (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1);
+    const int centre = ((wd - 1) * (2 * wh - 1) + (wh - 1)) * (2 * ww - 1) + (ww - 1);
     dim3 grid(nwin * heads);
-#define LAVT_FWD(NT_, FULL_)                                                                                                                        \
+#define LAVT_FWD(NT_)                                                                                                                        \
     do {                                                                                                                                     \
-        constexpr int NP = ((NT_ + 1) / 2) * 32;                                                                                             \
-        const size_t lds = (size_t)3 * NP * F_LD * 2 + (size_t)NP * 4 + NP + (size_t)R * 4 + 16;                                             \
+        constexpr int NP = ((NT_ + 1) / 2) * 32, WV = NT_ > 10 ? 8 : 4;          /* 25 query tiles: two waves per SIMD */                      \
+        const size_t lds = (size_t)3 * NP * F_LD * 2 + (size_t)NP * 4 + NP + (size_t)(R + centre + 1) * 4 + 16;                               \
         static size_t reserved = 0;                                                                                                          \
         if (lds > 65536 && lds > reserved) {                                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_fwd_mfma<NT_, true, FULL_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || \
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_fwd_mfma<NT_, false, FULL_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_fwd_mfma<NT_, WV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || \
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_fwd_mfma<NT_, WV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
                 lavt_set_error("lavt_window_attn_fwd(mfma): cannot reserve %zu bytes of LDS", lds);                                          \
                 return LAVT_ERR_LAUNCH;                                                                                                      \
             }                                                                                                                                \
             reserved = lds;                                                                                                                  \
         }                                                                                                                                    \
-        if (region) hipLaunchKernelGGL((wattn_fwd_mfma<NT_, true, FULL_>), grid, dim3(256), lds, st, (const bf16*)qkv, table, region, nw_img, (bf16*)out, lse, wd, wh, \
+        if (region) hipLaunchKernelGGL((wattn_fwd_mfma<NT_, WV, true>), grid, dim3(WV * 64), lds, st, (const bf16*)qkv, table, region, nw_img, (bf16*)out, lse, wd, wh, \
                                        ww, nwin, N, heads, scale);                                                                           \
-        else hipLaunchKernelGGL((wattn_fwd_mfma<NT_, false, FULL_>), grid, dim3(256), lds, st, (const bf16*)qkv, table, region, nw_img, (bf16*)out, lse, wd, wh, \
+        else hipLaunchKernelGGL((wattn_fwd_mfma<NT_, WV, false>), grid, dim3(WV * 64), lds, st, (const bf16*)qkv, table, region, nw_img, (bf16*)out, lse, wd, wh, \
                                 ww, nwin, N, heads, scale);                                                                                  \
     } while (0)
-    if (N <= 64) LAVT_FWD(4, false);
-    else if (N == 144) LAVT_FWD(9, true);
-    else if (N <= 144) LAVT_FWD(9, false);
-    else if (N <= 160) LAVT_FWD(10, false);
-    else LAVT_FWD(25, false);
+    if (N <= 64) LAVT_FWD(4);
+    else if (N <= 144) LAVT_FWD(9);
+    else if (N <= 160) LAVT_FWD(10);
+    else LAVT_FWD(25);
 #undef LAVT_FWD
     LAVT_CHECK_LAUNCH("lavt_window_attn_fwd(mfma)");
     return LAVT_OK;
@@ -631,7 +655,7 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     const int waves = force_waves ? force_waves : 8;
     // riders only on the 8-wave variants that sit two per CU (N <= 160): a rider occupies a whole workgroup slot, and the 392-token video kernel (149 KB of
     // LDS, one workgroup per CU) would run them as an extra round
-    const bool eight = !(N <= 64) && !(N == 144 && waves != 8) && (N <= 160 || lavt_tuning().probe[3] != 0);
+    const bool eight = !(N <= 64) && !(N <= 144 && waves != 8) && (N <= 160 || lavt_tuning().probe[3] != 0);
     DtableJob job{};
     int riders = 0;
     if (prev != nullptr) {
@@ -655,33 +679,33 @@ int lavt_window_attn_bwd_mfma(const void* qkv, const float* table, const int8_t*
     }
     const int attn_blocks = split_from + (units - split_from) * split_pieces;
     dim3 grid(attn_blocks + riders);
-#define LAVT_BWD_K(NT_, WV_, RG_, FULL_)                                                                                                    \
+#define LAVT_BWD_K(NT_, WV_, RG_)                                                                                                           \
     do {                                                                                                                                     \
         const size_t lds = bwd_lds_bytes<NT_>(R);                                                                                            \
+        if (bias_ld < 16 * NT_) { lavt_set_error("lavt_window_attn_bwd(mfma): bias_ld = %d < %d", bias_ld, 16 * NT_); return LAVT_ERR_INVALID; } \
         static size_t reserved = 0;                                                                                                          \
         if (lds > 65536 && lds > reserved) {                                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_bwd_mfma<NT_, WV_, RG_, FULL_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_bwd_mfma<NT_, WV_, RG_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
                 lavt_set_error("lavt_window_attn_bwd(mfma): cannot reserve %zu bytes of LDS", lds);                                          \
                 return LAVT_ERR_LAUNCH;                                                                                                      \
             }                                                                                                                                \
             reserved = lds;                                                                                                                  \
         }                                                                                                                                    \
-        hipLaunchKernelGGL((wattn_bwd_mfma<NT_, WV_, RG_, FULL_>), grid, dim3(WV_ * 64), lds, st, (const bf16*)qkv, table, region, nw_img,   \
+        hipLaunchKernelGGL((wattn_bwd_mfma<NT_, WV_, RG_>), grid, dim3(WV_ * 64), lds, st, (const bf16*)qkv, table, region, nw_img,          \
                            (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, reinterpret_cast<bf16*>(ws), bias_ld, wd, wh, ww, nwin, N, heads, scale, wpb, attn_blocks, job, \
                            split_from, split_pieces);                                                                                        \
     } while (0)
-#define LAVT_BWD(NT_, WV_, FULL_)                                                                                                            \
+#define LAVT_BWD(NT_, WV_)                                                                                                                   \
     do {                                                                                                                                     \
-        if (region) LAVT_BWD_K(NT_, WV_, true, FULL_);                                                                                       \
-        else LAVT_BWD_K(NT_, WV_, false, FULL_);                                                                                             \
+        if (region) LAVT_BWD_K(NT_, WV_, true);                                                                                              \
+        else LAVT_BWD_K(NT_, WV_, false);                                                                                                    \
     } while (0)
     // 8 waves share one window-head, capped at 128 VGPRs so two workgroups (16 waves) sit on a CU: 5-9% faster than 4 waves x 2 at every
     // stage shape of Swin-B w12 @480 (measured, tools/attn_bench2.py).  LAVT_ATTN_BWD_WAVES=4 keeps the 4-wave variant reachable.
-    if (N <= 64) LAVT_BWD(4, 4, false);
-    else if (N == 144) { if (waves == 8) LAVT_BWD(9, 8, true); else LAVT_BWD(9, 4, true); }
-    else if (N <= 144) LAVT_BWD(9, 8, false);
-    else if (N <= 160) LAVT_BWD(10, 8, false);
-    else LAVT_BWD(25, 8, false);           // Video-Swin 8x7x7 windows: 149 KB of LDS, one workgroup per CU
+    if (N <= 64) LAVT_BWD(4, 4);
+    else if (N <= 144) { if (waves == 8) LAVT_BWD(9, 8); else LAVT_BWD(9, 4); }
+    else if (N <= 160) LAVT_BWD(10, 8);
+    else LAVT_BWD(25, 8);                  // Video-Swin 8x7x7 windows: 149 KB of LDS, one workgroup per CU
 #undef LAVT_BWD
 #undef LAVT_BWD_K
     LAVT_CHECK_LAUNCH("lavt_window_attn_bwd(mfma)");

@@ -65,9 +65,11 @@ template <typename T> __device__ __forceinline__ void chunk_to_f(const uint4& c,
         }
     }
 }
+// (as a two-element vector conversion the pair is ONE v_cvt_pk_bf16_f32; converted one by one and joined with shift / or it was four instructions)
+typedef __bf16 lavt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float lavt_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    bf16 a = (bf16)lo, b = (bf16)hi;
-    return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(lavt_f32x2{lo, hi}, lavt_bf16x2));
 }
 template <typename T> __device__ __forceinline__ uint4 f_to_chunk(const float* f) {
     uint4 c;

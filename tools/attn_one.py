@@ -17,7 +17,12 @@ R = (2 * wd - 1) * (2 * ws - 1) ** 2
 dtable = torch.zeros(R, heads, device=dev)
 wsb = torch.empty(int(K.lib.lavt_window_attn_bwd_ws(K.dt(bf), nwin, N, heads, ld, wd, ws, ws)), device=dev)
 table = torch.randn(R, heads, device=dev) * 0.1
+# ATTN_SHIFT=1: the shifted block's region ids (one image of nwin windows; three bands per axis as in the reference's mask)
+region = None
+if os.environ.get("ATTN_SHIFT", "0") == "1":
+    region = torch.randint(0, 3, (nwin, N), device=dev, dtype=torch.int8)
+rg, nwi = (K.ptr(region), nwin) if region is not None else (None, 0)
 for _ in range(6):
-    K.check(K.lib.lavt_window_attn_fwd(K.dt(bf), K.ptr(qkv), None, ld, None, 0, K.ptr(out), K.ptr(lse), K.ptr(table), wd, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
-    K.check(K.lib.lavt_window_attn_bwd(K.dt(bf), K.ptr(qkv), None, ld, None, 0, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(table), K.ptr(dtable), K.ptr(wsb), wsb.numel(), None, wd, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
+    K.check(K.lib.lavt_window_attn_fwd(K.dt(bf), K.ptr(qkv), None, ld, rg, nwi, K.ptr(out), K.ptr(lse), K.ptr(table), wd, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
+    K.check(K.lib.lavt_window_attn_bwd(K.dt(bf), K.ptr(qkv), None, ld, rg, nwi, K.ptr(out), K.ptr(dout), K.ptr(lse), K.ptr(dqkv), K.ptr(table), K.ptr(dtable), K.ptr(wsb), wsb.numel(), None, wd, ws, ws, nwin, N, heads, 32, 32 ** -0.5, K.stream()))
 torch.cuda.synchronize()
