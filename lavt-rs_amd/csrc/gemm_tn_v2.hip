@@ -627,9 +627,8 @@ thread_local int64_t* g_defer_rows = nullptr;
 thread_local int g_defer_cap = 0, g_defer_n = 0;
 constexpr int TNF_ROW = 10;          // int64 per device row: the eight above + [block_begin, block_end) of the set in the finish launch
 
-// blocks of one set: 1024 outputs per workgroup (16-byte loads, all pieces in one thread) up to 8 pieces; beyond, 4 piece lanes x 256 outputs of C per workgroup
-// (64 x 16-byte loads per piece lane) followed by the column sums as 4 piece lanes x 64 outputs
-__host__ __device__ inline int64_t tnf_blocks(bool deep, int64_t W, int64_t cs) { return deep ? (W + 255) / 256 + (cs + 63) / 64 : (W + cs + 1023) / 1024; }
+// blocks of one set: 1024 outputs per workgroup (16-byte loads, all pieces in one thread) up to 8 pieces, 64 outputs x 4 piece lanes beyond
+__host__ __device__ inline int64_t tnf_blocks(bool deep, int64_t total) { return deep ? (total + 63) / 64 : (total + 1023) / 1024; }
 
 __global__ __launch_bounds__(256) void tn_pieces_finish_multi_kernel(const int64_t* __restrict__ desc, int nsets) {
     // set of this workgroup: lane l looks at sets l and l + 64 (nsets <= 128); the first set whose block_end exceeds blockIdx.x
@@ -690,65 +689,24 @@ __global__ __launch_bounds__(256) void tn_pieces_finish_multi_kernel(const int64
         }
         return;
     }
-    // (the arithmetic of tnp_reduce_pieces_deep / tn_reduce_pieces_group: piece lane sl adds pieces sl, sl + 4, ... into four rotating accumulators, the lanes are
-    //  added pairwise -- per output the same order of additions; here a thread carries four adjacent outputs of C through 16-byte loads)
+    // (the body of tnp_reduce_pieces_deep / tn_reduce_pieces_group)
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int64_t nbw = (W + 255) / 256;
-    const bool vec = (W & 3) == 0 && (J & 3) == 0 && (ldc & 3) == 0 && (((uintptr_t)part | (uintptr_t)C) & 15) == 0;
-    if (blk < nbw && vec) {
-        __shared__ float4 red4[4][64];
-        const int64_t e = blk * 256 + 4 * col;
-        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-        auto add = [](float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
-        if (e < W) {
-            const float* q = part + e;
-            int s = sl;
-            for (; s + 12 < ns; s += 16) {
-                const float4 v0 = *reinterpret_cast<const float4*>(q + (int64_t)s * W), v1 = *reinterpret_cast<const float4*>(q + (int64_t)(s + 4) * W);
-                const float4 v2 = *reinterpret_cast<const float4*>(q + (int64_t)(s + 8) * W), v3 = *reinterpret_cast<const float4*>(q + (int64_t)(s + 12) * W);
-                add(a0, v0); add(a1, v1); add(a2, v2); add(a3, v3);
-            }
-            float4 v[3];          // the remaining <= 3 pieces of this lane, requested together
-#pragma unroll
-            for (int u = 0; u < 3; ++u) v[u] = *reinterpret_cast<const float4*>(q + (int64_t)min(s + 4 * u, ns - 1) * W);
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-                if (s + 4 * u < ns) add(a0, v[u]);
-        }
-        red4[sl][col] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
-        __syncthreads();
-        if (sl == 0 && e < W) {
-            const float4 r0 = red4[0][col], r1 = red4[1][col], r2 = red4[2][col], r3 = red4[3][col];
-            const int64_t i = e / J;
-            float4* c = reinterpret_cast<float4*>(C + i * ldc + (e - i * J));
-            float4 o = *c;
-            o.x += (r0.x + r1.x) + (r2.x + r3.x); o.y += (r0.y + r1.y) + (r2.y + r3.y); o.z += (r0.z + r1.z) + (r2.z + r3.z); o.w += (r0.w + r1.w) + (r2.w + r3.w);
-            *c = o;
-        }
-        return;
+    const int64_t e = blk * 64 + col;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < total) {
+        const float* q = e < W ? part + e : part + (int64_t)ns * W + (e - W);
+        const int64_t st = e < W ? W : I;
+        int s = sl;
+        for (; s + 12 < ns; s += 16) { a0 += q[(int64_t)s * st]; a1 += q[(int64_t)(s + 4) * st]; a2 += q[(int64_t)(s + 8) * st]; a3 += q[(int64_t)(s + 12) * st]; }
+        for (; s < ns; s += 4) a0 += q[(int64_t)s * st];
     }
-    // scalar form: the column sums (blocks behind the C part), or a C part whose layout rules out 16-byte accesses (four rounds of 64 outputs)
-    const int rounds = blk < nbw ? 4 : 1;
-    for (int r = 0; r < rounds; ++r) {
-        const int64_t e = blk < nbw ? blk * 256 + 64 * r + col : W + (blk - nbw) * 64 + col;
-        const bool in = blk < nbw ? e < W : e < total;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (in) {
-            const float* q = e < W ? part + e : part + (int64_t)ns * W + (e - W);
-            const int64_t st = e < W ? W : I;
-            int s = sl;
-            for (; s + 12 < ns; s += 16) { a0 += q[(int64_t)s * st]; a1 += q[(int64_t)(s + 4) * st]; a2 += q[(int64_t)(s + 8) * st]; a3 += q[(int64_t)(s + 12) * st]; }
-            for (; s < ns; s += 4) a0 += q[(int64_t)s * st];
-        }
-        __syncthreads();
-        red[sl][col] = (a0 + a1) + (a2 + a3);
-        __syncthreads();
-        if (sl == 0 && in) {
-            const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-            if (e < W) { const int64_t i = e / J; C[i * ldc + (e - i * J)] += t; }
-            else if (cs_atomic) atomicAdd(colsum + (e - W), t);
-            else colsum[e - W] += t;
-        }
+    red[sl][col] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && e < total) {
+        const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        if (e < W) { const int64_t i = e / J; C[i * ldc + (e - i * J)] += t; }
+        else if (cs_atomic) atomicAdd(colsum + (e - W), t);
+        else colsum[e - W] += t;
     }
 }
 }  // namespace
@@ -769,7 +727,7 @@ extern "C" int lavt_tn_defer_close(void) {
     return n;
 }
 // workgroups of one recorded row in the finish launch (the caller builds the device rows: the 8 recorded values + [block_begin, block_end))
-extern "C" int64_t lavt_tn_pieces_finish_blocks(int flags, int I, int J, int has_colsum) { return tnf_blocks((flags & 2) != 0, (int64_t)I * J, has_colsum ? I : 0); }
+extern "C" int64_t lavt_tn_pieces_finish_blocks(int flags, int I, int J, int has_colsum) { return tnf_blocks((flags & 2) != 0, (int64_t)I * J + (has_colsum ? I : 0)); }
 extern "C" int lavt_tn_pieces_finish_multi(const int64_t* desc, int nsets, int64_t total_blocks, void* stream) {
     LAVT_CHECK_ARG(desc && nsets > 0 && nsets <= 128 && total_blocks > 0 && total_blocks < (1LL << 31), "lavt_tn_pieces_finish_multi: 1..128 sets");
     hipLaunchKernelGGL(tn_pieces_finish_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, nsets);
