@@ -244,17 +244,6 @@ int lavt_gemm_tn_grouped(const lavt_gemm_tn_t* probs, int n, void* stream);
  * the other: same result. */
 int lavt_gemm_tn_grouped_ln(const lavt_gemm_tn_t* probs, int n, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                             void* dx, float* ws, int64_t ws_floats, const void* dres, int rows, int C, void* stream);
-/* Deferred piece reductions (ABI v8).  A weight-gradient launch whose reduction is cut into K pieces (lavt_gemm_tn with `partials`, the grouped launches) ends with a
- * second launch that adds the partial tiles into C / colsum -- 5-11 us on the critical chain for results nothing reads before the optimizer.  Between
- * lavt_tn_defer_open(rows, cap) and lavt_tn_defer_close() (same thread) those second launches are NOT issued: each split member is described in 8 int64 of `rows`
- * {partials, pieces, I, J, C, ldc, colsum, flags} (host memory, cap rows; a launch that would not fit reduces at once) and close returns the number of rows
- * written.  The caller keeps every recorded member's `partials` region alive and untouched (per-launch regions, not a shared scratch) and later runs
- * lavt_tn_pieces_finish_multi over a DEVICE table of 10 int64 per row: the 8 recorded values + [block_begin, block_end) = running sums of
- * lavt_tn_pieces_finish_blocks(flags, I, J, colsum != NULL); nsets <= 128 per launch.  Same order of additions as the immediate launches: bit-identical gradients. */
-int lavt_tn_defer_open(int64_t* rows, int cap);
-int lavt_tn_defer_close(void);
-int64_t lavt_tn_pieces_finish_blocks(int flags, int I, int J, int has_colsum);
-int lavt_tn_pieces_finish_multi(const int64_t* desc, int nsets, int64_t total_blocks, void* stream);
 /* The same launch in stream-K form (ABI v5): 128x128 tiles, the K-tile iterations of all members cut into equal runs for ~512 persistent
  * workgroups (every workgroup ingests the same number of bytes); tiles whose reduction is split between runs meet through `scratch` (plain partial
  * tiles + a fixed-order sum: no atomics).  lavt_gemm_tn_grouped_sk_ws returns the floats of scratch the group wants, or 0 when it does not qualify

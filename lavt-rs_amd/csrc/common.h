@@ -15,10 +15,6 @@ typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
 
 // ---- error plumbing -------------------------------------------------------------------------
 void lavt_set_error(const char* fmt, ...);
-// Deferred piece reductions (round 6, gemm_tn_v2.hip): while a recorder is open (lavt_tn_defer_open) the second stage of a split weight gradient -- the sum of
-// its partial tiles into C / colsum -- is described in the caller's rows instead of launched; lavt_tn_pieces_finish_multi runs all of them in one launch.
-bool lavt_tn_defer_room(int rows);
-void lavt_tn_defer_take(const float* part, int ns, int I, int J, float* C, long long ldc, float* colsum, int flags);          // flags: 1 = colsum through atomics, 2 = 64 outputs x 4 piece lanes
 #define LAVT_CHECK_ARG(cond, ...)                 \
     do {                                          \
         if (!(cond)) {                            \

@@ -14,7 +14,7 @@ void lavt_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* lavt_last_error(void) { return g_err; }
-extern "C" int lavt_abi_version(void) { return 8; }
+extern "C" int lavt_abi_version(void) { return 7; }
 
 namespace {
 

@@ -665,12 +665,9 @@ int lavt_gemm_tn_grouped_pipe(const lavt_gemm_tn_t* probs, int n, hipStream_t st
     if (stages == 3) TNP_GO(3); else if (stages == 5) TNP_GO(5); else if (stages == 2) TNP_GO(2); else TNP_GO(4);
 #undef TNP_GO
     if (any_pieces) {
-        int max_ns = 1, rows = 0;
-        for (int i = 0; i < n; ++i) { max_ns = max_ns > g.m[i].pieces ? max_ns : g.m[i].pieces; rows += g.m[i].pieces > 1 ? 1 : 0; }
-        if (lavt_tn_defer_room(rows)) {          // deferred form (gemm_tn_v2.hip): one row per split member, summed by lavt_tn_pieces_finish_multi at the end of backward
-            for (int i = 0; i < n; ++i)
-                if (g.m[i].pieces > 1) lavt_tn_defer_take(g.m[i].part, g.m[i].pieces, g.m[i].I, g.m[i].J, g.m[i].C, g.m[i].ldc, g.m[i].colsum, ((g.m[i].flags & TNP_COLSUM_ATOMIC) ? 1 : 0) | (max_ns > 8 ? 2 : 0));
-        } else if (max_ns > 8) hipLaunchKernelGGL(tnp_reduce_pieces_deep, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
+        int max_ns = 1;
+        for (int i = 0; i < n; ++i) max_ns = max_ns > g.m[i].pieces ? max_ns : g.m[i].pieces;
+        if (max_ns > 8) hipLaunchKernelGGL(tnp_reduce_pieces_deep, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
         else hipLaunchKernelGGL(tnp_reduce_pieces, dim3((unsigned)cdiv(max_total, 1024), n), dim3(256), 0, st, g);
     }
     LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(pipe)");

@@ -569,8 +569,7 @@ template <int BI, int BJ, int WAVES, int STAGES, bool MAPS, int CS, bool CONVP =
     } else {
         hipLaunchKernelGGL((gemm_tn_v2_kernel<BI, BJ, WAVES, STAGES, MAPS, CS, CONVP>), grid, dim3(WAVES * 64), lds, st, p, per);
         const int64_t total = (int64_t)p.I * p.J + (p.colsum ? p.I : 0);
-        if (p.batch == 1 && lavt_tn_defer_room(1)) lavt_tn_defer_take(p.partials, pieces, p.I, p.J, p.C, p.ldc, p.colsum, 2);
-        else hipLaunchKernelGGL(tn_reduce_pieces, dim3((unsigned)cdiv(total, 64), p.batch), dim3(256), 0, st, p.partials, pieces, p.I, p.J, p.C, p.ldc, p.colsum, p.strideC, p.strideColsum);
+        hipLaunchKernelGGL(tn_reduce_pieces, dim3((unsigned)cdiv(total, 64), p.batch), dim3(256), 0, st, p.partials, pieces, p.I, p.J, p.C, p.ldc, p.colsum, p.strideC, p.strideColsum);
     }
     LAVT_CHECK_LAUNCH("lavt_gemm_tn(v2)");
     return LAVT_OK;
@@ -617,124 +616,6 @@ __global__ __launch_bounds__(256) void tn_reduce_pieces_group(const TnGroup g) {
 
 }  // namespace
 
-// ---- deferred piece reductions ------------------------------------------------------------------------------------------------------------------
-// The piece reductions of the weight-gradient launches (stage 0 / 1 groups, PWAM's 1x1 convolutions, the patch embedding: ten launches of 5-11 us in a Swin-B
-// step) feed nothing but the gradient buffer.  Under the step harness the caller lends per-launch partial-tile regions (not the shared scratch), opens a
-// recorder around the launch, and gets one row per split member back: {partials, pieces, I, J, C, ldc, colsum, flags: 1 = atomic column sums, 2 = the 4-lane form}.  One launch at the end of
-// backward (lavt_tn_pieces_finish_multi) adds them up, in the piece order the immediate kernels use: the gradients are bit-identical to the immediate form.
-namespace {
-thread_local int64_t* g_defer_rows = nullptr;
-thread_local int g_defer_cap = 0, g_defer_n = 0;
-constexpr int TNF_ROW = 10;          // int64 per device row: the eight above + [block_begin, block_end) of the set in the finish launch
-
-// blocks of one set: 1024 outputs per workgroup (16-byte loads, all pieces in one thread) up to 8 pieces, 64 outputs x 4 piece lanes beyond
-__host__ __device__ inline int64_t tnf_blocks(bool deep, int64_t total) { return deep ? (total + 63) / 64 : (total + 1023) / 1024; }
-
-__global__ __launch_bounds__(256) void tn_pieces_finish_multi_kernel(const int64_t* __restrict__ desc, int nsets) {
-    // set of this workgroup: lane l looks at sets l and l + 64 (nsets <= 128); the first set whose block_end exceeds blockIdx.x
-    const int ln = threadIdx.x & 63;
-    const int64_t e0 = ln < nsets ? desc[(int64_t)ln * TNF_ROW + 9] : INT64_MAX, e1 = ln + 64 < nsets ? desc[(int64_t)(ln + 64) * TNF_ROW + 9] : INT64_MAX;
-    const unsigned long long h0 = __ballot(e0 > (int64_t)blockIdx.x), h1 = __ballot(e1 > (int64_t)blockIdx.x);
-    const int set = h0 ? __ffsll((long long)h0) - 1 : 64 + __ffsll((long long)h1) - 1;
-    if (set >= nsets) return;
-    const int64_t* d = desc + (int64_t)set * TNF_ROW;
-    const float* part = reinterpret_cast<const float*>(d[0]);
-    const int ns = (int)d[1], I = (int)d[2], J = (int)d[3];
-    float* C = reinterpret_cast<float*>(d[4]);
-    const int64_t ldc = d[5];
-    float* colsum = reinterpret_cast<float*>(d[6]);
-    const bool cs_atomic = (d[7] & 1) != 0, deep = (d[7] & 2) != 0;
-    const int64_t blk = (int64_t)blockIdx.x - d[8];
-    const int64_t W = (int64_t)I * J, total = W + (colsum ? I : 0);
-    __shared__ float red[4][64];
-    if (!deep) {          // (the body of tnp_reduce_pieces: <= 8 pieces, same order of additions)
-        const int64_t q0 = (blk * 256 + threadIdx.x) * 4;
-        if (q0 >= total) return;
-        if ((J & 3) == 0 && (ldc & 3) == 0 && (W & 3) == 0 && (((uintptr_t)part | (uintptr_t)C) & 15) == 0 && q0 + 3 < W) {
-            const float* q = part + q0;
-            float4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(q + (int64_t)min(u, ns - 1) * W);
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ns >= 8) {
-                float4 a0 = a, a1 = a, a2 = a, a3 = a;
-#pragma unroll
-                for (int u = 0; u < 8; u += 4) {
-                    a0.x += v[u].x; a0.y += v[u].y; a0.z += v[u].z; a0.w += v[u].w; a1.x += v[u + 1].x; a1.y += v[u + 1].y; a1.z += v[u + 1].z; a1.w += v[u + 1].w;
-                    a2.x += v[u + 2].x; a2.y += v[u + 2].y; a2.z += v[u + 2].z; a2.w += v[u + 2].w; a3.x += v[u + 3].x; a3.y += v[u + 3].y; a3.z += v[u + 3].z; a3.w += v[u + 3].w;
-                }
-                a = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
-            } else {
-#pragma unroll
-                for (int u = 0; u < 7; ++u)
-                    if (u < ns) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
-            }
-            const int64_t i = q0 / J;
-            float4* c = reinterpret_cast<float4*>(C + i * ldc + (q0 - i * J));
-            float4 o = *c;
-            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-            *c = o;
-            return;
-        }
-        for (int k = 0; k < 4; ++k) {
-            const int64_t e = q0 + k;
-            if (e >= total) break;
-            const float* q = e < W ? part + e : part + (int64_t)ns * W + (e - W);
-            const int64_t st = e < W ? W : I;
-            float t = 0.f;
-            for (int s = 0; s < ns; ++s) t += q[(int64_t)s * st];
-            if (e < W) { const int64_t i = e / J; C[i * ldc + (e - i * J)] += t; }
-            else if (cs_atomic) atomicAdd(colsum + (e - W), t);
-            else colsum[e - W] += t;
-        }
-        return;
-    }
-    // (the body of tnp_reduce_pieces_deep / tn_reduce_pieces_group)
-    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int64_t e = blk * 64 + col;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (e < total) {
-        const float* q = e < W ? part + e : part + (int64_t)ns * W + (e - W);
-        const int64_t st = e < W ? W : I;
-        int s = sl;
-        for (; s + 12 < ns; s += 16) { a0 += q[(int64_t)s * st]; a1 += q[(int64_t)(s + 4) * st]; a2 += q[(int64_t)(s + 8) * st]; a3 += q[(int64_t)(s + 12) * st]; }
-        for (; s < ns; s += 4) a0 += q[(int64_t)s * st];
-    }
-    red[sl][col] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (sl == 0 && e < total) {
-        const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-        if (e < W) { const int64_t i = e / J; C[i * ldc + (e - i * J)] += t; }
-        else if (cs_atomic) atomicAdd(colsum + (e - W), t);
-        else colsum[e - W] += t;
-    }
-}
-}  // namespace
-
-bool lavt_tn_defer_room(int rows) { return g_defer_rows != nullptr && g_defer_n + rows <= g_defer_cap; }
-void lavt_tn_defer_take(const float* part, int ns, int I, int J, float* C, long long ldc, float* colsum, int flags) {
-    int64_t* r = g_defer_rows + (int64_t)g_defer_n++ * 8;
-    r[0] = (int64_t)(uintptr_t)part; r[1] = ns; r[2] = I; r[3] = J; r[4] = (int64_t)(uintptr_t)C; r[5] = ldc; r[6] = (int64_t)(uintptr_t)colsum; r[7] = flags;
-}
-extern "C" int lavt_tn_defer_open(int64_t* rows, int cap) {
-    LAVT_CHECK_ARG(rows && cap > 0 && g_defer_rows == nullptr, "lavt_tn_defer_open: rows required, one recorder at a time");
-    g_defer_rows = rows; g_defer_cap = cap; g_defer_n = 0;
-    return LAVT_OK;
-}
-extern "C" int lavt_tn_defer_close(void) {
-    const int n = g_defer_n;
-    g_defer_rows = nullptr; g_defer_cap = 0; g_defer_n = 0;
-    return n;
-}
-// workgroups of one recorded row in the finish launch (the caller builds the device rows: the 8 recorded values + [block_begin, block_end))
-extern "C" int64_t lavt_tn_pieces_finish_blocks(int flags, int I, int J, int has_colsum) { return tnf_blocks((flags & 2) != 0, (int64_t)I * J + (has_colsum ? I : 0)); }
-extern "C" int lavt_tn_pieces_finish_multi(const int64_t* desc, int nsets, int64_t total_blocks, void* stream) {
-    LAVT_CHECK_ARG(desc && nsets > 0 && nsets <= 128 && total_blocks > 0 && total_blocks < (1LL << 31), "lavt_tn_pieces_finish_multi: 1..128 sets");
-    hipLaunchKernelGGL(tn_pieces_finish_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, nsets);
-    LAVT_CHECK_LAUNCH("lavt_tn_pieces_finish_multi");
-    return LAVT_OK;
-}
-
 static bool tn_v2_eligible(const lavt_gemm_tn_t& p) {
     if (p.dtype != LAVT_BF16 || p.zeros == nullptr) return false;
     if (p.lda % 8 || p.ldb % 8 || (p.B2 && p.ldb2 % 8)) return false;
@@ -742,20 +623,6 @@ static bool tn_v2_eligible(const lavt_gemm_tn_t& p) {
     if ((p.a_rowmap || p.a_rowscale || p.b_rowmap) && (p.conv_kc > 0 || p.B2)) return false;      // the mapped K loop has no taps / second source
     if ((int64_t)p.K * (p.lda > p.ldb ? p.lda : p.ldb) >= (1LL << 31)) return false;                // 32-bit element offsets
     return true;
-}
-
-// the group's piece reduction: launched, or -- recorder open -- described row by row for lavt_tn_pieces_finish_multi
-static void tn_group_reduce(const TnGroup& g, int n, int64_t max_total, hipStream_t st) {
-    int rows = 0;
-    for (int i = 0; i < n; ++i) rows += (g.split[i] > 1 && g.p[i].partials != nullptr) ? 1 : 0;
-    if (rows > 0 && lavt_tn_defer_room(rows)) {
-        for (int i = 0; i < n; ++i) {
-            const lavt_gemm_tn_t& p = g.p[i];
-            if (g.split[i] > 1 && p.partials != nullptr) lavt_tn_defer_take(p.partials, g.split[i], p.I, p.J, p.C, p.ldc, p.colsum, (p.colsum_atomic ? 1 : 0) | 2);
-        }
-        return;
-    }
-    hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
 }
 
 // returns 1 when the group cannot run as one launch (the caller then issues the problems one by one)
@@ -862,7 +729,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st, 
 #undef TNG_GO
 #undef TNG_GO2
         if (done) {
-            if (any_parts) tn_group_reduce(g, n, max_total, st);
+            if (any_parts) hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
             LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
             return ln ? 3 : LAVT_OK;
         }
@@ -885,7 +752,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st, 
         else rode = false;          // (C = 1024: two chunks per lane need 164 registers -- a fourth workgroup per CU no longer fits; the two stage-3 blocks launch it on its own)
 #undef TNG_LN
         if (rode) {
-            if (any_parts) tn_group_reduce(g, n, max_total, st);
+            if (any_parts) hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
             LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped_ln(v2)");
             return LAVT_OK;
         }
@@ -897,7 +764,7 @@ int lavt_gemm_tn_grouped_v2(const lavt_gemm_tn_t* probs, int n, hipStream_t st, 
         if (maps) hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, true, 0>), dim3(tiles), dim3(256), lds, st, g);
         else hipLaunchKernelGGL((gemm_tn_v2_grouped_kernel<64, 64, 4, 2, false, 0>), dim3(tiles), dim3(256), lds, st, g);
     }
-    if (any_parts) tn_group_reduce(g, n, max_total, st);
+    if (any_parts) hipLaunchKernelGGL(tn_reduce_pieces_group, dim3((unsigned)cdiv(max_total, 64), n), dim3(256), 0, st, g);
     LAVT_CHECK_LAUNCH("lavt_gemm_tn_grouped(v2)");
     return ln ? 3 : LAVT_OK;
 }

@@ -153,10 +153,6 @@ _PROTOTYPES = {
     "lavt_droppath_draw": [vp, vp, vp, i32, i32, vp],
     "lavt_conv3x3_wgrad_ws": [i32, i32, i32, i32, i32, i32],
     "lavt_gemm_tn_grouped_ln": [C.POINTER(GemmTN), i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, vp],
-    "lavt_tn_defer_open": [vp, i32],
-    "lavt_tn_defer_close": [],
-    "lavt_tn_pieces_finish_blocks": [i32, i32, i32, i32],
-    "lavt_tn_pieces_finish_multi": [vp, i32, i64, vp],
     "lavt_gemm_tn_grouped_sk_ws": [C.POINTER(GemmTN), i32],
     "lavt_gemm_tn_grouped_sk": [C.POINTER(GemmTN), i32, vp, i64, vp],
     "lavt_conv3x3_wgrad": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp, i32, vp, vp],
@@ -256,7 +252,7 @@ for _name, _args in _PROTOTYPES.items():
     _fn = getattr(_cdll, _name)          # AttributeError here = header/library mismatch: fail loudly
     _fn.argtypes = _args
     _fn.restype = C.c_int
-EXPECTED_ABI = 8          # the ctypes struct layouts and prototypes in this file were written for this lavt_abi_version()
+EXPECTED_ABI = 7          # the ctypes struct layouts and prototypes in this file were written for this lavt_abi_version()
 if _cdll.lavt_abi_version() != EXPECTED_ABI:
     raise ImportError(f"{LIB_PATH} reports ABI v{_cdll.lavt_abi_version()} but lavt_hip/_capi.py binds ABI v{EXPECTED_ABI}: rebuild the library "
                       "(`make -C lavt-rs_amd/csrc`) -- a mismatch would make the kernels read past the caller's parameter structs")
@@ -264,7 +260,6 @@ _cdll.lavt_last_error.restype = C.c_char_p
 _cdll.lavt_window_attn_bwd_ws.restype = C.c_int64
 _cdll.lavt_conv3x3_wgrad_ws.restype = C.c_int64
 _cdll.lavt_gemm_tn_grouped_sk_ws.restype = C.c_int64
-_cdll.lavt_tn_pieces_finish_blocks.restype = C.c_int64
 _cdll.lavt_last_error.argtypes = []
 for _name in ("lavt_last_error", "lavt_window_attn_bwd_ws", "lavt_attn_uses_table", "lavt_abi_version", "lavt_layernorm_bwd_blocks", "lavt_window_attn_bwd_pieces", "lavt_gemm_tn_pieces", "lavt_pwam_q_parts", "lavt_pwam_words_records", "lavt_pwam_mix1_records", "lavt_adamw_chunk_elems", "lavt_tuning_reload", "lavt_conv3x3_wgrad_ws", "lavt_conv3x3_wgrad_f8_ok", "lavt_gemm_tn_grouped_sk_ws", "lavt_gemm_nt_colstats_plan", "lavt_cls_head_bwd_blocks", "lavt_reduce_partials_column_blocks"):      # queries, not launches: never timed
     setattr(lib, _name, getattr(_cdll, _name))

@@ -10,7 +10,6 @@ bf16 compute copies are produced by `weight()` and cached per parameter version.
 gradients are produced in fp32.
 """
 import ctypes as C
-import contextlib
 import os
 import types
 import weakref
@@ -647,7 +646,7 @@ def gemm_nt(dtype, M, N, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
 
 def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, strideB=0, strideC=0, a_rowmap=None,
             a_rowscale=None, a_rowscale_div=1, a_rowscale_binary=False, accumulate=False, B2=None, ldb2=0, b_split=0, b_rowmap=None, conv=None, alpha=1.0, c_conv_permute=False, colsum=None,
-            strideColsum=0, a_off=0, b_off=0, c_off=0, defer=None, colsum_atomic=False, extra=False, rider=None, pieces_params=None):
+            strideColsum=0, a_off=0, b_off=0, c_off=0, defer=None, colsum_atomic=False, extra=False, rider=None):
     es = 4 if dtype == torch.float32 else 2
     assert Cout.dtype == torch.float32
     p = K.GemmTN()
@@ -673,16 +672,8 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
         # batched: the per-sample word-side matrices of the fused PWAM node -- plain stores + a fixed-order sum, so the result is run-to-run identical)
         need = batch * int(K.lib.lavt_gemm_tn_pieces(C.byref(p))) * (I * J + I)
         if need <= (16 << 20):
-            # (pieces_params: this launch's parameters, for a caller outside the queue whose piece reduction may wait for the end of backward -- its own region then)
-            own = ln_deferred.alloc(need, A.device) if (defer is None and pieces_params is not None and batch == 1 and _TN_DEFER and ln_deferred.active()) else None
-            scr = own if own is not None else _tn_parts(need, A.device)
-            p.partials, p.partials_floats = K.ptr(scr), (need if (defer is not None or own is not None) else scr.numel())     # queued: flush() hands every member its own region
-            if own is not None:
-                if K.prof.enabled:
-                    K.prof.note = {"flops": 2.0 * I * J * Kd, "shape": f"tn {I}x{J}x{Kd}"}
-                with _PieceRecorder(pieces_params):
-                    K.check(K.lib.lavt_gemm_tn(C.byref(p), K.stream()))
-                return
+            scr = _tn_parts(need, A.device)
+            p.partials, p.partials_floats = K.ptr(scr), (need if defer is not None else scr.numel())     # queued: flush() hands every member its own region
     if defer is not None:
         if rider is not None:
             defer.add(p, (A, B, Cout, a_rowmap, a_rowscale, b_rowmap, colsum) + tuple(t for t in rider if torch.is_tensor(t)), extra=extra, rider=rider)
@@ -694,43 +685,15 @@ def gemm_tn(dtype, I, J, Kd, A, lda, B, ldb, Cout, ldc, *, batch=1, strideA=0, s
     K.check(K.lib.lavt_gemm_tn(C.byref(p), K.stream()))
 
 
-_TN_DEFER = os.environ.get("LAVT_TN_DEFER", "1") != "0"          # A/B switch: 0 = every split weight gradient reduces its pieces at once (round 5)
-
-
-class _PieceRecorder:
-    """Opens the library's recorder of piece reductions around ONE weight-gradient launch (lavt_tn_defer_open / _close): the launch describes the second stage of
-    its split members instead of issuing it, the rows go to ln_deferred (one lavt_tn_pieces_finish_multi at the end of backward) and `params` stay pending --
-    for the gradient buckets -- until then."""
-    CAP = 8
-
-    def __init__(self, params):
-        self.params, self.rows = params, 0
-
-    def __enter__(self):
-        self.buf = (C.c_int64 * (8 * self.CAP))()
-        K.check(K.lib.lavt_tn_defer_open(self.buf, self.CAP))
-        return self
-
-    def __exit__(self, *exc):
-        self.rows = int(K.lib.lavt_tn_defer_close())
-        if self.rows and exc[0] is None:
-            ln_deferred.add_pieces([tuple(int(self.buf[8 * i + k]) for k in range(8)) for i in range(self.rows)], self.params)
-        return False
-
-
-def assign_partials(items, device, own=False):
-    """the members of one grouped launch write their partial tiles at the same time: disjoint regions of the per-device scratch (own: of a region of the
-    deferred-reduction arena that stays theirs until the end of backward; -> whether they got one)"""
+def assign_partials(items, device):
+    """the members of one grouped launch write their partial tiles at the same time: disjoint regions of the per-device scratch"""
     need = [int(q.partials_floats) if q.partials else 0 for q in items]
     if sum(need):
-        region = ln_deferred.alloc(sum(need), device) if own else None
-        base, off = (region if region is not None else _tn_parts(sum(need), device)).data_ptr(), 0
+        base, off = _tn_parts(sum(need), device).data_ptr(), 0
         for q, nf in zip(items, need):
             if nf:
                 q.partials = base + 4 * off
                 off += nf
-        return region is not None
-    return False
 
 
 _LN_RIDER = os.environ.get("LAVT_LN_RIDER", "1") != "0"
@@ -794,7 +757,7 @@ class _WgradQueue:
                 for q in self.items:
                     if not q.accumulate:
                         sinks.mark_assigned_ptr(q.C)
-            own = assign_partials(self.items, next(t for t in self.keep[0] if t is not None).device, own=_TN_DEFER and not _STREAMK and ln_deferred.active())
+            assign_partials(self.items, next(t for t in self.keep[0] if t is not None).device)
             arr = (K.GemmTN * len(self.items))(*self.items)
             if K.prof.enabled:       # a grouped launch mixes scopes (qkv / proj with fc1 / fc2): the note carries the per-member flops and labels
                 fl = [2.0 * q.I * q.J * q.K for q in self.items]
@@ -814,26 +777,20 @@ class _WgradQueue:
                     _launch_ln_partial(rider)
                 self._after_flush()
                 return
-            rec = _PieceRecorder(list(self.ready)) if own else contextlib.nullcontext()
-            with rec:
-                if rider is not None and _LN_RIDER:
-                    dy_, x_, g_, mean_, rstd_, dx_, ws_, dres_, rows_, C_ = rider
-                    K.check(K.lib.lavt_gemm_tn_grouped_ln(arr, n_items, K.ptr(dy_), K.ptr(x_), K.ptr(g_), K.ptr(mean_), K.ptr(rstd_), K.ptr(dx_), K.ptr(ws_), ws_.numel(),
-                                                          K.ptr(dres_), rows_, C_, K.stream()))
-                else:
-                    K.check(K.lib.lavt_gemm_tn_grouped(arr, n_items, K.stream()))
-                    if rider is not None:
-                        _launch_ln_partial(rider)
-            self._after_flush(held=own and rec.rows > 0)
-            return
+            if rider is not None and _LN_RIDER:
+                dy_, x_, g_, mean_, rstd_, dx_, ws_, dres_, rows_, C_ = rider
+                K.check(K.lib.lavt_gemm_tn_grouped_ln(arr, n_items, K.ptr(dy_), K.ptr(x_), K.ptr(g_), K.ptr(mean_), K.ptr(rstd_), K.ptr(dx_), K.ptr(ws_), ws_.numel(),
+                                                      K.ptr(dres_), rows_, C_, K.stream()))
+                self._after_flush()
+                return
+            K.check(K.lib.lavt_gemm_tn_grouped(arr, n_items, K.stream()))
+            if rider is not None:
+                _launch_ln_partial(rider)
         self._after_flush()
 
-    def _after_flush(self, held=False):
-        """held: the group's piece reductions wait for the end of backward -- its parameters stay pending, ln_deferred.flush() reports them"""
+    def _after_flush(self):
         ready = self.ready
         self.items, self.keep, self.ready, self.scopes, self.primary = [], [], [], [], 0
-        if held:
-            return
         for prm in ready:
             self.pending.discard(id(prm))
             if sinks.on_ready is not None:
@@ -855,8 +812,8 @@ class _LnDeferred:
     ARENA_FLOATS = int(os.environ.get("LAVT_LN_ARENA_M", "96")) << 20          # 384 MiB of the 288 GB: Swin-B needs 37 x 450 x 1024 + ... = 24 M floats, Video-Swin-B (4608 rows) 50 M; beyond it a LayerNorm reduces at once
 
     def __init__(self):
-        self.arena, self.off, self.items, self.params, self.tables, self.pieces = None, 0, [], [], [], []
-        self.desc, self.desc_key, self.tdesc, self.tdesc_key, self.pdesc, self.pdesc_key = None, None, None, None, None, None
+        self.arena, self.off, self.items, self.params, self.tables = None, 0, [], [], []
+        self.desc, self.desc_key, self.tdesc, self.tdesc_key = None, None, None, None
 
     def active(self):
         return wgrads.active() and os.environ.get("LAVT_LN_DEFER", "1") != "0"
@@ -882,32 +839,8 @@ class _LnDeferred:
         self.params.append(param)
         wgrads.pending.add(id(param))
 
-    def add_pieces(self, rows, params):
-        """piece reductions of split weight gradients (rows of lavt_tn_defer_open): lavt_tn_pieces_finish_multi at flush"""
-        self.pieces.extend(rows)
-        for p in params:
-            self.params.append(p)
-            wgrads.pending.add(id(p))
-
     def flush(self):
         dtable_chain.flush()                     # the last attention-backward launch's binning job (chained form) runs on its own
-        if self.pieces:
-            key = tuple(self.pieces)
-            if key != self.pdesc_key:
-                if torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError("deferred piece reductions: the step being captured differs from the warm-up steps")
-                self.pdesc = []
-                for c0 in range(0, len(self.pieces), 128):          # <= 128 sets per launch; block ranges restart with every launch
-                    rows, off = [], 0
-                    for r in self.pieces[c0:c0 + 128]:
-                        nb = int(K.lib.lavt_tn_pieces_finish_blocks(r[7], r[2], r[3], int(r[6] != 0)))
-                        rows.append(r + (off, off + nb))
-                        off += nb
-                    self.pdesc.append((torch.tensor(rows, dtype=torch.int64).to(self.arena.device), len(rows), off))
-                self.pdesc_key = key
-            for desc, n, blocks in self.pdesc:
-                K.check(K.lib.lavt_tn_pieces_finish_multi(K.ptr(desc), n, blocks, K.stream()))
-            self.pieces = []
         if self.tables:
             key = tuple(self.tables)
             if key != self.tdesc_key:
@@ -2691,7 +2624,7 @@ class _PatchEmbed(torch.autograd.Function):
             K.check(K.lib.lavt_col2im4(K.dt(dtype), K.ptr(dcols), K.ptr(dimg), B, H, W, K.stream()))
         dW, wsink = sinks.buf(weight, (C0, 48))
         db, bsink = sinks.buf(bias, (C0,))
-        gemm_tn(dtype, C0, 48, M, dy, C0, cols, 48, dW, 48, colsum=db, pieces_params=(weight, bias) if (wsink and bsink) else None)
+        gemm_tn(dtype, C0, 48, M, dy, C0, cols, 48, dW, 48, colsum=db)
         return dimg, sinks.done(weight, dW, wsink), sinks.done(bias, db, bsink), None
 
 

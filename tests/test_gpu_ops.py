@@ -1785,72 +1785,3 @@ def test_pwam_mix1_word_reduction_by_product(B, T, C):
     dv_b, q_b = lang(False)
     assert_close(dv_a, dv_b.float().cpu(), bf, "dVW", bf16=1e-2)
     assert_close(q_a, q_b.cpu(), torch.float32, "Q / u", f32=2e-3)
-
-
-@pytest.mark.parametrize("pipe", ["1", "0"])
-@pytest.mark.parametrize("shapes", [[(128, 512, 28800), (512, 128, 28800), (128, 128, 28800), (384, 128, 28800)],          # stage-0 block: ~20 pieces (4-lane form)
-                                    [(256, 1024, 7200), (1024, 256, 7200), (256, 256, 7200), (768, 256, 7200)],            # stage-1 block: <= 8 pieces
-                                    [(128, 48, 28800)]])                                                                   # patch embedding: one problem, lavt_gemm_tn
-def test_deferred_piece_reductions_match_immediate(shapes, pipe, monkeypatch, request):
-    """ABI v8: a split weight gradient whose piece reduction is recorded (lavt_tn_defer_open / _close) and run later by lavt_tn_pieces_finish_multi gives the
-    bits of the immediate launch -- grouped launches on the pipelined 128x128 kernel and on the 64x64 kernel (LAVT_TN_PIPE=0), and the single-problem entry."""
-    import ctypes as C
-    from lavt_hip import ops, _capi as K
-    monkeypatch.setenv("LAVT_TN_PIPE", pipe)
-    K.lib.lavt_tuning_reload()
-    request.addfinalizer(lambda: (os.environ.pop("LAVT_TN_PIPE", None), K.lib.lavt_tuning_reload()))
-    bf = torch.bfloat16
-
-    class Collect:
-        def __init__(self):
-            self.items, self.keep = [], []
-
-        def add(self, p, tensors, extra=False, rider=None):
-            self.items.append(p)
-            self.keep.append(tensors)
-
-    def build():
-        q, outs = Collect(), []
-        for k, (I, J, Kd) in enumerate(shapes):
-            A, B = rnd(Kd, I, seed=10 + k).to(dev()).to(bf), rnd(Kd, J, seed=20 + k).to(dev()).to(bf)
-            Cm, cs = torch.zeros(I, J, device=dev()), torch.zeros(I, device=dev())
-            ops.gemm_tn(bf, I, J, Kd, A, I, B, J, Cm, J, colsum=cs, defer=q)
-            outs += [Cm, cs]
-        ops.assign_partials(q.items, torch.device(dev()))
-        return q, outs
-
-    def launch(q):
-        if len(q.items) == 1:
-            q.items[0].split_k = 0
-            K.check(K.lib.lavt_gemm_tn(C.byref(q.items[0]), K.stream()))
-        else:
-            arr = (K.GemmTN * len(q.items))(*q.items)
-            K.check(K.lib.lavt_gemm_tn_grouped(arr, len(q.items), K.stream()))
-
-    q1, imm = build()
-    launch(q1)
-    torch.cuda.synchronize()
-    imm = [t.clone() for t in imm]
-    q2, dfr = build()
-    rows = (C.c_int64 * (8 * 8))()
-    K.check(K.lib.lavt_tn_defer_open(rows, 8))
-    try:
-        launch(q2)
-    finally:
-        n = int(K.lib.lavt_tn_defer_close())
-    assert n >= 1, "no member of the launch was cut into pieces: the test shapes no longer exercise the deferred form"
-    torch.cuda.synchronize()
-    assert any(not torch.equal(a, b) for a, b in zip(imm, dfr)), "the recorded launch reduced its pieces after all"
-    desc, off = [], 0
-    for i in range(n):
-        r = tuple(int(rows[8 * i + k]) for k in range(8))
-        nb = int(K.lib.lavt_tn_pieces_finish_blocks(r[7], r[2], r[3], int(r[6] != 0)))
-        desc.append(r + (off, off + nb))
-        off += nb
-    d = torch.tensor(desc, dtype=torch.int64).to(dev())
-    K.check(K.lib.lavt_tn_pieces_finish_multi(K.ptr(d), n, off, K.stream()))
-    torch.cuda.synchronize()
-    for a, b in zip(imm, dfr):
-        assert torch.equal(a, b)
-    ref = (rnd(shapes[0][2], shapes[0][0], seed=10).to(bf).float().t() @ rnd(shapes[0][2], shapes[0][1], seed=20).to(bf).float())
-    assert float((dfr[0].cpu() - ref).norm() / ref.norm()) < 2e-3

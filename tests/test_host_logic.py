@@ -61,7 +61,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_capi.EXPORTED), declared ^ set(_capi.EXPORTED)
     for name in declared:
         assert hasattr(_capi.lib, name), f"liblavt_hip.so does not export {name}"
-    assert _capi.lib.lavt_abi_version() == _capi.EXPECTED_ABI == 8
+    assert _capi.lib.lavt_abi_version() == _capi.EXPECTED_ABI == 7
 
 
 def test_struct_layout_matches_header():
