@@ -34,11 +34,6 @@ __device__ __forceinline__ bf16x8 join4(bf16x4 lo, bf16x4 hi) {
 __device__ __forceinline__ bf16x8 lds_row8(const bf16* s, int ld, int row, int k0) {
     return *reinterpret_cast<const bf16x8*>(s + row * ld + k0);
 }
-// fragment of a k-major LDS tile s[k][ld]: element jj <-> k = kbase + 8*(lane>>4) + jj, column col0 + (lane & 15)
-__device__ __forceinline__ bf16x8 lds_kmajor8(const bf16* s, int ld, int kbase, int col0, int lane) {
-    const bf16* p = s + (kbase + 8 * (lane >> 4) + ((lane & 15) >> 2)) * ld + col0 + 4 * (lane & 3);
-    return join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p), __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * ld)));
-}
 __device__ __forceinline__ bf16x8 zero8() {
     bf16x8 z;
 #pragma unroll
@@ -65,7 +60,13 @@ __device__ __forceinline__ void store_head_row16(bf16* row_head, int g, uint2 p0
 // S^T = K Q^T) and the V^T fragments (A operand of O^T = V^T P^T, transposing LDS read) in registers for all its tiles.
 // S^T puts one query per lane column: softmax reductions are in-register + two shuffles, and the un-normalised P^T accumulators of two
 // key tiles are directly the B operand of the second MFMA (no LDS round trip for P).
-constexpr int F_LD = 40;        // bf16 elements per LDS row of Q / K / V (80 B)
+// LDS rows of Q / K / V (/ dO): 64 bytes = four 16-byte chunks, UNPADDED, chunk c of row r stored at chunk c ^ swz(r) (round 6).  With the 80-byte padded rows of
+// rounds 2-5 the 16-byte row reads were conflict-free but the transposing 8-byte reads of 8 consecutive rows were 2-way (39 % of the LDS cycles of the 392-token
+// backward were bank conflicts).  swz takes bit 2 of the row into bit 1 of the chunk and bit 3 into bit 0: the 16 rows of a row-fragment read (same chunk) land in 16
+// different 16-byte bank groups, and the 8 rows x 2 chunks of a transposing read cover the 64 banks once.  Tile offsets are multiples of 16 rows: a lane's swizzle
+// is a constant of the lane.
+constexpr int F_LD = 32;        // bf16 elements per LDS row
+__device__ __forceinline__ int swz(int row) { return (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
 
 // Arithmetic diet (the 392-token kernels are VALU-issue bound: rocprofv3 counters, profiles/r02_pmc_attention.json, r06_pmc_attn_392_tokens.json): scores live
 // in the log2 domain (table column and scale pre-multiplied by log2 e when staged, so the exponential is the bare v_exp_f32), the shift-mask compare is compiled
@@ -112,9 +113,10 @@ __global__ __launch_bounds__(WAVES * 64) void wattn_fwd_mfma(const bf16* __restr
             k = *reinterpret_cast<const uint4*>(r + C);
             v = *reinterpret_cast<const uint4*>(r + 2 * C);
         }
-        *reinterpret_cast<uint4*>(Qs + row * F_LD + c * 8) = q;
-        *reinterpret_cast<uint4*>(Ks + row * F_LD + c * 8) = k;
-        *reinterpret_cast<uint4*>(Vs + row * F_LD + c * 8) = v;
+        const int pc = (c ^ swz(row)) * 8;
+        *reinterpret_cast<uint4*>(Qs + row * F_LD + pc) = q;
+        *reinterpret_cast<uint4*>(Ks + row * F_LD + pc) = k;
+        *reinterpret_cast<uint4*>(Vs + row * F_LD + pc) = v;
     }
     for (int e = tid; e < NP; e += NTHR) {
         const int dz = e / (wh * ww), hy = (e / ww) % wh, wx = e % ww;
@@ -133,9 +135,12 @@ __global__ __launch_bounds__(WAVES * 64) void wattn_fwd_mfma(const bf16* __restr
     constexpr bool CACHE = NT <= 10;
     constexpr int NC = CACHE ? NT : 1, KC = CACHE ? KS : 1;
     bf16x8 kf[NC], vf[2][KC];
-    auto k_frag = [&](int t) { return lds_row8(Ks, F_LD, 16 * t + c16, 8 * g); };
+    const int kg = 8 * (g ^ swz(c16));                     // this lane's chunk of a row fragment (rows 16 t + c16)
+    const int rr = 4 * g + (c16 >> 2);                     // its row of a transposing read (rows 32 ks + rr, + 16), and the two column groups u = 0, 1
+    const int tcol[2] = {((((c16 >> 1) & 1)) ^ swz(rr)) * 8 + 4 * (c16 & 1), ((2 + ((c16 >> 1) & 1)) ^ swz(rr)) * 8 + 4 * (c16 & 1)};
+    auto k_frag = [&](int t) { return lds_row8(Ks, F_LD, 16 * t + c16, kg); };
     auto v_frag = [&](int u, int ks) {
-        const bf16* p = Vs + (32 * ks + 4 * g + (c16 >> 2)) * F_LD + 16 * u + 4 * (c16 & 3);
+        const bf16* p = Vs + (32 * ks + rr) * F_LD + tcol[u];
         return join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p), __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * F_LD)));
     };
     if constexpr (CACHE) {
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(WAVES * 64) void wattn_fwd_mfma(const bf16* __restr
     for (int it = wave; it < QT; it += WAVES) {
         const int i = 16 * it + c16;
         const bool vi = i < N;
-        const bf16x8 qf = lds_row8(Qs, F_LD, i, 8 * g);
+        const bf16x8 qf = lds_row8(Qs, F_LD, i, kg);
         const uint32_t ri4 = REGION ? 0x01010101u * Rs[i] : 0u;
         const uint32_t bi = tab_c + (uint32_t)bs[i];           // (a padded query lane gathers from wherever: its column is discarded)
         f32x4 s[2 * KS];
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(WAVES * 64) void wattn_fwd_mfma(const bf16* __restr
 // 159 KB of LDS (one workgroup per CU) to ~55 KB.  The relative-position-bias gradient is binned in an LDS histogram over the table
 // index (idx = base[i] - base[j] + centre) and flushed with one global atomic per table entry per workgroup; the dense [heads][N][ld]
 // gradient (dbias) is only written when no table pointer is given.
-constexpr int R_LD = 40;        // bf16 elements per LDS row of Q / K / V / dO (80 B rows, 16-byte aligned chunks)
+constexpr int R_LD = 32;        // bf16 elements per LDS row of Q / K / V / dO (64-byte rows, chunks swizzled by swz(row): see the forward)
 
 // Table-gradient binning of ONE attention-backward launch (wattn_dtable_kernel's arguments).  The binning kernel (7.5 us x 24 per Swin-B step)
 // sits between the attention backward and the qkv data gradient without either needing it: a launch can carry the job of the PREVIOUS
@@ -280,6 +285,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
     float* tab = reinterpret_cast<float*>(Rs + NP);        // this head's column of the bias table * log2 e
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int kg = 8 * (g ^ swz(c16));                     // this lane's chunk of a row fragment (rows 16 t + c16)
+    const int rr = 4 * g + (c16 >> 2);                     // its row of a transposing read (rows 32 ks + rr, + 16) and the two column groups u = 0, 1
+    const int tcol[2] = {((((c16 >> 1) & 1)) ^ swz(rr)) * 8 + 4 * (c16 & 1), ((2 + ((c16 >> 1) & 1)) ^ swz(rr)) * 8 + 4 * (c16 & 1)};
     const int QT = (N + 15) / 16;
     // Units beyond a whole number of rounds of the chip (18 windows x 16 heads = 288 on 256 CUs: the 32 CUs that hold two took 21.1 us where one unit per
     // CU takes 14.9) are cut into `split_pieces` workgroups, each with a contiguous run of the unit's 2 QT tasks (a task = one key tile of pass 1 or one query
@@ -326,10 +334,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
                 d = *reinterpret_cast<const uint4*>(dout + oo);
                 o = *reinterpret_cast<const uint4*>(out + oo);
             }
-            *reinterpret_cast<uint4*>(Qs + row * R_LD + c * 8) = q;
-            *reinterpret_cast<uint4*>(Ks + row * R_LD + c * 8) = k;
-            *reinterpret_cast<uint4*>(Vs + row * R_LD + c * 8) = v;
-            *reinterpret_cast<uint4*>(Os + row * R_LD + c * 8) = d;
+            const int pc = (c ^ swz(row)) * 8;
+            *reinterpret_cast<uint4*>(Qs + row * R_LD + pc) = q;
+            *reinterpret_cast<uint4*>(Ks + row * R_LD + pc) = k;
+            *reinterpret_cast<uint4*>(Vs + row * R_LD + pc) = v;
+            *reinterpret_cast<uint4*>(Os + row * R_LD + pc) = d;
             float fd[8], fo[8], part = 0.f;
             chunk_to_f<bf16>(d, fd);
             chunk_to_f<bf16>(o, fo);
@@ -351,8 +360,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
             // ---- pass 1: dV, dK of key tile jt ----------------------------------------------------------------------------
             const int jt = t;
             const int j = 16 * jt + c16;
-            const bf16x8 kfr = lds_row8(Ks, R_LD, j, 8 * g);
-            const bf16x8 vfr = lds_row8(Vs, R_LD, j, 8 * g);
+            const bf16x8 kfr = lds_row8(Ks, R_LD, j, kg);
+            const bf16x8 vfr = lds_row8(Vs, R_LD, j, kg);
             const uint32_t rj4 = REGION ? 0x01010101u * Rs[j] : 0u;
             f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dk[2] = {dv[0], dv[0]};
             const uint32_t bj = tab_c - (uint32_t)bs[j];              // + bs[i]: the LDS address of tab[idx_i - idx_j + centre]
@@ -366,8 +375,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
                         ppw[2 * half] = 0u; ppw[2 * half + 1] = 0u; dsw[2 * half] = 0u; dsw[2 * half + 1] = 0u;
                         continue;
                     }
-                    const bf16x8 qf = lds_row8(Qs, R_LD, 16 * it + c16, 8 * g);
-                    const bf16x8 of = lds_row8(Os, R_LD, 16 * it + c16, 8 * g);
+                    const bf16x8 qf = lds_row8(Qs, R_LD, 16 * it + c16, kg);
+                    const bf16x8 of = lds_row8(Os, R_LD, 16 * it + c16, kg);
                     const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kfr, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, vfr, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     const int i0 = 16 * it + 4 * g;
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
                 const bf16x8 pp = __builtin_bit_cast(bf16x8, ppw), dp8 = __builtin_bit_cast(bf16x8, dsw);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int off = (32 * ks + 4 * g + (c16 >> 2)) * R_LD + 16 * u + 4 * (c16 & 3);
+                    const int off = (32 * ks + rr) * R_LD + tcol[u];
                     const bf16x8 ot = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Os + off)),
                                             __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Os + off + 16 * R_LD)));
                     const bf16x8 qt = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Qs + off)),
@@ -414,8 +423,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
             const int it = t - QT;
             const int i = 16 * it + c16;
             const bool vi = i < N;
-            const bf16x8 qfb = lds_row8(Qs, R_LD, i, 8 * g);
-            const bf16x8 ofb = lds_row8(Os, R_LD, i, 8 * g);
+            const bf16x8 qfb = lds_row8(Qs, R_LD, i, kg);
+            const bf16x8 ofb = lds_row8(Os, R_LD, i, kg);
             const float nli = ls[i], ndi = dl[i];
             const uint32_t ri4 = REGION ? 0x01010101u * Rs[i] : 0u;
             const uint32_t bi = tab_c + (uint32_t)bs[i];
@@ -431,8 +440,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
                         dsw[2 * half] = 0u; dsw[2 * half + 1] = 0u;          // (slab columns >= N are never read)
                         continue;
                     }
-                    const bf16x8 ka = lds_row8(Ks, R_LD, 16 * jt + c16, 8 * g);
-                    const bf16x8 va = lds_row8(Vs, R_LD, 16 * jt + c16, 8 * g);
+                    const bf16x8 ka = lds_row8(Ks, R_LD, 16 * jt + c16, kg);
+                    const bf16x8 va = lds_row8(Vs, R_LD, 16 * jt + c16, kg);
                     const f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qfb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     const f32x4 dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, ofb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     const u32x4 bj4 = *reinterpret_cast<const u32x4*>(bs + j0);
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && NT <= 10) ? 4 : 2) void 
                 const bf16x8 ds8 = __builtin_bit_cast(bf16x8, dsw);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int off = (32 * ks + 4 * g + (c16 >> 2)) * R_LD + 16 * u + 4 * (c16 & 3);
+                    const int off = (32 * ks + rr) * R_LD + tcol[u];
                     const bf16x8 kt = join4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Ks + off)),
                                             __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Ks + off + 16 * R_LD)));
                     dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, ds8, dq[u], 0, 0, 0);
