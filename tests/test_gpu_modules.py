@@ -886,6 +886,53 @@ def test_train_step_graph_sees_foreign_optimizer_updates():
         ops.sinks.clear()
 
 
+def test_captured_step_with_fused_adamw_overfits_one_batch():
+    """Long horizon: 40 replays of ONE captured step (hipGraph) with FusedAdamW between them on a fixed batch -- every buffer the step reuses from replay to
+    replay (gradient sinks zeroed in-graph, deferred-reduction arenas, DropPath draws, bf16 weight copies refreshed by the optimizer, BatchNorm running
+    statistics) has to be in order for the loss to keep falling; the same loop on a twin model in fp32, eager, with torch.optim.AdamW is the yardstick."""
+    import lavt_hip
+    from lavt_hip import ops
+    from lavt_hip.engine import TrainStep
+    from lavt_hip.optim import FusedAdamW
+    x, l, m, t = det_inputs(2, 64, 20, seed=17)
+    x, l, m, t = x.to(DEV), l.to(DEV), m.to(DEV), t.to(DEV)
+    w = torch.tensor([0.9, 1.1], device=DEV)
+    steps, lr = 40, 3e-4
+    try:
+        with lavt_hip.use_dtype(torch.float32):
+            twin = _build(32, [2, 2, 2, 2], [1, 2, 4, 8], 7, dpr=0.0).train()
+            ref_opt = torch.optim.AdamW([p for p in twin.parameters()], lr=lr, weight_decay=1e-2)
+            ref = []
+            for _ in range(steps):
+                for p in twin.parameters():
+                    p.grad = None
+                lt = F.cross_entropy(twin(x, l, m), t, weight=w)
+                lt.backward()
+                ref.append(float(lt.detach()))
+                ref_opt.step()
+        with lavt_hip.use_dtype(torch.bfloat16):
+            model = _build(32, [2, 2, 2, 2], [1, 2, 4, 8], 7, dpr=0.0).train()
+            step = TrainStep(model, x, l, m, t, world=1, use_graph=True)
+            step.warmup_and_capture()
+            assert step.captured
+            for bn in [mod for mod in model.modules() if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm)]:
+                bn.reset_running_stats()
+            opt = FusedAdamW([p for p in model.parameters()], lr=lr, weight_decay=1e-2)
+            losses = []
+            for _ in range(steps):
+                losses.append(float(step.step()))
+                opt.step()
+            torch.cuda.synchronize()
+        assert all(np.isfinite(losses)), losses
+        assert abs(losses[0] - ref[0]) < 2e-2, (losses[0], ref[0])
+        assert ref[-1] < 0.6 * ref[0], f"the fp32 yardstick did not overfit the batch: {ref[0]:.4f} -> {ref[-1]:.4f}"
+        assert losses[-1] < 0.6 * losses[0], f"the captured bf16 step did not overfit the batch: {losses[0]:.4f} -> {losses[-1]:.4f} (fp32 twin {ref[0]:.4f} -> {ref[-1]:.4f})"
+        assert min(losses[-5:]) < 1.5 * max(ref[-5:]) + 0.05, f"bf16 replay trails the fp32 twin: {losses[-5:]} vs {ref[-5:]}"
+    finally:
+        ops.wgrads.enabled = False
+        ops.sinks.clear()
+
+
 @pytest.mark.parametrize("feature", ["LAVT_WMSA_FUSED", "LAVT_LN_FOLD"])
 @pytest.mark.parametrize("C,ws,H,W,shifted,stats", [(128, 12, 15, 15, 0, "randn"), (128, 12, 15, 15, 1, "randn"), (64, 7, 10, 9, 1, "randn"), (512, 12, 30, 30, 1, "randn"),
                                                     (192, 7, 14, 14, 0, "randn"), (384, 7, 7, 7, 1, "randn"), (1024, 12, 15, 15, 1, "randn"),
